@@ -1,0 +1,159 @@
+"""ctypes view of the C ABI declared in ``include/ffq.h``.
+
+Any shared library that exports that ABI can be wrapped by :class:`FFQLibrary`. The product wraps
+``fastforward_amd/csrc/libffq_hip.so`` (see :mod:`fastforward_amd._native`); the test-suite wraps
+the CPU oracle with the same class so both sides are driven through identical call sites.
+
+Nothing in this module touches torch: arguments are raw addresses and integers.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import enum
+import os
+
+from typing import Sequence
+
+from fastforward_amd.exceptions import QuantizationError
+
+FFQ_MAX_DIMS = 8
+FFQ_ABI_VERSION = 1
+
+
+class Status(enum.IntEnum):
+    OK = 0
+    ERR_TILE_RANK = 1
+    ERR_TILE_DIVIDE = 2
+    ERR_PARAM_NUMEL = 3
+    ERR_PRECISION = 4
+    ERR_EMPTY = 5
+    ERR_DTYPE = 6
+    ERR_ARG = 7
+    ERR_WORKSPACE = 8
+    ERR_LAUNCH = 9
+    ERR_PARAM_ROWS = 10
+
+
+class DType(enum.IntEnum):
+    F32 = 0
+    BF16 = 1
+    F16 = 2
+    F64 = 3
+    I8 = 4
+    I16 = 5
+    I32 = 6
+    I64 = 7
+    U8 = 8
+
+
+FLAG_INF = 1
+FLAG_NAN = 2
+
+# Exception type the reference raises for each failure (see the comments in include/ffq.h).
+_EXCEPTIONS: dict[int, type[Exception]] = {
+    Status.ERR_TILE_RANK: ValueError,
+    Status.ERR_TILE_DIVIDE: ValueError,
+    Status.ERR_PARAM_NUMEL: RuntimeError,
+    Status.ERR_PRECISION: RuntimeError,
+    Status.ERR_EMPTY: QuantizationError,
+    Status.ERR_DTYPE: NotImplementedError,
+    Status.ERR_ARG: ValueError,
+    Status.ERR_WORKSPACE: RuntimeError,
+    Status.ERR_LAUNCH: RuntimeError,
+    Status.ERR_PARAM_ROWS: ValueError,
+}
+
+
+class Tiling(ctypes.Structure):
+    """``ffq_tiling``: data shape and parameter-sharing tile."""
+
+    _fields_ = [
+        ("ndim", ctypes.c_int32),
+        ("shape", ctypes.c_int64 * FFQ_MAX_DIMS),
+        ("tile", ctypes.c_int64 * FFQ_MAX_DIMS),
+    ]
+
+    @classmethod
+    def make(cls, shape: Sequence[int], tile: Sequence[int]) -> "Tiling":
+        if len(shape) != len(tile):
+            # check_tile_compatibility, quantization/tiled_tensor.py:24-29
+            msg = (
+                "Input dimensionality must match tile_size dimensionality got "
+                f"{len(shape)} and {len(tile)}"
+            )
+            raise ValueError(msg)
+        if len(shape) > FFQ_MAX_DIMS:
+            raise NotImplementedError(f"tensors of rank > {FFQ_MAX_DIMS} are not supported")
+        t = cls()
+        t.ndim = len(shape)
+        for i, (s, b) in enumerate(zip(shape, tile)):
+            t.shape[i] = int(s)
+            t.tile[i] = int(b)
+        return t
+
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_d = ctypes.c_double
+_sz = ctypes.c_size_t
+_tp = ctypes.POINTER(Tiling)
+
+# name -> (restype, argtypes); mirrors include/ffq.h one to one.
+SIGNATURES: dict[str, tuple[object, list[object]]] = {
+    "ffq_abi_version": (_i, []),
+    "ffq_last_error": (ctypes.c_char_p, []),
+    "ffq_backend_name": (ctypes.c_char_p, []),
+    "ffq_num_tiles": (_i64, [_tp]),
+    "ffq_can_support_bitwidth": (_i, [_i, _d]),
+    "ffq_promote_types": (_i, [_i, _i]),
+    "ffq_quantize_by_tile": (_i, [_vp, _i, _vp, _i, _i64, _vp, _i, _i64, _tp, _d, _vp, _i, _vp]),
+    "ffq_dequantize_by_tile": (_i, [_vp, _i, _vp, _i, _i64, _vp, _i, _i64, _tp, _vp, _i, _vp]),
+    "ffq_dequantize_result_dtype": (_i, [_i, _i, _i, _i]),
+    "ffq_minmax_workspace_bytes": (_sz, [_tp, _i]),
+    "ffq_minmax_by_tile": (_i, [_vp, _i, _tp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "ffq_parameters_for_range": (_i, [_vp, _vp, _i, _i64, _d, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "ffq_quantize_dynamic_workspace_bytes": (_sz, [_tp, _i]),
+    "ffq_quantize_dynamic_by_tile": (_i, [_vp, _i, _tp, _d, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ffq_pack_int4": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
+    "ffq_unpack_int4": (_i, [_vp, _i64, _i64, _vp, _i, _vp]),
+    "ffq_linear_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "ffq_linear_w8a8": (
+        _i,
+        [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp],
+    ),
+}
+
+
+class FFQLibrary:
+    """A loaded implementation of the ``ffq_*`` ABI."""
+
+    def __init__(self, path: str | os.PathLike[str]):
+        self.path = os.fspath(path)
+        self._dll = ctypes.CDLL(self.path)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError as e:
+                raise ImportError(f"{self.path} does not export {name}") from e
+            fn.restype = restype
+            fn.argtypes = argtypes
+            setattr(self, name, fn)
+        version = self.ffq_abi_version()  # type: ignore[attr-defined]
+        if version != FFQ_ABI_VERSION:
+            raise ImportError(f"{self.path}: ABI version {version}, expected {FFQ_ABI_VERSION}")
+        self.backend_name: str = self.ffq_backend_name().decode()  # type: ignore[attr-defined]
+
+    @property
+    def is_device(self) -> bool:
+        """True when the library expects device pointers."""
+        return self.backend_name.startswith("hip")
+
+    def check(self, status: int) -> None:
+        """Raise the exception the reference raises for `status`."""
+        if status == Status.OK:
+            return
+        message = self.ffq_last_error().decode(errors="replace")  # type: ignore[attr-defined]
+        exc = _EXCEPTIONS.get(status, RuntimeError)
+        raise exc(message or f"ffq status {status}")

@@ -1,0 +1,187 @@
+// ffq_common.h — shared host/device helpers of libffq_hip.so (gfx950 only).
+//
+// Numerics contract (see include/ffq.h and DESIGN.md §3): every arithmetic step of the reference's
+// eager chain is one correctly rounded IEEE operation in the promoted dtype. The library is
+// compiled with -ffp-contract=off and without fast-math, so `a / b - c` below is a correctly
+// rounded divide followed by a correctly rounded subtract — never an FMA, never a reciprocal.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ffq.h"
+
+namespace ffq {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---------------------------------------------------------------------------------------------
+// dtype tags
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline bool dt_valid(int dt) { return dt >= FFQ_F32 && dt <= FFQ_U8; }
+__host__ __device__ inline bool dt_is_float(int dt) {
+  return dt == FFQ_F32 || dt == FFQ_BF16 || dt == FFQ_F16 || dt == FFQ_F64;
+}
+__host__ __device__ inline int dt_size(int dt) {
+  switch (dt) {
+    case FFQ_F32: case FFQ_I32: return 4;
+    case FFQ_BF16: case FFQ_F16: case FFQ_I16: return 2;
+    case FFQ_F64: case FFQ_I64: return 8;
+    default: return 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalar conversions (device + host). bf16 is handled as raw uint16 bits; f16 through _Float16.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline float bf16_bits_to_f32(uint16_t h) {
+  return __builtin_bit_cast(float, (uint32_t)h << 16);
+}
+// round-to-nearest-even, NaN stays a quiet NaN (matches c10::BFloat16)
+__host__ __device__ inline uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if (f != f) return 0x7FC0;
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__host__ __device__ inline float f16_bits_to_f32(uint16_t h) {
+  return (float)__builtin_bit_cast(_Float16, h);
+}
+__host__ __device__ inline uint16_t f32_to_f16_bits(float f) {
+  return __builtin_bit_cast(uint16_t, (_Float16)f);  // v_cvt_f16_f32: RNE, overflow -> inf
+}
+
+// Value a tensor of dtype `dt` holds after an op whose exact result (in float opmath) is `v`.
+__host__ __device__ inline float round_stage(float v, int dt) {
+  if (dt == FFQ_BF16) return bf16_bits_to_f32(f32_to_bf16_bits(v));
+  if (dt == FFQ_F16) return f16_bits_to_f32(f32_to_f16_bits(v));
+  return v;
+}
+
+// torch.round == rint in round-to-nearest-even mode.
+__host__ __device__ inline float rne(float v) { return __builtin_rintf(v); }
+__host__ __device__ inline double rne(double v) { return __builtin_rint(v); }
+
+// torch.clamp(x, lo, hi): NaN propagates.
+__host__ __device__ inline float clamp_nan(float v, float lo, float hi) {
+  float c = v < lo ? lo : v;
+  c = c > hi ? hi : c;
+  return v != v ? v : c;
+}
+__host__ __device__ inline double clamp_nan(double v, double lo, double hi) {
+  double c = v < lo ? lo : v;
+  c = c > hi ? hi : c;
+  return v != v ? v : c;
+}
+
+// Runtime-typed element access, used by the generic kernels and for parameter tables.
+__device__ inline double load_any(const void* p, int dt, int64_t i) {
+  switch (dt) {
+    case FFQ_F32: return (double)((const float*)p)[i];
+    case FFQ_BF16: return (double)bf16_bits_to_f32(((const uint16_t*)p)[i]);
+    case FFQ_F16: return (double)f16_bits_to_f32(((const uint16_t*)p)[i]);
+    case FFQ_F64: return ((const double*)p)[i];
+    case FFQ_I8: return (double)((const int8_t*)p)[i];
+    case FFQ_I16: return (double)((const int16_t*)p)[i];
+    case FFQ_I32: return (double)((const int32_t*)p)[i];
+    case FFQ_I64: return (double)((const int64_t*)p)[i];
+    default: return (double)((const uint8_t*)p)[i];
+  }
+}
+// NaN -> integer follows the x86 conversion of the reference's CPU path (INT_MIN, low bits for
+// narrower types), see oracle/ffq_oracle.c st().
+__device__ inline void store_any(void* p, int dt, int64_t i, double v) {
+  const bool nan = v != v;
+  switch (dt) {
+    case FFQ_F32: ((float*)p)[i] = (float)v; break;
+    case FFQ_BF16: ((uint16_t*)p)[i] = f32_to_bf16_bits((float)v); break;
+    case FFQ_F16: ((uint16_t*)p)[i] = f32_to_f16_bits((float)v); break;
+    case FFQ_F64: ((double*)p)[i] = v; break;
+    case FFQ_I8: ((int8_t*)p)[i] = nan ? 0 : (int8_t)(int64_t)v; break;
+    case FFQ_I16: ((int16_t*)p)[i] = nan ? 0 : (int16_t)(int64_t)v; break;
+    case FFQ_I32: ((int32_t*)p)[i] = nan ? INT32_MIN : (int32_t)(int64_t)v; break;
+    case FFQ_I64: ((int64_t*)p)[i] = nan ? INT64_MIN : (int64_t)v; break;
+    default: ((uint8_t*)p)[i] = nan ? 0 : (uint8_t)(int64_t)v; break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact unsigned 32-bit division by a launch-invariant divisor (no integer divider on CDNA):
+// q = (mulhi(n, mul) + n) >> shift evaluated in 64 bits, the classic round-up magic number.
+// ---------------------------------------------------------------------------------------------
+struct FastDiv {
+  uint32_t mul;
+  uint32_t shift;
+  uint32_t div;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.div = d;
+  if (d == 1) { f.mul = 0; f.shift = 0; return f; }
+  uint32_t l = 32 - (uint32_t)__builtin_clz(d - 1);  // ceil(log2 d)
+  uint64_t m = (((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1;
+  f.mul = (uint32_t)m;
+  f.shift = l;
+  return f;
+}
+__device__ inline uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  uint64_t t = (uint64_t)__umulhi(n, f.mul) + n;
+  return (uint32_t)(t >> f.shift);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side tiling analysis
+// ---------------------------------------------------------------------------------------------
+enum Layout {
+  LAYOUT_SCALAR = 0,   // one tile: parameters are wave-uniform
+  LAYOUT_ROWS = 1,     // every tile is a contiguous run of `run` elements: tile = flat / run
+  LAYOUT_CHANNEL = 2,  // tile = (flat / inner) % channels  (one strided channel dimension)
+  LAYOUT_GENERIC = 3   // N-d tile grid, resolved per element
+};
+
+struct TileInfo {
+  int layout;
+  int64_t numel;
+  int64_t ntiles;
+  int64_t run;       // ROWS
+  int64_t inner;     // CHANNEL
+  int64_t channels;  // CHANNEL
+};
+
+int check_tiling(const ffq_tiling* t);
+int analyse(const ffq_tiling* t, TileInfo* info);
+int check_param_numel(const char* what, int64_t numel, int64_t ntiles);
+
+// Generic N-d tile lookup descriptor passed by value to the generic kernels.
+struct GenericTiling {
+  int32_t ndim;
+  int64_t shape[FFQ_MAX_DIMS];
+  int64_t tile[FFQ_MAX_DIMS];
+  int64_t gstride[FFQ_MAX_DIMS];
+};
+GenericTiling make_generic(const ffq_tiling* t);
+
+__device__ inline int64_t generic_tile_of(const GenericTiling& g, int64_t flat) {
+  int64_t tile = 0;
+  for (int k = g.ndim - 1; k >= 0; --k) {
+    const int64_t extent = g.shape[k];
+    const int64_t idx = flat % extent;
+    flat /= extent;
+    tile += (idx / g.tile[k]) * g.gstride[k];
+  }
+  return tile;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+constexpr int kBlock = 256;       // 4 waves of 64 lanes
+constexpr int kMaxGridBlocks = 1 << 20;
+
+}  // namespace ffq

@@ -1,0 +1,285 @@
+// ffq_linear.hip — A6: W8A8 linear on the int8 matrix cores of gfx950.
+//
+// Replaces fallback.linear, src/fastforward/_gen/fallback.py:77-112: the reference dequantizes
+// the activation codes and the weight codes into bf16 tensors (two extra HBM round trips, 3 B/elem
+// of weight traffic each forward), runs a float GEMM and optionally re-quantizes. Here the integer
+// codes feed v_mfma_i32_32x32x32_i8 directly, accumulate exactly in int32, and the affine
+// parameters are applied once per output element in the epilogue:
+//
+//   y[m,n] = sx[m'] * sw[n'] * ( acc[m,n] + ox[m'] * rowsum_w[n] + ow[n'] * rowsum_x[m]
+//                                + K * ox[m'] * ow[n'] )  (+ bias[n])
+//
+// with acc = sum_k xq[m,k] * wq[n,k], ox / ow = round_half_even(offset) (A2), and the row sums
+// produced by a one-pass int8 reduction only when the corresponding offset exists.
+//
+// Layout: xq [M,K] and wq [N,K] are both K-contiguous, which is the operand order MFMA wants: lane
+// (r = lane % 32, g = lane / 32) of a wavefront supplies 16 consecutive k-bytes of row r for both
+// operands, so no transpose is ever needed. Block tile 128 x 128 x 64, 4 wavefronts (2 x 2), each
+// owning 64 x 64 = 2 x 2 MFMA tiles; double-buffered LDS with a 16-byte-slot XOR swizzle
+// (slot ^= (row >> 2) & 3) that makes every ds_read_b128 lane group hit 16 distinct slots.
+// blockIdx is remapped so that consecutive tiles of one weight panel stay on one XCD's L2.
+#include "ffq_common.h"
+#include "ffq_vec.h"
+
+#include <math.h>
+
+namespace ffq {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kTileBytes = BM * BK;  // 8 KiB per operand per stage
+
+struct LinearArgs {
+  const int8_t* xq;
+  const int8_t* wq;
+  const float* x_scale; const float* x_offset;
+  const float* w_scale; const float* w_offset;
+  const int32_t* rowsum_x; const int32_t* rowsum_w;
+  const void* bias; int bias_dt;
+  void* out; int out_dt;
+  const float* out_scale; const float* out_offset;
+  float out_lo, out_hi;
+  int x_per_row, w_per_row;
+  int M, N, K;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ uint32_t swizzled(uint32_t row, uint32_t slot) {
+  return row * BK + ((slot ^ ((row >> 2) & 3u)) << 4);
+}
+
+// 16 B of row `row` at byte column `kbyte` of a K-contiguous int8 matrix, zero outside the matrix.
+__device__ __forceinline__ u32x4 load_slot(const int8_t* base, int row, int rows, int kbyte, int K) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (row < rows && kbyte < K) v = *reinterpret_cast<const u32x4*>(base + (size_t)row * K + kbyte);
+  return v;
+}
+
+template <typename TOut>
+__device__ __forceinline__ void store_out(TOut* p, float v);
+template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = from_f32<bf16_t>(v); }
+template <> __device__ __forceinline__ void store_out<f16_t>(f16_t* p, float v) { *p = from_f32<f16_t>(v); }
+template <> __device__ __forceinline__ void store_out<int8_t>(int8_t* p, float v) { *p = from_f32<int8_t>(v); }
+
+template <typename TOut, bool REQUANT>
+__global__ __launch_bounds__(256) void w8a8_gemm_kernel(LinearArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2][2][kTileBytes];
+
+  // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (observed dispatch: XCD = b % 8),
+  // give each XCD a contiguous range of tiles so a weight panel is fetched into one L2 only.
+  const uint32_t nblk = gridDim.x;
+  const uint32_t xcd = blockIdx.x & 7u, slot_in_xcd = blockIdx.x >> 3;
+  const uint32_t q = nblk >> 3, r = nblk & 7u;
+  const uint32_t tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot_in_xcd;
+  // n-major inside a group of tiles_m rows: neighbours share the weight panel
+  const int tn = tile_id / a.tiles_m, tm = tile_id % a.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // staging map: 512 slots of 16 B per operand tile, two per lane
+  const int s_row0 = tid >> 2, s_slot = tid & 3;          // rows 0..63
+  const int s_row1 = s_row0 + 64;                          // rows 64..127
+
+  v16i acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+
+  const int ksteps = (a.K + BK - 1) / BK;
+  u32x4 ra0, ra1, rb0, rb1;
+  auto fetch = [&](int kt) {
+    const int kb = kt * BK + s_slot * 16;
+    ra0 = load_slot(a.xq, m0 + s_row0, a.M, kb, a.K);
+    ra1 = load_slot(a.xq, m0 + s_row1, a.M, kb, a.K);
+    rb0 = load_slot(a.wq, n0 + s_row0, a.N, kb, a.K);
+    rb1 = load_slot(a.wq, n0 + s_row1, a.N, kb, a.K);
+  };
+  auto stash = [&](int stage) {
+    *reinterpret_cast<u32x4*>(&lds[stage][0][swizzled(s_row0, s_slot)]) = ra0;
+    *reinterpret_cast<u32x4*>(&lds[stage][0][swizzled(s_row1, s_slot)]) = ra1;
+    *reinterpret_cast<u32x4*>(&lds[stage][1][swizzled(s_row0, s_slot)]) = rb0;
+    *reinterpret_cast<u32x4*>(&lds[stage][1][swizzled(s_row1, s_slot)]) = rb1;
+  };
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+
+  const uint32_t frag_row = lane & 31, frag_g = lane >> 5;
+  for (int kt = 0; kt < ksteps; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < ksteps) fetch(kt + 1);  // global loads fly under the MFMAs below
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      v4i fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint32_t row = wm * 64 + i * 32 + frag_row;
+        fa[i] = *reinterpret_cast<const v4i*>(&lds[cur][0][swizzled(row, kk * 2 + frag_g)]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t row = wn * 64 + j * 32 + frag_row;
+        fb[j] = *reinterpret_cast<const v4i*>(&lds[cur][1][swizzled(row, kk * 2 + frag_g)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < ksteps) stash(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+  TOut* out = static_cast<TOut*>(a.out);
+  const float kf = (float)a.K;
+  float oscale = 1.0f, ooff = 0.0f;
+  if constexpr (REQUANT) {
+    oscale = a.out_scale[0];
+    ooff = a.out_offset ? rne(a.out_offset[0]) : 0.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    if (n >= a.N) continue;
+    const float sw = a.w_scale[a.w_per_row ? n : 0];
+    const float ow = a.w_offset ? rne(a.w_offset[a.w_per_row ? n : 0]) : 0.0f;
+    const float rsw = a.rowsum_w ? (float)a.rowsum_w[n] : 0.0f;
+    const float bias = a.bias ? (float)load_any(a.bias, a.bias_dt, n) : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m >= a.M) continue;
+        const float sx = a.x_scale[a.x_per_row ? m : 0];
+        const float ox = a.x_offset ? rne(a.x_offset[a.x_per_row ? m : 0]) : 0.0f;
+        const float rsx = a.rowsum_x ? (float)a.rowsum_x[m] : 0.0f;
+        float v = (float)acc[i][j][e];
+        v = v + ox * rsw;
+        v = v + ow * rsx;
+        v = v + kf * ox * ow;
+        float y = (sx * sw) * v;
+        if (a.bias) y = y + bias;
+        if constexpr (REQUANT) {
+          // the reference rounds the linear output to bf16 before the output quantizer sees it
+          y = bf16_bits_to_f32(f32_to_bf16_bits(y));
+          float qv = rne(y / oscale - ooff);
+          qv = clamp_nan(qv, a.out_lo, a.out_hi);
+          store_out<TOut>(out + (size_t)m * a.N + n, qv);
+        } else {
+          store_out<TOut>(out + (size_t)m * a.N + n, y);
+        }
+      }
+    }
+  }
+}
+
+// one wavefront per row: sum of K int8 codes
+__global__ __launch_bounds__(256) void rowsum_i8_kernel(const int8_t* __restrict__ q, int rows, int K,
+                                                        int32_t* __restrict__ sums) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  int s = 0;
+  if (row < rows) {
+    const int8_t* p = q + (size_t)row * K;
+    for (int k = lane * 16; k < K; k += 64 * 16) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(p + k);
+      s = __builtin_amdgcn_sdot4((int)v.x, 0x01010101, s, false);
+      s = __builtin_amdgcn_sdot4((int)v.y, 0x01010101, s, false);
+      s = __builtin_amdgcn_sdot4((int)v.z, 0x01010101, s, false);
+      s = __builtin_amdgcn_sdot4((int)v.w, 0x01010101, s, false);
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+  if (lane == 0 && row < rows) sums[row] = s;
+}
+
+}  // namespace ffq
+
+using namespace ffq;
+
+extern "C" size_t ffq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  (void)K;
+  if (M < 0 || N < 0) return 0;
+  return (size_t)(((M + N) * 4 + 255) & ~(int64_t)255);
+}
+
+extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, const float* x_offset,
+                               int x_per_row, const float* w_scale, const float* w_offset, int w_per_row,
+                               const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
+                               const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (M == 0 || N == 0) return FFQ_OK;
+  if (!xq || !wq || !x_scale || !w_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return fail(FFQ_ERR_ARG, "extent exceeds 2^31");
+  if (K % 16 != 0 || !aligned16(xq) || !aligned16(wq))
+    return fail(FFQ_ERR_DTYPE, "w8a8 linear needs K %% 16 == 0 and 16-byte aligned code pointers");
+  if (bias && !dt_valid(bias_dt)) return fail(FFQ_ERR_ARG, "bad bias dtype");
+  const bool requant = out_scale != nullptr;
+  if (requant) {
+    if (!ffq_can_support_bitwidth(out_dt, out_num_bits))
+      return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.",
+                  out_dt, out_num_bits);
+  } else if (!(out_dt == FFQ_F32 || out_dt == FFQ_BF16 || out_dt == FFQ_F16)) {
+    return fail(FFQ_ERR_DTYPE, "real-valued output must be f32, bf16 or f16");
+  }
+  const size_t need = ffq_linear_w8a8_workspace_bytes(M, N, K);
+  if ((x_offset || w_offset) && (need > workspace_bytes || !workspace))
+    return fail(FFQ_ERR_WORKSPACE, "w8a8 linear needs %zu workspace bytes, got %zu", need, workspace_bytes);
+
+  LinearArgs a;
+  a.xq = xq; a.wq = wq;
+  a.x_scale = x_scale; a.x_offset = x_offset;
+  a.w_scale = w_scale; a.w_offset = w_offset;
+  a.rowsum_x = nullptr; a.rowsum_w = nullptr;
+  a.bias = bias; a.bias_dt = bias_dt;
+  a.out = out; a.out_dt = out_dt;
+  a.out_scale = out_scale; a.out_offset = out_offset;
+  const double lo = -pow(2.0, out_num_bits - 1.0);
+  a.out_lo = (float)lo; a.out_hi = (float)(-lo - 1.0);
+  a.x_per_row = x_per_row; a.w_per_row = w_per_row;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.tiles_m = (int)((M + BM - 1) / BM);
+  a.tiles_n = (int)((N + BN - 1) / BN);
+
+  int32_t* ws = static_cast<int32_t*>(workspace);
+  if (w_offset) {  // needs sum_k xq[m,k]
+    rowsum_i8_kernel<<<(unsigned)((M + 3) / 4), 256, 0, s>>>(xq, (int)M, (int)K, ws);
+    a.rowsum_x = ws;
+  }
+  if (x_offset) {  // needs sum_k wq[n,k]
+    rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(wq, (int)N, (int)K, ws + M);
+    a.rowsum_w = ws + M;
+  }
+  const unsigned grid = (unsigned)(a.tiles_m * a.tiles_n);
+  if (requant) {
+    switch (out_dt) {
+      case FFQ_I8: w8a8_gemm_kernel<int8_t, true><<<grid, 256, 0, s>>>(a); break;
+      case FFQ_BF16: w8a8_gemm_kernel<bf16_t, true><<<grid, 256, 0, s>>>(a); break;
+      case FFQ_F16: w8a8_gemm_kernel<f16_t, true><<<grid, 256, 0, s>>>(a); break;
+      case FFQ_F32: w8a8_gemm_kernel<float, true><<<grid, 256, 0, s>>>(a); break;
+      default: return fail(FFQ_ERR_DTYPE, "re-quantized output container must be i8, bf16, f16 or f32");
+    }
+  } else {
+    switch (out_dt) {
+      case FFQ_BF16: w8a8_gemm_kernel<bf16_t, false><<<grid, 256, 0, s>>>(a); break;
+      case FFQ_F16: w8a8_gemm_kernel<f16_t, false><<<grid, 256, 0, s>>>(a); break;
+      default: w8a8_gemm_kernel<float, false><<<grid, 256, 0, s>>>(a); break;
+    }
+  }
+  return check_launch("w8a8_gemm_kernel");
+}

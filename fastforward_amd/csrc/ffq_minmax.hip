@@ -1,0 +1,607 @@
+// ffq_minmax.hip — A4 (RunningMinMax reduction), A5 (range -> scale/offset), A3 (dynamic quantize).
+//
+// References
+//   A4  RunningMinMaxEstimator.estimate_step, src/fastforward/range_setting/minmax.py:215-239
+//       (torch.min + torch.max over a tiles_to_rows view, isinf().any() host sync, running merge)
+//   A5  parameters_for_range, src/fastforward/quantization/affine/range.py:54-122, plus the copy in
+//       LinearQuantizer.quantization_range.setter, src/fastforward/nn/linear_quantizer.py:350-357
+//   A3  quantize_dynamic_by_tile_impl, src/fastforward/quantization/_quantizer_impl.py:243-285
+//
+// The reference reads the tensor twice (min, then max) and synchronises with the host twice per
+// quantizer per step. Here one pass produces both extrema (2 B/elem for bf16), the Inf test becomes
+// a flag word on the device, and the global one-sided decision of A5 is taken inside the kernel,
+// so a calibration step enqueues without ever waiting for the GPU.
+//
+// Reduction shape: 16 B per lane loads, min/max in VGPRs, NaN tracked as a wave-level predicate,
+// wavefront (64-lane) xor-shuffle butterflies, one LDS hop across the 4 waves of a block.
+#include "ffq_common.h"
+#include "ffq_vec.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+namespace ffq {
+
+int quantize_impl(const void* data, int data_dt, const void* scale, int scale_dt, int64_t scale_numel,
+                  const void* offset, int offset_dt, int64_t offset_numel, const ffq_tiling* tiling,
+                  double num_bits, void* out, int out_dt, hipStream_t stream);
+
+// torch.min / torch.max propagate NaN; v_min_f32 / v_max_f32 do not, so NaN travels separately.
+struct MinMax {
+  float mn, mx;
+  bool nan;
+  __device__ __forceinline__ void init() { mn = INFINITY; mx = -INFINITY; nan = false; }
+  __device__ __forceinline__ void add(float v) {
+    mn = __builtin_fminf(mn, v);
+    mx = __builtin_fmaxf(mx, v);
+    nan |= v != v;
+  }
+  __device__ __forceinline__ void merge(const MinMax& o) {
+    mn = __builtin_fminf(mn, o.mn);
+    mx = __builtin_fmaxf(mx, o.mx);
+    nan |= o.nan;
+  }
+};
+
+// butterfly over `width` lanes (power of two <= 64) of a wavefront
+template <int WIDTH>
+__device__ __forceinline__ void wave_reduce(MinMax& m) {
+#pragma unroll
+  for (int d = WIDTH / 2; d >= 1; d >>= 1) {
+    const float omn = __shfl_xor(m.mn, d, 64);
+    const float omx = __shfl_xor(m.mx, d, 64);
+    const int onan = __shfl_xor((int)m.nan, d, 64);
+    m.mn = __builtin_fminf(m.mn, omn);
+    m.mx = __builtin_fmaxf(m.mx, omx);
+    m.nan |= onan != 0;
+  }
+}
+
+// all 256 lanes of the block -> result valid in thread 0
+__device__ __forceinline__ void block_reduce(MinMax& m, float* lds /* 3 * 4 floats */) {
+  wave_reduce<64>(m);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    lds[wave] = m.mn;
+    lds[4 + wave] = m.mx;
+    lds[8 + wave] = m.nan ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      m.mn = __builtin_fminf(m.mn, lds[w]);
+      m.mx = __builtin_fmaxf(m.mx, lds[4 + w]);
+      m.nan |= lds[8 + w] != 0.0f;
+    }
+  }
+}
+
+// Partial record in the workspace: {min, max, nan-flag, pad}
+struct Partial { float mn, mx, nan, pad; };
+
+// ---- stage 1, one tile: grid-stride over chunks, one Partial per block -------------------------
+template <typename T, int E, int U>
+__global__ __launch_bounds__(kBlock) void minmax_scalar_partial_kernel(const T* __restrict__ in,
+                                                                       uint32_t nchunks, int64_t numel,
+                                                                       Partial* __restrict__ partial) {
+  __shared__ float lds[12];
+  MinMax m;
+  m.init();
+  const uint32_t stride = gridDim.x * (uint32_t)(kBlock * U);
+  for (uint32_t base = blockIdx.x * (uint32_t)(kBlock * U) + threadIdx.x; base < nchunks; base += stride) {
+    Chunk<T, E> x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t c = base + u * kBlock;
+      if (c < nchunks) x[u].load(in + (size_t)c * E);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t c = base + u * kBlock;
+      if (c < nchunks) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) m.add(x[u].get(i));
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // numel % E trailing elements
+    for (int64_t i = (int64_t)nchunks * E; i < numel; ++i) m.add(to_f32(in[i]));
+  }
+  block_reduce(m, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = Partial{m.mn, m.mx, m.nan ? 1.0f : 0.0f, 0.0f};
+}
+
+// ---- contiguous runs: a group of P lanes (P <= 64, power of two) owns one tile ------------------
+struct RowsArgs {
+  uint32_t ntiles;
+  uint32_t chunks_per_run;
+  int accumulate;
+};
+
+template <typename T>
+__device__ __forceinline__ void write_result(T* mn_out, T* mx_out, uint32_t t, MinMax m, int accumulate,
+                                             int32_t* flags) {
+  float mn = m.nan ? NAN : m.mn;
+  float mx = m.nan ? NAN : m.mx;
+  int f = 0;
+  // flags describe THIS batch (minmax.py:233 tests data_min / data_max, not the running values)
+  if (__builtin_isinf(mn) || __builtin_isinf(mx)) f |= FFQ_FLAG_INF;
+  if (m.nan) f |= FFQ_FLAG_NAN;
+  if (accumulate) {
+    const float pmn = to_f32(mn_out[t]), pmx = to_f32(mx_out[t]);
+    // torch.min(self.min, data_min) / torch.max(self.max, data_max): NaN propagates    (:236-237)
+    mn = (pmn != pmn || mn != mn) ? NAN : __builtin_fminf(pmn, mn);
+    mx = (pmx != pmx || mx != mx) ? NAN : __builtin_fmaxf(pmx, mx);
+  }
+  mn_out[t] = from_f32<T>(mn);
+  mx_out[t] = from_f32<T>(mx);
+  if (f && flags) atomicOr(flags, f);
+}
+
+template <typename T, int E, int P>
+__global__ __launch_bounds__(kBlock) void minmax_rows_kernel(const T* __restrict__ in, T* __restrict__ mn_out,
+                                                             T* __restrict__ mx_out, int32_t* flags,
+                                                             RowsArgs a) {
+  constexpr int TILES_PER_BLOCK = kBlock / P;
+  const uint32_t t = blockIdx.x * TILES_PER_BLOCK + threadIdx.x / P;
+  const uint32_t lane = threadIdx.x % P;
+  MinMax m;
+  m.init();
+  if (t < a.ntiles) {
+    const T* row = in + (size_t)t * a.chunks_per_run * E;
+    uint32_t c = lane;
+    // two chunks in flight per lane
+    for (; c + P < a.chunks_per_run; c += 2 * P) {
+      Chunk<T, E> x0, x1;
+      x0.load(row + (size_t)c * E);
+      x1.load(row + (size_t)(c + P) * E);
+#pragma unroll
+      for (int i = 0; i < E; ++i) m.add(x0.get(i));
+#pragma unroll
+      for (int i = 0; i < E; ++i) m.add(x1.get(i));
+    }
+    if (c < a.chunks_per_run) {
+      Chunk<T, E> x0;
+      x0.load(row + (size_t)c * E);
+#pragma unroll
+      for (int i = 0; i < E; ++i) m.add(x0.get(i));
+    }
+  }
+  wave_reduce<P>(m);
+  if (lane == 0 && t < a.ntiles) write_result<T>(mn_out, mx_out, t, m, a.accumulate, flags);
+}
+
+// ---- few large tiles: 2-D grid (split, tile) -> Partial[tile][split] ----------------------------
+template <typename T, int E>
+__global__ __launch_bounds__(kBlock) void minmax_rows_split_kernel(const T* __restrict__ in,
+                                                                   uint32_t chunks_per_run,
+                                                                   Partial* __restrict__ partial) {
+  __shared__ float lds[12];
+  const uint32_t t = blockIdx.y, splits = gridDim.x;
+  const T* row = in + (size_t)t * chunks_per_run * E;
+  MinMax m;
+  m.init();
+  for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < chunks_per_run; c += splits * kBlock) {
+    Chunk<T, E> x;
+    x.load(row + (size_t)c * E);
+#pragma unroll
+    for (int i = 0; i < E; ++i) m.add(x.get(i));
+  }
+  block_reduce(m, lds);
+  if (threadIdx.x == 0) partial[(size_t)t * splits + blockIdx.x] = Partial{m.mn, m.mx, m.nan ? 1.0f : 0.0f, 0.0f};
+}
+
+// ---- one channel per column: lane keeps E running pairs, walks its row group --------------------
+struct ColsArgs {
+  uint32_t col_chunks, rows, row_groups;
+  FastDiv col_chunks_div;
+};
+template <typename T, int E>
+__global__ __launch_bounds__(kBlock) void minmax_columns_partial_kernel(const T* __restrict__ in,
+                                                                        Partial* __restrict__ partial,
+                                                                        ColsArgs a) {
+  const uint32_t g = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  const uint32_t group = fdiv(g, a.col_chunks_div);
+  if (group >= a.row_groups) return;
+  const uint32_t cc = g - group * a.col_chunks;
+  MinMax m[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) m[i].init();
+  const size_t row_elems = (size_t)a.col_chunks * E;
+  for (uint32_t r = group; r < a.rows; r += a.row_groups) {
+    Chunk<T, E> x;
+    x.load(in + (size_t)r * row_elems + (size_t)cc * E);
+#pragma unroll
+    for (int i = 0; i < E; ++i) m[i].add(x.get(i));
+  }
+  // Partial[channel][group]
+#pragma unroll
+  for (int i = 0; i < E; ++i)
+    partial[(size_t)(cc * E + i) * a.row_groups + group] =
+        Partial{m[i].mn, m[i].mx, m[i].nan ? 1.0f : 0.0f, 0.0f};
+}
+
+// ---- stage 2: Partial[tile][count] -> min/max in data dtype, running merge, flags ---------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void minmax_finalize_kernel(const Partial* __restrict__ partial,
+                                                                 uint32_t ntiles, uint32_t count,
+                                                                 T* __restrict__ mn_out, T* __restrict__ mx_out,
+                                                                 int accumulate, int32_t* flags) {
+  // one wavefront per tile
+  const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  MinMax m;
+  m.init();
+  if (t < ntiles) {
+    for (uint32_t k = lane; k < count; k += 64) {
+      const Partial p = partial[(size_t)t * count + k];
+      m.mn = __builtin_fminf(m.mn, p.mn);
+      m.mx = __builtin_fmaxf(m.mx, p.mx);
+      m.nan |= p.nan != 0.0f;
+    }
+  }
+  wave_reduce<64>(m);
+  if (lane == 0 && t < ntiles) write_result<T>(mn_out, mx_out, t, m, accumulate, flags);
+}
+
+// ---- generic tilings / wide dtypes: ordered-integer atomics on a double carrier -----------------
+__device__ __forceinline__ unsigned long long ordered_bits(double v) {
+  const unsigned long long u = (unsigned long long)__builtin_bit_cast(long long, v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double from_ordered_bits(unsigned long long k) {
+  const unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __builtin_bit_cast(double, (long long)u);
+}
+struct GenericCell { unsigned long long mn, mx; unsigned int nan; unsigned int pad; };
+
+__global__ void minmax_generic_init_kernel(GenericCell* cells, int64_t ntiles) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ntiles) cells[t] = GenericCell{ordered_bits(INFINITY), ordered_bits(-INFINITY), 0u, 0u};
+}
+__global__ __launch_bounds__(kBlock) void minmax_generic_scatter_kernel(const void* __restrict__ data, int dt,
+                                                                        int64_t numel, GenericTiling g,
+                                                                        GenericCell* cells) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel; i += stride) {
+    const int64_t t = generic_tile_of(g, i);
+    const double v = load_any(data, dt, i);
+    if (v != v) {
+      atomicOr(&cells[t].nan, 1u);
+    } else {
+      const unsigned long long k = ordered_bits(v);
+      atomicMin(&cells[t].mn, k);
+      atomicMax(&cells[t].mx, k);
+    }
+  }
+}
+__global__ void minmax_generic_finalize_kernel(const GenericCell* cells, int64_t ntiles, void* mn_out,
+                                               void* mx_out, int dt, int accumulate, int32_t* flags) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  const GenericCell c = cells[t];
+  double mn = c.nan ? NAN : from_ordered_bits(c.mn);
+  double mx = c.nan ? NAN : from_ordered_bits(c.mx);
+  int f = 0;
+  if (__builtin_isinf(mn) || __builtin_isinf(mx)) f |= FFQ_FLAG_INF;
+  if (c.nan) f |= FFQ_FLAG_NAN;
+  if (accumulate) {
+    const double pmn = load_any(mn_out, dt, t), pmx = load_any(mx_out, dt, t);
+    mn = (pmn != pmn || mn != mn) ? NAN : (pmn < mn ? pmn : mn);
+    mx = (pmx != pmx || mx != mx) ? NAN : (pmx > mx ? pmx : mx);
+  }
+  store_any(mn_out, dt, t, mn);
+  store_any(mx_out, dt, t, mx);
+  if (f && flags) atomicOr(flags, f);
+}
+
+// ---- launch plan ----------------------------------------------------------------------------
+enum Plan { PLAN_SCALAR, PLAN_ROWS_WAVE, PLAN_ROWS_SPLIT, PLAN_COLUMNS, PLAN_GENERIC };
+struct MinMaxPlan {
+  int plan;
+  int lanes_per_tile;   // ROWS_WAVE
+  uint32_t partials;    // Partial records per tile (SCALAR / ROWS_SPLIT / COLUMNS)
+  size_t workspace;
+};
+
+constexpr int kE = 8;                  // elements per 16 B chunk for 16-bit data (f32: two loads)
+constexpr uint32_t kScalarBlocks = 2048;  // 8 blocks per CU on 256 CUs
+
+static MinMaxPlan plan_for(const TileInfo& info, int data_dt) {
+  MinMaxPlan p;
+  p.plan = PLAN_GENERIC;
+  p.lanes_per_tile = 0;
+  p.partials = 0;
+  p.workspace = sizeof(GenericCell) * (size_t)info.ntiles;
+  const bool fast_dt = data_dt == FFQ_F32 || data_dt == FFQ_BF16 || data_dt == FFQ_F16;
+  if (!fast_dt || info.numel >= ((int64_t)1 << 32) - 4096 || getenv("FFQ_FORCE_GENERIC")) return p;
+  if (info.layout == LAYOUT_SCALAR) {
+    const uint32_t nchunks = (uint32_t)(info.numel / kE);
+    uint32_t blocks = (nchunks + kBlock * 4 - 1) / (kBlock * 4);
+    if (blocks < 1) blocks = 1;
+    if (blocks > kScalarBlocks) blocks = kScalarBlocks;
+    p.plan = PLAN_SCALAR;
+    p.partials = blocks;
+    p.workspace = sizeof(Partial) * blocks;
+    return p;
+  }
+  if (info.layout == LAYOUT_ROWS && info.run % kE == 0) {
+    const int64_t chunks = info.run / kE;
+    // enough tiles to fill the chip with one (sub-)wave per tile?
+    if (info.ntiles >= 2048 || chunks <= 64) {
+      int lanes = 64;
+      while (lanes > 1 && lanes / 2 >= chunks) lanes /= 2;
+      p.plan = PLAN_ROWS_WAVE;
+      p.lanes_per_tile = lanes;
+      p.workspace = 0;
+      return p;
+    }
+    uint32_t splits = (uint32_t)((chunks + kBlock * 4 - 1) / (kBlock * 4));
+    const uint32_t want = (uint32_t)(kScalarBlocks / info.ntiles) + 1;
+    if (splits > want) splits = want;
+    if (splits < 1) splits = 1;
+    p.plan = PLAN_ROWS_SPLIT;
+    p.partials = splits;
+    p.workspace = sizeof(Partial) * (size_t)splits * (size_t)info.ntiles;
+    return p;
+  }
+  if (info.layout == LAYOUT_CHANNEL && info.inner == 1 && info.channels % kE == 0) {
+    const uint32_t rows = (uint32_t)(info.numel / info.channels);
+    uint32_t groups = (rows + 15) / 16;
+    if (groups > 64) groups = 64;
+    if (groups < 1) groups = 1;
+    p.plan = PLAN_COLUMNS;
+    p.partials = groups;
+    p.workspace = sizeof(Partial) * (size_t)groups * (size_t)info.channels;
+    return p;
+  }
+  return p;
+}
+
+template <typename T>
+static int run_fast(const MinMaxPlan& p, const TileInfo& info, const void* data, void* mn, void* mx,
+                    int accumulate, int32_t* flags, void* workspace, hipStream_t stream) {
+  const T* in = static_cast<const T*>(data);
+  T* mn_out = static_cast<T*>(mn);
+  T* mx_out = static_cast<T*>(mx);
+  Partial* partial = static_cast<Partial*>(workspace);
+  switch (p.plan) {
+    case PLAN_SCALAR: {
+      const uint32_t nchunks = (uint32_t)(info.numel / kE);
+      minmax_scalar_partial_kernel<T, kE, 4><<<p.partials, kBlock, 0, stream>>>(in, nchunks, info.numel, partial);
+      minmax_finalize_kernel<T><<<1, kBlock, 0, stream>>>(partial, 1, p.partials, mn_out, mx_out, accumulate, flags);
+      break;
+    }
+    case PLAN_ROWS_WAVE: {
+      RowsArgs a;
+      a.ntiles = (uint32_t)info.ntiles;
+      a.chunks_per_run = (uint32_t)(info.run / kE);
+      a.accumulate = accumulate;
+#define FFQ_ROWS(P)                                                                              \
+  case P: {                                                                                      \
+    const unsigned grid = (unsigned)((info.ntiles + (kBlock / P) - 1) / (kBlock / P));           \
+    minmax_rows_kernel<T, kE, P><<<grid, kBlock, 0, stream>>>(in, mn_out, mx_out, flags, a);     \
+    break;                                                                                       \
+  }
+      switch (p.lanes_per_tile) {
+        FFQ_ROWS(64) FFQ_ROWS(32) FFQ_ROWS(16) FFQ_ROWS(8) FFQ_ROWS(4) FFQ_ROWS(2) FFQ_ROWS(1)
+      }
+#undef FFQ_ROWS
+      break;
+    }
+    case PLAN_ROWS_SPLIT: {
+      const dim3 grid(p.partials, (unsigned)info.ntiles);
+      minmax_rows_split_kernel<T, kE><<<grid, kBlock, 0, stream>>>(in, (uint32_t)(info.run / kE), partial);
+      minmax_finalize_kernel<T><<<(unsigned)((info.ntiles + 3) / 4), kBlock, 0, stream>>>(
+          partial, (uint32_t)info.ntiles, p.partials, mn_out, mx_out, accumulate, flags);
+      break;
+    }
+    default: {  // PLAN_COLUMNS
+      ColsArgs a;
+      a.col_chunks = (uint32_t)(info.channels / kE);
+      a.rows = (uint32_t)(info.numel / info.channels);
+      a.row_groups = p.partials;
+      a.col_chunks_div = make_fastdiv(a.col_chunks);
+      const uint64_t lanes = (uint64_t)a.row_groups * a.col_chunks;
+      minmax_columns_partial_kernel<T, kE><<<(unsigned)((lanes + kBlock - 1) / kBlock), kBlock, 0, stream>>>(in, partial, a);
+      minmax_finalize_kernel<T><<<(unsigned)((info.channels + 3) / 4), kBlock, 0, stream>>>(
+          partial, (uint32_t)info.channels, p.partials, mn_out, mx_out, accumulate, flags);
+      break;
+    }
+  }
+  return check_launch("minmax");
+}
+
+static int minmax_impl(const void* data, int data_dt, const ffq_tiling* tiling, void* mn, void* mx,
+                       int accumulate, int32_t* flags, void* workspace, size_t workspace_bytes,
+                       hipStream_t stream) {
+  TileInfo info;
+  int rc = analyse(tiling, &info);
+  if (rc) return rc;
+  if (!dt_valid(data_dt)) return fail(FFQ_ERR_ARG, "bad dtype tag");
+  if (info.numel == 0) return fail(FFQ_ERR_EMPTY, "min/max of an empty tensor");
+  if (!data || !mn || !mx) return fail(FFQ_ERR_ARG, "NULL buffer");
+  const MinMaxPlan p = plan_for(info, data_dt);
+  if (p.workspace > workspace_bytes || (p.workspace && !workspace))
+    return fail(FFQ_ERR_WORKSPACE, "min/max needs %zu workspace bytes, got %zu", p.workspace, workspace_bytes);
+  if (p.plan != PLAN_GENERIC && !aligned16(data)) {
+    // misaligned view: fall through to the element-wise kernels
+  } else if (p.plan != PLAN_GENERIC) {
+    switch (data_dt) {
+      case FFQ_F32: return run_fast<float>(p, info, data, mn, mx, accumulate, flags, workspace, stream);
+      case FFQ_BF16: return run_fast<bf16_t>(p, info, data, mn, mx, accumulate, flags, workspace, stream);
+      default: return run_fast<f16_t>(p, info, data, mn, mx, accumulate, flags, workspace, stream);
+    }
+  }
+  const size_t need = sizeof(GenericCell) * (size_t)info.ntiles;
+  if (need > workspace_bytes) return fail(FFQ_ERR_WORKSPACE, "min/max needs %zu workspace bytes, got %zu", need, workspace_bytes);
+  GenericCell* cells = static_cast<GenericCell*>(workspace);
+  const unsigned tb = (unsigned)((info.ntiles + kBlock - 1) / kBlock);
+  minmax_generic_init_kernel<<<tb, kBlock, 0, stream>>>(cells, info.ntiles);
+  int64_t blocks = (info.numel + kBlock - 1) / kBlock;
+  if (blocks > 8192) blocks = 8192;
+  minmax_generic_scatter_kernel<<<(unsigned)blocks, kBlock, 0, stream>>>(data, data_dt, info.numel, make_generic(tiling), cells);
+  minmax_generic_finalize_kernel<<<tb, kBlock, 0, stream>>>(cells, info.ntiles, mn, mx, data_dt, accumulate, flags);
+  return check_launch("minmax_generic");
+}
+
+static size_t minmax_workspace(const ffq_tiling* tiling, int data_dt) {
+  TileInfo info;
+  if (analyse(tiling, &info)) return 0;
+  if (info.numel == 0) return 0;
+  const MinMaxPlan p = plan_for(info, data_dt);
+  // a misaligned pointer may force the generic kernels at call time: size for both
+  const size_t generic = sizeof(GenericCell) * (size_t)info.ntiles;
+  size_t need = p.workspace > generic ? p.workspace : generic;
+  return (need + 255) & ~(size_t)255;
+}
+
+// ---- A5 -------------------------------------------------------------------------------------
+struct RangeArgs {
+  int range_dt, scale_dt, offset_dt;
+  int64_t ntiles;
+  int symmetric, allow_one_sided, round_offset;
+  float abs_int_min, abs_int_max, num_steps, int_min;
+};
+
+constexpr int kRangeBlock = 1024;
+
+__global__ __launch_bounds__(kRangeBlock) void parameters_for_range_kernel(const void* __restrict__ min_range,
+                                                                           const void* __restrict__ max_range,
+                                                                           void* __restrict__ scale_out,
+                                                                           void* __restrict__ offset_out,
+                                                                           RangeArgs a) {
+  __shared__ float lds_min[16];
+  __shared__ int lds_nan[16];
+  __shared__ int one_sided_s;
+  // one_sided = min_range.min() >= 0 and allow_one_sided — global over all tiles        (:100)
+  int one_sided = 0;
+  if (a.symmetric && a.allow_one_sided) {
+    float mn = INFINITY;
+    int nan = 0;
+    for (int64_t t = threadIdx.x; t < a.ntiles; t += kRangeBlock) {
+      const float v = (float)load_any(min_range, a.range_dt, t);  // .to(torch.float32)      (:90)
+      mn = __builtin_fminf(mn, v);
+      nan |= v != v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      mn = __builtin_fminf(mn, __shfl_xor(mn, d, 64));
+      nan |= __shfl_xor(nan, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { lds_min[threadIdx.x >> 6] = mn; lds_nan[threadIdx.x >> 6] = nan; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < kRangeBlock / 64; ++w) { mn = __builtin_fminf(mn, lds_min[w]); nan |= lds_nan[w]; }
+      one_sided_s = (!nan && mn >= 0.0f) ? 1 : 0;  // NaN >= 0 is False
+    }
+    __syncthreads();
+    one_sided = one_sided_s;
+  }
+  for (int64_t t = threadIdx.x; t < a.ntiles; t += kRangeBlock) {
+    float lo = (float)load_any(min_range, a.range_dt, t);
+    const float hi = (float)load_any(max_range, a.range_dt, t);
+    if (a.symmetric && one_sided) lo = 0.0f;                               // (:104-105)
+    float scale, offset;
+    if (a.symmetric && !one_sided) {
+      const float neg = __builtin_fabsf(lo) / a.abs_int_min;               // (:108)
+      const float pos = __builtin_fabsf(hi) / a.abs_int_max;               // (:109)
+      scale = (neg != neg || pos != pos) ? NAN : __builtin_fmaxf(neg, pos);  // torch.max  (:110)
+      offset = 0.0f;  // reference returns None; the setter fills the buffer with 0
+    } else {
+      const float interval = hi - lo;                                      // (:118)
+      scale = interval / a.num_steps;                                      // (:119)
+      scale = scale != scale ? scale : __builtin_fmaxf(scale, 1.1920928955078125e-07f);  // clamp(eps) (:120)
+      const float q = lo / scale;
+      offset = q - a.int_min;                                              // (:121)
+      if (a.round_offset) offset = rne(offset);                            // dynamic path, _quantizer_impl.py:275
+    }
+    store_any(scale_out, a.scale_dt, t, (double)scale);
+    if (offset_out) store_any(offset_out, a.offset_dt, t, (double)offset);
+  }
+}
+
+static int parameters_impl(const void* min_range, const void* max_range, int range_dt, int64_t ntiles,
+                           double num_bits, int symmetric, int allow_one_sided, void* scale_out, int scale_dt,
+                           void* offset_out, int offset_dt, int round_offset, hipStream_t stream) {
+  if (!min_range || !max_range || !scale_out || ntiles <= 0) return fail(FFQ_ERR_ARG, "bad argument");
+  if (!dt_valid(range_dt) || !dt_valid(scale_dt) || (offset_out && !dt_valid(offset_dt)))
+    return fail(FFQ_ERR_ARG, "bad dtype tag");
+  RangeArgs a;
+  a.range_dt = range_dt; a.scale_dt = scale_dt; a.offset_dt = offset_dt;
+  a.ntiles = ntiles;
+  a.symmetric = symmetric; a.allow_one_sided = allow_one_sided; a.round_offset = round_offset;
+  const double int_min = -pow(2.0, num_bits - 1.0), int_max = -int_min - 1.0;
+  a.abs_int_min = (float)fabs(int_min);
+  a.abs_int_max = (float)fabs(int_max);
+  a.num_steps = (float)(pow(2.0, num_bits) - 1.0);
+  a.int_min = (float)int_min;
+  parameters_for_range_kernel<<<1, kRangeBlock, 0, stream>>>(min_range, max_range, scale_out, offset_out, a);
+  return check_launch("parameters_for_range_kernel");
+}
+
+}  // namespace ffq
+
+using namespace ffq;
+
+extern "C" {
+
+size_t ffq_minmax_workspace_bytes(const ffq_tiling* tiling, int data_dt) { return minmax_workspace(tiling, data_dt); }
+
+int ffq_minmax_by_tile(const void* data, int data_dt, const ffq_tiling* tiling, void* min_inout,
+                       void* max_inout, int accumulate, int32_t* status_flags, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  return minmax_impl(data, data_dt, tiling, min_inout, max_inout, accumulate, status_flags, workspace,
+                     workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int ffq_parameters_for_range(const void* min_range, const void* max_range, int range_dt, int64_t ntiles,
+                             double num_bits, int symmetric, int allow_one_sided, void* scale_out,
+                             int scale_dt, void* offset_out, int offset_dt, void* stream) {
+  return parameters_impl(min_range, max_range, range_dt, ntiles, num_bits, symmetric, allow_one_sided,
+                         scale_out, scale_dt, offset_out, offset_dt, 0, static_cast<hipStream_t>(stream));
+}
+
+// workspace layout: [ minmax scratch | min (ntiles, data dtype) | max (ntiles, data dtype) ]
+size_t ffq_quantize_dynamic_workspace_bytes(const ffq_tiling* tiling, int data_dt) {
+  TileInfo info;
+  if (analyse(tiling, &info) || info.numel == 0) return 0;
+  const size_t mm = minmax_workspace(tiling, data_dt);
+  const size_t ranges = (((size_t)info.ntiles * dt_size(data_dt)) + 255) & ~(size_t)255;
+  return mm + 2 * ranges;
+}
+
+int ffq_quantize_dynamic_by_tile(const void* data, int data_dt, const ffq_tiling* tiling, double num_bits,
+                                 int symmetric, int allow_one_sided, void* out, int out_dt,
+                                 float* scale_out, float* offset_out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TileInfo info;
+  int rc = analyse(tiling, &info);
+  if (rc) return rc;
+  // torch.min over an empty row raises IndexError -> QuantizationError                 (:259-264)
+  if (info.numel == 0) return fail(FFQ_ERR_EMPTY, "Cannot dynamically quantize an empty tensor");
+  if (!scale_out || !offset_out) return fail(FFQ_ERR_ARG, "NULL parameter output");
+  if (!ffq_can_support_bitwidth(out_dt, num_bits))
+    return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.",
+                out_dt, num_bits);
+  const size_t need = ffq_quantize_dynamic_workspace_bytes(tiling, data_dt);
+  if (need > workspace_bytes || !workspace)
+    return fail(FFQ_ERR_WORKSPACE, "dynamic quantize needs %zu workspace bytes, got %zu", need, workspace_bytes);
+  const size_t mm = minmax_workspace(tiling, data_dt);
+  const size_t ranges = (((size_t)info.ntiles * dt_size(data_dt)) + 255) & ~(size_t)255;
+  char* base = static_cast<char*>(workspace);
+  void* mn = base + mm;
+  void* mx = base + mm + ranges;
+  if ((rc = minmax_impl(data, data_dt, tiling, mn, mx, 0, nullptr, base, mm, s))) return rc;
+  // parameters_for_range; offset None -> zeros; offset = round(offset)                  (:266-275)
+  if ((rc = parameters_impl(mn, mx, data_dt, info.ntiles, num_bits, symmetric, allow_one_sided, scale_out,
+                            FFQ_F32, offset_out, FFQ_F32, 1, s)))
+    return rc;
+  // round(row / scale - offset), clamp, cast                                            (:277-284)
+  return quantize_impl(data, data_dt, scale_out, FFQ_F32, info.ntiles, offset_out, FFQ_F32, info.ntiles,
+                       tiling, num_bits, out, out_dt, s);
+}
+
+}  // extern "C"

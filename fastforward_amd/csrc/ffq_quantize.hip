@@ -1,0 +1,429 @@
+// ffq_quantize.hip — A1: fastforward::quantize_by_tile on gfx950.
+//
+// Reference: quantize_by_tile_impl, src/fastforward/quantization/_quantizer_impl.py:144-169
+//   q = cast(clamp(round(x / s_t - round(o_t)), -2^(b-1), 2^(b-1)-1))
+// The reference runs this as five ATen passes over a tiles_to_rows view (a full copy for strided
+// channels). Here it is ONE pass: 16 B per lane in, packed codes out, the tile -> parameter map
+// folded into index arithmetic. HBM-bound: 3 B/elem for bf16 -> int8, 4 B/elem for bf16 -> bf16.
+//
+// Kernel families
+//   quantize_stream_kernel   fp32 stages, fp32 parameters, layouts SCALAR / ROWS / CHANNEL(block)
+//   quantize_columns_kernel  fp32 stages, fp32 parameters, one channel per COLUMN (PerChannel(-1)):
+//                            each lane keeps the parameters of its 8 columns in registers and
+//                            walks down the rows, so nothing is re-fetched and nothing is copied
+//   quantize_generic_kernel  any dtype mix / any N-d tiling, one element per lane, every
+//                            intermediate rounding of the eager chain reproduced
+#include "ffq_common.h"
+#include "ffq_vec.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+namespace ffq {
+
+struct StreamArgs {
+  float lo, hi;
+  uint32_t nchunks;
+  uint32_t scale_stride;   // 0 when scale is a single broadcast value, else 1
+  uint32_t offset_stride;  // same for offset
+  FastDiv chunks_per_run;  // ROWS: run / E             CHANNEL: inner / E
+  FastDiv channels;        // CHANNEL: number of channels
+};
+
+// x / s, correctly rounded. DIVMODE 0 is the compiler's IEEE sequence (v_div_scale / v_rcp /
+// v_fma x4 / v_div_fmas / v_div_fixup, ~11 VALU + hazard nops per element). DIVMODE 1 replaces it
+// by Markstein's FMA iteration around r = RN(1/s), which is computed once per chunk with the IEEE
+// sequence: q0 = RN(x r) is within 1.5 ulp, the first residual step makes it faithful, the second
+// one makes it the correctly rounded quotient (Markstein 1990; Muller et al., Handbook of
+// Floating-Point Arithmetic, division by FMA iteration: y = RN(1/b) and q faithful imply
+// RN(q + RN(a - b q) y) = RN(a/b)). The theorem assumes no overflow/underflow, hence the guards:
+// the fast path is taken only for 2^-100 < |s| < 2^100 and its result is used only while
+// |q0| < 2^100 — beyond that every candidate clamps to the same bound and q0 carries the right
+// sign / Inf / NaN. tests/test_divide_gpu.py compares both modes bit-for-bit on adversarial data.
+template <int DIVMODE>
+struct Divider {
+  float s, r;
+  bool safe;
+  __device__ __forceinline__ explicit Divider(float s_) : s(s_), r(0.0f), safe(false) {
+    if constexpr (DIVMODE == 1) {
+      r = 1.0f / s;
+      const float as = __builtin_fabsf(s);
+      safe = as > 0x1p-100f && as < 0x1p100f;
+    }
+  }
+  __device__ __forceinline__ float fast(float x) const {
+    const float q0 = x * r;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, s, x), r, q0);
+    const float q2 = __builtin_fmaf(__builtin_fmaf(-q1, s, x), r, q1);
+    return __builtin_fabsf(q0) < 0x1p100f ? q2 : q0;
+  }
+};
+
+// round(x / s - o) for E elements sharing one parameter pair.
+template <int DIVMODE, int E>
+__device__ __forceinline__ void quantize_chunk(const float (&x)[E], float s, float o, float (&r)[E]) {
+  Divider<DIVMODE> d(s);
+  if (DIVMODE == 1 && d.safe) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) r[i] = rne(d.fast(x[i]) - o);
+  } else {
+#pragma unroll
+    for (int i = 0; i < E; ++i) r[i] = rne(x[i] / s - o);  // separate roundings: -ffp-contract=off
+  }
+}
+
+// clamp + cast of E rounded values. Float containers: v_med3_f32 with NaN passed through
+// (torch.clamp propagates NaN). Integer containers: convert first (v_cvt_i32_f32 saturates and
+// maps NaN to 0, the value the reference's CPU cast yields for int8/int16), then v_med3_i32.
+template <typename TOut, int E>
+__device__ __forceinline__ void finalize_chunk(const float (&r)[E], float lo, float hi, Chunk<TOut, E>& y) {
+  if constexpr (TypeTag<TOut>::value == FFQ_I8 || TypeTag<TOut>::value == FFQ_I16 ||
+                TypeTag<TOut>::value == FFQ_I32) {
+    const int ilo = (int)lo, ihi = (int)hi;
+    int c[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      int v = (int)r[i];
+      v = v < ilo ? ilo : (v > ihi ? ihi : v);
+      if constexpr (TypeTag<TOut>::value == FFQ_I32) v = r[i] != r[i] ? INT32_MIN : v;
+      c[i] = v;
+    }
+    y.pack_int(c);
+  } else {
+    float c[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) c[i] = r[i] != r[i] ? r[i] : __builtin_amdgcn_fmed3f(r[i], lo, hi);
+    y.pack(c);
+  }
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ uint32_t tile_of_chunk(uint32_t chunk, const StreamArgs& a) {
+  if constexpr (LAYOUT == LAYOUT_SCALAR) {
+    return 0;
+  } else if constexpr (LAYOUT == LAYOUT_ROWS) {
+    return fdiv(chunk, a.chunks_per_run);
+  } else {
+    const uint32_t outer = fdiv(chunk, a.chunks_per_run);  // flat / inner
+    return outer - fdiv(outer, a.channels) * a.channels.div;
+  }
+}
+
+// One block = kBlock lanes x U chunks of E elements; chunk c of the block is read by lane
+// (c % kBlock) so that every load instruction of a wave covers one contiguous 64 * 16 B span.
+template <typename TIn, typename TOut, int LAYOUT, int E, int U, bool HAS_OFFSET, int DIVMODE>
+__global__ __launch_bounds__(kBlock) void quantize_stream_kernel(const TIn* __restrict__ in,
+                                                                 TOut* __restrict__ out,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ offset,
+                                                                 StreamArgs a) {
+  const uint32_t first = blockIdx.x * (uint32_t)(kBlock * U) + threadIdx.x;
+  Chunk<TIn, E> x[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t c = first + u * kBlock;
+    if (c < a.nchunks) x[u].load(in + (size_t)c * E);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t c = first + u * kBlock;
+    if (c >= a.nchunks) continue;
+    const uint32_t t = tile_of_chunk<LAYOUT>(c, a);
+    const float s = scale[t * a.scale_stride];
+    const float o = HAS_OFFSET ? rne(offset[t * a.offset_stride]) : 0.0f;
+    float xf[E], r[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) xf[i] = x[u].get(i);
+    quantize_chunk<DIVMODE, E>(xf, s, o, r);
+    Chunk<TOut, E> y;
+    finalize_chunk<TOut, E>(r, a.lo, a.hi, y);
+    y.store(out + (size_t)c * E);
+  }
+}
+
+struct ColumnArgs {
+  float lo, hi;
+  uint32_t col_chunks;   // channels / E
+  uint32_t rows;
+  uint32_t row_groups;   // rows are visited as row = group + k * row_groups
+  uint32_t scale_stride;
+  uint32_t offset_stride;
+  FastDiv col_chunks_div;
+};
+
+// data viewed as [rows, channels]; lane g owns column chunk g % col_chunks for every row of its
+// row group. The 2 x E parameters stay in VGPRs across the whole walk.
+template <typename TIn, typename TOut, int E, bool HAS_OFFSET>
+__global__ __launch_bounds__(kBlock) void quantize_columns_kernel(const TIn* __restrict__ in,
+                                                                  TOut* __restrict__ out,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ offset,
+                                                                  ColumnArgs a) {
+  const uint32_t g = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  const uint32_t group = fdiv(g, a.col_chunks_div);
+  if (group >= a.row_groups) return;
+  const uint32_t cc = g - group * a.col_chunks;
+  float s[E], o[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    s[i] = scale[(cc * E + i) * a.scale_stride];
+    o[i] = HAS_OFFSET ? rne(offset[(cc * E + i) * a.offset_stride]) : 0.0f;
+  }
+  const size_t row_elems = (size_t)a.col_chunks * E;
+  for (uint32_t r = group; r < a.rows; r += a.row_groups) {
+    const size_t at = (size_t)r * row_elems + (size_t)cc * E;
+    Chunk<TIn, E> x;
+    x.load(in + at);
+    float q[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) q[i] = rne(x.get(i) / s[i] - o[i]);
+    Chunk<TOut, E> y;
+    finalize_chunk<TOut, E>(q, a.lo, a.hi, y);
+    y.store(out + at);
+  }
+}
+
+struct GenericArgs {
+  int data_dt, scale_dt, offset_dt, out_dt;
+  int div_dt, sub_dt;
+  int has_offset;
+  int64_t start, count;
+  int64_t scale_numel, offset_numel;
+  double lo, hi;
+  GenericTiling g;
+};
+
+// Follows oracle-independent reading of the eager chain: each ATen op evaluates in float opmath
+// (double for f64 tensors) and rounds its result into the promoted dtype.
+__global__ __launch_bounds__(kBlock) void quantize_generic_kernel(const void* __restrict__ data,
+                                                                  const void* __restrict__ scale,
+                                                                  const void* __restrict__ offset,
+                                                                  void* __restrict__ out, GenericArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < a.count; k += stride) {
+    const int64_t i = a.start + k;
+    const int64_t t = generic_tile_of(a.g, i);
+    const double xs = load_any(data, a.data_dt, i);
+    const double ss = load_any(scale, a.scale_dt, a.scale_numel == 1 ? 0 : t);
+    double os = 0.0;
+    if (a.has_offset) {
+      os = load_any(offset, a.offset_dt, a.offset_numel == 1 ? 0 : t);
+      if (dt_is_float(a.offset_dt)) os = rne(os);  // torch.round; identity on integer tensors
+    }
+    double q;
+    if (a.sub_dt == FFQ_F64) {
+      double d = (a.div_dt == FFQ_F64) ? xs / ss
+                                       : (double)round_stage(round_stage((float)xs, a.div_dt) /
+                                                                 round_stage((float)ss, a.div_dt),
+                                                             a.div_dt);
+      q = clamp_nan(rne(d - os), a.lo, a.hi);
+    } else {
+      const float x = round_stage((float)xs, a.div_dt);
+      const float s = round_stage((float)ss, a.div_dt);
+      float d = round_stage(x / s, a.div_dt);
+      const float o = round_stage((float)os, a.sub_dt);
+      d = round_stage(round_stage(d, a.sub_dt) - o, a.sub_dt);
+      q = (double)clamp_nan(rne(d), round_stage((float)a.lo, a.sub_dt), round_stage((float)a.hi, a.sub_dt));
+    }
+    store_any(out, a.out_dt, i, q);
+  }
+}
+
+// FFQ_DIV_MODE=0 forces the compiler's IEEE division sequence in the streaming kernels;
+// the default is the Markstein iteration (bit-identical, see Divider).
+static int div_mode() {
+  static const int mode = [] {
+    const char* e = getenv("FFQ_DIV_MODE");
+    return e ? atoi(e) : 1;
+  }();
+  return mode;
+}
+
+static unsigned grid_for(int64_t work_items, int per_block) {
+  int64_t blocks = (work_items + per_block - 1) / per_block;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+static int launch_generic(const void* data, int data_dt, const void* scale, int scale_dt,
+                          int64_t scale_numel, const void* offset, int offset_dt, int64_t offset_numel,
+                          const ffq_tiling* tiling, double lo, double hi, int div_dt, int sub_dt,
+                          void* out, int out_dt, int64_t start, int64_t count, hipStream_t stream) {
+  if (count <= 0) return FFQ_OK;
+  GenericArgs a;
+  a.data_dt = data_dt; a.scale_dt = scale_dt; a.offset_dt = offset_dt; a.out_dt = out_dt;
+  a.div_dt = div_dt; a.sub_dt = sub_dt;
+  a.has_offset = offset != nullptr;
+  a.start = start; a.count = count;
+  a.scale_numel = scale_numel; a.offset_numel = offset_numel;
+  a.lo = lo; a.hi = hi;
+  a.g = make_generic(tiling);
+  int64_t blocks = (count + kBlock - 1) / kBlock;
+  if (blocks > 8192) blocks = 8192;
+  quantize_generic_kernel<<<dim3((unsigned)blocks), dim3(kBlock), 0, stream>>>(data, scale, offset, out, a);
+  return check_launch("quantize_generic_kernel");
+}
+
+template <typename TIn, typename TOut, int E>
+static int launch_stream(const TIn* in, TOut* out, const float* scale, int64_t scale_numel,
+                         const float* offset, int64_t offset_numel, const TileInfo& info, float lo,
+                         float hi, hipStream_t stream) {
+  constexpr int U = 4;
+  StreamArgs a;
+  a.lo = lo; a.hi = hi;
+  a.nchunks = (uint32_t)(info.numel / E);
+  a.scale_stride = scale_numel == 1 ? 0u : 1u;
+  a.offset_stride = offset_numel == 1 ? 0u : 1u;
+  a.chunks_per_run = make_fastdiv(1);
+  a.channels = make_fastdiv(1);
+  const unsigned grid = grid_for(a.nchunks, kBlock * U);
+  const dim3 block(kBlock);
+#define FFQ_LAUNCH_D(LAYOUT, D)                                                                      \
+  do {                                                                                               \
+    if (offset)                                                                                      \
+      quantize_stream_kernel<TIn, TOut, LAYOUT, E, U, true, D><<<grid, block, 0, stream>>>(in, out, scale, offset, a); \
+    else                                                                                             \
+      quantize_stream_kernel<TIn, TOut, LAYOUT, E, U, false, D><<<grid, block, 0, stream>>>(in, out, scale, offset, a); \
+  } while (0)
+#define FFQ_LAUNCH(LAYOUT)                                                                           \
+  do {                                                                                               \
+    if (div_mode() == 1) FFQ_LAUNCH_D(LAYOUT, 1); else FFQ_LAUNCH_D(LAYOUT, 0);                      \
+  } while (0)
+  switch (info.layout) {
+    case LAYOUT_SCALAR: FFQ_LAUNCH(LAYOUT_SCALAR); break;
+    case LAYOUT_ROWS:
+      a.chunks_per_run = make_fastdiv((uint32_t)(info.run / E));
+      FFQ_LAUNCH(LAYOUT_ROWS);
+      break;
+    default:
+      a.chunks_per_run = make_fastdiv((uint32_t)(info.inner / E));
+      a.channels = make_fastdiv((uint32_t)info.channels);
+      FFQ_LAUNCH(LAYOUT_CHANNEL);
+      break;
+  }
+#undef FFQ_LAUNCH
+#undef FFQ_LAUNCH_D
+  return check_launch("quantize_stream_kernel");
+}
+
+template <typename TIn, typename TOut, int E>
+static int launch_columns(const TIn* in, TOut* out, const float* scale, int64_t scale_numel,
+                          const float* offset, int64_t offset_numel, const TileInfo& info, float lo,
+                          float hi, hipStream_t stream) {
+  ColumnArgs a;
+  a.lo = lo; a.hi = hi;
+  a.col_chunks = (uint32_t)(info.channels / E);
+  a.rows = (uint32_t)(info.numel / info.channels);
+  a.scale_stride = scale_numel == 1 ? 0u : 1u;
+  a.offset_stride = offset_numel == 1 ? 0u : 1u;
+  a.col_chunks_div = make_fastdiv(a.col_chunks);
+  // ~8 rows per lane amortise the 2*E parameter loads; never more groups than rows.
+  uint32_t groups = (a.rows + 7) / 8;
+  if (groups < 1) groups = 1;
+  a.row_groups = groups;
+  const uint64_t lanes = (uint64_t)groups * a.col_chunks;
+  const unsigned grid = grid_for((int64_t)lanes, kBlock);
+  if (offset)
+    quantize_columns_kernel<TIn, TOut, E, true><<<grid, dim3(kBlock), 0, stream>>>(in, out, scale, offset, a);
+  else
+    quantize_columns_kernel<TIn, TOut, E, false><<<grid, dim3(kBlock), 0, stream>>>(in, out, scale, offset, a);
+  return check_launch("quantize_columns_kernel");
+}
+
+// Decide whether the streaming kernels apply: fp32 stages + fp32 parameters + 16 B alignment + a
+// layout whose tiles never split a chunk; everything else goes to the generic kernel.
+template <typename TIn, typename TOut>
+static int dispatch_fast(const void* data, const void* scale, int64_t scale_numel, const void* offset,
+                         int64_t offset_numel, const TileInfo& info, float lo, float hi, void* out,
+                         hipStream_t stream, bool* handled) {
+  constexpr int E = 8;
+  *handled = false;
+  if (info.numel >= ((int64_t)1 << 32) - 4096) return FFQ_OK;  // 32-bit chunk index
+  if (!aligned16(data) || !aligned16(out)) return FFQ_OK;
+  const TIn* in = static_cast<const TIn*>(data);
+  TOut* o = static_cast<TOut*>(out);
+  const float* s = static_cast<const float*>(scale);
+  const float* f = static_cast<const float*>(offset);
+  if (info.layout == LAYOUT_SCALAR || (info.layout == LAYOUT_ROWS && info.run % E == 0) ||
+      (info.layout == LAYOUT_CHANNEL && info.inner % E == 0)) {
+    if (info.numel / E == 0) return FFQ_OK;
+    *handled = true;
+    return launch_stream<TIn, TOut, E>(in, o, s, scale_numel, f, offset_numel, info, lo, hi, stream);
+  }
+  if (info.layout == LAYOUT_CHANNEL && info.inner == 1 && info.channels % E == 0) {
+    *handled = true;
+    return launch_columns<TIn, TOut, E>(in, o, s, scale_numel, f, offset_numel, info, lo, hi, stream);
+  }
+  return FFQ_OK;
+}
+
+template <typename TIn>
+static int dispatch_out(int out_dt, const void* data, const void* scale, int64_t scale_numel,
+                        const void* offset, int64_t offset_numel, const TileInfo& info, float lo,
+                        float hi, void* out, hipStream_t stream, bool* handled) {
+  switch (out_dt) {
+    case FFQ_F32: return dispatch_fast<TIn, float>(data, scale, scale_numel, offset, offset_numel, info, lo, hi, out, stream, handled);
+    case FFQ_BF16: return dispatch_fast<TIn, bf16_t>(data, scale, scale_numel, offset, offset_numel, info, lo, hi, out, stream, handled);
+    case FFQ_F16: return dispatch_fast<TIn, f16_t>(data, scale, scale_numel, offset, offset_numel, info, lo, hi, out, stream, handled);
+    case FFQ_I8: return dispatch_fast<TIn, int8_t>(data, scale, scale_numel, offset, offset_numel, info, lo, hi, out, stream, handled);
+    case FFQ_I16: return dispatch_fast<TIn, int16_t>(data, scale, scale_numel, offset, offset_numel, info, lo, hi, out, stream, handled);
+    case FFQ_I32: return dispatch_fast<TIn, int32_t>(data, scale, scale_numel, offset, offset_numel, info, lo, hi, out, stream, handled);
+    default: *handled = false; return FFQ_OK;
+  }
+}
+
+int quantize_impl(const void* data, int data_dt, const void* scale, int scale_dt, int64_t scale_numel,
+                  const void* offset, int offset_dt, int64_t offset_numel, const ffq_tiling* tiling,
+                  double num_bits, void* out, int out_dt, hipStream_t stream) {
+  TileInfo info;
+  int rc = analyse(tiling, &info);
+  if (rc) return rc;
+  if (!dt_valid(data_dt) || !dt_valid(scale_dt) || !dt_valid(out_dt) || (offset && !dt_valid(offset_dt)))
+    return fail(FFQ_ERR_ARG, "bad dtype tag");
+  if (info.numel != 0) {
+    if ((rc = check_param_numel("scale", scale_numel, info.ntiles))) return rc;
+    if (offset && (rc = check_param_numel("offset", offset_numel, info.ntiles))) return rc;
+  }
+  const int off_dt = offset ? offset_dt : scale_dt;
+  // min_threshold = -(2 ** (num_bits - 1)); max_threshold = -min_threshold - 1      (:158-159)
+  const double lo = -pow(2.0, num_bits - 1.0), hi = -lo - 1.0;
+  int div_dt = ffq_promote_types(data_dt, scale_dt);
+  if (!dt_is_float(div_dt)) div_dt = FFQ_F32;  // integer / integer is a true division in float
+  const int sub_dt = ffq_promote_types(div_dt, off_dt);
+  if (!ffq_can_support_bitwidth(out_dt, num_bits))
+    return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.",
+                out_dt, num_bits);
+  if (info.numel == 0) return FFQ_OK;
+  if (!data || !scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+
+  const bool fast_types = num_bits == floor(num_bits) && num_bits >= 1 && num_bits <= 32 &&
+                          div_dt == FFQ_F32 && sub_dt == FFQ_F32 && scale_dt == FFQ_F32 &&
+                          (!offset || offset_dt == FFQ_F32) && getenv("FFQ_FORCE_GENERIC") == nullptr;
+  int64_t done = 0;
+  if (fast_types) {
+    bool handled = false;
+    switch (data_dt) {
+      case FFQ_F32: rc = dispatch_out<float>(out_dt, data, scale, scale_numel, offset, offset_numel, info, (float)lo, (float)hi, out, stream, &handled); break;
+      case FFQ_BF16: rc = dispatch_out<bf16_t>(out_dt, data, scale, scale_numel, offset, offset_numel, info, (float)lo, (float)hi, out, stream, &handled); break;
+      case FFQ_F16: rc = dispatch_out<f16_t>(out_dt, data, scale, scale_numel, offset, offset_numel, info, (float)lo, (float)hi, out, stream, &handled); break;
+      default: break;
+    }
+    if (rc) return rc;
+    if (handled) {
+      // only the SCALAR layout can leave a tail (numel % 8); ROWS/CHANNEL tiles are whole chunks
+      done = info.layout == LAYOUT_SCALAR ? (info.numel / 8) * 8 : info.numel;
+    }
+  }
+  return launch_generic(data, data_dt, scale, scale_dt, scale_numel, offset, offset_dt, offset_numel,
+                        tiling, lo, hi, div_dt, sub_dt, out, out_dt, done, info.numel - done, stream);
+}
+
+}  // namespace ffq
+
+extern "C" int ffq_quantize_by_tile(const void* data, int data_dt, const void* scale, int scale_dt,
+                                    int64_t scale_numel, const void* offset, int offset_dt,
+                                    int64_t offset_numel, const ffq_tiling* tiling, double num_bits,
+                                    void* out, int out_dt, void* stream) {
+  return ffq::quantize_impl(data, data_dt, scale, scale_dt, scale_numel, offset, offset_dt, offset_numel,
+                            tiling, num_bits, out, out_dt, static_cast<hipStream_t>(stream));
+}

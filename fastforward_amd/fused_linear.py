@@ -1,0 +1,95 @@
+"""The W8A8 linear registered in the quantized-operator dispatcher (plug-in seam #2).
+
+The reference registers no kernel for ``"linear"``; every quantized linear therefore runs
+``fallback.linear`` (src/fastforward/_gen/fallback.py:77-112): dequantize x, dequantize w, float
+GEMM, output quantizer. This module registers a kernel whose predicate accepts the combinations the
+int8-MFMA kernel A6 covers and returns False for everything else, so the reference behaviour (the
+float fallback in :mod:`fastforward_amd.nn.functional`) still applies there.
+
+The kernel accepts both calling conventions the dispatcher produces:
+``kernel(input, weight, bias)`` from ``QuantizedTensor.__torch_function__`` when user code calls
+``torch.nn.functional.linear`` on quantized tensors, and
+``kernel(input=..., weight=..., bias=..., output_quantizer=..., strict_quantization=...)`` from
+``fastforward_amd.nn.functional.linear``.
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+
+from fastforward_amd import _native, ops
+from fastforward_amd.dispatcher import Predicate, register
+from fastforward_amd.exceptions import QuantizationError
+from fastforward_amd.quantization import granularity as granularities
+from fastforward_amd.quantization._linear_quantized_ops import _static_affine
+from fastforward_amd.quantized_tensor import QuantizedTensor
+
+
+def _row_mode(tensor: QuantizedTensor) -> str | None:
+    """'tensor' (one parameter pair), 'row' (one pair per row of the last-dim-contiguous matrix), or None."""
+    params = tensor.quantization_context.quantization_params
+    tile = params.granularity.tile_size(tensor.shape)
+    if isinstance(tile, str) or tuple(tile) == tuple(tensor.shape):
+        return "tensor"
+    if tensor.dim() >= 1 and all(t == 1 for t in tile[:-1]) and tile[-1] == tensor.shape[-1]:
+        return "row"
+    return None
+
+
+def _supported(input: Any, weight: Any, bias: Any = None, **_: Any) -> bool:
+    if not (_static_affine(input) and _static_affine(weight)):
+        return False
+    try:
+        lib = _native.library()
+    except Exception:
+        return False
+    on_backend = (input.is_cuda and weight.is_cuda) if lib.is_device else (input.device.type == "cpu" and weight.device.type == "cpu")
+    if not on_backend or weight.dim() != 2 or input.dim() < 1:
+        return False
+    if input.shape[-1] != weight.shape[1] or weight.shape[1] % 16 != 0 or input.numel() == 0:
+        return False
+    xp, wp = input.quantization_context.quantization_params, weight.quantization_context.quantization_params
+    if xp.num_bits > 8 or wp.num_bits > 8 or xp.num_bits != int(xp.num_bits) or wp.num_bits != int(wp.num_bits):
+        return False
+    if _row_mode(input) is None or _row_mode(weight) is None:
+        return False
+    deq = xp.dequantize_dtype or torch.get_default_dtype()
+    if deq not in (torch.bfloat16, torch.float16, torch.float32):
+        return False
+    if (wp.dequantize_dtype or deq) != deq:
+        return False  # the float fallback would raise on mixed dtypes; let it
+    if isinstance(bias, QuantizedTensor) and not _static_affine(bias):
+        return False
+    return True
+
+
+def _int8_codes(tensor: QuantizedTensor) -> torch.Tensor:
+    """Codes as int8. Float / wider containers hold the same integers; they are
+    converted exactly by A1 with scale 1 (x / 1 - 0, round, clamp to the int8 range)."""
+    raw = tensor.raw_data
+    if raw.dtype == torch.int8:
+        return raw
+    one = torch.ones(1, dtype=torch.float32, device=raw.device)
+    return ops.quantize_by_tile(raw, one, raw.shape, 8, torch.int8)
+
+
+def fused_linear(input: QuantizedTensor, weight: QuantizedTensor, bias: Any = None, *, output_quantizer: Any = None, strict_quantization: bool | None = None) -> torch.Tensor:
+    if strict_quantization and output_quantizer is None:
+        raise QuantizationError("'output_quantizer' must be provided if strict_quantization=True")
+    xp, wp = input.quantization_context.quantization_params, weight.quantization_context.quantization_params
+    deq = xp.dequantize_dtype or torch.get_default_dtype()
+    if isinstance(bias, QuantizedTensor):
+        bias = bias.dequantize()
+    out = ops.linear_w8a8(
+        _int8_codes(input), _int8_codes(weight),
+        x_scale=torch.as_tensor(xp.scale, device=input.device), x_offset=None if xp.offset is None else torch.as_tensor(xp.offset, device=input.device),
+        w_scale=torch.as_tensor(wp.scale, device=weight.device), w_offset=None if wp.offset is None else torch.as_tensor(wp.offset, device=weight.device),
+        bias=bias, out_dtype=deq,
+    )
+    return output_quantizer(out) if output_quantizer is not None else out
+
+
+fused_linear_predicate = Predicate(_supported)
+_registration = register("linear", fused_linear_predicate, fused_linear)

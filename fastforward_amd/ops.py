@@ -1,0 +1,431 @@
+"""Tensor-level entry points of the hot path: torch tensors in, C-ABI calls out.
+
+These functions are the bodies of the torch custom ops ``fastforward_amd::quantize_by_tile``,
+``dequantize_by_tile``, ``quantize_dynamic_by_tile`` and ``quantize_by_tile_backward`` — the same
+four schemas the reference registers under ``fastforward::`` (reference:
+src/fastforward/quantization/_quantizer_impl.py:144-285) — plus the reduction / parameter / packing /
+linear kernels the reference expresses as ATen chains. Every call is one enqueue on torch's current
+HIP stream through the C ABI of ``include/ffq.h``: no host synchronisation, no hidden allocation in
+the library (outputs and scratch are torch allocations), legal under hipGraph capture.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+from typing import Sequence
+
+import torch
+
+from fastforward_amd import _native
+from fastforward_amd._cabi import FLAG_INF, FLAG_NAN, DType, Tiling
+from fastforward_amd.exceptions import BackendError
+
+__all__ = [
+    "quantize_by_tile",
+    "dequantize_by_tile",
+    "quantize_dynamic_by_tile",
+    "quantize_by_tile_backward",
+    "minmax_by_tile",
+    "parameters_for_range",
+    "pack_int4",
+    "unpack_int4",
+    "linear_w8a8",
+    "FLAG_INF",
+    "FLAG_NAN",
+]
+
+_TAGS: dict[torch.dtype, int] = {
+    torch.float32: DType.F32,
+    torch.bfloat16: DType.BF16,
+    torch.float16: DType.F16,
+    torch.float64: DType.F64,
+    torch.int8: DType.I8,
+    torch.int16: DType.I16,
+    torch.int32: DType.I32,
+    torch.int64: DType.I64,
+    torch.uint8: DType.U8,
+}
+_DTYPES = {int(tag): dtype for dtype, tag in _TAGS.items()}
+
+
+def _tag(dtype: torch.dtype) -> int:
+    try:
+        return int(_TAGS[dtype])
+    except KeyError:
+        raise NotImplementedError(f"fastforward_amd: dtype {dtype} is not supported by the HIP backend") from None
+
+
+def _prepare(*tensors: torch.Tensor | None):
+    """Check that all tensors live where the loaded backend computes; return (lib, stream)."""
+    lib = _native.library()
+    device = None
+    for t in tensors:
+        if t is None:
+            continue
+        if device is None:
+            device = t.device
+        elif t.device != device:
+            raise RuntimeError(
+                f"Expected all tensors to be on the same device, but found at least two devices, {device} and {t.device}!"
+            )
+    assert device is not None
+    if lib.is_device:
+        if device.type != "cuda":
+            raise BackendError(
+                f"fastforward_amd runs on the HIP device only (tensor on '{device}'); there is no CPU "
+                "implementation. Move the tensors to 'cuda'."
+            )
+        stream = torch.cuda.current_stream(device).cuda_stream
+    else:  # the CPU oracle, injected by the test-suite only
+        if device.type != "cpu":
+            raise BackendError("the injected oracle backend computes on host memory only")
+        stream = None
+    return lib, stream
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _tile_of(data: torch.Tensor, tile_size: Sequence[int]) -> Tiling:
+    return Tiling.make(tuple(data.shape), tuple(int(v) for v in tile_size))
+
+
+def _flat(t: torch.Tensor | None) -> torch.Tensor | None:
+    if t is None:
+        return None
+    return t.detach().reshape(-1).contiguous()
+
+
+def quantize_by_tile(
+    data: torch.Tensor,
+    scale: torch.Tensor,
+    tile_size: Sequence[int],
+    num_bits: float,
+    output_dtype: torch.dtype | None,
+    offset: torch.Tensor | None = None,
+) -> torch.Tensor:
+    """A1 — ``fastforward::quantize_by_tile`` (reference _quantizer_impl.py:144-169)."""
+    data_c = data.detach().contiguous()
+    scale_c, offset_c = _flat(scale), _flat(offset)
+    lib, stream = _prepare(data_c, scale_c, offset_c)
+    tiling = _tile_of(data_c, tile_size)
+    if output_dtype is None:
+        # `output_dtype or result.dtype`: the dtype the eager chain ends in             (:164)
+        div = lib.ffq_promote_types(_tag(data_c.dtype), _tag(scale_c.dtype))
+        if div not in (DType.F32, DType.BF16, DType.F16, DType.F64):
+            div = DType.F32
+        sub = lib.ffq_promote_types(div, _tag((offset_c if offset_c is not None else scale_c).dtype))
+        output_dtype = _DTYPES[sub]
+    out = torch.empty(data_c.shape, dtype=output_dtype, device=data_c.device)
+    lib.check(
+        lib.ffq_quantize_by_tile(
+            _ptr(data_c), _tag(data_c.dtype), _ptr(scale_c), _tag(scale_c.dtype), scale_c.numel(),
+            _ptr(offset_c), _tag(offset_c.dtype) if offset_c is not None else 0,
+            offset_c.numel() if offset_c is not None else 0,
+            ctypes.byref(tiling), float(num_bits), _ptr(out), _tag(output_dtype), stream,
+        )
+    )
+    return out
+
+
+def dequantize_by_tile(
+    data: torch.Tensor,
+    scale: torch.Tensor,
+    tile_size: Sequence[int],
+    offset: torch.Tensor | None = None,
+    output_dtype: torch.dtype | None = None,
+) -> torch.Tensor:
+    """A2 — ``fastforward::dequantize_by_tile`` (reference _quantizer_impl.py:172-190)."""
+    data_c = data.detach().contiguous()
+    scale_c, offset_c = _flat(scale), _flat(offset)
+    lib, stream = _prepare(data_c, scale_c, offset_c)
+    tiling = _tile_of(data_c, tile_size)
+    if output_dtype is None:
+        tag = lib.ffq_dequantize_result_dtype(
+            _tag(data_c.dtype), _tag(scale_c.dtype),
+            _tag(offset_c.dtype) if offset_c is not None else 0, int(offset_c is not None),
+        )
+        output_dtype = _DTYPES[tag]
+    out = torch.empty(data_c.shape, dtype=output_dtype, device=data_c.device)
+    lib.check(
+        lib.ffq_dequantize_by_tile(
+            _ptr(data_c), _tag(data_c.dtype), _ptr(scale_c), _tag(scale_c.dtype), scale_c.numel(),
+            _ptr(offset_c), _tag(offset_c.dtype) if offset_c is not None else 0,
+            offset_c.numel() if offset_c is not None else 0,
+            ctypes.byref(tiling), _ptr(out), _tag(output_dtype), stream,
+        )
+    )
+    return out
+
+
+def _workspace(nbytes: int, device: torch.device) -> torch.Tensor | None:
+    if nbytes <= 0:
+        return None
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def quantize_dynamic_by_tile(
+    data: torch.Tensor,
+    tile_size: Sequence[int],
+    num_bits: float,
+    symmetric: bool,
+    allow_one_sided: bool,
+    output_dtype: torch.dtype | None,
+) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """A3 — ``fastforward::quantize_dynamic_by_tile`` (reference _quantizer_impl.py:243-285)."""
+    data_c = data.detach().contiguous()
+    lib, stream = _prepare(data_c)
+    tiling = _tile_of(data_c, tile_size)
+    ntiles = lib.ffq_num_tiles(ctypes.byref(tiling))
+    if ntiles < 0:
+        lib.check(-ntiles)
+    if output_dtype is None:
+        output_dtype = data_c.dtype if data_c.dtype in (torch.float32, torch.float64) else torch.float32
+    out = torch.empty(data_c.shape, dtype=output_dtype, device=data_c.device)
+    scale = torch.empty(ntiles, dtype=torch.float32, device=data_c.device)
+    offset = torch.empty(ntiles, dtype=torch.float32, device=data_c.device)
+    nbytes = lib.ffq_quantize_dynamic_workspace_bytes(ctypes.byref(tiling), _tag(data_c.dtype))
+    ws = _workspace(nbytes, data_c.device)
+    lib.check(
+        lib.ffq_quantize_dynamic_by_tile(
+            _ptr(data_c), _tag(data_c.dtype), ctypes.byref(tiling), float(num_bits), int(symmetric),
+            int(allow_one_sided), _ptr(out), _tag(output_dtype), _ptr(scale), _ptr(offset), _ptr(ws), nbytes, stream,
+        )
+    )
+    return out, scale, offset
+
+
+def quantize_by_tile_backward(
+    data: torch.Tensor,
+    output_grad: torch.Tensor,
+    scale: torch.Tensor,
+    tile_size: Sequence[int],
+    num_bits: float,
+    offset: torch.Tensor | None = None,
+) -> list[torch.Tensor]:
+    """A8 — ``fastforward::quantize_by_tile_backward`` (reference _quantizer_impl.py:193-237).
+
+    Not on the forward/calibration path this package accelerates: kept as a
+    composition of device tensor ops behind the reference's schema so autograd keeps working; a HIP
+    kernel is listed under "next" in DESIGN.md. Gradient formulas: clipped elements pass no data
+    gradient; d/dscale is (round(u) - u) inside the grid and the clip bound (+offset) outside;
+    d/doffset is scale * grad on clipped elements only.
+    """
+    from fastforward_amd.quantization.tiled_tensor import rows_to_tiles, tiles_to_rows
+
+    param_shape = scale.shape
+    s = scale.reshape(-1)
+    o = torch.round(offset.reshape(-1)) if offset is not None else torch.zeros_like(s)
+    tile = torch.Size(tile_size)
+    lo = -(2 ** (num_bits - 1))
+    hi = -lo - 1
+    rows = tiles_to_rows(data, tile)
+    grows = tiles_to_rows(output_grad, tile)
+    u = rows / s[:, None] - o[:, None]
+    q = torch.round(u)
+    below, above = q < lo, q > hi
+    clipped = below | above
+    dinput = rows_to_tiles(torch.where(clipped, torch.zeros_like(grows), grows), data.shape, tile)
+    if offset is None:
+        doffset = torch.Tensor()
+    else:
+        doffset = torch.where(clipped, s[:, None] * grows, torch.zeros_like(grows)).sum(1).reshape(param_shape)
+    bound = torch.where(below, s.new_tensor([lo]), s.new_tensor([hi])) + o[:, None].to(s.dtype)
+    dscale = torch.where(clipped, bound, (q - u).to(s.dtype)) * grows
+    return [dinput, dscale.sum(1).reshape(param_shape), doffset]
+
+
+def minmax_by_tile(
+    data: torch.Tensor,
+    tile_size: Sequence[int],
+    running_min: torch.Tensor | None = None,
+    running_max: torch.Tensor | None = None,
+    status_flags: torch.Tensor | None = None,
+) -> tuple[torch.Tensor, torch.Tensor]:
+    """A4 — per-tile (min, max) of `data` in the data dtype (reference minmax.py:227-237).
+
+    With `running_min` / `running_max` given they are updated IN PLACE (running min / running max)
+    and returned. `status_flags` (int32[1] on the data's device) is OR-ed with FLAG_INF / FLAG_NAN
+    for this batch so the caller can decide when to look at it; nothing here waits for the device.
+    """
+    data_c = data.detach().contiguous()
+    lib, stream = _prepare(data_c, running_min, running_max, status_flags)
+    tiling = _tile_of(data_c, tile_size)
+    ntiles = lib.ffq_num_tiles(ctypes.byref(tiling))
+    if ntiles < 0:
+        lib.check(-ntiles)
+    accumulate = running_min is not None
+    if accumulate:
+        assert running_max is not None
+        mn, mx = running_min, running_max
+        if mn.numel() != ntiles or mx.numel() != ntiles or mn.dtype != data_c.dtype or mx.dtype != data_c.dtype:
+            raise RuntimeError(
+                f"running min/max must hold {ntiles} values of dtype {data_c.dtype}, got "
+                f"{mn.numel()} x {mn.dtype}"
+            )
+        if not (mn.is_contiguous() and mx.is_contiguous()):
+            raise RuntimeError("running min/max must be contiguous")
+    else:
+        mn = torch.empty(ntiles, dtype=data_c.dtype, device=data_c.device)
+        mx = torch.empty(ntiles, dtype=data_c.dtype, device=data_c.device)
+    nbytes = lib.ffq_minmax_workspace_bytes(ctypes.byref(tiling), _tag(data_c.dtype))
+    ws = _workspace(nbytes, data_c.device)
+    lib.check(
+        lib.ffq_minmax_by_tile(
+            _ptr(data_c), _tag(data_c.dtype), ctypes.byref(tiling), _ptr(mn), _ptr(mx), int(accumulate),
+            _ptr(status_flags), _ptr(ws), nbytes, stream,
+        )
+    )
+    return mn, mx
+
+
+def parameters_for_range(
+    min_range: torch.Tensor,
+    max_range: torch.Tensor,
+    num_bits: float,
+    symmetric: bool,
+    allow_one_sided: bool,
+    scale_out: torch.Tensor | None = None,
+    offset_out: torch.Tensor | None = None,
+    want_offset: bool = True,
+) -> tuple[torch.Tensor, torch.Tensor | None]:
+    """A5 on the device — see :func:`fastforward_amd.quantization.affine.parameters_for_range`.
+
+    Writes into `scale_out` / `offset_out` when given (the quantizer's own parameters), else into
+    fresh fp32 tensors. When the symmetric two-sided branch is taken the offset output holds zeros
+    (the reference returns None there and its range setter fills the buffer with 0).
+    """
+    mn, mx = _flat(min_range), _flat(max_range)
+    if mn.dtype != mx.dtype:
+        common = torch.promote_types(mn.dtype, mx.dtype)
+        mn, mx = mn.to(common), mx.to(common)
+    lib, stream = _prepare(mn, mx, scale_out, offset_out)
+    n = mn.numel()
+    if mx.numel() != n:
+        raise RuntimeError(f"min_range and max_range must have the same number of elements ({n} vs {mx.numel()})")
+    if scale_out is None:
+        scale_out = torch.empty(n, dtype=torch.float32, device=mn.device)
+    if offset_out is None and want_offset:
+        offset_out = torch.empty(n, dtype=torch.float32, device=mn.device)
+    for name, t in (("scale", scale_out), ("offset", offset_out)):
+        if t is not None and (t.numel() != n or not t.is_contiguous()):
+            raise RuntimeError(f"{name} output must be contiguous with {n} elements, got {tuple(t.shape)}")
+    lib.check(
+        lib.ffq_parameters_for_range(
+            _ptr(mn), _ptr(mx), _tag(mn.dtype), n, float(num_bits), int(symmetric), int(allow_one_sided),
+            _ptr(scale_out), _tag(scale_out.dtype), _ptr(offset_out),
+            _tag(offset_out.dtype) if offset_out is not None else 0, stream,
+        )
+    )
+    return scale_out, offset_out
+
+
+def pack_int4(codes: torch.Tensor, block: int = 32) -> torch.Tensor:
+    """A7 — pack codes in [-8, 7] two per byte, GGUF Q4_0 nibble order (reference _packing.py:44-53)."""
+    codes_c = codes.detach().contiguous()
+    lib, stream = _prepare(codes_c)
+    n = codes_c.numel()
+    out = torch.empty(n // 2, dtype=torch.uint8, device=codes_c.device)
+    lib.check(lib.ffq_pack_int4(_ptr(codes_c), _tag(codes_c.dtype), n, int(block), _ptr(out), stream))
+    return out
+
+
+def unpack_int4(packed: torch.Tensor, shape: Sequence[int], dtype: torch.dtype = torch.int8, block: int = 32) -> torch.Tensor:
+    """Inverse of :func:`pack_int4`: ``unpack_int4(pack_int4(q), q.shape, q.dtype) == q``."""
+    packed_c = packed.detach().contiguous()
+    lib, stream = _prepare(packed_c)
+    out = torch.empty(tuple(shape), dtype=dtype, device=packed_c.device)
+    if out.numel() != packed_c.numel() * 2:
+        raise ValueError(f"shape {tuple(shape)} does not hold {packed_c.numel() * 2} codes")
+    lib.check(lib.ffq_unpack_int4(_ptr(packed_c), out.numel(), int(block), _ptr(out), _tag(dtype), stream))
+    return out
+
+
+def linear_w8a8(
+    x_codes: torch.Tensor,
+    w_codes: torch.Tensor,
+    x_scale: torch.Tensor,
+    x_offset: torch.Tensor | None,
+    w_scale: torch.Tensor,
+    w_offset: torch.Tensor | None,
+    bias: torch.Tensor | None = None,
+    out_dtype: torch.dtype = torch.bfloat16,
+    out_scale: torch.Tensor | None = None,
+    out_offset: torch.Tensor | None = None,
+    out_num_bits: float = 8.0,
+) -> torch.Tensor:
+    """A6 — int8 codes in, real-valued (or re-quantized) linear output out.
+
+    `x_codes` is [..., K] int8, `w_codes` is [N, K] int8. Scales/offsets are fp32 with one entry
+    (per-tensor) or one per row (per-token for x, per-output-channel for w).
+    """
+    if x_codes.dtype != torch.int8 or w_codes.dtype != torch.int8:
+        raise TypeError("linear_w8a8 expects int8 codes")
+    xc = x_codes.detach().contiguous()
+    wc = w_codes.detach().contiguous()
+    K = xc.shape[-1]
+    N = wc.shape[0]
+    M = xc.numel() // K if K else 0
+    if wc.dim() != 2 or wc.shape[1] != K:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({M}x{K} and {tuple(wc.shape)}^T)")
+
+    def f32(t: torch.Tensor | None) -> torch.Tensor | None:
+        return None if t is None else t.detach().reshape(-1).to(torch.float32).contiguous()
+
+    xs, xo, ws_, wo, os_, oo = f32(x_scale), f32(x_offset), f32(w_scale), f32(w_offset), f32(out_scale), f32(out_offset)
+    bias_c = None if bias is None else bias.detach().contiguous()
+    lib, stream = _prepare(xc, wc, xs, xo, ws_, wo, bias_c, os_, oo)
+    x_per_row = int(xs.numel() != 1)
+    w_per_row = int(ws_.numel() != 1)
+    if x_per_row and xs.numel() != M:
+        raise RuntimeError(f"activation scale must have 1 or {M} entries, got {xs.numel()}")
+    if w_per_row and ws_.numel() != N:
+        raise RuntimeError(f"weight scale must have 1 or {N} entries, got {ws_.numel()}")
+    out = torch.empty((*xc.shape[:-1], N), dtype=out_dtype, device=xc.device)
+    nbytes = lib.ffq_linear_w8a8_workspace_bytes(M, N, K)
+    ws = _workspace(nbytes, xc.device)
+    lib.check(
+        lib.ffq_linear_w8a8(
+            _ptr(xc), _ptr(wc), _ptr(xs), _ptr(xo), x_per_row, _ptr(ws_), _ptr(wo), w_per_row,
+            _ptr(bias_c), _tag(bias_c.dtype) if bias_c is not None else 0, _ptr(out), _tag(out_dtype),
+            _ptr(os_), _ptr(oo), float(out_num_bits), M, N, K, _ptr(ws), nbytes, stream,
+        )
+    )
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# torch custom-op registration: same four schemas as the reference's `fastforward::` ops, in this
+# package's own namespace (defining `fastforward::*` twice in one process is an error).
+# ---------------------------------------------------------------------------------------------
+_LIBRARY = torch.library.Library("fastforward_amd", "DEF")
+_LIBRARY.define(
+    "quantize_by_tile(Tensor data, Tensor scale, SymInt[] tile_size, float num_bits, "
+    "ScalarType? output_dtype, Tensor? offset=None) -> Tensor"
+)
+_LIBRARY.define(
+    "dequantize_by_tile(Tensor data, Tensor scale, SymInt[] tile_size, Tensor? offset=None, "
+    "ScalarType? output_dtype=None) -> Tensor"
+)
+_LIBRARY.define(
+    "quantize_dynamic_by_tile(Tensor data, SymInt[] tile_size, float num_bits, bool symmetric, "
+    "bool allow_one_sided, ScalarType? output_dtype) -> (Tensor, Tensor, Tensor)"
+)
+_LIBRARY.define(
+    "quantize_by_tile_backward(Tensor data, Tensor output_grad, Tensor scale, SymInt[] tile_size, "
+    "float num_bits, Tensor? offset=None) -> Tensor[]"
+)
+_LIBRARY.impl("quantize_by_tile", quantize_by_tile, "CompositeExplicitAutograd")
+_LIBRARY.impl("dequantize_by_tile", dequantize_by_tile, "CompositeExplicitAutograd")
+_LIBRARY.impl("quantize_dynamic_by_tile", quantize_dynamic_by_tile, "CompositeExplicitAutograd")
+_LIBRARY.impl("quantize_by_tile_backward", quantize_by_tile_backward, "CompositeExplicitAutograd")
+
+
+def _meta_like(data: torch.Tensor, *_a: object, **_k: object) -> torch.Tensor:
+    return torch.empty_like(data)
+
+
+_LIBRARY.impl("quantize_by_tile", _meta_like, "Meta")
+_LIBRARY.impl("dequantize_by_tile", _meta_like, "Meta")

@@ -1,0 +1,196 @@
+/*
+ * ffq.h — C ABI of the MI355X-native fake-quantization backend.
+ *
+ * This is the drop-in boundary for ONE hot path of Qualcomm-AI-research/fastforward:
+ * affine quantize / dequantize by tile, the RunningMinMax reduction, range -> (scale, offset),
+ * sub-byte packing, and the W8A8 linear. The reference exposes this path as four torch custom
+ * ops in the `fastforward::` namespace plus one dispatcher hook; each entry point below names
+ * the reference interface (file:line under the reference's `src/fastforward/`) it replaces.
+ *
+ * Two libraries export exactly this ABI:
+ *   - libffq_hip.so    (fastforward_amd/csrc, hand-written HIP for gfx950) — pointers are DEVICE
+ *                      pointers, `stream` is a hipStream_t. This is the product.
+ *   - libffq_oracle.so (oracle/, plain C)                                  — pointers are HOST
+ *                      pointers, `stream` is ignored. This is test infrastructure only.
+ *
+ * Conventions
+ *   - All tensors are dense, row-major ("contiguous"), described by dtype tags + ffq_tiling.
+ *   - Functional: inputs are never written, outputs are caller-allocated, same numel as `data`.
+ *   - Nothing here allocates, synchronises or reads back: every call is a pure enqueue on
+ *     `stream` and is therefore legal inside hipGraph capture. Scratch memory is passed in by the
+ *     caller (`workspace`), sized by the matching *_workspace_bytes() query.
+ *   - Every function returns an ffq_status; ffq_last_error() gives a thread-local message.
+ *   - Parameters (scale/offset) are indexed by tile in the row order defined by the reference's
+ *     `tiles_to_rows` (quantization/tiled_tensor.py:71-98): tile-grid index row-major.
+ */
+#ifndef FFQ_H
+#define FFQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFQ_MAX_DIMS 8
+#define FFQ_ABI_VERSION 1
+
+typedef enum ffq_status {
+  FFQ_OK = 0,
+  FFQ_ERR_TILE_RANK = 1,   /* -> ValueError, tiled_tensor.py:24-29 (rank mismatch)              */
+  FFQ_ERR_TILE_DIVIDE = 2, /* -> ValueError, tiled_tensor.py:31-42 (tile does not divide shape) */
+  FFQ_ERR_PARAM_NUMEL = 3, /* -> RuntimeError, broadcast failure of scale[:, None]
+                                 (_quantizer_impl.py:161; tests/nn/test_linear_quantizer.py:168-186) */
+  FFQ_ERR_PRECISION = 4,   /* -> RuntimeError, _quantizer_impl.py:165-167                       */
+  FFQ_ERR_EMPTY = 5,       /* -> QuantizationError, _quantizer_impl.py:259-264                  */
+  FFQ_ERR_DTYPE = 6,       /* -> NotImplementedError: dtype combination not built               */
+  FFQ_ERR_ARG = 7,         /* -> ValueError: null pointer, bad enum, bad size                   */
+  FFQ_ERR_WORKSPACE = 8,   /* -> RuntimeError: workspace too small                              */
+  FFQ_ERR_LAUNCH = 9,      /* -> RuntimeError: HIP runtime reported an error                    */
+  FFQ_ERR_PARAM_ROWS = 10  /* -> ValueError: one tile but several parameters; the eager chain
+                                 broadcasts rows [1,L] against scale [P,1] and rows_to_tiles then
+                                 rejects the [P,L] result (tiled_tensor.py:128-131)             */
+} ffq_status;
+
+/* Element types. Values are part of the ABI. */
+typedef enum ffq_dtype {
+  FFQ_F32 = 0,
+  FFQ_BF16 = 1,
+  FFQ_F16 = 2,
+  FFQ_F64 = 3,
+  FFQ_I8 = 4,
+  FFQ_I16 = 5,
+  FFQ_I32 = 6,
+  FFQ_I64 = 7,
+  FFQ_U8 = 8
+} ffq_dtype;
+
+/*
+ * Tile layout: `shape` is the data shape, `tile` the parameter-sharing tile
+ * (Granularity.tile_size, quantization/granularity.py:52-62). tile[i] must divide shape[i].
+ * ndim == 0 denotes a scalar (one tile of one element).
+ */
+typedef struct ffq_tiling {
+  int32_t ndim;
+  int64_t shape[FFQ_MAX_DIMS];
+  int64_t tile[FFQ_MAX_DIMS];
+} ffq_tiling;
+
+/* Bits written into the int32 `status_flags` word by ffq_minmax_by_tile. */
+#define FFQ_FLAG_INF 1 /* a per-tile min or max is +-Inf (range_setting/minmax.py:233-234) */
+#define FFQ_FLAG_NAN 2 /* a per-tile min or max is NaN (informational)                    */
+
+int ffq_abi_version(void);
+const char* ffq_last_error(void);
+/* "hip:gfx950" for the product library, "oracle:c" for the oracle. */
+const char* ffq_backend_name(void);
+
+/* Number of tiles (= number of scale/offset entries); negative ffq_status on a bad tiling. */
+int64_t ffq_num_tiles(const ffq_tiling* tiling);
+
+/* can_support_bitwidth, _quantizer_impl.py:44-75. Returns 1/0. */
+int ffq_can_support_bitwidth(int dtype, double num_bits);
+
+/* torch.result_type for two dimensioned tensors (the promotion the eager chain performs). */
+int ffq_promote_types(int a, int b);
+
+/*
+ * A1 — fastforward::quantize_by_tile, _quantizer_impl.py:144-169 (called from
+ * affine/_autograd.py:86).
+ *   q = cast<out_dt>( clamp( round_half_even( x / s_t - round_half_even(o_t) ), -2^(b-1), 2^(b-1)-1 ) )
+ * Arithmetic follows the eager chain's dtype promotion: the division is evaluated and rounded in
+ * result_type(data, scale), the subtraction in result_type(that, offset). `offset == NULL` means
+ * zeros_like(scale) (_infer_offset, :140-141). scale_numel / offset_numel must equal the number
+ * of tiles, or 1 (the eager chain broadcasts `scale[:, None]` over the rows).
+ */
+int ffq_quantize_by_tile(const void* data, int data_dt, const void* scale, int scale_dt,
+                         int64_t scale_numel, const void* offset, int offset_dt,
+                         int64_t offset_numel, const ffq_tiling* tiling, double num_bits, void* out,
+                         int out_dt, void* stream);
+
+/*
+ * A2 — fastforward::dequantize_by_tile, _quantizer_impl.py:172-190 (affine/_autograd.py:148).
+ *   x^ = cast<out_dt>( (q + round_half_even(o_t)) * s_t )
+ * The add is rounded in result_type(data, offset), the multiply in result_type(that, scale).
+ */
+int ffq_dequantize_by_tile(const void* data, int data_dt, const void* scale, int scale_dt,
+                           int64_t scale_numel, const void* offset, int offset_dt,
+                           int64_t offset_numel, const ffq_tiling* tiling, void* out, int out_dt,
+                           void* stream);
+
+/* The dtype dequantize_by_tile produces when output_dtype is None (_quantizer_impl.py:187-189). */
+int ffq_dequantize_result_dtype(int data_dt, int scale_dt, int offset_dt, int has_offset);
+
+/*
+ * A4 — the reduction inside RunningMinMaxEstimator.estimate_step, range_setting/minmax.py:227-237
+ * (also the first half of quantize_dynamic_by_tile, _quantizer_impl.py:257-258).
+ * Per-tile min and max of `data`, NaN-propagating like torch.min/torch.max, written in the DATA
+ * dtype (the reference keeps them in data dtype, minmax.py:209-213). With accumulate != 0 the
+ * result is merged into the existing contents (running min / running max, :236-237).
+ * `status_flags` (nullable, one int32) is OR-ed with FFQ_FLAG_* for THIS batch's per-tile
+ * values, so the caller can raise NotImplementedError("Infinite") without a sync per step.
+ */
+size_t ffq_minmax_workspace_bytes(const ffq_tiling* tiling, int data_dt);
+int ffq_minmax_by_tile(const void* data, int data_dt, const ffq_tiling* tiling, void* min_inout,
+                       void* max_inout, int accumulate, int32_t* status_flags, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/*
+ * A5 — parameters_for_range, quantization/affine/range.py:54-122, fused with the copy performed
+ * by the LinearQuantizer.quantization_range setter, nn/linear_quantizer.py:350-357.
+ * min/max (dtype `range_dt`, `ntiles` entries) are cast to fp32 (:90); the one-sided test is
+ * GLOBAL over all tiles (:100) and is decided on the device. scale_out / offset_out are written
+ * in their own dtypes. When the symmetric two-sided branch is taken (reference returns
+ * offset=None) and offset_out != NULL it is filled with 0 (linear_quantizer.py:353-357).
+ */
+int ffq_parameters_for_range(const void* min_range, const void* max_range, int range_dt,
+                             int64_t ntiles, double num_bits, int symmetric, int allow_one_sided,
+                             void* scale_out, int scale_dt, void* offset_out, int offset_dt,
+                             void* stream);
+
+/*
+ * A3 — fastforward::quantize_dynamic_by_tile, _quantizer_impl.py:243-285 (affine/_autograd.py:121).
+ * = A4 (fresh min/max) + A5 + round(offset) + A1, returning (q, scale, offset) with fp32 params.
+ * Empty input -> FFQ_ERR_EMPTY.
+ */
+size_t ffq_quantize_dynamic_workspace_bytes(const ffq_tiling* tiling, int data_dt);
+int ffq_quantize_dynamic_by_tile(const void* data, int data_dt, const ffq_tiling* tiling,
+                                 double num_bits, int symmetric, int allow_one_sided, void* out,
+                                 int out_dt, float* scale_out, float* offset_out, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
+/*
+ * A7 — sub-byte storage. The reference keeps 4-bit codes unpacked; its only packing convention is
+ * GGUF Q4_0 (export/stages/gguf/_packing.py:44-53): within each block of `block` codes,
+ *   byte[j] = (code[j] + 8) | ((code[j + block/2] + 8) << 4),  j in [0, block/2).
+ * `codes` holds integer-valued elements in [-8, 7] in any supported dtype; numel % block == 0,
+ * block even. unpack(pack(q)) == q exactly.
+ */
+int ffq_pack_int4(const void* codes, int codes_dt, int64_t numel, int64_t block, uint8_t* packed,
+                  void* stream);
+int ffq_unpack_int4(const uint8_t* packed, int64_t numel, int64_t block, void* codes_out,
+                    int codes_dt, void* stream);
+
+/*
+ * A6 — the quantized linear that replaces `fallback.linear`, _gen/fallback.py:77-112 (reached via
+ * ff.nn.functional.linear, _gen/operators.py:79-106, from QuantizedLinear.forward,
+ * nn/linear.py:32-39). Integer codes in, real-valued output out:
+ *   y[m,n] = sx[m'] * sw[n'] * sum_k (xq[m,k] + ox[m']) * (wq[n,k] + ow[n'])  (+ bias[n])
+ * with ox/ow = round_half_even(offset) (A2), m' = m if x_per_row else 0, n' likewise.
+ * The contraction runs on int8 MFMA with int32 accumulation; the zero-point terms use row sums.
+ * If out_scale != NULL the result is re-quantized (A1, per-tensor) into `out` instead
+ * (the `output_quantizer` of fallback.py:110-111), else `out` holds y in out_dt (bf16/f16/f32).
+ * Tolerance vs the reference's bf16 eager path is stated in tests/test_linear_gpu.py.
+ */
+size_t ffq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, const float* x_offset,
+                    int x_per_row, const float* w_scale, const float* w_offset, int w_per_row,
+                    const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
+                    const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFQ_H */

@@ -1,0 +1,673 @@
+/*
+ * ffq_oracle.c — CPU restatement of the reference's affine fake-quantization path, in plain C.
+ *
+ * TEST INFRASTRUCTURE ONLY. This file is the checker the HIP kernels are compared against; it is
+ * never shipped, never linked into fastforward_amd, and never a fallback. Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * It exports the ABI of include/ffq.h with HOST pointers (stream is ignored). Each function
+ * follows the reference's eager chain step by step, including the intermediate roundings the
+ * chain performs because every ATen op materialises its result in the promoted dtype. Citations
+ * are file:line under /root/reference/src/fastforward/.
+ *
+ * Parity pin: tests/test_oracle_golden.py checks this file against the fixtures in tests/golden/,
+ * which tests/golden/gen_golden.py produced by importing the reference itself (CPU eager) in the
+ * build container, and against the known-answer vectors the reference's own tests hold
+ * (tests/nn/test_linear_quantizer.py:20-72,189-219,400-418; tests/quantization/test_tiled_tensor.py;
+ * tests/quantization/affine/test_range.py:10-40; tests/range_setting/test_minmax.py:41-87).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; never -ffast-math).
+ */
+#include "../include/ffq.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static __thread char g_err[512];
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int ffq_abi_version(void) { return FFQ_ABI_VERSION; }
+const char* ffq_last_error(void) { return g_err; }
+const char* ffq_backend_name(void) { return "oracle:c"; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* dtype helpers                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+static int dt_valid(int dt) { return dt >= FFQ_F32 && dt <= FFQ_U8; }
+static int dt_is_float(int dt) { return dt == FFQ_F32 || dt == FFQ_BF16 || dt == FFQ_F16 || dt == FFQ_F64; }
+static size_t dt_size(int dt) {
+  switch (dt) {
+    case FFQ_F32: case FFQ_I32: return 4;
+    case FFQ_BF16: case FFQ_F16: case FFQ_I16: return 2;
+    case FFQ_F64: case FFQ_I64: return 8;
+    default: return 1;
+  }
+}
+
+static float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* bf16 <-> f32: round to nearest even, NaN kept quiet (c10::BFloat16 round_to_nearest_even). */
+static uint16_t f32_to_bf16(float f) {
+  uint32_t u = f32_bits(f);
+  if (f != f) return 0x7FC0;
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf16_to_f32(uint16_t h) { return bits_f32((uint32_t)h << 16); }
+
+/* IEEE binary16 <-> f32, round to nearest even, with subnormals and overflow to inf. */
+static uint16_t f32_to_f16(float f) {
+  uint32_t x = f32_bits(f);
+  uint32_t sign = (x >> 16) & 0x8000u;
+  uint32_t abs = x & 0x7FFFFFFFu;
+  if (abs > 0x7F800000u) return (uint16_t)(sign | 0x7E00u);         /* NaN */
+  if (abs >= 0x47800000u) return (uint16_t)(sign | 0x7C00u);        /* >= 65536 -> inf (incl. inf) */
+  if (abs < 0x38800000u) {                                          /* subnormal half or zero */
+    if (abs < 0x33000000u) return (uint16_t)sign;                   /* < 2^-25 -> 0 */
+    /* value = abs * 2^24 rounded to integer, RNE */
+    float scaled = bits_f32(abs) * 16777216.0f;                      /* exact: power-of-two scale */
+    float r = nearbyintf(scaled);                                   /* RNE in default mode */
+    return (uint16_t)(sign | (uint32_t)r);
+  }
+  uint32_t mant = abs & 0x007FFFFFu;
+  uint32_t exp = (abs >> 23) - 112u;                                 /* rebias 127 -> 15 */
+  uint32_t h = (exp << 10) | (mant >> 13);
+  uint32_t rem = mant & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h += 1u;        /* carries into exponent ok */
+  return (uint16_t)(sign | h);
+}
+static float f16_to_f32(uint16_t h) {
+  uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1Fu;
+  uint32_t mant = h & 0x3FFu;
+  if (exp == 0) {
+    float v = (float)mant * (1.0f / 16777216.0f);                    /* mant * 2^-24 */
+    return bits_f32(sign | f32_bits(v));
+  }
+  if (exp == 31) return bits_f32(sign | 0x7F800000u | (mant << 13));
+  return bits_f32(sign | ((exp + 112u) << 23) | (mant << 13));
+}
+
+/* Load element i of a typed buffer as a double (exact for every supported dtype but I64 > 2^53). */
+static double ld(const void* p, int dt, int64_t i) {
+  switch (dt) {
+    case FFQ_F32: return (double)((const float*)p)[i];
+    case FFQ_BF16: return (double)bf16_to_f32(((const uint16_t*)p)[i]);
+    case FFQ_F16: return (double)f16_to_f32(((const uint16_t*)p)[i]);
+    case FFQ_F64: return ((const double*)p)[i];
+    case FFQ_I8: return (double)((const int8_t*)p)[i];
+    case FFQ_I16: return (double)((const int16_t*)p)[i];
+    case FFQ_I32: return (double)((const int32_t*)p)[i];
+    case FFQ_I64: return (double)((const int64_t*)p)[i];
+    case FFQ_U8: return (double)((const uint8_t*)p)[i];
+  }
+  return 0.0;
+}
+
+/*
+ * Round a value to what a tensor of dtype `dt` can hold. ATen evaluates half/bfloat16 ops in float
+ * ("opmath") and rounds the result once; callers therefore pass a value that was computed in
+ * float for those dtypes (see op2()).
+ */
+static double round_to(double v, int dt) {
+  switch (dt) {
+    case FFQ_F32: return (double)(float)v;
+    case FFQ_BF16: return (double)bf16_to_f32(f32_to_bf16((float)v));
+    case FFQ_F16: return (double)f16_to_f32(f32_to_f16((float)v));
+    default: return v; /* F64, and integer dtypes never appear as a compute stage */
+  }
+}
+
+/* One binary ATen op in dtype `dt`: operands already hold dt-representable values. */
+enum { OP_DIV, OP_SUB, OP_ADD, OP_MUL };
+static double op2(int op, double a, double b, int dt) {
+  if (dt == FFQ_F64) {
+    switch (op) {
+      case OP_DIV: return a / b;
+      case OP_SUB: return a - b;
+      case OP_ADD: return a + b;
+      default: return a * b;
+    }
+  }
+  /* f32 / bf16 / f16: evaluate in float, then round to dt. The volatile stops gcc folding the
+     float op into a double one. */
+  volatile float fa = (float)a, fb = (float)b, r;
+  switch (op) {
+    case OP_DIV: r = fa / fb; break;
+    case OP_SUB: r = fa - fb; break;
+    case OP_ADD: r = fa + fb; break;
+    default: r = fa * fb; break;
+  }
+  return round_to((double)r, dt);
+}
+
+/* tensor.to(dtype) for a value coming from a float compute stage or an integer tensor. */
+static double cast_to(double v, int src_dt, int dst_dt) {
+  (void)src_dt;
+  if (dt_is_float(dst_dt)) return round_to(v, dst_dt);
+  return v;
+}
+
+/*
+ * Store a float-stage value into an output buffer. For integer outputs this is a C cast of an
+ * integer-valued, in-range number; NaN follows the x86 conversion the reference's CPU path
+ * executes (cvttss2si gives INT_MIN; narrower types keep its low bits, i.e. 0).
+ */
+static void st(void* p, int dt, int64_t i, double v) {
+  switch (dt) {
+    case FFQ_F32: ((float*)p)[i] = (float)v; break;
+    case FFQ_BF16: ((uint16_t*)p)[i] = f32_to_bf16((float)v); break;
+    case FFQ_F16: ((uint16_t*)p)[i] = f32_to_f16((float)v); break;
+    case FFQ_F64: ((double*)p)[i] = v; break;
+    case FFQ_I8: ((int8_t*)p)[i] = (v != v) ? 0 : (int8_t)(int64_t)v; break;
+    case FFQ_I16: ((int16_t*)p)[i] = (v != v) ? 0 : (int16_t)(int64_t)v; break;
+    case FFQ_I32: ((int32_t*)p)[i] = (v != v) ? INT32_MIN : (int32_t)(int64_t)v; break;
+    case FFQ_I64: ((int64_t*)p)[i] = (v != v) ? INT64_MIN : (int64_t)v; break;
+    case FFQ_U8: ((uint8_t*)p)[i] = (v != v) ? 0 : (uint8_t)(int64_t)v; break;
+  }
+}
+
+/* torch.result_type for two tensors with dim >= 1 (c10::promoteTypes). */
+int ffq_promote_types(int a, int b) {
+  if (!dt_valid(a) || !dt_valid(b)) return -FFQ_ERR_ARG;
+  if (a == b) return a;
+  int fa = dt_is_float(a), fb = dt_is_float(b);
+  if (fa && !fb) return a;
+  if (fb && !fa) return b;
+  if (fa && fb) {
+    if (a == FFQ_F64 || b == FFQ_F64) return FFQ_F64;
+    if (a == FFQ_F32 || b == FFQ_F32) return FFQ_F32;
+    return FFQ_F32; /* bf16 x f16 */
+  }
+  /* both integer */
+  if (a == FFQ_I64 || b == FFQ_I64) return FFQ_I64;
+  if (a == FFQ_I32 || b == FFQ_I32) return FFQ_I32;
+  if (a == FFQ_I16 || b == FFQ_I16) return FFQ_I16;
+  return FFQ_I16; /* i8 x u8 */
+}
+
+/* can_support_bitwidth, quantization/_quantizer_impl.py:44-75 */
+int ffq_can_support_bitwidth(int dtype, double num_bits) {
+  double avail;
+  switch (dtype) {
+    case FFQ_BF16: avail = 7; break;
+    case FFQ_F16: avail = 10; break;
+    case FFQ_F32: avail = 23; break;
+    case FFQ_F64: avail = 52; break;
+    case FFQ_I8: case FFQ_U8: avail = 8; break;
+    case FFQ_I16: avail = 16; break;
+    case FFQ_I32: avail = 32; break;
+    case FFQ_I64: avail = 64; break;
+    default: return 0;
+  }
+  return (avail + 2) >= num_bits;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* tile layout: quantization/tiled_tensor.py                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* check_tile_compatibility, tiled_tensor.py:19-42 (rank equality is implied by the struct). */
+static int check_tiling(const ffq_tiling* t) {
+  if (!t) return fail(FFQ_ERR_ARG, "tiling is NULL");
+  if (t->ndim < 0 || t->ndim > FFQ_MAX_DIMS)
+    return fail(FFQ_ERR_TILE_RANK, "tiling rank %d outside [0, %d]", t->ndim, FFQ_MAX_DIMS);
+  for (int i = 0; i < t->ndim; ++i) {
+    if (t->shape[i] < 0) return fail(FFQ_ERR_ARG, "negative extent");
+    if (t->tile[i] > 0 && t->shape[i] % t->tile[i] != 0)
+      return fail(FFQ_ERR_TILE_DIVIDE,
+                  "Each dimension of tile_size must divide the corresponding input dimension. Got "
+                  "%lld and %lld for dimension %d.",
+                  (long long)t->shape[i], (long long)t->tile[i], i);
+    if (t->tile[i] <= 0 && t->shape[i] != 0)
+      return fail(FFQ_ERR_TILE_DIVIDE, "tile extent %lld for dimension %d", (long long)t->tile[i], i);
+  }
+  return FFQ_OK;
+}
+
+static int64_t numel_of(const ffq_tiling* t) {
+  int64_t n = 1;
+  for (int i = 0; i < t->ndim; ++i) n *= t->shape[i];
+  return n;
+}
+
+int64_t ffq_num_tiles(const ffq_tiling* t) {
+  int rc = check_tiling(t);
+  if (rc) return -rc;
+  int64_t n = 1;
+  for (int i = 0; i < t->ndim; ++i) {
+    if (t->shape[i] == 0) return 1; /* tiles_to_rows on empty data: reshape(1, 0), :87-88 */
+    n *= t->shape[i] / t->tile[i];
+  }
+  return n;
+}
+
+/*
+ * Row index of every element under tiles_to_rows (tiled_tensor.py:90-98): the data is reshaped to
+ * [n0, t0, n1, t1, ...], permuted to [n0, n1, ..., t0, t1, ...] and flattened to
+ * [num_tiles, tile_numel]; so element (i0, i1, ...) lands in row sum_k (i_k / t_k) * stride_k with
+ * the strides of the row-major tile grid. An odometer walks the elements in memory order.
+ */
+typedef struct {
+  int nd;
+  int64_t idx[FFQ_MAX_DIMS];
+  int64_t gstride[FFQ_MAX_DIMS];
+  const ffq_tiling* t;
+} walker;
+
+static void walker_init(walker* w, const ffq_tiling* t) {
+  w->nd = t->ndim;
+  w->t = t;
+  int64_t s = 1;
+  for (int k = t->ndim - 1; k >= 0; --k) {
+    w->idx[k] = 0;
+    w->gstride[k] = s;
+    s *= t->shape[k] / t->tile[k];
+  }
+}
+static int64_t walker_tile(const walker* w) {
+  int64_t r = 0;
+  for (int k = 0; k < w->nd; ++k) r += (w->idx[k] / w->t->tile[k]) * w->gstride[k];
+  return r;
+}
+static void walker_next(walker* w) {
+  for (int k = w->nd - 1; k >= 0; --k) {
+    if (++w->idx[k] < w->t->shape[k]) return;
+    w->idx[k] = 0;
+  }
+}
+
+/* Broadcast rule of `scale[:, None]` against the [num_tiles, tile_numel] rows. */
+static int check_param_numel(const char* what, int64_t numel, int64_t ntiles) {
+  if (numel == ntiles || numel == 1) return FFQ_OK;
+  if (ntiles == 1)
+    return fail(FFQ_ERR_PARAM_ROWS, "tiled_data is expected to be of size (1, L) but %s has %lld entries",
+                what, (long long)numel);
+  return fail(FFQ_ERR_PARAM_NUMEL,
+              "The size of tensor a (%lld) must match the size of tensor b (%lld) at non-singleton "
+              "dimension 0 (%s vs number of tiles)",
+              (long long)ntiles, (long long)numel, what);
+}
+
+/* torch.round on one element of dtype dt: half-to-even for floats, identity for integers. */
+static double round_half_even(double v, int dt) {
+  if (!dt_is_float(dt)) return v;
+  return nearbyint(v); /* default rounding mode = to nearest even; exact in every float dtype */
+}
+
+/* torch.clamp(x, lo, hi) on a float tensor: NaN propagates (ATen clamp_kernel). */
+static double clamp_nan(double v, double lo, double hi) {
+  if (v != v) return v;
+  if (v < lo) v = lo;
+  if (v > hi) v = hi;
+  return v;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A1: quantize_by_tile_impl, quantization/_quantizer_impl.py:144-169                          */
+/* ------------------------------------------------------------------------------------------ */
+int ffq_quantize_by_tile(const void* data, int data_dt, const void* scale, int scale_dt,
+                         int64_t scale_numel, const void* offset, int offset_dt,
+                         int64_t offset_numel, const ffq_tiling* tiling, double num_bits, void* out,
+                         int out_dt, void* stream) {
+  (void)stream;
+  int rc = check_tiling(tiling);
+  if (rc) return rc;
+  if (!dt_valid(data_dt) || !dt_valid(scale_dt) || !dt_valid(out_dt) || (offset && !dt_valid(offset_dt)))
+    return fail(FFQ_ERR_ARG, "bad dtype tag");
+  int64_t n = numel_of(tiling);
+  int64_t ntiles = ffq_num_tiles(tiling);
+  if (n != 0) { /* an empty tensor broadcasts against anything and comes back empty */
+    if ((rc = check_param_numel("scale", scale_numel, ntiles))) return rc;
+    if (offset && (rc = check_param_numel("offset", offset_numel, ntiles))) return rc;
+  }
+
+  /* offset = round(offset) if given else zeros_like(scale)                      (:140-141,155) */
+  int off_dt = offset ? offset_dt : scale_dt;
+  /* min_threshold = -(2 ** (num_bits - 1)); max_threshold = -min_threshold - 1   (:158-159) */
+  double lo = -pow(2.0, num_bits - 1.0), hi = -lo - 1.0;
+  /* row / scale[:, None] is evaluated in result_type(data, scale); "- offset[:, None]" in
+     result_type(of that, offset)                                                 (:161) */
+  int div_dt = ffq_promote_types(data_dt, scale_dt);
+  if (!dt_is_float(div_dt)) div_dt = FFQ_F32; /* true division of integers yields default float */
+  int sub_dt = ffq_promote_types(div_dt, off_dt);
+  /* output_dtype or result.dtype; the precision guard                            (:164-167) */
+  if (!ffq_can_support_bitwidth(out_dt, num_bits))
+    return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.",
+                out_dt, num_bits);
+  if (n == 0) return FFQ_OK;
+  if (!data || !scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  /* clamp's scalar bounds are converted to the tensor dtype */
+  double lo_c = round_to(lo, sub_dt), hi_c = round_to(hi, sub_dt);
+
+  walker w;
+  walker_init(&w, tiling);
+  for (int64_t i = 0; i < n; ++i, walker_next(&w)) {
+    int64_t t = walker_tile(&w);
+    double x = cast_to(ld(data, data_dt, i), data_dt, div_dt);
+    double s = cast_to(ld(scale, scale_dt, scale_numel == 1 ? 0 : t), scale_dt, div_dt);
+    double q = op2(OP_DIV, x, s, div_dt);
+    double o = offset ? round_half_even(ld(offset, offset_dt, offset_numel == 1 ? 0 : t), offset_dt) : 0.0;
+    q = op2(OP_SUB, cast_to(q, div_dt, sub_dt), cast_to(o, off_dt, sub_dt), sub_dt);
+    q = round_half_even(q, sub_dt);      /* round_ste == torch.round forward, ste.py:96      */
+    q = clamp_nan(q, lo_c, hi_c);        /* torch.clamp                                 (:162) */
+    st(out, out_dt, i, q);               /* result.to(output_dtype)                     (:168) */
+  }
+  return FFQ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A2: dequantize_by_tile_impl, quantization/_quantizer_impl.py:172-190                        */
+/* ------------------------------------------------------------------------------------------ */
+int ffq_dequantize_result_dtype(int data_dt, int scale_dt, int offset_dt, int has_offset) {
+  int off_dt = has_offset ? offset_dt : scale_dt;
+  int add_dt = ffq_promote_types(data_dt, off_dt);
+  if (add_dt < 0) return add_dt;
+  return ffq_promote_types(add_dt, scale_dt);
+}
+
+int ffq_dequantize_by_tile(const void* data, int data_dt, const void* scale, int scale_dt,
+                           int64_t scale_numel, const void* offset, int offset_dt,
+                           int64_t offset_numel, const ffq_tiling* tiling, void* out, int out_dt,
+                           void* stream) {
+  (void)stream;
+  int rc = check_tiling(tiling);
+  if (rc) return rc;
+  if (!dt_valid(data_dt) || !dt_valid(scale_dt) || !dt_valid(out_dt) || (offset && !dt_valid(offset_dt)))
+    return fail(FFQ_ERR_ARG, "bad dtype tag");
+  int64_t n = numel_of(tiling);
+  int64_t ntiles = ffq_num_tiles(tiling);
+  if (n != 0) {
+    if ((rc = check_param_numel("scale", scale_numel, ntiles))) return rc;
+    if (offset && (rc = check_param_numel("offset", offset_numel, ntiles))) return rc;
+  }
+  int off_dt = offset ? offset_dt : scale_dt;
+  /* (row + offset[:, None]) * scale[:, None]                                      (:182) */
+  int add_dt = ffq_promote_types(data_dt, off_dt);
+  int mul_dt = ffq_promote_types(add_dt, scale_dt);
+  if (!dt_is_float(mul_dt)) return fail(FFQ_ERR_DTYPE, "integer-only dequantize is not built");
+  if (n == 0) return FFQ_OK;
+  if (!data || !scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+
+  walker w;
+  walker_init(&w, tiling);
+  for (int64_t i = 0; i < n; ++i, walker_next(&w)) {
+    int64_t t = walker_tile(&w);
+    double q = cast_to(ld(data, data_dt, i), data_dt, add_dt);
+    double o = offset ? round_half_even(ld(offset, offset_dt, offset_numel == 1 ? 0 : t), offset_dt) : 0.0;
+    double v;
+    if (dt_is_float(add_dt)) {
+      v = op2(OP_ADD, q, cast_to(o, off_dt, add_dt), add_dt);
+    } else {
+      v = q + o; /* integer add: exact for the code ranges involved */
+    }
+    double s = cast_to(ld(scale, scale_dt, scale_numel == 1 ? 0 : t), scale_dt, mul_dt);
+    v = op2(OP_MUL, cast_to(v, add_dt, mul_dt), s, mul_dt);
+    st(out, out_dt, i, cast_to(v, mul_dt, out_dt)); /* .to(output_dtype)               (:184-185) */
+  }
+  return FFQ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A4: RunningMinMaxEstimator.estimate_step, range_setting/minmax.py:227-237                   */
+/* ------------------------------------------------------------------------------------------ */
+size_t ffq_minmax_workspace_bytes(const ffq_tiling* tiling, int data_dt) {
+  (void)tiling; (void)data_dt;
+  return 0;
+}
+
+/* torch.min / torch.max (reduction and elementwise) propagate NaN. */
+static double min_nan(double a, double b) { return (a != a || b != b) ? NAN : (b < a ? b : a); }
+static double max_nan(double a, double b) { return (a != a || b != b) ? NAN : (b > a ? b : a); }
+
+static int minmax_core(const void* data, int data_dt, const ffq_tiling* tiling, double* mn, double* mx) {
+  int64_t n = numel_of(tiling);
+  int64_t ntiles = ffq_num_tiles(tiling);
+  for (int64_t t = 0; t < ntiles; ++t) { mn[t] = INFINITY; mx[t] = -INFINITY; }
+  walker w;
+  walker_init(&w, tiling);
+  for (int64_t i = 0; i < n; ++i, walker_next(&w)) {
+    int64_t t = walker_tile(&w);
+    double v = ld(data, data_dt, i);
+    mn[t] = min_nan(mn[t], v);   /* torch.min(reshaped_data, -1).values            (:229) */
+    mx[t] = max_nan(mx[t], v);   /* torch.max(reshaped_data, -1).values            (:230) */
+  }
+  return FFQ_OK;
+}
+
+int ffq_minmax_by_tile(const void* data, int data_dt, const ffq_tiling* tiling, void* min_inout,
+                       void* max_inout, int accumulate, int32_t* status_flags, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  int rc = check_tiling(tiling);
+  if (rc) return rc;
+  if (!dt_valid(data_dt)) return fail(FFQ_ERR_ARG, "bad dtype tag");
+  int64_t n = numel_of(tiling);
+  if (n == 0) return fail(FFQ_ERR_EMPTY, "min/max of an empty tensor");
+  if (!data || !min_inout || !max_inout) return fail(FFQ_ERR_ARG, "NULL buffer");
+  int64_t ntiles = ffq_num_tiles(tiling);
+  double* mn = (double*)malloc(sizeof(double) * (size_t)ntiles * 2);
+  if (!mn) return fail(FFQ_ERR_ARG, "out of memory");
+  double* mx = mn + ntiles;
+  minmax_core(data, data_dt, tiling, mn, mx);
+  int32_t flags = 0;
+  for (int64_t t = 0; t < ntiles; ++t) {
+    /* data_min.isinf().any() or data_max.isinf().any()                            (:233) */
+    if (isinf(mn[t]) || isinf(mx[t])) flags |= FFQ_FLAG_INF;
+    if (mn[t] != mn[t] || mx[t] != mx[t]) flags |= FFQ_FLAG_NAN;
+    double a = mn[t], b = mx[t];
+    if (accumulate) {
+      a = min_nan(ld(min_inout, data_dt, t), a);   /* torch.min(self.min, data_min)  (:236) */
+      b = max_nan(ld(max_inout, data_dt, t), b);   /* torch.max(self.max, data_max)  (:237) */
+    }
+    st(min_inout, data_dt, t, a);
+    st(max_inout, data_dt, t, b);
+  }
+  if (status_flags) *status_flags |= flags;
+  free(mn);
+  return FFQ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A5: parameters_for_range, quantization/affine/range.py:54-122                               */
+/* ------------------------------------------------------------------------------------------ */
+int ffq_parameters_for_range(const void* min_range, const void* max_range, int range_dt,
+                             int64_t ntiles, double num_bits, int symmetric, int allow_one_sided,
+                             void* scale_out, int scale_dt, void* offset_out, int offset_dt,
+                             void* stream) {
+  (void)stream;
+  if (!min_range || !max_range || !scale_out || ntiles <= 0) return fail(FFQ_ERR_ARG, "bad argument");
+  if (!dt_valid(range_dt) || !dt_valid(scale_dt) || (offset_out && !dt_valid(offset_dt)))
+    return fail(FFQ_ERR_ARG, "bad dtype tag");
+  /* min_range.to(float32), max_range.to(float32)                                    (:90) */
+  /* one_sided = min_range.min() >= 0 and allow_one_sided                            (:100) */
+  double gmin = INFINITY;
+  for (int64_t t = 0; t < ntiles; ++t) gmin = min_nan(gmin, (double)(float)ld(min_range, range_dt, t));
+  int one_sided = (gmin >= 0.0) && allow_one_sided;
+  /* int_min = -(2 ** (num_bits - 1)); integer_maximum = -int_min - 1                 (:9-28) */
+  double int_min = -pow(2.0, num_bits - 1.0), int_max = -int_min - 1.0;
+  for (int64_t t = 0; t < ntiles; ++t) {
+    double lo = (double)(float)ld(min_range, range_dt, t);
+    double hi = (double)(float)ld(max_range, range_dt, t);
+    if (symmetric && one_sided) lo = 0.0;                      /* zeros_like(min_range) (:104-105) */
+    if (symmetric && !one_sided) {
+      /* neg_scale = |min| / |int_min|; pos_scale = |max| / |int_max|; max of both    (:107-111) */
+      double neg = op2(OP_DIV, fabs(lo), round_to(fabs(int_min), FFQ_F32), FFQ_F32);
+      double pos = op2(OP_DIV, fabs(hi), round_to(fabs(int_max), FFQ_F32), FFQ_F32);
+      st(scale_out, scale_dt, t, cast_to(max_nan(neg, pos), FFQ_F32, scale_dt));
+      /* offset is None -> the setter fills the buffer with 0   (nn/linear_quantizer.py:353-357) */
+      if (offset_out) st(offset_out, offset_dt, t, 0.0);
+    } else {
+      /* num_steps = 2**num_bits - 1; scale = (max - min) / num_steps, clamped at eps   (:117-121) */
+      double num_steps = pow(2.0, num_bits) - 1.0;
+      double interval = op2(OP_SUB, hi, lo, FFQ_F32);
+      double sc = op2(OP_DIV, interval, round_to(num_steps, FFQ_F32), FFQ_F32);
+      if (sc == sc && sc < (double)FLT_EPSILON) sc = (double)FLT_EPSILON;
+      /* offset = min_range / scale - int_min                                          (:122) */
+      double of = op2(OP_SUB, op2(OP_DIV, lo, sc, FFQ_F32), round_to(int_min, FFQ_F32), FFQ_F32);
+      st(scale_out, scale_dt, t, cast_to(sc, FFQ_F32, scale_dt));
+      if (offset_out) st(offset_out, offset_dt, t, cast_to(of, FFQ_F32, offset_dt));
+    }
+  }
+  return FFQ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A3: quantize_dynamic_by_tile_impl, quantization/_quantizer_impl.py:243-285                  */
+/* ------------------------------------------------------------------------------------------ */
+size_t ffq_quantize_dynamic_workspace_bytes(const ffq_tiling* tiling, int data_dt) {
+  (void)tiling; (void)data_dt;
+  return 0;
+}
+
+int ffq_quantize_dynamic_by_tile(const void* data, int data_dt, const ffq_tiling* tiling,
+                                 double num_bits, int symmetric, int allow_one_sided, void* out,
+                                 int out_dt, float* scale_out, float* offset_out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes;
+  int rc = check_tiling(tiling);
+  if (rc) return rc;
+  int64_t n = numel_of(tiling);
+  /* torch.min over an empty row raises IndexError -> QuantizationError             (:259-264) */
+  if (n == 0) return fail(FFQ_ERR_EMPTY, "Cannot dynamically quantize an empty tensor");
+  if (!scale_out || !offset_out) return fail(FFQ_ERR_ARG, "NULL parameter output");
+  if (!ffq_can_support_bitwidth(out_dt, num_bits))
+    return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.",
+                out_dt, num_bits);
+  int64_t ntiles = ffq_num_tiles(tiling);
+  /* min_range / max_range live in the data dtype                                    (:257-258) */
+  void* mn = malloc(dt_size(data_dt) * (size_t)ntiles * 2);
+  if (!mn) return fail(FFQ_ERR_ARG, "out of memory");
+  void* mx = (char*)mn + dt_size(data_dt) * (size_t)ntiles;
+  rc = ffq_minmax_by_tile(data, data_dt, tiling, mn, mx, 0, NULL, NULL, 0, stream);
+  /* parameters_for_range(...); offset None -> zeros_like(scale); offset = round(offset) (:266-275) */
+  if (!rc)
+    rc = ffq_parameters_for_range(mn, mx, data_dt, ntiles, num_bits, symmetric, allow_one_sided,
+                                  scale_out, FFQ_F32, offset_out, FFQ_F32, stream);
+  free(mn);
+  if (rc) return rc;
+  for (int64_t t = 0; t < ntiles; ++t) offset_out[t] = nearbyintf(offset_out[t]);
+  /* round(row / scale - offset), clamp, cast                                        (:277-284) */
+  return ffq_quantize_by_tile(data, data_dt, scale_out, FFQ_F32, ntiles, offset_out, FFQ_F32, ntiles,
+                              tiling, num_bits, out, out_dt, stream);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A7: GGUF Q4_0 nibble order, export/stages/gguf/_packing.py:44-53                            */
+/* ------------------------------------------------------------------------------------------ */
+int ffq_pack_int4(const void* codes, int codes_dt, int64_t numel, int64_t block, uint8_t* packed,
+                  void* stream) {
+  (void)stream;
+  if (!dt_valid(codes_dt)) return fail(FFQ_ERR_ARG, "bad dtype tag");
+  if (block <= 0 || (block & 1) || numel % block) return fail(FFQ_ERR_ARG, "numel %% block != 0 or odd block");
+  if (numel == 0) return FFQ_OK;
+  if (!codes || !packed) return fail(FFQ_ERR_ARG, "NULL buffer");
+  int64_t half = block / 2;
+  for (int64_t b = 0; b < numel / block; ++b) {
+    for (int64_t j = 0; j < half; ++j) {
+      /* gguf_qs = (int_codes + 8).clamp(0, 15); packed = qs[:, 0, :] | (qs[:, 1, :] << 4) */
+      int64_t lo = (int64_t)ld(codes, codes_dt, b * block + j) + 8;
+      int64_t hi = (int64_t)ld(codes, codes_dt, b * block + half + j) + 8;
+      lo = lo < 0 ? 0 : (lo > 15 ? 15 : lo);
+      hi = hi < 0 ? 0 : (hi > 15 ? 15 : hi);
+      packed[b * half + j] = (uint8_t)(lo | (hi << 4));
+    }
+  }
+  return FFQ_OK;
+}
+
+int ffq_unpack_int4(const uint8_t* packed, int64_t numel, int64_t block, void* codes_out,
+                    int codes_dt, void* stream) {
+  (void)stream;
+  if (!dt_valid(codes_dt)) return fail(FFQ_ERR_ARG, "bad dtype tag");
+  if (block <= 0 || (block & 1) || numel % block) return fail(FFQ_ERR_ARG, "numel %% block != 0 or odd block");
+  if (numel == 0) return FFQ_OK;
+  if (!codes_out || !packed) return fail(FFQ_ERR_ARG, "NULL buffer");
+  int64_t half = block / 2;
+  for (int64_t b = 0; b < numel / block; ++b) {
+    for (int64_t j = 0; j < half; ++j) {
+      uint8_t byte = packed[b * half + j];
+      st(codes_out, codes_dt, b * block + j, (double)((int)(byte & 15) - 8));
+      st(codes_out, codes_dt, b * block + half + j, (double)((int)(byte >> 4) - 8));
+    }
+  }
+  return FFQ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* A6: fallback.linear, _gen/fallback.py:77-112                                                */
+/* ------------------------------------------------------------------------------------------ */
+size_t ffq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  (void)M; (void)N; (void)K;
+  return 0;
+}
+
+/*
+ * The reference dequantizes both operands into their dequantize_dtype (A2), runs
+ * torch.nn.functional.linear on them and applies the output quantizer. Restated here with the
+ * operands dequantized to `out_dt` (the activation dtype of the caller) and the contraction
+ * accumulated in double, i.e. the exact value a float GEMM approximates; tests compare with the
+ * tolerance stated there.
+ */
+int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, const float* x_offset,
+                    int x_per_row, const float* w_scale, const float* w_offset, int w_per_row,
+                    const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
+                    const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (M == 0 || N == 0) return FFQ_OK;
+  if (!xq || !wq || !x_scale || !w_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  int deq_dt = out_scale ? FFQ_BF16 : out_dt;
+  if (!dt_is_float(deq_dt)) return fail(FFQ_ERR_DTYPE, "real-valued output must be a float dtype");
+  if (out_scale && !ffq_can_support_bitwidth(out_dt, out_num_bits))
+    return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.",
+                out_dt, out_num_bits);
+  double lo = -pow(2.0, out_num_bits - 1.0), hi = -lo - 1.0;
+  double* xr = (double*)malloc(sizeof(double) * (size_t)(K > 0 ? K : 1));
+  if (!xr) return fail(FFQ_ERR_ARG, "out of memory");
+  for (int64_t m = 0; m < M; ++m) {
+    double sx = x_scale[x_per_row ? m : 0];
+    double ox = x_offset ? (double)nearbyintf(x_offset[x_per_row ? m : 0]) : 0.0;
+    for (int64_t k = 0; k < K; ++k) {
+      /* input.dequantize(): (q + o) * s in fp32, cast to the dequantize dtype            (A2) */
+      double v = op2(OP_MUL, op2(OP_ADD, (double)xq[m * K + k], ox, FFQ_F32), sx, FFQ_F32);
+      xr[k] = cast_to(v, FFQ_F32, deq_dt);
+    }
+    for (int64_t n = 0; n < N; ++n) {
+      double sw = w_scale[w_per_row ? n : 0];
+      double ow = w_offset ? (double)nearbyintf(w_offset[w_per_row ? n : 0]) : 0.0;
+      double acc = 0.0;
+      for (int64_t k = 0; k < K; ++k) {
+        double wv = op2(OP_MUL, op2(OP_ADD, (double)wq[n * K + k], ow, FFQ_F32), sw, FFQ_F32);
+        acc += xr[k] * cast_to(wv, FFQ_F32, deq_dt);
+      }
+      if (bias) acc += ld(bias, bias_dt, n);
+      double y = round_to(acc, deq_dt);
+      if (out_scale) {
+        /* output_quantizer(output): per-tensor A1 on the real-valued result (fallback.py:110-111) */
+        double o = out_offset ? (double)nearbyintf(out_offset[0]) : 0.0;
+        double q = op2(OP_SUB, op2(OP_DIV, y, (double)out_scale[0], FFQ_F32), o, FFQ_F32);
+        q = clamp_nan(nearbyint(q), lo, hi);
+        st(out, out_dt, m * N + n, q);
+      } else {
+        st(out, out_dt, m * N + n, y);
+      }
+    }
+  }
+  free(xr);
+  return FFQ_OK;
+}
