@@ -1,0 +1,354 @@
+"""Generate the golden fixtures in this directory by running the REFERENCE itself (CPU eager).
+
+Run only in the build container, where /root/reference exists:
+
+    mkdir -p /tmp/ffshim/optree && echo "from torch.utils._pytree import tree_map, tree_flatten, \
+tree_unflatten, tree_leaves" > /tmp/ffshim/optree/__init__.py
+    PYTHONPATH=/root/reference/src:/tmp/ffshim python tests/golden/gen_golden.py
+
+(`optree` is the one eagerly imported dependency of the reference that is not installed here; the
+two-line shim re-exports torch's own pytree functions and lives outside the repository.)
+
+Nothing of the reference travels: the fixtures hold inputs (or the seed that regenerates them with
+torch's CPU generator) and the outputs the reference produced. Files are torch.save'd dicts of
+tensors and plain Python values, loadable with ``torch.load(..., weights_only=True)``.
+"""
+
+from __future__ import annotations
+
+import itertools
+import pathlib
+import sys
+
+import torch
+
+HERE = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+from datagen import make_data  # noqa: E402
+
+try:
+    import fastforward as ff
+
+    from fastforward.quantization import affine
+    from fastforward.quantization.affine import parameters_for_range
+    from fastforward.quantization.tiled_tensor import tiles_to_rows
+except ImportError as e:  # pragma: no cover
+    sys.exit(f"the reference is not importable ({e}); see the module docstring")
+
+
+def gran_of(spec):
+    kind = spec[0]
+    if kind == "tensor":
+        return ff.PerTensor()
+    if kind == "channel":
+        return ff.PerChannel(spec[1])
+    if kind == "block":
+        return ff.PerBlock(block_dims=spec[1], block_sizes=spec[2], per_channel_dims=spec[3])
+    if kind == "tile":
+        return ff.PerTile(tuple(spec[1]))
+    raise ValueError(spec)
+
+
+def tile_of(spec, shape):
+    tile = gran_of(spec).tile_size(torch.Size(shape))
+    return list(shape) if isinstance(tile, str) else list(tile)
+
+
+def params_from_range(x, spec, num_bits, mode):
+    """(scale, offset) the way LinearQuantizer derives them from the per-tile min/max of x."""
+    tile = tile_of(spec, x.shape)
+    rows = tiles_to_rows(x.float(), tile)
+    lo, hi = rows.min(-1).values, rows.max(-1).values
+    symmetric = mode != "asymmetric"
+    scale, offset = parameters_for_range(lo, hi, num_bits, symmetric=symmetric, allow_one_sided=True)
+    return scale, offset
+
+
+def static_case(name, x, spec, num_bits, scale, offset, quantized_dtype):
+    q = affine.quantize_per_granularity(x, scale, offset, gran_of(spec), num_bits, quantized_dtype)
+    return {
+        "name": name,
+        "granularity": list(spec),
+        "tile": tile_of(spec, x.shape),
+        "shape": list(x.shape),
+        "num_bits": num_bits,
+        "scale": None if scale is None else scale.clone(),
+        "offset": None if offset is None else offset.clone(),
+        "quantized_dtype": str(quantized_dtype).removeprefix("torch.") if quantized_dtype else None,
+        "codes": q.raw_data.clone(),
+        "dequantized": q.dequantize().clone(),
+    }
+
+
+def g1_known_answers():
+    """Known-answer vectors of the reference's own tests (tests/nn/test_linear_quantizer.py)."""
+    out = {}
+    # :20-72 — linspace(-8, 8, 17), scale 2, 2 bits, no offset
+    data = torch.linspace(-8, 8, 17)
+    params = affine.StaticAffineQuantParams(scale=torch.tensor(2.0), offset=None, granularity=ff.PerTensor(), num_bits=2)
+    q = affine.AffineQuantizationFunction.quantize(data, params)
+    out["symmetric_2bit"] = {
+        "data": data, "scale": torch.tensor(2.0), "offset": None, "num_bits": 2,
+        "codes": q.raw_data.clone(), "dequantized": q.dequantize().clone(),
+        "expected_codes_in_reference_test": torch.tensor([-2.0] * 6 + [-1.0, 0.0, 0.0, 0.0] + [1.0] * 7),
+    }
+    # :189-219 — asymmetric per tensor, scale 2 offset 4
+    data = torch.stack([torch.linspace(-2, 14, 17)] * 32)
+    quantizer = ff.nn.LinearQuantizer(num_bits=2, symmetric=False)
+    quantizer.quantization_range = (data.min(), data.max())
+    with torch.no_grad():
+        quantizer.scale.fill_(2.0)
+        quantizer.offset.fill_(4.0)
+    q = quantizer(data)
+    out["asymmetric_2bit"] = {
+        "data": data, "scale": torch.tensor([2.0]), "offset": torch.tensor([4.0]), "num_bits": 2,
+        "codes": q.raw_data.clone(), "dequantized": q.dequantize().clone(),
+        "expected_row_in_reference_test": torch.tensor([-2.0] * 8 + [-1.0, 0.0, 0.0, 0.0] + [1.0] * 5),
+    }
+    # :400-418 — one-sided data: 4-bit symmetric quantizer picks offset 8
+    data = torch.rand(64, generator=torch.Generator().manual_seed(7))
+    quantizer = ff.nn.LinearQuantizer(num_bits=4, symmetric=True, allow_one_sided=True)
+    quantizer.quantization_range = (data.min(), data.max())
+    q = quantizer(data)
+    out["one_sided_4bit"] = {
+        "data": data, "range_min": data.min(), "range_max": data.max(), "num_bits": 4,
+        "scale": quantizer.scale.detach().clone(), "offset": quantizer.offset.detach().clone(),
+        "codes": q.raw_data.clone(), "dequantized": q.dequantize().clone(),
+    }
+    return out
+
+
+def g2_edges():
+    """Ties, clamping edges, NaN, +-Inf, -0.0 with scale 1 and half-even rounding of the offset."""
+    vals = [-2.5, -1.5, -0.5, 0.5, 1.5, 2.5, 126.5, 127.5, 128.5, -127.5, -128.5, -129.0,
+            float("nan"), float("inf"), float("-inf"), -0.0, 0.0, 3.4e38, -3.4e38, 1e-45]
+    cases = []
+    for dtype, qdt, off in itertools.product(
+        (torch.float32, torch.bfloat16), (None, torch.int8, torch.int32), (None, 0.5, 1.5, -2.5)
+    ):
+        x = torch.tensor(vals, dtype=dtype)
+        offset = None if off is None else torch.tensor([off])
+        name = f"edge_{str(dtype).removeprefix('torch.')}_{qdt}_{off}"
+        cases.append(static_case(name, x, ("tensor",), 8, torch.tensor([1.0]), offset, qdt) | {"data": x})
+    # zero and denormal scales (0/0 -> NaN, x/0 -> +-Inf -> clamp)
+    x = torch.tensor([0.0, -0.0, 1.0, -1.0, 1e-40, -1e-40], dtype=torch.float32)
+    for s in (0.0, 1e-42, 3.0e38):
+        cases.append(static_case(f"edge_scale_{s}", x, ("tensor",), 8, torch.tensor([s]), None, None) | {"data": x})
+    return cases
+
+
+G3_GRANULARITIES = [
+    ("tensor",),
+    ("channel", (0,)),
+    ("channel", (1,)),
+    ("channel", (-1,)),
+    ("channel", (0, 2)),
+    ("block", (2,), (4,), (0,)),
+    ("tile", (16, 8, 4)),
+    ("tile", (1, 1, 1)),
+]
+
+
+def seeded_case(name, seed, shape, dtype, kind, spec, num_bits, mode, keep_dequantized=True):
+    """A case whose input is regenerated from `seed`; codes stored as int8, dequantized in the data dtype."""
+    x = make_data(seed, shape, dtype, kind)
+    scale, offset = params_from_range(x, spec, num_bits, mode)
+    c = static_case(name, x, spec, num_bits, scale, offset, None)
+    # the int8 container must hold the same integers as the default (data dtype) container
+    c8 = static_case(name, x, spec, num_bits, scale, offset, torch.int8)
+    assert torch.equal(c["codes"].to(torch.int8), c8["codes"]) or torch.isnan(c["codes"].float()).any()
+    assert torch.equal(c["dequantized"], c8["dequantized"]) or torch.isnan(c["dequantized"].float()).any()
+    c["codes"] = c8["codes"]
+    if not keep_dequantized:
+        c["dequantized"] = None
+    c |= {"seed": seed, "kind": kind, "dtype": str(dtype).removeprefix("torch."), "mode": mode}
+    del c["quantized_dtype"]
+    return c
+
+
+def g3_sweeps():
+    """Random sweeps on the reference's own test shape (32, 16, 8) and two 2-D shapes."""
+    cases = []
+    seed = 1000
+    for spec, num_bits, dtype, mode in itertools.product(G3_GRANULARITIES, (2, 4, 8), (torch.float32, torch.bfloat16), ("symmetric", "asymmetric")):
+        for kind in ("normal", "outlier") if num_bits == 8 else ("normal",):
+            seed += 1
+            name = f"sweep3d_{'_'.join(map(str, spec))}_{num_bits}b_{str(dtype).removeprefix('torch.')}_{mode}_{kind}"
+            cases.append(seeded_case(name, seed, (32, 16, 8), dtype, kind, spec, num_bits, mode))
+    for spec, dtype in itertools.product((("tensor",), ("channel", (0,))), (torch.float32, torch.bfloat16)):
+        seed += 1  # all-positive data: the symmetric quantizer switches to the one-sided grid
+        cases.append(seeded_case(f"sweep3d_onesided_{spec[0]}_{dtype}", seed, (32, 16, 8), dtype, "positive", spec, 4, "symmetric"))
+    specs2d = [(("tensor",), 8, "asymmetric"), (("channel", (0,)), 8, "symmetric"), (("channel", (-1,)), 8, "symmetric"),
+               (("block", (1,), (128,), (0,)), 4, "symmetric"), (("channel", (0,)), 4, "asymmetric")]
+    for (spec, num_bits, mode), dtype in itertools.product(specs2d, (torch.float32, torch.bfloat16)):
+        seed += 1
+        cases.append(seeded_case(f"sweep2d_64x512_{'_'.join(map(str, spec))}_{num_bits}b_{dtype}", seed, (64, 512), dtype, "normal", spec, num_bits, mode))
+    for spec, num_bits, mode in specs2d[:4]:  # one Llama-shaped slab, bf16, codes only
+        seed += 1
+        cases.append(seeded_case(f"sweep2d_128x4096_{'_'.join(map(str, spec))}_{num_bits}b", seed, (128, 4096), torch.bfloat16, "normal", spec, num_bits, mode, keep_dequantized=False))
+    # config 1 of BASELINE.json: nn.Linear(1024, 1024) fp32 weight, 8-bit per-tensor
+    seed += 1
+    cases.append(seeded_case("cfg1_linear1024_weight", seed, (1024, 1024), torch.float32, "normal", ("tensor",), 8, "symmetric", keep_dequantized=False))
+    return cases
+
+
+def g3_dtype_sweep():
+    """Mixed dtypes of data / scale / offset / container (the generic kernel's territory).
+
+    Mirrors _quantize_per_element_impl, tests/quantization/test_tiled_affine.py:309-365, with the
+    data 5 % away from rounding boundaries (gen_data, :283-306) — plus unconstrained random data so
+    that the per-op roundings of half-precision parameters are actually exercised.
+    """
+    cases = []
+    seed = 5000
+    data_dtypes = (torch.float16, torch.bfloat16, torch.float32, torch.int32, torch.int16, torch.int8)
+    scale_dtypes = (torch.float32, torch.float16, torch.bfloat16)
+    offset_dtypes = (None, torch.float32, torch.float16, torch.bfloat16, torch.int32, torch.int8)
+    out_dtypes = (torch.int32, torch.int16, torch.float32, torch.float16)
+    for ddt, sdt, odt, qdt in itertools.product(data_dtypes, scale_dtypes, offset_dtypes, out_dtypes):
+        seed += 1
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(8, 6, 4, generator=g) * 3
+        x = (x * 10).to(ddt) if not ddt.is_floating_point else x.to(ddt)
+        spec = ("channel", (1,))
+        scale = (torch.rand(6, generator=g) * 0.5 + 0.2).to(sdt)
+        offset = None if odt is None else (torch.randn(6, generator=g) * 2 + 0.3).to(odt)
+        try:
+            c = static_case(f"dtypes_{ddt}_{sdt}_{odt}_{qdt}", x, spec, 4, scale, offset, qdt)
+        except Exception as e:  # a combination the reference itself cannot run on CPU
+            print(f"skip {ddt} {sdt} {odt} {qdt}: {type(e).__name__}: {str(e)[:60]}")
+            continue
+        cases.append(c | {"data": x})
+    return cases
+
+
+def g4_ranges():
+    cases = []
+    g = torch.Generator().manual_seed(42)
+    for num_bits, symmetric, one_sided, kind, n in itertools.product((2, 4, 8), (True, False), (True, False), ("mixed", "positive", "degenerate", "zero"), (1, 7)):
+        lo = torch.randn(n, generator=g) - 0.5
+        hi = lo + torch.rand(n, generator=g) * 3
+        if kind == "positive":
+            lo = lo.abs()
+            hi = lo + torch.rand(n, generator=g) * 3
+        elif kind == "degenerate":
+            hi = lo.clone()
+        elif kind == "zero":
+            lo = torch.zeros(n)
+            hi = torch.zeros(n)
+        scale, offset = parameters_for_range(lo, hi, num_bits, symmetric=symmetric, allow_one_sided=one_sided)
+        cases.append({"min": lo, "max": hi, "num_bits": num_bits, "symmetric": symmetric, "allow_one_sided": one_sided,
+                      "scale": scale.clone(), "offset": None if offset is None else offset.clone()})
+    # tests/quantization/affine/test_range.py:17-40 — bf16 inputs give the same parameters as fp32
+    lo16, hi16 = torch.tensor([-1.0], dtype=torch.bfloat16), torch.tensor([1.0], dtype=torch.bfloat16)
+    for num_bits in (4, 8, 16):
+        s, o = parameters_for_range(lo16, hi16, num_bits, symmetric=False, allow_one_sided=False)
+        cases.append({"min": lo16, "max": hi16, "num_bits": num_bits, "symmetric": False, "allow_one_sided": False, "scale": s.clone(), "offset": o.clone()})
+    return cases
+
+
+def g5_minmax():
+    """Five scaled batches as in tests/range_setting/test_minmax.py:44-61, plus bf16 and per-channel."""
+    out = []
+    for spec, dtype, symmetric in itertools.product((("tensor",), ("channel", (0,)), ("channel", (-1,))), (torch.float32, torch.bfloat16), (True, False)):
+        g = torch.Generator().manual_seed(99)
+        base = torch.randn(16, 24, generator=g)
+        batches = [(base * (i + 1) / 3).to(dtype) for i in range(5)]
+        quantizer = ff.nn.LinearQuantizer(4, symmetric=symmetric, granularity=gran_of(spec))
+        model = torch.nn.ModuleList([quantizer])
+        outputs = []
+        with ff.estimate_ranges(model, ff.range_setting.running_minmax):
+            for b in batches:
+                outputs.append(quantizer(b).raw_data.clone())
+        out.append({
+            "granularity": list(spec), "symmetric": symmetric, "num_bits": 4, "batches": batches,
+            "scale": quantizer.scale.detach().clone(),
+            "offset": None if quantizer.offset is None else quantizer.offset.detach().clone(),
+            "codes_per_step": outputs,
+        })
+    return out
+
+
+def g6_linear():
+    """QuantizedLinear W8A8 forward through the reference's fallback.linear."""
+    torch.manual_seed(1234)
+    cases = []
+    for dtype, bias in ((torch.bfloat16, True), (torch.float32, False)):
+        lin = torch.nn.Linear(256, 192, bias=bias).to(dtype)
+        x = torch.randn(2, 48, 256).to(dtype)
+        model = torch.nn.Sequential(lin)
+        ff.quantize_model(model)
+        lin.weight_quantizer = ff.nn.LinearQuantizer(8, granularity=ff.PerChannel(0))
+        lin.input_quantizer = ff.nn.LinearQuantizer(8, symmetric=False)
+        with ff.strict_quantization(False):
+            with ff.estimate_ranges(model, ff.range_setting.running_minmax):
+                model(x)
+            y = model(x)
+            xq = lin.input_quantizer(x)
+            wq = lin.weight_quantizer(lin.weight)
+        y64 = torch.nn.functional.linear(xq.dequantize().double(), wq.dequantize().double(), None if lin.bias is None else lin.bias.double())
+        cases.append({
+            "x": x, "weight": lin.weight.detach().clone(), "bias": None if lin.bias is None else lin.bias.detach().clone(),
+            "x_scale": lin.input_quantizer.scale.detach().clone(), "x_offset": lin.input_quantizer.offset.detach().clone(),
+            "w_scale": lin.weight_quantizer.scale.detach().clone(), "w_offset": lin.weight_quantizer.offset.detach().clone(),
+            "x_codes": xq.raw_data.to(torch.int8), "w_codes": wq.raw_data.to(torch.int8),
+            "y": y.detach().clone(), "y_float64": y64.float(),
+        })
+    return cases
+
+
+def g8_int4():
+    """Group-128 4-bit codes and their GGUF Q4_0 nibble packing (block 32)."""
+    torch.manual_seed(77)
+    w = torch.randn(64, 256, dtype=torch.bfloat16)
+    spec = ("block", (1,), (128,), (0,))
+    scale, offset = params_from_range(w, spec, 4, "symmetric")
+    q = affine.quantize_per_granularity(w, scale, offset, gran_of(spec), 4, torch.int8)
+    out = {"weight": w, "scale": scale, "offset": offset, "codes": q.raw_data.clone(), "dequantized": q.dequantize().clone()}
+    try:
+        from fastforward.export.stages.gguf._packing import pack_q4_0_blocks
+
+        codes32 = q.raw_data.reshape(-1, 32)
+        packed = pack_q4_0_blocks(codes32, torch.ones(codes32.shape[0]))
+        out["q4_0_nibbles_block32"] = packed[:, 2:].contiguous()  # drop the fp16 scale bytes
+    except Exception as e:  # gguf adapter needs packages that are not installed here
+        print("pack_q4_0_blocks not importable:", type(e).__name__, e)
+        gq = (q.raw_data.reshape(-1, 2, 16).to(torch.int16) + 8).clamp(0, 15).to(torch.uint8)
+        out["q4_0_nibbles_block32"] = gq[:, 0, :] | (gq[:, 1, :] << 4)  # the two lines of _packing.py:50-51
+        out["note"] = "nibbles computed from the formula at export/stages/gguf/_packing.py:48-51"
+    return out
+
+
+def g9_dispatcher():
+    """What predicate and kernel see on the two call paths of `linear`."""
+    seen = []
+
+    def predicate(*args, **kwargs):
+        seen.append((len(args), sorted(kwargs)))
+        return False
+
+    x = affine.quantize_per_tensor(torch.randn(2, 8), 0.1, None, 8)
+    w = affine.quantize_per_tensor(torch.randn(4, 8), 0.1, None, 8)
+    with ff.strict_quantization(False), ff.dispatcher.register("linear", ff.dispatcher.Predicate(predicate), lambda *a, **k: None):
+        ff.nn.functional.linear(x, w)
+        torch.nn.functional.linear(x, w)
+    return {"functional_then_torch": seen}
+
+
+def main() -> None:
+    torch.set_num_threads(8)
+    torch.save(g1_known_answers(), HERE / "g1_known_answers.pt")
+    torch.save(g2_edges(), HERE / "g2_edges.pt")
+    torch.save(g3_sweeps(), HERE / "g3_sweeps.pt")
+    torch.save(g3_dtype_sweep(), HERE / "g3_dtype_sweep.pt")
+    torch.save(g4_ranges(), HERE / "g4_ranges.pt")
+    torch.save(g5_minmax(), HERE / "g5_minmax.pt")
+    torch.save(g6_linear(), HERE / "g6_linear.pt")
+    torch.save(g8_int4(), HERE / "g8_int4.pt")
+    torch.save(g9_dispatcher(), HERE / "g9_dispatcher.pt")
+    for f in sorted(HERE.glob("*.pt")):
+        print(f"{f.name}: {f.stat().st_size / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

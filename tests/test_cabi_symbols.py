@@ -1,0 +1,50 @@
+"""The HIP library loads here (no GPU needed) and exports every symbol include/ffq.h declares."""
+
+import ctypes
+import re
+
+from conftest import HIP_SO, ORACLE_SO, ROOT, load_oracle
+
+from fastforward_amd._cabi import SIGNATURES, FFQLibrary
+
+
+def declared_symbols() -> set[str]:
+    text = (ROOT / "include" / "ffq.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(ffq_[a-z0-9_]+)\s*\(", text))
+
+
+def test_header_and_ctypes_table_agree():
+    assert declared_symbols() == set(SIGNATURES)
+
+
+def test_hip_library_exports_every_declared_symbol():
+    assert HIP_SO.exists(), "build it with: make -C fastforward_amd/csrc"
+    dll = ctypes.CDLL(str(HIP_SO))
+    for name in declared_symbols():
+        assert hasattr(dll, name), name
+    lib = FFQLibrary(HIP_SO)
+    assert lib.backend_name == "hip:gfx950" and lib.is_device
+
+
+def test_oracle_exports_the_same_abi():
+    lib = load_oracle()
+    assert ORACLE_SO.exists()
+    assert lib.backend_name == "oracle:c" and not lib.is_device
+
+
+def test_pure_host_queries_of_the_hip_library():
+    """Entry points that never touch the device can be called without a GPU."""
+    from fastforward_amd._cabi import DType, Tiling
+
+    lib = FFQLibrary(HIP_SO)
+    t = Tiling.make((14336, 4096), (1, 128))
+    assert lib.ffq_num_tiles(ctypes.byref(t)) == 14336 * 32
+    assert lib.ffq_promote_types(DType.BF16, DType.F32) == DType.F32
+    assert lib.ffq_promote_types(DType.BF16, DType.F16) == DType.F32
+    assert lib.ffq_promote_types(DType.I32, DType.F16) == DType.F16
+    assert lib.ffq_can_support_bitwidth(DType.BF16, 9.0) == 1
+    assert lib.ffq_can_support_bitwidth(DType.BF16, 16.0) == 0
+    bad = Tiling.make((10, 4), (3, 4))
+    assert lib.ffq_num_tiles(ctypes.byref(bad)) == -2  # FFQ_ERR_TILE_DIVIDE
+    assert b"must divide" in lib.ffq_last_error()

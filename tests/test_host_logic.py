@@ -1,0 +1,456 @@
+"""Host-side surface on CPU: the oracle stands in for the HIP library (same C ABI, host pointers).
+
+Re-expresses, against fastforward_amd's imports, the assertions of the reference tests that pin this
+path: tests/test_dispatcher.py, tests/quantization/test_tiled_tensor.py,
+tests/nn/test_linear_quantizer.py (initialisation / error behaviour / per-channel == per-tensor),
+tests/quantization/test_dynamic.py, tests/range_setting/test_minmax.py, plus conversion
+(`quantize_model`), the override stack and QuantizedTensor's torch-function routing.
+"""
+
+import copy
+import math
+import pickle
+
+from unittest import mock
+
+import pytest
+import torch
+
+import fastforward_amd as ff
+
+from conftest import golden
+from fastforward_amd.dispatcher import DispatcherPriority, Predicate, dispatch, register
+from fastforward_amd.exceptions import BackendError, QuantizationError
+from fastforward_amd.quantization import tiled_tensor
+from fastforward_amd.quantization.affine import AffineQuantizationFunction, StaticAffineQuantParams
+
+
+@pytest.fixture(autouse=True)
+def _backend(oracle_backend):
+    yield
+
+
+def spy(fn):
+    return mock.Mock(wraps=fn)
+
+
+# ---- dispatcher (reference tests/test_dispatcher.py) -----------------------------------------------
+def test_predicate_algebra_short_circuits():
+    m1, m2 = spy(lambda x, y: x == "test"), spy(lambda x, y: y == "not")
+    p = Predicate(m1) | Predicate(m2)
+    assert p("test", "not")
+    m1.assert_called_once()
+    m2.assert_not_called()
+    m1.reset_mock(), m2.reset_mock()
+    assert not p("not", "test")
+    m1.assert_called_once()
+    m2.assert_called_once()
+    q = Predicate(m1) & Predicate(m2)
+    m1.reset_mock(), m2.reset_mock()
+    assert not q("nope", "not")
+    m2.assert_not_called()
+    assert (~Predicate(m1))("nope", "x")
+
+
+def test_dispatch_order_is_newest_first_within_a_priority():
+    op = "softmax_order_test"
+    p1, k1 = spy(lambda input, dim: input.dtype == torch.int8), spy(lambda input, dim: "k1")
+    p2, k2 = spy(lambda input, dim: dim == 1), spy(lambda input, dim: "k2")
+    p3, k3 = spy(lambda input, dim: isinstance(input, str)), spy(lambda input, dim: "k3")
+    hooks = [register(op, Predicate(p), k) for p, k in ((p1, k1), (p2, k2), (p3, k3))]
+    try:
+        x = torch.zeros(2, 3, dtype=torch.int8)
+        kernel = dispatch(op, x, 1)
+        assert kernel(x, 1) == "k2"
+        p3.assert_called_once(), p2.assert_called_once(), p1.assert_not_called()
+        k3.assert_not_called(), k1.assert_not_called()
+        # fallbacks are consulted after every DEFAULT kernel
+        fb = register(op, None, lambda input, dim: "fallback", DispatcherPriority.FALLBACK)
+        hooks.append(fb)
+        assert dispatch(op, x, 1)(x, 1) == "k2"
+        assert dispatch(op, torch.zeros(1), 0)(x, 0) == "fallback"
+    finally:
+        for h in hooks:
+            h.remove()
+    assert dispatch(op, x, 1) is None
+
+
+def test_registration_hook_and_decorator_forms():
+    op = "hook_test"
+    with register(op, Predicate(lambda a: a > 0), lambda a: a * 2):
+        assert dispatch(op, 3)(3) == 6
+        assert dispatch(op, -3) is None
+    assert dispatch(op, 3) is None
+
+    @register(op, Predicate(lambda a: True))
+    def kernel(a):
+        return a + 1
+
+    try:
+        assert kernel(1) == 2 and dispatch(op, 5) is kernel
+    finally:
+        ff.dispatcher._DISPATCHER[op].clear()
+
+
+def test_linear_call_signatures_match_reference_capture():
+    """What predicate/kernel see on both call paths equals what was captured from the reference (G9)."""
+    seen = []
+
+    def predicate(*args, **kwargs):
+        seen.append((len(args), sorted(kwargs)))
+        return False
+
+    x = ff.quantization.affine.quantize_per_tensor(torch.randn(2, 16), 0.1, None, 8)
+    w = ff.quantization.affine.quantize_per_tensor(torch.randn(4, 16), 0.1, None, 8)
+    with ff.strict_quantization(False), register("linear", Predicate(predicate), lambda *a, **k: None):
+        ff.nn.functional.linear(x, w)
+        torch.nn.functional.linear(x, w)
+    expected = [tuple(e) if isinstance(e, (list, tuple)) else e for e in golden("g9_dispatcher.pt")["functional_then_torch"]]
+    assert [(n, list(k)) for n, k in seen] == [(n, list(k)) for n, k in expected]
+
+
+def test_same_kernel_for_functional_torch_function_and_operator():
+    a = ff.quantization.affine.quantize_per_tensor(torch.randn(5, 1, 3), 0.1, None, 8)
+    b = ff.quantization.affine.quantize_per_tensor(torch.randn(1, 2, 1), 0.2, 3.0, 8)
+    with ff.strict_quantization(False):
+        expected = a.dequantize() + b.dequantize()
+        torch.testing.assert_close(torch.add(a, b), expected)
+        torch.testing.assert_close(a + b, expected)
+        kernel = spy(lambda input, other, **kw: input.dequantize() - other.dequantize())
+        with register("add", Predicate(lambda *a_, **k_: True), kernel):
+            out1 = torch.add(a, b)
+            out2 = a + b
+        assert kernel.call_count == 2
+        torch.testing.assert_close(out1, a.dequantize() - b.dequantize())
+        torch.testing.assert_close(out2, out1)
+
+
+# ---- tile layout (reference tests/quantization/test_tiled_tensor.py:10-43) ---------------------------
+def test_tiles_to_rows_known_layout():
+    blocks = [torch.ones(2, 2) * v for v in range(1, 9)]
+    p1 = torch.stack([torch.hstack(blocks[0:2]), torch.hstack(blocks[2:4])]).reshape(4, 4)
+    p2 = torch.stack([torch.hstack(blocks[4:6]), torch.hstack(blocks[6:8])]).reshape(4, 4)
+    data = torch.stack([p1, p2])
+    rows = tiled_tensor.tiles_to_rows(data, (1, 2, 2))
+    torch.testing.assert_close(rows, torch.ones(8, 4) * torch.arange(1, 9)[:, None])
+    torch.testing.assert_close(tiled_tensor.rows_to_tiles(rows, data.shape, (1, 2, 2)), data)
+    for bad in ((1, 2, 3, 4), (3, 2, 2)):
+        with pytest.raises(ValueError):
+            tiled_tensor.tiles_to_rows(data, bad)
+    with pytest.raises(ValueError):
+        tiled_tensor.rows_to_tiles(rows[:, :-1], data.shape, (1, 2, 2))
+    with pytest.raises(ValueError):
+        tiled_tensor.rows_to_tiles(rows[:, :-1], data.shape, (2, 2, 2))
+
+
+def test_kernel_parameter_order_is_tiles_to_rows_order():
+    """The C ABI's tile index == row index of tiles_to_rows, for every layout class."""
+    g = torch.Generator().manual_seed(0)
+    for shape, tile in [((6, 8), (1, 8)), ((6, 8), (6, 1)), ((6, 8), (2, 4)), ((4, 6, 8), (4, 1, 8)), ((4, 6, 8), (1, 6, 1)), ((4, 6, 8), (2, 3, 4)), ((4, 6, 8), (1, 1, 4))]:
+        x = torch.randn(*shape, generator=g)
+        rows = tiled_tensor.tiles_to_rows(x, tile)
+        lo, hi = ff.ops.minmax_by_tile(x, tile)
+        assert torch.equal(lo, rows.min(-1).values) and torch.equal(hi, rows.max(-1).values), (shape, tile)
+        scale = torch.rand(rows.shape[0], generator=g) + 0.1
+        q = ff.ops.quantize_by_tile(x, scale, tile, 4, None)
+        ref = tiled_tensor.rows_to_tiles(torch.clamp(torch.round(rows / scale[:, None]), -8, 7), shape, tile)
+        assert torch.equal(q, ref), (shape, tile)
+
+
+# ---- granularities -----------------------------------------------------------------------------------
+def test_granularity_tile_sizes():
+    shape = torch.Size((4, 6, 8))
+    assert ff.PerTensor().tile_size(shape) == "data_shape"
+    assert ff.PerChannel().tile_size(shape) == (1, 6, 8)
+    assert ff.PerChannel(-1).tile_size(shape) == (4, 6, 1)
+    assert ff.PerChannel((0, 2)).tile_size(shape) == (1, 6, 1)
+    assert ff.PerBlock(2, 4, 0).tile_size(shape) == (1, 6, 4)
+    assert ff.PerBlock(block_dims=1, block_sizes=128, per_channel_dims=0).tile_size(torch.Size((4096, 4096))) == (1, 128)
+    assert ff.PerBlock(1, 128, 0).parameter_dimensionality(torch.Size((4096, 4096))) == 131072
+    assert ff.PerTile((2, 3, 4)).tile_size(shape) == (2, 3, 4)
+    with pytest.raises(ValueError):
+        ff.PerTile((3, 3, 4)).tile_size(shape)
+    with pytest.raises(ValueError):
+        ff.PerBlock(2, 3, 0).tile_size(shape)
+    with pytest.raises(ValueError):
+        ff.PerBlock(2, 16, 0).tile_size(shape)
+    assert ff.PerChannel(0) == ff.PerChannel((0,)) and ff.PerChannel(0) != ff.PerChannel(1) and ff.PerTensor() == ff.PerTensor()
+    from fastforward_amd.quantization.granularity import granularity_from_sizes
+
+    assert granularity_from_sizes(shape, shape) == ff.PerTensor()
+    assert granularity_from_sizes(shape, torch.Size((1, 6, 8))) == ff.PerChannel(0)
+    assert granularity_from_sizes(shape, torch.Size((1, 6, 4))).tile_size(shape) == (1, 6, 4)
+
+
+# ---- LinearQuantizer (reference tests/nn/test_linear_quantizer.py) ---------------------------------
+@pytest.mark.parametrize("quantized_dtype", [torch.float16, torch.float32, torch.int16])
+@pytest.mark.parametrize("param_dtype", [torch.float16, torch.float32])
+def test_linear_quantizer_initialisation_behaviour(quantized_dtype, param_dtype):
+    data = torch.rand(32, 14, 17)
+    quantizer = ff.nn.LinearQuantizer(2, symmetric=False, quantized_dtype=quantized_dtype, param_dtype=param_dtype)
+    with pytest.raises(ValueError, match="uninitialized quantizer"):
+        quantizer(data)
+    assert quantizer.has_uninitialized_params and quantizer.quantization_range == (None, None)
+    quantizer.quantization_range = (data.min(), data.max())
+    q = quantizer(data)
+    assert isinstance(q, ff.QuantizedTensor) and q.raw_data.dtype == quantized_dtype
+    assert all(p.dtype == param_dtype for p in quantizer.parameters())
+
+
+def test_linear_quantizer_range_setter_errors_and_defaults():
+    quantizer = ff.nn.LinearQuantizer(2, symmetric=False)
+    lo, hi = torch.tensor(0.1), torch.tensor(0.9)
+    with pytest.raises(ValueError):
+        quantizer.quantization_range = (lo, hi, hi)
+    with pytest.raises(ValueError):
+        quantizer.quantization_range = lo
+    quantizer.quantization_range = (lo, hi)
+    assert not quantizer.has_uninitialized_params
+    # defaults of the reference: symmetric, one-sided allowed, offset is a BUFFER; None when not allowed
+    default = ff.nn.LinearQuantizer(8)
+    assert default.symmetric and "offset" in default._buffers and isinstance(default.granularity, ff.PerTensor)
+    assert ff.nn.LinearQuantizer(8, allow_one_sided=False).offset is None
+    assert isinstance(ff.nn.LinearQuantizer(8, symmetric=False).offset, torch.nn.Parameter)
+    default.quantization_range = (-1.0, 2.0)
+    assert torch.equal(default.offset, torch.zeros(1)) and default.offset.dtype == torch.float32
+    lo_, hi_ = default.quantization_range
+    torch.testing.assert_close(hi_, torch.tensor([2.0]))
+
+
+@pytest.mark.parametrize("channel_dim", [(0,), (1,), (2,), (0, 1), (0, 2), (1, 2), (0, 1, 2)])
+@pytest.mark.parametrize("data_shape", [(3, 4, 9), (32, 14, 17)])
+def test_parameter_count_must_match_tile_count(data_shape, channel_dim):
+    data = torch.rand(data_shape)
+    n = math.prod(data.shape[d] for d in channel_dim)
+    good = ff.nn.LinearQuantizer(2, symmetric=False, granularity=ff.PerChannel(channel_dim))
+    good.quantization_range = (torch.zeros(n), torch.ones(n))
+    assert good(data) is not None
+    bad = ff.nn.LinearQuantizer(2, symmetric=False, granularity=ff.PerChannel(channel_dim))
+    bad.quantization_range = (torch.zeros(2), torch.ones(2))
+    with pytest.raises(RuntimeError):
+        bad(data)
+
+
+def test_per_channel_equals_stack_of_per_tensor():
+    g = torch.Generator().manual_seed(3)
+    data = torch.randn(6, 10, generator=g)
+    scale, offset = torch.rand(6, generator=g) + 0.1, torch.randn(6, generator=g)
+    whole = ff.quantization.affine.quantize_per_channel(data, scale, offset, 0, 3)
+    for r in range(6):
+        row = ff.quantization.affine.quantize_per_tensor(data[r], scale[r : r + 1], offset[r : r + 1], 3)
+        assert torch.equal(whole.raw_data[r], row.raw_data)
+        assert torch.equal(whole.dequantize()[r], row.dequantize())
+
+
+def test_precision_guard_and_type_errors():
+    with pytest.raises(RuntimeError, match="not enough"):
+        ff.quantization.affine.quantize_by_tile(torch.tensor([257.0]), torch.tensor([1.0]), torch.tensor([0.0]), torch.Size((1,)), 16, output_dtype=torch.bfloat16)
+    with pytest.raises(ValueError):  # rank mismatch between tile and data
+        ff.quantization.affine.quantize_by_tile(torch.zeros(4, 4), torch.ones(1), None, torch.Size((4,)), 8)
+    dyn = ff.quantization.affine.dynamic.quantization_context(ff.PerTensor(), 8)
+    with pytest.raises(TypeError, match="dynamic"):
+        AffineQuantizationFunction.dequantize(torch.zeros(3), dyn.quantization_params)
+    with pytest.raises(TypeError):
+        AffineQuantizationFunction.quantize(torch.zeros(3), object())
+    with pytest.raises(QuantizationError):
+        ff.quantization.affine.dynamic.quantize_per_tensor(torch.zeros(0), 8)
+
+
+def test_dynamic_equals_static_with_minmax_range():
+    g = torch.Generator().manual_seed(11)
+    data = torch.randn(8, 20, generator=g)
+    for symmetric in (False, True):
+        dyn = ff.quantization.affine.dynamic.quantize_per_channel(data, 0, 4, symmetric=symmetric)
+        lo, hi = data.min(1).values, data.max(1).values
+        scale, offset = ff.quantization.affine.parameters_for_range(lo, hi, 4, symmetric=symmetric, allow_one_sided=True)
+        stat = ff.quantization.affine.quantize_per_channel(data, scale, offset, 0, 4)
+        assert torch.equal(dyn.raw_data, stat.raw_data)
+        assert torch.equal(dyn.dequantize(), stat.dequantize())
+
+
+def test_gradients_flow_through_the_backward_op():
+    data = torch.linspace(-8, 8, 17, requires_grad=True)
+    scale, offset = torch.tensor([2.0], requires_grad=True), torch.tensor([2.3], requires_grad=True)
+    params = StaticAffineQuantParams(scale=scale, offset=offset, num_bits=2, granularity=ff.PerTensor())
+    q = AffineQuantizationFunction.quantize(data, params)
+    q.dequantize().sum().backward()
+    for t in (data, scale, offset):
+        assert t.grad is not None and torch.count_nonzero(t.grad)
+    # straight-through inside the grid, zero on clipped elements
+    inside = (torch.round(data.detach() / 2.0 - 2.0) >= -2) & (torch.round(data.detach() / 2.0 - 2.0) <= 1)
+    assert torch.equal(data.grad != 0, inside)
+
+
+# ---- QuantizedTensor -----------------------------------------------------------------------------------
+def test_quantized_tensor_routing_and_strictness():
+    q = ff.quantization.affine.quantize_per_tensor(torch.randn(4, 6), torch.tensor([0.05]), None, 8)
+    assert isinstance(q, ff.QuantizedTensor) and q.shape == (4, 6) and q.dtype == torch.float32
+    assert not isinstance(q.raw_data, ff.QuantizedTensor) and q.int_repr() is not q
+    with pytest.raises(QuantizationError, match="strict_quantization"):
+        torch.relu(q)
+    with ff.strict_quantization(False):
+        torch.testing.assert_close(torch.relu(q), torch.relu(q.dequantize()))
+        assert q.float().dtype == torch.float32 and q.double().dtype == torch.float64
+        assert q.to(torch.float16).dtype == torch.float16
+    with pytest.raises(NotImplementedError):
+        q[0]
+    with pytest.raises(NotImplementedError):
+        q.add_(1)
+    with pytest.warns(UserWarning):
+        assert q.is_quantized is False
+    assert isinstance(q.view(4, 6), ff.QuantizedTensor) and isinstance(q.reshape(6, 4), ff.QuantizedTensor)
+    assert isinstance(q.contiguous(), ff.QuantizedTensor)
+    assert isinstance(q.transpose(0, 1).contiguous(), ff.QuantizedTensor)
+    c = q.clone()
+    assert torch.equal(c.raw_data, q.raw_data) and c.quant_args().scale is not q.quant_args().scale
+    d = copy.deepcopy(q)
+    assert torch.equal(d.dequantize(), q.dequantize())
+    r = pickle.loads(pickle.dumps(q))
+    assert isinstance(r, ff.QuantizedTensor) and torch.equal(r.dequantize(), q.dequantize())
+    assert "quant_func=AffineQuantizationFunction" in repr(q)
+    with pytest.raises(ValueError):
+        q.to(torch.zeros(1))
+
+
+def test_per_channel_view_requires_same_shape():
+    q = ff.quantization.affine.quantize_per_channel(torch.randn(4, 6), torch.ones(4), None, 0, 8)
+    assert isinstance(q.view(4, 6), ff.QuantizedTensor)  # same shape: always allowed
+    with pytest.raises(QuantizationError):
+        q.view(6, 4)  # no kernel for per-channel reshape -> dequantization fallback -> strict error
+
+
+# ---- modules: conversion, overrides, estimators ------------------------------------------------------------
+def make_model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Linear(32, 8, bias=False))
+
+
+def test_quantize_model_swaps_classes_and_creates_stubs():
+    model = ff.quantize_model(make_model())
+    assert type(model).__name__ == "QuantizedSequential" and isinstance(model[0], ff.nn.QuantizedLinear)
+    lin = model[0]
+    for name, tag in (("input_quantizer", "activation/input"), ("weight_quantizer", "parameter/weight"), ("bias_quantizer", "parameter/bias"), ("output_quantizer", "activation/output")):
+        stub = getattr(lin, name)
+        assert isinstance(stub, ff.nn.QuantizerStub) and tag in stub.quant_metadata and tag.split("/")[0] in stub.quant_metadata
+    assert lin.weight_quantizer.quant_metadata.shape == lin.weight.shape
+    assert model[1].bias_quantizer is None
+    assert list(ff.nn.named_quantizers(model)) == [] and len(list(ff.nn.named_quantizers(model, skip_stubs=False))) == 7
+    x = torch.randn(3, 16)
+    with ff.strict_quantization(False):
+        torch.testing.assert_close(model(x), make_model()(x))  # stubs are identities
+    with pytest.raises(QuantizationError, match="no quantized version"):
+        ff.quantize_model(torch.nn.Sequential(torch.nn.Conv2d(1, 1, 1)))
+    surrogate = ff.nn.surrogate_quantized_modules(torch.nn.Sequential(torch.nn.Tanh()))
+    assert torch.nn.Tanh in surrogate
+    ff.quantize_model(torch.nn.Sequential(torch.nn.Tanh()), extra_conversion=surrogate)
+
+
+def test_strict_quantization_of_quantized_linear():
+    model = ff.quantize_model(make_model())
+    with pytest.raises(QuantizationError):
+        model(torch.randn(3, 16))  # strict by default: stubs do not produce QuantizedTensors
+
+
+def test_override_stack_order_and_removal():
+    quantizer = ff.nn.QuantizerStub()
+    calls = []
+
+    def make(tag):
+        def fn(ctx, nxt, args, kwargs):
+            calls.append(tag)
+            return nxt(*args, **kwargs) + 1
+
+        return fn
+
+    h1, h2 = quantizer.register_override(make("first")), quantizer.register_override(make("second"))
+    assert quantizer(torch.zeros(1)).item() == 2 and calls == ["second", "first"]
+    h2.remove()
+    calls.clear()
+    assert quantizer(torch.zeros(1)).item() == 1 and calls == ["first"]
+    with h1:
+        pass
+    assert quantizer(torch.zeros(1)).item() == 0 and list(quantizer.overrides) == []
+
+
+def test_disable_and_enable_quantization():
+    model = ff.quantize_model(make_model())
+    model[0].input_quantizer = ff.nn.LinearQuantizer(4)
+    model[0].input_quantizer.quantization_range = (-1.0, 1.0)
+    x = torch.randn(3, 16)
+    with ff.disable_quantization(model):
+        assert not ff.get_strict_quantization()
+        assert not isinstance(model[0].input_quantizer(x), ff.QuantizedTensor)
+        with ff.enable_quantization(model):
+            assert isinstance(model[0].input_quantizer(x), ff.QuantizedTensor)
+    assert ff.get_strict_quantization() and isinstance(model[0].input_quantizer(x), ff.QuantizedTensor)
+
+
+def test_running_minmax_matches_reference_test_values():
+    """tests/range_setting/test_minmax.py:41-87: five scaled batches, per tensor and per channel."""
+    g = torch.Generator().manual_seed(1)
+    base = torch.randn(10, 12, generator=g)
+    batches = [base * (i + 1) for i in range(5)]
+    for gran, reduce_dims in ((ff.PerTensor(), None), (ff.PerChannel(0), 1)):
+        quantizer = ff.nn.LinearQuantizer(8, symmetric=False, granularity=gran)
+        with ff.estimate_ranges(torch.nn.ModuleList([quantizer]), ff.range_setting.running_minmax):
+            for b in batches:
+                out = quantizer(b)
+                assert isinstance(out, ff.QuantizedTensor)
+        stacked = torch.stack(batches)
+        lo = stacked.min() if reduce_dims is None else stacked.amin((0, 2))
+        hi = stacked.max() if reduce_dims is None else stacked.amax((0, 2))
+        got_lo, got_hi = quantizer.quantization_range
+        torch.testing.assert_close(got_lo.reshape(lo.shape), lo, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(got_hi.reshape(hi.shape), hi, rtol=1e-5, atol=1e-5)
+        assert list(quantizer.overrides) == []
+
+
+def test_disable_quantization_estimation_passes_data_through():
+    quantizer = ff.nn.LinearQuantizer(8)
+    with ff.estimate_ranges(torch.nn.ModuleList([quantizer]), ff.range_setting.running_minmax, disable_quantization=True):
+        out = quantizer(torch.randn(4, 4))
+    assert not isinstance(out, ff.QuantizedTensor) and not quantizer.has_uninitialized_params
+
+
+def test_estimator_rejects_instances_with_args_and_unsupported_quantizers():
+    with pytest.raises(ValueError):
+        with ff.estimate_ranges(torch.nn.ModuleList(), ff.range_setting.running_minmax(), True):
+            pass
+    with pytest.raises(TypeError):
+        with ff.estimate_ranges(torch.nn.ModuleList([ff.nn.DynamicLinearQuantizer(8)]), ff.range_setting.running_minmax):
+            pass
+
+
+def test_smoothed_minmax():
+    quantizer = ff.nn.LinearQuantizer(8, symmetric=False)
+    a, b = torch.tensor([-1.0, 2.0]), torch.tensor([-3.0, 1.0])
+    with ff.estimate_ranges(torch.nn.ModuleList([quantizer]), ff.range_setting.smoothed_minmax, gamma=0.5):
+        quantizer(a), quantizer(b)
+    lo, hi = quantizer.quantization_range
+    torch.testing.assert_close(lo, torch.tensor([-2.0])), torch.testing.assert_close(hi, torch.tensor([1.5]))
+
+
+def test_flags_setters_return_restoring_contexts():
+    assert ff.get_strict_quantization()
+    with ff.strict_quantization(False):
+        assert not ff.get_strict_quantization()
+    assert ff.get_strict_quantization()
+    ff.set_strict_quantization(False)
+    assert not ff.get_strict_quantization()
+
+    @ff.flags.context(ff.strict_quantization, True)
+    def inner():
+        return ff.get_strict_quantization()
+
+    assert inner() and not ff.get_strict_quantization()
+
+
+def test_no_cpu_fallback_in_the_product(hip_lib):
+    """With the real library active, host tensors are refused loudly."""
+    from conftest import use_backend
+
+    with use_backend(hip_lib):
+        with pytest.raises(BackendError, match="no CPU"):
+            ff.quantization.affine.quantize_per_tensor(torch.randn(4), 0.1, None, 8)
+        with pytest.raises(BackendError):
+            ff.ops.minmax_by_tile(torch.randn(4), (4,))

@@ -1,0 +1,47 @@
+"""Pins the C oracle to the reference: every fixture produced by the reference must be reproduced.
+
+CPU only. The fixtures come from tests/golden/gen_golden.py (the reference imported and run in the
+build container) and include the known-answer vectors of the reference's own test-suite.
+"""
+
+import pytest
+
+import parity_cases
+
+
+@pytest.fixture(autouse=True)
+def _backend(oracle_backend):
+    yield
+
+
+def test_known_answer_vectors():
+    parity_cases.check_known_answers("cpu")
+
+
+def test_ties_clamps_nan_inf_negative_zero():
+    parity_cases.check_edges("cpu")
+
+
+def test_random_sweeps_all_granularities():
+    parity_cases.check_sweeps("cpu")
+
+
+def test_mixed_dtype_sweep():
+    parity_cases.check_dtype_sweep("cpu")
+
+
+def test_parameters_for_range():
+    parity_cases.check_ranges("cpu")
+
+
+@pytest.mark.parametrize("sync_free", [False, True])
+def test_running_minmax_trajectories(sync_free):
+    parity_cases.check_running_minmax("cpu", sync_free=sync_free)
+
+
+def test_int4_codes_and_q4_0_nibble_order():
+    parity_cases.check_int4("cpu")
+
+
+def test_quantized_linear_w8a8():
+    parity_cases.check_linear("cpu")

@@ -1,0 +1,294 @@
+"""Parity of the HIP kernels (through the C ABI of libffq_hip.so) on an MI355X.
+
+Three layers:
+  1. the golden fixtures produced by the reference (same checks as tests/test_oracle_golden.py);
+  2. HIP vs the C oracle on seeded random inputs at sizes the oracle finishes in seconds,
+     covering every kernel family (stream / columns / generic; rows / split / columns reductions);
+  3. size-independent properties at BASELINE.json's full sizes (Llama-3-8B weight shapes and
+     [8, 2048, 14336] activations): quantize->dequantize->quantize idempotence, code range,
+     dynamic == static-with-minmax, per-channel == stack of per-tensor, pack round trip.
+Integer codes must match bit-for-bit; dequantized floats bit-for-bit as well (same IEEE ops).
+"""
+
+import os
+
+import pytest
+import torch
+
+import fastforward_amd as ff
+import parity_cases
+
+from conftest import load_oracle, use_backend
+from fastforward_amd import ops
+from helpers import mismatch_report, same_with_nan
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _backend(hip_backend):
+    yield
+
+
+# ---- 1. golden fixtures -------------------------------------------------------------------------
+def test_known_answer_vectors():
+    parity_cases.check_known_answers(DEV)
+
+
+def test_ties_clamps_nan_inf_negative_zero():
+    parity_cases.check_edges(DEV)
+
+
+def test_random_sweeps_all_granularities():
+    parity_cases.check_sweeps(DEV)
+
+
+def test_mixed_dtype_sweep():
+    parity_cases.check_dtype_sweep(DEV)
+
+
+def test_parameters_for_range():
+    parity_cases.check_ranges(DEV)
+
+
+@pytest.mark.parametrize("sync_free", [False, True])
+def test_running_minmax_trajectories(sync_free):
+    parity_cases.check_running_minmax(DEV, sync_free=sync_free)
+
+
+def test_int4_codes_and_q4_0_nibble_order():
+    parity_cases.check_int4(DEV)
+
+
+def test_quantized_linear_w8a8():
+    parity_cases.check_linear(DEV)
+
+
+def test_golden_sweeps_with_ieee_division_kernels(monkeypatch):
+    """FFQ_DIV_MODE is read once per process; the generic kernels always use the IEEE sequence."""
+    monkeypatch.setenv("FFQ_FORCE_GENERIC", "1")
+    parity_cases.check_sweeps(DEV, name_filter=lambda n: "sweep3d" in n)
+
+
+# ---- 2. HIP vs oracle on seeded inputs ------------------------------------------------------------
+def _both(fn):
+    """Run fn(device) with the HIP backend on cuda and with the oracle on cpu."""
+    got = fn(DEV)
+    with use_backend(load_oracle()):
+        want = fn("cpu")
+    return got, want
+
+
+SHAPES_AND_GRANULARITIES = [
+    ((7, 33), ff.PerTensor()),                      # scalar layout with a tail (231 % 8 != 0)
+    ((1,), ff.PerTensor()),
+    ((64, 1000), ff.PerChannel(0)),                 # rows, 1000 % 8 == 0
+    ((64, 1001), ff.PerChannel(0)),                 # rows that split chunks -> generic
+    ((512, 4096), ff.PerChannel(0)),
+    ((96, 2048), ff.PerChannel(-1)),                # columns kernel
+    ((33, 72), ff.PerChannel(-1)),
+    ((10, 12, 64), ff.PerChannel(1)),               # channel with inner 64
+    ((10, 12, 64), ff.PerChannel((0, 2))),          # generic
+    ((128, 1024), ff.PerBlock(1, 128, 0)),          # group 128
+    ((128, 1024), ff.PerBlock(1, 32, 0)),
+    ((6, 40, 96), ff.PerTile((3, 8, 32))),          # generic tiles
+    ((4, 128, 4096), ff.PerChannel((0, 1))),        # per-token activations
+    ((3, 5, 7), ff.PerTile((1, 1, 1))),             # per element
+]
+
+
+@pytest.mark.parametrize("shape,gran", SHAPES_AND_GRANULARITIES, ids=lambda v: str(v))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize("num_bits,symmetric", [(8, True), (8, False), (4, False), (3, True)])
+def test_static_quantize_dequantize_matches_oracle(shape, gran, dtype, num_bits, symmetric):
+    g = torch.Generator().manual_seed(hash((shape, num_bits, symmetric)) & 0xFFFF)
+    x = (torch.randn(*shape, generator=g) * 2).to(dtype)
+    x.view(-1)[0] = float("nan")
+    if x.numel() > 3:
+        x.view(-1)[1] = float("inf")
+        x.view(-1)[2] = -0.0
+    n = gran.parameter_dimensionality(x.shape)
+    scale = torch.rand(n, generator=g) * 0.05 + 0.01
+    offset = None if symmetric else torch.randn(n, generator=g) * 20
+
+    def run(device):
+        outs = []
+        for qdt in (None, torch.int8, torch.int32):
+            q = ff.quantization.affine.quantize_per_granularity(
+                x.to(device), scale.to(device), None if offset is None else offset.to(device), gran, num_bits, qdt
+            )
+            outs += [q.raw_data.cpu(), q.dequantize().cpu()]
+        return outs
+
+    got, want = _both(run)
+    for a, b in zip(got, want):
+        assert a.dtype == b.dtype
+        assert same_with_nan(a, b), mismatch_report(a, b)
+
+
+@pytest.mark.parametrize("shape,gran", SHAPES_AND_GRANULARITIES, ids=lambda v: str(v))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_minmax_and_dynamic_quantize_match_oracle(shape, gran, dtype):
+    g = torch.Generator().manual_seed(len(shape) * 131 + shape[0])
+    x = (torch.randn(*shape, generator=g) * 3).to(dtype)
+
+    def run(device):
+        xd = x.to(device)
+        tile = gran.tile_size(xd.shape)
+        tile = xd.shape if isinstance(tile, str) else tile
+        lo, hi = ops.minmax_by_tile(xd, tile)
+        outs = [lo.cpu(), hi.cpu()]
+        lo2, hi2 = (lo * 0.5).contiguous(), (hi * 0.5).contiguous()
+        flags = torch.zeros(1, dtype=torch.int32, device=device)
+        ops.minmax_by_tile(xd, tile, running_min=lo2, running_max=hi2, status_flags=flags)
+        outs += [lo2.cpu(), hi2.cpu(), flags.cpu()]
+        for symmetric in (True, False):
+            q = ff.quantization.affine.dynamic.quantize_per_granularity(xd, gran, 8, symmetric=symmetric, output_dtype=torch.int8)
+            p = q.quantization_context.quantization_params
+            outs += [q.raw_data.cpu(), p.scale.cpu(), p.offset.cpu(), q.dequantize().cpu()]
+        return outs
+
+    got, want = _both(run)
+    for a, b in zip(got, want):
+        assert same_with_nan(a, b), mismatch_report(a, b)
+
+
+def test_minmax_flags_inf_and_nan():
+    x = torch.randn(64, 256, device=DEV, dtype=torch.bfloat16)
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.minmax_by_tile(x, (1, 256), status_flags=flags)
+    assert flags.item() == 0
+    x[3, 5] = float("inf")
+    ops.minmax_by_tile(x, (1, 256), status_flags=flags)
+    assert flags.item() == ops.FLAG_INF
+    x[7, 9] = float("nan")
+    lo, hi = ops.minmax_by_tile(x, (1, 256), status_flags=flags)
+    assert flags.item() == ops.FLAG_INF | ops.FLAG_NAN
+    assert lo[7].isnan() and hi[7].isnan() and hi[3].isinf() and not lo[0].isnan()
+
+
+def test_running_minmax_raises_on_infinite_like_reference():
+    quantizer = ff.nn.LinearQuantizer(8, device=DEV)
+    model = torch.nn.ModuleList([quantizer])
+    x = torch.randn(4, 32, device=DEV)
+    x[0, 0] = float("inf")
+    with pytest.raises(NotImplementedError, match="Infinite"):
+        with ff.estimate_ranges(model, ff.range_setting.running_minmax):
+            quantizer(x)
+    quantizer2 = ff.nn.LinearQuantizer(8, device=DEV)
+    with pytest.raises(NotImplementedError, match="Infinite"):
+        with ff.estimate_ranges(torch.nn.ModuleList([quantizer2]), ff.range_setting.running_minmax, sync_free=True):
+            quantizer2(x)  # deferred: raised when the context exits
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 16, 16), (96, 200, 144), (256, 384, 512), (300, 130, 4096), (17, 1000, 256)])
+@pytest.mark.parametrize("x_per_row,w_per_row,x_off,w_off", [(0, 1, True, False), (0, 0, False, False), (1, 1, True, True), (0, 1, False, True)])
+def test_w8a8_linear_exact_integer_math(m, n, k, x_per_row, w_per_row, x_off, w_off):
+    """The contraction is exact: compare with an int64 matmul of the same codes, fp32 epilogue."""
+    g = torch.Generator().manual_seed(m * 7 + n)
+    xq = torch.randint(-128, 128, (m, k), generator=g, dtype=torch.int8)
+    wq = torch.randint(-128, 128, (n, k), generator=g, dtype=torch.int8)
+    sx = torch.rand(m if x_per_row else 1, generator=g) * 0.02 + 0.001
+    sw = torch.rand(n if w_per_row else 1, generator=g) * 0.02 + 0.001
+    ox = torch.randn(m if x_per_row else 1, generator=g) * 30 if x_off else None
+    ow = torch.randn(n if w_per_row else 1, generator=g) * 3 if w_off else None
+    bias = torch.randn(n, generator=g)
+    y = ops.linear_w8a8(xq.to(DEV), wq.to(DEV), sx.to(DEV), None if ox is None else ox.to(DEV), sw.to(DEV),
+                        None if ow is None else ow.to(DEV), bias=bias.to(DEV), out_dtype=torch.float32).cpu()
+    xi = xq.double() + (torch.round(ox).double()[:, None] if ox is not None and x_per_row else (torch.round(ox).double() if ox is not None else 0))
+    wi = wq.double() + (torch.round(ow).double()[:, None] if ow is not None and w_per_row else (torch.round(ow).double() if ow is not None else 0))
+    ref = (xi @ wi.T) * (sx.double()[:, None] if x_per_row else sx.double()) * (sw.double()[None, :] if w_per_row else sw.double()) + bias.double()
+    torch.testing.assert_close(y.double(), ref, rtol=2e-6, atol=2e-6 * float(ref.abs().max()))
+
+
+def test_w8a8_linear_matches_oracle_bf16():
+    g = torch.Generator().manual_seed(5)
+    xq = torch.randint(-128, 128, (40, 256), generator=g, dtype=torch.int8)
+    wq = torch.randint(-128, 128, (72, 256), generator=g, dtype=torch.int8)
+    sx, ox = torch.tensor([0.013]), torch.tensor([-11.4])
+    sw = torch.rand(72, generator=g) * 0.01 + 0.001
+
+    def run(device):
+        return [ops.linear_w8a8(xq.to(device), wq.to(device), sx.to(device), ox.to(device), sw.to(device), None, out_dtype=torch.bfloat16).cpu()]
+
+    got, want = _both(run)
+    # oracle = the reference's dequantize-then-float-GEMM semantics evaluated exactly
+    torch.testing.assert_close(got[0].float(), want[0].float(), atol=1e-1, rtol=1.3e-2)
+
+
+def test_fused_linear_is_dispatched_for_both_call_paths():
+    lin = torch.nn.Linear(128, 64, bias=False).to(DEV, torch.bfloat16)
+    x = torch.randn(8, 128, device=DEV, dtype=torch.bfloat16)
+    wq = ff.quantization.affine.quantize_per_channel(lin.weight, torch.full((64,), 0.01, device=DEV), None, 0, 8, torch.int8)
+    xq = ff.quantization.affine.quantize_per_tensor(x, torch.tensor([0.03], device=DEV), torch.tensor([3.0], device=DEV), 8, torch.int8)
+    assert ff.dispatcher.dispatch("linear", xq, wq) is ff.fused_linear.fused_linear
+    with ff.strict_quantization(False):
+        a = torch.nn.functional.linear(xq, wq)           # __torch_function__ path (positional)
+        b = ff.nn.functional.linear(xq, wq)              # functional path (keywords)
+        ref = torch.nn.functional.linear(xq.dequantize(), wq.dequantize())
+    assert torch.equal(a, b)
+    torch.testing.assert_close(a.float(), ref.float(), atol=1e-1, rtol=1.3e-2)
+
+
+# ---- 3. properties at full BASELINE sizes -----------------------------------------------------------
+LLAMA8B_WEIGHTS = [(4096, 4096), (1024, 4096), (14336, 4096), (4096, 14336)]
+
+
+@pytest.mark.parametrize("shape", LLAMA8B_WEIGHTS, ids=str)
+def test_full_size_weight_properties(shape):
+    torch.manual_seed(1234 + shape[0])
+    w = (torch.randn(shape, device=DEV) * 0.02).to(torch.bfloat16)
+    quantizer = ff.nn.LinearQuantizer(8, granularity=ff.PerChannel(0), quantized_dtype=torch.int8, device=DEV)
+    with ff.estimate_ranges(torch.nn.ModuleList([quantizer]), ff.range_setting.running_minmax, sync_free=True):
+        q = quantizer(w)
+    codes = q.raw_data
+    # symmetric per-channel 8-bit from the row min/max: every row reaches +-127/-128 exactly once at least
+    assert codes.dtype == torch.int8 and int(codes.max()) == 127 or int(codes.min()) == -128
+    amax = w.float().abs().amax(1)
+    assert torch.equal(codes.float().abs().amax(1) >= 127, torch.ones_like(amax, dtype=torch.bool))
+    # scale reproduces parameters_for_range on the row extrema
+    lo, hi = w.float().amin(1), w.float().amax(1)
+    assert torch.equal(quantizer.scale.detach(), torch.maximum(lo.abs() / 128, hi.abs() / 127))
+    # quantize(dequantize(q)) == q  (idempotence) and |x - x^| <= scale/2 (+ bf16 rounding)
+    deq = q.dequantize()
+    again = quantizer(deq).raw_data
+    assert torch.equal(again, codes)
+    err = (w.float() - deq.float()).abs()
+    bound = quantizer.scale.detach()[:, None] * 0.5 + deq.float().abs() * 2.0**-8
+    assert bool((err <= bound).all())
+    # bf16 container holds the same integers
+    quantizer.quantized_dtype = None
+    assert torch.equal(quantizer(w).raw_data.to(torch.int8), codes)
+    # per-channel == stack of per-tensor on a few rows (tests/nn/test_linear_quantizer.py:246-276)
+    for r in (0, shape[0] // 2, shape[0] - 1):
+        row = ff.quantization.affine.quantize_per_tensor(w[r], quantizer.scale.detach()[r : r + 1], None, 8, torch.int8)
+        assert torch.equal(row.raw_data, codes[r])
+    # int4 pack round trip on the real shape (group 128)
+    q4 = ff.quantization.affine.dynamic.quantize_per_granularity(w, ff.PerBlock(1, 128, 0), 4, symmetric=True, output_dtype=torch.int8)
+    packed = ops.pack_int4(q4.raw_data, block=128)
+    assert packed.numel() == w.numel() // 2
+    assert torch.equal(ops.unpack_int4(packed, w.shape, torch.int8, block=128), q4.raw_data)
+
+
+@pytest.mark.parametrize("hidden", [4096, 14336])
+def test_full_size_activation_properties(hidden):
+    torch.manual_seed(99)
+    x = torch.randn(8, 2048, hidden, device=DEV, dtype=torch.bfloat16)
+    quantizer = ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=torch.int8, device=DEV)
+    with ff.estimate_ranges(torch.nn.ModuleList([quantizer]), ff.range_setting.running_minmax, sync_free=True):
+        q = quantizer(x)
+    lo, hi = x.float().min(), x.float().max()
+    scale = ((hi - lo) / 255).clamp(torch.finfo(torch.float32).eps)
+    assert torch.equal(quantizer.scale.detach(), scale.reshape(1))
+    assert torch.equal(quantizer.offset.detach(), (lo / scale + 128).reshape(1))
+    assert int(q.raw_data.min()) == -128 and int(q.raw_data.max()) == 127
+    # dynamic quantization == static quantization with the min/max range (tests/quantization/test_dynamic.py:13-30)
+    dyn = ff.quantization.affine.dynamic.quantize_per_tensor(x, 8, symmetric=False, output_dtype=torch.int8)
+    assert torch.equal(dyn.raw_data, q.raw_data)
+    # checksum of codes against a chunked recomputation with plain torch ops in fp32
+    off = torch.round(quantizer.offset.detach())
+    total = 0
+    for chunk in x.chunk(8):
+        total += int(torch.clamp(torch.round(chunk.float() / quantizer.scale.detach() - off), -128, 127).sum(dtype=torch.int64))
+    assert int(q.raw_data.sum(dtype=torch.int64)) == total
