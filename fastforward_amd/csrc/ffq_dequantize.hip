@@ -42,6 +42,7 @@ __global__ __launch_bounds__(kBlock) void dequantize_stream_kernel(const TIn* __
                                                                    DqStreamArgs a) {
   const uint32_t first = blockIdx.x * (uint32_t)(kBlock * U) + threadIdx.x;
   Chunk<TIn, E> x[U];
+  float s[U], o[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t c = first + u * kBlock;
@@ -50,15 +51,24 @@ __global__ __launch_bounds__(kBlock) void dequantize_stream_kernel(const TIn* __
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t c = first + u * kBlock;
+    s[u] = 1.0f;
+    o[u] = 0.0f;
+    if (c < a.nchunks) {
+      const uint32_t t = dq_tile_of_chunk<LAYOUT>(c, a);
+      s[u] = scale[t * a.scale_stride];
+      if constexpr (HAS_OFFSET) o[u] = offset[t * a.offset_stride];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t c = first + u * kBlock;
     if (c >= a.nchunks) continue;
-    const uint32_t t = dq_tile_of_chunk<LAYOUT>(c, a);
-    const float s = scale[t * a.scale_stride];
-    const float o = HAS_OFFSET ? rne(offset[t * a.offset_stride]) : 0.0f;
+    const float off = HAS_OFFSET ? rne(o[u]) : 0.0f;
     float v[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) {
-      float q = x[u].get(i) + o;
-      v[i] = q * s;
+      float q = x[u].get(i) + off;
+      v[i] = q * s[u];
     }
     Chunk<TOut, E> y;
     y.pack(v);
@@ -153,7 +163,7 @@ template <typename TIn, typename TOut, int E>
 static int dq_launch_stream(const TIn* in, TOut* out, const float* scale, int64_t scale_numel,
                             const float* offset, int64_t offset_numel, const TileInfo& info,
                             hipStream_t stream) {
-  constexpr int U = 4;
+  constexpr int U = (E * (int)sizeof(TIn) >= 16 && E * (int)sizeof(TOut) >= 32) ? 2 : 4;
   DqStreamArgs a;
   a.nchunks = (uint32_t)(info.numel / E);
   a.scale_stride = scale_numel == 1 ? 0u : 1u;
@@ -207,15 +217,11 @@ static int dq_launch_columns(const TIn* in, TOut* out, const float* scale, int64
   return check_launch("dequantize_columns_kernel");
 }
 
-template <typename TIn, typename TOut>
-static int dq_dispatch_fast(const void* data, const void* scale, int64_t scale_numel, const void* offset,
-                            int64_t offset_numel, const TileInfo& info, void* out, hipStream_t stream,
-                            int64_t* done) {
-  // 16 elements per chunk for 1-byte codes keeps the load at 16 B per lane
-  constexpr int E = sizeof(TIn) == 1 ? 16 : 8;
+template <typename TIn, typename TOut, int E>
+static int dq_dispatch_fast_e(const void* data, const void* scale, int64_t scale_numel, const void* offset,
+                              int64_t offset_numel, const TileInfo& info, void* out, hipStream_t stream,
+                              int64_t* done) {
   *done = 0;
-  if (info.numel >= ((int64_t)1 << 32) - 4096) return FFQ_OK;
-  if (!aligned16(data) || !aligned16(out)) return FFQ_OK;
   const TIn* in = static_cast<const TIn*>(data);
   TOut* o = static_cast<TOut*>(out);
   const float* s = static_cast<const float*>(scale);
@@ -226,9 +232,28 @@ static int dq_dispatch_fast(const void* data, const void* scale, int64_t scale_n
     *done = info.layout == LAYOUT_SCALAR ? (info.numel / E) * E : info.numel;
     return dq_launch_stream<TIn, TOut, E>(in, o, s, scale_numel, f, offset_numel, info, stream);
   }
-  if (info.layout == LAYOUT_CHANNEL && info.inner == 1 && info.channels % E == 0) {
+  return FFQ_OK;
+}
+
+template <typename TIn, typename TOut>
+static int dq_dispatch_fast(const void* data, const void* scale, int64_t scale_numel, const void* offset,
+                            int64_t offset_numel, const TileInfo& info, void* out, hipStream_t stream,
+                            int64_t* done) {
+  *done = 0;
+  if (info.numel >= ((int64_t)1 << 32) - 4096) return FFQ_OK;
+  if (!aligned16(data) || !aligned16(out)) return FFQ_OK;
+  int rc = FFQ_OK;
+  if constexpr (sizeof(TIn) == 1) {  // 16 one-byte codes per chunk keep the load at 16 B per lane
+    rc = dq_dispatch_fast_e<TIn, TOut, 16>(data, scale, scale_numel, offset, offset_numel, info, out, stream, done);
+    if (rc || *done) return rc;
+  }
+  rc = dq_dispatch_fast_e<TIn, TOut, 8>(data, scale, scale_numel, offset, offset_numel, info, out, stream, done);
+  if (rc || *done) return rc;
+  if (info.layout == LAYOUT_CHANNEL && info.inner == 1 && info.channels % 8 == 0) {
     *done = info.numel;
-    return dq_launch_columns<TIn, TOut, E>(in, o, s, scale_numel, f, offset_numel, info, stream);
+    return dq_launch_columns<TIn, TOut, 8>(static_cast<const TIn*>(data), static_cast<TOut*>(out),
+                                           static_cast<const float*>(scale), scale_numel,
+                                           static_cast<const float*>(offset), offset_numel, info, stream);
   }
   return FFQ_OK;
 }

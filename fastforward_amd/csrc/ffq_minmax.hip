@@ -151,17 +151,17 @@ __global__ __launch_bounds__(kBlock) void minmax_rows_kernel(const T* __restrict
   if (t < a.ntiles) {
     const T* row = in + (size_t)t * a.chunks_per_run * E;
     uint32_t c = lane;
-    // two chunks in flight per lane
-    for (; c + P < a.chunks_per_run; c += 2 * P) {
-      Chunk<T, E> x0, x1;
-      x0.load(row + (size_t)c * E);
-      x1.load(row + (size_t)(c + P) * E);
+    // four chunks (64 B) in flight per lane
+    for (; c + 3 * P < a.chunks_per_run; c += 4 * P) {
+      Chunk<T, E> x[4];
 #pragma unroll
-      for (int i = 0; i < E; ++i) m.add(x0.get(i));
+      for (int u = 0; u < 4; ++u) x[u].load(row + (size_t)(c + u * P) * E);
 #pragma unroll
-      for (int i = 0; i < E; ++i) m.add(x1.get(i));
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < E; ++i) m.add(x[u].get(i));
     }
-    if (c < a.chunks_per_run) {
+    for (; c < a.chunks_per_run; c += P) {
       Chunk<T, E> x0;
       x0.load(row + (size_t)c * E);
 #pragma unroll

@@ -36,10 +36,14 @@ struct StreamArgs {
 // sequence: q0 = RN(x r) is within 1.5 ulp, the first residual step makes it faithful, the second
 // one makes it the correctly rounded quotient (Markstein 1990; Muller et al., Handbook of
 // Floating-Point Arithmetic, division by FMA iteration: y = RN(1/b) and q faithful imply
-// RN(q + RN(a - b q) y) = RN(a/b)). The theorem assumes no overflow/underflow, hence the guards:
-// the fast path is taken only for 2^-100 < |s| < 2^100 and its result is used only while
-// |q0| < 2^100 — beyond that every candidate clamps to the same bound and q0 carries the right
-// sign / Inf / NaN. tests/test_divide_gpu.py compares both modes bit-for-bit on adversarial data.
+// RN(q + RN(a - b q) y) = RN(a/b)). The theorem needs the residuals a - b q to be exact, i.e. no
+// underflow, hence the guards: the iteration is used only for 2^-40 < |s| < 2^40 AND
+// 2^-40 < |q0| < 2^40 (so |x| > 2^-80 and every residual bit is a normal number). Outside:
+//   |q0| >= 2^40 (or Inf/NaN): every candidate clamps to the same bound; q0 carries sign/Inf/NaN;
+//   |q0| <= 2^-40 (incl. +-0):  round(q0 - o) cannot depend on the last bit of q0; q0 keeps the
+//                               sign of the quotient, which decides between -0.0 and +0.0;
+//   |s| outside the window:     the whole chunk takes the IEEE sequence.
+// tests/test_parity_gpu.py compares both modes bit-for-bit on adversarial data.
 template <int DIVMODE>
 struct Divider {
   float s, r;
@@ -48,14 +52,15 @@ struct Divider {
     if constexpr (DIVMODE == 1) {
       r = 1.0f / s;
       const float as = __builtin_fabsf(s);
-      safe = as > 0x1p-100f && as < 0x1p100f;
+      safe = as > 0x1p-40f && as < 0x1p40f;
     }
   }
   __device__ __forceinline__ float fast(float x) const {
     const float q0 = x * r;
     const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, s, x), r, q0);
     const float q2 = __builtin_fmaf(__builtin_fmaf(-q1, s, x), r, q1);
-    return __builtin_fabsf(q0) < 0x1p100f ? q2 : q0;
+    const float a0 = __builtin_fabsf(q0);
+    return (a0 > 0x1p-40f && a0 < 0x1p40f) ? q2 : q0;
   }
 };
 
@@ -119,6 +124,8 @@ __global__ __launch_bounds__(kBlock) void quantize_stream_kernel(const TIn* __re
                                                                  StreamArgs a) {
   const uint32_t first = blockIdx.x * (uint32_t)(kBlock * U) + threadIdx.x;
   Chunk<TIn, E> x[U];
+  float s[U], o[U];
+  // all HBM loads first, then the (L2-resident) parameter loads: nothing below waits in series
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t c = first + u * kBlock;
@@ -127,14 +134,22 @@ __global__ __launch_bounds__(kBlock) void quantize_stream_kernel(const TIn* __re
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t c = first + u * kBlock;
+    s[u] = 1.0f;
+    o[u] = 0.0f;
+    if (c < a.nchunks) {
+      const uint32_t t = tile_of_chunk<LAYOUT>(c, a);
+      s[u] = scale[t * a.scale_stride];
+      if constexpr (HAS_OFFSET) o[u] = offset[t * a.offset_stride];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t c = first + u * kBlock;
     if (c >= a.nchunks) continue;
-    const uint32_t t = tile_of_chunk<LAYOUT>(c, a);
-    const float s = scale[t * a.scale_stride];
-    const float o = HAS_OFFSET ? rne(offset[t * a.offset_stride]) : 0.0f;
     float xf[E], r[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) xf[i] = x[u].get(i);
-    quantize_chunk<DIVMODE, E>(xf, s, o, r);
+    quantize_chunk<DIVMODE, E>(xf, s[u], HAS_OFFSET ? rne(o[u]) : 0.0f, r);
     Chunk<TOut, E> y;
     finalize_chunk<TOut, E>(r, a.lo, a.hi, y);
     y.store(out + (size_t)c * E);
@@ -268,7 +283,7 @@ template <typename TIn, typename TOut, int E>
 static int launch_stream(const TIn* in, TOut* out, const float* scale, int64_t scale_numel,
                          const float* offset, int64_t offset_numel, const TileInfo& info, float lo,
                          float hi, hipStream_t stream) {
-  constexpr int U = 4;
+  constexpr int U = E >= 16 ? 2 : 4;  // 64 B of input in flight per lane either way (16-bit data)
   StreamArgs a;
   a.lo = lo; a.hi = hi;
   a.nchunks = (uint32_t)(info.numel / E);
@@ -332,14 +347,11 @@ static int launch_columns(const TIn* in, TOut* out, const float* scale, int64_t 
 
 // Decide whether the streaming kernels apply: fp32 stages + fp32 parameters + 16 B alignment + a
 // layout whose tiles never split a chunk; everything else goes to the generic kernel.
-template <typename TIn, typename TOut>
-static int dispatch_fast(const void* data, const void* scale, int64_t scale_numel, const void* offset,
-                         int64_t offset_numel, const TileInfo& info, float lo, float hi, void* out,
-                         hipStream_t stream, bool* handled) {
-  constexpr int E = 8;
-  *handled = false;
-  if (info.numel >= ((int64_t)1 << 32) - 4096) return FFQ_OK;  // 32-bit chunk index
-  if (!aligned16(data) || !aligned16(out)) return FFQ_OK;
+template <typename TIn, typename TOut, int E>
+static int dispatch_fast_e(const void* data, const void* scale, int64_t scale_numel, const void* offset,
+                           int64_t offset_numel, const TileInfo& info, float lo, float hi, void* out,
+                           hipStream_t stream, int64_t* done) {
+  *done = 0;
   const TIn* in = static_cast<const TIn*>(data);
   TOut* o = static_cast<TOut*>(out);
   const float* s = static_cast<const float*>(scale);
@@ -347,12 +359,35 @@ static int dispatch_fast(const void* data, const void* scale, int64_t scale_nume
   if (info.layout == LAYOUT_SCALAR || (info.layout == LAYOUT_ROWS && info.run % E == 0) ||
       (info.layout == LAYOUT_CHANNEL && info.inner % E == 0)) {
     if (info.numel / E == 0) return FFQ_OK;
-    *handled = true;
+    // only the SCALAR layout can leave a tail (numel % E); ROWS / CHANNEL tiles are whole chunks
+    *done = info.layout == LAYOUT_SCALAR ? (info.numel / E) * E : info.numel;
     return launch_stream<TIn, TOut, E>(in, o, s, scale_numel, f, offset_numel, info, lo, hi, stream);
   }
-  if (info.layout == LAYOUT_CHANNEL && info.inner == 1 && info.channels % E == 0) {
-    *handled = true;
-    return launch_columns<TIn, TOut, E>(in, o, s, scale_numel, f, offset_numel, info, lo, hi, stream);
+  return FFQ_OK;
+}
+
+// Decide whether the streaming kernels apply: fp32 stages + fp32 parameters + 16 B alignment + a
+// layout whose tiles never split a chunk; everything else goes to the generic kernel.
+// One-byte containers use 16-element chunks so that the store is 16 B per lane as well.
+template <typename TIn, typename TOut>
+static int dispatch_fast(const void* data, const void* scale, int64_t scale_numel, const void* offset,
+                         int64_t offset_numel, const TileInfo& info, float lo, float hi, void* out,
+                         hipStream_t stream, int64_t* done) {
+  *done = 0;
+  if (info.numel >= ((int64_t)1 << 32) - 4096) return FFQ_OK;  // 32-bit chunk index
+  if (!aligned16(data) || !aligned16(out)) return FFQ_OK;
+  int rc = FFQ_OK;
+  if constexpr (sizeof(TOut) == 1) {
+    rc = dispatch_fast_e<TIn, TOut, 16>(data, scale, scale_numel, offset, offset_numel, info, lo, hi, out, stream, done);
+    if (rc || *done) return rc;
+  }
+  rc = dispatch_fast_e<TIn, TOut, 8>(data, scale, scale_numel, offset, offset_numel, info, lo, hi, out, stream, done);
+  if (rc || *done) return rc;
+  if (info.layout == LAYOUT_CHANNEL && info.inner == 1 && info.channels % 8 == 0) {
+    *done = info.numel;
+    return launch_columns<TIn, TOut, 8>(static_cast<const TIn*>(data), static_cast<TOut*>(out),
+                                        static_cast<const float*>(scale), scale_numel,
+                                        static_cast<const float*>(offset), offset_numel, info, lo, hi, stream);
   }
   return FFQ_OK;
 }
@@ -360,7 +395,7 @@ static int dispatch_fast(const void* data, const void* scale, int64_t scale_nume
 template <typename TIn>
 static int dispatch_out(int out_dt, const void* data, const void* scale, int64_t scale_numel,
                         const void* offset, int64_t offset_numel, const TileInfo& info, float lo,
-                        float hi, void* out, hipStream_t stream, bool* handled) {
+                        float hi, void* out, hipStream_t stream, int64_t* handled) {
   switch (out_dt) {
     case FFQ_F32: return dispatch_fast<TIn, float>(data, scale, scale_numel, offset, offset_numel, info, lo, hi, out, stream, handled);
     case FFQ_BF16: return dispatch_fast<TIn, bf16_t>(data, scale, scale_numel, offset, offset_numel, info, lo, hi, out, stream, handled);
@@ -368,7 +403,7 @@ static int dispatch_out(int out_dt, const void* data, const void* scale, int64_t
     case FFQ_I8: return dispatch_fast<TIn, int8_t>(data, scale, scale_numel, offset, offset_numel, info, lo, hi, out, stream, handled);
     case FFQ_I16: return dispatch_fast<TIn, int16_t>(data, scale, scale_numel, offset, offset_numel, info, lo, hi, out, stream, handled);
     case FFQ_I32: return dispatch_fast<TIn, int32_t>(data, scale, scale_numel, offset, offset_numel, info, lo, hi, out, stream, handled);
-    default: *handled = false; return FFQ_OK;
+    default: *handled = 0; return FFQ_OK;
   }
 }
 
@@ -401,18 +436,13 @@ int quantize_impl(const void* data, int data_dt, const void* scale, int scale_dt
                           (!offset || offset_dt == FFQ_F32) && getenv("FFQ_FORCE_GENERIC") == nullptr;
   int64_t done = 0;
   if (fast_types) {
-    bool handled = false;
     switch (data_dt) {
-      case FFQ_F32: rc = dispatch_out<float>(out_dt, data, scale, scale_numel, offset, offset_numel, info, (float)lo, (float)hi, out, stream, &handled); break;
-      case FFQ_BF16: rc = dispatch_out<bf16_t>(out_dt, data, scale, scale_numel, offset, offset_numel, info, (float)lo, (float)hi, out, stream, &handled); break;
-      case FFQ_F16: rc = dispatch_out<f16_t>(out_dt, data, scale, scale_numel, offset, offset_numel, info, (float)lo, (float)hi, out, stream, &handled); break;
+      case FFQ_F32: rc = dispatch_out<float>(out_dt, data, scale, scale_numel, offset, offset_numel, info, (float)lo, (float)hi, out, stream, &done); break;
+      case FFQ_BF16: rc = dispatch_out<bf16_t>(out_dt, data, scale, scale_numel, offset, offset_numel, info, (float)lo, (float)hi, out, stream, &done); break;
+      case FFQ_F16: rc = dispatch_out<f16_t>(out_dt, data, scale, scale_numel, offset, offset_numel, info, (float)lo, (float)hi, out, stream, &done); break;
       default: break;
     }
     if (rc) return rc;
-    if (handled) {
-      // only the SCALAR layout can leave a tail (numel % 8); ROWS/CHANNEL tiles are whole chunks
-      done = info.layout == LAYOUT_SCALAR ? (info.numel / 8) * 8 : info.numel;
-    }
   }
   return launch_generic(data, data_dt, scale, scale_dt, scale_numel, offset, offset_dt, offset_numel,
                         tiling, lo, hi, div_dt, sub_dt, out, out_dt, done, info.numel - done, stream);

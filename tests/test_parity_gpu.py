@@ -71,6 +71,45 @@ def test_golden_sweeps_with_ieee_division_kernels(monkeypatch):
     parity_cases.check_sweeps(DEV, name_filter=lambda n: "sweep3d" in n)
 
 
+def test_fast_division_is_bit_identical_to_ieee_division(monkeypatch):
+    """The streaming kernels' FMA-iteration divide vs the compiler's IEEE divide (generic kernel).
+
+    Quotients are placed in [2^18, 2^25) where one ulp is 1/32 ... 2, so that a last-bit error in
+    x / s changes round(x / s) — the subsequent rounding cannot hide it. 32 M (x, s) pairs with a
+    distinct scale per 8 elements, plus raw bit patterns (denormals, huge, tiny, Inf, NaN, -0.0).
+    """
+    g = torch.Generator(device=DEV).manual_seed(2024)
+    n = 4 << 20
+    regimes = []
+    for lo_exp, hi_exp in ((-30, 30), (-3, 3), (-39, -30), (30, 39)):
+        s = torch.exp2(torch.empty(n, device=DEV).uniform_(lo_exp, hi_exp, generator=g)) * torch.empty(n, device=DEV).uniform_(1, 2, generator=g)
+        q = torch.exp2(torch.empty(n, 8, device=DEV).uniform_(18, 25, generator=g)) * torch.where(torch.rand(n, 8, device=DEV, generator=g) < 0.5, -1.0, 1.0)
+        regimes.append((q * s[:, None], s))
+    # mantissa-exhaustive-ish: s with all-ones / all-zero / random mantissas
+    bits = torch.randint(0x3F000000, 0x40800000, (n,), device=DEV, generator=g, dtype=torch.int32)
+    bits[::3] |= 0x007FFFFF
+    s = bits.view(torch.float32)
+    x = torch.randint(0x49000000, 0x4B800000, (n, 8), device=DEV, generator=g, dtype=torch.int32).view(torch.float32)
+    regimes.append((x, s))
+    # arbitrary bit patterns for x (incl. denormal / Inf / NaN / -0.0), ordinary scales
+    x = torch.randint(-(2**31), 2**31 - 1, (n, 8), device=DEV, generator=g, dtype=torch.int64).to(torch.int32).view(torch.float32)
+    regimes.append((x, torch.rand(n, device=DEV, generator=g) + 0.01))
+    # arbitrary bit patterns for the scale as well (zero, denormal, huge, NaN scales take the IEEE path)
+    sb = torch.randint(-(2**31), 2**31 - 1, (n,), device=DEV, generator=g, dtype=torch.int64).to(torch.int32).view(torch.float32)
+    regimes.append((torch.randn(n, 8, device=DEV, generator=g), sb))
+    for x, s in regimes:
+        for offset in (None, torch.full_like(s, 3.0)):
+            monkeypatch.delenv("FFQ_FORCE_GENERIC", raising=False)
+            fast = ops.quantize_by_tile(x, s, (1, 8), 26, torch.int32, offset)
+            fast_f = ops.quantize_by_tile(x, s, (1, 8), 25, torch.float32, offset)
+            monkeypatch.setenv("FFQ_FORCE_GENERIC", "1")
+            slow = ops.quantize_by_tile(x, s, (1, 8), 26, torch.int32, offset)
+            slow_f = ops.quantize_by_tile(x, s, (1, 8), 25, torch.float32, offset)
+            assert torch.equal(fast, slow), mismatch_report(fast.cpu(), slow.cpu())
+            assert same_with_nan(fast_f.cpu(), slow_f.cpu()), mismatch_report(fast_f.cpu(), slow_f.cpu())
+    monkeypatch.delenv("FFQ_FORCE_GENERIC", raising=False)
+
+
 # ---- 2. HIP vs oracle on seeded inputs ------------------------------------------------------------
 def _both(fn):
     """Run fn(device) with the HIP backend on cuda and with the oracle on cpu."""
@@ -248,8 +287,10 @@ def test_full_size_weight_properties(shape):
     amax = w.float().abs().amax(1)
     assert torch.equal(codes.float().abs().amax(1) >= 127, torch.ones_like(amax, dtype=torch.bool))
     # scale reproduces parameters_for_range on the row extrema
-    lo, hi = w.float().amin(1), w.float().amax(1)
-    assert torch.equal(quantizer.scale.detach(), torch.maximum(lo.abs() / 128, hi.abs() / 127))
+    # (computed on the CPU: torch's GPU kernel for tensor / python_scalar multiplies by the
+    #  reciprocal, the reference's CPU path and our kernel divide)
+    lo, hi = w.float().amin(1).cpu(), w.float().amax(1).cpu()
+    assert torch.equal(quantizer.scale.detach().cpu(), torch.maximum(lo.abs() / 128, hi.abs() / 127))
     # quantize(dequantize(q)) == q  (idempotence) and |x - x^| <= scale/2 (+ bf16 rounding)
     deq = q.dequantize()
     again = quantizer(deq).raw_data
@@ -278,10 +319,10 @@ def test_full_size_activation_properties(hidden):
     quantizer = ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=torch.int8, device=DEV)
     with ff.estimate_ranges(torch.nn.ModuleList([quantizer]), ff.range_setting.running_minmax, sync_free=True):
         q = quantizer(x)
-    lo, hi = x.float().min(), x.float().max()
+    lo, hi = x.float().min().cpu(), x.float().max().cpu()  # CPU: true division, see above
     scale = ((hi - lo) / 255).clamp(torch.finfo(torch.float32).eps)
-    assert torch.equal(quantizer.scale.detach(), scale.reshape(1))
-    assert torch.equal(quantizer.offset.detach(), (lo / scale + 128).reshape(1))
+    assert torch.equal(quantizer.scale.detach().cpu(), scale.reshape(1))
+    assert torch.equal(quantizer.offset.detach().cpu(), (lo / scale + 128).reshape(1))
     assert int(q.raw_data.min()) == -128 and int(q.raw_data.max()) == 127
     # dynamic quantization == static quantization with the min/max range (tests/quantization/test_dynamic.py:13-30)
     dyn = ff.quantization.affine.dynamic.quantize_per_tensor(x, 8, symmetric=False, output_dtype=torch.int8)
@@ -289,6 +330,6 @@ def test_full_size_activation_properties(hidden):
     # checksum of codes against a chunked recomputation with plain torch ops in fp32
     off = torch.round(quantizer.offset.detach())
     total = 0
-    for chunk in x.chunk(8):
+    for chunk in x.chunk(8):  # tensor / tensor is a true division on the GPU as well
         total += int(torch.clamp(torch.round(chunk.float() / quantizer.scale.detach() - off), -128, 127).sum(dtype=torch.int64))
     assert int(q.raw_data.sum(dtype=torch.int64)) == total
