@@ -1,0 +1,297 @@
+"""bench.py — Llama-3-8B W8A8 quantized forward on N MI355X GPUs (one process per GPU).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): tokens/sec of the Llama-3-8B W8A8 quantized forward, plus quant/dequant
+GB/s against the HBM3E peak. Workload = BASELINE.json configs[2]'s forward: Llama-3-8B shapes,
+synthetic N(0, 0.02^2) bf16 weights, 8-bit per-channel symmetric weight quantizers and 8-bit
+per-tensor asymmetric input quantizers on the 7 linears of each of the 32 layers, ranges from a
+RunningMinMax calibration (sharded over the ranks, ONE RCCL all-reduce of the activation ranges).
+
+A "step" is one forward pass over one batch of B x S synthetic token ids resident in HBM. With the
+reference's semantics every step re-quantizes all 6.98 G weight elements (nn/linear.py:34),
+quantizes the 7 linear inputs per layer and runs the 224 quantized linears. The forward is captured
+once into a hipGraph and replayed (no tracing compiler; the C ABI only enqueues kernels), so the
+timed region holds no Python.
+
+Multi-GPU: inference shards over the batch with no data-path collective (replicas; "weak"
+scaling: per-GPU batch fixed). value = total tokens of all ranks / max-over-ranks time.
+
+Output: ONE JSON line on rank 0. `roofline` describes the dominant kernel of the step (the int8
+MFMA GEMM); `hbm_kernels` lists the HBM-bound hot-path kernels on the headline shape
+[14336, 4096] bf16 per-channel with achieved GB/s vs 8 TB/s; `cpu_baseline` is the reference's
+eager ATen chain (oracle/eager_chain.py, a port) timed on this box's host cores on a bounded sample.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import pathlib
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import fastforward_amd as ff  # noqa: E402
+
+from fastforward_amd import distributed as ffd  # noqa: E402
+from fastforward_amd import llama, ops  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+INT8_PEAK_TOPS = 5000.0    # dense int8 MFMA peak = 2 x the 2.5 PF dense bf16 peak (same guide)
+
+
+def event_time_ms(fn, iters: int, reps: int = 8) -> float:
+    """Median duration of one call of `fn`: `reps` calls captured into a hipGraph on the stream the
+    C ABI launches on, replayed `iters` times between HIP events."""
+    for r in range(2):
+        fn(r)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.cuda.graph(graph, stream=side):
+        for r in range(reps):
+            fn(r)
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
+    torch.cuda.synchronize()
+    samples = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        graph.replay()
+        b.record()
+        b.synchronize()
+        samples.append(a.elapsed_time(b) / reps)
+    return statistics.median(samples)
+
+
+def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device) -> dict:
+    """The dominant kernel of the step: w8a8_gemm_kernel. Algorithmic ops per launch = 2*T*N*K."""
+    h, i, kv = config.hidden_size, config.intermediate_size, config.num_kv_heads * config.head_dim
+    shapes = {"q/o_proj": (h, h, 2), "k/v_proj": (kv, h, 2), "gate/up_proj": (i, h, 2), "down_proj": (h, i, 1)}
+    total_ops = total_ms = launches = 0.0
+    per_shape = {}
+    for name, (n, k, count) in shapes.items():
+        xq = torch.randint(-128, 128, (tokens, k), device=device, dtype=torch.int8)
+        wq = torch.randint(-128, 128, (n, k), device=device, dtype=torch.int8)
+        sx, ox = torch.tensor([0.02], device=device), torch.tensor([4.0], device=device)
+        sw = torch.rand(n, device=device) * 0.001 + 0.0005
+        ms = event_time_ms(lambda r: ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.bfloat16), iters=5, reps=4)
+        # the rowsum kernel of the zero-point term runs inside this call; it is 1 B/elem of the weight
+        flop = 2.0 * tokens * n * k
+        per_shape[name] = {"N": n, "K": k, "ms": round(ms, 4), "TOP/s": round(flop / ms / 1e9, 1)}
+        total_ops += count * flop
+        total_ms += count * ms
+        launches += count
+        del xq, wq
+    achieved = total_ops / total_ms / 1e9
+    return {
+        "bound": "mfma",
+        "kernel": "w8a8_gemm_kernel (v_mfma_i32_32x32x32_i8)",
+        "achieved": round(achieved, 1),
+        "peak": INT8_PEAK_TOPS,
+        "unit": "TFLOP/s",
+        "unit_note": "integer multiply-accumulates (TOP/s); dense int8 MFMA peak",
+        "frac": round(achieved / INT8_PEAK_TOPS, 4),
+        "traffic": None,
+        "avg_launch_ms": round(total_ms / launches, 4),
+        "algorithmic_ops_per_launch": total_ops / launches,
+        "per_shape": per_shape,
+    }
+
+
+def hbm_kernels(device: torch.device) -> list[dict]:
+    """A1 / A2 / A4 on the headline shape of SURVEY §8(d): [14336, 4096] bf16, per-channel."""
+    shape = (14336, 4096)
+    n = shape[0] * shape[1]
+    ws = [(torch.randn(shape, device=device) * 0.02).to(torch.bfloat16) for _ in range(6)]  # > Infinity Cache
+    scale = torch.rand(shape[0], device=device) * 0.001 + 0.0005
+    tile = (1, shape[1])
+    qs = [ops.quantize_by_tile(w, scale, tile, 8, torch.int8) for w in ws]
+    rows = []
+
+    def add(name, kernel, bytes_per_elem, fn):
+        ms = event_time_ms(fn, iters=10, reps=12)
+        gbs = n * bytes_per_elem / ms / 1e6
+        rows.append({"op": name, "kernel": kernel, "bound": "hbm", "bytes_per_elem": bytes_per_elem, "ms": round(ms, 5),
+                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)})
+
+    add("quantize per-channel bf16->int8", "quantize_stream_kernel<bf16,i8,ROWS>", 3, lambda r: ops.quantize_by_tile(ws[r % 6], scale, tile, 8, torch.int8))
+    add("quantize per-channel bf16->bf16 (reference default container)", "quantize_stream_kernel<bf16,bf16,ROWS>", 4, lambda r: ops.quantize_by_tile(ws[r % 6], scale, tile, 8, torch.bfloat16))
+    add("dequantize per-channel int8->bf16", "dequantize_stream_kernel<i8,bf16,ROWS>", 3, lambda r: ops.dequantize_by_tile(qs[r % 6], scale, tile, None, torch.bfloat16))
+    add("running min/max per-channel bf16", "minmax_rows_kernel<bf16>", 2, lambda r: ops.minmax_by_tile(ws[r % 6], tile))
+    return rows
+
+
+def cpu_baseline(config: llama.LlamaConfig, budget_s: float = 20.0) -> dict:
+    """The reference's eager chain on this box's host cores: the 7 W8A8 linears of ONE decoder layer
+    (quantize x, re-quantize W, dequantize both, bf16 F.linear) on a token sample sized to ~budget_s."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import eager_chain
+
+    torch.manual_seed(1236)
+    h, i, kv = config.hidden_size, config.intermediate_size, config.num_kv_heads * config.head_dim
+    shapes = [(h, h), (kv, h), (kv, h), (h, h), (i, h), (i, h), (h, i)]
+    weights = [(torch.randn(n, k) * 0.02).to(torch.bfloat16) for n, k in shapes]
+    params = []
+    for w in weights:
+        lo, hi = eager_chain.minmax(w, (1, w.shape[1]))
+        params.append(eager_chain.parameters_for_range(lo, hi, 8, True, True)[0])
+
+    def layer(tokens: int) -> float:
+        t0 = time.perf_counter()
+        for w, ws in zip(weights, params):
+            x = torch.randn(tokens, w.shape[1]).to(torch.bfloat16)
+            eager_chain.linear_w8a8(x, w, torch.tensor([0.03]), torch.tensor([3.0]), ws, torch.zeros_like(ws), 8)
+        return time.perf_counter() - t0
+
+    layer(8)  # page in
+    probe_tokens = 64
+    probe = layer(probe_tokens)
+    # time(tokens) ~ fixed (weight quant/dequant) + slope * tokens; estimate with a second probe
+    probe2 = layer(2 * probe_tokens)
+    slope = max((probe2 - probe) / probe_tokens, 1e-9)
+    fixed = max(probe - slope * probe_tokens, 0.0)
+    tokens = int(min(2048, max(128, (budget_s - fixed) / slope)))
+    tokens = 1 << (tokens.bit_length() - 1)
+    seconds = layer(tokens)
+    return {
+        "value": round(tokens / (seconds * config.num_layers), 3),
+        "unit": "tokens/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"eager ATen chain (oracle/eager_chain.py) of the 7 W8A8 linears of ONE decoder layer at Llama-3-8B shapes on {tokens} tokens: {seconds:.2f} s, scaled by {config.num_layers} layers (attention/norms excluded, so this flatters the CPU)",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="sequences per GPU per step")
+    ap.add_argument("--seq-len", type=int, default=2048)
+    ap.add_argument("--calib-seqs", type=int, default=16, help="calibration sequences per GPU (BASELINE config: 512 in total)")
+    ap.add_argument("--model", choices=["llama3-8b", "llama3-70b", "tiny"], default="llama3-8b")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-side-measurements", action="store_true", help="skip roofline / cpu_baseline legs")
+    args = ap.parse_args()
+
+    rank, local_rank, world = ffd.init_process_group_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    config = {"llama3-8b": llama.LlamaConfig.llama3_8b, "llama3-70b": llama.LlamaConfig.llama3_70b, "tiny": llama.LlamaConfig.tiny}[args.model]()
+
+    # synthetic model + data (seeds per SURVEY §8d: 1234 + config index; ranks hold identical replicas)
+    model = llama.build_model(config, device, torch.bfloat16, seed=1234 + 2)
+    llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
+    gen = torch.Generator(device=device).manual_seed(4321 + rank)
+    batch = torch.randint(0, config.vocab_size, (args.batch, args.seq_len), device=device, generator=gen)
+
+    # calibration: RunningMinMax on this rank's share, then ONE all-reduce of the activation ranges
+    calib_steps = max(1, args.calib_seqs // args.batch)
+    calib = [torch.randint(0, config.vocab_size, (args.batch, args.seq_len), device=device, generator=gen) for _ in range(calib_steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    payload = ffd.calibrate_sharded(model, calib, disable_quantization=False)
+    torch.cuda.synchronize()
+    calib_s = time.perf_counter() - t0
+    del calib
+
+    def forward():
+        with torch.no_grad(), ff.strict_quantization(False):
+            return model(batch, logits=True)
+
+    for _ in range(max(args.warmup, 1)):
+        forward()
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.cuda.graph(graph, stream=side):
+            static_out = forward()
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()
+        torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            forward()
+
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    tokens_per_step = args.batch * args.seq_len * world
+    result = {
+        "metric": "tokens/sec Llama-3-8B W8A8 quantized fwd; quant/dequant GB/s vs HBM peak",
+        "value": round(tokens_per_step * args.steps / elapsed, 1),
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int8 codes x int8 codes -> int32 (MFMA), fp32 scale epilogue, bf16 activations",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.model} shapes, W8 per-channel symmetric + A8 per-tensor asymmetric on the 7 linears x {config.num_layers} layers "
+                        f"(BASELINE.json configs[2] forward), weights re-quantized every step as in the reference",
+            "global_batch": args.batch * world,
+            "seq_len": args.seq_len,
+            "tokens_per_step": tokens_per_step,
+            "parallelism": f"dp{world} (batch-sharded replicas, no data-path collective)",
+            "quantizers": llama.count_quantizers(model),
+            "launch": "hipGraph replay" if graph is not None else "eager",
+        },
+        "calibration": {"sequences_per_gpu": calib_steps * args.batch, "seconds": round(calib_s, 3),
+                        "sequences_per_s_all_gpus": round(calib_steps * args.batch * world / calib_s, 2),
+                        "allreduce_floats": payload, "collective": "1 x all_reduce(MIN) over RCCL" if world > 1 else "none (1 GPU)"},
+    }
+    if rank == 0 and not args.no_side_measurements:
+        del graph
+        torch.cuda.empty_cache()
+        result["roofline"] = gemm_roofline(config, args.batch * args.seq_len, device)
+        result["hbm_kernels"] = hbm_kernels(device)
+        if world == 1:
+            result["cpu_baseline"] = cpu_baseline(config)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,282 @@
+"""Llama-3-shaped caller of the hot path: the harness behind bench.py and the multi-GPU calibration.
+
+The reference defines "Llama W8A8" through its example helpers
+(docs/examples/doc_helpers/quantized_llama/{attention,mlp,decoder,rms_norm}.py) and the quick-start
+recipe (docs/examples/quick_start_quantize_llms.nb.py:140-232):
+
+  * ``ff.quantize_model(model)`` turns every ``nn.Linear`` into a ``QuantizedLinear`` and gives the
+    attention / MLP / decoder / norm modules identity ``QuantizerStub``s;
+  * weight quantizers of the 7 linears per layer: ``LinearQuantizer(8, granularity=PerChannel())``;
+  * input quantizers of the same 7 linears: ``LinearQuantizer(8, symmetric=False, PerTensor())``;
+  * embedding, lm_head, RMSNorm, rotary, softmax stay float (``strict_quantization(False)``).
+
+This module restates that structure with its own minimal decoder (no ``transformers`` dependency on
+the GPU box): per decoder layer 7 weight quantizations (A1, per-channel, re-run every forward as in
+reference nn/linear.py:34), 7 activation quantizations (A1, per-tensor asymmetric) and 7 quantized
+linears (A6). Everything that is not a quantized linear runs as ordinary torch ops — it is the
+traffic between hot-path calls, not the product.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import math
+
+import torch
+import torch.nn.functional as F
+
+import fastforward_amd as ff
+
+from fastforward_amd.nn import QuantizedModule, QuantizerStub
+
+
+@dataclasses.dataclass(frozen=True)
+class LlamaConfig:
+    hidden_size: int = 4096
+    intermediate_size: int = 14336
+    num_layers: int = 32
+    num_heads: int = 32
+    num_kv_heads: int = 8
+    vocab_size: int = 128256
+    rope_theta: float = 500000.0
+    rms_norm_eps: float = 1e-5
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_heads
+
+    @classmethod
+    def llama3_8b(cls) -> "LlamaConfig":
+        return cls()
+
+    @classmethod
+    def llama3_70b(cls) -> "LlamaConfig":
+        return cls(hidden_size=8192, intermediate_size=28672, num_layers=80, num_heads=64, num_kv_heads=8)
+
+    @classmethod
+    def tiny(cls) -> "LlamaConfig":
+        """The 2-layer shape used by tests."""
+        return cls(hidden_size=256, intermediate_size=896, num_layers=2, num_heads=8, num_kv_heads=2, vocab_size=512)
+
+    def quantized_weight_elems(self) -> int:
+        h, i, kv = self.hidden_size, self.intermediate_size, self.num_kv_heads * self.head_dim
+        return self.num_layers * (2 * h * h + 2 * kv * h + 3 * h * i)
+
+    def linear_flops_per_token(self) -> int:
+        return 2 * self.quantized_weight_elems()
+
+
+class LlamaRMSNorm(torch.nn.Module):
+    def __init__(self, hidden_size: int, eps: float) -> None:
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        dtype = hidden_states.dtype
+        h = hidden_states.to(torch.float32)
+        h = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + self.variance_epsilon)
+        return self.weight * h.to(dtype)
+
+
+def rotary_tables(seq_len: int, head_dim: int, theta: float, device: torch.device | str, dtype: torch.dtype) -> tuple[torch.Tensor, torch.Tensor]:
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, device=device, dtype=torch.float32) / head_dim))
+    freqs = torch.outer(torch.arange(seq_len, device=device, dtype=torch.float32), inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def _rotate_half(x: torch.Tensor) -> torch.Tensor:
+    half = x.shape[-1] // 2
+    return torch.cat((-x[..., half:], x[..., :half]), dim=-1)
+
+
+class LlamaAttention(torch.nn.Module):
+    def __init__(self, config: LlamaConfig) -> None:
+        super().__init__()
+        self.config = config
+        h, d = config.hidden_size, config.head_dim
+        self.q_proj = torch.nn.Linear(h, config.num_heads * d, bias=False)
+        self.k_proj = torch.nn.Linear(h, config.num_kv_heads * d, bias=False)
+        self.v_proj = torch.nn.Linear(h, config.num_kv_heads * d, bias=False)
+        self.o_proj = torch.nn.Linear(config.num_heads * d, h, bias=False)
+
+    def forward(self, hidden_states: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+        b, s, _ = hidden_states.shape
+        cfg = self.config
+        q = self.q_proj(hidden_states).view(b, s, cfg.num_heads, cfg.head_dim).transpose(1, 2)
+        k = self.k_proj(hidden_states).view(b, s, cfg.num_kv_heads, cfg.head_dim).transpose(1, 2)
+        v = self.v_proj(hidden_states).view(b, s, cfg.num_kv_heads, cfg.head_dim).transpose(1, 2)
+        q = q * cos + _rotate_half(q) * sin
+        k = k * cos + _rotate_half(k) * sin
+        attn = F.scaled_dot_product_attention(q, k, v, is_causal=s > 1, enable_gqa=cfg.num_kv_heads != cfg.num_heads)
+        return self.o_proj(attn.transpose(1, 2).reshape(b, s, -1))
+
+
+class LlamaMLP(torch.nn.Module):
+    def __init__(self, config: LlamaConfig) -> None:
+        super().__init__()
+        self.gate_proj = torch.nn.Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.up_proj = torch.nn.Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.down_proj = torch.nn.Linear(config.intermediate_size, config.hidden_size, bias=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+class LlamaDecoderLayer(torch.nn.Module):
+    def __init__(self, config: LlamaConfig) -> None:
+        super().__init__()
+        self.self_attn = LlamaAttention(config)
+        self.mlp = LlamaMLP(config)
+        self.input_layernorm = LlamaRMSNorm(config.hidden_size, config.rms_norm_eps)
+        self.post_attention_layernorm = LlamaRMSNorm(config.hidden_size, config.rms_norm_eps)
+
+    def forward(self, hidden_states: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+        hidden_states = hidden_states + self.self_attn(self.input_layernorm(hidden_states), cos, sin)
+        return hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
+
+
+class LlamaModel(torch.nn.Module):
+    """Embedding -> decoder layers -> final norm -> lm_head (logits)."""
+
+    def __init__(self, config: LlamaConfig) -> None:
+        super().__init__()
+        self.config = config
+        self.embed_tokens = torch.nn.Embedding(config.vocab_size, config.hidden_size)
+        self.layers = torch.nn.ModuleList(LlamaDecoderLayer(config) for _ in range(config.num_layers))
+        self.norm = LlamaRMSNorm(config.hidden_size, config.rms_norm_eps)
+        self.lm_head = torch.nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+
+    def forward(self, input_ids: torch.Tensor, logits: bool = True) -> torch.Tensor:
+        hidden_states = self.embed_tokens(input_ids)
+        cos, sin = rotary_tables(input_ids.shape[1], self.config.head_dim, self.config.rope_theta, hidden_states.device, hidden_states.dtype)
+        for layer in self.layers:
+            hidden_states = layer(hidden_states, cos, sin)
+        hidden_states = self.norm(hidden_states)
+        return self.lm_head(hidden_states) if logits else hidden_states
+
+
+# ---- quantized counterparts: same stub slots as the reference's helpers ---------------------------
+class QuantizedLlamaRMSNorm(QuantizedModule, LlamaRMSNorm):
+    """Float under strict_quantization(False), like reference rms_norm.py:17-35."""
+
+    def __init_quantization__(self) -> None:
+        super().__init_quantization__()
+        self.input_quantizer = QuantizerStub(input_quantizer=True)
+        self.output_quantizer = QuantizerStub(output_quantizer=True)
+        self.weight_quantizer = QuantizerStub(weight_quantizer=True)
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        with ff.strict_quantization(False):
+            return self.output_quantizer(LlamaRMSNorm.forward(self, self.input_quantizer(hidden_states)))
+
+
+class QuantizedLlamaAttention(QuantizedModule, LlamaAttention):
+    """Reference attention.py:129-183 (the SDPA variant: one input stub, fused attention)."""
+
+    def __init_quantization__(self) -> None:
+        super().__init_quantization__()
+        self.input_quantizer = QuantizerStub(input_quantizer=True)
+
+    def forward(self, hidden_states: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+        return LlamaAttention.forward(self, self.input_quantizer(hidden_states), cos, sin)
+
+
+class QuantizedLlamaMLP(QuantizedModule, LlamaMLP):
+    """Reference mlp.py:19-40."""
+
+    def __init_quantization__(self) -> None:
+        super().__init_quantization__()
+        self.input_quantizer = QuantizerStub(input_quantizer=True)
+        self.gate_act_quantizer = QuantizerStub(input_quantizer=True)
+        self.gated_up_proj_output_quantizer = QuantizerStub(output_quantizer=True)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.input_quantizer(x)
+        gated = self.gated_up_proj_output_quantizer(self.gate_act_quantizer(F.silu(self.gate_proj(x))) * self.up_proj(x))
+        return self.down_proj(gated)
+
+
+class QuantizedLlamaDecoderLayer(QuantizedModule, LlamaDecoderLayer):
+    """Reference decoder.py:19-90."""
+
+    def __init_quantization__(self) -> None:
+        super().__init_quantization__()
+        self.input_quantizer = QuantizerStub(input_quantizer=True)
+        self.attn_res_act_quantizer = QuantizerStub(output_quantizer=True)
+        self.mlp_res_act_quantizer = QuantizerStub(output_quantizer=True)
+
+    def forward(self, hidden_states: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+        hidden_states = self.input_quantizer(hidden_states)
+        hidden_states = self.attn_res_act_quantizer(hidden_states + self.self_attn(self.input_layernorm(hidden_states), cos, sin))
+        return self.mlp_res_act_quantizer(hidden_states + self.mlp(self.post_attention_layernorm(hidden_states)))
+
+
+class QuantizedLlamaModel(QuantizedModule, LlamaModel):
+    pass
+
+
+class QuantizedEmbedding(QuantizedModule, torch.nn.Embedding):
+    """Embedding stays float in the Llama recipe (not matched by the quantizer queries)."""
+
+
+# ---- recipe ------------------------------------------------------------------------------------------
+def decoder_linears(model: LlamaModel):
+    """(name, QuantizedLinear) for the 7 linears of every decoder layer — what the reference's queries
+    ``**/layers/*/self_attn/*`` and ``**/layers/*/mlp/*`` select; lm_head is not matched."""
+    for li, layer in enumerate(model.layers):
+        for group, names in (("self_attn", ("q_proj", "k_proj", "v_proj", "o_proj")), ("mlp", ("gate_proj", "up_proj", "down_proj"))):
+            for name in names:
+                yield f"layers.{li}.{group}.{name}", getattr(getattr(layer, group), name)
+
+
+def build_model(config: LlamaConfig, device: torch.device | str, dtype: torch.dtype = torch.bfloat16, seed: int = 1234, std: float = 0.02) -> LlamaModel:
+    """Random-init model with N(0, std^2) weights, created directly on `device`."""
+    with torch.device(device):
+        model = LlamaModel(config).to(dtype)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, std, generator=gen)
+    return model.eval()
+
+
+def quantize_llama(
+    model: LlamaModel,
+    w_bits: int | None = 8,
+    a_bits: int | None = 8,
+    quantized_dtype: torch.dtype | None = torch.int8,
+    weight_granularity: ff.quantization.granularity.Granularity | None = None,
+) -> LlamaModel:
+    """``ff.quantize_model`` + the quick-start W{w_bits}A{a_bits} recipe. Quantizers are created on the
+    model's device; ranges are uninitialised until a calibration pass (``ff.estimate_ranges``)."""
+    device = next(model.parameters()).device
+    ff.quantize_model(model)
+    for _, linear in decoder_linears(model):
+        if w_bits is not None:
+            linear.weight_quantizer = ff.nn.LinearQuantizer(
+                w_bits, granularity=weight_granularity or ff.PerChannel(0), quantized_dtype=quantized_dtype, device=device
+            )
+        if a_bits is not None:
+            linear.input_quantizer = ff.nn.LinearQuantizer(
+                a_bits, symmetric=False, granularity=ff.PerTensor(), quantized_dtype=quantized_dtype, device=device
+            )
+    return model
+
+
+def calibrate(model: LlamaModel, batches, sync_free: bool = True, disable_quantization: bool = False) -> None:
+    """RunningMinMax calibration over `batches` of token ids (reference quick-start :193,255)."""
+    with torch.no_grad(), ff.strict_quantization(False):
+        with ff.estimate_ranges(model, ff.range_setting.running_minmax, sync_free=sync_free, disable_quantization=disable_quantization):
+            for ids in batches:
+                model(ids, logits=False)
+
+
+def count_quantizers(model: LlamaModel) -> int:
+    return sum(1 for _ in ff.nn.named_quantizers(model))
+
+
+def approx_tokens_per_second(config: LlamaConfig, tokens: int, seconds: float) -> float:
+    return tokens / seconds if seconds > 0 else math.inf
