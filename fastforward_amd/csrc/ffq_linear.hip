@@ -22,6 +22,7 @@
 #include "ffq_vec.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace ffq {
 
@@ -185,6 +186,192 @@ __global__ __launch_bounds__(256) void w8a8_gemm_kernel(LinearArgs a) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// v2: 256 x 256 x 64 block tile, 8 wavefronts (2 x 4), each owning 128 x 64 = 4 x 2 MFMA tiles.
+//
+// Why a second kernel: the 128^2 tile moves (BM + BN) / (2 BM BN) = 1/128 byte per op from L2 into
+// LDS — 9 TB/s at the 1.15 POP/s it reaches, i.e. it is L2-bound. 256^2 halves that, and:
+//   * operands go global -> LDS directly (global_load_lds_dwordx4: no staging VGPRs, no ds_write);
+//     the LDS image is lane-linear per wave instruction, so the bank swizzle is applied to the
+//     per-lane SOURCE address and, identically, to the ds_read address;
+//   * 3-stage LDS ring, loads for tile k+2 issued right after the barrier of tile k, waited for with
+//     a COUNTED s_waitcnt vmcnt(4) (tile k+1 stays in flight across the barrier), one raw s_barrier
+//     per K-step;
+//   * the zero-point row sums sum_k wq[n,k] are accumulated with v_dot4 on the B fragments already in
+//     registers (VALU work in the shadow of the MFMAs) — no extra pass over the weight codes;
+//   * tiles are visited in groups of 8 M-tiles x all N (within each XCD's contiguous range), so the
+//     32 CUs of an XCD share 8 activation panels and 4 weight panels per K-slice in their L2.
+// Needs K % 64 == 0 (no K tail in the DMA path); M / N tails are handled by clamped loads + guarded
+// stores.
+constexpr int BM2 = 256, BN2 = 256, BK2 = 64, STAGES2 = 3;
+constexpr int OPER_BYTES2 = BM2 * BK2;            // 16 KiB per operand per stage
+constexpr int STAGE_BYTES2 = 2 * OPER_BYTES2;     // 32 KiB
+constexpr int GROUP_M2 = 8;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <typename TOut, bool REQUANT>
+__global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
+
+  // XCD-aware, grouped tile order
+  const uint32_t nblk = gridDim.x;
+  const uint32_t xcd = blockIdx.x & 7u, slot_in_xcd = blockIdx.x >> 3;
+  const uint32_t q = nblk >> 3, r = nblk & 7u;
+  const uint32_t tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot_in_xcd;
+  const uint32_t per_group = GROUP_M2 * (uint32_t)a.tiles_n;
+  const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
+  const uint32_t group_rows = min((uint32_t)GROUP_M2, (uint32_t)a.tiles_m - group * GROUP_M2);
+  const int tm = (int)(group * GROUP_M2 + in_group % group_rows);
+  const int tn = (int)(in_group / group_rows);
+  const int m0 = tm * BM2, n0 = tn * BN2;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // DMA map: wave w copies 16-row chunks {2w, 2w+1} of A and of B. Inside a chunk lane l lands at
+  // LDS slot l (16 B units): row = l / 4, physical k-slot = l % 4, logical k-slot = physical ^ swz(row).
+  const int d_row = lane >> 2;
+  const int d_slot = (lane & 3) ^ ((d_row >> 2) & 3);
+  const int8_t* a_src[2];
+  const int8_t* b_src[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    int ra = m0 + (wave * 2 + c) * 16 + d_row;
+    int rb = n0 + (wave * 2 + c) * 16 + d_row;
+    ra = ra < a.M ? ra : a.M - 1;  // rows past the edge are loaded from the last row and never stored
+    rb = rb < a.N ? rb : a.N - 1;
+    a_src[c] = a.xq + (size_t)ra * a.K + d_slot * 16;
+    b_src[c] = a.wq + (size_t)rb * a.K + d_slot * 16;
+  }
+  auto issue = [&](int kt, int stage) {
+    uint8_t* base = lds2 + stage * STAGE_BYTES2 + wave * 2048;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[c] + kt * BK2), (lds_void_t*)(base + c * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_src[c] + kt * BK2), (lds_void_t*)(base + OPER_BYTES2 + c * 1024), 16, 0, 0);
+    }
+  };
+
+  v16i acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+  int rsw[2] = {0, 0};
+
+  const int ksteps = a.K / BK2;
+  issue(0, 0);
+  if (ksteps > 1) issue(1, 1);
+
+  const uint32_t frag_row = lane & 31, frag_g = lane >> 5;
+  // per-lane LDS byte offsets of the fragments (row * 64 + swizzled slot * 16), kk = 0 / 1
+  uint32_t a_off[4][2], b_off[2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t row = wm * 128 + i * 32 + frag_row;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) a_off[i][kk] = row * BK2 + (((kk * 2 + frag_g) ^ ((row >> 2) & 3u)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const uint32_t row = wn * 64 + j * 32 + frag_row;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) b_off[j][kk] = OPER_BYTES2 + row * BK2 + (((kk * 2 + frag_g) ^ ((row >> 2) & 3u)) << 4);
+  }
+
+  int stage = 0;
+  for (int kt = 0; kt < ksteps; ++kt) {
+    // my DMA of tile kt has landed (tile kt+1 may still be in flight), then everybody's has — and
+    // everybody has finished reading the stage that tile kt+2 is about to overwrite
+    if (kt + 1 < ksteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < ksteps) {
+      int next = stage + 2;
+      next = next >= STAGES2 ? next - STAGES2 : next;
+      issue(kt + 2, next);
+    }
+    const uint8_t* st = lds2 + stage * STAGE_BYTES2;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      v4i fa[4], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const v4i*>(st + b_off[j][kk]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const v4i*>(st + a_off[i][kk]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        rsw[j] = __builtin_amdgcn_sdot4(fb[j].x, 0x01010101, rsw[j], false);
+        rsw[j] = __builtin_amdgcn_sdot4(fb[j].y, 0x01010101, rsw[j], false);
+        rsw[j] = __builtin_amdgcn_sdot4(fb[j].z, 0x01010101, rsw[j], false);
+        rsw[j] = __builtin_amdgcn_sdot4(fb[j].w, 0x01010101, rsw[j], false);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    stage = stage + 1 == STAGES2 ? 0 : stage + 1;
+  }
+  // lanes l and l+32 hold the two k-halves of the same weight row
+#pragma unroll
+  for (int j = 0; j < 2; ++j) rsw[j] += __shfl_xor(rsw[j], 32, 64);
+
+  // epilogue (C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5))
+  TOut* out = static_cast<TOut*>(a.out);
+  const float kf = (float)a.K;
+  float oscale = 1.0f, ooff = 0.0f;
+  if constexpr (REQUANT) {
+    oscale = a.out_scale[0];
+    ooff = a.out_offset ? rne(a.out_offset[0]) : 0.0f;
+  }
+  const bool x_uniform = !a.x_per_row;
+  const float sx0 = a.x_scale[0];
+  const float ox0 = a.x_offset ? rne(a.x_offset[0]) : 0.0f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    if (n >= a.N) continue;
+    const float sw = a.w_scale[a.w_per_row ? n : 0];
+    const float ow = a.w_offset ? rne(a.w_offset[a.w_per_row ? n : 0]) : 0.0f;
+    const float rs = (float)rsw[j];
+    const float bias = a.bias ? (float)load_any(a.bias, a.bias_dt, n) : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m >= a.M) continue;
+        const float sx = x_uniform ? sx0 : a.x_scale[m];
+        const float ox = x_uniform ? ox0 : (a.x_offset ? rne(a.x_offset[m]) : 0.0f);
+        const float rsx = a.rowsum_x ? (float)a.rowsum_x[m] : 0.0f;
+        float v = (float)acc[i][j][e];
+        v = v + ox * rs;
+        v = v + ow * rsx;
+        v = v + kf * ox * ow;
+        float y = (sx * sw) * v;
+        if (a.bias) y = y + bias;
+        if constexpr (REQUANT) {
+          y = bf16_bits_to_f32(f32_to_bf16_bits(y));
+          float qv = rne(y / oscale - ooff);
+          qv = clamp_nan(qv, a.out_lo, a.out_hi);
+          store_out<TOut>(out + (size_t)m * a.N + n, qv);
+        } else {
+          store_out<TOut>(out + (size_t)m * a.N + n, y);
+        }
+      }
+    }
+  }
+}
+
 // one wavefront per row: sum of K int8 codes
 __global__ __launch_bounds__(256) void rowsum_i8_kernel(const int8_t* __restrict__ q, int rows, int K,
                                                         int32_t* __restrict__ sums) {
@@ -260,6 +447,43 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
   if (w_offset) {  // needs sum_k xq[m,k]
     rowsum_i8_kernel<<<(unsigned)((M + 3) / 4), 256, 0, s>>>(xq, (int)M, (int)K, ws);
     a.rowsum_x = ws;
+  }
+  // the 256^2 kernel computes the weight row sums itself; it needs K % 64 == 0 and enough tiles
+  static const int force_v1 = getenv("FFQ_GEMM_V1") ? 1 : 0;
+  const bool use_v2 = !force_v1 && K % BK2 == 0 && M >= 128 && N >= 128 &&
+                      ((M + BM2 - 1) / BM2) * ((N + BN2 - 1) / BN2) >= 64;
+  if (use_v2) {
+    a.tiles_m = (int)((M + BM2 - 1) / BM2);
+    a.tiles_n = (int)((N + BN2 - 1) / BN2);
+    const unsigned grid2 = (unsigned)(a.tiles_m * a.tiles_n);
+    const size_t lds_bytes = (size_t)STAGES2 * STAGE_BYTES2;
+#define FFQ_GEMM2(T, RQ)                                                                                   \
+  do {                                                                                                     \
+    static bool attr_set = false;                                                                          \
+    if (!attr_set) {                                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256_kernel<T, RQ>),                    \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                     \
+      attr_set = true;                                                                                     \
+    }                                                                                                      \
+    w8a8_gemm256_kernel<T, RQ><<<grid2, 512, lds_bytes, s>>>(a);                                           \
+  } while (0)
+    if (requant) {
+      switch (out_dt) {
+        case FFQ_I8: FFQ_GEMM2(int8_t, true); break;
+        case FFQ_BF16: FFQ_GEMM2(bf16_t, true); break;
+        case FFQ_F16: FFQ_GEMM2(f16_t, true); break;
+        case FFQ_F32: FFQ_GEMM2(float, true); break;
+        default: return fail(FFQ_ERR_DTYPE, "re-quantized output container must be i8, bf16, f16 or f32");
+      }
+    } else {
+      switch (out_dt) {
+        case FFQ_BF16: FFQ_GEMM2(bf16_t, false); break;
+        case FFQ_F16: FFQ_GEMM2(f16_t, false); break;
+        default: FFQ_GEMM2(float, false); break;
+      }
+    }
+#undef FFQ_GEMM2
+    return check_launch("w8a8_gemm256_kernel");
   }
   if (x_offset) {  // needs sum_k wq[n,k]
     rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(wq, (int)N, (int)K, ws + M);

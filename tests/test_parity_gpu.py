@@ -221,7 +221,8 @@ def test_running_minmax_raises_on_infinite_like_reference():
             quantizer2(x)  # deferred: raised when the context exits
 
 
-@pytest.mark.parametrize("m,n,k", [(1, 16, 16), (96, 200, 144), (256, 384, 512), (300, 130, 4096), (17, 1000, 256)])
+# the last three shapes have >= 64 tiles of 256 x 256 and K % 64 == 0: they take the direct-to-LDS kernel
+@pytest.mark.parametrize("m,n,k", [(1, 16, 16), (96, 200, 144), (256, 384, 512), (300, 130, 4096), (17, 1000, 256), (2048, 2048, 256), (2050, 2300, 192), (4100, 1030, 1024)])
 @pytest.mark.parametrize("x_per_row,w_per_row,x_off,w_off", [(0, 1, True, False), (0, 0, False, False), (1, 1, True, True), (0, 1, False, True)])
 def test_w8a8_linear_exact_integer_math(m, n, k, x_per_row, w_per_row, x_off, w_off):
     """The contraction is exact: compare with an int64 matmul of the same codes, fp32 epilogue."""
