@@ -284,42 +284,76 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
     for (int kk = 0; kk < 2; ++kk) b_off[j][kk] = OPER_BYTES2 + row * BK2 + (((kk * 2 + frag_g) ^ ((row >> 2) & 3u)) << 4);
   }
 
+  // Two fragment register sets: the ds_reads of one half K-step fly under the MFMAs of the other.
+  //   top of iteration kt : issue DMA of tile kt+2 (its stage was last read in iteration kt-1 and every
+  //                         wave passed the mid barrier of kt-1 with lgkmcnt(0), so it is free);
+  //                         read set1 <- (tile kt, k-half 1); MFMA on set0 (tile kt, k-half 0)
+  //   middle              : counted vmcnt (tile kt+1 landed, tile kt+2 stays in flight), lgkmcnt(0),
+  //                         raw s_barrier; read set0 <- (tile kt+1, k-half 0); MFMA on set1
+  v4i fa0[4], fb0[2], fa1[4], fb1[2];
+  auto read_frags = [&](const uint8_t* st, int kk, v4i (&fa)[4], v4i (&fb)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const v4i*>(st + b_off[j][kk]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const v4i*>(st + a_off[i][kk]);
+  };
+  // 8 MFMAs on (fa, fb) with the 6 ds_read_b128 of the NEXT fragment set slotted between them: each
+  // read issues in the shadow of an MFMA and has returned by the time its set is consumed. The
+  // sched_group_barriers pin that interleave (mask 0x8 = MFMA, 0x100 = DS read, 0x2 = VALU).
+  auto mma_prefetch = [&](const v4i (&fa)[4], const v4i (&fb)[2], const uint8_t* st, int kk, v4i (&na)[4], v4i (&nb)[2], bool prefetch) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      rsw[j] = __builtin_amdgcn_sdot4(fb[j].x, 0x01010101, rsw[j], false);
+      rsw[j] = __builtin_amdgcn_sdot4(fb[j].y, 0x01010101, rsw[j], false);
+      rsw[j] = __builtin_amdgcn_sdot4(fb[j].z, 0x01010101, rsw[j], false);
+      rsw[j] = __builtin_amdgcn_sdot4(fb[j].w, 0x01010101, rsw[j], false);
+    }
+    // first MFMA alone: hipcc places its (conservative) lgkmcnt(0) for this fragment set here, while
+    // no newer ds_read is outstanding; the fence keeps the prefetch reads below it
+    acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0], fb[0], acc[0][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (prefetch) read_frags(st, kk, na, nb);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (i != 0 || j != 0) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (ksteps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_frags(lds2, 0, fa0, fb0);
+
   int stage = 0;
   for (int kt = 0; kt < ksteps; ++kt) {
-    // my DMA of tile kt has landed (tile kt+1 may still be in flight), then everybody's has — and
-    // everybody has finished reading the stage that tile kt+2 is about to overwrite
-    if (kt + 1 < ksteps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    const int next = stage + 1 == STAGES2 ? 0 : stage + 1;
     if (kt + 2 < ksteps) {
-      int next = stage + 2;
-      next = next >= STAGES2 ? next - STAGES2 : next;
-      issue(kt + 2, next);
+      const int nn = next + 1 == STAGES2 ? 0 : next + 1;
+      issue(kt + 2, nn);
     }
-    const uint8_t* st = lds2 + stage * STAGE_BYTES2;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      v4i fa[4], fb[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const v4i*>(st + b_off[j][kk]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const v4i*>(st + a_off[i][kk]);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        rsw[j] = __builtin_amdgcn_sdot4(fb[j].x, 0x01010101, rsw[j], false);
-        rsw[j] = __builtin_amdgcn_sdot4(fb[j].y, 0x01010101, rsw[j], false);
-        rsw[j] = __builtin_amdgcn_sdot4(fb[j].z, 0x01010101, rsw[j], false);
-        rsw[j] = __builtin_amdgcn_sdot4(fb[j].w, 0x01010101, rsw[j], false);
-      }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(1);
+    mma_prefetch(fa0, fb0, lds2 + stage * STAGE_BYTES2, 1, fa1, fb1, true);
+    __builtin_amdgcn_s_setprio(0);
+    const bool more = kt + 1 < ksteps;
+    if (more) {
+      if (kt + 2 < ksteps) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
-    stage = stage + 1 == STAGES2 ? 0 : stage + 1;
+    __builtin_amdgcn_s_setprio(1);
+    mma_prefetch(fa1, fb1, lds2 + next * STAGE_BYTES2, 0, fa0, fb0, more);
+    __builtin_amdgcn_s_setprio(0);
+    stage = next;
   }
   // lanes l and l+32 hold the two k-halves of the same weight row
 #pragma unroll
@@ -336,37 +370,88 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
   const bool x_uniform = !a.x_per_row;
   const float sx0 = a.x_scale[0];
   const float ox0 = a.x_offset ? rne(a.x_offset[0]) : 0.0f;
+  float sw[2], ow[2], rs[2], bias[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    n = n < a.N ? n : a.N - 1;
+    sw[j] = a.w_scale[a.w_per_row ? n : 0];
+    ow[j] = a.w_offset ? rne(a.w_offset[a.w_per_row ? n : 0]) : 0.0f;
+    rs[j] = (float)rsw[j];
+    bias[j] = a.bias ? (float)load_any(a.bias, a.bias_dt, n) : 0.0f;
+  }
+  auto finish = [&](int i, int j, int e, int m) -> float {
+    const float sx = x_uniform ? sx0 : a.x_scale[m];
+    const float ox = x_uniform ? ox0 : (a.x_offset ? rne(a.x_offset[m]) : 0.0f);
+    const float rsx = a.rowsum_x ? (float)a.rowsum_x[m] : 0.0f;
+    float v = (float)acc[i][j][e];
+    v = v + ox * rs[j];
+    v = v + ow[j] * rsx;
+    v = v + kf * ox * ow[j];
+    float y = (sx * sw[j]) * v;
+    if (a.bias) y = y + bias[j];
+    if constexpr (REQUANT) {
+      y = bf16_bits_to_f32(f32_to_bf16_bits(y));
+      y = clamp_nan(rne(y / oscale - ooff), a.out_lo, a.out_hi);
+    }
+    return y;
+  };
+
+  // Two-byte outputs whose rows are 16 B aligned go through LDS so that every global store is
+  // 16 B per lane and 8 lanes cover one full 128 B line: each wave transposes its 128 x 64 tile in two
+  // halves of 64 rows through a private 64 x 144 B (padded) LDS region. The direct path below writes
+  // 64 B row segments (2 per store instruction) and is kept for tails, fp32 and int8 outputs.
+  const bool wave_cols_inside = n0 + wn * 64 + 64 <= a.N;
+  if constexpr (sizeof(TOut) == 2) {
+    if ((a.N & 7) == 0 && wave_cols_inside) {
+      constexpr int ROW_BYTES = 144;  // 128 B of payload + 16 B pad: lanes l and l+32 (rows r, r+4) hit disjoint banks
+      __syncthreads();                // every wave is done with the operand ring
+      uint8_t* region = lds2 + wave * (64 * ROW_BYTES);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          const int i = h * 2 + ii;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int lr = ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+              int m = m0 + wm * 128 + h * 64 + lr;
+              m = m < a.M ? m : a.M - 1;
+              const float y = finish(i, j, e, m);
+              *reinterpret_cast<uint16_t*>(region + lr * ROW_BYTES + (j * 32 + (lane & 31)) * 2) =
+                  __builtin_bit_cast(uint16_t, from_f32<TOut>(y));
+            }
+        }
+        // wave-private region: no block barrier needed, only this wave's own LDS writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int c = lane + 64 * t;
+          const int row = c >> 3, seg = c & 7;
+          const int m = m0 + wm * 128 + h * 64 + row;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * ROW_BYTES + seg * 16);
+          if (m < a.M)
+            *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)m * a.N + n0 + wn * 64) * 2 + seg * 16) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 64 + j * 32 + (lane & 31);
     if (n >= a.N) continue;
-    const float sw = a.w_scale[a.w_per_row ? n : 0];
-    const float ow = a.w_offset ? rne(a.w_offset[a.w_per_row ? n : 0]) : 0.0f;
-    const float rs = (float)rsw[j];
-    const float bias = a.bias ? (float)load_any(a.bias, a.bias_dt, n) : 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (m >= a.M) continue;
-        const float sx = x_uniform ? sx0 : a.x_scale[m];
-        const float ox = x_uniform ? ox0 : (a.x_offset ? rne(a.x_offset[m]) : 0.0f);
-        const float rsx = a.rowsum_x ? (float)a.rowsum_x[m] : 0.0f;
-        float v = (float)acc[i][j][e];
-        v = v + ox * rs;
-        v = v + ow * rsx;
-        v = v + kf * ox * ow;
-        float y = (sx * sw) * v;
-        if (a.bias) y = y + bias;
-        if constexpr (REQUANT) {
-          y = bf16_bits_to_f32(f32_to_bf16_bits(y));
-          float qv = rne(y / oscale - ooff);
-          qv = clamp_nan(qv, a.out_lo, a.out_hi);
-          store_out<TOut>(out + (size_t)m * a.N + n, qv);
-        } else {
-          store_out<TOut>(out + (size_t)m * a.N + n, y);
-        }
+        store_out<TOut>(out + (size_t)m * a.N + n, finish(i, j, e, m));
       }
     }
   }
