@@ -246,7 +246,11 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
     a_src[c] = a.xq + (size_t)ra * a.K + d_slot * 16;
     b_src[c] = a.wq + (size_t)rb * a.K + d_slot * 16;
   }
+  const int last_tile = a.K / BK2 - 1;
+  // Tiles past the end are re-loads of the last tile into a stage nobody reads any more: it keeps
+  // the K-loop free of branches (fixed DMA count per iteration => one constant vmcnt).
   auto issue = [&](int kt, int stage) {
+    kt = kt < last_tile ? kt : last_tile;
     uint8_t* base = lds2 + stage * STAGE_BYTES2 + wave * 2048;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -266,7 +270,8 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
 
   const int ksteps = a.K / BK2;
   issue(0, 0);
-  if (ksteps > 1) issue(1, 1);
+  issue(1, 1);
+  issue(2, 2);
 
   const uint32_t frag_row = lane & 31, frag_g = lane >> 5;
   // per-lane LDS byte offsets of the fragments (row * 64 + swizzled slot * 16), kk = 0 / 1
@@ -284,12 +289,16 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
     for (int kk = 0; kk < 2; ++kk) b_off[j][kk] = OPER_BYTES2 + row * BK2 + (((kk * 2 + frag_g) ^ ((row >> 2) & 3u)) << 4);
   }
 
-  // Two fragment register sets: the ds_reads of one half K-step fly under the MFMAs of the other.
-  //   top of iteration kt : issue DMA of tile kt+2 (its stage was last read in iteration kt-1 and every
-  //                         wave passed the mid barrier of kt-1 with lgkmcnt(0), so it is free);
-  //                         read set1 <- (tile kt, k-half 1); MFMA on set0 (tile kt, k-half 0)
-  //   middle              : counted vmcnt (tile kt+1 landed, tile kt+2 stays in flight), lgkmcnt(0),
-  //                         raw s_barrier; read set0 <- (tile kt+1, k-half 0); MFMA on set1
+  // Schedule of one K-step (tile kt lives in stage kt % 3; two fragment register sets):
+  //   first half : 8 MFMAs on set0 (tile kt, k-half 0); the 6 ds_reads of set1 (tile kt, k-half 1)
+  //                are slotted between them
+  //   middle     : counted s_waitcnt — tile kt+1 has landed while tile kt+2 stays in flight —
+  //                plus lgkmcnt(0), then ONE raw s_barrier: from here on nobody reads stage kt % 3
+  //   second half: 8 MFMAs on set1 with, slotted between them, the 6 ds_reads of set0 for tile kt+1
+  //                and the 4 LDS-DMA instructions that refill stage kt % 3 with tile kt+3
+  // so every ds_read and every DMA issue sits in the shadow of an MFMA, DMA runs two K-steps ahead,
+  // and hipcc's own (conservative) lgkmcnt(0) for a fragment set lands on the first MFMA of a half,
+  // where no newer LDS read is outstanding.
   v4i fa0[4], fb0[2], fa1[4], fb1[2];
   auto read_frags = [&](const uint8_t* st, int kk, v4i (&fa)[4], v4i (&fb)[2]) {
 #pragma unroll
@@ -297,10 +306,7 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const v4i*>(st + a_off[i][kk]);
   };
-  // 8 MFMAs on (fa, fb) with the 6 ds_read_b128 of the NEXT fragment set slotted between them: each
-  // read issues in the shadow of an MFMA and has returned by the time its set is consumed. The
-  // sched_group_barriers pin that interleave (mask 0x8 = MFMA, 0x100 = DS read, 0x2 = VALU).
-  auto mma_prefetch = [&](const v4i (&fa)[4], const v4i (&fb)[2], const uint8_t* st, int kk, v4i (&na)[4], v4i (&nb)[2], bool prefetch) {
+  auto rowsums = [&](const v4i (&fb)[2]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       rsw[j] = __builtin_amdgcn_sdot4(fb[j].x, 0x01010101, rsw[j], false);
@@ -308,16 +314,29 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
       rsw[j] = __builtin_amdgcn_sdot4(fb[j].z, 0x01010101, rsw[j], false);
       rsw[j] = __builtin_amdgcn_sdot4(fb[j].w, 0x01010101, rsw[j], false);
     }
-    // first MFMA alone: hipcc places its (conservative) lgkmcnt(0) for this fragment set here, while
-    // no newer ds_read is outstanding; the fence keeps the prefetch reads below it
-    acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0], fb[0], acc[0][0], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (prefetch) read_frags(st, kk, na, nb);
+  };
+  auto mfma_rest = [&](const v4i (&fa)[4], const v4i (&fb)[2]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         if (i != 0 || j != 0) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+  };
+
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_frags(lds2, 0, fa0, fb0);
+
+  int stage = 0;
+  for (int kt = 0; kt < ksteps; ++kt) {
+    const int next = stage + 1 == STAGES2 ? 0 : stage + 1;
+    // ---- first half
+    __builtin_amdgcn_s_setprio(1);
+    rowsums(fb0);
+    acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa0[0], fb0[0], acc[0][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(lds2 + stage * STAGE_BYTES2, 1, fa1, fb1);
+    mfma_rest(fa0, fb0);
 #pragma unroll
     for (int g = 0; g < 6; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -327,34 +346,34 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
     __builtin_amdgcn_sched_barrier(0);
-  };
-
-  if (ksteps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  read_frags(lds2, 0, fa0, fb0);
-
-  int stage = 0;
-  for (int kt = 0; kt < ksteps; ++kt) {
-    const int next = stage + 1 == STAGES2 ? 0 : stage + 1;
-    if (kt + 2 < ksteps) {
-      const int nn = next + 1 == STAGES2 ? 0 : next + 1;
-      issue(kt + 2, nn);
-    }
-    __builtin_amdgcn_s_setprio(1);
-    mma_prefetch(fa0, fb0, lds2 + stage * STAGE_BYTES2, 1, fa1, fb1, true);
     __builtin_amdgcn_s_setprio(0);
-    const bool more = kt + 1 < ksteps;
-    if (more) {
-      if (kt + 2 < ksteps) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
+    // ---- middle: tile kt+1 landed (tile kt+2 stays in flight), my LDS reads done, everybody here
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- second half (the reads of the last iteration fetch a stale stage and are never used)
     __builtin_amdgcn_s_setprio(1);
-    mma_prefetch(fa1, fb1, lds2 + next * STAGE_BYTES2, 0, fa0, fb0, more);
+    rowsums(fb1);
+    acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa1[0], fb1[0], acc[0][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(lds2 + next * STAGE_BYTES2, 0, fa0, fb0);
+    issue(kt + 3, stage);
+    mfma_rest(fa1, fb1);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
     stage = next;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing dummy DMA must not land in the epilogue's LDS
   // lanes l and l+32 hold the two k-halves of the same weight row
 #pragma unroll
   for (int j = 0; j < 2; ++j) rsw[j] += __shfl_xor(rsw[j], 32, 64);
