@@ -203,16 +203,26 @@ __global__ __launch_bounds__(256) void w8a8_gemm_kernel(LinearArgs a) {
 //     32 CUs of an XCD share 8 activation panels and 4 weight panels per K-slice in their L2.
 // Needs K % 64 == 0 (no K tail in the DMA path); M / N tails are handled by clamped loads + guarded
 // stores.
-constexpr int BM2 = 256, BN2 = 256, BK2 = 64, STAGES2 = 3;
-constexpr int OPER_BYTES2 = BM2 * BK2;            // 16 KiB per operand per stage
-constexpr int STAGE_BYTES2 = 2 * OPER_BYTES2;     // 32 KiB
+constexpr int BM2 = 256, BK2 = 64, STAGES2 = 3;
 constexpr int GROUP_M2 = 8;
+// Two shapes of the same kernel (each wave always owns 128 x 64):
+//   NW = 8: block 256 x 256, one block per CU  (1/256 B of L2->LDS traffic per op)
+//   NW = 4: block 256 x 128, TWO blocks per CU (1/171 B per op) — the two blocks have independent
+//           barriers, so one block's MFMAs fill the matrix pipe while the other one synchronises.
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <typename TOut, bool REQUANT>
-__global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
+template <typename TOut, bool REQUANT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) {
+  constexpr int BN2 = NW * 32;                       // 256 or 128 columns per block
+  constexpr int WAVES_N = BN2 / 64;                  // 4 or 2
+  constexpr int A_BYTES = BM2 * BK2;                 // 16 KiB
+  constexpr int OPER_BYTES2 = A_BYTES;               // offset of the B operand inside a stage
+  constexpr int STAGE_BYTES2 = (BM2 + BN2) * BK2;    // 32 or 24 KiB
+  constexpr int A_CHUNKS = (BM2 / 16) / NW;          // 16-row DMA chunks of A per wave: 2 or 4
+  constexpr int B_CHUNKS = (BN2 / 16) / NW;          // ... of B per wave: 2
+  constexpr int DMA_PER_STEP = A_CHUNKS + B_CHUNKS;  // LDS-DMA instructions per wave per K-step
   extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
 
   // XCD-aware, grouped tile order
@@ -229,21 +239,25 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  // DMA map: wave w copies 16-row chunks {2w, 2w+1} of A and of B. Inside a chunk lane l lands at
-  // LDS slot l (16 B units): row = l / 4, physical k-slot = l % 4, logical k-slot = physical ^ swz(row).
+  // DMA map: wave w copies the 16-row chunks {A_CHUNKS w ...} of A and {B_CHUNKS w ...} of B. Inside a
+  // chunk lane l lands at LDS slot l (16 B units): row = l / 4, physical k-slot = l % 4,
+  // logical k-slot = physical ^ swz(row).
   const int d_row = lane >> 2;
   const int d_slot = (lane & 3) ^ ((d_row >> 2) & 3);
-  const int8_t* a_src[2];
-  const int8_t* b_src[2];
+  const int8_t* a_src[A_CHUNKS];
+  const int8_t* b_src[B_CHUNKS];
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    int ra = m0 + (wave * 2 + c) * 16 + d_row;
-    int rb = n0 + (wave * 2 + c) * 16 + d_row;
+  for (int c = 0; c < A_CHUNKS; ++c) {
+    int ra = m0 + (wave * A_CHUNKS + c) * 16 + d_row;
     ra = ra < a.M ? ra : a.M - 1;  // rows past the edge are loaded from the last row and never stored
-    rb = rb < a.N ? rb : a.N - 1;
     a_src[c] = a.xq + (size_t)ra * a.K + d_slot * 16;
+  }
+#pragma unroll
+  for (int c = 0; c < B_CHUNKS; ++c) {
+    int rb = n0 + (wave * B_CHUNKS + c) * 16 + d_row;
+    rb = rb < a.N ? rb : a.N - 1;
     b_src[c] = a.wq + (size_t)rb * a.K + d_slot * 16;
   }
   const int last_tile = a.K / BK2 - 1;
@@ -251,12 +265,13 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
   // the K-loop free of branches (fixed DMA count per iteration => one constant vmcnt).
   auto issue = [&](int kt, int stage) {
     kt = kt < last_tile ? kt : last_tile;
-    uint8_t* base = lds2 + stage * STAGE_BYTES2 + wave * 2048;
+    uint8_t* base = lds2 + stage * STAGE_BYTES2;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[c] + kt * BK2), (lds_void_t*)(base + c * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_src[c] + kt * BK2), (lds_void_t*)(base + OPER_BYTES2 + c * 1024), 16, 0, 0);
-    }
+    for (int c = 0; c < A_CHUNKS; ++c)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[c] + kt * BK2), (lds_void_t*)(base + (wave * A_CHUNKS + c) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int c = 0; c < B_CHUNKS; ++c)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_src[c] + kt * BK2), (lds_void_t*)(base + OPER_BYTES2 + (wave * B_CHUNKS + c) * 1024), 16, 0, 0);
   };
 
   v16i acc[4][2];
@@ -320,10 +335,11 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        if (i != 0 || j != 0) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (i != 0 || j != 0) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[j], fa[i], acc[i][j], 0, 0, 0);
   };
 
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if constexpr (DMA_PER_STEP == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_frags(lds2, 0, fa0, fb0);
 
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
     // ---- first half
     __builtin_amdgcn_s_setprio(1);
     rowsums(fb0);
-    acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa0[0], fb0[0], acc[0][0], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb0[0], fa0[0], acc[0][0], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_frags(lds2 + stage * STAGE_BYTES2, 1, fa1, fb1);
     mfma_rest(fa0, fb0);
@@ -348,12 +364,13 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
     // ---- middle: tile kt+1 landed (tile kt+2 stays in flight), my LDS reads done, everybody here
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    if constexpr (DMA_PER_STEP == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // ---- second half (the reads of the last iteration fetch a stale stage and are never used)
     __builtin_amdgcn_s_setprio(1);
     rowsums(fb1);
-    acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa1[0], fb1[0], acc[0][0], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb1[0], fa1[0], acc[0][0], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_frags(lds2 + next * STAGE_BYTES2, 0, fa0, fb0);
     issue(kt + 3, stage);
@@ -363,11 +380,11 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, DMA_PER_STEP == 4 ? 1 : 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x010, DMA_PER_STEP == 4 ? 1 : 0, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
@@ -378,7 +395,11 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) rsw[j] += __shfl_xor(rsw[j], 32, 64);
 
-  // epilogue (C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5))
+  // Epilogue. The weight fragment is the MFMA's A operand, so with the 32x32 C/D layout
+  // (col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) lane l holds, for each (i, j, q):
+  //   C[m = i*32 + (l & 31)][n = j*32 + 8*q + 4*(l >> 5) + (0..3)],  e = 4*q + (0..3)
+  // i.e. FOUR CONSECUTIVE output columns of one row: 8 B of bf16 that go to LDS as one ds_write_b64
+  // (32 per lane instead of 128 two-byte writes) and leave as full 16 B per lane / 128 B per line.
   TOut* out = static_cast<TOut*>(a.out);
   const float kf = (float)a.K;
   float oscale = 1.0f, ooff = 0.0f;
@@ -386,92 +407,92 @@ __global__ __launch_bounds__(512) void w8a8_gemm256_kernel(LinearArgs a) {
     oscale = a.out_scale[0];
     ooff = a.out_offset ? rne(a.out_offset[0]) : 0.0f;
   }
-  const bool x_uniform = !a.x_per_row;
-  const float sx0 = a.x_scale[0];
-  const float ox0 = a.x_offset ? rne(a.x_offset[0]) : 0.0f;
-  float sw[2], ow[2], rs[2], bias[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int n = n0 + wn * 64 + j * 32 + (lane & 31);
-    n = n < a.N ? n : a.N - 1;
-    sw[j] = a.w_scale[a.w_per_row ? n : 0];
-    ow[j] = a.w_offset ? rne(a.w_offset[a.w_per_row ? n : 0]) : 0.0f;
-    rs[j] = (float)rsw[j];
-    bias[j] = a.bias ? (float)load_any(a.bias, a.bias_dt, n) : 0.0f;
+  __syncthreads();  // every wave is done with the operand ring: LDS is free for the epilogue
+  constexpr int ROW_BYTES = 144;  // 128 B payload + 16 B pad
+  constexpr int REGION_BYTES = 128 * ROW_BYTES + 256;
+  uint8_t* region = lds2 + wave * REGION_BYTES;
+  float* rs_lds = reinterpret_cast<float*>(region + 128 * ROW_BYTES);
+  if (lane < 32) {
+    rs_lds[lane] = (float)rsw[0];
+    rs_lds[32 + lane] = (float)rsw[1];
   }
-  auto finish = [&](int i, int j, int e, int m) -> float {
-    const float sx = x_uniform ? sx0 : a.x_scale[m];
-    const float ox = x_uniform ? ox0 : (a.x_offset ? rne(a.x_offset[m]) : 0.0f);
-    const float rsx = a.rowsum_x ? (float)a.rowsum_x[m] : 0.0f;
-    float v = (float)acc[i][j][e];
-    v = v + ox * rs[j];
-    v = v + ow[j] * rsx;
-    v = v + kf * ox * ow[j];
-    float y = (sx * sw[j]) * v;
-    if (a.bias) y = y + bias[j];
-    if constexpr (REQUANT) {
-      y = bf16_bits_to_f32(f32_to_bf16_bits(y));
-      y = clamp_nan(rne(y / oscale - ooff), a.out_lo, a.out_hi);
-    }
-    return y;
-  };
+  const int g = lane >> 5;
+  const int wave_n0 = n0 + wn * 64;
+  const int wave_m0 = m0 + wm * 128;
+  const bool lds_path = sizeof(TOut) == 2 && (a.N & 7) == 0 && wave_n0 + 64 <= a.N;
 
-  // Two-byte outputs whose rows are 16 B aligned go through LDS so that every global store is
-  // 16 B per lane and 8 lanes cover one full 128 B line: each wave transposes its 128 x 64 tile in two
-  // halves of 64 rows through a private 64 x 144 B (padded) LDS region. The direct path below writes
-  // 64 B row segments (2 per store instruction) and is kept for tails, fp32 and int8 outputs.
-  const bool wave_cols_inside = n0 + wn * 64 + 64 <= a.N;
-  if constexpr (sizeof(TOut) == 2) {
-    if ((a.N & 7) == 0 && wave_cols_inside) {
-      constexpr int ROW_BYTES = 144;  // 128 B of payload + 16 B pad: lanes l and l+32 (rows r, r+4) hit disjoint banks
-      __syncthreads();                // every wave is done with the operand ring
-      uint8_t* region = lds2 + wave * (64 * ROW_BYTES);
+  // per-row (activation side) parameters of this lane's 4 rows m = wave_m0 + i*32 + (lane & 31)
+  float sx[4], ox[4], rsx[4];
+  bool m_ok[4];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          const int i = h * 2 + ii;
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int lr = ii * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-              int m = m0 + wm * 128 + h * 64 + lr;
-              m = m < a.M ? m : a.M - 1;
-              const float y = finish(i, j, e, m);
-              *reinterpret_cast<uint16_t*>(region + lr * ROW_BYTES + (j * 32 + (lane & 31)) * 2) =
-                  __builtin_bit_cast(uint16_t, from_f32<TOut>(y));
-            }
-        }
-        // wave-private region: no block barrier needed, only this wave's own LDS writes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const int c = lane + 64 * t;
-          const int row = c >> 3, seg = c & 7;
-          const int m = m0 + wm * 128 + h * 64 + row;
-          const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * ROW_BYTES + seg * 16);
-          if (m < a.M)
-            *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)m * a.N + n0 + wn * 64) * 2 + seg * 16) = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      return;
-    }
+  for (int i = 0; i < 4; ++i) {
+    int m = wave_m0 + i * 32 + (lane & 31);
+    m_ok[i] = m < a.M;
+    m = m_ok[i] ? m : a.M - 1;
+    sx[i] = a.x_scale[a.x_per_row ? m : 0];
+    ox[i] = a.x_offset ? rne(a.x_offset[a.x_per_row ? m : 0]) : 0.0f;
+    rsx[i] = a.rowsum_x ? (float)a.rowsum_x[m] : 0.0f;
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-    if (n >= a.N) continue;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int q = 0; q < 4; ++q) {
+      asm volatile("" ::: "memory");  // keep the parameter quads of different (j, q) from being hoisted together
+      const int nb = j * 32 + 8 * q + 4 * g;  // this lane's 4 columns: wave_n0 + nb + (0..3)
+      float sw4[4], ow4[4], rs4[4], b4[4];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (m >= a.M) continue;
-        store_out<TOut>(out + (size_t)m * a.N + n, finish(i, j, e, m));
+      for (int t = 0; t < 4; ++t) {
+        int n = wave_n0 + nb + t;
+        n = n < a.N ? n : a.N - 1;
+        sw4[t] = a.w_scale[a.w_per_row ? n : 0];
+        ow4[t] = a.w_offset ? rne(a.w_offset[a.w_per_row ? n : 0]) : 0.0f;
+        rs4[t] = rs_lds[nb + t];
+        b4[t] = a.bias ? (float)load_any(a.bias, a.bias_dt, n) : 0.0f;
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float y[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float v = (float)acc[i][j][4 * q + t] + ox[i] * rs4[t];
+          v = v + ow4[t] * rsx[i];
+          v = v + kf * ox[i] * ow4[t];
+          float r = (sx[i] * sw4[t]) * v;
+          if (a.bias) r = r + b4[t];
+          if constexpr (REQUANT) {
+            r = bf16_bits_to_f32(f32_to_bf16_bits(r));
+            r = clamp_nan(rne(r / oscale - ooff), a.out_lo, a.out_hi);
+          }
+          y[t] = r;
+        }
+        if constexpr (sizeof(TOut) == 2) {
+          if (lds_path) {
+            u32x2 pk;
+            pk.x = pack2<TOut>(y[0], y[1]);
+            pk.y = pack2<TOut>(y[2], y[3]);
+            *reinterpret_cast<u32x2*>(region + (i * 32 + (lane & 31)) * ROW_BYTES + nb * 2) = pk;
+            continue;
+          }
+        }
+        if (m_ok[i]) {
+          const size_t at = (size_t)(wave_m0 + i * 32 + (lane & 31)) * a.N + wave_n0 + nb;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (wave_n0 + nb + t < a.N) store_out<TOut>(out + at + t, y[t]);
+        }
+      }
+    }
+  }
+  if (lds_path) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: only this wave's own writes
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int c = lane + 64 * t;
+      const int row = c >> 3, seg = c & 7;
+      const int m = wave_m0 + row;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * ROW_BYTES + seg * 16);
+      if (m < a.M)
+        *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)m * a.N + wave_n0) * 2 + seg * 16) = v;
     }
   }
 }
@@ -552,24 +573,33 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
     rowsum_i8_kernel<<<(unsigned)((M + 3) / 4), 256, 0, s>>>(xq, (int)M, (int)K, ws);
     a.rowsum_x = ws;
   }
-  // the 256^2 kernel computes the weight row sums itself; it needs K % 64 == 0 and enough tiles
+  // the direct-to-LDS kernels compute the weight row sums themselves; they need K % 64 == 0
   static const int force_v1 = getenv("FFQ_GEMM_V1") ? 1 : 0;
-  const bool use_v2 = !force_v1 && K % BK2 == 0 && M >= 128 && N >= 128 &&
-                      ((M + BM2 - 1) / BM2) * ((N + BN2 - 1) / BN2) >= 64;
+  static const int force_nw = getenv("FFQ_GEMM_NW") ? atoi(getenv("FFQ_GEMM_NW")) : 0;
+  const int64_t tiles256 = ((M + BM2 - 1) / BM2) * ((N + 255) / 256);
+  const bool use_v2 = !force_v1 && K % BK2 == 0 && M >= 128 && N >= 128 && tiles256 >= 64;
   if (use_v2) {
+    const int nw = force_nw ? force_nw : 8;
+    const int bn = nw * 32;
     a.tiles_m = (int)((M + BM2 - 1) / BM2);
-    a.tiles_n = (int)((N + BN2 - 1) / BN2);
+    a.tiles_n = (int)((N + bn - 1) / bn);
     const unsigned grid2 = (unsigned)(a.tiles_m * a.tiles_n);
-    const size_t lds_bytes = (size_t)STAGES2 * STAGE_BYTES2;
-#define FFQ_GEMM2(T, RQ)                                                                                   \
+    const size_t ring_bytes = (size_t)STAGES2 * (BM2 + bn) * BK2;
+    const size_t epilogue_bytes = (size_t)nw * (128 * 144 + 256);  // one padded 128 x 64 bf16 tile per wave
+    const size_t lds_bytes = ring_bytes > epilogue_bytes ? ring_bytes : epilogue_bytes;
+#define FFQ_GEMM2_NW(T, RQ, NW)                                                                            \
   do {                                                                                                     \
     static bool attr_set = false;                                                                          \
     if (!attr_set) {                                                                                       \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256_kernel<T, RQ>),                    \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256_kernel<T, RQ, NW>),            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);               \
       attr_set = true;                                                                                     \
     }                                                                                                      \
-    w8a8_gemm256_kernel<T, RQ><<<grid2, 512, lds_bytes, s>>>(a);                                           \
+    w8a8_gemm256_kernel<T, RQ, NW><<<grid2, NW * 64, lds_bytes, s>>>(a);                                   \
+  } while (0)
+#define FFQ_GEMM2(T, RQ)                                                                                   \
+  do {                                                                                                     \
+    if (nw == 8) FFQ_GEMM2_NW(T, RQ, 8); else FFQ_GEMM2_NW(T, RQ, 4);                                      \
   } while (0)
     if (requant) {
       switch (out_dt) {
@@ -587,6 +617,7 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
       }
     }
 #undef FFQ_GEMM2
+#undef FFQ_GEMM2_NW
     return check_launch("w8a8_gemm256_kernel");
   }
   if (x_offset) {  // needs sum_k wq[n,k]
