@@ -159,11 +159,10 @@ __global__ __launch_bounds__(kBlock) void dequantize_generic_kernel(const void* 
   }
 }
 
-template <typename TIn, typename TOut, int E>
-static int dq_launch_stream(const TIn* in, TOut* out, const float* scale, int64_t scale_numel,
-                            const float* offset, int64_t offset_numel, const TileInfo& info,
-                            hipStream_t stream) {
-  constexpr int U = (E * (int)sizeof(TIn) >= 16 && E * (int)sizeof(TOut) >= 32) ? 2 : 4;
+template <typename TIn, typename TOut, int E, int U>
+static int dq_launch_stream_u(const TIn* in, TOut* out, const float* scale, int64_t scale_numel,
+                              const float* offset, int64_t offset_numel, const TileInfo& info,
+                              hipStream_t stream) {
   DqStreamArgs a;
   a.nchunks = (uint32_t)(info.numel / E);
   a.scale_stride = scale_numel == 1 ? 0u : 1u;
@@ -193,6 +192,21 @@ static int dq_launch_stream(const TIn* in, TOut* out, const float* scale, int64_
   }
 #undef FFQ_LAUNCH
   return check_launch("dequantize_stream_kernel");
+}
+
+// chunks per lane: short blocks win on MI355X (same finding as ffq_quantize.hip::launch_stream)
+template <typename TIn, typename TOut, int E>
+static int dq_launch_stream(const TIn* in, TOut* out, const float* scale, int64_t scale_numel,
+                            const float* offset, int64_t offset_numel, const TileInfo& info,
+                            hipStream_t stream) {
+  const char* e = getenv("FFQ_STREAM_U");
+  int u = e ? atoi(e) : 0;
+  if (u == 0) u = 1;
+  switch (u) {
+    case 1: return dq_launch_stream_u<TIn, TOut, E, 1>(in, out, scale, scale_numel, offset, offset_numel, info, stream);
+    case 4: return dq_launch_stream_u<TIn, TOut, E, 4>(in, out, scale, scale_numel, offset, offset_numel, info, stream);
+    default: return dq_launch_stream_u<TIn, TOut, E, 2>(in, out, scale, scale_numel, offset, offset_numel, info, stream);
+  }
 }
 
 template <typename TIn, typename TOut, int E>
@@ -243,7 +257,10 @@ static int dq_dispatch_fast(const void* data, const void* scale, int64_t scale_n
   if (info.numel >= ((int64_t)1 << 32) - 4096) return FFQ_OK;
   if (!aligned16(data) || !aligned16(out)) return FFQ_OK;
   int rc = FFQ_OK;
-  if constexpr (sizeof(TIn) == 1) {  // 16 one-byte codes per chunk keep the load at 16 B per lane
+  // 8 codes per chunk: an 8 B load and ONE dense 16 B store per lane beats 16 codes per chunk (16 B
+  // load, two half-dense 16 B stores): 30.1 vs 32.1 us on [14336, 4096] int8 -> bf16 (FFQ_DQ_E16=1 to compare)
+  const char* e16 = getenv("FFQ_DQ_E16");
+  if (sizeof(TIn) == 1 && e16 && e16[0] == '1') {
     rc = dq_dispatch_fast_e<TIn, TOut, 16>(data, scale, scale_numel, offset, offset_numel, info, out, stream, done);
     if (rc || *done) return rc;
   }

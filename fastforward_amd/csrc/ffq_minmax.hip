@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void minmax_scalar_partial_kernel(const T* 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t c = base + u * kBlock;
-      if (c < nchunks) x[u].load(in + (size_t)c * E);
+      if (c < nchunks) x[u].load_nt(in + (size_t)c * E);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -139,7 +139,9 @@ __device__ __forceinline__ void write_result(T* mn_out, T* mx_out, uint32_t t, M
   if (f && flags) atomicOr(flags, f);
 }
 
-template <typename T, int E, int P>
+// UF x 16 B non-temporal loads in flight per lane. Measured on [14336, 4096] bf16 (interleaved A/B):
+// temporal UF=4 23.3 us, non-temporal UF=4 21.6 us, non-temporal UF=8 21.4 us (5.49 TB/s).
+template <typename T, int E, int P, int UF = 8, bool NT = true>
 __global__ __launch_bounds__(kBlock) void minmax_rows_kernel(const T* __restrict__ in, T* __restrict__ mn_out,
                                                              T* __restrict__ mx_out, int32_t* flags,
                                                              RowsArgs a) {
@@ -151,13 +153,15 @@ __global__ __launch_bounds__(kBlock) void minmax_rows_kernel(const T* __restrict
   if (t < a.ntiles) {
     const T* row = in + (size_t)t * a.chunks_per_run * E;
     uint32_t c = lane;
-    // four chunks (64 B) in flight per lane
-    for (; c + 3 * P < a.chunks_per_run; c += 4 * P) {
-      Chunk<T, E> x[4];
+    // UF chunks (UF x 16 B) in flight per lane
+    for (; c + (UF - 1) * P < a.chunks_per_run; c += UF * P) {
+      Chunk<T, E> x[UF];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) x[u].load(row + (size_t)(c + u * P) * E);
+      for (int u = 0; u < UF; ++u) {
+        if constexpr (NT) x[u].load_nt(row + (size_t)(c + u * P) * E); else x[u].load(row + (size_t)(c + u * P) * E);
+      }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < UF; ++u)
 #pragma unroll
         for (int i = 0; i < E; ++i) m.add(x[u].get(i));
     }

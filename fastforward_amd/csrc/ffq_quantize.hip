@@ -116,7 +116,7 @@ __device__ __forceinline__ uint32_t tile_of_chunk(uint32_t chunk, const StreamAr
 
 // One block = kBlock lanes x U chunks of E elements; chunk c of the block is read by lane
 // (c % kBlock) so that every load instruction of a wave covers one contiguous 64 * 16 B span.
-template <typename TIn, typename TOut, int LAYOUT, int E, int U, bool HAS_OFFSET, int DIVMODE>
+template <typename TIn, typename TOut, int LAYOUT, int E, int U, bool HAS_OFFSET, int DIVMODE, int NT = 0>
 __global__ __launch_bounds__(kBlock) void quantize_stream_kernel(const TIn* __restrict__ in,
                                                                  TOut* __restrict__ out,
                                                                  const float* __restrict__ scale,
@@ -129,7 +129,9 @@ __global__ __launch_bounds__(kBlock) void quantize_stream_kernel(const TIn* __re
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const uint32_t c = first + u * kBlock;
-    if (c < a.nchunks) x[u].load(in + (size_t)c * E);
+    if (c < a.nchunks) {
+      if constexpr (NT & 1) x[u].load_nt(in + (size_t)c * E); else x[u].load(in + (size_t)c * E);
+    }
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void quantize_stream_kernel(const TIn* __re
     quantize_chunk<DIVMODE, E>(xf, s[u], HAS_OFFSET ? rne(o[u]) : 0.0f, r);
     Chunk<TOut, E> y;
     finalize_chunk<TOut, E>(r, a.lo, a.hi, y);
-    y.store(out + (size_t)c * E);
+    if constexpr (NT & 2) y.store_nt(out + (size_t)c * E); else y.store(out + (size_t)c * E);
   }
 }
 
@@ -279,11 +281,18 @@ static int launch_generic(const void* data, int data_dt, const void* scale, int 
   return check_launch("quantize_generic_kernel");
 }
 
-template <typename TIn, typename TOut, int E>
-static int launch_stream(const TIn* in, TOut* out, const float* scale, int64_t scale_numel,
-                         const float* offset, int64_t offset_numel, const TileInfo& info, float lo,
-                         float hi, hipStream_t stream) {
-  constexpr int U = E >= 16 ? 2 : 4;  // 64 B of input in flight per lane either way (16-bit data)
+// chunks per lane: measured on MI355X (tools/q_variants.py, interleaved A/B): short blocks win —
+// bf16 -> int8 [14336, 4096]: E=16/U=1 29.2 us vs E=16/U=2 32.4 us vs E=8/U=4 34.3 us; U=1 also wins for
+// bf16 -> bf16 (38.5 vs 41.0 us at U=4) and per-tensor activations (33.2 vs 39.2 us).
+static int stream_u_override() {
+  const char* e = getenv("FFQ_STREAM_U");
+  return e ? atoi(e) : 0;
+}
+
+template <typename TIn, typename TOut, int E, int U>
+static int launch_stream_u(const TIn* in, TOut* out, const float* scale, int64_t scale_numel,
+                           const float* offset, int64_t offset_numel, const TileInfo& info, float lo,
+                           float hi, hipStream_t stream) {
   StreamArgs a;
   a.lo = lo; a.hi = hi;
   a.nchunks = (uint32_t)(info.numel / E);
@@ -319,6 +328,19 @@ static int launch_stream(const TIn* in, TOut* out, const float* scale, int64_t s
 #undef FFQ_LAUNCH
 #undef FFQ_LAUNCH_D
   return check_launch("quantize_stream_kernel");
+}
+
+template <typename TIn, typename TOut, int E>
+static int launch_stream(const TIn* in, TOut* out, const float* scale, int64_t scale_numel,
+                         const float* offset, int64_t offset_numel, const TileInfo& info, float lo,
+                         float hi, hipStream_t stream) {
+  int u = stream_u_override();
+  if (u == 0) u = 1;
+  switch (u) {
+    case 1: return launch_stream_u<TIn, TOut, E, 1>(in, out, scale, scale_numel, offset, offset_numel, info, lo, hi, stream);
+    case 4: return launch_stream_u<TIn, TOut, E, 4>(in, out, scale, scale_numel, offset, offset_numel, info, lo, hi, stream);
+    default: return launch_stream_u<TIn, TOut, E, 2>(in, out, scale, scale_numel, offset, offset_numel, info, lo, hi, stream);
+  }
 }
 
 template <typename TIn, typename TOut, int E>
