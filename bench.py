@@ -75,6 +75,24 @@ def event_time_ms(fn, iters: int, reps: int = 8) -> float:
     return statistics.median(samples)
 
 
+def pmc_traffic(*needles: str) -> tuple[float | None, str | None]:
+    """HBM bytes per launch (read + write) of the kernel whose name contains all `needles`, from the
+    committed PMC passes (profiles/*_pmc_FETCH_SIZE.json / *_pmc_WRITE_SIZE.json, produced by
+    tools/collect_profiles.sh: separate --pmc runs, FETCH_SIZE x2 on gfx950 as the microarch guide
+    prescribes). bench.py cannot run rocprofv3 on itself, so this is a lookup, labelled with its source."""
+    import glob
+
+    reads = sorted(glob.glob(str(ROOT / "profiles" / "*_pmc_FETCH_SIZE.json")))
+    writes = sorted(glob.glob(str(ROOT / "profiles" / "*_pmc_WRITE_SIZE.json")))
+    if not reads or not writes:
+        return None, None
+    r, w = json.load(open(reads[-1])), json.load(open(writes[-1]))
+    for name, row in r.items():
+        if all(n in name for n in needles) and name in w:
+            return float(row["hbm_read_bytes"] + w[name]["hbm_write_bytes"]), pathlib.Path(reads[-1]).name.split("_pmc_")[0]
+    return None, None
+
+
 def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device) -> dict:
     """The dominant kernel of the step: w8a8_gemm_kernel. Algorithmic ops per launch = 2*T*N*K."""
     h, i, kv = config.hidden_size, config.intermediate_size, config.num_kv_heads * config.head_dim
@@ -95,15 +113,17 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device) 
         launches += count
         del xq, wq
     achieved = total_ops / total_ms / 1e9
+    traffic, source = pmc_traffic("w8a8_gemm256_kernel")
     return {
         "bound": "mfma",
-        "kernel": "w8a8_gemm_kernel (v_mfma_i32_32x32x32_i8)",
+        "kernel": "w8a8_gemm256_kernel (v_mfma_i32_32x32x32_i8, 256x256x64 tiles)",
         "achieved": round(achieved, 1),
         "peak": INT8_PEAK_TOPS,
         "unit": "TFLOP/s",
         "unit_note": "integer multiply-accumulates (TOP/s); dense int8 MFMA peak",
         "frac": round(achieved / INT8_PEAK_TOPS, 4),
-        "traffic": None,
+        "traffic": traffic,
+        "traffic_note": None if traffic is None else f"HBM read+write bytes per launch, mean over the forward's launch mix; PMC passes of profiles/{source}_pmc_*.json",
         "avg_launch_ms": round(total_ms / launches, 4),
         "algorithmic_ops_per_launch": total_ops / launches,
         "per_shape": per_shape,
@@ -120,16 +140,21 @@ def hbm_kernels(device: torch.device) -> list[dict]:
     qs = [ops.quantize_by_tile(w, scale, tile, 8, torch.int8) for w in ws]
     rows = []
 
-    def add(name, kernel, bytes_per_elem, fn):
+    def add(name, kernel, needles, bytes_per_elem, fn):
         ms = event_time_ms(fn, iters=10, reps=12)
         gbs = n * bytes_per_elem / ms / 1e6
-        rows.append({"op": name, "kernel": kernel, "bound": "hbm", "bytes_per_elem": bytes_per_elem, "ms": round(ms, 5),
-                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)})
+        traffic, _ = pmc_traffic(*needles)
+        rows.append({"op": name, "kernel": kernel, "bound": "hbm", "bytes_per_elem": bytes_per_elem, "algorithmic_bytes": n * bytes_per_elem,
+                     "ms": round(ms, 5), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic})
 
-    add("quantize per-channel bf16->int8", "quantize_stream_kernel<bf16,i8,ROWS>", 3, lambda r: ops.quantize_by_tile(ws[r % 6], scale, tile, 8, torch.int8))
-    add("quantize per-channel bf16->bf16 (reference default container)", "quantize_stream_kernel<bf16,bf16,ROWS>", 4, lambda r: ops.quantize_by_tile(ws[r % 6], scale, tile, 8, torch.bfloat16))
-    add("dequantize per-channel int8->bf16", "dequantize_stream_kernel<i8,bf16,ROWS>", 3, lambda r: ops.dequantize_by_tile(qs[r % 6], scale, tile, None, torch.bfloat16))
-    add("running min/max per-channel bf16", "minmax_rows_kernel<bf16>", 2, lambda r: ops.minmax_by_tile(ws[r % 6], tile))
+    add("quantize per-channel bf16->int8", "quantize_stream_kernel<bf16,i8,ROWS>", ("quantize_stream_kernel<ffq::bf16_t, signed char, 1,", "false"), 3,
+        lambda r: ops.quantize_by_tile(ws[r % 6], scale, tile, 8, torch.int8))
+    add("quantize per-channel bf16->bf16 (reference default container)", "quantize_stream_kernel<bf16,bf16,ROWS>", ("quantize_stream_kernel<ffq::bf16_t, ffq::bf16_t, 1,", "false"), 4,
+        lambda r: ops.quantize_by_tile(ws[r % 6], scale, tile, 8, torch.bfloat16))
+    add("dequantize per-channel int8->bf16", "dequantize_stream_kernel<i8,bf16,ROWS>", ("dequantize_stream_kernel<signed char, ffq::bf16_t, 1,", "false"), 3,
+        lambda r: ops.dequantize_by_tile(qs[r % 6], scale, tile, None, torch.bfloat16))
+    add("running min/max per-channel bf16", "minmax_rows_kernel<bf16>", ("minmax_rows_kernel<ffq::bf16_t",), 2, lambda r: ops.minmax_by_tile(ws[r % 6], tile))
     return rows
 
 

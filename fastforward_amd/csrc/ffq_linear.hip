@@ -213,7 +213,7 @@ constexpr int GROUP_M2 = 8;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-template <typename TOut, bool REQUANT, int NW>
+template <typename TOut, bool REQUANT, int NW, bool WOFF>
 __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) {
   constexpr int BN2 = NW * 32;                       // 256 or 128 columns per block
   constexpr int WAVES_N = BN2 / 64;                  // 4 or 2
@@ -282,6 +282,7 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
   int rsw[2] = {0, 0};
+  int rsx_acc[4] = {0, 0, 0, 0};  // WOFF: sum_k xq[m,k] for this lane's 4 activation rows, same trick
 
   const int ksteps = a.K / BK2;
   issue(0, 0);
@@ -321,13 +322,22 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const v4i*>(st + a_off[i][kk]);
   };
-  auto rowsums = [&](const v4i (&fb)[2]) {
+  auto rowsums = [&](const v4i (&fa)[4], const v4i (&fb)[2]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       rsw[j] = __builtin_amdgcn_sdot4(fb[j].x, 0x01010101, rsw[j], false);
       rsw[j] = __builtin_amdgcn_sdot4(fb[j].y, 0x01010101, rsw[j], false);
       rsw[j] = __builtin_amdgcn_sdot4(fb[j].z, 0x01010101, rsw[j], false);
       rsw[j] = __builtin_amdgcn_sdot4(fb[j].w, 0x01010101, rsw[j], false);
+    }
+    if constexpr (WOFF) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rsx_acc[i] = __builtin_amdgcn_sdot4(fa[i].x, 0x01010101, rsx_acc[i], false);
+        rsx_acc[i] = __builtin_amdgcn_sdot4(fa[i].y, 0x01010101, rsx_acc[i], false);
+        rsx_acc[i] = __builtin_amdgcn_sdot4(fa[i].z, 0x01010101, rsx_acc[i], false);
+        rsx_acc[i] = __builtin_amdgcn_sdot4(fa[i].w, 0x01010101, rsx_acc[i], false);
+      }
     }
   };
   auto mfma_rest = [&](const v4i (&fa)[4], const v4i (&fb)[2]) {
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
     const int next = stage + 1 == STAGES2 ? 0 : stage + 1;
     // ---- first half
     __builtin_amdgcn_s_setprio(1);
-    rowsums(fb0);
+    rowsums(fa0, fb0);
     acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb0[0], fa0[0], acc[0][0], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_frags(lds2 + stage * STAGE_BYTES2, 1, fa1, fb1);
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
     __builtin_amdgcn_s_barrier();
     // ---- second half (the reads of the last iteration fetch a stale stage and are never used)
     __builtin_amdgcn_s_setprio(1);
-    rowsums(fb1);
+    rowsums(fa1, fb1);
     acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb1[0], fa1[0], acc[0][0], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_frags(lds2 + next * STAGE_BYTES2, 0, fa0, fb0);
@@ -394,6 +404,10 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
   // lanes l and l+32 hold the two k-halves of the same weight row
 #pragma unroll
   for (int j = 0; j < 2; ++j) rsw[j] += __shfl_xor(rsw[j], 32, 64);
+  if constexpr (WOFF) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rsx_acc[i] += __shfl_xor(rsx_acc[i], 32, 64);
+  }
 
   // Epilogue. The weight fragment is the MFMA's A operand, so with the 32x32 C/D layout
   // (col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) lane l holds, for each (i, j, q):
@@ -431,7 +445,7 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
     m = m_ok[i] ? m : a.M - 1;
     sx[i] = a.x_scale[a.x_per_row ? m : 0];
     ox[i] = a.x_offset ? rne(a.x_offset[a.x_per_row ? m : 0]) : 0.0f;
-    rsx[i] = a.rowsum_x ? (float)a.rowsum_x[m] : 0.0f;
+    rsx[i] = WOFF ? (float)rsx_acc[i] : 0.0f;  // this lane's MFMA column IS its activation row
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -569,10 +583,6 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
   a.tiles_n = (int)((N + BN - 1) / BN);
 
   int32_t* ws = static_cast<int32_t*>(workspace);
-  if (w_offset) {  // needs sum_k xq[m,k]
-    rowsum_i8_kernel<<<(unsigned)((M + 3) / 4), 256, 0, s>>>(xq, (int)M, (int)K, ws);
-    a.rowsum_x = ws;
-  }
   // the direct-to-LDS kernels compute the weight row sums themselves; they need K % 64 == 0
   static const int force_v1 = getenv("FFQ_GEMM_V1") ? 1 : 0;
   static const int force_nw = getenv("FFQ_GEMM_NW") ? atoi(getenv("FFQ_GEMM_NW")) : 0;
@@ -587,19 +597,20 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
     const size_t ring_bytes = (size_t)STAGES2 * (BM2 + bn) * BK2;
     const size_t epilogue_bytes = (size_t)nw * (128 * 144 + 256);  // one padded 128 x 64 bf16 tile per wave
     const size_t lds_bytes = ring_bytes > epilogue_bytes ? ring_bytes : epilogue_bytes;
-#define FFQ_GEMM2_NW(T, RQ, NW)                                                                            \
+#define FFQ_GEMM2_NW(T, RQ, NW, WO)                                                                        \
   do {                                                                                                     \
     static bool attr_set = false;                                                                          \
     if (!attr_set) {                                                                                       \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256_kernel<T, RQ, NW>),            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256_kernel<T, RQ, NW, WO>),        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);               \
       attr_set = true;                                                                                     \
     }                                                                                                      \
-    w8a8_gemm256_kernel<T, RQ, NW><<<grid2, NW * 64, lds_bytes, s>>>(a);                                   \
+    w8a8_gemm256_kernel<T, RQ, NW, WO><<<grid2, NW * 64, lds_bytes, s>>>(a);                               \
   } while (0)
 #define FFQ_GEMM2(T, RQ)                                                                                   \
   do {                                                                                                     \
-    if (nw == 8) FFQ_GEMM2_NW(T, RQ, 8); else FFQ_GEMM2_NW(T, RQ, 4);                                      \
+    if (nw == 8) { if (w_offset) FFQ_GEMM2_NW(T, RQ, 8, true); else FFQ_GEMM2_NW(T, RQ, 8, false); }       \
+    else { if (w_offset) FFQ_GEMM2_NW(T, RQ, 4, true); else FFQ_GEMM2_NW(T, RQ, 4, false); }               \
   } while (0)
     if (requant) {
       switch (out_dt) {
@@ -619,6 +630,11 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
 #undef FFQ_GEMM2
 #undef FFQ_GEMM2_NW
     return check_launch("w8a8_gemm256_kernel");
+  }
+  // 128^2 kernel (small problems, K tails): row sums by a separate one-pass reduction
+  if (w_offset) {  // needs sum_k xq[m,k]
+    rowsum_i8_kernel<<<(unsigned)((M + 3) / 4), 256, 0, s>>>(xq, (int)M, (int)K, ws);
+    a.rowsum_x = ws;
   }
   if (x_offset) {  // needs sum_k wq[n,k]
     rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(wq, (int)N, (int)K, ws + M);

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun) from the repo root: kernel-trace stats of the default bench command,
+# then two separate PMC passes (FETCH_SIZE, WRITE_SIZE; never combined with other trace domains).
+# Raw outputs are summarised in place and deleted (gpurun copies back at most 64 MiB).
+set -u
+export TMPDIR=/tmp
+TAG=${1:-r01}
+OUT=gpurun_out/profiles
+rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --kernel-trace --stats -d $OUT/bench_trace -o bench -- python3 bench.py > $OUT/${TAG}_bench_under_rocprof.log 2>&1
+echo "trace rc=$?"
+python3 tools/rocprof_summary.py $OUT/bench_trace/bench_results.db $OUT/${TAG}_bench_kernel_stats.md "$TAG — rocprofv3 --kernel-trace --stats -- python3 bench.py (Llama-3-8B W8A8 forward, B=8 S=2048, 1x MI355X)"
+rm -rf $OUT/bench_trace
+grep '^{' $OUT/${TAG}_bench_under_rocprof.log > $OUT/${TAG}_bench_line_under_rocprof.json
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$c -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-graph --calib-seqs 8 > $OUT/pmc_$c.log 2>&1
+  echo "$c rc=$?"
+  python3 tools/pmc_summary.py $(ls $OUT/pmc_$c/*counter_collection.csv | head -1) $c $OUT/${TAG}_pmc_${c}.json
+  rm -rf $OUT/pmc_$c $OUT/pmc_$c.log
+done
+python3 bench.py > $OUT/${TAG}_bench_plain.log 2>&1
+grep '^{' $OUT/${TAG}_bench_plain.log > $OUT/${TAG}_bench_line.json
+du -sh $OUT; ls -la $OUT
