@@ -24,6 +24,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace ffq {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const v4i*>(st + a_off[i][kk]);
   };
-  auto rowsums = [&](const v4i (&fa)[4], const v4i (&fb)[2]) {
+  auto rowsums = [&](auto with_x, const v4i (&fa)[4], const v4i (&fb)[2]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       rsw[j] = __builtin_amdgcn_sdot4(fb[j].x, 0x01010101, rsw[j], false);
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
       rsw[j] = __builtin_amdgcn_sdot4(fb[j].z, 0x01010101, rsw[j], false);
       rsw[j] = __builtin_amdgcn_sdot4(fb[j].w, 0x01010101, rsw[j], false);
     }
-    if constexpr (WOFF) {
+    if constexpr (decltype(with_x)::value) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         rsx_acc[i] = __builtin_amdgcn_sdot4(fa[i].x, 0x01010101, rsx_acc[i], false);
@@ -353,53 +355,68 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
   __builtin_amdgcn_s_barrier();
   read_frags(lds2, 0, fa0, fb0);
 
-  int stage = 0;
-  for (int kt = 0; kt < ksteps; ++kt) {
-    const int next = stage + 1 == STAGES2 ? 0 : stage + 1;
-    // ---- first half
-    __builtin_amdgcn_s_setprio(1);
-    rowsums(fa0, fb0);
-    acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb0[0], fa0[0], acc[0][0], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(lds2 + stage * STAGE_BYTES2, 1, fa1, fb1);
-    mfma_rest(fa0, fb0);
-#pragma unroll
-    for (int g = 0; g < 6; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(0);
-    // ---- middle: tile kt+1 landed (tile kt+2 stays in flight), my LDS reads done, everybody here
-    if constexpr (DMA_PER_STEP == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // ---- second half (the reads of the last iteration fetch a stale stage and are never used)
-    __builtin_amdgcn_s_setprio(1);
-    rowsums(fa1, fb1);
-    acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb1[0], fa1[0], acc[0][0], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_frags(lds2 + next * STAGE_BYTES2, 0, fa0, fb0);
-    issue(kt + 3, stage);
-    mfma_rest(fa1, fb1);
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x010, DMA_PER_STEP == 4 ? 1 : 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x010, DMA_PER_STEP == 4 ? 1 : 0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(0);
-    stage = next;
+  // The activation row sums (needed only for the ow * sum_k xq term) cost 32 extra v_dot4 per K-step
+  // and measurably slow the loop (+7 % per launch), while symmetric weight quantizers carry an offset
+  // BUFFER that is all zeros (reference nn/linear_quantizer.py:164-170). The block therefore looks at the
+  // offsets of ITS columns on the device and takes the loop without them when they are all zero —
+  // no host synchronisation, same result.
+  bool need_x_sums = false;
+  if constexpr (WOFF) {
+    int n = n0 + (tid % BN2);
+    n = n < a.N ? n : a.N - 1;
+    need_x_sums = __syncthreads_or(rne(a.w_offset[a.w_per_row ? n : 0]) != 0.0f) != 0;
   }
+  auto k_loop = [&](auto with_x) {
+    int stage = 0;
+    for (int kt = 0; kt < ksteps; ++kt) {
+      const int next = stage + 1 == STAGES2 ? 0 : stage + 1;
+      // ---- first half
+      __builtin_amdgcn_s_setprio(1);
+      rowsums(with_x, fa0, fb0);
+      acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb0[0], fa0[0], acc[0][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(lds2 + stage * STAGE_BYTES2, 1, fa1, fb1);
+      mfma_rest(fa0, fb0);
+  #pragma unroll
+      for (int g = 0; g < 6; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+      // ---- middle: tile kt+1 landed (tile kt+2 stays in flight), my LDS reads done, everybody here
+      if constexpr (DMA_PER_STEP == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // ---- second half (the reads of the last iteration fetch a stale stage and are never used)
+      __builtin_amdgcn_s_setprio(1);
+      rowsums(with_x, fa1, fb1);
+      acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb1[0], fa1[0], acc[0][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(lds2 + next * STAGE_BYTES2, 0, fa0, fb0);
+      issue(kt + 3, stage);
+      mfma_rest(fa1, fb1);
+  #pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, DMA_PER_STEP == 4 ? 1 : 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, DMA_PER_STEP == 4 ? 1 : 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+      stage = next;
+    }
+  };
+  if (need_x_sums) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing dummy DMA must not land in the epilogue's LDS
   // lanes l and l+32 hold the two k-halves of the same weight row
 #pragma unroll
