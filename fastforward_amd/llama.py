@@ -40,6 +40,7 @@ class LlamaConfig:
     vocab_size: int = 128256
     rope_theta: float = 500000.0
     rms_norm_eps: float = 1e-5
+    attention: str = "sdpa"  # "sdpa": fused torch attention; "eager": the op sequence of the reference's helper
 
     @property
     def head_dim(self) -> int:
@@ -109,8 +110,26 @@ class LlamaAttention(torch.nn.Module):
         v = self.v_proj(hidden_states).view(b, s, cfg.num_kv_heads, cfg.head_dim).transpose(1, 2)
         q = q * cos + _rotate_half(q) * sin
         k = k * cos + _rotate_half(k) * sin
-        attn = F.scaled_dot_product_attention(q, k, v, is_causal=s > 1, enable_gqa=cfg.num_kv_heads != cfg.num_heads)
+        if cfg.attention == "eager":
+            attn = self._eager_attention(q, k, v)
+        else:
+            attn = F.scaled_dot_product_attention(q, k, v, is_causal=s > 1, enable_gqa=cfg.num_kv_heads != cfg.num_heads)
         return self.o_proj(attn.transpose(1, 2).reshape(b, s, -1))
+
+    def _eager_attention(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        """matmul -> scale -> additive causal mask -> fp32 softmax -> matmul, the order used by the
+        reference's QuantizedLlamaAttention (docs/examples/doc_helpers/quantized_llama/attention.py:60-92)."""
+        cfg = self.config
+        groups = cfg.num_heads // cfg.num_kv_heads
+        b, _, s, d = q.shape
+        if groups > 1:  # repeat_kv
+            k = k[:, :, None, :, :].expand(b, cfg.num_kv_heads, groups, s, d).reshape(b, cfg.num_heads, s, d)
+            v = v[:, :, None, :, :].expand(b, cfg.num_kv_heads, groups, s, d).reshape(b, cfg.num_heads, s, d)
+        weights = torch.matmul(q, k.transpose(2, 3)) * (d**-0.5)
+        mask = torch.full((s, s), torch.finfo(q.dtype).min, dtype=q.dtype, device=q.device).triu(1)
+        weights = weights + mask
+        weights = F.softmax(weights.to(torch.float32), dim=-1).to(q.dtype)
+        return torch.matmul(weights, v)
 
 
 class LlamaMLP(torch.nn.Module):
@@ -222,6 +241,18 @@ class QuantizedEmbedding(QuantizedModule, torch.nn.Embedding):
 
 
 # ---- recipe ------------------------------------------------------------------------------------------
+def load_hf_state_dict(model: LlamaModel, weights: dict[str, torch.Tensor]) -> None:
+    """Load a Hugging Face ``LlamaForCausalLM`` state dict (keys ``model.layers.N...``, ``lm_head.weight``)."""
+    own = model.state_dict()
+    with torch.no_grad():
+        for key, value in weights.items():
+            name = key.removeprefix("model.")
+            if name in own:
+                own[name].copy_(value.to(own[name].dtype))
+            elif "rotary" not in name:
+                raise KeyError(key)
+
+
 def decoder_linears(model: LlamaModel):
     """(name, QuantizedLinear) for the 7 linears of every decoder layer — what the reference's queries
     ``**/layers/*/self_attn/*`` and ``**/layers/*/mlp/*`` select; lm_head is not matched."""

@@ -297,6 +297,68 @@ def g6_linear():
     return cases
 
 
+def g7_tiny_llama():
+    """End-to-end: the reference's Llama W8A8 recipe on a 2-layer fp32 model (CPU eager).
+
+    Follows docs/examples/quick_start_quantize_llms.nb.py: quantize_model (:140), strict off (:145),
+    weight quantizers LinearQuantizer(8, PerChannel()) on self_attn/* and mlp/* (:159-161),
+    input quantizers LinearQuantizer(8, symmetric=False, PerTensor()) on every nn.Linear of the layers
+    (:227-232), RunningMinMax calibration (:193,255). Stored: the weights (bf16-representable fp32),
+    token ids, all 28 quantizers' (scale, offset), the int8 codes each input quantizer produced in the
+    final forward, and the logits.
+    """
+    sys.path.insert(0, "/root/reference/docs/examples")
+    from doc_helpers import quantized_llama  # noqa: F401  (registers the quantized Llama modules)
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    cfg = LlamaConfig(
+        hidden_size=128, intermediate_size=448, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2,
+        vocab_size=256, max_position_embeddings=128, rms_norm_eps=1e-5, rope_theta=500000.0,
+        attn_implementation="eager", tie_word_embeddings=False, attention_bias=False, mlp_bias=False,
+    )
+    torch.manual_seed(1240)
+    model = LlamaForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for p_ in model.parameters():
+            if p_.dim() >= 2:
+                p_.normal_(0.0, 0.08)
+            p_.copy_(p_.to(torch.bfloat16).float())  # store as bf16, compute in fp32
+    weights = {k: v.detach().to(torch.bfloat16) for k, v in model.state_dict().items() if "rotary" not in k}
+    g = torch.Generator().manual_seed(1241)
+    calib = [torch.randint(0, cfg.vocab_size, (4, 64), generator=g) for _ in range(2)]
+    ids = torch.randint(0, cfg.vocab_size, (4, 64), generator=g)
+
+    ff.quantize_model(model)
+    ff.set_strict_quantization(False)
+    w_quantizers = ff.find_quantizers(model, "**/layers/*/self_attn/*/[quantizer:parameter/weight]")
+    w_quantizers |= ff.find_quantizers(model, "**/layers/*/mlp/*/[quantizer:parameter/weight]")
+    w_quantizers.initialize(ff.nn.LinearQuantizer, num_bits=8, granularity=ff.PerChannel())
+    a_quantizers = ff.find_quantizers(model, "**/layers/**/[cls:torch.nn.Linear]/[quantizer:activation/input]")
+    a_quantizers.initialize(ff.nn.LinearQuantizer, num_bits=8, symmetric=False, granularity=ff.PerTensor())
+    with torch.no_grad(), ff.estimate_ranges(model, ff.range_setting.running_minmax):
+        for batch in calib:
+            model(batch)
+    named = dict(ff.nn.quantized_module.named_quantizers(model))
+    assert len(named) == 28, len(named)
+    codes = {}
+    hooks = []
+    for name, q in named.items():
+        if name.endswith("input_quantizer"):
+            hooks.append(q.register_forward_hook(lambda mod, inp, out, name=name: codes.__setitem__(name, out.raw_data.to(torch.int8).clone())))
+    with torch.no_grad():
+        logits = model(ids).logits
+    for h in hooks:
+        h.remove()
+    ff.set_strict_quantization(True)
+    return {
+        "config": {"hidden_size": 128, "intermediate_size": 448, "num_layers": 2, "num_heads": 8, "num_kv_heads": 2,
+                   "vocab_size": 256, "rope_theta": 500000.0, "rms_norm_eps": 1e-5},
+        "weights": weights, "calibration_ids": calib, "ids": ids,
+        "quantizers": {n: {"scale": q.scale.detach().clone(), "offset": None if q.offset is None else q.offset.detach().clone()} for n, q in named.items()},
+        "input_codes": codes, "logits": logits.clone(),
+    }
+
+
 def g8_int4():
     """Group-128 4-bit codes and their GGUF Q4_0 nibble packing (block 32)."""
     torch.manual_seed(77)
@@ -344,6 +406,7 @@ def main() -> None:
     torch.save(g4_ranges(), HERE / "g4_ranges.pt")
     torch.save(g5_minmax(), HERE / "g5_minmax.pt")
     torch.save(g6_linear(), HERE / "g6_linear.pt")
+    torch.save(g7_tiny_llama(), HERE / "g7_tiny_llama.pt")
     torch.save(g8_int4(), HERE / "g8_int4.pt")
     torch.save(g9_dispatcher(), HERE / "g9_dispatcher.pt")
     for f in sorted(HERE.glob("*.pt")):

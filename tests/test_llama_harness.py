@@ -1,0 +1,98 @@
+"""The Llama-3 harness (fastforward_amd/llama.py) against the reference's own recipe (fixture G7).
+
+The fixture was produced by the reference's quantized Llama helpers on a 2-layer fp32 model
+(tests/golden/gen_golden.py::g7_tiny_llama). The harness loads the same weights and must reproduce:
+  * with the float fallback linear (the reference's own code path): every quantizer's (scale, offset),
+    the int8 codes of all 14 input quantizers and the logits — exactly, on CPU (same torch ops);
+  * with the fused int8 linear: weight quantizers exactly; activation ranges, codes and logits within
+    the tolerance of a differently rounded (exact-integer) contraction.
+"""
+
+import pytest
+import torch
+
+import fastforward_amd as ff
+
+from conftest import golden
+from fastforward_amd import llama
+
+
+def build(fixture, device, fused: bool):
+    cfg = llama.LlamaConfig(attention="eager", **fixture["config"])
+    model = llama.LlamaModel(cfg).to(torch.float32).eval()
+    llama.load_hf_state_dict(model, fixture["weights"])
+    model.to(device)
+    llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8 if fused else None)
+    with torch.no_grad(), ff.strict_quantization(False):
+        with ff.estimate_ranges(model, ff.range_setting.running_minmax):
+            for batch in fixture["calibration_ids"]:
+                model(batch.to(device), logits=False)
+    return model
+
+
+def run(fixture, device, fused: bool):
+    if not fused:  # take the fused kernel out of the dispatcher: the reference's float fallback runs
+        ff.fused_linear._registration.remove()
+    try:
+        model = build(fixture, device, fused)
+        codes = {}
+        handles = []
+        for name, q in ff.nn.named_quantizers(model):
+            if name.endswith("input_quantizer"):
+                handles.append(q.register_forward_hook(lambda m, i, o, name=name: codes.__setitem__("model." + name, o.raw_data.to(torch.int8).cpu())))
+        with torch.no_grad(), ff.strict_quantization(False):
+            logits = model(fixture["ids"].to(device)).float().cpu()
+        for h in handles:
+            h.remove()
+        params = {"model." + n: (q.scale.detach().cpu(), None if q.offset is None else q.offset.detach().cpu()) for n, q in ff.nn.named_quantizers(model)}
+        return params, codes, logits
+    finally:
+        if not fused:
+            ff.fused_linear._registration = ff.dispatcher.register("linear", ff.fused_linear.fused_linear_predicate, ff.fused_linear.fused_linear)
+
+
+def check_exact(fixture, params, codes, logits):
+    assert set(params) == set(fixture["quantizers"]) and len(params) == 28
+    for name, want in fixture["quantizers"].items():
+        scale, offset = params[name]
+        assert torch.equal(scale, want["scale"]), name
+        assert torch.equal(offset, want["offset"]), name
+    for name, want in fixture["input_codes"].items():
+        assert torch.equal(codes[name], want), name
+    assert torch.equal(logits, fixture["logits"])
+
+
+def check_close(fixture, params, codes, logits):
+    for name, want in fixture["quantizers"].items():
+        scale, offset = params[name]
+        if name.endswith("weight_quantizer"):
+            assert torch.equal(scale, want["scale"]) and torch.equal(offset, want["offset"]), name
+        else:
+            torch.testing.assert_close(scale, want["scale"], rtol=2e-3, atol=0)
+            torch.testing.assert_close(offset, want["offset"], rtol=0, atol=0.5)
+    for name, want in fixture["input_codes"].items():
+        off_by = (codes[name].int() - want.int()).abs()
+        assert int(off_by.max()) <= 2 and float((off_by > 0).float().mean()) < 0.05, name
+    # a flipped activation code moves a logit by about one quantization step of the layers above it:
+    # bound the error against the spread of the logits instead of element-wise relative error
+    err, spread = logits - fixture["logits"], float(fixture["logits"].std())
+    assert float(err.pow(2).mean().sqrt()) < 0.02 * spread and float(err.abs().max()) < 0.3 * spread
+
+
+def test_harness_reproduces_reference_recipe_exactly_with_float_linear(oracle_backend):
+    fixture = golden("g7_tiny_llama.pt")
+    check_exact(fixture, *run(fixture, "cpu", fused=False))
+
+
+def test_harness_with_fused_int8_linear_is_close(oracle_backend):
+    fixture = golden("g7_tiny_llama.pt")
+    check_close(fixture, *run(fixture, "cpu", fused=True))
+
+
+@pytest.mark.gpu
+def test_harness_on_gpu(hip_backend):
+    fixture = golden("g7_tiny_llama.pt")
+    params, codes, logits = run(fixture, "cuda", fused=True)
+    check_close(fixture, params, codes, logits)
+    params, codes, logits = run(fixture, "cuda", fused=False)
+    check_close(fixture, params, codes, logits)  # float GEMMs on the GPU round differently than on the CPU
