@@ -312,8 +312,8 @@ def g7_tiny_llama():
     from transformers import LlamaConfig, LlamaForCausalLM
 
     cfg = LlamaConfig(
-        hidden_size=128, intermediate_size=448, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2,
-        vocab_size=256, max_position_embeddings=128, rms_norm_eps=1e-5, rope_theta=500000.0,
+        hidden_size=256, intermediate_size=896, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2,
+        vocab_size=512, max_position_embeddings=128, rms_norm_eps=1e-5, rope_theta=500000.0,
         attn_implementation="eager", tie_word_embeddings=False, attention_bias=False, mlp_bias=False,
     )
     torch.manual_seed(1240)
@@ -351,8 +351,8 @@ def g7_tiny_llama():
         h.remove()
     ff.set_strict_quantization(True)
     return {
-        "config": {"hidden_size": 128, "intermediate_size": 448, "num_layers": 2, "num_heads": 8, "num_kv_heads": 2,
-                   "vocab_size": 256, "rope_theta": 500000.0, "rms_norm_eps": 1e-5},
+        "config": {"hidden_size": 256, "intermediate_size": 896, "num_layers": 2, "num_heads": 8, "num_kv_heads": 2,
+                   "vocab_size": 512, "rope_theta": 500000.0, "rms_norm_eps": 1e-5},
         "weights": weights, "calibration_ids": calib, "ids": ids,
         "quantizers": {n: {"scale": q.scale.detach().clone(), "offset": None if q.offset is None else q.offset.detach().clone()} for n, q in named.items()},
         "input_codes": codes, "logits": logits.clone(),
