@@ -18,7 +18,8 @@ from typing import Sequence
 from fastforward_amd.exceptions import QuantizationError
 
 FFQ_MAX_DIMS = 8
-FFQ_ABI_VERSION = 1
+FFQ_MAX_FANOUT = 3
+FFQ_ABI_VERSION = 2
 
 
 class Status(enum.IntEnum):
@@ -93,12 +94,36 @@ class Tiling(ctypes.Structure):
         return t
 
 
+class FanOut(ctypes.Structure):
+    """``ffq_fanout``: the static per-tensor int8 quantizers fed by one fused producer."""
+
+    _fields_ = [
+        ("count", ctypes.c_int32),
+        ("num_bits", ctypes.c_double),
+        ("scale", ctypes.c_void_p * FFQ_MAX_FANOUT),
+        ("offset", ctypes.c_void_p * FFQ_MAX_FANOUT),
+        ("codes", ctypes.c_void_p * FFQ_MAX_FANOUT),
+    ]
+
+    @classmethod
+    def make(cls, num_bits: float, scales: Sequence[int], offsets: Sequence[int | None], codes: Sequence[int]) -> "FanOut":
+        if not (len(scales) == len(offsets) == len(codes)) or len(scales) > FFQ_MAX_FANOUT:
+            raise ValueError(f"a fused producer feeds at most {FFQ_MAX_FANOUT} quantizers")
+        f = cls()
+        f.count = len(scales)
+        f.num_bits = float(num_bits)
+        for j, (s, o, c) in enumerate(zip(scales, offsets, codes)):
+            f.scale[j], f.offset[j], f.codes[j] = s, o, c
+        return f
+
+
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _i64 = ctypes.c_int64
 _d = ctypes.c_double
 _sz = ctypes.c_size_t
 _tp = ctypes.POINTER(Tiling)
+_fp = ctypes.POINTER(FanOut)
 
 # name -> (restype, argtypes); mirrors include/ffq.h one to one.
 SIGNATURES: dict[str, tuple[object, list[object]]] = {
@@ -123,6 +148,9 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
         _i,
         [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp],
     ),
+    "ffq_add_rmsnorm_quantize": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _d, _vp, _fp, _vp]),
+    "ffq_silu_mul_quantize": (_i, [_vp, _vp, _i, _i64, _vp, _fp, _vp]),
+    "ffq_rope_inplace": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _i64, _vp, _vp, _vp]),
 }
 
 

@@ -305,6 +305,156 @@ def calibrate(model: LlamaModel, batches, sync_free: bool = True, disable_quanti
                 model(ids, logits=False)
 
 
+class FusedForward:
+    """Inference forward of a calibrated W8A8 Llama with A1 fused into the kernels that produce the
+    quantized linears' inputs.
+
+    The module graph above follows the reference helpers op for op: every ``QuantizedLinear`` quantizes
+    its own input (reference nn/linear.py:33) and RMSNorm / rotary / SiLU*up run as eager ATen chains
+    between the hot-path calls. This runner executes the same computation with the producers of
+    ``fastforward_amd/csrc/ffq_producers.hip``: residual add + RMSNorm + the q/k/v (or gate/up) input
+    quantizers in one pass, SiLU(gate)*up + the down_proj input quantizer in one pass, rotary embedding
+    in place on the projections. Weight quantizers still run on every call (reference nn/linear.py:34)
+    unless ``cache_weight_codes`` is set, in which case codes are kept per ``(weight, scale, offset)``
+    version (weights of a calibrated inference model do not change).
+
+    It refuses anything it cannot reproduce exactly — active quantizer overrides (i.e. a running
+    ``estimate_ranges``), non-stub activation quantizers between the linears, dynamic quantizers,
+    per-channel activations, biases — instead of silently computing something else.
+    """
+
+    def __init__(self, model: LlamaModel, cache_weight_codes: bool = False) -> None:
+        problems = self.unsupported(model)
+        if problems:
+            raise ff.exceptions.QuantizationError("FusedForward cannot run this model: " + "; ".join(problems[:4]))
+        self.model = model
+        self.cache_weight_codes = cache_weight_codes
+        self._weight_cache: dict[int, tuple[tuple[int, int, int], torch.Tensor]] = {}
+        # One host comparison per layer, once: consumers of the same tensor usually hold the same range.
+        self._fan: list[dict[str, tuple[list[tuple[torch.Tensor, torch.Tensor | None]], list[int]]]] = []
+        for layer in model.layers:
+            attn, mlp = layer.self_attn, layer.mlp
+            self._fan.append({
+                "qkv": self._distinct([attn.q_proj, attn.k_proj, attn.v_proj]),
+                "gate_up": self._distinct([mlp.gate_proj, mlp.up_proj]),
+            })
+
+    @staticmethod
+    def _params(linear: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor | None]:
+        q = linear.input_quantizer
+        return q.scale, q.offset
+
+    @classmethod
+    def _distinct(cls, linears: list[torch.nn.Module]) -> tuple[list[tuple[torch.Tensor, torch.Tensor | None]], list[int]]:
+        """(distinct parameter pairs, index of each linear's pair)."""
+        pairs: list[tuple[torch.Tensor, torch.Tensor | None]] = []
+        index: list[int] = []
+        for linear in linears:
+            s, o = cls._params(linear)
+            for i, (ps, po) in enumerate(pairs):
+                if torch.equal(ps, s) and ((po is None and o is None) or (po is not None and o is not None and torch.equal(po, o))):
+                    index.append(i)
+                    break
+            else:
+                pairs.append((s, o))
+                index.append(len(pairs) - 1)
+        return pairs, index
+
+    @staticmethod
+    def unsupported(model: LlamaModel) -> list[str]:
+        from fastforward_amd.nn import LinearQuantizer
+
+        problems: list[str] = []
+        cfg = model.config
+        if cfg.hidden_size % 16 or cfg.hidden_size > 8192 or cfg.head_dim % 16 or cfg.intermediate_size % 16:
+            problems.append("hidden size / head dim outside the fused kernels' range")
+        if next(model.parameters()).dtype != torch.bfloat16:
+            problems.append("fused producers are built for bf16 models")
+        for name, q in ff.nn.named_quantizers(model, skip_stubs=False):
+            if q is None:
+                continue
+            if next(iter(q.overrides), None) is not None:
+                problems.append(f"{name}: an override is active (range estimation running?)")
+            is_linear_slot = any(name.endswith(f"{p}.{slot}") for p in ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj") for slot in ("input_quantizer", "weight_quantizer")) and ".layers." in "." + name
+            if not is_linear_slot:
+                if not q.is_stub():
+                    problems.append(f"{name}: only the decoder linears' input/weight quantizers may be set")
+                continue
+            if not isinstance(q, LinearQuantizer) or q.has_uninitialized_params:
+                problems.append(f"{name}: needs an initialised LinearQuantizer")
+                continue
+            if q.num_bits > 8 or int(q.num_bits) != q.num_bits:
+                problems.append(f"{name}: more than 8 bits")
+            if name.endswith("input_quantizer") and (not q.per_tensor or q.scale.numel() != 1):
+                problems.append(f"{name}: activation quantizers must be per-tensor")
+            if name.endswith("weight_quantizer") and q.quantized_dtype is not torch.int8:
+                problems.append(f"{name}: weight codes must be stored as int8")
+        for name, linear in decoder_linears(model):
+            if linear.bias is not None:
+                problems.append(f"{name}: bias")
+        return problems
+
+    def _weight(self, linear: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None]:
+        """(int8 codes, scale, offset) of the linear's weight — A1 through the quantizer's own forward."""
+        wq = linear.weight_quantizer
+        if self.cache_weight_codes:
+            key = (linear.weight._version, wq.scale._version, -1 if wq.offset is None else wq.offset._version)
+            hit = self._weight_cache.get(id(linear))
+            if hit is not None and hit[0] == key:
+                return hit[1], wq.scale, wq.offset
+            codes = wq(linear.weight).raw_data
+            self._weight_cache[id(linear)] = (key, codes)
+            return codes, wq.scale, wq.offset
+        return wq(linear.weight).raw_data, wq.scale, wq.offset
+
+    def _linear(self, x_codes: torch.Tensor, linear: torch.nn.Module) -> torch.Tensor:
+        w_codes, w_scale, w_offset = self._weight(linear)
+        x_scale, x_offset = self._params(linear)
+        return ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16)
+
+    @torch.no_grad()
+    def __call__(self, input_ids: torch.Tensor, logits: bool = True) -> torch.Tensor:
+        model, cfg = self.model, self.model.config
+        b, s = input_ids.shape
+        d = cfg.head_dim
+        hidden = model.embed_tokens(input_ids)
+        cos, sin = rotary_tables(s, d, cfg.rope_theta, hidden.device, hidden.dtype)
+        pending: torch.Tensor | None = None
+        for layer, fan in zip(model.layers, self._fan):
+            attn, mlp = layer.self_attn, layer.mlp
+            pairs, index = fan["qkv"]
+            bits = attn.q_proj.input_quantizer.num_bits
+            hidden, _, codes = ff.ops.add_rmsnorm_quantize(
+                hidden, pending, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, pairs, bits, sum_inplace=pending is not None
+            )
+            q = self._linear(codes[index[0]], attn.q_proj)
+            k = self._linear(codes[index[1]], attn.k_proj)
+            v = self._linear(codes[index[2]], attn.v_proj)
+            ff.ops.rope_(q, k, cos, sin, d)
+            ctx = F.scaled_dot_product_attention(
+                q.view(b, s, cfg.num_heads, d).transpose(1, 2), k.view(b, s, cfg.num_kv_heads, d).transpose(1, 2),
+                v.view(b, s, cfg.num_kv_heads, d).transpose(1, 2), is_causal=s > 1, enable_gqa=cfg.num_kv_heads != cfg.num_heads,
+            ).transpose(1, 2).reshape(b, s, -1)
+            o_in = attn.o_proj.input_quantizer
+            o_codes = ff.ops.quantize_by_tile(ctx, o_in.scale, ctx.shape, o_in.num_bits, torch.int8, o_in.offset)
+            attn_out = self._linear(o_codes, attn.o_proj)
+            pairs, index = fan["gate_up"]
+            hidden, _, codes = ff.ops.add_rmsnorm_quantize(
+                hidden, attn_out, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon,
+                pairs, mlp.gate_proj.input_quantizer.num_bits, sum_inplace=True,
+            )
+            gate = self._linear(codes[index[0]], mlp.gate_proj)
+            up = self._linear(codes[index[1]], mlp.up_proj)
+            d_in = mlp.down_proj.input_quantizer
+            _, (d_codes,) = ff.ops.silu_mul_quantize(gate, up, [(d_in.scale, d_in.offset)], d_in.num_bits)
+            pending = self._linear(d_codes, mlp.down_proj)
+        _, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, model.norm.weight, model.norm.variance_epsilon, (), want_sum=False, want_norm=True)
+        if not logits:
+            return normed
+        with ff.strict_quantization(False):  # lm_head stays float in the recipe (quick-start :145)
+            return model.lm_head(normed)
+
+
 def count_quantizers(model: LlamaModel) -> int:
     return sum(1 for _ in ff.nn.named_quantizers(model))
 

@@ -18,7 +18,7 @@ from typing import Sequence
 import torch
 
 from fastforward_amd import _native
-from fastforward_amd._cabi import FLAG_INF, FLAG_NAN, DType, Tiling
+from fastforward_amd._cabi import FLAG_INF, FLAG_NAN, DType, FanOut, Tiling
 from fastforward_amd.exceptions import BackendError
 
 __all__ = [
@@ -31,6 +31,9 @@ __all__ = [
     "pack_int4",
     "unpack_int4",
     "linear_w8a8",
+    "add_rmsnorm_quantize",
+    "silu_mul_quantize",
+    "rope_",
     "FLAG_INF",
     "FLAG_NAN",
 ]
@@ -394,6 +397,102 @@ def linear_w8a8(
         )
     )
     return out
+
+
+def _fan(quantizers: Sequence[tuple[torch.Tensor, torch.Tensor | None]], num_bits: float, shape: Sequence[int], device: torch.device):
+    """(FanOut struct, code tensors, tensors kept alive) for the static per-tensor quantizers of a fused producer."""
+    scales, offsets, keep = [], [], []
+    for scale, offset in quantizers:
+        s = scale.detach().reshape(-1).to(torch.float32)
+        o = None if offset is None else offset.detach().reshape(-1).to(torch.float32)
+        if s.numel() != 1 or (o is not None and o.numel() != 1):
+            raise RuntimeError("fused producers take per-tensor quantizers (one scale, one offset)")
+        scales.append(s)
+        offsets.append(o)
+        keep += [s, o]
+    codes = [torch.empty(tuple(shape), dtype=torch.int8, device=device) for _ in quantizers]
+    fan = FanOut.make(num_bits, [_ptr(s) for s in scales], [_ptr(o) for o in offsets], [_ptr(c) for c in codes])
+    return fan, codes, keep
+
+
+def add_rmsnorm_quantize(
+    x: torch.Tensor,
+    delta: torch.Tensor | None,
+    weight: torch.Tensor,
+    eps: float,
+    quantizers: Sequence[tuple[torch.Tensor, torch.Tensor | None]] = (),
+    num_bits: float = 8.0,
+    want_sum: bool = True,
+    want_norm: bool = False,
+    sum_inplace: bool = False,
+) -> tuple[torch.Tensor | None, torch.Tensor | None, list[torch.Tensor]]:
+    """Residual add + RMSNorm + A1 for up to three per-tensor int8 quantizers, one pass
+    (reference docs/examples/doc_helpers/quantized_llama/rms_norm.py:17-35 behind decoder.py:60-90).
+
+    Returns ``(x + delta, normalised or None, [codes per quantizer])``; with ``delta is None`` the first
+    element is `x` itself. ``sum_inplace`` writes the sum over `x` (the residual stream of a decoder).
+    """
+    xc = x.detach().contiguous()
+    dc = None if delta is None else delta.detach().contiguous()
+    wc = weight.detach().contiguous()
+    if dc is not None and dc.shape != xc.shape:
+        raise RuntimeError(f"residual shapes differ: {tuple(xc.shape)} vs {tuple(dc.shape)}")
+    if wc.dim() != 1 or wc.shape[0] != xc.shape[-1] or wc.dtype != xc.dtype or (dc is not None and dc.dtype != xc.dtype):
+        raise RuntimeError("RMSNorm weight must be [hidden] in the activation dtype")
+    lib, stream = _prepare(xc, dc, wc, *[t for q in quantizers for t in q])
+    cols = xc.shape[-1]
+    rows = xc.numel() // cols if cols else 0
+    if sum_inplace and xc.data_ptr() != x.data_ptr():
+        raise RuntimeError("sum_inplace needs a contiguous residual tensor")
+    total = xc if dc is None or sum_inplace else (torch.empty_like(xc) if want_sum else None)
+    norm = torch.empty_like(xc) if want_norm else None
+    fan, codes, keep = _fan(quantizers, num_bits, xc.shape, xc.device)
+    lib.check(
+        lib.ffq_add_rmsnorm_quantize(
+            _ptr(xc), _ptr(dc), None if dc is None else _ptr(total), _ptr(wc), _tag(xc.dtype), rows, cols, float(eps),
+            _ptr(norm), ctypes.byref(fan), stream,
+        )
+    )
+    del keep
+    return total, norm, codes
+
+
+def silu_mul_quantize(
+    gate: torch.Tensor,
+    up: torch.Tensor,
+    quantizers: Sequence[tuple[torch.Tensor, torch.Tensor | None]] = (),
+    num_bits: float = 8.0,
+    want_product: bool = False,
+) -> tuple[torch.Tensor | None, list[torch.Tensor]]:
+    """``silu(gate) * up`` + A1, one pass (reference quantized_llama/mlp.py:30-40)."""
+    gc, uc = gate.detach().contiguous(), up.detach().contiguous()
+    if gc.shape != uc.shape or gc.dtype != uc.dtype:
+        raise RuntimeError(f"gate and up differ: {tuple(gc.shape)} {gc.dtype} vs {tuple(uc.shape)} {uc.dtype}")
+    lib, stream = _prepare(gc, uc, *[t for q in quantizers for t in q])
+    product = torch.empty_like(gc) if want_product else None
+    fan, codes, keep = _fan(quantizers, num_bits, gc.shape, gc.device)
+    lib.check(lib.ffq_silu_mul_quantize(_ptr(gc), _ptr(uc), _tag(gc.dtype), gc.numel(), _ptr(product), ctypes.byref(fan), stream))
+    del keep
+    return product, codes
+
+
+def rope_(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, head_dim: int) -> None:
+    """Rotary embedding IN PLACE on the q/k projections laid out ``[batch, seq, heads * head_dim]``
+    (reference quantized_llama/attention.py:20-41); `cos`/`sin` are ``[seq, head_dim]``."""
+    if not (q.is_contiguous() and k.is_contiguous() and cos.is_contiguous() and sin.is_contiguous()):
+        raise RuntimeError("rope_ works in place on contiguous projections")
+    if q.dim() != 3 or k.dim() != 3 or q.shape[:2] != k.shape[:2] or cos.shape != (q.shape[1], head_dim) or sin.shape != cos.shape:
+        raise RuntimeError("rope_ expects q/k [batch, seq, heads * head_dim] and cos/sin [seq, head_dim]")
+    if not (q.dtype == k.dtype == cos.dtype == sin.dtype):
+        raise RuntimeError("rope_ expects one dtype")
+    lib, stream = _prepare(q, k, cos, sin)
+    tokens = q.shape[0] * q.shape[1]
+    lib.check(
+        lib.ffq_rope_inplace(
+            _ptr(q), q.shape[2] // head_dim, _ptr(k), k.shape[2] // head_dim, _tag(q.dtype), tokens, q.shape[1], head_dim,
+            _ptr(cos), _ptr(sin), stream,
+        )
+    )
 
 
 # ---------------------------------------------------------------------------------------------

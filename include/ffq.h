@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define FFQ_MAX_DIMS 8
-#define FFQ_ABI_VERSION 1
+#define FFQ_ABI_VERSION 2
 
 typedef enum ffq_status {
   FFQ_OK = 0,
@@ -189,6 +189,56 @@ int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, co
                     const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
                     const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Producer-fused A1 (ABI version 2). In the reference's quantized Llama helpers
+ * (docs/examples/doc_helpers/quantized_llama/) every quantized linear quantizes its own input
+ * (nn/linear.py:33), and those inputs leave three elementwise producers that run as eager ATen
+ * chains. Each entry point below is one pass: the bf16 value the eager chain would have stored is
+ * formed with the same per-op roundings, optionally written, and quantized (A1, static per-tensor
+ * parameters, int8 container) for up to FFQ_MAX_FANOUT consumers. Quantizers holding equal
+ * parameters get equal codes, as they would from separate A1 calls.
+ */
+#define FFQ_MAX_FANOUT 3
+typedef struct ffq_fanout {
+  int32_t count;                          /* 0..FFQ_MAX_FANOUT quantizers fed by this producer     */
+  double num_bits;                        /* shared bit-width (1..8, integral)                      */
+  const float* scale[FFQ_MAX_FANOUT];     /* one fp32 scale each (per-tensor)                       */
+  const float* offset[FFQ_MAX_FANOUT];    /* nullable: zeros                                        */
+  int8_t* codes[FFQ_MAX_FANOUT];          /* outputs, same numel as the producer's result           */
+} ffq_fanout;
+
+/*
+ * RMSNorm behind a residual add — rms_norm.py:17-35 after decoder.py:60-90:
+ *   sum  = x + delta                     (bf16; skipped when delta == NULL, then sum = x)
+ *   h    = float(sum); h = h * rsqrt(mean(h^2, -1) + eps)          (fp32)
+ *   z    = weight * bf16(h)              (bf16)
+ *   codes_j = A1(z; scale_j, offset_j)
+ * x, delta, sum_out, norm_out: [rows, cols] of `dt` (bf16 only); weight: [cols]. sum_out and
+ * norm_out are nullable (sum_out may alias x). The fp32 summation order of mean(h^2) is the
+ * kernel's own, so z can differ from the eager chain by one bf16 ulp on rare elements; the codes are
+ * exactly A1 of the z this call produces. cols % 16 == 0, cols <= 8192.
+ */
+int ffq_add_rmsnorm_quantize(const void* x, const void* delta, void* sum_out, const void* weight,
+                             int dt, int64_t rows, int64_t cols, double eps, void* norm_out,
+                             const ffq_fanout* fan, void* stream);
+
+/*
+ * SiLU(gate) * up — mlp.py:30-40:  z = bf16(silu(float(gate))) * up  (bf16), codes = A1(z).
+ * silu(v) = v / (1 + exp(-v)) in fp32, as ATen evaluates it. product_out is nullable. numel % 16 == 0.
+ */
+int ffq_silu_mul_quantize(const void* gate, const void* up, int dt, int64_t numel, void* product_out,
+                          const ffq_fanout* fan, void* stream);
+
+/*
+ * Rotary position embedding in place — attention.py:20-41 (apply_rotary_pos_emb):
+ *   out = bf16(bf16(v * cos) + bf16(rotate_half(v) * sin)),  rotate_half(v) = cat(-v[D/2:], v[:D/2])
+ * q: [tokens, q_heads, head_dim], k: [tokens, k_heads, head_dim] as they leave the projections;
+ * cos/sin: [seq_len, head_dim]; the position of token t is t % seq_len. head_dim % 16 == 0.
+ */
+int ffq_rope_inplace(void* q, int64_t q_heads, void* k, int64_t k_heads, int dt, int64_t tokens,
+                     int64_t seq_len, int64_t head_dim, const void* cos_table, const void* sin_table,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -671,3 +671,145 @@ int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, co
   free(xr);
   return FFQ_OK;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Producer-fused A1 (ABI version 2): the three elementwise producers of the reference's       */
+/* quantized Llama helpers, docs/examples/doc_helpers/quantized_llama/, each followed by A1.    */
+/* Where the eager chain's result depends on the platform (the order of the fp32 sum in        */
+/* mean(), the last bit of rsqrt and exp) this file takes the most accurate reading (double     */
+/* sum, 1/sqrtf, expf); tests compare the bf16 results with a one-ulp tolerance and the codes   */
+/* through A1 of the values actually produced.                                                  */
+/* ------------------------------------------------------------------------------------------ */
+static float bf16_round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+static int fan_check(const ffq_fanout* fan, double* lo, double* hi) {
+  *lo = *hi = 0.0;
+  if (!fan || fan->count == 0) return FFQ_OK;
+  if (fan->count < 0 || fan->count > FFQ_MAX_FANOUT) return fail(FFQ_ERR_ARG, "fan-out count must be 0..%d", FFQ_MAX_FANOUT);
+  if (!(fan->num_bits >= 1 && fan->num_bits <= 8 && fan->num_bits == floor(fan->num_bits)))
+    return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.", FFQ_I8, fan->num_bits);
+  for (int j = 0; j < fan->count; ++j)
+    if (!fan->scale[j] || !fan->codes[j]) return fail(FFQ_ERR_ARG, "NULL scale / codes in fan-out %d", j);
+  *lo = -pow(2.0, fan->num_bits - 1.0);
+  *hi = -*lo - 1.0;
+  return FFQ_OK;
+}
+
+/* A1 on one bf16-valued element for every quantizer of the fan-out (_quantizer_impl.py:154-169,
+   bf16 data with fp32 parameters: division and subtraction are fp32 ops). */
+static void fan_quantize(const ffq_fanout* fan, double lo, double hi, float z, int64_t i) {
+  if (!fan) return;
+  for (int j = 0; j < fan->count; ++j) {
+    float s = fan->scale[j][0];
+    float o = fan->offset[j] ? nearbyintf(fan->offset[j][0]) : 0.0f;
+    float q = z / s;
+    q = q - o;
+    q = nearbyintf(q);
+    double c = clamp_nan((double)q, lo, hi);
+    st(fan->codes[j], FFQ_I8, i, c);
+  }
+}
+
+/* rms_norm.py:17-35 (LlamaRMSNorm.forward) behind the residual add of decoder.py:60-90 */
+int ffq_add_rmsnorm_quantize(const void* x, const void* delta, void* sum_out, const void* weight,
+                             int dt, int64_t rows, int64_t cols, double eps, void* norm_out,
+                             const ffq_fanout* fan, void* stream) {
+  (void)stream;
+  if (rows < 0 || cols < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "fused RMSNorm is built for bf16 activations");
+  if (cols == 0) return fail(FFQ_ERR_EMPTY, "RMSNorm over an empty row");
+  if (cols % 16 != 0 || cols > 8192) return fail(FFQ_ERR_DTYPE, "fused RMSNorm needs cols %% 16 == 0 and cols <= 8192 (got %lld)", (long long)cols);
+  double lo, hi;
+  int rc = fan_check(fan, &lo, &hi);
+  if (rc) return rc;
+  if (rows == 0) return FFQ_OK;
+  if (!x || !weight) return fail(FFQ_ERR_ARG, "NULL buffer");
+  const uint16_t* xs = (const uint16_t*)x;
+  const uint16_t* ds = (const uint16_t*)delta;
+  const uint16_t* ws = (const uint16_t*)weight;
+  float* h = (float*)malloc((size_t)cols * sizeof(float));
+  for (int64_t r = 0; r < rows; ++r) {
+    double ss = 0.0;
+    for (int64_t c = 0; c < cols; ++c) {
+      float v = bf16_to_f32(xs[r * cols + c]);
+      if (ds) {                                   /* hidden_states = residual + hidden_states (bf16 add) */
+        v = bf16_round(v + bf16_to_f32(ds[r * cols + c]));
+        if (sum_out) ((uint16_t*)sum_out)[r * cols + c] = f32_to_bf16(v);
+      }
+      h[c] = v;                                   /* hidden_states.to(torch.float32)             (:27) */
+      float sq = v * v;                           /* .pow(2)                                     (:28) */
+      ss += (double)sq;
+    }
+    float variance = (float)(ss / (double)cols);  /* .mean(-1, keepdim=True)                     (:28) */
+    float r_std = 1.0f / sqrtf(variance + (float)eps); /* torch.rsqrt(variance + eps)             (:29) */
+    for (int64_t c = 0; c < cols; ++c) {
+      float n = bf16_round(h[c] * r_std);         /* (hidden * rsqrt).to(input_dtype)        (:29-30) */
+      float z = bf16_round(bf16_to_f32(ws[c]) * n); /* self.weight * hidden (bf16 * bf16)         (:30) */
+      if (norm_out) ((uint16_t*)norm_out)[r * cols + c] = f32_to_bf16(z);
+      fan_quantize(fan, lo, hi, z, r * cols + c);
+    }
+  }
+  free(h);
+  return FFQ_OK;
+}
+
+/* mlp.py:30-40: down_proj(act_fn(gate_proj(x)) * up_proj(x)); ATen silu: x / (1 + exp(-x)) in fp32 */
+int ffq_silu_mul_quantize(const void* gate, const void* up, int dt, int64_t numel, void* product_out,
+                          const ffq_fanout* fan, void* stream) {
+  (void)stream;
+  if (numel < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "fused SiLU*up is built for bf16 activations");
+  if (numel % 16 != 0) return fail(FFQ_ERR_DTYPE, "fused SiLU*up needs numel %% 16 == 0 and numel < 2^35");
+  double lo, hi;
+  int rc = fan_check(fan, &lo, &hi);
+  if (rc) return rc;
+  if (numel == 0) return FFQ_OK;
+  if (!gate || !up) return fail(FFQ_ERR_ARG, "NULL buffer");
+  const uint16_t* g = (const uint16_t*)gate;
+  const uint16_t* u = (const uint16_t*)up;
+  for (int64_t i = 0; i < numel; ++i) {
+    float v = bf16_to_f32(g[i]);
+    float act = bf16_round(v / (1.0f + expf(-v)));
+    float z = bf16_round(act * bf16_to_f32(u[i]));
+    if (product_out) ((uint16_t*)product_out)[i] = f32_to_bf16(z);
+    fan_quantize(fan, lo, hi, z, i);
+  }
+  return FFQ_OK;
+}
+
+/* attention.py:20-41: (q * cos) + (rotate_half(q) * sin), rotate_half(x) = cat(-x[D/2:], x[:D/2]) */
+int ffq_rope_inplace(void* q, int64_t q_heads, void* k, int64_t k_heads, int dt, int64_t tokens,
+                     int64_t seq_len, int64_t head_dim, const void* cos_table, const void* sin_table,
+                     void* stream) {
+  (void)stream;
+  if (tokens < 0 || q_heads < 0 || k_heads < 0 || seq_len <= 0 || head_dim <= 0) return fail(FFQ_ERR_ARG, "bad extent");
+  if (dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "fused rotary embedding is built for bf16 activations");
+  if (head_dim % 16 != 0) return fail(FFQ_ERR_DTYPE, "fused rotary embedding needs head_dim %% 16 == 0");
+  if (tokens % seq_len != 0) return fail(FFQ_ERR_ARG, "tokens must be a multiple of seq_len");
+  if (tokens * (q_heads + k_heads) == 0) return FFQ_OK;
+  if ((q_heads && !q) || (k_heads && !k) || !cos_table || !sin_table) return fail(FFQ_ERR_ARG, "NULL buffer");
+  const uint16_t* ct = (const uint16_t*)cos_table;
+  const uint16_t* stb = (const uint16_t*)sin_table;
+  const int64_t half = head_dim / 2;
+  float* tmp = (float*)malloc((size_t)head_dim * sizeof(float));
+  for (int which = 0; which < 2; ++which) {
+    uint16_t* base = (uint16_t*)(which ? k : q);
+    int64_t heads = which ? k_heads : q_heads;
+    for (int64_t t = 0; t < tokens; ++t) {
+      int64_t pos = t % seq_len;
+      for (int64_t hd = 0; hd < heads; ++hd) {
+        uint16_t* row = base + (t * heads + hd) * head_dim;
+        for (int64_t d = 0; d < head_dim; ++d) {
+          float v = bf16_to_f32(row[d]);
+          float rot = d < half ? -bf16_to_f32(row[d + half]) : bf16_to_f32(row[d - half]);
+          float a = bf16_round(v * bf16_to_f32(ct[pos * head_dim + d]));
+          float b = bf16_round(rot * bf16_to_f32(stb[pos * head_dim + d]));
+          tmp[d] = bf16_round(a + b);
+        }
+        for (int64_t d = 0; d < head_dim; ++d) row[d] = f32_to_bf16(tmp[d]);
+      }
+    }
+  }
+  free(tmp);
+  return FFQ_OK;
+}

@@ -397,8 +397,57 @@ def g9_dispatcher():
     return {"functional_then_torch": seen}
 
 
+def g10_producers():
+    """The three elementwise producers of the reference's quantized Llama helpers in bf16 (CPU eager), each
+    followed by a static per-tensor 8-bit quantizer: residual add + QuantizedLlamaRMSNorm
+    (quantized_llama/rms_norm.py:17-35, decoder.py:60-90), SiLU(gate) * up (mlp.py:30-40), and
+    apply_rotary_pos_emb (rotary_embedding.py:14-62)."""
+    sys.path.insert(0, "/root/reference/docs/examples")
+    from doc_helpers.quantized_llama.rotary_embedding import apply_rotary_pos_emb
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm, LlamaRotaryEmbedding
+
+    def quantize(t, bits=8):
+        lo, hi = t.float().min(), t.float().max()
+        scale, offset = parameters_for_range(lo, hi, bits, symmetric=False, allow_one_sided=True)
+        q = affine.quantize_per_tensor(t, scale, offset, bits, torch.int8)
+        return {"scale": scale.reshape(1).clone(), "offset": offset.reshape(1).clone(), "codes": q.raw_data.clone()}
+
+    out = {}
+    torch.manual_seed(1250)
+    for name, (rows, cols) in {"rmsnorm_256": (48, 256), "rmsnorm_4096": (12, 4096), "rmsnorm_1040": (5, 1040)}.items():
+        x = (torch.randn(rows, cols) * 1.7).to(torch.bfloat16)
+        delta = (torch.randn(rows, cols) * 0.6).to(torch.bfloat16)
+        norm = LlamaRMSNorm(cols, eps=1e-5).to(torch.bfloat16)
+        with torch.no_grad():
+            norm.weight.copy_((1.0 + 0.2 * torch.randn(cols)).to(torch.bfloat16))
+            total = x + delta
+            z = norm(total)
+        out[name] = {"x": x, "delta": delta, "weight": norm.weight.detach().clone(), "eps": 1e-5, "sum": total, "normalised": z, "quantized": quantize(z)}
+    gate = (torch.randn(24, 896) * 2.5).to(torch.bfloat16)
+    up = torch.randn(24, 896).to(torch.bfloat16)
+    gate[0, :8] = torch.tensor([0.0, -0.0, 20.0, -20.0, 88.0, -88.0, 1e-3, -1e-3]).to(torch.bfloat16)
+    z = torch.nn.functional.silu(gate) * up
+    out["silu_mul"] = {"gate": gate, "up": up, "product": z, "quantized": quantize(z)}
+    cfg = LlamaConfig(hidden_size=256, num_attention_heads=8, num_key_value_heads=2, max_position_embeddings=128, rope_theta=500000.0)
+    rotary = LlamaRotaryEmbedding(cfg)
+    b, s_, d = 2, 48, 32
+    q = torch.randn(b, s_, 8 * d).to(torch.bfloat16)
+    k = torch.randn(b, s_, 2 * d).to(torch.bfloat16)
+    cos, sin = rotary(q, torch.arange(s_)[None, :])  # [1, s, d] in q's dtype
+    qe, ke = apply_rotary_pos_emb(q.view(b, s_, 8, d).transpose(1, 2), k.view(b, s_, 2, d).transpose(1, 2), cos, sin)
+    out["rope"] = {"q": q, "k": k, "cos": cos[0].clone(), "sin": sin[0].clone(), "head_dim": d,
+                   "q_rotated": qe.transpose(1, 2).reshape(b, s_, -1).clone(), "k_rotated": ke.transpose(1, 2).reshape(b, s_, -1).clone()}
+    return out
+
+
 def main() -> None:
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:  # regenerate only the named fixtures, e.g. `gen_golden.py g10_producers`
+        for name in sys.argv[1:]:
+            torch.save(globals()[name](), HERE / f"{name}.pt")
+            print(f"{name}.pt: {(HERE / f'{name}.pt').stat().st_size / 1024:.0f} KiB")
+        return
     torch.save(g1_known_answers(), HERE / "g1_known_answers.pt")
     torch.save(g2_edges(), HERE / "g2_edges.pt")
     torch.save(g3_sweeps(), HERE / "g3_sweeps.pt")
@@ -409,6 +458,7 @@ def main() -> None:
     torch.save(g7_tiny_llama(), HERE / "g7_tiny_llama.pt")
     torch.save(g8_int4(), HERE / "g8_int4.pt")
     torch.save(g9_dispatcher(), HERE / "g9_dispatcher.pt")
+    torch.save(g10_producers(), HERE / "g10_producers.pt")
     for f in sorted(HERE.glob("*.pt")):
         print(f"{f.name}: {f.stat().st_size / 1024:.0f} KiB")
 

@@ -154,3 +154,74 @@ def check_linear(device):
         # for bf16 (operand + output rounding), tight for fp32
         tol = 2.0**-7 if dtype == torch.bfloat16 else 1e-5
         torch.testing.assert_close(y.detach().cpu().float(), c["y_float64"], atol=tol, rtol=tol)
+
+
+def _ulps_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Distance in bf16 units-in-the-last-place between two bf16 tensors (finite values)."""
+    def key(t):
+        bits = t.contiguous().view(torch.int16).to(torch.int32) & 0xFFFF
+        return torch.where(bits >= 0x8000, 0x8000 - bits, bits)  # monotone in the value
+    return (key(a) - key(b)).abs()
+
+
+def check_producers(device):
+    """Fixture G10: the reference's RMSNorm (behind a residual add), SiLU*up and rotary embedding in
+    bf16, each followed by a static per-tensor 8-bit quantizer.
+
+    Contract (include/ffq.h): adds, multiplies and the rotary embedding are exact; the normalised value
+    and silu may differ from the reference's CPU result by ONE bf16 ulp on rare elements (fp32 summation
+    order of the mean, last bit of rsqrt / exp differ between platforms); codes are exactly A1 of the
+    value the call produced, hence equal to the reference's codes wherever that value is equal.
+    """
+    g = golden("g10_producers.pt")
+    for name, c in g.items():
+        if not name.startswith("rmsnorm"):
+            continue
+        qp = c["quantized"]
+        quantizers = [(qp["scale"].to(device), qp["offset"].to(device))] * 2 + [(qp["scale"].to(device) * 2, None)]
+        total, norm, codes = ops.add_rmsnorm_quantize(c["x"].to(device), c["delta"].to(device), c["weight"].to(device), c["eps"], quantizers, want_norm=True)
+        assert torch.equal(total.cpu(), c["sum"]), name
+        ulps = _ulps_bf16(norm.cpu(), c["normalised"])
+        assert int(ulps.max()) <= 1 and float((ulps > 0).float().mean()) < 0.01, f"{name}: {int(ulps.max())} ulp, {float((ulps > 0).float().mean()):.4f} differ"
+        same = ulps == 0
+        assert torch.equal(codes[0].cpu()[same], qp["codes"][same]), name
+        assert int((codes[0].cpu().int() - qp["codes"].int()).abs().max()) <= 1, name
+        assert torch.equal(codes[0], codes[1]), name
+        # the codes are A1 of the value this call produced
+        for (s, o), got in zip(quantizers, codes):
+            want = ops.quantize_by_tile(norm, s, norm.shape, 8, torch.int8, o)
+            assert torch.equal(got, want), name
+        # without the residual: sum is the input itself, nothing else changes
+        total2, norm2, codes2 = ops.add_rmsnorm_quantize(total, None, c["weight"].to(device), c["eps"], quantizers[:1], want_norm=True)
+        assert total2.data_ptr() == total.data_ptr() and torch.equal(norm2, norm) and torch.equal(codes2[0], codes[0]), name
+        # no quantizers, no normalised output requested
+        total3, norm3, codes3 = ops.add_rmsnorm_quantize(c["x"].to(device), c["delta"].to(device), c["weight"].to(device), c["eps"])
+        assert torch.equal(total3, total) and norm3 is None and codes3 == []
+
+    c = g["silu_mul"]
+    qp = c["quantized"]
+    quantizers = [(qp["scale"].to(device), qp["offset"].to(device))]
+    product, codes = ops.silu_mul_quantize(c["gate"].to(device), c["up"].to(device), quantizers, want_product=True)
+    ulps = _ulps_bf16(product.cpu(), c["product"])
+    assert int(ulps.max()) <= 1 and float((ulps > 0).float().mean()) < 0.01, f"silu_mul: {int(ulps.max())} ulp"
+    same = ulps == 0
+    assert torch.equal(codes[0].cpu()[same], qp["codes"][same])
+    assert torch.equal(codes[0], ops.quantize_by_tile(product, quantizers[0][0], product.shape, 8, torch.int8, quantizers[0][1]))
+    none, codes_only = ops.silu_mul_quantize(c["gate"].to(device), c["up"].to(device), quantizers)
+    assert none is None and torch.equal(codes_only[0], codes[0])
+
+    c = g["rope"]
+    q, k = c["q"].clone().to(device), c["k"].clone().to(device)
+    ops.rope_(q, k, c["cos"].to(device), c["sin"].to(device), c["head_dim"])
+    assert torch.equal(q.cpu(), c["q_rotated"]) and torch.equal(k.cpu(), c["k_rotated"])
+
+    # argument errors follow the other entry points
+    import pytest
+
+    x = torch.zeros(2, 24, dtype=torch.bfloat16, device=device)
+    with pytest.raises(NotImplementedError):
+        ops.add_rmsnorm_quantize(x, None, torch.ones(24, dtype=torch.bfloat16, device=device), 1e-5)  # 24 % 16 != 0
+    with pytest.raises(NotImplementedError):
+        ops.add_rmsnorm_quantize(x.float(), None, torch.ones(24, device=device), 1e-5)
+    with pytest.raises(RuntimeError):
+        ops.silu_mul_quantize(x, x[:1])

@@ -100,3 +100,50 @@ def test_harness_on_gpu(hip_backend):
     check_close(fixture, params, codes, logits)
     params, codes, logits = run(fixture, "cuda", fused=False)
     check_close(fixture, params, codes, logits)  # float GEMMs on the GPU round differently than on the CPU
+
+
+# ---- FusedForward: the same computation with A1 fused into RMSNorm / SiLU*up, rotary in place ----------
+def build_bf16(fixture, device):
+    cfg = llama.LlamaConfig(**fixture["config"])
+    model = llama.LlamaModel(cfg).to(torch.bfloat16).eval()
+    llama.load_hf_state_dict(model, fixture["weights"])
+    model.to(device)
+    llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
+    llama.calibrate(model, [b.to(device) for b in fixture["calibration_ids"]])
+    return model
+
+
+def check_fused_against_module_graph(fixture, device):
+    model = build_bf16(fixture, device)
+    ids = fixture["ids"].to(device)
+    with torch.no_grad(), ff.strict_quantization(False):
+        want = model(ids).float().cpu()
+    fused = llama.FusedForward(model)
+    got = fused(ids).float().cpu()
+    err, spread = got - want, float(want.std())
+    # same integer arithmetic, same bf16 roundings; only the fp32 summation order inside RMSNorm differs
+    assert float(err.pow(2).mean().sqrt()) < 0.01 * spread and float(err.abs().max()) < 0.25 * spread
+    cached = llama.FusedForward(model, cache_weight_codes=True)
+    assert torch.equal(cached(ids).float().cpu(), got) and torch.equal(cached(ids).float().cpu(), got)
+    with torch.no_grad():  # a changed weight invalidates its cached codes
+        model.layers[0].mlp.down_proj.weight.mul_(1.5)
+    assert torch.equal(cached(ids).float().cpu(), fused(ids).float().cpu())
+    assert not torch.equal(fused(ids).float().cpu(), got)
+    # hidden states of the final norm instead of logits
+    assert fused(ids, logits=False).shape == (*ids.shape, model.config.hidden_size)
+    # refusals: range estimation running, float containers for the weight codes
+    with ff.estimate_ranges(model, ff.range_setting.running_minmax):
+        with pytest.raises(ff.exceptions.QuantizationError, match="override"):
+            llama.FusedForward(model)
+    model.layers[1].self_attn.k_proj.weight_quantizer.quantized_dtype = None
+    with pytest.raises(ff.exceptions.QuantizationError, match="int8"):
+        llama.FusedForward(model)
+
+
+def test_fused_forward_matches_module_graph(oracle_backend):
+    check_fused_against_module_graph(golden("g7_tiny_llama.pt"), "cpu")
+
+
+@pytest.mark.gpu
+def test_fused_forward_matches_module_graph_on_gpu(hip_backend):
+    check_fused_against_module_graph(golden("g7_tiny_llama.pt"), "cuda")

@@ -45,3 +45,7 @@ def test_int4_codes_and_q4_0_nibble_order():
 
 def test_quantized_linear_w8a8():
     parity_cases.check_linear("cpu")
+
+
+def test_fused_producers_rmsnorm_silu_rope():
+    parity_cases.check_producers("cpu")

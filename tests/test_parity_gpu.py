@@ -19,7 +19,7 @@ import fastforward_amd as ff
 import parity_cases
 
 from conftest import load_oracle, use_backend
-from fastforward_amd import ops
+from fastforward_amd import llama, ops
 from helpers import mismatch_report, same_with_nan
 
 pytestmark = pytest.mark.gpu
@@ -63,6 +63,10 @@ def test_int4_codes_and_q4_0_nibble_order():
 
 def test_quantized_linear_w8a8():
     parity_cases.check_linear(DEV)
+
+
+def test_fused_producers_rmsnorm_silu_rope():
+    parity_cases.check_producers(DEV)
 
 
 def test_golden_sweeps_with_ieee_division_kernels(monkeypatch):
@@ -334,3 +338,86 @@ def test_full_size_activation_properties(hidden):
     for chunk in x.chunk(8):  # tensor / tensor is a true division on the GPU as well
         total += int(torch.clamp(torch.round(chunk.float() / quantizer.scale.detach() - off), -128, 127).sum(dtype=torch.int64))
     assert int(q.raw_data.sum(dtype=torch.int64)) == total
+
+
+# ---- producer-fused A1 (RMSNorm / SiLU*up / rotary) ------------------------------------------------
+def _one_ulp(a, b, frac):
+    ulps = parity_cases._ulps_bf16(a.cpu(), b.cpu())
+    return int(ulps.max()) <= 1 and float((ulps > 0).float().mean()) < frac
+
+
+@pytest.mark.parametrize("rows,cols", [(7, 16), (64, 256), (33, 1024), (19, 2064), (9, 4096), (5, 8192)])
+@pytest.mark.parametrize("with_delta", [True, False])
+def test_add_rmsnorm_quantize_matches_oracle(rows, cols, with_delta):
+    gen = torch.Generator().manual_seed(rows * 131 + cols)
+    x = (torch.randn(rows, cols, generator=gen) * 3).to(torch.bfloat16)
+    delta = torch.randn(rows, cols, generator=gen).to(torch.bfloat16) if with_delta else None
+    w = (1 + 0.3 * torch.randn(cols, generator=gen)).to(torch.bfloat16)
+    qs = [(torch.tensor([0.021]), torch.tensor([3.5])), (torch.tensor([0.05]), None), (torch.tensor([0.021]), torch.tensor([3.5]))]
+    with use_backend(load_oracle()):
+        want = ops.add_rmsnorm_quantize(x, delta, w, 1e-5, qs, want_norm=True)
+    dev = lambda t: None if t is None else t.to(DEV)
+    got = ops.add_rmsnorm_quantize(dev(x), dev(delta), dev(w), 1e-5, [(dev(s), dev(o)) for s, o in qs], want_norm=True)
+    assert torch.equal(got[0].cpu(), want[0])
+    assert _one_ulp(got[1], want[1], 0.01)
+    for (s, o), codes in zip(qs, got[2]):
+        assert torch.equal(codes, ops.quantize_by_tile(got[1], dev(s), got[1].shape, 8, torch.int8, dev(o)))
+    assert torch.equal(got[2][0], got[2][2])
+
+
+def test_silu_mul_and_rope_match_oracle():
+    gen = torch.Generator().manual_seed(99)
+    gate = (torch.randn(37, 896, generator=gen) * 4).to(torch.bfloat16)
+    up = torch.randn(37, 896, generator=gen).to(torch.bfloat16)
+    q = [(torch.tensor([0.07]), torch.tensor([-11.0]))]
+    with use_backend(load_oracle()):
+        want = ops.silu_mul_quantize(gate, up, q, want_product=True)
+    got = ops.silu_mul_quantize(gate.to(DEV), up.to(DEV), [(q[0][0].to(DEV), q[0][1].to(DEV))], want_product=True)
+    assert _one_ulp(got[0], want[0], 0.01)
+    same = parity_cases._ulps_bf16(got[0].cpu(), want[0]) == 0
+    assert torch.equal(got[1][0].cpu()[same], want[1][0][same])
+    # against ATen's own silu and multiply on the device: identical
+    ref = torch.nn.functional.silu(gate.to(DEV)) * up.to(DEV)
+    assert torch.equal(got[0], ref)
+
+    for b, s, hq, hk, d in [(2, 24, 8, 2, 128), (1, 5, 3, 1, 64), (3, 16, 4, 4, 16)]:
+        qq = torch.randn(b, s, hq * d, generator=gen).to(torch.bfloat16)
+        kk = torch.randn(b, s, hk * d, generator=gen).to(torch.bfloat16)
+        cos, sin = llama.rotary_tables(s, d, 500000.0, "cpu", torch.bfloat16)
+        with use_backend(load_oracle()):
+            wq, wk = qq.clone(), kk.clone()
+            ops.rope_(wq, wk, cos, sin, d)
+        gq, gk = qq.to(DEV), kk.to(DEV)
+        ops.rope_(gq, gk, cos.to(DEV), sin.to(DEV), d)
+        assert torch.equal(gq.cpu(), wq) and torch.equal(gk.cpu(), wk)
+
+
+def test_full_size_producers_properties():
+    """Llama-3-8B activation sizes ([8, 2048, 4096] through RMSNorm, [8, 2048, 14336] through SiLU*up):
+    codes == A1 of the produced value, the produced value within one bf16 ulp of the ATen chain on the
+    device, rotary embedding identical to the ATen chain."""
+    torch.manual_seed(5)
+    x = torch.randn(8, 2048, 4096, device=DEV, dtype=torch.bfloat16)
+    delta = torch.randn_like(x) * 0.3
+    w = (1 + 0.1 * torch.randn(4096, device=DEV)).to(torch.bfloat16)
+    s, o = torch.tensor([0.04], device=DEV), torch.tensor([2.0], device=DEV)
+    total, norm, codes = ops.add_rmsnorm_quantize(x, delta, w, 1e-5, [(s, o)], want_norm=True)
+    assert torch.equal(total, x + delta)
+    ref = llama.LlamaRMSNorm.forward(type("N", (), {"weight": w, "variance_epsilon": 1e-5})(), total)
+    assert _one_ulp(norm, ref, 0.01)
+    assert torch.equal(codes[0], ops.quantize_by_tile(norm, s, norm.shape, 8, torch.int8, o))
+    del x, delta, total, norm, ref, codes
+    gate = torch.randn(8, 2048, 14336, device=DEV, dtype=torch.bfloat16) * 2
+    up = torch.randn_like(gate)
+    product, codes = ops.silu_mul_quantize(gate, up, [(s, o)], want_product=True)
+    assert torch.equal(product, torch.nn.functional.silu(gate) * up)
+    assert torch.equal(codes[0], ops.quantize_by_tile(product, s, product.shape, 8, torch.int8, o))
+    del gate, up, product, codes
+    q = torch.randn(8, 2048, 4096, device=DEV, dtype=torch.bfloat16)
+    k = torch.randn(8, 2048, 1024, device=DEV, dtype=torch.bfloat16)
+    cos, sin = llama.rotary_tables(2048, 128, 500000.0, DEV, torch.bfloat16)
+    qh, kh = q.view(8, 2048, 32, 128).transpose(1, 2), k.view(8, 2048, 8, 128).transpose(1, 2)
+    want_q = (qh * cos + llama._rotate_half(qh) * sin).transpose(1, 2).reshape(8, 2048, -1)
+    want_k = (kh * cos + llama._rotate_half(kh) * sin).transpose(1, 2).reshape(8, 2048, -1)
+    ops.rope_(q, k, cos, sin, 128)
+    assert torch.equal(q, want_q) and torch.equal(k, want_k)
