@@ -47,6 +47,7 @@ struct LinearArgs {
   int x_per_row, w_per_row;
   int M, N, K;
   int tiles_m, tiles_n;
+  int debug;  // FFQ_GEMM_DEBUG ablation bits (tools/gemm_time.py): 1 = no global stores, 2 = no epilogue at all
 };
 
 __device__ __forceinline__ uint32_t swizzled(uint32_t row, uint32_t slot) {
@@ -438,6 +439,13 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
     oscale = a.out_scale[0];
     ooff = a.out_offset ? rne(a.out_offset[0]) : 0.0f;
   }
+  if (a.debug & 2) {  // ablation: keep the accumulators alive, do nothing with them
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
   __syncthreads();  // every wave is done with the operand ring: LDS is free for the epilogue
   constexpr int ROW_BYTES = 144;  // 128 B payload + 16 B pad
   constexpr int REGION_BYTES = 128 * ROW_BYTES + 256;
@@ -522,8 +530,9 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
       const int row = c >> 3, seg = c & 7;
       const int m = wave_m0 + row;
       const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * ROW_BYTES + seg * 16);
-      if (m < a.M)
+      if (m < a.M && !(a.debug & 1))
         *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)m * a.N + wave_n0) * 2 + seg * 16) = v;
+      if (a.debug & 1) asm volatile("" ::"v"(v));
     }
   }
 }
@@ -598,6 +607,8 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.tiles_m = (int)((M + BM - 1) / BM);
   a.tiles_n = (int)((N + BN - 1) / BN);
+  static const int debug_bits = getenv("FFQ_GEMM_DEBUG") ? atoi(getenv("FFQ_GEMM_DEBUG")) : 0;
+  a.debug = debug_bits;
 
   int32_t* ws = static_cast<int32_t*>(workspace);
   // the direct-to-LDS kernels compute the weight row sums themselves; they need K % 64 == 0

