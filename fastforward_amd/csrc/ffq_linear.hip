@@ -216,6 +216,120 @@ constexpr int GROUP_M2 = 8;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
+// Epilogue shared by the 256-row kernels: scale / zero-point terms, LDS transpose, 16-byte stores.
+template <typename TOut, bool REQUANT, bool WOFF, int NW>
+__device__ __forceinline__ void gemm256_epilogue(const LinearArgs& a, v16i (&acc)[4][2], int (&rsw)[2], int (&rsx_acc)[4],
+                                                 uint8_t* lds2, int wave, int lane, int wm, int wn, int m0, int n0) {
+  // Epilogue. The weight fragment is the MFMA's A operand, so with the 32x32 C/D layout
+  // (col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) lane l holds, for each (i, j, q):
+  //   C[m = i*32 + (l & 31)][n = j*32 + 8*q + 4*(l >> 5) + (0..3)],  e = 4*q + (0..3)
+  // i.e. FOUR CONSECUTIVE output columns of one row: 8 B of bf16 that go to LDS as one ds_write_b64
+  // (32 per lane instead of 128 two-byte writes) and leave as full 16 B per lane / 128 B per line.
+  TOut* out = static_cast<TOut*>(a.out);
+  const float kf = (float)a.K;
+  float oscale = 1.0f, ooff = 0.0f;
+  if constexpr (REQUANT) {
+    oscale = a.out_scale[0];
+    ooff = a.out_offset ? rne(a.out_offset[0]) : 0.0f;
+  }
+  if (a.debug & 2) {  // ablation: keep the accumulators alive, do nothing with them
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+  __syncthreads();  // every wave is done with the operand ring: LDS is free for the epilogue
+  constexpr int ROW_BYTES = 144;  // 128 B payload + 16 B pad
+  constexpr int REGION_BYTES = 128 * ROW_BYTES + 256;
+  uint8_t* region = lds2 + wave * REGION_BYTES;
+  float* rs_lds = reinterpret_cast<float*>(region + 128 * ROW_BYTES);
+  if (lane < 32) {
+    rs_lds[lane] = (float)rsw[0];
+    rs_lds[32 + lane] = (float)rsw[1];
+  }
+  const int g = lane >> 5;
+  const int wave_n0 = n0 + wn * 64;
+  const int wave_m0 = m0 + wm * 128;
+  const bool lds_path = sizeof(TOut) == 2 && (a.N & 7) == 0 && wave_n0 + 64 <= a.N;
+
+  // per-row (activation side) parameters of this lane's 4 rows m = wave_m0 + i*32 + (lane & 31)
+  float sx[4], ox[4], rsx[4];
+  bool m_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = wave_m0 + i * 32 + (lane & 31);
+    m_ok[i] = m < a.M;
+    m = m_ok[i] ? m : a.M - 1;
+    sx[i] = a.x_scale[a.x_per_row ? m : 0];
+    ox[i] = a.x_offset ? rne(a.x_offset[a.x_per_row ? m : 0]) : 0.0f;
+    rsx[i] = WOFF ? (float)rsx_acc[i] : 0.0f;  // this lane's MFMA column IS its activation row
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      asm volatile("" ::: "memory");  // keep the parameter quads of different (j, q) from being hoisted together
+      const int nb = j * 32 + 8 * q + 4 * g;  // this lane's 4 columns: wave_n0 + nb + (0..3)
+      float sw4[4], ow4[4], rs4[4], b4[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        int n = wave_n0 + nb + t;
+        n = n < a.N ? n : a.N - 1;
+        sw4[t] = a.w_scale[a.w_per_row ? n : 0];
+        ow4[t] = a.w_offset ? rne(a.w_offset[a.w_per_row ? n : 0]) : 0.0f;
+        rs4[t] = rs_lds[nb + t];
+        b4[t] = a.bias ? (float)load_any(a.bias, a.bias_dt, n) : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float y[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float v = (float)acc[i][j][4 * q + t] + ox[i] * rs4[t];
+          v = v + ow4[t] * rsx[i];
+          v = v + kf * ox[i] * ow4[t];
+          float r = (sx[i] * sw4[t]) * v;
+          if (a.bias) r = r + b4[t];
+          if constexpr (REQUANT) {
+            r = bf16_bits_to_f32(f32_to_bf16_bits(r));
+            r = clamp_nan(rne(r / oscale - ooff), a.out_lo, a.out_hi);
+          }
+          y[t] = r;
+        }
+        if constexpr (sizeof(TOut) == 2) {
+          if (lds_path) {
+            u32x2 pk;
+            pk.x = pack2<TOut>(y[0], y[1]);
+            pk.y = pack2<TOut>(y[2], y[3]);
+            *reinterpret_cast<u32x2*>(region + (i * 32 + (lane & 31)) * ROW_BYTES + nb * 2) = pk;
+            continue;
+          }
+        }
+        if (m_ok[i]) {
+          const size_t at = (size_t)(wave_m0 + i * 32 + (lane & 31)) * a.N + wave_n0 + nb;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (wave_n0 + nb + t < a.N) store_out<TOut>(out + at + t, y[t]);
+        }
+      }
+    }
+  }
+  if (lds_path) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: only this wave's own writes
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int c = lane + 64 * t;
+      const int row = c >> 3, seg = c & 7;
+      const int m = wave_m0 + row;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * ROW_BYTES + seg * 16);
+      if (m < a.M && !(a.debug & 1))
+        *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)m * a.N + wave_n0) * 2 + seg * 16) = v;
+      if (a.debug & 1) asm volatile("" ::"v"(v));
+    }
+  }
+}
+
 template <typename TOut, bool REQUANT, int NW, bool WOFF>
 __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) {
   constexpr int BN2 = NW * 32;                       // 256 or 128 columns per block
@@ -427,114 +541,208 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
     for (int i = 0; i < 4; ++i) rsx_acc[i] += __shfl_xor(rsx_acc[i], 32, 64);
   }
 
-  // Epilogue. The weight fragment is the MFMA's A operand, so with the 32x32 C/D layout
-  // (col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) lane l holds, for each (i, j, q):
-  //   C[m = i*32 + (l & 31)][n = j*32 + 8*q + 4*(l >> 5) + (0..3)],  e = 4*q + (0..3)
-  // i.e. FOUR CONSECUTIVE output columns of one row: 8 B of bf16 that go to LDS as one ds_write_b64
-  // (32 per lane instead of 128 two-byte writes) and leave as full 16 B per lane / 128 B per line.
-  TOut* out = static_cast<TOut*>(a.out);
-  const float kf = (float)a.K;
-  float oscale = 1.0f, ooff = 0.0f;
-  if constexpr (REQUANT) {
-    oscale = a.out_scale[0];
-    ooff = a.out_offset ? rne(a.out_offset[0]) : 0.0f;
-  }
-  if (a.debug & 2) {  // ablation: keep the accumulators alive, do nothing with them
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
-  }
-  __syncthreads();  // every wave is done with the operand ring: LDS is free for the epilogue
-  constexpr int ROW_BYTES = 144;  // 128 B payload + 16 B pad
-  constexpr int REGION_BYTES = 128 * ROW_BYTES + 256;
-  uint8_t* region = lds2 + wave * REGION_BYTES;
-  float* rs_lds = reinterpret_cast<float*>(region + 128 * ROW_BYTES);
-  if (lane < 32) {
-    rs_lds[lane] = (float)rsw[0];
-    rs_lds[32 + lane] = (float)rsw[1];
-  }
-  const int g = lane >> 5;
-  const int wave_n0 = n0 + wn * 64;
-  const int wave_m0 = m0 + wm * 128;
-  const bool lds_path = sizeof(TOut) == 2 && (a.N & 7) == 0 && wave_n0 + 64 <= a.N;
+  gemm256_epilogue<TOut, REQUANT, WOFF, NW>(a, acc, rsw, rsx_acc, lds2, wave, lane, wm, wn, m0, n0);
+}
 
-  // per-row (activation side) parameters of this lane's 4 rows m = wave_m0 + i*32 + (lane & 31)
-  float sx[4], ox[4], rsx[4];
-  bool m_ok[4];
+// -------------------------------------------------------------------------------------------------
+// v3 ("ping-pong"): same 256 x 256 x 64 tile, operand image, swizzle and epilogue as v2, different
+// K-loop. v2 lets every wave interleave its own ds_reads, LDS-DMA issues and v_dot4 row sums with its
+// own MFMAs, and all 8 waves run the same half-step at the same time (PMC: 27 % of wave time parked at
+// s_waitcnt / s_barrier, MFMA busy 55 %). Ablations on the MI355X (tools/gemm_variants.sh, no epilogue,
+// down_proj shape): v2 2.23 POP/s; MFMA + barriers alone 3.29; the in-loop v_dot4c row sums cost 18 %,
+// LDS-DMA issued next to the ds_reads 20 %. Hence:
+//   * a half-step is a LOAD segment (the 6 ds_read_b128 of ONE fragment set) and an MFMA cluster
+//     (8 MFMAs under s_setprio 1) separated by raw barriers, and the upper wave group (waves 4-7, the
+//     second wave of every SIMD) runs one barrier interval behind the lower group: while one wave of a
+//     SIMD feeds the matrix pipe its partner reads LDS — the 8-phase template of the CDNA GEMM
+//     playbook restated for int8 32x32x32;
+//          interval n     : group 0  C(p)   | group 1  L(p)
+//          interval n + 1 : group 0  L(p+1) | group 1  C(p)
+//   * the two LDS-DMA issues of a half-step sit INSIDE the cluster, after its second MFMA (3.0 POP/s
+//     vs 2.3 with the DMA in the load segment);
+//   * the weight row sums of the zero-point term come from a one-pass side kernel (1 B/elem of the
+//     weight, once per launch instead of once per M-tile); only a weight offset that is really
+//     non-zero (checked on the device) turns the in-loop activation row sums back on.
+// Ring of 4 stages (128 KiB): tile kt lives in stage kt & 3. Cluster C(2kt) issues the B half of tile
+// kt+2, C(2kt+1) the A half of tile kt+3; the load segment L(2kt+1) waits with vmcnt(4) — everything
+// but tile kt+2 has landed, i.e. tile kt+1 — and tile kt+1 is first read one phase (two barriers)
+// later. A stage is re-filled at the earliest two full intervals after the slower group retired its
+// last read of it. These are the two ordering rules of the playbook (RAW: wait -> barrier -> read;
+// WAR: read retired -> barrier -> DMA issue).
+constexpr int STAGES3 = 4;
+
+template <typename TOut, bool REQUANT, bool WOFF>
+__global__ __launch_bounds__(512, 2) void w8a8_gemm256pp_kernel(LinearArgs a) {
+  constexpr int NW = 8, BN2 = 256, WAVES_N = 4;
+  constexpr int A_BYTES = BM2 * BK2;
+  constexpr int OPER_BYTES2 = A_BYTES;
+  constexpr int STAGE_BYTES2 = (BM2 + BN2) * BK2;  // 32 KiB
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
+
+  const uint32_t nblk = gridDim.x;
+  const uint32_t xcd = blockIdx.x & 7u, slot_in_xcd = blockIdx.x >> 3;
+  const uint32_t q = nblk >> 3, r = nblk & 7u;
+  const uint32_t tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot_in_xcd;
+  const uint32_t per_group = GROUP_M2 * (uint32_t)a.tiles_n;
+  const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
+  const uint32_t group_rows = min((uint32_t)GROUP_M2, (uint32_t)a.tiles_m - group * GROUP_M2);
+  const int tm = (int)(group * GROUP_M2 + in_group % group_rows);
+  const int tn = (int)(in_group / group_rows);
+  const int m0 = tm * BM2, n0 = tn * BN2;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;  // wm is also the ping-pong group
+
+  // DMA map as in v2: wave w copies the 16-row chunks {2w, 2w+1} of A and of B.
+  const int d_row = lane >> 2;
+  const int d_slot = (lane & 3) ^ ((d_row >> 2) & 3);
+  const int8_t* a_src[2];
+  const int8_t* b_src[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    int ra = m0 + (wave * 2 + c) * 16 + d_row;
+    ra = ra < a.M ? ra : a.M - 1;
+    a_src[c] = a.xq + (size_t)ra * a.K + d_slot * 16;
+    int rb = n0 + (wave * 2 + c) * 16 + d_row;
+    rb = rb < a.N ? rb : a.N - 1;
+    b_src[c] = a.wq + (size_t)rb * a.K + d_slot * 16;
+  }
+  const int last_tile = a.K / BK2 - 1;
+  // Tiles past the end re-load the last tile into a stage nobody reads any more (constant vmcnt).
+  auto issue_a = [&](int kt) {
+    const int stage = kt & (STAGES3 - 1);
+    kt = kt < last_tile ? kt : last_tile;
+    uint8_t* base = lds2 + stage * STAGE_BYTES2;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[c] + kt * BK2), (lds_void_t*)(base + (wave * 2 + c) * 1024), 16, 0, 0);
+  };
+  auto issue_b = [&](int kt) {
+    const int stage = kt & (STAGES3 - 1);
+    kt = kt < last_tile ? kt : last_tile;
+    uint8_t* base = lds2 + stage * STAGE_BYTES2 + OPER_BYTES2;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_src[c] + kt * BK2), (lds_void_t*)(base + (wave * 2 + c) * 1024), 16, 0, 0);
+  };
+
+  v16i acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+  int rsx_acc[4] = {0, 0, 0, 0};
+
+  // Symmetric weight quantizers carry an all-zero offset BUFFER (reference nn/linear_quantizer.py:164-170):
+  // look at this block's offsets on the device — before any DMA is in flight, the compiler drains vmcnt
+  // for an ordinary load — and take the loop without activation row sums when they are all zero.
+  bool need_x_sums = false;
+  if constexpr (WOFF) {
+    int n = n0 + (tid % BN2);
+    n = n < a.N ? n : a.N - 1;
+    need_x_sums = __syncthreads_or(rne(a.w_offset[a.w_per_row ? n : 0]) != 0.0f) != 0;
+  }
+  // sum_k wq[n, k] of this lane's two weight rows (side kernel; only read when x has an offset)
+  int rsw[2] = {0, 0};
+  if (a.rowsum_w) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int n = n0 + wn * 64 + j * 32 + (lane & 31);
+      n = n < a.N ? n : a.N - 1;
+      rsw[j] = a.rowsum_w[n];
+    }
+  }
+
+  const int ksteps = a.K / BK2;
+  // prologue: tiles 0 and 1 entirely, A half of tile 2
+  issue_a(0); issue_b(0);
+  issue_a(1); issue_b(1);
+  issue_a(2);
+
+  const uint32_t frag_row = lane & 31, frag_g = lane >> 5;
+  uint32_t a_off[4][2], b_off[2][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int m = wave_m0 + i * 32 + (lane & 31);
-    m_ok[i] = m < a.M;
-    m = m_ok[i] ? m : a.M - 1;
-    sx[i] = a.x_scale[a.x_per_row ? m : 0];
-    ox[i] = a.x_offset ? rne(a.x_offset[a.x_per_row ? m : 0]) : 0.0f;
-    rsx[i] = WOFF ? (float)rsx_acc[i] : 0.0f;  // this lane's MFMA column IS its activation row
+    const uint32_t row = wm * 128 + i * 32 + frag_row;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) a_off[i][kk] = row * BK2 + (((kk * 2 + frag_g) ^ ((row >> 2) & 3u)) << 4);
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
+    const uint32_t row = wn * 64 + j * 32 + frag_row;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      asm volatile("" ::: "memory");  // keep the parameter quads of different (j, q) from being hoisted together
-      const int nb = j * 32 + 8 * q + 4 * g;  // this lane's 4 columns: wave_n0 + nb + (0..3)
-      float sw4[4], ow4[4], rs4[4], b4[4];
+    for (int kk = 0; kk < 2; ++kk) b_off[j][kk] = OPER_BYTES2 + row * BK2 + (((kk * 2 + frag_g) ^ ((row >> 2) & 3u)) << 4);
+  }
+
+  v4i fa[4], fb[2];
+  auto read_frags = [&](const uint8_t* st, int kk) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        int n = wave_n0 + nb + t;
-        n = n < a.N ? n : a.N - 1;
-        sw4[t] = a.w_scale[a.w_per_row ? n : 0];
-        ow4[t] = a.w_offset ? rne(a.w_offset[a.w_per_row ? n : 0]) : 0.0f;
-        rs4[t] = rs_lds[nb + t];
-        b4[t] = a.bias ? (float)load_any(a.bias, a.bias_dt, n) : 0.0f;
+    for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const v4i*>(st + b_off[j][kk]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const v4i*>(st + a_off[i][kk]);
+  };
+  auto cluster = [&](auto with_x, auto dma) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      if (i == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        dma();
+        __builtin_amdgcn_sched_barrier(0);
       }
+    }
+    if constexpr (decltype(with_x)::value) {  // rare: a weight offset that is really non-zero
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float y[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float v = (float)acc[i][j][4 * q + t] + ox[i] * rs4[t];
-          v = v + ow4[t] * rsx[i];
-          v = v + kf * ox[i] * ow4[t];
-          float r = (sx[i] * sw4[t]) * v;
-          if (a.bias) r = r + b4[t];
-          if constexpr (REQUANT) {
-            r = bf16_bits_to_f32(f32_to_bf16_bits(r));
-            r = clamp_nan(rne(r / oscale - ooff), a.out_lo, a.out_hi);
-          }
-          y[t] = r;
-        }
-        if constexpr (sizeof(TOut) == 2) {
-          if (lds_path) {
-            u32x2 pk;
-            pk.x = pack2<TOut>(y[0], y[1]);
-            pk.y = pack2<TOut>(y[2], y[3]);
-            *reinterpret_cast<u32x2*>(region + (i * 32 + (lane & 31)) * ROW_BYTES + nb * 2) = pk;
-            continue;
-          }
-        }
-        if (m_ok[i]) {
-          const size_t at = (size_t)(wave_m0 + i * 32 + (lane & 31)) * a.N + wave_n0 + nb;
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (wave_n0 + nb + t < a.N) store_out<TOut>(out + at + t, y[t]);
-        }
+        rsx_acc[i] = __builtin_amdgcn_sdot4(fa[i].x, 0x01010101, rsx_acc[i], false);
+        rsx_acc[i] = __builtin_amdgcn_sdot4(fa[i].y, 0x01010101, rsx_acc[i], false);
+        rsx_acc[i] = __builtin_amdgcn_sdot4(fa[i].z, 0x01010101, rsx_acc[i], false);
+        rsx_acc[i] = __builtin_amdgcn_sdot4(fa[i].w, 0x01010101, rsx_acc[i], false);
       }
     }
-  }
-  if (lds_path) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: only this wave's own writes
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int c = lane + 64 * t;
-      const int row = c >> 3, seg = c & 7;
-      const int m = wave_m0 + row;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * ROW_BYTES + seg * 16);
-      if (m < a.M && !(a.debug & 1))
-        *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)m * a.N + wave_n0) * 2 + seg * 16) = v;
-      if (a.debug & 1) asm volatile("" ::"v"(v));
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // tile 0 has landed (this wave's share): tile 1 (4) and the A half of tile 2 (2) stay in flight
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // the upper group runs one interval behind
+
+  auto k_loop = [&](auto with_x) {
+    for (int kt = 0; kt < ksteps; ++kt) {
+      const uint8_t* st = lds2 + (kt & (STAGES3 - 1)) * STAGE_BYTES2;
+      // ---- phase 2kt
+      read_frags(st, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(with_x, [&] { issue_b(kt + 2); });
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 2kt + 1
+      read_frags(st, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tile kt + 1 landed, tile kt + 2 stays in flight
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(with_x, [&] { issue_a(kt + 3); });
+      __builtin_amdgcn_s_barrier();
     }
+  };
+  if (need_x_sums) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // same number of barriers for both groups
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing dummy DMA must not land in the epilogue's LDS
+  if constexpr (WOFF) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rsx_acc[i] += __shfl_xor(rsx_acc[i], 32, 64);
   }
+  gemm256_epilogue<TOut, REQUANT, WOFF, NW>(a, acc, rsw, rsx_acc, lds2, wave, lane, wm, wn, m0, n0);
 }
 
 // one wavefront per row: sum of K int8 codes
@@ -617,6 +825,48 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
   const int64_t tiles256 = ((M + BM2 - 1) / BM2) * ((N + 255) / 256);
   const bool use_v2 = !force_v1 && K % BK2 == 0 && M >= 128 && N >= 128 && tiles256 >= 64;
   if (use_v2) {
+    static const int force_v2 = getenv("FFQ_GEMM_V2") ? 1 : 0;
+    if (!force_v2 && !force_nw && K / BK2 >= 4) {
+      a.tiles_m = (int)((M + BM2 - 1) / BM2);
+      a.tiles_n = (int)((N + 255) / 256);
+      if (x_offset) {  // sum_k wq[n, k] for the zero-point term: one pass over the weight codes
+        rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(wq, (int)N, (int)K, ws + M);
+        a.rowsum_w = ws + M;
+      }
+      const unsigned grid3 = (unsigned)(a.tiles_m * a.tiles_n);
+      const size_t ring3 = (size_t)STAGES3 * (BM2 + 256) * BK2;
+      const size_t epi3 = (size_t)8 * (128 * 144 + 256);
+      const size_t lds3 = ring3 > epi3 ? ring3 : epi3;
+#define FFQ_GEMM3_W(T, RQ, WO)                                                                             \
+  do {                                                                                                     \
+    static bool attr_set = false;                                                                          \
+    if (!attr_set) {                                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256pp_kernel<T, RQ, WO>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);                    \
+      attr_set = true;                                                                                     \
+    }                                                                                                      \
+    w8a8_gemm256pp_kernel<T, RQ, WO><<<grid3, 512, lds3, s>>>(a);                                          \
+  } while (0)
+#define FFQ_GEMM3(T, RQ) do { if (w_offset) FFQ_GEMM3_W(T, RQ, true); else FFQ_GEMM3_W(T, RQ, false); } while (0)
+      if (requant) {
+        switch (out_dt) {
+          case FFQ_I8: FFQ_GEMM3(int8_t, true); break;
+          case FFQ_BF16: FFQ_GEMM3(bf16_t, true); break;
+          case FFQ_F16: FFQ_GEMM3(f16_t, true); break;
+          case FFQ_F32: FFQ_GEMM3(float, true); break;
+          default: return fail(FFQ_ERR_DTYPE, "re-quantized output container must be i8, bf16, f16 or f32");
+        }
+      } else {
+        switch (out_dt) {
+          case FFQ_BF16: FFQ_GEMM3(bf16_t, false); break;
+          case FFQ_F16: FFQ_GEMM3(f16_t, false); break;
+          default: FFQ_GEMM3(float, false); break;
+        }
+      }
+#undef FFQ_GEMM3
+#undef FFQ_GEMM3_W
+      return check_launch("w8a8_gemm256pp_kernel");
+    }
     const int nw = force_nw ? force_nw : 8;
     const int bn = nw * 32;
     a.tiles_m = (int)((M + BM2 - 1) / BM2);

@@ -2,7 +2,11 @@
 import sys, pathlib, statistics
 import torch
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
-from fastforward_amd import ops
+from fastforward_amd import ops, _native
+import os
+if os.environ.get("FFQ_LIB"):  # experiment builds (tools/gemm_variants.sh)
+    from fastforward_amd._cabi import FFQLibrary
+    _native._LIB = FFQLibrary(os.environ["FFQ_LIB"])
 from bench import event_time_ms
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
@@ -11,7 +15,7 @@ tot_ops = tot_ms = 0
 for name, n, k, cnt in (("qo", 4096, 4096, 2), ("kv", 1024, 4096, 2), ("gateup", 14336, 4096, 2), ("down", 4096, 14336, 1)):
     xq = torch.randint(-128, 128, (T, k), device=dev, dtype=torch.int8)
     wq = torch.randint(-128, 128, (n, k), device=dev, dtype=torch.int8)
-    sx, ox = torch.tensor([0.02], device=dev), torch.tensor([4.0], device=dev)
+    sx, ox = torch.tensor([0.02], device=dev), (None if os.environ.get("GT_NO_XOFF") else torch.tensor([4.0], device=dev))
     sw = torch.rand(n, device=dev) * 0.001 + 0.0005
     ms = event_time_ms(lambda r: ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.bfloat16), iters=5, reps=4)
     print(f"{name:7s} N={n:5d} K={k:5d} {ms:.4f} ms {2*T*n*k/ms/1e9:8.1f} TOP/s")
