@@ -105,7 +105,7 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device) 
         sx, ox = torch.tensor([0.02], device=device), torch.tensor([4.0], device=device)
         sw = torch.rand(n, device=device) * 0.001 + 0.0005
         ms = event_time_ms(lambda r: ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.bfloat16), iters=5, reps=4)
-        # the rowsum kernel of the zero-point term runs inside this call; it is 1 B/elem of the weight
+        # the side kernel with the weight row sums of the zero-point term (1 B/elem of the weight) runs inside this call
         flop = 2.0 * tokens * n * k
         per_shape[name] = {"N": n, "K": k, "ms": round(ms, 4), "TOP/s": round(flop / ms / 1e9, 1)}
         total_ops += count * flop
@@ -113,10 +113,10 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device) 
         launches += count
         del xq, wq
     achieved = total_ops / total_ms / 1e9
-    traffic, source = pmc_traffic("w8a8_gemm256_kernel")
+    traffic, source = pmc_traffic("w8a8_gemm256pp_kernel")
     return {
         "bound": "mfma",
-        "kernel": "w8a8_gemm256_kernel (v_mfma_i32_32x32x32_i8, 256x256x64 tiles)",
+        "kernel": "w8a8_gemm256pp_kernel (v_mfma_i32_32x32x32_i8, 256x256x64 tiles, ping-pong wave groups) + rowsum_i8_kernel",
         "achieved": round(achieved, 1),
         "peak": INT8_PEAK_TOPS,
         "unit": "TFLOP/s",
