@@ -210,17 +210,60 @@ def quantize_by_tile_backward(
 ) -> list[torch.Tensor]:
     """A8 — ``fastforward::quantize_by_tile_backward`` (reference _quantizer_impl.py:193-237).
 
-    Not on the forward/calibration path this package accelerates: kept as a
-    composition of device tensor ops behind the reference's schema so autograd keeps working; a HIP
-    kernel is listed under "next" in DESIGN.md. Gradient formulas: clipped elements pass no data
-    gradient; d/dscale is (round(u) - u) inside the grid and the clip bound (+offset) outside;
-    d/doffset is scale * grad on clipped elements only.
+    Gradients of quantize -> dequantize: clipped elements pass no data gradient; d/dscale is
+    ``round(u) - u`` inside the grid and the clip bound plus the rounded offset outside; d/doffset
+    is ``scale * grad`` on clipped elements only. One HIP pass + a deterministic finalize for
+    per-tensor and contiguous-run tilings with fp32 parameters; other tilings / dtypes take
+    :func:`_quantize_by_tile_backward_composite` (device tensor ops, same formulas).
     """
+    fast = (
+        data.dtype == output_grad.dtype
+        and data.dtype in (torch.float32, torch.bfloat16, torch.float16)
+        and scale.dtype == torch.float32
+        and (offset is None or offset.dtype == torch.float32)
+        and data.shape == output_grad.shape
+    )
+    if fast:
+        data_c, grad_c = data.detach().contiguous(), output_grad.detach().contiguous()
+        scale_c, offset_c = _flat(scale), _flat(offset)
+        lib, stream = _prepare(data_c, grad_c, scale_c, offset_c)
+        tiling = _tile_of(data_c, tile_size)
+        ntiles = lib.ffq_num_tiles(ctypes.byref(tiling))
+        if ntiles < 0:
+            lib.check(-ntiles)
+        dinput = torch.empty_like(data_c)
+        dscale = torch.empty(ntiles, dtype=torch.float32, device=data_c.device)
+        doffset = None if offset_c is None else torch.empty(ntiles, dtype=torch.float32, device=data_c.device)
+        nbytes = lib.ffq_quantize_backward_workspace_bytes(ctypes.byref(tiling))
+        ws = _workspace(nbytes, data_c.device)
+        status = lib.ffq_quantize_by_tile_backward(
+            _ptr(data_c), _ptr(grad_c), _tag(data_c.dtype), _ptr(scale_c), scale_c.numel(), _ptr(offset_c),
+            offset_c.numel() if offset_c is not None else 0, ctypes.byref(tiling), float(num_bits), _ptr(dinput), _ptr(dscale),
+            _ptr(doffset), _ptr(ws), nbytes, stream,
+        )
+        if status == 0:
+            return [dinput, dscale.reshape(scale.shape), torch.Tensor() if doffset is None else doffset.reshape(scale.shape)]
+        if status != 6:  # FFQ_ERR_DTYPE: a tiling the kernel does not cover
+            lib.check(status)
+    return _quantize_by_tile_backward_composite(data, output_grad, scale, tile_size, num_bits, offset)
+
+
+def _quantize_by_tile_backward_composite(
+    data: torch.Tensor,
+    output_grad: torch.Tensor,
+    scale: torch.Tensor,
+    tile_size: Sequence[int],
+    num_bits: float,
+    offset: torch.Tensor | None = None,
+) -> list[torch.Tensor]:
+    """The same gradients as a composition of tensor ops on the tensors' own device, op for op as the
+    reference writes them (_quantizer_impl.py:203-237): strided channels, N-d tiles, half-precision
+    parameters."""
     from fastforward_amd.quantization.tiled_tensor import rows_to_tiles, tiles_to_rows
 
     param_shape = scale.shape
     s = scale.reshape(-1)
-    o = torch.round(offset.reshape(-1)) if offset is not None else torch.zeros_like(s)
+    o = torch.round(offset.reshape(-1)) if offset is not None else torch.zeros_like(s)  # _infer_offset (:140-141)
     tile = torch.Size(tile_size)
     lo = -(2 ** (num_bits - 1))
     hi = -lo - 1
@@ -234,7 +277,7 @@ def quantize_by_tile_backward(
     if offset is None:
         doffset = torch.Tensor()
     else:
-        doffset = torch.where(clipped, s[:, None] * grows, torch.zeros_like(grows)).sum(1).reshape(param_shape)
+        doffset = torch.where(clipped, s[:, None] * grows, torch.zeros_like(s[:, None] * grows)).sum(1).reshape(param_shape)
     bound = torch.where(below, s.new_tensor([lo]), s.new_tensor([hi])) + o[:, None].to(s.dtype)
     dscale = torch.where(clipped, bound, (q - u).to(s.dtype)) * grows
     return [dinput, dscale.sum(1).reshape(param_shape), doffset]

@@ -240,6 +240,24 @@ int ffq_rope_inplace(void* q, int64_t q_heads, void* k, int64_t k_heads, int dt,
                      int64_t seq_len, int64_t head_dim, const void* cos_table, const void* sin_table,
                      void* stream);
 
+/*
+ * A8 — fastforward::quantize_by_tile_backward, _quantizer_impl.py:193-237 (affine/_autograd.py:99): the
+ * straight-through / LSQ gradients of quantize -> dequantize.
+ *   u = x / s_t - round(o_t);  q = round(u);  clip = (q < lo) | (q > hi)
+ *   dinput  = clip ? 0 : g                                   (dtype of data / output_grad, `dt`)
+ *   doffset = sum over the tile of (clip ? s_t * g : 0)      (fp32, one per tile; only when offset != NULL)
+ *   dscale  = sum over the tile of (clip ? (q < lo ? lo : hi) + round(o_t) : q - u) * g   (fp32, one per tile)
+ * scale / offset are fp32 with one entry per tile. The elementwise part is exact; the per-tile sums are
+ * fp32 sums in this implementation's own (fixed, deterministic) order. Tilings covered: one tile
+ * (per-tensor) and contiguous-run tiles (per-channel on dim 0, per-block along the last dim,
+ * per-token) with numel % 8 == 0; anything else returns FFQ_ERR_DTYPE.
+ */
+size_t ffq_quantize_backward_workspace_bytes(const ffq_tiling* tiling);
+int ffq_quantize_by_tile_backward(const void* data, const void* output_grad, int dt, const float* scale,
+                                  int64_t scale_numel, const float* offset, int64_t offset_numel,
+                                  const ffq_tiling* tiling, double num_bits, void* dinput, float* dscale,
+                                  float* doffset, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

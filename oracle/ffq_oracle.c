@@ -813,3 +813,55 @@ int ffq_rope_inplace(void* q, int64_t q_heads, void* k, int64_t k_heads, int dt,
   free(tmp);
   return FFQ_OK;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* A8: quant_dequant_by_tile_grad_impl, quantization/_quantizer_impl.py:193-237                */
+/* The per-tile sums are accumulated in double and rounded to fp32 once (the reference sums in  */
+/* fp32 in ATen's order; tests state the tolerance).                                            */
+/* ------------------------------------------------------------------------------------------ */
+size_t ffq_quantize_backward_workspace_bytes(const ffq_tiling* tiling) { (void)tiling; return 0; }
+
+int ffq_quantize_by_tile_backward(const void* data, const void* output_grad, int dt, const float* scale,
+                                  int64_t scale_numel, const float* offset, int64_t offset_numel,
+                                  const ffq_tiling* tiling, double num_bits, void* dinput, float* dscale,
+                                  float* doffset, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  int rc = check_tiling(tiling);
+  if (rc) return rc;
+  if (!(dt == FFQ_F32 || dt == FFQ_BF16 || dt == FFQ_F16)) return fail(FFQ_ERR_DTYPE, "backward is built for f32 / bf16 / f16 data");
+  int64_t n = numel_of(tiling);
+  int64_t ntiles = ffq_num_tiles(tiling);
+  if (n != 0) {
+    if ((rc = check_param_numel("scale", scale_numel, ntiles))) return rc;
+    if (offset && (rc = check_param_numel("offset", offset_numel, ntiles))) return rc;
+  }
+  if (n == 0) return FFQ_OK;
+  if (!data || !output_grad || !scale || !dinput || !dscale) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (offset && !doffset) return fail(FFQ_ERR_ARG, "doffset is required when offset is given");
+  if (scale_numel == 1 && ntiles != 1) return fail(FFQ_ERR_DTYPE, "backward kernel needs one scale per tile");
+  float lo = (float)(-pow(2.0, num_bits - 1.0)), hi = -lo - 1.0f;          /* (:208-209) */
+  double* acc_s = (double*)calloc((size_t)ntiles, sizeof(double));
+  double* acc_o = (double*)calloc((size_t)ntiles, sizeof(double));
+  walker w;
+  walker_init(&w, tiling);
+  for (int64_t i = 0; i < n; ++i, walker_next(&w)) {
+    int64_t t = walker_tile(&w);
+    float x = (float)ld(data, dt, i), g = (float)ld(output_grad, dt, i);
+    float s = scale[t], o = offset ? nearbyintf(offset[t]) : 0.0f;   /* _infer_offset rounds   (:140-141,204) */
+    float u = x / s;                                  /* data_as_rows / scale[:, None]          (:214) */
+    u = u - o;                                        /*   - round_ste(offset[:, None])               */
+    float q = nearbyintf(u);                          /* torch.round(pre_round)                 (:215) */
+    int below = q < lo, above = q > hi, clip = below || above;           /* clip_mask  (:216) */
+    st(dinput, dt, i, clip ? 0.0 : (double)g);        /* torch.where(clip_mask, 0, grad)        (:218) */
+    if (offset) acc_o[t] += clip ? (double)(s * g) : 0.0;                /* (:223-224) */
+    float bound = (below ? lo : hi) + o;              /* where(q < min, min, max) + offset  (:226-230) */
+    float term = clip ? bound : q - u;                /* where(clip, dscale, q - pre_round)     (:231) */
+    acc_s[t] += (double)(term * g);                   /* dscale.mul_(grad)                      (:232) */
+  }
+  for (int64_t t = 0; t < ntiles; ++t) {
+    dscale[t] = (float)acc_s[t];
+    if (offset) doffset[t] = (float)acc_o[t];
+  }
+  free(acc_s); free(acc_o);
+  return FFQ_OK;
+}

@@ -441,6 +441,35 @@ def g10_producers():
     return out
 
 
+def g11_backward():
+    """quantize_by_tile_backward of the reference on seeded inputs: per-tensor, per-channel(0), group-128 and
+    per-token tiles, symmetric (offset None) and asymmetric (fractional offsets), fp32 and bf16 data."""
+    from fastforward.quantization import _quantizer_impl  # noqa: F401  (registers the ops)
+
+    cases = []
+    gen = torch.Generator().manual_seed(1260)
+    for name, shape, tile, dtype, bits, with_offset in [
+        ("tensor_f32", (32, 16, 8), (32, 16, 8), torch.float32, 4, True),
+        ("tensor_f32_sym", (64, 256), (64, 256), torch.float32, 8, False),
+        ("channel0_bf16", (48, 512), (1, 512), torch.bfloat16, 4, True),
+        ("channel0_f32_sym", (16, 4096), (1, 4096), torch.float32, 3, False),
+        ("group128_bf16", (24, 512), (1, 128), torch.bfloat16, 4, True),
+        ("token_f32", (4, 6, 256), (1, 1, 256), torch.float32, 8, True),
+        ("channel_last_f32", (40, 24), (40, 1), torch.float32, 4, True),
+    ]:
+        x = (torch.randn(shape, generator=gen) * 1.5).to(dtype)
+        grad = torch.randn(shape, generator=gen).to(dtype)
+        ntiles = 1
+        for s_, t_ in zip(shape, tile):
+            ntiles *= s_ // t_
+        scale = torch.rand(ntiles, generator=gen) * 0.3 + 0.15
+        offset = (torch.rand(ntiles, generator=gen) * 5 - 2.5) if with_offset else None
+        dinput, dscale, doffset = torch.ops.fastforward.quantize_by_tile_backward(x, grad, scale, list(tile), float(bits), offset)
+        cases.append({"name": name, "data": x, "grad": grad, "tile": list(tile), "num_bits": bits, "scale": scale, "offset": offset,
+                      "dinput": dinput.clone(), "dscale": dscale.clone(), "doffset": doffset.clone()})
+    return cases
+
+
 def main() -> None:
     torch.set_num_threads(8)
     if len(sys.argv) > 1:  # regenerate only the named fixtures, e.g. `gen_golden.py g10_producers`
@@ -459,6 +488,7 @@ def main() -> None:
     torch.save(g8_int4(), HERE / "g8_int4.pt")
     torch.save(g9_dispatcher(), HERE / "g9_dispatcher.pt")
     torch.save(g10_producers(), HERE / "g10_producers.pt")
+    torch.save(g11_backward(), HERE / "g11_backward.pt")
     for f in sorted(HERE.glob("*.pt")):
         print(f"{f.name}: {f.stat().st_size / 1024:.0f} KiB")
 

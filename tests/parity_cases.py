@@ -224,3 +224,43 @@ def check_producers(device):
         ops.add_rmsnorm_quantize(x.float(), None, torch.ones(24, device=device), 1e-5)
     with pytest.raises(RuntimeError):
         ops.silu_mul_quantize(x, x[:1])
+
+
+def _backward_terms64(c):
+    """Per-element gradient terms of fixture case `c` in float64 (an independent statement of the formulas),
+    as rows per tile: (dscale terms, doffset terms)."""
+    from fastforward_amd.quantization.tiled_tensor import tiles_to_rows
+
+    tile = torch.Size(c["tile"])
+    s = c["scale"].double()[:, None]
+    o = (c["offset"] if c["offset"] is not None else torch.zeros_like(c["scale"])).double()[:, None]
+    x, g = tiles_to_rows(c["data"].float(), tile), tiles_to_rows(c["grad"].double(), tile)
+    lo = -(2.0 ** (c["num_bits"] - 1))
+    hi = -lo - 1
+    o = torch.round(o)  # _infer_offset rounds the offset once, for every use (reference :140-141)
+    u = (x / c["scale"][:, None] - o.float()).double()  # the fp32 value the kernel sees
+    q = torch.round(u)
+    below, clip = q < lo, (q < lo) | (q > hi)
+    ds = torch.where(clip, torch.where(below, lo, hi) + o, q - u) * g
+    do = torch.where(clip, s * g, torch.zeros_like(g))
+    return ds, do
+
+
+def check_backward(device):
+    """Fixture G11: fastforward::quantize_by_tile_backward of the reference. dinput is exact; the per-tile sums
+    are fp32 sums in an implementation-defined order: |got - want| <= 4e-6 * sum|terms| (about 30 ulp of the
+    largest partial sum), the bound the reference's own fp32 summation satisfies against float64."""
+    for c in golden("g11_backward.pt"):
+        offset = None if c["offset"] is None else c["offset"].to(device)
+        dinput, dscale, doffset = ops.quantize_by_tile_backward(c["data"].to(device), c["grad"].to(device), c["scale"].to(device), c["tile"], float(c["num_bits"]), offset)
+        assert dinput.dtype == c["dinput"].dtype and same_with_nan(dinput.cpu(), c["dinput"]), c["name"]
+        ds64, do64 = _backward_terms64(c)
+        tol_s = 4e-6 * ds64.abs().sum(1) + 1e-30
+        assert dscale.shape == c["dscale"].shape and bool(((dscale.cpu().double() - c["dscale"].double()).abs() <= tol_s).all()), c["name"]
+        assert bool(((dscale.cpu().double() - ds64.sum(1)).abs() <= tol_s).all()), c["name"]
+        if c["offset"] is None:
+            assert doffset.numel() == 0, c["name"]
+        else:
+            tol_o = 4e-6 * do64.abs().sum(1) + 1e-30
+            assert bool(((doffset.cpu().double() - c["doffset"].double()).abs() <= tol_o).all()), c["name"]
+            assert bool(((doffset.cpu().double() - do64.sum(1)).abs() <= tol_o).all()), c["name"]

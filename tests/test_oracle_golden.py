@@ -49,3 +49,7 @@ def test_quantized_linear_w8a8():
 
 def test_fused_producers_rmsnorm_silu_rope():
     parity_cases.check_producers("cpu")
+
+
+def test_quantize_by_tile_backward():
+    parity_cases.check_backward("cpu")

@@ -69,6 +69,10 @@ def test_fused_producers_rmsnorm_silu_rope():
     parity_cases.check_producers(DEV)
 
 
+def test_quantize_by_tile_backward():
+    parity_cases.check_backward(DEV)
+
+
 def test_golden_sweeps_with_ieee_division_kernels(monkeypatch):
     """FFQ_DIV_MODE is read once per process; the generic kernels always use the IEEE sequence."""
     monkeypatch.setenv("FFQ_FORCE_GENERIC", "1")
@@ -425,3 +429,28 @@ def test_full_size_producers_properties():
     want_k = (kh * cos + llama._rotate_half(kh) * sin).transpose(1, 2).reshape(8, 2048, -1)
     ops.rope_(q, k, cos, sin, 128)
     assert torch.equal(q, want_q) and torch.equal(k, want_k)
+
+
+# ---- A8: backward ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,tile", [((4096, 4096), (1, 4096)), ((8, 2048, 4096), (8, 2048, 4096)), ((4096, 4096), (1, 128)), ((1000, 1000), (1000, 1000)), ((24, 1024), (1, 1024))])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_backward_kernel_matches_composite_formulas(shape, tile, dtype):
+    """HIP kernel vs the op-for-op composite on the device at Llama sizes: dinput identical, per-tile sums within
+    the fp32 summation tolerance; the straight-through property dinput == grad where nothing clips."""
+    torch.manual_seed(3)
+    x = (torch.randn(shape, device=DEV) * 2).to(dtype)
+    g = torch.randn(shape, device=DEV).to(dtype)
+    ntiles = 1
+    for s_, t_ in zip(shape, tile):
+        ntiles *= s_ // t_
+    scale = torch.rand(ntiles, device=DEV) * 0.05 + 0.02
+    offset = torch.rand(ntiles, device=DEV) * 6 - 3
+    got = ops.quantize_by_tile_backward(x, g, scale, tile, 8.0, offset)
+    want = ops._quantize_by_tile_backward_composite(x, g, scale, tile, 8.0, offset)
+    assert torch.equal(got[0], want[0])
+    from fastforward_amd.quantization.tiled_tensor import tiles_to_rows
+    mag = tiles_to_rows(g.float().abs(), torch.Size(tile)).sum(1)  # every term is bounded by (|bound| + |offset|) |g|
+    assert bool(((got[1] - want[1]).abs() <= 4e-6 * 132 * mag + 1e-6).all())
+    assert bool(((got[2] - want[2]).abs() <= 4e-6 * 0.07 * mag + 1e-6).all())
+    wide = ops.quantize_by_tile_backward(x, g, scale * 1e3, tile, 8.0, offset)  # grid wide enough: nothing clips
+    assert torch.equal(wide[0], g) and float(wide[2].abs().max()) == 0.0
