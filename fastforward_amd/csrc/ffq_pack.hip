@@ -5,8 +5,11 @@
 //   the low nibbles and the second half to the high nibbles: byte[j] = qs[j] | qs[j + block/2] << 4.
 // The reference itself keeps 4-bit codes unpacked; this pair makes W4 weights occupy 0.5 B/elem in
 // HBM while `unpack(pack(q)) == q` holds exactly.
+#include "ffq_affine.h"
 #include "ffq_common.h"
 #include "ffq_vec.h"
+
+#include <math.h>
 
 namespace ffq {
 
@@ -79,6 +82,113 @@ __global__ __launch_bounds__(kBlock) void unpack_int4_generic_kernel(const uint8
   }
 }
 
+
+// ---- A1 + A7 in one pass: x -> 4-bit codes -> nibbles (2 + 0.5 B/elem for bf16) -------------------------
+// One lane owns 16 consecutive elements of the low half of a packing block and the 16 elements at the same
+// position of the high half: two 32-byte loads in, one dense 16-byte store out.
+struct Pack4Args {
+  uint32_t nitems;         // numel / 32
+  uint32_t block;          // packing block (codes)
+  FastDiv items_per_block; // block / 32
+  FastDiv chunks_per_run;  // ROWS: run / 16 (16-element chunks per tile)
+  int rows;                // 1: ROWS layout, 0: one tile
+  uint32_t scale_stride, offset_stride;
+};
+
+template <typename T, bool HAS_OFFSET>
+__global__ __launch_bounds__(kBlock) void quantize_pack_int4_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                                   const float* __restrict__ offset,
+                                                                   uint8_t* __restrict__ packed, Pack4Args a) {
+  const uint32_t item = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  if (item >= a.nitems) return;
+  const uint32_t b = fdiv(item, a.items_per_block);
+  const uint32_t j = item - b * a.items_per_block.div;
+  const uint32_t e_lo = b * a.block + j * 16, e_hi = e_lo + a.block / 2;
+  Chunk<T, 16> cl, ch;
+  cl.load(x + e_lo);
+  ch.load(x + e_hi);
+  const uint32_t t_lo = a.rows ? fdiv(e_lo / 16, a.chunks_per_run) : 0u;
+  const uint32_t t_hi = a.rows ? fdiv(e_hi / 16, a.chunks_per_run) : 0u;
+  const float s_lo = scale[t_lo * a.scale_stride], s_hi = scale[t_hi * a.scale_stride];
+  const float o_lo = HAS_OFFSET ? rne(offset[t_lo * a.offset_stride]) : 0.0f;
+  const float o_hi = HAS_OFFSET ? rne(offset[t_hi * a.offset_stride]) : 0.0f;
+  float xl[16], xh[16], rl[16], rh[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { xl[i] = cl.get(i); xh[i] = ch.get(i); }
+  quantize_chunk<1, 16>(xl, s_lo, o_lo, rl);
+  quantize_chunk<1, 16>(xh, s_hi, o_hi, rh);
+  Chunk<uint8_t, 16> out;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int l = (int)rl[4 * w + i], h = (int)rh[4 * w + i];  // v_cvt_i32_f32: NaN -> 0 (the int8 container's value)
+      l = (l < -8 ? -8 : (l > 7 ? 7 : l)) + 8;
+      h = (h < -8 ? -8 : (h > 7 ? 7 : h)) + 8;
+      word |= (uint32_t)(l | (h << 4)) << (8 * i);
+    }
+    out.w[w] = word;
+  }
+  out.store(packed + (size_t)b * (a.block / 2) + j * 16);
+}
+
+// ---- A7 + A2 in one pass: nibbles -> codes -> (q + round(o)) * s (0.5 + 2 B/elem for bf16) -------------
+template <typename T, bool HAS_OFFSET>
+__global__ __launch_bounds__(kBlock) void unpack_dequantize_int4_kernel(const uint8_t* __restrict__ packed,
+                                                                       const float* __restrict__ scale,
+                                                                       const float* __restrict__ offset, T* __restrict__ out,
+                                                                       Pack4Args a) {
+  const uint32_t item = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  if (item >= a.nitems) return;
+  const uint32_t b = fdiv(item, a.items_per_block);
+  const uint32_t j = item - b * a.items_per_block.div;
+  const uint32_t e_lo = b * a.block + j * 16, e_hi = e_lo + a.block / 2;
+  Chunk<uint8_t, 16> in;
+  in.load(packed + (size_t)b * (a.block / 2) + j * 16);
+  const uint32_t t_lo = a.rows ? fdiv(e_lo / 16, a.chunks_per_run) : 0u;
+  const uint32_t t_hi = a.rows ? fdiv(e_hi / 16, a.chunks_per_run) : 0u;
+  const float s_lo = scale[t_lo * a.scale_stride], s_hi = scale[t_hi * a.scale_stride];
+  const float o_lo = HAS_OFFSET ? rne(offset[t_lo * a.offset_stride]) : 0.0f;
+  const float o_hi = HAS_OFFSET ? rne(offset[t_hi * a.offset_stride]) : 0.0f;
+  float yl[16], yh[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t byte = (in.w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+    yl[i] = ((float)((int)(byte & 15u) - 8) + o_lo) * s_lo;  // add and multiply are separate fp32 roundings
+    yh[i] = ((float)((int)(byte >> 4) - 8) + o_hi) * s_hi;
+  }
+  Chunk<T, 16> cl, ch;
+  cl.pack(yl);
+  ch.pack(yh);
+  cl.store(out + e_lo);
+  ch.store(out + e_hi);
+}
+
+static int pack4_plan(const ffq_tiling* tiling, int64_t block, int64_t scale_numel, const float* offset, int64_t offset_numel,
+                      Pack4Args* a, int64_t* numel) {
+  TileInfo info;
+  int rc = analyse(tiling, &info);
+  if (rc) return rc;
+  *numel = info.numel;
+  if (block <= 0 || (block & 1) || info.numel % block) return fail(FFQ_ERR_ARG, "numel %% block != 0 or odd block");
+  if (info.numel != 0) {
+    if ((rc = check_param_numel("scale", scale_numel, info.ntiles))) return rc;
+    if (offset && (rc = check_param_numel("offset", offset_numel, info.ntiles))) return rc;
+  }
+  const bool layout_ok = info.layout == LAYOUT_SCALAR || (info.layout == LAYOUT_ROWS && info.run % 16 == 0);
+  if (!layout_ok || block % 32 != 0 || info.numel >= ((int64_t)1 << 32))
+    return fail(FFQ_ERR_DTYPE, "fused 4-bit kernels cover per-tensor / contiguous-run tiles (run %% 16 == 0) and block %% 32 == 0");
+  a->nitems = (uint32_t)(info.numel / 32);
+  a->block = (uint32_t)block;
+  a->items_per_block = make_fastdiv((uint32_t)(block / 32));
+  a->rows = info.layout == LAYOUT_ROWS;
+  a->chunks_per_run = make_fastdiv(a->rows ? (uint32_t)(info.run / 16) : 1u);
+  a->scale_stride = scale_numel == 1 ? 0u : 1u;
+  a->offset_stride = offset_numel == 1 ? 0u : 1u;
+  return FFQ_OK;
+}
+
 static bool fast_ok(const void* a, const void* b, int64_t numel, int64_t block) {
   return block % 8 == 0 && numel < ((int64_t)1 << 32) && (reinterpret_cast<uintptr_t>(a) & 3u) == 0 &&
          (reinterpret_cast<uintptr_t>(b) & 3u) == 0;
@@ -142,4 +252,58 @@ extern "C" int ffq_unpack_int4(const uint8_t* packed, int64_t numel, int64_t blo
   }
   unpack_int4_generic_kernel<<<grid_of(nbytes), kBlock, 0, s>>>(packed, codes_out, codes_dt, nbytes, block);
   return check_launch("unpack_int4_generic_kernel");
+}
+
+extern "C" int ffq_quantize_pack_int4(const void* data, int data_dt, const float* scale, int64_t scale_numel,
+                                      const float* offset, int64_t offset_numel, const ffq_tiling* tiling, int64_t block,
+                                      uint8_t* packed, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Pack4Args a;
+  int64_t numel = 0;
+  int rc = pack4_plan(tiling, block, scale_numel, offset, offset_numel, &a, &numel);
+  if (rc) return rc;
+  if (numel == 0) return FFQ_OK;
+  if (!data || !scale || !packed) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (!(data_dt == FFQ_BF16 || data_dt == FFQ_F16 || data_dt == FFQ_F32) || !aligned16(data) || !aligned16(packed))
+    return fail(FFQ_ERR_DTYPE, "fused quantize+pack is built for 16-byte aligned f32 / bf16 / f16 data");
+  const unsigned grid = (a.nitems + kBlock - 1) / kBlock;
+#define FFQ_QP(T)                                                                                                   \
+  do {                                                                                                              \
+    if (offset) quantize_pack_int4_kernel<T, true><<<grid, kBlock, 0, s>>>(static_cast<const T*>(data), scale, offset, packed, a); \
+    else quantize_pack_int4_kernel<T, false><<<grid, kBlock, 0, s>>>(static_cast<const T*>(data), scale, offset, packed, a);       \
+  } while (0)
+  switch (data_dt) {
+    case FFQ_BF16: FFQ_QP(bf16_t); break;
+    case FFQ_F16: FFQ_QP(f16_t); break;
+    default: FFQ_QP(float); break;
+  }
+#undef FFQ_QP
+  return check_launch("quantize_pack_int4_kernel");
+}
+
+extern "C" int ffq_unpack_dequantize_int4(const uint8_t* packed, const float* scale, int64_t scale_numel, const float* offset,
+                                          int64_t offset_numel, const ffq_tiling* tiling, int64_t block, void* out, int out_dt,
+                                          void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Pack4Args a;
+  int64_t numel = 0;
+  int rc = pack4_plan(tiling, block, scale_numel, offset, offset_numel, &a, &numel);
+  if (rc) return rc;
+  if (numel == 0) return FFQ_OK;
+  if (!packed || !scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (!(out_dt == FFQ_BF16 || out_dt == FFQ_F16 || out_dt == FFQ_F32) || !aligned16(out) || !aligned16(packed))
+    return fail(FFQ_ERR_DTYPE, "fused unpack+dequantize is built for 16-byte aligned f32 / bf16 / f16 outputs");
+  const unsigned grid = (a.nitems + kBlock - 1) / kBlock;
+#define FFQ_UD(T)                                                                                                   \
+  do {                                                                                                              \
+    if (offset) unpack_dequantize_int4_kernel<T, true><<<grid, kBlock, 0, s>>>(packed, scale, offset, static_cast<T*>(out), a); \
+    else unpack_dequantize_int4_kernel<T, false><<<grid, kBlock, 0, s>>>(packed, scale, offset, static_cast<T*>(out), a);       \
+  } while (0)
+  switch (out_dt) {
+    case FFQ_BF16: FFQ_UD(bf16_t); break;
+    case FFQ_F16: FFQ_UD(f16_t); break;
+    default: FFQ_UD(float); break;
+  }
+#undef FFQ_UD
+  return check_launch("unpack_dequantize_int4_kernel");
 }

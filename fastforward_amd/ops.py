@@ -30,6 +30,8 @@ __all__ = [
     "parameters_for_range",
     "pack_int4",
     "unpack_int4",
+    "quantize_pack_int4",
+    "unpack_dequantize_int4",
     "linear_w8a8",
     "add_rmsnorm_quantize",
     "silu_mul_quantize",
@@ -387,6 +389,54 @@ def unpack_int4(packed: torch.Tensor, shape: Sequence[int], dtype: torch.dtype =
         raise ValueError(f"shape {tuple(shape)} does not hold {packed_c.numel() * 2} codes")
     lib.check(lib.ffq_unpack_int4(_ptr(packed_c), out.numel(), int(block), _ptr(out), _tag(dtype), stream))
     return out
+
+
+def quantize_pack_int4(
+    data: torch.Tensor, scale: torch.Tensor, tile_size: Sequence[int], offset: torch.Tensor | None = None, block: int = 32
+) -> torch.Tensor:
+    """A1 (4 bits) + A7 in one pass: ``pack_int4(quantize_by_tile(data, ..., num_bits=4, int8), block)`` without the
+    codes' round trip through HBM. Tilings / dtypes outside the fused kernel's range compose the two steps."""
+    data_c = data.detach().contiguous()
+    scale_c, offset_c = _flat(scale), _flat(offset)
+    fast = scale_c.dtype == torch.float32 and (offset_c is None or offset_c.dtype == torch.float32) and data_c.dtype in (torch.float32, torch.bfloat16, torch.float16)
+    if fast:
+        lib, stream = _prepare(data_c, scale_c, offset_c)
+        tiling = _tile_of(data_c, tile_size)
+        out = torch.empty(data_c.numel() // 2, dtype=torch.uint8, device=data_c.device)
+        status = lib.ffq_quantize_pack_int4(
+            _ptr(data_c), _tag(data_c.dtype), _ptr(scale_c), scale_c.numel(), _ptr(offset_c),
+            offset_c.numel() if offset_c is not None else 0, ctypes.byref(tiling), int(block), _ptr(out), stream,
+        )
+        if status == 0:
+            return out
+        if status != 6:  # FFQ_ERR_DTYPE: not covered by the fused kernel
+            lib.check(status)
+    return pack_int4(quantize_by_tile(data, scale, tile_size, 4, torch.int8, offset), block)
+
+
+def unpack_dequantize_int4(
+    packed: torch.Tensor, scale: torch.Tensor, shape: Sequence[int], tile_size: Sequence[int], offset: torch.Tensor | None = None,
+    block: int = 32, output_dtype: torch.dtype = torch.bfloat16,
+) -> torch.Tensor:
+    """A7 + A2 in one pass: ``dequantize_by_tile(unpack_int4(packed, shape, int8, block), ...)``."""
+    packed_c = packed.detach().contiguous()
+    scale_c, offset_c = _flat(scale), _flat(offset)
+    fast = scale_c.dtype == torch.float32 and (offset_c is None or offset_c.dtype == torch.float32) and output_dtype in (torch.float32, torch.bfloat16, torch.float16)
+    if fast:
+        lib, stream = _prepare(packed_c, scale_c, offset_c)
+        out = torch.empty(tuple(shape), dtype=output_dtype, device=packed_c.device)
+        if out.numel() != packed_c.numel() * 2:
+            raise ValueError(f"shape {tuple(shape)} does not hold {packed_c.numel() * 2} codes")
+        tiling = _tile_of(out, tile_size)
+        status = lib.ffq_unpack_dequantize_int4(
+            _ptr(packed_c), _ptr(scale_c), scale_c.numel(), _ptr(offset_c), offset_c.numel() if offset_c is not None else 0,
+            ctypes.byref(tiling), int(block), _ptr(out), _tag(output_dtype), stream,
+        )
+        if status == 0:
+            return out
+        if status != 6:
+            lib.check(status)
+    return dequantize_by_tile(unpack_int4(packed, shape, torch.int8, block), scale, tile_size, offset, output_dtype)
 
 
 def linear_w8a8(

@@ -258,6 +258,20 @@ int ffq_quantize_by_tile_backward(const void* data, const void* output_grad, int
                                   const ffq_tiling* tiling, double num_bits, void* dinput, float* dscale,
                                   float* doffset, void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * A1 + A7 and A7 + A2 in one pass each (4-bit, the W4 PerBlock(128) configuration): the codes never make
+ * an HBM round trip. packed == ffq_pack_int4(ffq_quantize_by_tile(data, num_bits = 4, int8 container)),
+ * out == ffq_dequantize_by_tile(ffq_unpack_int4(packed)) exactly. fp32 parameters; per-tensor or
+ * contiguous-run tiles with run % 16 == 0; block % 32 == 0; anything else returns FFQ_ERR_DTYPE and the
+ * caller composes the two-step path.
+ */
+int ffq_quantize_pack_int4(const void* data, int data_dt, const float* scale, int64_t scale_numel,
+                           const float* offset, int64_t offset_numel, const ffq_tiling* tiling, int64_t block,
+                           uint8_t* packed, void* stream);
+int ffq_unpack_dequantize_int4(const uint8_t* packed, const float* scale, int64_t scale_numel, const float* offset,
+                               int64_t offset_numel, const ffq_tiling* tiling, int64_t block, void* out, int out_dt,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -865,3 +865,32 @@ int ffq_quantize_by_tile_backward(const void* data, const void* output_grad, int
   free(acc_s); free(acc_o);
   return FFQ_OK;
 }
+
+/* A1 + A7 / A7 + A2 composed (the fused kernels must equal the two-step path exactly) */
+int ffq_quantize_pack_int4(const void* data, int data_dt, const float* scale, int64_t scale_numel,
+                           const float* offset, int64_t offset_numel, const ffq_tiling* tiling, int64_t block,
+                           uint8_t* packed, void* stream) {
+  int rc = check_tiling(tiling);
+  if (rc) return rc;
+  int64_t n = numel_of(tiling);
+  if (block <= 0 || (block & 1) || n % block) return fail(FFQ_ERR_ARG, "numel %% block != 0 or odd block");
+  int8_t* codes = (int8_t*)malloc((size_t)(n ? n : 1));
+  rc = ffq_quantize_by_tile(data, data_dt, scale, FFQ_F32, scale_numel, offset, FFQ_F32, offset_numel, tiling, 4.0, codes, FFQ_I8, stream);
+  if (!rc) rc = ffq_pack_int4(codes, FFQ_I8, n, block, packed, stream);
+  free(codes);
+  return rc;
+}
+
+int ffq_unpack_dequantize_int4(const uint8_t* packed, const float* scale, int64_t scale_numel, const float* offset,
+                               int64_t offset_numel, const ffq_tiling* tiling, int64_t block, void* out, int out_dt,
+                               void* stream) {
+  int rc = check_tiling(tiling);
+  if (rc) return rc;
+  int64_t n = numel_of(tiling);
+  if (block <= 0 || (block & 1) || n % block) return fail(FFQ_ERR_ARG, "numel %% block != 0 or odd block");
+  int8_t* codes = (int8_t*)malloc((size_t)(n ? n : 1));
+  rc = ffq_unpack_int4(packed, n, block, codes, FFQ_I8, stream);
+  if (!rc) rc = ffq_dequantize_by_tile(codes, FFQ_I8, scale, FFQ_F32, scale_numel, offset, FFQ_F32, offset_numel, tiling, out, out_dt, stream);
+  free(codes);
+  return rc;
+}

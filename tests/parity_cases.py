@@ -116,6 +116,20 @@ def check_int4(device):
         for dtype in (torch.int8, torch.bfloat16, torch.float32, torch.int32):
             codes = q.raw_data.to(dtype)
             assert torch.equal(ops.unpack_int4(ops.pack_int4(codes, block=block), codes.shape, dtype, block=block), codes)
+    # fused A1+A7 / A7+A2 (one pass each) == the reference's codes, nibbles and dequantized values
+    w, scale, offset = c["weight"].to(device), c["scale"].to(device), to_device(c["offset"], device)
+    tile = gran.tile_size(w.shape)
+    fused = ops.quantize_pack_int4(w, scale, tile, offset, block=32)
+    assert torch.equal(fused.cpu().reshape(-1, 16), c["q4_0_nibbles_block32"])
+    assert same_with_nan(ops.unpack_dequantize_int4(fused, scale, w.shape, tile, offset, block=32, output_dtype=w.dtype).cpu(), c["dequantized"])
+    for block in (32, 128, 256):
+        for dtype in (torch.bfloat16, torch.float32):
+            x = c["weight"].to(dtype).to(device)
+            for tl, sc, of in ((tile, scale, offset), (tuple(x.shape), scale[:1], None), ((1, x.shape[1]), scale[: x.shape[0]], offset[: x.shape[0]] if offset is not None else None)):
+                packed = ops.quantize_pack_int4(x, sc, tl, of, block=block)
+                assert torch.equal(packed, ops.pack_int4(ops.quantize_by_tile(x, sc, tl, 4, torch.int8, of), block=block))
+                back = ops.unpack_dequantize_int4(packed, sc, x.shape, tl, of, block=block, output_dtype=dtype)
+                assert same_with_nan(back.cpu(), ops.dequantize_by_tile(ops.unpack_int4(packed, x.shape, torch.int8, block=block), sc, tl, of, dtype).cpu())
 
 
 def linear_tolerances(dtype):

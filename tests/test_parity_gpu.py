@@ -454,3 +454,18 @@ def test_backward_kernel_matches_composite_formulas(shape, tile, dtype):
     assert bool(((got[2] - want[2]).abs() <= 4e-6 * 0.07 * mag + 1e-6).all())
     wide = ops.quantize_by_tile_backward(x, g, scale * 1e3, tile, 8.0, offset)  # grid wide enough: nothing clips
     assert torch.equal(wide[0], g) and float(wide[2].abs().max()) == 0.0
+
+
+def test_full_size_w4_fused_pack_paths():
+    """[14336, 4096] bf16, PerBlock(128): fused quantize+pack == A1 then A7, fused unpack+dequantize == A7 then A2,
+    and the round trip is idempotent (re-quantizing the dequantized weights gives the same nibbles)."""
+    torch.manual_seed(9)
+    w = (torch.randn(14336, 4096, device=DEV) * 0.02).to(torch.bfloat16)
+    tile = (1, 128)
+    lo, hi = ops.minmax_by_tile(w, tile)
+    scale, offset = ops.parameters_for_range(lo, hi, 4, True, True)
+    packed = ops.quantize_pack_int4(w, scale, tile, offset, block=128)
+    assert torch.equal(packed, ops.pack_int4(ops.quantize_by_tile(w, scale, tile, 4, torch.int8, offset), block=128))
+    deq = ops.unpack_dequantize_int4(packed, scale, w.shape, tile, offset, block=128)
+    assert torch.equal(deq, ops.dequantize_by_tile(ops.unpack_int4(packed, w.shape, torch.int8, block=128), scale, tile, offset, torch.bfloat16))
+    assert torch.equal(ops.quantize_pack_int4(deq, scale, tile, offset, block=128), packed)

@@ -163,6 +163,18 @@ def cfg4() -> dict:
         codes = ops.unpack_int4(packed[state["i"] % 6], shape, torch.int8, block=128)
         return ops.dequantize_by_tile(codes, scale, tile, offset, torch.bfloat16)
 
+    def quant_pack_fused():
+        state["i"] += 1
+        return ops.quantize_pack_int4(ws[state["i"] % 6], scale, tile, offset, block=128)
+
+    def unpack_dequant_fused():
+        state["i"] += 1
+        return ops.unpack_dequantize_int4(packed[state["i"] % 6], scale, shape, tile, offset, block=128)
+
+    for name, fn, kern in (("quantize+pack fused", quant_pack_fused, "quantize_pack_int4_kernel"), ("unpack+dequantize fused", unpack_dequant_fused, "unpack_dequantize_int4_kernel")):
+        ms = event_ms(fn)
+        out[f"{name}_[14336,4096]"] = {"ms": round(ms, 4), "GB_per_s_algorithmic_2.5B_per_elem": round(n * 2.5 / ms / 1e6, 1),
+                                       "frac_of_hbm_peak": round(n * 2.5 / ms / 1e6 / HBM_PEAK_GBS, 4), "kernels": kern + " (one launch)"}
     ms = event_ms(quant_pack)
     out["quantize_plus_pack_[14336,4096]"] = {"ms": round(ms, 4), "GB_per_s_algorithmic_2.5B_per_elem": round(n * 2.5 / ms / 1e6, 1),
                                               "frac_of_hbm_peak": round(n * 2.5 / ms / 1e6 / HBM_PEAK_GBS, 4), "kernels": "A1 (bf16 -> int8 codes) + A7 pack (two launches; codes make one HBM round trip)"}
