@@ -65,15 +65,10 @@ def ids(config, batch, seq, seed):
 
 
 def event_ms(fn, reps: int = 10) -> float:
-    fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        fn()
-    b.record()
-    b.synchronize()
-    return a.elapsed_time(b) / reps
+    """Median ms per call: `reps` calls captured into a hipGraph and replayed (no host launch path in the timing)."""
+    from bench import event_time_ms
+
+    return event_time_ms(lambda r: fn(), iters=8, reps=reps)
 
 
 def cfg2() -> dict:
