@@ -72,11 +72,13 @@ __device__ __forceinline__ void fan_store(const FanOut& f, const FanParams& p, c
 
 // ---------------------------------------------------------------------------------------------------
 // P1: sum = x + delta (residual add, bf16); z = weight * bf16(sum_f32 * rsqrt(mean(sum_f32^2) + eps));
-//     codes_j = A1(z; s_j, o_j). One wavefront per row, the row stays in registers between the
-//     reduction and the normalisation (CPL chunks of 16 elements per lane: cols <= 1024 * CPL).
+//     codes_j = A1(z; s_j, o_j). WPR wavefronts per row (1 for short rows, 4 = the whole block for
+//     hidden sizes above 1024), the row stays in registers between the reduction and the normalisation
+//     (CPL chunks of 16 elements per lane: cols <= 1024 * WPR * CPL). Few registers per lane on purpose:
+//     the one-wave-per-row form of a 4096-wide row needs 117 VGPRs (4 waves/SIMD) and reaches 4.5 TB/s.
 //     Algorithmic bytes / element: 2 (x) [+ 2 (delta) + 2 (sum)] [+ 2 (z)] + 1 per distinct code tensor.
 // ---------------------------------------------------------------------------------------------------
-template <int CPL>
+template <int CPL, int WPR>
 __global__ __launch_bounds__(kBlock) void add_rmsnorm_quantize_kernel(const bf16_t* __restrict__ x,
                                                                       const bf16_t* __restrict__ delta,
                                                                       bf16_t* __restrict__ sum_out,
@@ -84,26 +86,27 @@ __global__ __launch_bounds__(kBlock) void add_rmsnorm_quantize_kernel(const bf16
                                                                       bf16_t* __restrict__ norm_out, FanOut f,
                                                                       uint32_t rows, uint32_t chunks_per_row,
                                                                       float inv_cols, float eps) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t row = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  constexpr uint32_t LPR = 64u * WPR;  // lanes per row
+  const uint32_t lane = threadIdx.x % LPR;
+  const uint32_t row = blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR;
+  if (row >= rows) return;  // block-uniform when WPR == 4
   const size_t base = (size_t)row * chunks_per_row * 16;
   Chunk<bf16_t, 16> h[CPL];
 #pragma unroll
   for (int u = 0; u < CPL; ++u) {
-    const uint32_t c = lane + 64u * u;
+    const uint32_t c = lane + LPR * u;
     if (c < chunks_per_row) h[u].load(x + base + (size_t)c * 16);
   }
   if (delta) {
     Chunk<bf16_t, 16> d[CPL];
 #pragma unroll
     for (int u = 0; u < CPL; ++u) {
-      const uint32_t c = lane + 64u * u;
+      const uint32_t c = lane + LPR * u;
       if (c < chunks_per_row) d[u].load(delta + base + (size_t)c * 16);
     }
 #pragma unroll
     for (int u = 0; u < CPL; ++u) {
-      const uint32_t c = lane + 64u * u;
+      const uint32_t c = lane + LPR * u;
       if (c >= chunks_per_row) continue;
       float v[16];
 #pragma unroll
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void add_rmsnorm_quantize_kernel(const bf16
   float ss = 0.0f;
 #pragma unroll
   for (int u = 0; u < CPL; ++u) {
-    const uint32_t c = lane + 64u * u;
+    const uint32_t c = lane + LPR * u;
     if (c >= chunks_per_row) continue;
     float part = 0.0f;
 #pragma unroll
@@ -128,11 +131,17 @@ __global__ __launch_bounds__(kBlock) void add_rmsnorm_quantize_kernel(const bf16
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) ss = ss + __shfl_xor(ss, d, 64);
+  if constexpr (WPR > 1) {
+    __shared__ float wave_ss[kBlock / 64];
+    if ((threadIdx.x & 63u) == 0) wave_ss[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    ss = ((wave_ss[0] + wave_ss[1]) + wave_ss[2]) + wave_ss[3];
+  }
   const float r = rsqrtf(ss * inv_cols + eps);
   const FanParams p = load_fan(f);
 #pragma unroll
   for (int u = 0; u < CPL; ++u) {
-    const uint32_t c = lane + 64u * u;
+    const uint32_t c = lane + LPR * u;
     if (c >= chunks_per_row) continue;
     Chunk<bf16_t, 16> w;
     w.load(weight + (size_t)c * 16);
@@ -268,16 +277,14 @@ extern "C" int ffq_add_rmsnorm_quantize(const void* x, const void* delta, void* 
       (norm_out && !aligned16(norm_out)))
     return fail(FFQ_ERR_ARG, "buffers must be 16-byte aligned");
   const uint32_t cpr = (uint32_t)(cols / 16);
-  const unsigned grid = (unsigned)((rows + 3) / 4);
   const float inv = (float)(1.0 / (double)cols);  // ATen's mean multiplies the sum by float(1/N)
-#define FFQ_P1(CPL)                                                                                       \
-  add_rmsnorm_quantize_kernel<CPL><<<grid, kBlock, 0, s>>>(                                               \
+#define FFQ_P1(CPL, WPR)                                                                                  \
+  add_rmsnorm_quantize_kernel<CPL, WPR><<<(unsigned)((rows + 4 / WPR - 1) / (4 / WPR)), kBlock, 0, s>>>(  \
       static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(delta), static_cast<bf16_t*>(sum_out),    \
       static_cast<const bf16_t*>(weight), static_cast<bf16_t*>(norm_out), f, (uint32_t)rows, cpr, inv, (float)eps)
-  if (cpr <= 64) FFQ_P1(1);
-  else if (cpr <= 128) FFQ_P1(2);
-  else if (cpr <= 256) FFQ_P1(4);
-  else FFQ_P1(8);
+  if (cpr <= 64) FFQ_P1(1, 1);
+  else if (cpr <= 256) FFQ_P1(1, 4);
+  else FFQ_P1(2, 4);
 #undef FFQ_P1
   return check_launch("add_rmsnorm_quantize_kernel");
 }

@@ -330,6 +330,9 @@ class FusedForward:
         self.model = model
         self.cache_weight_codes = cache_weight_codes
         self._weight_cache: dict[int, tuple[tuple[int, int, int], torch.Tensor]] = {}
+        # when set to a list, every quantized linear appends (N, K, start event, end event): bench.py times the
+        # GEMM launches of a real forward (real code distributions) with it
+        self.linear_events: list[tuple[int, int, torch.cuda.Event, torch.cuda.Event]] | None = None
         # One host comparison per layer, once: consumers of the same tensor usually hold the same range.
         self._fan: list[dict[str, tuple[list[tuple[torch.Tensor, torch.Tensor | None]], list[int]]]] = []
         for layer in model.layers:
@@ -410,7 +413,14 @@ class FusedForward:
     def _linear(self, x_codes: torch.Tensor, linear: torch.nn.Module) -> torch.Tensor:
         w_codes, w_scale, w_offset = self._weight(linear)
         x_scale, x_offset = self._params(linear)
-        return ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16)
+        if self.linear_events is None:
+            return ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16)
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        out = ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16)
+        end.record()
+        self.linear_events.append((w_codes.shape[0], w_codes.shape[1], start, end))
+        return out
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, logits: bool = True) -> torch.Tensor:
