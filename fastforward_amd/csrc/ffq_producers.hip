@@ -27,7 +27,13 @@ struct FanOut {
   float lo, hi;
 };
 
-__device__ __forceinline__ float bf16_round(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+// Round two fp32 values to bf16 and back with ONE v_cvt_pk_bf16_f32 (RNE) + two bit moves, instead of the
+// ~6-instruction integer sequence per value: the producers round after every ATen op of the eager chain.
+__device__ __forceinline__ void bf16_round2(float& a, float& b) {
+  const uint32_t w = pack2<bf16_t>(a, b);
+  a = __builtin_bit_cast(float, w << 16);
+  b = __builtin_bit_cast(float, w & 0xFFFF0000u);
+}
 
 // 16 bf16-valued floats -> int8 codes for every quantizer of the fan-out. Quantizers that hold the same
 // (scale, offset) — q/k/v_proj see the same tensor, so RunningMinMax gives them the same range — reuse
@@ -147,7 +153,13 @@ __global__ __launch_bounds__(kBlock) void add_rmsnorm_quantize_kernel(const bf16
     w.load(weight + (size_t)c * 16);
     float z[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = bf16_round(w.get(i) * bf16_round(h[u].get(i) * r));
+    for (int i = 0; i < 16; i += 2) {
+      float n0 = h[u].get(i) * r, n1 = h[u].get(i + 1) * r;
+      bf16_round2(n0, n1);                      // (hidden * rsqrt).to(bf16)
+      z[i] = w.get(i) * n0;
+      z[i + 1] = w.get(i + 1) * n1;
+      bf16_round2(z[i], z[i + 1]);              // weight * hidden in bf16
+    }
     if (norm_out) {
       Chunk<bf16_t, 16> zc;
       zc.pack(z);
@@ -174,10 +186,13 @@ __global__ __launch_bounds__(kBlock) void silu_mul_quantize_kernel(const bf16_t*
   const FanParams p = load_fan(f);
   float z[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const float x = g.get(i);
-    const float act = bf16_round(x / (1.0f + expf(-x)));
-    z[i] = bf16_round(act * u.get(i));
+  for (int i = 0; i < 16; i += 2) {
+    const float x0 = g.get(i), x1 = g.get(i + 1);
+    float a0 = x0 / (1.0f + expf(-x0)), a1 = x1 / (1.0f + expf(-x1));
+    bf16_round2(a0, a1);                        // F.silu rounds to bf16
+    z[i] = a0 * u.get(i);
+    z[i + 1] = a1 * u.get(i + 1);
+    bf16_round2(z[i], z[i + 1]);                // the product rounds again
   }
   if (product_out) {
     Chunk<bf16_t, 16> zc;
@@ -223,8 +238,11 @@ __global__ __launch_bounds__(kBlock) void rope_kernel(RopeArgs a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const float x1 = lo.get(i), x2 = hi.get(i);
-    ol[i] = bf16_round(x1 * cl.get(i)) + bf16_round((-x2) * sl.get(i));
-    oh[i] = bf16_round(x2 * ch.get(i)) + bf16_round(x1 * sh.get(i));
+    float a = x1 * cl.get(i), b = (-x2) * sl.get(i), c = x2 * ch.get(i), d = x1 * sh.get(i);
+    bf16_round2(a, b);
+    bf16_round2(c, d);
+    ol[i] = a + b;
+    oh[i] = c + d;
   }
   lo.pack(ol);
   hi.pack(oh);

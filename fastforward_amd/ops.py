@@ -32,6 +32,7 @@ __all__ = [
     "unpack_int4",
     "quantize_pack_int4",
     "unpack_dequantize_int4",
+    "grid_sqerror_by_tile",
     "linear_w8a8",
     "add_rmsnorm_quantize",
     "silu_mul_quantize",
@@ -388,6 +389,48 @@ def unpack_int4(packed: torch.Tensor, shape: Sequence[int], dtype: torch.dtype =
     if out.numel() != packed_c.numel() * 2:
         raise ValueError(f"shape {tuple(shape)} does not hold {packed_c.numel() * 2} codes")
     lib.check(lib.ffq_unpack_int4(_ptr(packed_c), out.numel(), int(block), _ptr(out), _tag(dtype), stream))
+    return out
+
+
+def grid_sqerror_by_tile(
+    data: torch.Tensor,
+    scales: torch.Tensor,
+    offsets: torch.Tensor | None,
+    tile_size: Sequence[int],
+    num_bits: float,
+    out: torch.Tensor | None = None,
+) -> torch.Tensor | None:
+    """Sum over every tile of ``(dequantize(quantize(data)) - data) ** 2`` for each candidate parameter set
+    (``scales`` / ``offsets``: ``[candidates, tiles]`` fp32), all candidates in ONE pass over `data` — the inner loop
+    of the min-error grid estimator (reference range_setting/min_error.py:218-231). With `out` given the sums are
+    added to it. Returns None when the tiling is outside the kernel's range (the caller loops over A1 / A2)."""
+    data_c = data.detach().contiguous()
+    sc = scales.detach().to(torch.float32).contiguous()
+    of = None if offsets is None else offsets.detach().to(torch.float32).contiguous()
+    if data_c.dtype not in (torch.float32, torch.bfloat16, torch.float16) or sc.dim() != 2:
+        return None
+    lib, stream = _prepare(data_c, sc, of, out)
+    tiling = _tile_of(data_c, tile_size)
+    ntiles = lib.ffq_num_tiles(ctypes.byref(tiling))
+    if ntiles < 0:
+        lib.check(-ntiles)
+    ncand = sc.shape[0]
+    if sc.shape[1] != ntiles or (of is not None and of.shape != sc.shape):
+        raise RuntimeError(f"candidate parameters must be [candidates, {ntiles}], got {tuple(sc.shape)}")
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty((ncand, ntiles), dtype=torch.float32, device=data_c.device)
+    elif out.shape != sc.shape or out.dtype != torch.float32 or not out.is_contiguous():
+        raise RuntimeError("`out` must be a contiguous fp32 [candidates, tiles] tensor")
+    nbytes = lib.ffq_grid_sqerror_workspace_bytes(ctypes.byref(tiling), ncand)
+    ws = _workspace(nbytes, data_c.device)
+    status = lib.ffq_grid_sqerror_by_tile(
+        _ptr(data_c), _tag(data_c.dtype), _ptr(sc), _ptr(of), ncand, ctypes.byref(tiling), float(num_bits), _ptr(out),
+        int(accumulate), _ptr(ws), nbytes, stream,
+    )
+    if status == 6:  # FFQ_ERR_DTYPE: tiling not covered
+        return None
+    lib.check(status)
     return out
 
 

@@ -272,6 +272,21 @@ int ffq_unpack_dequantize_int4(const uint8_t* packed, const float* scale, int64_
                                int64_t offset_numel, const ffq_tiling* tiling, int64_t block, void* out, int out_dt,
                                void* stream);
 
+/*
+ * Inner loop of the min-error (MSE grid) range estimator — _MinAvgErrorGridEstimator.estimate_step,
+ * range_setting/min_error.py:218-231 with error_fn = mse_error (:62-72): for each of `ncand` candidate
+ * parameter sets (scales / offsets: [ncand, ntiles] fp32, offsets nullable) the SUM over every tile of
+ *   ( cast<dt>( cast<dt>( dequantize(quantize(x)) ) - x ) )^2   (each step rounded to `dt` as the eager chain does)
+ * is written to (accumulate == 0) or added to (accumulate != 0) err[ncand, ntiles] (fp32). The caller divides
+ * by the tile size for the mean. One pass over the data for all candidates; the per-tile sums are fp32 sums in
+ * a fixed, implementation-defined order. Tilings covered: one tile, and contiguous runs of 8 * 2^k <= 512 or a
+ * multiple of 2048 elements; anything else returns FFQ_ERR_DTYPE and the caller loops over A1 / A2.
+ */
+size_t ffq_grid_sqerror_workspace_bytes(const ffq_tiling* tiling, int64_t ncand);
+int ffq_grid_sqerror_by_tile(const void* data, int dt, const float* scales, const float* offsets, int64_t ncand,
+                             const ffq_tiling* tiling, double num_bits, float* err, int accumulate, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -894,3 +894,48 @@ int ffq_unpack_dequantize_int4(const uint8_t* packed, const float* scale, int64_
   free(codes);
   return rc;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Min-error grid search, range_setting/min_error.py:218-231 with mse_error (:62-72): per       */
+/* candidate, quantize (A1) -> dequantize (A2, cast to the data dtype) -> (qdq - x) ** 2 in the  */
+/* data dtype -> summed per tile (double accumulation, rounded to fp32 once).                    */
+/* ------------------------------------------------------------------------------------------ */
+size_t ffq_grid_sqerror_workspace_bytes(const ffq_tiling* tiling, int64_t ncand) { (void)tiling; (void)ncand; return 0; }
+
+int ffq_grid_sqerror_by_tile(const void* data, int dt, const float* scales, const float* offsets, int64_t ncand,
+                             const ffq_tiling* tiling, double num_bits, float* err, int accumulate, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes; (void)stream;
+  int rc = check_tiling(tiling);
+  if (rc) return rc;
+  if (ncand <= 0 || ncand > 4096) return fail(FFQ_ERR_ARG, "number of candidates must be 1..4096");
+  if (!(dt == FFQ_F32 || dt == FFQ_BF16 || dt == FFQ_F16)) return fail(FFQ_ERR_DTYPE, "grid error is built for f32 / bf16 / f16 data");
+  int64_t n = numel_of(tiling), ntiles = ffq_num_tiles(tiling);
+  if (n == 0) return fail(FFQ_ERR_EMPTY, "grid error over an empty tensor");
+  if (!data || !scales || !err) return fail(FFQ_ERR_ARG, "NULL buffer");
+  float lo = (float)(-pow(2.0, num_bits - 1.0)), hi = -lo - 1.0f;
+  double* acc = (double*)malloc((size_t)ntiles * sizeof(double));
+  for (int64_t c = 0; c < ncand; ++c) {
+    memset(acc, 0, (size_t)ntiles * sizeof(double));
+    walker w;
+    walker_init(&w, tiling);
+    for (int64_t i = 0; i < n; ++i, walker_next(&w)) {
+      int64_t t = walker_tile(&w);
+      float x = (float)ld(data, dt, i);
+      float s = scales[c * ntiles + t];
+      float ro = offsets ? nearbyintf(offsets[c * ntiles + t]) : 0.0f;
+      float q = x / s;                         /* A1: _quantizer_impl.py:161 */
+      q = q - ro;
+      q = (float)clamp_nan((double)nearbyintf(q), lo, hi);
+      float y = q + ro;                        /* A2: :186 */
+      y = y * s;
+      y = (float)round_to((double)y, dt);      /* dequantize() returns the data dtype */
+      float d = (float)round_to((double)(y - x), dt);   /* quantized_data - unquantized_data  (min_error.py:72) */
+      float e = (float)round_to((double)(d * d), dt);   /* ** 2 */
+      acc[t] += (double)e;
+    }
+    for (int64_t t = 0; t < ntiles; ++t) err[c * ntiles + t] = (accumulate ? err[c * ntiles + t] : 0.0f) + (float)acc[t];
+  }
+  free(acc);
+  return FFQ_OK;
+}

@@ -470,6 +470,42 @@ def g11_backward():
     return cases
 
 
+def g12_mse_grid():
+    """The reference's mse_grid estimator (range_setting/min_error.py) over 3 scaled batches: the search grid, the
+    cumulative error of every candidate and the (scale, offset) the quantizer ends with."""
+    from fastforward.range_setting.min_error import _MinAvgErrorGridEstimator, mse_grid
+
+    cases = []
+    for name, shape, spec, symmetric, negative, dtype, bits, ncand in [
+        ("tensor_asym_f32", (64, 256), ("tensor",), False, True, torch.float32, 8, 25),
+        ("tensor_sym_f32", (64, 256), ("tensor",), True, True, torch.float32, 4, 20),
+        ("tensor_onesided_f32", (64, 256), ("tensor",), True, False, torch.float32, 4, 20),
+        ("channel0_asym_f32", (24, 2048), ("channel", 0), False, True, torch.float32, 4, 16),
+        ("channel0_sym_bf16", (24, 2048), ("channel", 0), True, True, torch.bfloat16, 4, 16),
+        ("group128_asym_f32", (8, 512), ("block", (1,), (128,), (0,)), False, True, torch.float32, 4, 16),
+        ("channel_last_sym_f32", (24, 16), ("channel", -1), True, True, torch.float32, 8, 9),
+    ]:
+        gen = torch.Generator().manual_seed(1270 + len(cases))
+        batches = []
+        for k in range(3):
+            x = torch.randn(shape, generator=gen) * (1.0 + 0.25 * k)
+            if not negative:
+                x = x.abs()
+            batches.append(x.to(dtype))
+        quantizer = ff.nn.LinearQuantizer(bits, granularity=gran_of(spec), symmetric=symmetric)
+        with ff.estimate_ranges(quantizer, mse_grid, num_candidates=ncand):
+            estimator = next(o for o in quantizer._quantizer_overrides.values() if isinstance(o, _MinAvgErrorGridEstimator))
+            for x in batches:
+                quantizer(x)
+            cases.append({
+                "name": name, "granularity": list(spec), "symmetric": symmetric, "num_bits": bits, "num_candidates": ncand, "batches": batches,
+                "min_threshold": estimator.min_threshold.clone(), "max_threshold": estimator.max_threshold.clone(),
+                "cumulative_error": estimator.cumulative_error.clone(),
+                "scale": quantizer.scale.detach().clone(), "offset": None if quantizer.offset is None else quantizer.offset.detach().clone(),
+            })
+    return cases
+
+
 def main() -> None:
     torch.set_num_threads(8)
     if len(sys.argv) > 1:  # regenerate only the named fixtures, e.g. `gen_golden.py g10_producers`
@@ -489,6 +525,7 @@ def main() -> None:
     torch.save(g9_dispatcher(), HERE / "g9_dispatcher.pt")
     torch.save(g10_producers(), HERE / "g10_producers.pt")
     torch.save(g11_backward(), HERE / "g11_backward.pt")
+    torch.save(g12_mse_grid(), HERE / "g12_mse_grid.pt")
     for f in sorted(HERE.glob("*.pt")):
         print(f"{f.name}: {f.stat().st_size / 1024:.0f} KiB")
 

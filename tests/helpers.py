@@ -14,7 +14,7 @@ def granularity_of(spec):
     if kind == "tensor":
         return ff.PerTensor()
     if kind == "channel":
-        return ff.PerChannel(tuple(spec[1]))
+        return ff.PerChannel(tuple(spec[1]) if isinstance(spec[1], (list, tuple)) else spec[1])
     if kind == "block":
         return ff.PerBlock(block_dims=tuple(spec[1]), block_sizes=tuple(spec[2]), per_channel_dims=tuple(spec[3]))
     if kind == "tile":

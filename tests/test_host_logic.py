@@ -454,3 +454,77 @@ def test_no_cpu_fallback_in_the_product(hip_lib):
             ff.quantization.affine.quantize_per_tensor(torch.randn(4), 0.1, None, 8)
         with pytest.raises(BackendError):
             ff.ops.minmax_by_tile(torch.randn(4), (4,))
+
+
+def test_fuse_qdq_weights_snaps_weights_and_is_idempotent(oracle_backend):
+    """Reference quantization/fuse.py:199-242 and its tests (tests/quantization/test_fuse.py): weights become their QDQ
+    values, re-quantizing them is a no-op, stubbing removes the weight quantizers, tied weights must agree on the grid."""
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(32, 16), torch.nn.Linear(16, 8))
+    ff.quantize_model(model)
+    for layer in (model[0], model[1]):
+        layer.weight_quantizer = ff.nn.LinearQuantizer(4, granularity=ff.PerChannel(0))
+    with ff.estimate_ranges(model, ff.range_setting.running_minmax), ff.strict_quantization(False):
+        model(torch.randn(4, 32))
+    with ff.strict_quantization(False):
+        want = [layer.weight_quantizer(layer.weight).dequantize().clone() for layer in (model[0], model[1])]
+        before = model(torch.ones(2, 32))
+    targets = ff.quantization.find_weight_quantizers(model)
+    assert [t[1] for t in targets] == ["weight", "weight"] and len(targets) == 2
+    ff.quantization.fuse_qdq_weights(model)
+    for layer, w in zip((model[0], model[1]), want):
+        assert torch.equal(layer.weight, w)
+        with ff.strict_quantization(False):
+            assert torch.equal(layer.weight_quantizer(layer.weight).dequantize(), w)  # idempotent
+    with ff.strict_quantization(False):
+        assert torch.equal(model(torch.ones(2, 32)), before)
+    ff.quantization.fuse_qdq_weights(model, stub_quantizers=True)
+    assert model[0].weight_quantizer.is_stub() and model[1].weight_quantizer.is_stub()
+    assert ff.quantization.find_weight_quantizers(model) == []
+    # tied weight, two different grids
+    a, b = torch.nn.Linear(8, 8, bias=False), torch.nn.Linear(8, 8, bias=False)
+    b.weight = a.weight
+    tied = torch.nn.Sequential(a, b)
+    ff.quantize_model(tied)
+    tied[0].weight_quantizer = ff.nn.LinearQuantizer(8)
+    tied[1].weight_quantizer = ff.nn.LinearQuantizer(2)
+    for q in (tied[0].weight_quantizer, tied[1].weight_quantizer):
+        q.quantization_range = (torch.tensor(-1.0), torch.tensor(1.0))
+    with pytest.raises(ff.exceptions.QuantizationError, match="tied"):
+        ff.quantization.fuse_qdq_weights(tied)
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+@pytest.mark.parametrize("negative_data", [True, False])
+def test_uniform_search_grid(symmetric, negative_data):
+    """Reference tests/range_setting/test_minerror.py:59-82."""
+    from fastforward_amd.range_setting.min_error import _UniformSearchGrid
+
+    data = torch.rand((5, 7))
+    if negative_data:
+        data = data - 0.5
+    lo, hi = _UniformSearchGrid()(data, symmetric=symmetric, parameter_dimensionality=5, num_candidates=3)
+    assert lo.shape == (3, 5) and hi.shape == (3, 5) and bool((lo < hi).all())
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+@pytest.mark.parametrize("negative_data", [True, False])
+@pytest.mark.parametrize("gran", [ff.PerChannel(0), ff.PerChannel(-1), ff.PerTensor(), ff.PerTile((12, 16))], ids=str)
+@pytest.mark.parametrize("custom_error", [False, True])
+def test_mse_grid_error_decreases_with_a_finer_grid(oracle_backend, symmetric, negative_data, gran, custom_error):
+    """Reference tests/range_setting/test_minerror.py:14-56, for the one-pass kernel path and for the
+    candidate-by-candidate loop a custom error function takes."""
+    from fastforward_amd.range_setting.min_error import mse_error
+
+    torch.manual_seed(3)
+    data = torch.randn(24, 16)
+    if not negative_data:
+        data = data.abs()
+    quantizer = ff.nn.LinearQuantizer(8, granularity=gran, symmetric=symmetric)
+    error_fn = (lambda a, b: mse_error(a, b)) if custom_error else mse_error
+    errors = []
+    for n in (9, 81):
+        with ff.estimate_ranges(quantizer, ff.range_setting.mse_grid, num_candidates=n, error_fn=error_fn):
+            quantizer(data)
+        errors.append(float(torch.sum((quantizer(data).dequantize() - data) ** 2)))
+    assert errors[0] >= errors[1]

@@ -53,3 +53,7 @@ def test_fused_producers_rmsnorm_silu_rope():
 
 def test_quantize_by_tile_backward():
     parity_cases.check_backward("cpu")
+
+
+def test_mse_grid_range_estimator():
+    parity_cases.check_mse_grid("cpu")

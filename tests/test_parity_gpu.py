@@ -73,6 +73,10 @@ def test_quantize_by_tile_backward():
     parity_cases.check_backward(DEV)
 
 
+def test_mse_grid_range_estimator():
+    parity_cases.check_mse_grid(DEV)
+
+
 def test_golden_sweeps_with_ieee_division_kernels(monkeypatch):
     """FFQ_DIV_MODE is read once per process; the generic kernels always use the IEEE sequence."""
     monkeypatch.setenv("FFQ_FORCE_GENERIC", "1")
@@ -469,3 +473,24 @@ def test_full_size_w4_fused_pack_paths():
     deq = ops.unpack_dequantize_int4(packed, scale, w.shape, tile, offset, block=128)
     assert torch.equal(deq, ops.dequantize_by_tile(ops.unpack_int4(packed, w.shape, torch.int8, block=128), scale, tile, offset, torch.bfloat16))
     assert torch.equal(ops.quantize_pack_int4(deq, scale, tile, offset, block=128), packed)
+
+
+# ---- min-error grid: fused kernel vs the candidate-by-candidate loop -------------------------------------
+@pytest.mark.parametrize("shape,gran,symmetric", [((4096, 4096), ff.PerChannel(0), True), ((4, 512, 4096), ff.PerTensor(), False), ((1024, 1024), ff.PerBlock(1, 128, 0), True)], ids=str)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_grid_sqerror_kernel_matches_candidate_loop(shape, gran, symmetric, dtype):
+    from fastforward_amd.range_setting.min_error import _MinAvgErrorGridEstimator, mse_error
+
+    torch.manual_seed(11)
+    x = torch.randn(shape, device=DEV).to(dtype)
+    results = []
+    for fused in (True, False):
+        q = ff.nn.LinearQuantizer(4, granularity=gran, symmetric=symmetric, device=DEV)
+        error_fn = mse_error if fused else (lambda a, b: mse_error(a, b))  # a different callable forces the reference loop
+        with ff.estimate_ranges(q, ff.range_setting.mse_grid, num_candidates=12, error_fn=error_fn):
+            est = next(o for o in q.overrides if isinstance(o, _MinAvgErrorGridEstimator))
+            q(x)
+            assert est.used_fused_kernel == fused
+            results.append(est.cumulative_error.float().clone())
+    rtol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    torch.testing.assert_close(results[0], results[1], rtol=rtol, atol=1e-12)
