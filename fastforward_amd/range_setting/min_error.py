@@ -127,7 +127,10 @@ class _MinAvgErrorGridEstimator(SimpleEstimatorStep, torch.nn.Module):
         needed = ("num_bits", "symmetric", "allow_one_sided", "granularity")
         if self.error_fn is not mse_error or not all(hasattr(quantizer, n) for n in needed) or not hasattr(quantizer, "_parameters_for_range"):
             return None
-        n_cand, n_tiles = self.min_threshold.shape
+        # The reference evaluates candidates range(num_candidates) (:219) although the asymmetric grid holds
+        # floor(sqrt(n)) * (floor(sqrt(n)) + n - floor(sqrt(n))**2) rows — more than n unless n is a perfect square;
+        # rows past num_candidates keep a cumulative error of 0. Same here.
+        n_cand, n_tiles = min(self.num_candidates, self.min_threshold.shape[0]), self.min_threshold.shape[1]
         device = self.min_threshold.device
         scales = torch.empty((n_cand, n_tiles), dtype=torch.float32, device=device)
         offsets = torch.empty((n_cand, n_tiles), dtype=torch.float32, device=device)
@@ -151,7 +154,7 @@ class _MinAvgErrorGridEstimator(SimpleEstimatorStep, torch.nn.Module):
             return False
         tile_numel = data.numel() // params[0].shape[1]
         err = (sums / tile_numel).to(self.cumulative_error.dtype)  # torch.mean: fp32 accumulation, result in the data dtype
-        self.cumulative_error += err
+        self.cumulative_error[: err.shape[0]] += err
         return True
 
     def estimate_step(self, quantizer: Any, data: torch.Tensor) -> None:
