@@ -82,14 +82,15 @@ def pmc_traffic(*needles: str) -> tuple[float | None, str | None]:
     prescribes). bench.py cannot run rocprofv3 on itself, so this is a lookup, labelled with its source."""
     import glob
 
-    reads = sorted(glob.glob(str(ROOT / "profiles" / "*_pmc_FETCH_SIZE.json")))
-    writes = sorted(glob.glob(str(ROOT / "profiles" / "*_pmc_WRITE_SIZE.json")))
-    if not reads or not writes:
-        return None, None
-    r, w = json.load(open(reads[-1])), json.load(open(writes[-1]))
-    for name, row in r.items():
-        if all(n in name for n in needles) and name in w:
-            return float(row["hbm_read_bytes"] + w[name]["hbm_write_bytes"]), pathlib.Path(reads[-1]).name.split("_pmc_")[0]
+    for stem in ("_pmc_", "_pmc_hbm_"):
+        reads = sorted(glob.glob(str(ROOT / "profiles" / f"*{stem}FETCH_SIZE.json")))
+        writes = sorted(glob.glob(str(ROOT / "profiles" / f"*{stem}WRITE_SIZE.json")))
+        if not reads or not writes:
+            continue
+        r, w = json.load(open(reads[-1])), json.load(open(writes[-1]))
+        for name, row in r.items():
+            if all(n in name for n in needles) and name in w:
+                return float(row["hbm_read_bytes"] + w[name]["hbm_write_bytes"]), pathlib.Path(reads[-1]).name.split("_pmc_")[0]
     return None, None
 
 
