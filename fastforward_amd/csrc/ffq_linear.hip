@@ -18,6 +18,7 @@
 // owning 64 x 64 = 2 x 2 MFMA tiles; double-buffered LDS with a 16-byte-slot XOR swizzle
 // (slot ^= (row >> 2) & 3) that makes every ds_read_b128 lane group hit 16 distinct slots.
 // blockIdx is remapped so that consecutive tiles of one weight panel stay on one XCD's L2.
+#include "ffq_affine.h"
 #include "ffq_common.h"
 #include "ffq_vec.h"
 
@@ -47,6 +48,8 @@ struct LinearArgs {
   int x_per_row, w_per_row;
   int M, N, K;
   int tiles_m, tiles_n;
+  // MLP mode of the v3 kernel (gate and up projections in one launch): the second weight matrix
+  const int8_t* wq2; const float* w_scale2; const int32_t* rowsum_w2;
   int debug;  // FFQ_GEMM_DEBUG ablation bits (tools/gemm_time.py): 1 = no global stores, 2 = no epilogue at all.
               // Measured: sc1 / nt / sc0 sc1 policies on the output stores change nothing (the store burst is HBM-write-bound).
 };
@@ -545,6 +548,81 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
   gemm256_epilogue<TOut, REQUANT, WOFF, NW>(a, acc, rsw, rsx_acc, lds2, wave, lane, wm, wn, m0, n0);
 }
 
+// Epilogue of the MLP mode: acc[i][0] holds gate_proj and acc[i][1] up_proj for the SAME 32 output columns, so
+//   z = bf16(silu(bf16(gate))) * bf16(up)  (bf16),  codes = A1(z; out_scale, out_offset)
+// is formed in registers with exactly the roundings of the three-launch path (GEMM epilogue -> bf16 tensors ->
+// silu_mul_quantize_kernel), goes through ONE block-wide LDS tile [256][128 B] and leaves as full 128-byte lines
+// of int8 codes: a quarter of the bytes of one bf16 projection, instead of two.
+__device__ __forceinline__ void mlp_epilogue(const LinearArgs& a, v16i (&acc)[4][2], int (&rsw)[2], uint8_t* lds2, int wave,
+                                             int lane, int wm, int wn, int m0, int n0) {
+  constexpr int PITCH = 144;  // 128 B of codes + 16 B pad
+  const float sx = a.x_scale[0];
+  const float ox = a.x_offset ? rne(a.x_offset[0]) : 0.0f;
+  const float so = a.out_scale[0];
+  const float oo = a.out_offset ? rne(a.out_offset[0]) : 0.0f;
+  const Divider<1> div(so);
+  __syncthreads();  // every wave is done with the operand ring
+  // row sums of this lane's gate / up weight rows live in other lanes' registers: share them through LDS
+  float* rs_lds = reinterpret_cast<float*>(lds2 + 256 * PITCH) + wave * 64;
+  if (lane < 32) {
+    rs_lds[lane] = (float)rsw[0];
+    rs_lds[32 + lane] = (float)rsw[1];
+  }
+  const int g = lane >> 5;
+  const int col0 = n0 + wn * 32;  // this wave's 32 output columns
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cb = 8 * q + 4 * g;  // this lane's 4 columns: col0 + cb + (0..3)
+    float swg[4], swu[4], rsg[4], rsu[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = col0 + cb + t;  // N % 128 == 0: always inside
+      swg[t] = a.w_scale[n];
+      swu[t] = a.w_scale2[n];
+      rsg[t] = rs_lds[cb + t];
+      rsu[t] = rs_lds[32 + cb + t];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int c[4];
+#pragma unroll
+      for (int t = 0; t < 4; t += 2) {
+        float g0 = (sx * swg[t]) * ((float)acc[i][0][4 * q + t] + ox * rsg[t]);
+        float g1 = (sx * swg[t + 1]) * ((float)acc[i][0][4 * q + t + 1] + ox * rsg[t + 1]);
+        float u0 = (sx * swu[t]) * ((float)acc[i][1][4 * q + t] + ox * rsu[t]);
+        float u1 = (sx * swu[t + 1]) * ((float)acc[i][1][4 * q + t + 1] + ox * rsu[t + 1]);
+        uint32_t w = pack2<bf16_t>(g0, g1);  // the bf16 tensors the two projections would have written
+        g0 = __builtin_bit_cast(float, w << 16); g1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
+        w = pack2<bf16_t>(u0, u1);
+        u0 = __builtin_bit_cast(float, w << 16); u1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
+        float a0 = g0 / (1.0f + expf(-g0)), a1 = g1 / (1.0f + expf(-g1));  // ATen's silu in fp32
+        w = pack2<bf16_t>(a0, a1);
+        a0 = __builtin_bit_cast(float, w << 16); a1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
+        float z0 = a0 * u0, z1 = a1 * u1;
+        w = pack2<bf16_t>(z0, z1);
+        z0 = __builtin_bit_cast(float, w << 16); z1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
+        const float r0 = div.safe ? rne(div.fast(z0) - oo) : rne(z0 / so - oo);
+        const float r1 = div.safe ? rne(div.fast(z1) - oo) : rne(z1 / so - oo);
+        int c0 = (int)r0, c1 = (int)r1;  // v_cvt_i32_f32: NaN -> 0, the int8 container's value
+        const int lo = (int)a.out_lo, hi = (int)a.out_hi;
+        c[t] = c0 < lo ? lo : (c0 > hi ? hi : c0);
+        c[t + 1] = c1 < lo ? lo : (c1 > hi ? hi : c1);
+      }
+      const int row = wm * 128 + i * 32 + (lane & 31);
+      *reinterpret_cast<uint32_t*>(lds2 + row * PITCH + wn * 32 + cb) = pack_bytes(c[0], c[1], c[2], c[3]);
+    }
+  }
+  __syncthreads();
+  int8_t* out = static_cast<int8_t*>(a.out);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = wave * 32 + t * 8 + (lane >> 3), seg = lane & 7;
+    const int m = m0 + row;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(lds2 + row * PITCH + seg * 16);
+    if (m < a.M && !(a.debug & 1)) *reinterpret_cast<u32x4*>(out + (size_t)m * a.N + n0 + seg * 16) = v;
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // v3 ("ping-pong"): same 256 x 256 x 64 tile, operand image, swizzle and epilogue as v2, different
 // K-loop. v2 lets every wave interleave its own ds_reads, LDS-DMA issues and v_dot4 row sums with its
@@ -572,9 +650,10 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
 // WAR: read retired -> barrier -> DMA issue).
 constexpr int STAGES3 = 4;
 
-template <typename TOut, bool REQUANT, bool WOFF>
+template <typename TOut, bool REQUANT, bool WOFF, bool MLP = false>
 __global__ __launch_bounds__(512, 2) void w8a8_gemm256pp_kernel(LinearArgs a) {
   constexpr int NW = 8, BN2 = 256, WAVES_N = 4;
+  constexpr int BN_OUT = MLP ? 128 : 256;  // output columns per block (MLP: 128 gate rows + 128 up rows in the B tile)
   constexpr int A_BYTES = BM2 * BK2;
   constexpr int OPER_BYTES2 = A_BYTES;
   constexpr int STAGE_BYTES2 = (BM2 + BN2) * BK2;  // 32 KiB
@@ -589,7 +668,7 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256pp_kernel(LinearArgs a) {
   const uint32_t group_rows = min((uint32_t)GROUP_M2, (uint32_t)a.tiles_m - group * GROUP_M2);
   const int tm = (int)(group * GROUP_M2 + in_group % group_rows);
   const int tn = (int)(in_group / group_rows);
-  const int m0 = tm * BM2, n0 = tn * BN2;
+  const int m0 = tm * BM2, n0 = tn * BN_OUT;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -605,9 +684,17 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256pp_kernel(LinearArgs a) {
     int ra = m0 + (wave * 2 + c) * 16 + d_row;
     ra = ra < a.M ? ra : a.M - 1;
     a_src[c] = a.xq + (size_t)ra * a.K + d_slot * 16;
-    int rb = n0 + (wave * 2 + c) * 16 + d_row;
-    rb = rb < a.N ? rb : a.N - 1;
-    b_src[c] = a.wq + (size_t)rb * a.K + d_slot * 16;
+    if constexpr (MLP) {
+      // B-tile rows [64 wn', 64 wn' + 32) are gate rows n0 + 32 wn' + (0..31), the next 32 the same rows of up
+      const int chunk = wave * 2 + c;           // 16-row chunk of the B tile
+      const int within = (chunk & 3) * 16;      // row inside the wave-column's 64 rows
+      const int rb = n0 + (chunk >> 2) * 32 + (within & 31) + d_row;
+      b_src[c] = (within < 32 ? a.wq : a.wq2) + (size_t)rb * a.K + d_slot * 16;
+    } else {
+      int rb = n0 + (wave * 2 + c) * 16 + d_row;
+      rb = rb < a.N ? rb : a.N - 1;
+      b_src[c] = a.wq + (size_t)rb * a.K + d_slot * 16;
+    }
   }
   const int last_tile = a.K / BK2 - 1;
   // Tiles past the end re-load the last tile into a stage nobody reads any more (constant vmcnt).
@@ -649,11 +736,16 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256pp_kernel(LinearArgs a) {
   // sum_k wq[n, k] of this lane's two weight rows (side kernel; only read when x has an offset)
   int rsw[2] = {0, 0};
   if (a.rowsum_w) {
+    if constexpr (MLP) {
+      rsw[0] = a.rowsum_w[n0 + wn * 32 + (lane & 31)];
+      rsw[1] = a.rowsum_w2[n0 + wn * 32 + (lane & 31)];
+    } else {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int n = n0 + wn * 64 + j * 32 + (lane & 31);
-      n = n < a.N ? n : a.N - 1;
-      rsw[j] = a.rowsum_w[n];
+      for (int j = 0; j < 2; ++j) {
+        int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        n = n < a.N ? n : a.N - 1;
+        rsw[j] = a.rowsum_w[n];
+      }
     }
   }
 
@@ -743,7 +835,8 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256pp_kernel(LinearArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) rsx_acc[i] += __shfl_xor(rsx_acc[i], 32, 64);
   }
-  gemm256_epilogue<TOut, REQUANT, WOFF, NW>(a, acc, rsw, rsx_acc, lds2, wave, lane, wm, wn, m0, n0);
+  if constexpr (MLP) mlp_epilogue(a, acc, rsw, lds2, wave, lane, wm, wn, m0, n0);
+  else gemm256_epilogue<TOut, REQUANT, WOFF, NW>(a, acc, rsw, rsx_acc, lds2, wave, lane, wm, wn, m0, n0);
 }
 
 // one wavefront per row: sum of K int8 codes
@@ -807,6 +900,7 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
   a.x_scale = x_scale; a.x_offset = x_offset;
   a.w_scale = w_scale; a.w_offset = w_offset;
   a.rowsum_x = nullptr; a.rowsum_w = nullptr;
+  a.wq2 = nullptr; a.w_scale2 = nullptr; a.rowsum_w2 = nullptr;
   a.bias = bias; a.bias_dt = bias_dt;
   a.out = out; a.out_dt = out_dt;
   a.out_scale = out_scale; a.out_offset = out_offset;
@@ -936,4 +1030,60 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
     }
   }
   return check_launch("w8a8_gemm_kernel");
+}
+
+// ---- gate_proj + up_proj + SiLU * up + the down_proj input quantizer in one launch -----------------------------
+extern "C" size_t ffq_mlp_gate_up_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  (void)M; (void)K;
+  if (N < 0) return 0;
+  return (size_t)((2 * N * 4 + 255) & ~(int64_t)255);
+}
+
+extern "C" int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const float* x_scale,
+                                    const float* x_offset, const float* gate_w_scale, const float* up_w_scale,
+                                    int8_t* codes_out, const float* out_scale, const float* out_offset, double out_num_bits,
+                                    int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (M == 0 || N == 0) return FFQ_OK;
+  if (!xq || !gate_wq || !up_wq || !x_scale || !gate_w_scale || !up_w_scale || !codes_out || !out_scale)
+    return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return fail(FFQ_ERR_ARG, "extent exceeds 2^31");
+  if (N % 128 != 0 || K % BK2 != 0 || K / BK2 < 4 || !aligned16(xq) || !aligned16(gate_wq) || !aligned16(up_wq) || !aligned16(codes_out))
+    return fail(FFQ_ERR_DTYPE, "fused gate/up kernel needs N %% 128 == 0, K %% 64 == 0, K >= 256 and 16-byte aligned buffers");
+  if (!(out_num_bits >= 1 && out_num_bits <= 8 && out_num_bits == floor(out_num_bits)))
+    return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.", FFQ_I8, out_num_bits);
+  const size_t need = ffq_mlp_gate_up_w8a8_workspace_bytes(M, N, K);
+  if (x_offset && (need > workspace_bytes || !workspace)) return fail(FFQ_ERR_WORKSPACE, "fused gate/up needs %zu workspace bytes, got %zu", need, workspace_bytes);
+  LinearArgs a;
+  a.xq = xq; a.wq = gate_wq; a.wq2 = up_wq;
+  a.x_scale = x_scale; a.x_offset = x_offset;
+  a.w_scale = gate_w_scale; a.w_scale2 = up_w_scale; a.w_offset = nullptr;
+  a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.rowsum_w2 = nullptr;
+  a.bias = nullptr; a.bias_dt = 0;
+  a.out = codes_out; a.out_dt = FFQ_I8;
+  a.out_scale = out_scale; a.out_offset = out_offset;
+  const double lo = -pow(2.0, out_num_bits - 1.0);
+  a.out_lo = (float)lo; a.out_hi = (float)(-lo - 1.0);
+  a.x_per_row = 0; a.w_per_row = 1;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.tiles_m = (int)((M + BM2 - 1) / BM2);
+  a.tiles_n = (int)(N / 128);
+  static const int debug_bits = getenv("FFQ_GEMM_DEBUG") ? atoi(getenv("FFQ_GEMM_DEBUG")) : 0;
+  a.debug = debug_bits;
+  if (x_offset) {
+    int32_t* ws = static_cast<int32_t*>(workspace);
+    rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(gate_wq, (int)N, (int)K, ws);
+    rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(up_wq, (int)N, (int)K, ws + N);
+    a.rowsum_w = ws; a.rowsum_w2 = ws + N;
+  }
+  const size_t lds = (size_t)STAGES3 * (BM2 + 256) * BK2;  // the ring (128 KiB) also holds the 36 KiB output tile
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256pp_kernel<int8_t, true, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  w8a8_gemm256pp_kernel<int8_t, true, false, true><<<(unsigned)(a.tiles_m * a.tiles_n), 512, lds, s>>>(a);
+  return check_launch("w8a8_gemm256pp_kernel<mlp>");
 }

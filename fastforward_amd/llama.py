@@ -323,12 +323,16 @@ class FusedForward:
     per-channel activations, biases — instead of silently computing something else.
     """
 
-    def __init__(self, model: LlamaModel, cache_weight_codes: bool = False) -> None:
+    def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True) -> None:
         problems = self.unsupported(model)
         if problems:
             raise ff.exceptions.QuantizationError("FusedForward cannot run this model: " + "; ".join(problems[:4]))
         self.model = model
         self.cache_weight_codes = cache_weight_codes
+        # gate_proj + up_proj + SiLU*up + the down_proj input quantizer in one launch (ops.mlp_gate_up_w8a8) where
+        # both projections see the same activation codes and carry symmetric (zero-offset) weight quantizers
+        self.fuse_mlp = fuse_mlp
+        self._zero_offset: dict[int, tuple[int, bool]] = {}
         self._weight_cache: dict[int, tuple[tuple[int, int, int], torch.Tensor]] = {}
         # when set to a list, every quantized linear appends (N, K, start event, end event): bench.py times the
         # GEMM launches of a real forward (real code distributions) with it
@@ -341,6 +345,8 @@ class FusedForward:
                 "qkv": self._distinct([attn.q_proj, attn.k_proj, attn.v_proj]),
                 "gate_up": self._distinct([mlp.gate_proj, mlp.up_proj]),
             })
+            if fuse_mlp:  # host reads happen here, never inside a (possibly graph-captured) forward
+                self._symmetric_weights(mlp.gate_proj), self._symmetric_weights(mlp.up_proj)
 
     @staticmethod
     def _params(linear: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor | None]:
@@ -396,6 +402,18 @@ class FusedForward:
             if linear.bias is not None:
                 problems.append(f"{name}: bias")
         return problems
+
+    def _symmetric_weights(self, linear: torch.nn.Module) -> bool:
+        """True if the weight quantizer's offset is absent or all zero — one host read per offset version (the offset of
+        a symmetric quantizer is a zero buffer unless its weights are one-sided)."""
+        offset = linear.weight_quantizer.offset
+        if offset is None:
+            return True
+        hit = self._zero_offset.get(id(linear))
+        if hit is None or hit[0] != offset._version:
+            hit = (offset._version, not bool(offset.any()))
+            self._zero_offset[id(linear)] = hit
+        return hit[1]
 
     def _weight(self, linear: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None]:
         """(int8 codes, scale, offset) of the linear's weight — A1 through the quantizer's own forward."""
@@ -453,10 +471,17 @@ class FusedForward:
                 hidden, attn_out, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon,
                 pairs, mlp.gate_proj.input_quantizer.num_bits, sum_inplace=True,
             )
-            gate = self._linear(codes[index[0]], mlp.gate_proj)
-            up = self._linear(codes[index[1]], mlp.up_proj)
             d_in = mlp.down_proj.input_quantizer
-            _, (d_codes,) = ff.ops.silu_mul_quantize(gate, up, [(d_in.scale, d_in.offset)], d_in.num_bits)
+            d_codes = None
+            if self.fuse_mlp and index[0] == index[1] and self._symmetric_weights(mlp.gate_proj) and self._symmetric_weights(mlp.up_proj):
+                g_codes, g_scale, _ = self._weight(mlp.gate_proj)
+                u_codes, u_scale, _ = self._weight(mlp.up_proj)
+                x_scale, x_offset = self._params(mlp.gate_proj)
+                d_codes = ff.ops.mlp_gate_up_w8a8(codes[index[0]], g_codes, u_codes, x_scale, x_offset, g_scale, u_scale, d_in.scale, d_in.offset, d_in.num_bits)
+            if d_codes is None:
+                gate = self._linear(codes[index[0]], mlp.gate_proj)
+                up = self._linear(codes[index[1]], mlp.up_proj)
+                _, (d_codes,) = ff.ops.silu_mul_quantize(gate, up, [(d_in.scale, d_in.offset)], d_in.num_bits)
             pending = self._linear(d_codes, mlp.down_proj)
         _, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, model.norm.weight, model.norm.variance_epsilon, (), want_sum=False, want_norm=True)
         if not logits:

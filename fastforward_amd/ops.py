@@ -34,6 +34,7 @@ __all__ = [
     "unpack_dequantize_int4",
     "grid_sqerror_by_tile",
     "linear_w8a8",
+    "mlp_gate_up_w8a8",
     "add_rmsnorm_quantize",
     "silu_mul_quantize",
     "rope_",
@@ -532,6 +533,55 @@ def linear_w8a8(
             _ptr(os_), _ptr(oo), float(out_num_bits), M, N, K, _ptr(ws), nbytes, stream,
         )
     )
+    return out
+
+
+def mlp_gate_up_w8a8(
+    x_codes: torch.Tensor,
+    gate_codes: torch.Tensor,
+    up_codes: torch.Tensor,
+    x_scale: torch.Tensor,
+    x_offset: torch.Tensor | None,
+    gate_scale: torch.Tensor,
+    up_scale: torch.Tensor,
+    out_scale: torch.Tensor,
+    out_offset: torch.Tensor | None,
+    out_num_bits: float = 8.0,
+) -> torch.Tensor | None:
+    """gate_proj + up_proj + ``silu(gate) * up`` + the down_proj input quantizer in ONE launch (reference
+    quantized_llama/mlp.py:30-40): int8 codes of the product, equal to
+    ``silu_mul_quantize(linear_w8a8(x, gate), linear_w8a8(x, up))`` exactly. Per-tensor activation parameters,
+    per-output-channel symmetric weights. Returns None when the shapes are outside the kernel's range."""
+    xc, gc, uc = x_codes.detach().contiguous(), gate_codes.detach().contiguous(), up_codes.detach().contiguous()
+    if not (xc.dtype == gc.dtype == uc.dtype == torch.int8) or gc.shape != uc.shape or gc.dim() != 2:
+        raise TypeError("mlp_gate_up_w8a8 expects int8 codes and equally shaped gate / up weights")
+    K, N = xc.shape[-1], gc.shape[0]
+    M = xc.numel() // K if K else 0
+    if gc.shape[1] != K:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({M}x{K} and {tuple(gc.shape)}^T)")
+    if N % 128 or K % 64 or K < 256:
+        return None
+
+    def f32(t: torch.Tensor | None, n: int) -> torch.Tensor | None:
+        if t is None:
+            return None
+        t = t.detach().reshape(-1).to(torch.float32).contiguous()
+        if t.numel() != n:
+            raise RuntimeError(f"expected {n} parameter entries, got {t.numel()}")
+        return t
+
+    xs, xo, gs, us, os_, oo = f32(x_scale, 1), f32(x_offset, 1), f32(gate_scale, N), f32(up_scale, N), f32(out_scale, 1), f32(out_offset, 1)
+    lib, stream = _prepare(xc, gc, uc, xs, xo, gs, us, os_, oo)
+    out = torch.empty((*xc.shape[:-1], N), dtype=torch.int8, device=xc.device)
+    nbytes = lib.ffq_mlp_gate_up_w8a8_workspace_bytes(M, N, K)
+    ws = _workspace(nbytes, xc.device)
+    status = lib.ffq_mlp_gate_up_w8a8(
+        _ptr(xc), _ptr(gc), _ptr(uc), _ptr(xs), _ptr(xo), _ptr(gs), _ptr(us), _ptr(out), _ptr(os_), _ptr(oo),
+        float(out_num_bits), M, N, K, _ptr(ws), nbytes, stream,
+    )
+    if status == 6:
+        return None
+    lib.check(status)
     return out
 
 

@@ -287,6 +287,21 @@ int ffq_grid_sqerror_by_tile(const void* data, int dt, const float* scales, cons
                              const ffq_tiling* tiling, double num_bits, float* err, int accumulate, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/*
+ * The MLP front half of the reference's quantized Llama (docs/examples/doc_helpers/quantized_llama/mlp.py:30-40)
+ * in ONE launch: gate_proj and up_proj (two A6 linears on the same activation codes), SiLU(gate) * up, and the
+ * input quantizer of down_proj (nn/linear.py:33):
+ *   codes = A1( bf16(silu(bf16(gate_linear(x)))) * bf16(up_linear(x)) ;  out_scale, out_offset )
+ * == ffq_silu_mul_quantize(ffq_linear_w8a8(x, gate -> bf16), ffq_linear_w8a8(x, up -> bf16)) exactly, without the two
+ * bf16 projections ever visiting HBM. x: per-tensor (scale, offset); weights: per-output-channel scales, no offset
+ * (symmetric); N % 128 == 0, K % 64 == 0, K >= 256.
+ */
+size_t ffq_mlp_gate_up_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const float* x_scale,
+                         const float* x_offset, const float* gate_w_scale, const float* up_w_scale,
+                         int8_t* codes_out, const float* out_scale, const float* out_offset, double out_num_bits,
+                         int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

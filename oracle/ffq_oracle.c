@@ -939,3 +939,28 @@ int ffq_grid_sqerror_by_tile(const void* data, int dt, const float* scales, cons
   free(acc);
   return FFQ_OK;
 }
+
+/* mlp.py:30-40 composed from the restatements above: two A6 linears (bf16 outputs), SiLU * up, A1 */
+size_t ffq_mlp_gate_up_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K) { (void)K; return ffq_linear_w8a8_workspace_bytes(M, N, 0); }
+
+int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const float* x_scale,
+                         const float* x_offset, const float* gate_w_scale, const float* up_w_scale,
+                         int8_t* codes_out, const float* out_scale, const float* out_offset, double out_num_bits,
+                         int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (M == 0 || N == 0) return FFQ_OK;
+  if (N % 128 != 0 || K % 64 != 0 || K / 64 < 4)
+    return fail(FFQ_ERR_DTYPE, "fused gate/up kernel needs N %% 128 == 0, K %% 64 == 0, K >= 256 and 16-byte aligned buffers");
+  uint16_t* g = (uint16_t*)malloc((size_t)M * N * 2);
+  uint16_t* u = (uint16_t*)malloc((size_t)M * N * 2);
+  int rc = ffq_linear_w8a8(xq, gate_wq, x_scale, x_offset, 0, gate_w_scale, NULL, 1, NULL, 0, g, FFQ_BF16, NULL, NULL, 8.0, M, N, K, workspace, workspace_bytes, stream);
+  if (!rc) rc = ffq_linear_w8a8(xq, up_wq, x_scale, x_offset, 0, up_w_scale, NULL, 1, NULL, 0, u, FFQ_BF16, NULL, NULL, 8.0, M, N, K, workspace, workspace_bytes, stream);
+  if (!rc) {
+    ffq_fanout fan;
+    memset(&fan, 0, sizeof fan);
+    fan.count = 1; fan.num_bits = out_num_bits; fan.scale[0] = out_scale; fan.offset[0] = out_offset; fan.codes[0] = codes_out;
+    rc = ffq_silu_mul_quantize(g, u, FFQ_BF16, M * N, NULL, &fan, stream);
+  }
+  free(g); free(u);
+  return rc;
+}

@@ -123,6 +123,8 @@ def check_fused_against_module_graph(fixture, device):
     err, spread = got - want, float(want.std())
     # same integer arithmetic, same bf16 roundings; only the fp32 summation order inside RMSNorm differs
     assert float(err.pow(2).mean().sqrt()) < 0.01 * spread and float(err.abs().max()) < 0.25 * spread
+    # the MLP front half in one launch is the same arithmetic as gate GEMM, up GEMM and the SiLU*up producer
+    assert torch.equal(llama.FusedForward(model, fuse_mlp=False)(ids).float().cpu(), got)
     cached = llama.FusedForward(model, cache_weight_codes=True)
     assert torch.equal(cached(ids).float().cpu(), got) and torch.equal(cached(ids).float().cpu(), got)
     with torch.no_grad():  # a changed weight invalidates its cached codes

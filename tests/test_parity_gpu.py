@@ -494,3 +494,43 @@ def test_grid_sqerror_kernel_matches_candidate_loop(shape, gran, symmetric, dtyp
             results.append(est.cumulative_error.float().clone())
     rtol = 2e-2 if dtype == torch.bfloat16 else 1e-5
     torch.testing.assert_close(results[0], results[1], rtol=rtol, atol=1e-12)
+
+
+# ---- gate_proj + up_proj + SiLU*up + quantize in one launch ------------------------------------------------------
+@pytest.mark.parametrize("m,n,k", [(256, 128, 256), (300, 256, 512), (1000, 896, 256), (2048, 1024, 4096), (77, 384, 1024)])
+@pytest.mark.parametrize("x_off", [True, False])
+def test_fused_gate_up_equals_three_launch_path(m, n, k, x_off):
+    gen = torch.Generator().manual_seed(m * 7 + n + k)
+    xq = torch.randint(-128, 128, (m, k), generator=gen, dtype=torch.int8).to(DEV)
+    gq = torch.randint(-128, 128, (n, k), generator=gen, dtype=torch.int8).to(DEV)
+    uq = torch.randint(-128, 128, (n, k), generator=gen, dtype=torch.int8).to(DEV)
+    sx = torch.tensor([0.011], device=DEV)
+    ox = torch.tensor([-3.0], device=DEV) if x_off else None
+    sg = (torch.rand(n, generator=gen) * 2e-4 + 1e-4).to(DEV)
+    su = (torch.rand(n, generator=gen) * 2e-4 + 1e-4).to(DEV)
+    so, oo = torch.tensor([0.02], device=DEV), torch.tensor([5.0], device=DEV)
+    fused = ops.mlp_gate_up_w8a8(xq, gq, uq, sx, ox, sg, su, so, oo, 8)
+    gate = ops.linear_w8a8(xq, gq, sx, ox, sg, None, out_dtype=torch.bfloat16)
+    up = ops.linear_w8a8(xq, uq, sx, ox, su, None, out_dtype=torch.bfloat16)
+    _, (want,) = ops.silu_mul_quantize(gate, up, [(so, oo)], 8)
+    assert fused is not None and torch.equal(fused, want), f"{int((fused != want).sum())} of {want.numel()} codes differ"
+    assert int(want.float().std()) > 0  # the comparison is not about a saturated tensor
+
+
+def test_fused_gate_up_at_llama_size_and_in_the_forward():
+    torch.manual_seed(21)
+    t, n, k = 8 * 2048, 14336, 4096
+    xq = torch.randint(-128, 128, (t, k), device=DEV, dtype=torch.int8)
+    gq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8)
+    uq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8)
+    sx, ox = torch.tensor([0.02], device=DEV), torch.tensor([4.0], device=DEV)
+    sg = torch.rand(n, device=DEV) * 1e-5 + 2e-5
+    su = torch.rand(n, device=DEV) * 1e-5 + 2e-5
+    so, oo = torch.tensor([0.004], device=DEV), torch.tensor([-9.0], device=DEV)
+    fused = ops.mlp_gate_up_w8a8(xq, gq, uq, sx, ox, sg, su, so, oo, 8)
+    gate = ops.linear_w8a8(xq, gq, sx, ox, sg, None, out_dtype=torch.bfloat16)
+    up = ops.linear_w8a8(xq, uq, sx, ox, su, None, out_dtype=torch.bfloat16)
+    _, (want,) = ops.silu_mul_quantize(gate, up, [(so, oo)], 8)
+    assert torch.equal(fused, want)
+    assert 10 < float(want.float().std()) < 100
+    assert ops.mlp_gate_up_w8a8(xq[:, :192], gq[:, :192], uq[:, :192], sx, ox, sg, su, so, oo, 8) is None  # K < 256: not covered
