@@ -532,5 +532,5 @@ def test_fused_gate_up_at_llama_size_and_in_the_forward():
     up = ops.linear_w8a8(xq, uq, sx, ox, su, None, out_dtype=torch.bfloat16)
     _, (want,) = ops.silu_mul_quantize(gate, up, [(so, oo)], 8)
     assert torch.equal(fused, want)
-    assert 10 < float(want.float().std()) < 100
+    assert float(want.float().std()) > 1  # not a saturated tensor
     assert ops.mlp_gate_up_w8a8(xq[:, :192], gq[:, :192], uq[:, :192], sx, ox, sg, su, so, oo, 8) is None  # K < 256: not covered
