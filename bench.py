@@ -98,7 +98,9 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
     """The dominant kernel of the step: the int8 MFMA GEMM. Algorithmic ops per launch = 2*T*N*K.
 
     `achieved` comes from the launches of a REAL forward (the code distributions the timed steps see): one eager
-    forward with a HIP event pair around each of the 224 quantized linears, on the stream they are launched on.
+    forward with a HIP event pair around each int8 GEMM launch (192 per forward: q, k, v, o, down and the fused
+    gate+up launch, which contracts both weight matrices and carries the SiLU*up + quantize epilogue), on the stream
+    they are launched on.
     The event pair also covers the one-pass side kernel with the weight row sums (1 B/elem of the weight).
     `per_shape_uniform_random` repeats the measurement on uniform random int8 operands (hipGraph-replayed), the
     worst case for the chip's power management: the matrix pipe clocks lower on high-entropy data."""
@@ -125,12 +127,14 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
             for n, k, a, b in fused.linear_events:
                 samples.setdefault((n, k), []).append(a.elapsed_time(b))
             fused.linear_events = None
-        for name, (n, k, count) in shapes.items():
-            ms = statistics.mean(samples[(n, k)])
-            per_shape[name] = {"N": n, "K": k, "ms": round(ms, 4), "TOP/s": round(2.0 * tokens * n * k / ms / 1e9, 1), "launches_per_forward": len(samples[(n, k)]) // 2}
-            total_ops += len(samples[(n, k)]) * 2.0 * tokens * n * k
-            total_ms += sum(samples[(n, k)])
-            launches += len(samples[(n, k)])
+        names = {(h, h): "q/o_proj", (kv, h): "k/v_proj", (i, h): "gate/up_proj", (h, i): "down_proj",
+                 (2 * i, h): "gate_proj + up_proj + SiLU*up + quantize (one launch, both weight matrices)"}
+        for (n, k), times in samples.items():
+            ms = statistics.mean(times)
+            per_shape[names.get((n, k), f"{n}x{k}")] = {"N": n, "K": k, "ms": round(ms, 4), "TOP/s": round(2.0 * tokens * n * k / ms / 1e9, 1), "launches_per_forward": len(times) // 2}
+            total_ops += len(times) * 2.0 * tokens * n * k
+            total_ms += sum(times)
+            launches += len(times)
         source = "HIP events around every quantized linear of two eager forwards of the benchmarked model (real codes)"
     else:
         for name, (n, k, count) in shapes.items():
@@ -142,7 +146,7 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
     traffic, prof = pmc_traffic("w8a8_gemm256pp_kernel")
     return {
         "bound": "mfma",
-        "kernel": "w8a8_gemm256pp_kernel (v_mfma_i32_32x32x32_i8, 256x256x64 tiles, ping-pong wave groups) + rowsum_i8_kernel",
+        "kernel": "w8a8_gemm256pp_kernel (v_mfma_i32_32x32x32_i8, 256x256x64 tiles, ping-pong wave groups; plain and gate+up/SiLU-epilogue modes) + rowsum_i8_kernel",
         "achieved": round(achieved, 1),
         "peak": INT8_PEAK_TOPS,
         "unit": "TFLOP/s",

@@ -334,8 +334,8 @@ class FusedForward:
         self.fuse_mlp = fuse_mlp
         self._zero_offset: dict[int, tuple[int, bool]] = {}
         self._weight_cache: dict[int, tuple[tuple[int, int, int], torch.Tensor]] = {}
-        # when set to a list, every quantized linear appends (N, K, start event, end event): bench.py times the
-        # GEMM launches of a real forward (real code distributions) with it
+        # when set to a list, every int8 GEMM launch appends (output rows of weight processed, K, start event, end event)
+        # — the fused gate/up launch counts both matrices: bench.py times the GEMM launches of a real forward with it
         self.linear_events: list[tuple[int, int, torch.cuda.Event, torch.cuda.Event]] | None = None
         # One host comparison per layer, once: consumers of the same tensor usually hold the same range.
         self._fan: list[dict[str, tuple[list[tuple[torch.Tensor, torch.Tensor | None]], list[int]]]] = []
@@ -477,7 +477,13 @@ class FusedForward:
                 g_codes, g_scale, _ = self._weight(mlp.gate_proj)
                 u_codes, u_scale, _ = self._weight(mlp.up_proj)
                 x_scale, x_offset = self._params(mlp.gate_proj)
+                if self.linear_events is not None:
+                    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    start.record()
                 d_codes = ff.ops.mlp_gate_up_w8a8(codes[index[0]], g_codes, u_codes, x_scale, x_offset, g_scale, u_scale, d_in.scale, d_in.offset, d_in.num_bits)
+                if self.linear_events is not None and d_codes is not None:
+                    end.record()
+                    self.linear_events.append((2 * g_codes.shape[0], g_codes.shape[1], start, end))
             if d_codes is None:
                 gate = self._linear(codes[index[0]], mlp.gate_proj)
                 up = self._linear(codes[index[1]], mlp.up_proj)
