@@ -15,6 +15,11 @@ tot_ops = tot_ms = 0
 for name, n, k, cnt in (("qo", 4096, 4096, 2), ("kv", 1024, 4096, 2), ("gateup", 14336, 4096, 2), ("down", 4096, 14336, 1)):
     xq = torch.randint(-128, 128, (T, k), device=dev, dtype=torch.int8)
     wq = torch.randint(-128, 128, (n, k), device=dev, dtype=torch.int8)
+    if os.environ.get("GT_FILL") == "zero":
+        xq.zero_(); wq.zero_()
+    elif os.environ.get("GT_FILL") == "gauss":  # what real quantized weights / activations look like
+        xq = (torch.randn(T, k, device=dev) * 20).round().clamp(-128, 127).to(torch.int8)
+        wq = (torch.randn(n, k, device=dev) * 30).round().clamp(-128, 127).to(torch.int8)
     sx, ox = torch.tensor([0.02], device=dev), (None if os.environ.get("GT_NO_XOFF") else torch.tensor([4.0], device=dev))
     sw = torch.rand(n, device=dev) * 0.001 + 0.0005
     ms = event_time_ms(lambda r: ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.bfloat16), iters=5, reps=4)
