@@ -334,7 +334,8 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "int8 codes x int8 codes -> int32 (MFMA), fp32 scale epilogue, bf16 activations",
+        "dtype": "int8",
+        "dtype_note": "int8 codes x int8 codes -> int32 on the matrix cores, fp32 scale / zero-point epilogue; everything between the quantized linears in bf16 (fp32 math inside RMSNorm / SiLU / softmax), as the reference recipe",
         "data": "synthetic",
         "config": {
             "workload": f"{args.model} shapes, W8 per-channel symmetric + A8 per-tensor asymmetric on the 7 linears x {config.num_layers} layers "
