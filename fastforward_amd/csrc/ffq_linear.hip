@@ -839,6 +839,209 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256pp_kernel(LinearArgs a) {
   else gemm256_epilogue<TOut, REQUANT, WOFF, NW>(a, acc, rsw, rsx_acc, lds2, wave, lane, wm, wn, m0, n0);
 }
 
+// -------------------------------------------------------------------------------------------------
+// v3 with full-line staging ("fl"): the same ping-pong K-loop, but the LDS image holds 128 k-bytes per row
+// (two K-steps) in two 64 KiB slots, so every LDS-DMA instruction moves 8 whole 128-byte cache lines.
+// Needs K % 128 == 0.
+template <typename TOut, bool REQUANT, bool WOFF, bool MLP = false>
+__global__ __launch_bounds__(512, 2) void w8a8_gemm256fl_kernel(LinearArgs a) {
+  constexpr int NW = 8, BN2 = 256, WAVES_N = 4;
+  constexpr int BN_OUT = MLP ? 128 : 256;  // output columns per block (MLP: 128 gate rows + 128 up rows in the B tile)
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
+
+  const uint32_t nblk = gridDim.x;
+  const uint32_t xcd = blockIdx.x & 7u, slot_in_xcd = blockIdx.x >> 3;
+  const uint32_t q = nblk >> 3, r = nblk & 7u;
+  const uint32_t tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot_in_xcd;
+  const uint32_t per_group = GROUP_M2 * (uint32_t)a.tiles_n;
+  const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
+  const uint32_t group_rows = min((uint32_t)GROUP_M2, (uint32_t)a.tiles_m - group * GROUP_M2);
+  const int tm = (int)(group * GROUP_M2 + in_group % group_rows);
+  const int tn = (int)(in_group / group_rows);
+  const int m0 = tm * BM2, n0 = tn * BN_OUT;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;  // wm is also the ping-pong group
+
+  // DMA map: full 128-byte lines. A slot holds TWO K-steps (128 k-bytes per row): one LDS-DMA instruction copies
+  // 8 rows x 128 B — 8 whole cache lines instead of the 16 half lines of the 64-byte-row image (half the TA / L2
+  // requests per byte). Wave w copies the 8-row chunks {4w .. 4w+3} of A and of B. Inside a chunk lane l lands at
+  // LDS slot l: row = l / 8, physical 16-B slot = l % 8, logical slot = physical ^ ((row >> 1) & 7).
+  const int d_row = lane >> 3;
+  const int8_t* a_src[4];
+  const int8_t* b_src[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int row = (wave * 4 + c) * 8 + d_row;  // row inside the 256-row tile
+    const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
+    int ra = m0 + row;
+    ra = ra < a.M ? ra : a.M - 1;
+    a_src[c] = a.xq + (size_t)ra * a.K + d_slot * 16;
+    if constexpr (MLP) {
+      const int rb = n0 + (row >> 6) * 32 + (row & 31);
+      b_src[c] = ((row & 32) ? a.wq2 : a.wq) + (size_t)rb * a.K + d_slot * 16;
+    } else {
+      int rb = n0 + row;
+      rb = rb < a.N ? rb : a.N - 1;
+      b_src[c] = a.wq + (size_t)rb * a.K + d_slot * 16;
+    }
+  }
+  constexpr int SLOT_BYTES = (BM2 + BN2) * 128;  // 64 KiB: A image (32 KiB) then B image
+  constexpr int B_IMAGE = BM2 * 128;
+  const int last_super = a.K / 128 - 1;
+  // super-steps past the end re-load the last one into a slot nobody reads any more
+  auto issue_a = [&](int ks, int c0) {
+    const int slot = ks & 1;
+    ks = ks < last_super ? ks : last_super;
+    uint8_t* base = lds2 + slot * SLOT_BYTES;
+#pragma unroll
+    for (int c = c0; c < c0 + 2; ++c)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[c] + ks * 128), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+  };
+  auto issue_b = [&](int ks, int c0) {
+    const int slot = ks & 1;
+    ks = ks < last_super ? ks : last_super;
+    uint8_t* base = lds2 + slot * SLOT_BYTES + B_IMAGE;
+#pragma unroll
+    for (int c = c0; c < c0 + 2; ++c)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_src[c] + ks * 128), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+  };
+
+  v16i acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+  int rsx_acc[4] = {0, 0, 0, 0};
+
+  // Symmetric weight quantizers carry an all-zero offset BUFFER (reference nn/linear_quantizer.py:164-170):
+  // look at this block's offsets on the device — before any DMA is in flight, the compiler drains vmcnt
+  // for an ordinary load — and take the loop without activation row sums when they are all zero.
+  bool need_x_sums = false;
+  if constexpr (WOFF) {
+    int n = n0 + (tid % BN2);
+    n = n < a.N ? n : a.N - 1;
+    need_x_sums = __syncthreads_or(rne(a.w_offset[a.w_per_row ? n : 0]) != 0.0f) != 0;
+  }
+  // sum_k wq[n, k] of this lane's two weight rows (side kernel; only read when x has an offset)
+  int rsw[2] = {0, 0};
+  if (a.rowsum_w) {
+    if constexpr (MLP) {
+      rsw[0] = a.rowsum_w[n0 + wn * 32 + (lane & 31)];
+      rsw[1] = a.rowsum_w2[n0 + wn * 32 + (lane & 31)];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        n = n < a.N ? n : a.N - 1;
+        rsw[j] = a.rowsum_w[n];
+      }
+    }
+  }
+
+  const int ksuper = a.K / 128;
+  // prologue: super-step 0 (both K-steps of the first 128 k-bytes)
+  issue_a(0, 0); issue_a(0, 2); issue_b(0, 0); issue_b(0, 2);
+
+  const uint32_t frag_row = lane & 31, frag_g = lane >> 5;
+  // fragment byte offsets inside a slot: row * 128 + swizzled 16-B slot; v = 4 p + 2 kk + g (p = K-step parity)
+  uint32_t a_off[4][4], b_off[2][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t row = wm * 128 + i * 32 + frag_row;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a_off[i][v] = row * 128 + ((((v * 2) + frag_g) ^ ((row >> 1) & 7u)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const uint32_t row = wn * 64 + j * 32 + frag_row;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) b_off[j][v] = B_IMAGE + row * 128 + ((((v * 2) + frag_g) ^ ((row >> 1) & 7u)) << 4);
+  }
+
+  v4i fa[4], fb[2];
+  auto read_frags = [&](const uint8_t* st, int kk) {  // kk = 2 * (K-step parity) + k-half
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const v4i*>(st + b_off[j][kk]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const v4i*>(st + a_off[i][kk]);
+  };
+  auto cluster = [&](auto with_x, auto dma) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      if (i == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        dma();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (decltype(with_x)::value) {  // rare: a weight offset that is really non-zero
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rsx_acc[i] = __builtin_amdgcn_sdot4(fa[i].x, 0x01010101, rsx_acc[i], false);
+        rsx_acc[i] = __builtin_amdgcn_sdot4(fa[i].y, 0x01010101, rsx_acc[i], false);
+        rsx_acc[i] = __builtin_amdgcn_sdot4(fa[i].z, 0x01010101, rsx_acc[i], false);
+        rsx_acc[i] = __builtin_amdgcn_sdot4(fa[i].w, 0x01010101, rsx_acc[i], false);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // super-step 0 has landed (this wave's share)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // the upper group runs one interval behind
+
+  // One iteration = one super-step = two K-steps = four phases. The slot that held super-step ks - 1 is re-filled
+  // with super-step ks + 1 by the four clusters' ... first two clusters (8 LDS-DMA per wave), and waited for with
+  // vmcnt(0) in the last load segment: nothing newer is in flight then.
+  auto k_loop = [&](auto with_x) {
+    for (int ks = 0; ks < ksuper; ++ks) {
+      const uint8_t* st = lds2 + (ks & 1) * SLOT_BYTES;
+      read_frags(st, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(with_x, [&] { issue_a(ks + 1, 0); issue_b(ks + 1, 0); });
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(with_x, [&] { issue_a(ks + 1, 2); issue_b(ks + 1, 2); });
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(with_x, [] {});
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // super-step ks + 1 landed
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(with_x, [] {});
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+  if (need_x_sums) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // same number of barriers for both groups
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing dummy DMA must not land in the epilogue's LDS
+  if constexpr (WOFF) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rsx_acc[i] += __shfl_xor(rsx_acc[i], 32, 64);
+  }
+  if constexpr (MLP) mlp_epilogue(a, acc, rsw, lds2, wave, lane, wm, wn, m0, n0);
+  else gemm256_epilogue<TOut, REQUANT, WOFF, NW>(a, acc, rsw, rsx_acc, lds2, wave, lane, wm, wn, m0, n0);
+}
+
 // one wavefront per row: sum of K int8 codes
 __global__ __launch_bounds__(256) void rowsum_i8_kernel(const int8_t* __restrict__ q, int rows, int K,
                                                         int32_t* __restrict__ sums) {
@@ -932,15 +1135,20 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
       const size_t ring3 = (size_t)STAGES3 * (BM2 + 256) * BK2;
       const size_t epi3 = (size_t)8 * (128 * 144 + 256);
       const size_t lds3 = ring3 > epi3 ? ring3 : epi3;
+      static const int use_fl = getenv("FFQ_GEMM_FL") ? atoi(getenv("FFQ_GEMM_FL")) : 1;  // full-line staging: +2.4 % (A/B on one box)
+      const bool fl = use_fl && K % 128 == 0;
 #define FFQ_GEMM3_W(T, RQ, WO)                                                                             \
   do {                                                                                                     \
     static bool attr_set = false;                                                                          \
     if (!attr_set) {                                                                                       \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256pp_kernel<T, RQ, WO>),          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fl_kernel<T, RQ, WO>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);                    \
       attr_set = true;                                                                                     \
     }                                                                                                      \
-    w8a8_gemm256pp_kernel<T, RQ, WO><<<grid3, 512, lds3, s>>>(a);                                          \
+    if (fl) w8a8_gemm256fl_kernel<T, RQ, WO><<<grid3, 512, lds3, s>>>(a);                                  \
+    else w8a8_gemm256pp_kernel<T, RQ, WO><<<grid3, 512, lds3, s>>>(a);                                     \
   } while (0)
 #define FFQ_GEMM3(T, RQ) do { if (w_offset) FFQ_GEMM3_W(T, RQ, true); else FFQ_GEMM3_W(T, RQ, false); } while (0)
       if (requant) {
@@ -1082,8 +1290,12 @@ extern "C" int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, con
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256pp_kernel<int8_t, true, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fl_kernel<int8_t, true, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  w8a8_gemm256pp_kernel<int8_t, true, false, true><<<(unsigned)(a.tiles_m * a.tiles_n), 512, lds, s>>>(a);
-  return check_launch("w8a8_gemm256pp_kernel<mlp>");
+  static const int use_fl = getenv("FFQ_GEMM_FL") ? atoi(getenv("FFQ_GEMM_FL")) : 1;
+  if (use_fl && K % 128 == 0) w8a8_gemm256fl_kernel<int8_t, true, false, true><<<(unsigned)(a.tiles_m * a.tiles_n), 512, lds, s>>>(a);
+  else w8a8_gemm256pp_kernel<int8_t, true, false, true><<<(unsigned)(a.tiles_m * a.tiles_n), 512, lds, s>>>(a);
+  return check_launch("w8a8_gemm256 (mlp mode)");
 }
