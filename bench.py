@@ -143,7 +143,7 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
             launches += count
         per_shape = per_shape_random
     achieved = total_ops / total_ms / 1e9
-    traffic, prof = pmc_traffic("w8a8_gemm256fl_kernel", "false, false>")
+    traffic, prof = pmc_traffic("w8a8_gemm256fl_kernel", "bf16_t")
     return {
         "bound": "mfma",
         "kernel": "w8a8_gemm256fl_kernel (v_mfma_i32_32x32x32_i8, 256x256 tiles, ping-pong wave groups, full-line LDS-DMA staging; plain and gate+up/SiLU-epilogue modes) + rowsum_i8_kernel",

@@ -345,8 +345,8 @@ class FusedForward:
                 "qkv": self._distinct([attn.q_proj, attn.k_proj, attn.v_proj]),
                 "gate_up": self._distinct([mlp.gate_proj, mlp.up_proj]),
             })
-            if fuse_mlp:  # host reads happen here, never inside a (possibly graph-captured) forward
-                self._symmetric_weights(mlp.gate_proj), self._symmetric_weights(mlp.up_proj)
+        for _, linear in decoder_linears(model):  # host reads happen here, never inside a (possibly graph-captured) forward
+            self._symmetric_weights(linear)
 
     @staticmethod
     def _params(linear: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor | None]:
@@ -430,6 +430,8 @@ class FusedForward:
 
     def _linear(self, x_codes: torch.Tensor, linear: torch.nn.Module) -> torch.Tensor:
         w_codes, w_scale, w_offset = self._weight(linear)
+        if w_offset is not None and self._symmetric_weights(linear):
+            w_offset = None  # an all-zero offset buffer: same result, no device-side offset check in the kernel
         x_scale, x_offset = self._params(linear)
         if self.linear_events is None:
             return ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16)
