@@ -969,7 +969,7 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fl_kernel(LinearArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const v4i*>(st + a_off[i][kk]);
   };
-  auto cluster = [&](auto with_x, auto dma) {
+  auto cluster = [&](auto with_x, auto dma, auto dma2) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -980,6 +980,11 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fl_kernel(LinearArgs a) {
       if (i == 0) {
         __builtin_amdgcn_sched_barrier(0);
         dma();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (i == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        dma2();
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -1002,31 +1007,33 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fl_kernel(LinearArgs a) {
   if (wm == 1) __builtin_amdgcn_s_barrier();  // the upper group runs one interval behind
 
   // One iteration = one super-step = two K-steps = four phases. The slot that held super-step ks - 1 is re-filled
-  // with super-step ks + 1 by the four clusters' ... first two clusters (8 LDS-DMA per wave), and waited for with
-  // vmcnt(0) in the last load segment: nothing newer is in flight then.
+  // with super-step ks + 1 by the first two clusters (8 LDS-DMA per wave: two after the second MFMA of a cluster, two
+  // after the sixth — +1..2 % over four in one place) and waited for with vmcnt(0) in the last load segment, one phase
+  // before its first read; nothing newer is in flight then. WAR: the slot's last reads (phase 3 of the previous
+  // iteration) were retired by the slower group one barrier before the faster group's first cluster.
   auto k_loop = [&](auto with_x) {
     for (int ks = 0; ks < ksuper; ++ks) {
       const uint8_t* st = lds2 + (ks & 1) * SLOT_BYTES;
       read_frags(st, 0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-      cluster(with_x, [&] { issue_a(ks + 1, 0); issue_b(ks + 1, 0); });
+      cluster(with_x, [&] { issue_a(ks + 1, 0); }, [&] { issue_b(ks + 1, 0); });
       __builtin_amdgcn_s_barrier();
       read_frags(st, 1);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-      cluster(with_x, [&] { issue_a(ks + 1, 2); issue_b(ks + 1, 2); });
+      cluster(with_x, [&] { issue_a(ks + 1, 2); }, [&] { issue_b(ks + 1, 2); });
       __builtin_amdgcn_s_barrier();
       read_frags(st, 2);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-      cluster(with_x, [] {});
+      cluster(with_x, [] {}, [] {});
       __builtin_amdgcn_s_barrier();
       read_frags(st, 3);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // super-step ks + 1 landed
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-      cluster(with_x, [] {});
+      cluster(with_x, [] {}, [] {});
       __builtin_amdgcn_s_barrier();
     }
   };
