@@ -143,10 +143,10 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
             launches += count
         per_shape = per_shape_random
     achieved = total_ops / total_ms / 1e9
-    traffic, prof = pmc_traffic("w8a8_gemm256fl_kernel", "bf16_t")
+    traffic, prof = pmc_traffic("w8a8_gemm256fp_kernel", "bf16_t")
     return {
         "bound": "mfma",
-        "kernel": "w8a8_gemm256fl_kernel (v_mfma_i32_32x32x32_i8, 256x256 tiles, ping-pong wave groups, full-line LDS-DMA staging; plain and gate+up/SiLU-epilogue modes) + rowsum_i8_kernel",
+        "kernel": "w8a8_gemm256fp_kernel (v_mfma_i32_32x32x32_i8, 256x256 tiles, persistent one-block-per-CU tile loop, ping-pong wave groups, full-line LDS-DMA staging; plain and gate+up/SiLU-epilogue modes) + rowsum_i8_kernel",
         "achieved": round(achieved, 1),
         "peak": INT8_PEAK_TOPS,
         "unit": "TFLOP/s",

@@ -1049,6 +1049,273 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fl_kernel(LinearArgs a) {
   else gemm256_epilogue<TOut, REQUANT, WOFF, NW>(a, acc, rsw, rsx_acc, lds2, wave, lane, wm, wn, m0, n0);
 }
 
+// -------------------------------------------------------------------------------------------------
+// v3 persistent ("fp"): one block per CU walks its tiles; the K-loop is the full-line ping-pong loop of
+// w8a8_gemm256fl_kernel running straight across tile boundaries: the last iteration of a tile prefetches the first
+// super-step of the NEXT tile, which then lands under the epilogue (the 64 KiB + latency prologue burst that every
+// CU issues at the same moment otherwise costs ~3.5 us of a ~70 us tile). The epilogue works in the slot the tile
+// has just consumed: four 32-row slabs per wave (plain mode) or the block-wide code tile (MLP mode).
+// Plain (no weight offset) and MLP modes only; weight offsets take the non-persistent kernel.
+template <typename TOut, bool REQUANT>
+__device__ __forceinline__ void gemm256_epilogue_slabs(const LinearArgs& a, v16i (&acc)[4][2], uint8_t* scratch, int wave, int lane,
+                                                       int wm, int wn, int m0, int n0) {
+  TOut* out = static_cast<TOut*>(a.out);
+  float oscale = 1.0f, ooff = 0.0f;
+  if constexpr (REQUANT) {
+    oscale = a.out_scale[0];
+    ooff = a.out_offset ? rne(a.out_offset[0]) : 0.0f;
+  }
+  constexpr int ROW_BYTES = 144;
+  constexpr int WAVE_BYTES = 32 * ROW_BYTES + 3 * 64 * 4;  // one 32-row slab + the wave's 64 columns' parameters
+  uint8_t* region = scratch + wave * WAVE_BYTES;
+  float* colp = reinterpret_cast<float*>(region + 32 * ROW_BYTES);  // [3][64]: weight scale, weight row sum, bias
+  const int g = lane >> 5;
+  const int wave_n0 = n0 + wn * 64;
+  const int wave_m0 = m0 + wm * 128;
+  const bool lds_path = sizeof(TOut) == 2 && (a.N & 7) == 0 && wave_n0 + 64 <= a.N;
+  {
+    int n = wave_n0 + lane;
+    n = n < a.N ? n : a.N - 1;
+    colp[lane] = a.w_scale[a.w_per_row ? n : 0];
+    colp[64 + lane] = a.rowsum_w ? (float)a.rowsum_w[n] : 0.0f;
+    colp[128 + lane] = a.bias ? (float)load_any(a.bias, a.bias_dt, n) : 0.0f;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private: only this wave's own writes
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = wave_m0 + i * 32 + (lane & 31);
+    const bool m_ok = m < a.M;
+    m = m_ok ? m : a.M - 1;
+    const float sx = a.x_scale[a.x_per_row ? m : 0];
+    const float ox = a.x_offset ? rne(a.x_offset[a.x_per_row ? m : 0]) : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nb = j * 32 + 8 * q + 4 * g;
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 sw4 = *reinterpret_cast<const f32x4*>(colp + nb);
+        const f32x4 rs4 = *reinterpret_cast<const f32x4*>(colp + 64 + nb);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(colp + 128 + nb);
+        float y[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float v = (float)acc[i][j][4 * q + t] + ox * rs4[t];
+          float r = (sx * sw4[t]) * v;
+          if (a.bias) r = r + b4[t];
+          if constexpr (REQUANT) {
+            r = bf16_bits_to_f32(f32_to_bf16_bits(r));
+            r = clamp_nan(rne(r / oscale - ooff), a.out_lo, a.out_hi);
+          }
+          y[t] = r;
+        }
+        if constexpr (sizeof(TOut) == 2) {
+          if (lds_path) {
+            u32x2 pk;
+            pk.x = pack2<TOut>(y[0], y[1]);
+            pk.y = pack2<TOut>(y[2], y[3]);
+            *reinterpret_cast<u32x2*>(region + (lane & 31) * ROW_BYTES + nb * 2) = pk;
+            continue;
+          }
+        }
+        if (m_ok) {
+          const size_t at = (size_t)m * a.N + wave_n0 + nb;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (wave_n0 + nb + t < a.N) store_out<TOut>(out + at + t, y[t]);
+        }
+      }
+    if (lds_path) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = lane + 64 * t;
+        const int row = c >> 3, seg = c & 7;
+        const int mm = wave_m0 + i * 32 + row;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * ROW_BYTES + seg * 16);
+        if (mm < a.M && !(a.debug & 1))
+          *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * a.N + wave_n0) * 2 + seg * 16) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is re-written by the next i
+    }
+  }
+}
+
+template <typename TOut, bool REQUANT, bool MLP>
+__global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, int total_tiles) {
+  constexpr int BN2 = 256, WAVES_N = 4;
+  constexpr int BN_OUT = MLP ? 128 : 256;
+  constexpr int SLOT_BYTES = (BM2 + BN2) * 128;
+  constexpr int B_IMAGE = BM2 * 128;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // this block's tiles: XCD x (= blockIdx % 8) owns a contiguous range of the grouped tile order and its blocks walk
+  // it round-robin, i.e. the order in which a non-persistent launch would dispatch them
+  const uint32_t nblk = gridDim.x;
+  const uint32_t xcd = blockIdx.x & 7u, j_in_xcd = blockIdx.x >> 3;
+  const uint32_t blocks_in_xcd = (nblk >> 3) + (xcd < (nblk & 7u) ? 1u : 0u);
+  const uint32_t tq = (uint32_t)total_tiles >> 3, tr = (uint32_t)total_tiles & 7u;
+  const uint32_t xcd_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const uint32_t xcd_count = tq + (xcd < tr ? 1u : 0u);
+  const int my_tiles = j_in_xcd < xcd_count ? (int)((xcd_count - j_in_xcd + blocks_in_xcd - 1) / blocks_in_xcd) : 0;
+  if (my_tiles == 0) return;
+
+  const int d_row = lane >> 3;
+  const int8_t* a_src[4];
+  const int8_t* b_src[4];
+  int m0 = 0, n0 = 0;          // tile being computed
+  auto tile_origin = [&](int it, int& tm0, int& tn0) {
+    const uint32_t tile_id = xcd_first + j_in_xcd + (uint32_t)it * blocks_in_xcd;
+    const uint32_t per_group = GROUP_M2 * (uint32_t)a.tiles_n;
+    const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
+    const uint32_t group_rows = min((uint32_t)GROUP_M2, (uint32_t)a.tiles_m - group * GROUP_M2);
+    tm0 = (int)(group * GROUP_M2 + in_group % group_rows) * BM2;
+    tn0 = (int)(in_group / group_rows) * BN_OUT;
+  };
+  auto set_sources = [&](int tm0, int tn0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int row = (wave * 4 + c) * 8 + d_row;
+      const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
+      int ra = tm0 + row;
+      ra = ra < a.M ? ra : a.M - 1;
+      a_src[c] = a.xq + (size_t)ra * a.K + d_slot * 16;
+      if constexpr (MLP) {
+        const int rb = tn0 + (row >> 6) * 32 + (row & 31);
+        b_src[c] = ((row & 32) ? a.wq2 : a.wq) + (size_t)rb * a.K + d_slot * 16;
+      } else {
+        int rb = tn0 + row;
+        rb = rb < a.N ? rb : a.N - 1;
+        b_src[c] = a.wq + (size_t)rb * a.K + d_slot * 16;
+      }
+    }
+  };
+  // LDS-DMA of super-step `ks` of the tile the sources point at, into slot `slot`
+  auto issue_a = [&](int ks, int slot, int c0) {
+    uint8_t* base = lds2 + slot * SLOT_BYTES;
+#pragma unroll
+    for (int c = c0; c < c0 + 2; ++c)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[c] + ks * 128), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+  };
+  auto issue_b = [&](int ks, int slot, int c0) {
+    uint8_t* base = lds2 + slot * SLOT_BYTES + B_IMAGE;
+#pragma unroll
+    for (int c = c0; c < c0 + 2; ++c)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_src[c] + ks * 128), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+  };
+
+  const uint32_t frag_row = lane & 31, frag_g = lane >> 5;
+  uint32_t a_off[4][4], b_off[2][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t row = wm * 128 + i * 32 + frag_row;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a_off[i][v] = row * 128 + ((((v * 2) + frag_g) ^ ((row >> 1) & 7u)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const uint32_t row = wn * 64 + j * 32 + frag_row;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) b_off[j][v] = B_IMAGE + row * 128 + ((((v * 2) + frag_g) ^ ((row >> 1) & 7u)) << 4);
+  }
+
+  v16i acc[4][2];
+  v4i fa[4], fb[2];
+  auto read_frags = [&](const uint8_t* st, int kk) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const v4i*>(st + b_off[j][kk]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const v4i*>(st + a_off[i][kk]);
+  };
+  auto cluster = [&](auto dma, auto dma2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      if (i == 0) { __builtin_amdgcn_sched_barrier(0); dma(); __builtin_amdgcn_sched_barrier(0); }
+      if (i == 2) { __builtin_amdgcn_sched_barrier(0); dma2(); __builtin_amdgcn_sched_barrier(0); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  const int ksuper = a.K / 128;
+  int slot = 0;  // slot of the super-step about to be computed
+  tile_origin(0, m0, n0);
+  set_sources(m0, n0);
+  issue_a(0, 0, 0); issue_a(0, 0, 2); issue_b(0, 0, 0); issue_b(0, 0, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int it = 0; it < my_tiles; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+    int nm0 = m0, nn0 = n0;
+    const bool has_next = it + 1 < my_tiles;
+    if (has_next) tile_origin(it + 1, nm0, nn0);
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // the upper group runs one interval behind
+    for (int ks = 0; ks < ksuper; ++ks) {
+      const uint8_t* st = lds2 + slot * SLOT_BYTES;
+      // what the first two clusters fetch into the other slot: the next super-step of this tile, or the first one of
+      // the next tile (nothing after the block's last tile: a re-load of this super-step keeps the waits uniform)
+      int fetch = ks + 1;
+      if (ks == ksuper - 1) {
+        fetch = has_next ? 0 : ks;
+        if (has_next) set_sources(nm0, nn0);
+      }
+      read_frags(st, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster([&] { issue_a(fetch, slot ^ 1, 0); }, [&] { issue_b(fetch, slot ^ 1, 0); });
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster([&] { issue_a(fetch, slot ^ 1, 2); }, [&] { issue_b(fetch, slot ^ 1, 2); });
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster([] {}, [] {});
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the fetched super-step landed (and older epilogue stores)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster([] {}, [] {});
+      __builtin_amdgcn_s_barrier();
+      slot ^= 1;
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();  // same number of barriers for both groups
+    // `slot` now names the slot holding the prefetched super-step; the other one has been consumed: epilogue scratch
+    uint8_t* scratch = lds2 + (slot ^ 1) * SLOT_BYTES;
+    __syncthreads();
+    if constexpr (MLP) {
+      int rsw[2] = {0, 0};
+      if (a.rowsum_w) {
+        rsw[0] = a.rowsum_w[n0 + wn * 32 + (lane & 31)];
+        rsw[1] = a.rowsum_w2[n0 + wn * 32 + (lane & 31)];
+      }
+      mlp_epilogue(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0);
+    } else {
+      gemm256_epilogue_slabs<TOut, REQUANT>(a, acc, scratch, wave, lane, wm, wn, m0, n0);
+    }
+    __syncthreads();  // the scratch slot is the next tile's DMA target
+    m0 = nm0; n0 = nn0;
+  }
+}
+
 // one wavefront per row: sum of K int8 codes
 __global__ __launch_bounds__(256) void rowsum_i8_kernel(const int8_t* __restrict__ q, int rows, int K,
                                                         int32_t* __restrict__ sums) {
@@ -1144,8 +1411,23 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
       const size_t lds3 = ring3 > epi3 ? ring3 : epi3;
       static const int use_fl = getenv("FFQ_GEMM_FL") ? atoi(getenv("FFQ_GEMM_FL")) : 1;  // full-line staging: +2.4 % (A/B on one box)
       const bool fl = use_fl && K % 128 == 0;
+      static const int use_fp = getenv("FFQ_GEMM_FP") ? atoi(getenv("FFQ_GEMM_FP")) : 1;  // persistent tile loop: +4.9 % (A/B on one box)
+      const bool fp = fl && use_fp && !w_offset;
+      const unsigned grid_fp = grid3 < 256u ? grid3 : 256u;  // persistent: one block per CU
+      const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128;
+#define FFQ_GEMM3_FP(T, RQ)                                                                                \
+  do {                                                                                                     \
+    static bool attr_set_fp = false;                                                                       \
+    if (!attr_set_fp) {                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fp_kernel<T, RQ, false>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fp);                  \
+      attr_set_fp = true;                                                                                  \
+    }                                                                                                      \
+    w8a8_gemm256fp_kernel<T, RQ, false><<<grid_fp, 512, lds_fp, s>>>(a, (int)grid3);                       \
+  } while (0)
 #define FFQ_GEMM3_W(T, RQ, WO)                                                                             \
   do {                                                                                                     \
+    if (fp) { FFQ_GEMM3_FP(T, RQ); break; }                                                                \
     static bool attr_set = false;                                                                          \
     if (!attr_set) {                                                                                       \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256pp_kernel<T, RQ, WO>),          \
@@ -1175,6 +1457,7 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
       }
 #undef FFQ_GEMM3
 #undef FFQ_GEMM3_W
+#undef FFQ_GEMM3_FP
       return check_launch("w8a8_gemm256pp_kernel");
     }
     const int nw = force_nw ? force_nw : 8;
@@ -1302,6 +1585,19 @@ extern "C" int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, con
     attr_set = true;
   }
   static const int use_fl = getenv("FFQ_GEMM_FL") ? atoi(getenv("FFQ_GEMM_FL")) : 1;
+  static const int use_fp = getenv("FFQ_GEMM_FP") ? atoi(getenv("FFQ_GEMM_FP")) : 1;  // persistent tile loop: +4.9 % (A/B on one box)
+  if (use_fl && use_fp && K % 128 == 0) {
+    static bool attr_set_fp = false;
+    const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128;
+    if (!attr_set_fp) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fp_kernel<int8_t, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fp);
+      attr_set_fp = true;
+    }
+    const int total = a.tiles_m * a.tiles_n;
+    w8a8_gemm256fp_kernel<int8_t, true, true><<<(unsigned)(total < 256 ? total : 256), 512, lds_fp, s>>>(a, total);
+    return check_launch("w8a8_gemm256fp_kernel (mlp mode)");
+  }
   if (use_fl && K % 128 == 0) w8a8_gemm256fl_kernel<int8_t, true, false, true><<<(unsigned)(a.tiles_m * a.tiles_n), 512, lds, s>>>(a);
   else w8a8_gemm256pp_kernel<int8_t, true, false, true><<<(unsigned)(a.tiles_m * a.tiles_n), 512, lds, s>>>(a);
   return check_launch("w8a8_gemm256 (mlp mode)");
