@@ -553,7 +553,8 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
 // is formed in registers with exactly the roundings of the three-launch path (GEMM epilogue -> bf16 tensors ->
 // silu_mul_quantize_kernel), goes through ONE block-wide LDS tile [256][128 B] and leaves as full 128-byte lines
 // of int8 codes: a quarter of the bytes of one bf16 projection, instead of two.
-__device__ __forceinline__ void mlp_epilogue(const LinearArgs& a, v16i (&acc)[4][2], int (&rsw)[2], uint8_t* lds2, int wave,
+template <bool SAFE>
+__device__ __forceinline__ void mlp_epilogue_body(const LinearArgs& a, v16i (&acc)[4][2], int (&rsw)[2], uint8_t* lds2, int wave,
                                              int lane, int wm, int wn, int m0, int n0) {
   constexpr int PITCH = 144;  // 128 B of codes + 16 B pad
   const float sx = a.x_scale[0];
@@ -601,8 +602,10 @@ __device__ __forceinline__ void mlp_epilogue(const LinearArgs& a, v16i (&acc)[4]
         float z0 = a0 * u0, z1 = a1 * u1;
         w = pack2<bf16_t>(z0, z1);
         z0 = __builtin_bit_cast(float, w << 16); z1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
-        const float r0 = div.safe ? rne(div.fast(z0) - oo) : rne(z0 / so - oo);
-        const float r1 = div.safe ? rne(div.fast(z1) - oo) : rne(z1 / so - oo);
+        // SAFE: the Markstein division of ffq_affine.h (scale inside its no-underflow window), else the IEEE sequence;
+        // decided once per launch — a per-element select would evaluate both
+        const float r0 = SAFE ? rne(div.fast(z0) - oo) : rne(z0 / so - oo);
+        const float r1 = SAFE ? rne(div.fast(z1) - oo) : rne(z1 / so - oo);
         int c0 = (int)r0, c1 = (int)r1;  // v_cvt_i32_f32: NaN -> 0, the int8 container's value
         const int lo = (int)a.out_lo, hi = (int)a.out_hi;
         c[t] = c0 < lo ? lo : (c0 > hi ? hi : c0);
@@ -621,6 +624,13 @@ __device__ __forceinline__ void mlp_epilogue(const LinearArgs& a, v16i (&acc)[4]
     const u32x4 v = *reinterpret_cast<const u32x4*>(lds2 + row * PITCH + seg * 16);
     if (m < a.M && !(a.debug & 1)) *reinterpret_cast<u32x4*>(out + (size_t)m * a.N + n0 + seg * 16) = v;
   }
+}
+
+__device__ __forceinline__ void mlp_epilogue(const LinearArgs& a, v16i (&acc)[4][2], int (&rsw)[2], uint8_t* lds2, int wave,
+                                             int lane, int wm, int wn, int m0, int n0) {
+  const float as = __builtin_fabsf(a.out_scale[0]);
+  if (as > 0x1p-40f && as < 0x1p40f) mlp_epilogue_body<true>(a, acc, rsw, lds2, wave, lane, wm, wn, m0, n0);
+  else mlp_epilogue_body<false>(a, acc, rsw, lds2, wave, lane, wm, wn, m0, n0);
 }
 
 // -------------------------------------------------------------------------------------------------
