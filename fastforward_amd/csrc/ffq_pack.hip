@@ -189,6 +189,62 @@ static int pack4_plan(const ffq_tiling* tiling, int64_t block, int64_t scale_num
   return FFQ_OK;
 }
 
+// ---- GGUF block-32 writers: Q4_0 = [fp16 d | 16 nibble bytes] (18 B), Q8_0 = [fp16 d | 32 int8] (34 B) ------------
+// Reference: pack_q4_0_blocks / pack_q8_0_blocks, src/fastforward/export/stages/gguf/_packing.py:23-72 — FastForward's
+// signed codes and positive per-block scales written in the byte layout llama.cpp dequantizes (d = +scale,
+// qs = code + 8 nibble-packed low/high halves; Q8_0 codes clipped to [-127, 127]). One lane builds one block; the
+// block's bytes go through LDS so that the 18- / 34-byte records leave as dense 16-byte stores.
+template <int FORMAT>  // 4: Q4_0, 8: Q8_0
+__global__ __launch_bounds__(kBlock) void pack_gguf_blocks_kernel(const int8_t* __restrict__ codes, const float* __restrict__ scales,
+                                                                 uint8_t* __restrict__ out, uint32_t nblocks) {
+  constexpr int REC = FORMAT == 4 ? 18 : 34;
+  __shared__ __attribute__((aligned(16))) uint8_t stage[kBlock * REC];
+  const uint32_t b = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  if (b < nblocks) {
+    Chunk<int8_t, 16> lo, hi;
+    lo.load(codes + (size_t)b * 32);
+    hi.load(codes + (size_t)b * 32 + 16);
+    uint16_t* rec16 = reinterpret_cast<uint16_t*>(stage + threadIdx.x * REC);  // REC is even: 2-byte aligned
+    rec16[0] = f32_to_f16_bits(scales[b]);
+    if constexpr (FORMAT == 4) {
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        uint32_t pair = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          int l = (int)(int8_t)(lo.w[(i + k) >> 2] >> (8 * ((i + k) & 3))) + 8;
+          int h = (int)(int8_t)(hi.w[(i + k) >> 2] >> (8 * ((i + k) & 3))) + 8;
+          l = l < 0 ? 0 : (l > 15 ? 15 : l);
+          h = h < 0 ? 0 : (h > 15 ? 15 : h);
+          pair |= (uint32_t)(l | (h << 4)) << (8 * k);
+        }
+        rec16[1 + i / 2] = (uint16_t)pair;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 32; i += 2) {
+        const uint32_t w = i < 16 ? lo.w[i >> 2] : hi.w[(i - 16) >> 2];
+        int c0 = (int)(int8_t)(w >> (8 * (i & 3))), c1 = (int)(int8_t)(w >> (8 * ((i + 1) & 3)));
+        c0 = c0 < -127 ? -127 : c0;
+        c1 = c1 < -127 ? -127 : c1;
+        rec16[1 + i / 2] = (uint16_t)((c0 & 0xFF) | ((c1 & 0xFF) << 8));
+      }
+    }
+  }
+  __syncthreads();
+  // this thread block's records are contiguous in `out`, starting at a multiple of 256 * REC bytes (16-byte aligned)
+  const uint32_t first = blockIdx.x * (uint32_t)kBlock;
+  const uint32_t valid = (nblocks - first < (uint32_t)kBlock ? nblocks - first : (uint32_t)kBlock) * REC;
+  uint8_t* dst = out + (size_t)first * REC;
+  for (uint32_t off = threadIdx.x * 16; off < valid; off += kBlock * 16) {
+    if (off + 16 <= valid) {
+      *reinterpret_cast<u32x4*>(dst + off) = *reinterpret_cast<const u32x4*>(stage + off);
+    } else {
+      for (uint32_t k = off; k < valid; ++k) dst[k] = stage[k];
+    }
+  }
+}
+
 static bool fast_ok(const void* a, const void* b, int64_t numel, int64_t block) {
   return block % 8 == 0 && numel < ((int64_t)1 << 32) && (reinterpret_cast<uintptr_t>(a) & 3u) == 0 &&
          (reinterpret_cast<uintptr_t>(b) & 3u) == 0;
@@ -306,4 +362,17 @@ extern "C" int ffq_unpack_dequantize_int4(const uint8_t* packed, const float* sc
   }
 #undef FFQ_UD
   return check_launch("unpack_dequantize_int4_kernel");
+}
+
+extern "C" int ffq_pack_gguf_blocks(const int8_t* codes, const float* scales, int64_t nblocks, int format, uint8_t* out, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (format != 4 && format != 8) return fail(FFQ_ERR_ARG, "GGUF block format must be 4 (Q4_0) or 8 (Q8_0)");
+  if (nblocks < 0 || nblocks >= ((int64_t)1 << 31)) return fail(FFQ_ERR_ARG, "bad block count");
+  if (nblocks == 0) return FFQ_OK;
+  if (!codes || !scales || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (!aligned16(codes) || !aligned16(out)) return fail(FFQ_ERR_ARG, "codes and output must be 16-byte aligned");
+  const unsigned grid = (unsigned)((nblocks + kBlock - 1) / kBlock);
+  if (format == 4) pack_gguf_blocks_kernel<4><<<grid, kBlock, 0, s>>>(codes, scales, out, (uint32_t)nblocks);
+  else pack_gguf_blocks_kernel<8><<<grid, kBlock, 0, s>>>(codes, scales, out, (uint32_t)nblocks);
+  return check_launch("pack_gguf_blocks_kernel");
 }

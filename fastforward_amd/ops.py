@@ -30,6 +30,8 @@ __all__ = [
     "parameters_for_range",
     "pack_int4",
     "unpack_int4",
+    "pack_q4_0_blocks",
+    "pack_q8_0_blocks",
     "quantize_pack_int4",
     "unpack_dequantize_int4",
     "grid_sqerror_by_tile",
@@ -433,6 +435,31 @@ def grid_sqerror_by_tile(
         return None
     lib.check(status)
     return out
+
+
+def _pack_gguf(int_codes: torch.Tensor, scales: torch.Tensor, fmt: int) -> torch.Tensor:
+    codes = int_codes.detach().to(torch.int8).contiguous()
+    if codes.dim() != 2 or codes.shape[1] != 32:
+        raise ValueError(f"GGUF block-32 formats expect codes of shape (n_blocks, 32), got {tuple(codes.shape)}")
+    sc = scales.detach().reshape(-1).to(torch.float32).contiguous()
+    if sc.numel() != codes.shape[0]:
+        raise RuntimeError(f"expected {codes.shape[0]} scales, got {sc.numel()}")
+    lib, stream = _prepare(codes, sc)
+    out = torch.empty((codes.shape[0], 18 if fmt == 4 else 34), dtype=torch.uint8, device=codes.device)
+    lib.check(lib.ffq_pack_gguf_blocks(_ptr(codes), _ptr(sc), codes.shape[0], fmt, _ptr(out), stream))
+    return out
+
+
+def pack_q4_0_blocks(int_codes: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+    """``(n_blocks, 32)`` codes in [-8, 7] + per-block scales -> ``(n_blocks, 18)`` raw GGUF Q4_0 bytes
+    (reference export/stages/gguf/_packing.py:23-55)."""
+    return _pack_gguf(int_codes, scales, 4)
+
+
+def pack_q8_0_blocks(int_codes: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+    """``(n_blocks, 32)`` codes in [-128, 127] + per-block scales -> ``(n_blocks, 34)`` raw GGUF Q8_0 bytes, codes
+    clipped to [-127, 127] (reference export/stages/gguf/_packing.py:58-79)."""
+    return _pack_gguf(int_codes, scales, 8)
 
 
 def quantize_pack_int4(

@@ -302,6 +302,15 @@ int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* 
                          int8_t* codes_out, const float* out_scale, const float* out_offset, double out_num_bits,
                          int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * GGUF block-32 records — pack_q4_0_blocks / pack_q8_0_blocks, export/stages/gguf/_packing.py:23-72: `codes` is
+ * [nblocks, 32] int8 in FastForward's signed convention, `scales` [nblocks] fp32 (positive). format 4 -> Q4_0:
+ * 18 bytes per block = fp16(scale) then byte[j] = (code[j] + 8) | (code[j + 16] + 8) << 4 (nibbles clamped to
+ * [0, 15]); format 8 -> Q8_0: 34 bytes per block = fp16(scale) then the 32 codes clipped to [-127, 127].
+ * `out` holds nblocks * 18 (34) bytes that llama.cpp dequantizes as d * (qs - 8) (d * qs).
+ */
+int ffq_pack_gguf_blocks(const int8_t* codes, const float* scales, int64_t nblocks, int format, uint8_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

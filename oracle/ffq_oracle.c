@@ -964,3 +964,32 @@ int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* 
   free(g); free(u);
   return rc;
 }
+
+/* pack_q4_0_blocks / pack_q8_0_blocks, export/stages/gguf/_packing.py:23-72. The module cannot be imported in the
+   build container (it pulls in the `gguf` package, which is not installed), so this restatement is pinned by the
+   reference's own assertions for it (tests/export/stages/gguf/test_packing.py), re-expressed in tests/. */
+int ffq_pack_gguf_blocks(const int8_t* codes, const float* scales, int64_t nblocks, int format, uint8_t* out, void* stream) {
+  (void)stream;
+  if (format != 4 && format != 8) return fail(FFQ_ERR_ARG, "GGUF block format must be 4 (Q4_0) or 8 (Q8_0)");
+  if (nblocks < 0) return fail(FFQ_ERR_ARG, "bad block count");
+  if (nblocks == 0) return FFQ_OK;
+  if (!codes || !scales || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  const int rec = format == 4 ? 18 : 34;
+  for (int64_t b = 0; b < nblocks; ++b) {
+    uint8_t* r = out + b * rec;
+    uint16_t d = f32_to_f16(scales[b]);                    /* scales.to(torch.float16).view(uint8)        (:47,:75) */
+    r[0] = (uint8_t)(d & 0xFF); r[1] = (uint8_t)(d >> 8);
+    const int8_t* q = codes + b * 32;
+    if (format == 4) {
+      for (int j = 0; j < 16; ++j) {
+        int lo = q[j] + 8, hi = q[j + 16] + 8;             /* (int_codes + 8).clamp(0, 15)                     (:49) */
+        lo = lo < 0 ? 0 : (lo > 15 ? 15 : lo);
+        hi = hi < 0 ? 0 : (hi > 15 ? 15 : hi);
+        r[2 + j] = (uint8_t)(lo | (hi << 4));              /* first half low nibble, second half high      (:51-52) */
+      }
+    } else {
+      for (int j = 0; j < 32; ++j) r[2 + j] = (uint8_t)(int8_t)(q[j] < -127 ? -127 : q[j]);  /* clamp(-127, 127)  (:77) */
+    }
+  }
+  return FFQ_OK;
+}

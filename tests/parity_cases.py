@@ -309,3 +309,49 @@ def check_mse_grid(device):
             assert same_with_nan(quantizer.scale.detach().cpu(), c["scale"]), c["name"]
             if c["offset"] is not None:
                 assert same_with_nan(quantizer.offset.detach().cpu(), c["offset"]), c["name"]
+
+
+def check_gguf_blocks(device):
+    """The reference's assertions for its GGUF block-32 packers (tests/export/stages/gguf/test_packing.py), re-expressed:
+    record widths, positive fp16 scale, +8 nibble offset with low/high halves, llama.cpp's dequantization formulas
+    reproduce scale * code, -128 is clipped to -127 in Q8_0."""
+    import numpy as np
+
+    def dequant_q4_0(b):
+        d = b[:, :2].copy().view(np.float16).astype(np.float32).reshape(-1, 1)
+        qs = b[:, 2:]
+        return d * np.concatenate([(qs & 0x0F).astype(np.int16) - 8, (qs >> 4).astype(np.int16) - 8], axis=1).astype(np.float32)
+
+    def dequant_q8_0(b):
+        d = b[:, :2].copy().view(np.float16).astype(np.float32).reshape(-1, 1)
+        return d * b[:, 2:].view(np.int8).astype(np.float32)
+
+    codes = torch.zeros(2, 32, dtype=torch.int8)
+    codes[0, 0], codes[0, 1], codes[1, :] = -8, 7, 3
+    scales = torch.tensor([0.5, 2.0])
+    packed = ops.pack_q4_0_blocks(codes.to(device), scales.to(device)).cpu()
+    assert packed.shape == (2, 18) and packed.dtype == torch.uint8
+    np.testing.assert_allclose(packed.numpy()[:, :2].copy().view(np.float16).astype(np.float32).reshape(-1), scales.numpy(), rtol=1e-3)
+    assert int(packed[0, 2]) & 0x0F == 0 and int(packed[0, 2]) >> 4 == 8 and int(packed[0, 3]) & 0x0F == 15
+    assert bool((packed[1, 2:] == (11 | (11 << 4))).all())
+    rng = np.random.default_rng(0)
+    c4 = torch.from_numpy(rng.integers(-8, 8, size=(16, 32)).astype(np.int8))
+    s4 = torch.from_numpy(rng.uniform(0.05, 2.0, size=16).astype(np.float32))
+    np.testing.assert_allclose(dequant_q4_0(ops.pack_q4_0_blocks(c4.to(device), s4.to(device)).cpu().numpy()), s4.numpy()[:, None] * c4.numpy().astype(np.float32), atol=1e-2)
+    rng = np.random.default_rng(1)
+    c8 = torch.from_numpy(rng.integers(-127, 128, size=(16, 32)).astype(np.int8))
+    s8 = torch.from_numpy(rng.uniform(0.001, 0.5, size=16).astype(np.float32))
+    np.testing.assert_allclose(dequant_q8_0(ops.pack_q8_0_blocks(c8.to(device), s8.to(device)).cpu().numpy()), s8.numpy()[:, None] * c8.numpy().astype(np.float32), atol=1e-2)
+    clipped = ops.pack_q8_0_blocks(torch.full((1, 32), -128, dtype=torch.int8, device=device), torch.tensor([0.1], device=device)).cpu()
+    assert clipped.shape == (1, 34) and int(clipped[:, 2:].numpy().view(np.int8).min()) == -127
+    for fn, width in ((ops.pack_q4_0_blocks, 18), (ops.pack_q8_0_blocks, 34)):
+        assert fn(torch.zeros(1, 32, dtype=torch.int8, device=device), torch.ones(1, device=device)).shape == (1, width)
+    # the exact bytes, against a direct statement of the layout, on a block count that is not a multiple of the launch block
+    n = 1000
+    gen = torch.Generator().manual_seed(8)
+    codes = torch.randint(-128, 128, (n, 32), generator=gen, dtype=torch.int8)
+    scales = torch.rand(n, generator=gen) * 0.3 + 1e-3
+    d = scales.to(torch.float16).view(torch.uint8).reshape(n, 2)
+    q = (codes.to(torch.int16) + 8).clamp(0, 15).to(torch.uint8)
+    assert torch.equal(ops.pack_q4_0_blocks(codes.to(device), scales.to(device)).cpu(), torch.cat([d, q[:, :16] | (q[:, 16:] << 4)], dim=1))
+    assert torch.equal(ops.pack_q8_0_blocks(codes.to(device), scales.to(device)).cpu(), torch.cat([d, codes.clamp(-127, 127).view(torch.uint8)], dim=1))

@@ -57,3 +57,7 @@ def test_quantize_by_tile_backward():
 
 def test_mse_grid_range_estimator():
     parity_cases.check_mse_grid("cpu")
+
+
+def test_gguf_block_writers():
+    parity_cases.check_gguf_blocks("cpu")

@@ -77,6 +77,19 @@ def test_mse_grid_range_estimator():
     parity_cases.check_mse_grid(DEV)
 
 
+def test_gguf_block_writers():
+    parity_cases.check_gguf_blocks(DEV)
+    # a weight-sized tensor: Q4_0 bytes of group-32 codes == the nibbles of pack_int4 next to the fp16 scales
+    torch.manual_seed(2)
+    w = (torch.randn(4096, 4096, device=DEV) * 0.02).to(torch.bfloat16)
+    lo, hi = ops.minmax_by_tile(w, (1, 32))
+    scale, offset = ops.parameters_for_range(lo, hi, 4, True, False)
+    codes = ops.quantize_by_tile(w, scale, (1, 32), 4, torch.int8)
+    blocks = ops.pack_q4_0_blocks(codes.reshape(-1, 32), scale)
+    assert torch.equal(blocks[:, 2:].reshape(-1), ops.pack_int4(codes, block=32))
+    assert torch.equal(blocks[:, :2].reshape(-1), scale.to(torch.float16).view(torch.uint8))
+
+
 def test_golden_sweeps_with_ieee_division_kernels(monkeypatch):
     """FFQ_DIV_MODE is read once per process; the generic kernels always use the IEEE sequence."""
     monkeypatch.setenv("FFQ_FORCE_GENERIC", "1")
