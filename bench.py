@@ -274,7 +274,7 @@ def main() -> None:
     calib = [torch.randint(0, config.vocab_size, (args.batch, args.seq_len), device=device, generator=gen) for _ in range(calib_steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    payload = ffd.calibrate_sharded(model, calib, disable_quantization=False)
+    payload = ffd.calibrate_sharded(model, calib, disable_quantization=False, fused=not args.module_graph)
     torch.cuda.synchronize()
     calib_s = time.perf_counter() - t0
     del calib

@@ -111,16 +111,25 @@ def calibrate_sharded(
     local_batches: Iterable[torch.Tensor],
     disable_quantization: bool = True,
     group: dist.ProcessGroup | None = None,
+    fused: bool = False,
 ) -> int:
     """RunningMinMax calibration of `model` on this rank's batches followed by the range all-reduce.
 
     `local_batches` is this rank's share (see :func:`shard`). Returns the all-reduce payload size in
     floats. Nothing waits for the device until the single flag read after the collective.
     """
+    forward = None
+    if fused:  # Llama harness only: the producers between the quantizers as one-pass kernels
+        from fastforward_amd.llama import FusedCalibrationForward
+
+        forward = FusedCalibrationForward(model)
     with torch.no_grad(), ff.strict_quantization(False):
         with ff.estimate_ranges(model, ff.range_setting.running_minmax, sync_free=True, disable_quantization=disable_quantization):
             for batch in local_batches:
-                model(batch, logits=False) if _accepts_logits(model) else model(batch)
+                if forward is not None:
+                    forward(batch)
+                else:
+                    model(batch, logits=False) if _accepts_logits(model) else model(batch)
             return all_reduce_ranges(model, group)
 
 

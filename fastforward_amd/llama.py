@@ -297,12 +297,14 @@ def quantize_llama(
     return model
 
 
-def calibrate(model: LlamaModel, batches, sync_free: bool = True, disable_quantization: bool = False) -> None:
-    """RunningMinMax calibration over `batches` of token ids (reference quick-start :193,255)."""
+def calibrate(model: LlamaModel, batches, sync_free: bool = True, disable_quantization: bool = False, fused: bool = False) -> None:
+    """RunningMinMax calibration over `batches` of token ids (reference quick-start :193,255). ``fused`` runs the
+    producers between the quantizers as one-pass kernels (:class:`FusedCalibrationForward`)."""
+    forward = FusedCalibrationForward(model) if fused else (lambda ids: model(ids, logits=False))
     with torch.no_grad(), ff.strict_quantization(False):
         with ff.estimate_ranges(model, ff.range_setting.running_minmax, sync_free=sync_free, disable_quantization=disable_quantization):
             for ids in batches:
-                model(ids, logits=False)
+                forward(ids)
 
 
 class FusedForward:
@@ -496,6 +498,66 @@ class FusedForward:
             return normed
         with ff.strict_quantization(False):  # lm_head stays float in the recipe (quick-start :145)
             return model.lm_head(normed)
+
+
+class FusedCalibrationForward:
+    """The forward to run INSIDE ``ff.estimate_ranges(model, ...)``: producers fused, quantizers untouched.
+
+    Range estimation needs every quantizer's own ``forward`` (that is where ``estimate_ranges`` installs its
+    override: update the running min/max, set the range, quantize — reference range_setting/common.py:218-238), so
+    nothing is fused INTO a quantizer here. What is fused is everything between them: residual add + RMSNorm, the
+    rotary embedding and SiLU*up run as the one-pass producers of csrc/ffq_producers.hip instead of eager ATen
+    chains, and the quantized linears take the codes straight to the int8 GEMM. Results equal the module graph up to
+    the summation order inside RMSNorm (see FusedForward).
+    """
+
+    def __init__(self, model: LlamaModel) -> None:
+        cfg = model.config
+        if cfg.hidden_size % 16 or cfg.hidden_size > 8192 or cfg.head_dim % 16 or cfg.intermediate_size % 16:
+            raise ff.exceptions.QuantizationError("hidden size / head dim outside the fused kernels' range")
+        if next(model.parameters()).dtype != torch.bfloat16:
+            raise ff.exceptions.QuantizationError("fused producers are built for bf16 models")
+        for name, linear in decoder_linears(model):
+            if linear.bias is not None or linear.input_quantizer.is_stub() or linear.weight_quantizer.is_stub():
+                raise ff.exceptions.QuantizationError(f"{name}: needs input and weight quantizers and no bias")
+        self.model = model
+
+    @staticmethod
+    def _linear(x: torch.Tensor, linear: torch.nn.Module) -> torch.Tensor:
+        """QuantizedLinear.forward with the quantizers' own forwards (overrides included) and the int8 GEMM."""
+        xq = linear.input_quantizer(x)
+        wq = linear.weight_quantizer(linear.weight)
+        if not (isinstance(xq, ff.QuantizedTensor) and isinstance(wq, ff.QuantizedTensor)) or xq.raw_data.dtype != torch.int8 or wq.raw_data.dtype != torch.int8:
+            return ff.nn.functional.linear(xq, wq, None, output_quantizer=linear.output_quantizer)  # e.g. disable_quantization=True
+        xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
+        return ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, wp.offset, None, out_dtype=torch.bfloat16)
+
+    @torch.no_grad()
+    def __call__(self, input_ids: torch.Tensor, logits: bool = False) -> torch.Tensor:
+        model, cfg = self.model, self.model.config
+        b, s = input_ids.shape
+        d = cfg.head_dim
+        with ff.strict_quantization(False):
+            hidden = model.embed_tokens(input_ids)
+            cos, sin = rotary_tables(s, d, cfg.rope_theta, hidden.device, hidden.dtype)
+            pending: torch.Tensor | None = None
+            for layer in model.layers:
+                attn, mlp = layer.self_attn, layer.mlp
+                ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
+                hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, ln1.weight, ln1.variance_epsilon, (), want_norm=True, sum_inplace=pending is not None)
+                q, k, v = self._linear(normed, attn.q_proj), self._linear(normed, attn.k_proj), self._linear(normed, attn.v_proj)
+                ff.ops.rope_(q, k, cos, sin, d)
+                ctx = F.scaled_dot_product_attention(
+                    q.view(b, s, cfg.num_heads, d).transpose(1, 2), k.view(b, s, cfg.num_kv_heads, d).transpose(1, 2),
+                    v.view(b, s, cfg.num_kv_heads, d).transpose(1, 2), is_causal=s > 1, enable_gqa=cfg.num_kv_heads != cfg.num_heads,
+                ).transpose(1, 2).reshape(b, s, -1)
+                attn_out = self._linear(ctx, attn.o_proj)
+                hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, attn_out, ln2.weight, ln2.variance_epsilon, (), want_norm=True, sum_inplace=True)
+                gate, up = self._linear(normed, mlp.gate_proj), self._linear(normed, mlp.up_proj)
+                product, _ = ff.ops.silu_mul_quantize(gate, up, (), want_product=True)
+                pending = self._linear(product, mlp.down_proj)
+            _, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, model.norm.weight, model.norm.variance_epsilon, (), want_sum=False, want_norm=True)
+            return model.lm_head(normed) if logits else normed
 
 
 def count_quantizers(model: LlamaModel) -> int:

@@ -149,3 +149,45 @@ def test_fused_forward_matches_module_graph(oracle_backend):
 @pytest.mark.gpu
 def test_fused_forward_matches_module_graph_on_gpu(hip_backend):
     check_fused_against_module_graph(golden("g7_tiny_llama.pt"), "cuda")
+
+
+def check_fused_calibration(fixture, device):
+    """Calibrating through FusedCalibrationForward (every quantizer's own forward with its estimator override, fused
+    producers in between) gives the module graph's ranges: weight quantizers exactly, activation ranges within the
+    effect of RMSNorm's summation order."""
+    def calibrated(fused):
+        cfg = llama.LlamaConfig(**fixture["config"])
+        model = llama.LlamaModel(cfg).to(torch.bfloat16).eval()
+        llama.load_hf_state_dict(model, fixture["weights"])
+        model.to(device)
+        llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
+        llama.calibrate(model, [b.to(device) for b in fixture["calibration_ids"]], fused=fused)
+        return model, {n: (q.scale.detach().cpu(), q.offset.detach().cpu()) for n, q in ff.nn.named_quantizers(model)}
+
+    _, want = calibrated(False)
+    model, got = calibrated(True)
+    assert set(got) == set(want) and len(got) == 28
+    for name in want:
+        if name.endswith("weight_quantizer"):
+            assert torch.equal(got[name][0], want[name][0]) and torch.equal(got[name][1], want[name][1]), name
+        else:
+            torch.testing.assert_close(got[name][0], want[name][0], rtol=1e-2, atol=0)
+            torch.testing.assert_close(got[name][1], want[name][1], rtol=0, atol=1.0)
+    llama.FusedForward(model)(fixture["ids"].to(device))  # the calibrated model runs
+    # ranges collected on the un-quantized forward take the float linear
+    cfg = llama.LlamaConfig(**fixture["config"])
+    m2 = llama.LlamaModel(cfg).to(torch.bfloat16).eval()
+    llama.load_hf_state_dict(m2, fixture["weights"])
+    m2.to(device)
+    llama.quantize_llama(m2, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
+    llama.calibrate(m2, [b.to(device) for b in fixture["calibration_ids"]], fused=True, disable_quantization=True)
+    assert all(not q.has_uninitialized_params for _, q in ff.nn.named_quantizers(m2))
+
+
+def test_fused_calibration_matches_module_graph(oracle_backend):
+    check_fused_calibration(golden("g7_tiny_llama.pt"), "cpu")
+
+
+@pytest.mark.gpu
+def test_fused_calibration_matches_module_graph_on_gpu(hip_backend):
+    check_fused_calibration(golden("g7_tiny_llama.pt"), "cuda")

@@ -109,12 +109,17 @@ def cfg3(total_sequences: int) -> dict:
     batches = [torch.randint(0, config.vocab_size, (8, 2048), device=DEV, generator=gen) for _ in range(steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    payload = ffd.calibrate_sharded(model, batches, disable_quantization=False)
+    ffd.calibrate_sharded(model, batches[:8], disable_quantization=False)  # the reference-shaped module graph, 64 sequences
+    torch.cuda.synchronize()
+    s_mg = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    payload = ffd.calibrate_sharded(model, batches, disable_quantization=False, fused=True)
     torch.cuda.synchronize()
     s = time.perf_counter() - t0
     out = {"config": f"Llama-3-8B W8A8, RunningMinMax calibration over {steps * 8} sequences x 2048 tokens ({steps} steps of 8), quantize-while-calibrating (reference default)",
            "calibration": {"seconds": round(s, 2), "sequences_per_s": round(steps * 8 / s, 2), "tokens_per_s": round(steps * 8 * 2048 / s, 1),
-                           "range_floats_for_allreduce": payload}}
+                           "range_floats_for_allreduce": payload, "forward": "FusedCalibrationForward (quantizers' own forwards with their estimator overrides; fused producers in between)"},
+           "calibration_module_graph_64_sequences": {"seconds": round(s_mg, 2), "sequences_per_s": round(64 / s_mg, 2)}}
     batch = batches[0]
     fused = llama.FusedForward(model)
     s = timed_forward(lambda: fused(batch))
@@ -203,7 +208,7 @@ def cfg5(local_sequences: int) -> dict:
     batches = [torch.randint(0, config.vocab_size, (8, 2048), device=DEV, generator=gen) for _ in range(steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    payload = ffd.calibrate_sharded(model, batches, disable_quantization=True)
+    payload = ffd.calibrate_sharded(model, batches, disable_quantization=True, fused=True)
     torch.cuda.synchronize()
     s = time.perf_counter() - t0
     fingerprint = ffd.ranges_fingerprint(model)
