@@ -34,6 +34,7 @@ __all__ = [
     "pack_q8_0_blocks",
     "quantize_pack_int4",
     "unpack_dequantize_int4",
+    "gptq_block",
     "grid_sqerror_by_tile",
     "linear_w8a8",
     "mlp_gate_up_w8a8",
@@ -393,6 +394,41 @@ def unpack_int4(packed: torch.Tensor, shape: Sequence[int], dtype: torch.dtype =
         raise ValueError(f"shape {tuple(shape)} does not hold {packed_c.numel() * 2} codes")
     lib.check(lib.ffq_unpack_int4(_ptr(packed_c), out.numel(), int(block), _ptr(out), _tag(dtype), stream))
     return out
+
+
+def gptq_block(
+    weights: torch.Tensor,
+    quantized: torch.Tensor,
+    errors: torch.Tensor,
+    col0: int,
+    block_cols: int,
+    hessian_inverse: torch.Tensor,
+    scale: torch.Tensor,
+    offset: torch.Tensor | None,
+    num_bits: float,
+) -> bool:
+    """GPTQ's column loop for ``weights[:, col0 : col0 + block_cols]`` in one launch (reference
+    quantization/gptq.py:101-131): fills the block's columns of `quantized` and `errors` in place. fp32 matrices,
+    one (scale, offset) per row or one in total. Returns False when the kernel does not cover the call."""
+    tensors = (weights, quantized, errors, hessian_inverse)
+    if any(t.dtype != torch.float32 or t.dim() != 2 or not t.is_contiguous() for t in tensors) or block_cols > 128:
+        return False
+    if not (weights.shape == quantized.shape == errors.shape):
+        return False
+    sc = scale.detach().reshape(-1).to(torch.float32).contiguous()
+    of = None if offset is None else offset.detach().reshape(-1).to(torch.float32).contiguous()
+    rows = weights.shape[0]
+    if sc.numel() not in (1, rows) or (of is not None and of.numel() not in (1, rows)):
+        return False
+    lib, stream = _prepare(weights, quantized, errors, hessian_inverse, sc, of)
+    lib.check(
+        lib.ffq_gptq_block(
+            _ptr(weights), _ptr(quantized), _ptr(errors), rows, weights.shape[1], int(col0), int(block_cols),
+            _ptr(hessian_inverse), hessian_inverse.shape[1], _ptr(sc), sc.numel(), _ptr(of), of.numel() if of is not None else 0,
+            float(num_bits), stream,
+        )
+    )
+    return True
 
 
 def grid_sqerror_by_tile(

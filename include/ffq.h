@@ -311,6 +311,21 @@ int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* 
  */
 int ffq_pack_gguf_blocks(const int8_t* codes, const float* scales, int64_t nblocks, int format, uint8_t* out, void* stream);
 
+/*
+ * The inner loop of GPTQ for one block of columns — gptq(), quantization/gptq.py:101-131, with the per-row
+ * quantize-dequantize of column_quantizer (:149-235) for PerTensor / PerChannel(0) weight quantizers:
+ *   for j in 0 .. block_cols:   q = dequantize(quantize(w[:, col0 + j]));  e = (w[:, col0 + j] - q) / hinv[col0 + j, col0 + j]
+ *                               quantized[:, col0 + j] = q;  errors[:, col0 + j] = e
+ *                               w[:, col0 + k] -= e * hinv[col0 + j, col0 + k]     for j < k < block_cols (block-local copy)
+ * All matrices fp32: weights / quantized / errors [rows, row_stride], hinv [n, hinv_stride] (the upper Cholesky factor of
+ * the inverse Hessian). `weights` is read only (the reference updates a clone of the block); the caller applies the
+ * trailing update weights[:, col0 + block_cols:] -= errors[:, block] @ hinv[block, col0 + block_cols:] (:133) as a GEMM.
+ * block_cols <= 128; scale / offset: one per row or one in total.
+ */
+int ffq_gptq_block(float* weights, float* quantized, float* errors, int64_t rows, int64_t row_stride,
+                   int64_t col0, int64_t block_cols, const float* hinv, int64_t hinv_stride, const float* scale,
+                   int64_t scale_numel, const float* offset, int64_t offset_numel, double num_bits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -993,3 +993,40 @@ int ffq_pack_gguf_blocks(const int8_t* codes, const float* scales, int64_t nbloc
   }
   return FFQ_OK;
 }
+
+/* gptq(), quantization/gptq.py:101-131 for one block of columns (per-row parameters: column_quantizer :149-235) */
+int ffq_gptq_block(float* weights, float* quantized, float* errors, int64_t rows, int64_t row_stride,
+                   int64_t col0, int64_t block_cols, const float* hinv, int64_t hinv_stride, const float* scale,
+                   int64_t scale_numel, const float* offset, int64_t offset_numel, double num_bits, void* stream) {
+  (void)stream;
+  if (rows < 0 || block_cols < 0 || col0 < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (block_cols > 128) return fail(FFQ_ERR_DTYPE, "GPTQ block kernel handles at most %d columns per block", 128);
+  if (rows == 0 || block_cols == 0) return FFQ_OK;
+  if (!weights || !quantized || !errors || !hinv || !scale) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if ((scale_numel != 1 && scale_numel != rows) || (offset && offset_numel != 1 && offset_numel != rows))
+    return fail(FFQ_ERR_PARAM_NUMEL, "GPTQ block kernel takes one scale / offset per row (or one in total)");
+  float lo = (float)(-pow(2.0, num_bits - 1.0)), hi = -lo - 1.0f;
+  float* w = (float*)malloc(sizeof(float) * (size_t)block_cols);
+  for (int64_t r = 0; r < rows; ++r) {
+    float s = scale[scale_numel == 1 ? 0 : r];
+    float o = offset ? nearbyintf(offset[offset_numel == 1 ? 0 : r]) : 0.0f;
+    for (int64_t k = 0; k < block_cols; ++k) w[k] = weights[r * row_stride + col0 + k];   /* weights_block = ...clone() (:104) */
+    for (int64_t j = 0; j < block_cols; ++j) {
+      float q = w[j] / s;                                   /* quant_deq(weights_block[:, j])           (:124-125) */
+      q = q - o;
+      q = (float)clamp_nan((double)nearbyintf(q), lo, hi);
+      float dq = q + o;
+      dq = dq * s;
+      float d = w[j] - dq;
+      float e = d / hinv[(col0 + j) * hinv_stride + col0 + j];   /* errors[:, i + j]                    (:127-129) */
+      quantized[r * row_stride + col0 + j] = dq;
+      errors[r * row_stride + col0 + j] = e;
+      for (int64_t k = j + 1; k < block_cols; ++k) {       /* weights_block[:, j + 1:] -= e @ hinv[j, j + 1:]  (:131) */
+        float p = e * hinv[(col0 + j) * hinv_stride + col0 + k];
+        w[k] = w[k] - p;
+      }
+    }
+  }
+  free(w);
+  return FFQ_OK;
+}

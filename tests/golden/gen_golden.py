@@ -506,6 +506,35 @@ def g12_mse_grid():
     return cases
 
 
+def g13_gptq():
+    """The reference's gptq() (quantization/gptq.py) on small QuantizedLinear layers, CPU: initial weight, the layer's
+    input activations, and the weight / scale / offset it ends with."""
+    from fastforward.quantization.gptq import gptq
+
+    cases = []
+    for name, gran, symmetric, bits, out_f, in_f, block_size, actorder in [
+        ("channel0_asym_4bit", ff.PerChannel(0), False, 4, 48, 160, 64, False),
+        ("tensor_sym_4bit", ff.PerTensor(), True, 4, 40, 128, 128, False),
+        ("channel0_sym_3bit_actorder", ff.PerChannel(0), True, 3, 32, 96, 32, True),
+        ("group16_asym_4bit", ff.PerBlock(block_dims=1, block_sizes=16, per_channel_dims=0), False, 4, 24, 64, 32, False),
+        ("channel1_sym_4bit", ff.PerChannel(1), True, 4, 24, 64, 32, False),
+    ]:
+        torch.manual_seed(1280 + len(cases))
+        layer = torch.nn.Linear(in_f, out_f, bias=False)
+        ff.quantize_model(layer)
+        layer.weight_quantizer = ff.nn.LinearQuantizer(bits, granularity=gran, symmetric=symmetric)
+        weight0 = layer.weight.detach().clone()
+        acts = [torch.randn(2, 24, in_f) * (1.0 + 0.5 * torch.rand(in_f)) for _ in range(3)]
+        dataset = [((a.clone(),), {}) for a in acts]  # calculate_hessian scales its fp32 input IN PLACE (gptq.py:312)
+        with torch.no_grad(), ff.strict_quantization(False):
+            gptq(layer, dataset, block_size=block_size, actorder=actorder)
+        q = layer.weight_quantizer
+        cases.append({"name": name, "granularity": name.split("_")[0], "symmetric": symmetric, "num_bits": bits, "block_size": block_size, "actorder": actorder,
+                      "weight": weight0, "activations": acts, "result": layer.weight.detach().clone(),
+                      "scale": q.scale.detach().clone(), "offset": None if q.offset is None else q.offset.detach().clone()})
+    return cases
+
+
 def main() -> None:
     torch.set_num_threads(8)
     if len(sys.argv) > 1:  # regenerate only the named fixtures, e.g. `gen_golden.py g10_producers`
@@ -526,6 +555,7 @@ def main() -> None:
     torch.save(g10_producers(), HERE / "g10_producers.pt")
     torch.save(g11_backward(), HERE / "g11_backward.pt")
     torch.save(g12_mse_grid(), HERE / "g12_mse_grid.pt")
+    torch.save(g13_gptq(), HERE / "g13_gptq.pt")
     for f in sorted(HERE.glob("*.pt")):
         print(f"{f.name}: {f.stat().st_size / 1024:.0f} KiB")
 

@@ -61,3 +61,7 @@ def test_mse_grid_range_estimator():
 
 def test_gguf_block_writers():
     parity_cases.check_gguf_blocks("cpu")
+
+
+def test_gptq_matches_the_reference_bit_for_bit():
+    parity_cases.check_gptq("cpu", exact=True)

@@ -90,6 +90,10 @@ def test_gguf_block_writers():
     assert torch.equal(blocks[:, :2].reshape(-1), scale.to(torch.float16).view(torch.uint8))
 
 
+def test_gptq_block_kernel():
+    parity_cases.check_gptq(DEV, exact=False)
+
+
 def test_golden_sweeps_with_ieee_division_kernels(monkeypatch):
     """FFQ_DIV_MODE is read once per process; the generic kernels always use the IEEE sequence."""
     monkeypatch.setenv("FFQ_FORCE_GENERIC", "1")
