@@ -9,7 +9,7 @@ dev = "cuda"
 torch.manual_seed(0)
 n_out, n_in = (int(v) for v in (sys.argv[1:3] if len(sys.argv) > 2 else (4096, 4096)))
 acts = [((torch.randn(4, 512, n_in, device=dev),), {}) for _ in range(2)]
-for fused in (True, False):
+for fused in (True, True, False, True, False):  # the first pass warms hipSOLVER / hipBLASLt up
     layer = torch.nn.Linear(n_in, n_out, bias=False, device=dev)
     ff.quantize_model(layer)
     layer.weight_quantizer = ff.nn.LinearQuantizer(4, granularity=ff.PerChannel(0), symmetric=False, device=dev)
