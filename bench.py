@@ -194,6 +194,15 @@ def hbm_kernels(device: torch.device) -> list[dict]:
         lambda r: ops.add_rmsnorm_quantize(ws[r % 6], ws[(r + 1) % 6], gamma, 1e-5, [(s1, o1)]))
     add("SiLU(gate) * up + quantize (bf16, bf16 -> int8 codes)", "silu_mul_quantize_kernel", ("silu_mul_quantize_kernel",), 5,
         lambda r: ops.silu_mul_quantize(ws[r % 6], ws[(r + 1) % 6], [(s1, o1)]))
+    # W4 group-128: A1 + A7 and A7 + A2 in one pass each (2.5 B/elem), and the backward of fake quantization (6 B/elem)
+    g4 = torch.rand(n // 128, device=device) * 0.002 + 0.002
+    packed = [ops.quantize_pack_int4(w, g4, (1, 128), None, block=128) for w in ws]
+    add("W4 group-128 quantize + pack (bf16 -> nibbles)", "quantize_pack_int4_kernel", ("quantize_pack_int4_kernel",), 2.5,
+        lambda r: ops.quantize_pack_int4(ws[r % 6], g4, (1, 128), None, block=128))
+    add("W4 group-128 unpack + dequantize (nibbles -> bf16)", "unpack_dequantize_int4_kernel", ("unpack_dequantize_int4_kernel",), 2.5,
+        lambda r: ops.unpack_dequantize_int4(packed[r % 6], g4, shape, (1, 128), None, block=128))
+    add("quantize_by_tile_backward per-channel (bf16 data + grad -> bf16 dinput, fp32 dscale)", "quantize_backward_kernel", ("quantize_backward_kernel",), 6,
+        lambda r: ops.quantize_by_tile_backward(ws[r % 6], ws[(r + 1) % 6], scale, tile, 8.0, None))
     return rows
 
 
