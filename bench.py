@@ -75,14 +75,14 @@ def event_time_ms(fn, iters: int, reps: int = 8) -> float:
     return statistics.median(samples)
 
 
-def pmc_traffic(*needles: str) -> tuple[float | None, str | None]:
+def pmc_traffic(*needles: str, stems: tuple[str, ...] = ("_pmc_", "_pmc_hbm_")) -> tuple[float | None, str | None]:
     """HBM bytes per launch (read + write) of the kernel whose name contains all `needles`, from the
     committed PMC passes (profiles/*_pmc_FETCH_SIZE.json / *_pmc_WRITE_SIZE.json, produced by
     tools/collect_profiles.sh: separate --pmc runs, FETCH_SIZE x2 on gfx950 as the microarch guide
     prescribes). bench.py cannot run rocprofv3 on itself, so this is a lookup, labelled with its source."""
     import glob
 
-    for stem in ("_pmc_", "_pmc_hbm_"):
+    for stem in stems:
         reads = sorted(glob.glob(str(ROOT / "profiles" / f"*{stem}FETCH_SIZE.json")))
         writes = sorted(glob.glob(str(ROOT / "profiles" / f"*{stem}WRITE_SIZE.json")))
         if not reads or not writes:
@@ -175,7 +175,7 @@ def hbm_kernels(device: torch.device) -> list[dict]:
     def add(name, kernel, needles, bytes_per_elem, fn):
         ms = event_time_ms(fn, iters=10, reps=12)
         gbs = n * bytes_per_elem / ms / 1e6
-        traffic, _ = pmc_traffic(*needles)
+        traffic, _ = pmc_traffic(*needles, stems=("_pmc_hbm_",))  # the launches of tools/hbm_probe.py: this shape
         rows.append({"op": name, "kernel": kernel, "bound": "hbm", "bytes_per_elem": bytes_per_elem, "algorithmic_bytes": n * bytes_per_elem,
                      "ms": round(ms, 5), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic})
