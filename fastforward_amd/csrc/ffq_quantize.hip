@@ -87,6 +87,7 @@ __global__ __launch_bounds__(kBlock) void quantize_stream_kernel(const TIn* __re
   }
 }
 
+
 struct ColumnArgs {
   float lo, hi;
   uint32_t col_chunks;   // channels / E
@@ -210,7 +211,9 @@ static int launch_generic(const void* data, int data_dt, const void* scale, int 
   return check_launch("quantize_generic_kernel");
 }
 
-// chunks per lane: measured on MI355X (tools/q_variants.py, interleaved A/B): short blocks win —
+// chunks per lane: measured on MI355X (interleaved A/B): short blocks win. Also measured and rejected for 2-byte ->
+// 1-byte: two coalesced 16-B loads per lane (chunks l and l + 64) with a lane-pair exchange into 16-B stores (4.2-5.3 TB/s)
+// or with two 8-B stores (4.1-5.4 TB/s) against 6.0 TB/s for the 16-element chunk below —
 // bf16 -> int8 [14336, 4096]: E=16/U=1 29.2 us vs E=16/U=2 32.4 us vs E=8/U=4 34.3 us; U=1 also wins for
 // bf16 -> bf16 (38.5 vs 41.0 us at U=4) and per-tensor activations (33.2 vs 39.2 us).
 static int stream_u_override() {
