@@ -361,7 +361,7 @@ def main() -> None:
             "parallelism": f"dp{world} (batch-sharded replicas, no data-path collective)",
             "quantizers": llama.count_quantizers(model),
             "launch": "hipGraph replay" if graph is not None else "eager",
-            "forward": "module graph (reference-shaped)" if fused is None else "llama.FusedForward (A1 fused into RMSNorm / SiLU*up, rotary in place)",
+            "forward": "module graph (reference-shaped)" if fused is None else "llama.FusedForward (A1 fused into RMSNorm / SiLU*up / attention, rotary in place)",
         },
         "calibration": {"sequences_per_gpu": calib_steps * args.batch, "seconds": round(calib_s, 3),
                         "sequences_per_s_all_gpus": round(calib_steps * args.batch * world / calib_s, 2),

@@ -161,6 +161,7 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_add_rmsnorm_quantize": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _d, _vp, _fp, _vp]),
     "ffq_silu_mul_quantize": (_i, [_vp, _vp, _i, _i64, _vp, _fp, _vp]),
     "ffq_rope_inplace": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "ffq_attention": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _d, _i, _vp, _vp, _vp, _vp, _d, _vp]),
 }
 
 

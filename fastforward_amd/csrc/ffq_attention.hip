@@ -1,0 +1,330 @@
+// ffq_attention.hip — the attention between q/k/v_proj and o_proj of the reference's quantized Llama
+// (docs/examples/doc_helpers/quantized_llama/attention.py:45-92: repeat_kv, matmul, scale, causal mask,
+// fp32 softmax, matmul; the three quantizers inside are stubs in the recipe), fused with the INPUT
+// QUANTIZER of o_proj (nn/linear.py:33 -> A1), so the context tensor never has to visit HBM as bf16.
+//
+// Flash-style: no S x S matrix. One workgroup = 8 waves = 256 query rows of one (batch, head); a wave owns
+// 32 rows. K/V tiles of 64 keys are register-staged into a 2-deep LDS ring (global loads issued before the
+// tile's matrix work, LDS writes after it, one barrier per tile).
+//   * scores transposed: S^T[key][query] = mfma_32x32x16_bf16(A = K rows, B = Q rows), so a lane holds one
+//     query column: the row max / row sum of the online softmax are 32 in-register ops + one cross-half
+//     exchange, and the running (m, l) are lane-local;
+//   * context transposed: O^T[d][query] = mfma(A = V^T, B = P): P's bf16 fragments are the exponentiated
+//     score registers in place (a contraction is invariant under a permutation of its index applied to both
+//     operands), V^T fragments come from the row-major V image through ds_read_b64_tr_b16 (row pitch 320 B:
+//     the four key rows of a transposing read land in four different 64-byte bank groups);
+//   * K image XOR-swizzled (16-byte slot ^= row & 15) so the ds_read_b128 of a fragment is conflict-free;
+//   * causal: tiles above a wave's rows are skipped wave-uniformly, the diagonal tiles mask in registers,
+//     heavy query blocks are dispatched first; blockIdx -> (kv head = XCD) so the 4 query heads of a GQA
+//     group and the query blocks of one sequence share their K/V in one XCD's L2;
+//   * epilogue: O^T / l -> bf16 -> per-wave LDS tile -> whole rows back out: bf16 context (optional) and the
+//     int8 codes of A1 with the arithmetic of ffq_affine.h (bit-identical to ffq_quantize_by_tile on the
+//     bf16 context this call produces).
+// MFMA-bound (4 * S^2 * D / 2 flops per (batch, head) causal); bf16 operands, fp32 accumulation and softmax.
+#include "ffq_affine.h"
+#include "ffq_common.h"
+#include "ffq_vec.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+namespace ffq {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+constexpr int kD = 128;             // head dim
+constexpr int kKeys = 64;           // keys per tile
+constexpr int kWaves = 8;
+constexpr int kRowsPerWave = 32;
+constexpr int kQBlock = kWaves * kRowsPerWave;  // 256 query rows per workgroup
+constexpr int kKPitch = 256;        // bytes per K row in LDS (swizzled slots)
+constexpr int kVPitch = 320;        // bytes per V row in LDS (64-byte skew per row)
+constexpr int kKBytes = kKeys * kKPitch;
+constexpr int kVBytes = kKeys * kVPitch;
+constexpr int kLdsBytes = 2 * kKBytes + 2 * kVBytes;   // 73728
+constexpr int kOPitch = 272;        // bytes per output row in the epilogue image
+static_assert(kWaves * kRowsPerWave * kOPitch <= kLdsBytes, "epilogue image must fit the K/V ring");
+
+struct AttnArgs {
+  const uint16_t* q;
+  const uint16_t* k;
+  const uint16_t* v;
+  uint16_t* ctx;          // nullable
+  int8_t* codes;          // nullable
+  const float* scale;     // A1 parameters of the codes
+  const float* offset;    // nullable
+  int32_t B, S, H, HKV;
+  int32_t nqb;            // query blocks per sequence
+  float c;                // softmax scale * log2(e)
+  float lo, hi;           // clamp bounds of the codes
+};
+
+// V^T fragment of one MFMA: 8 keys x 1 column per lane = two transposing reads.
+template <int VMODE>
+__device__ __forceinline__ bf16x8 load_vt(const unsigned char* vbuf, uint32_t lane_off, int imm, uint32_t lane) {
+  if constexpr (VMODE == 0) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vbuf + lane_off + imm));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vbuf + lane_off + imm + 8 * kVPitch));
+    const s16x8 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, ab);
+  } else {
+    // debugging form: plain 2-byte gathers of the same elements (no assumption about the transposing read)
+    const uint32_t h = lane >> 5, col = lane & 31;
+    s16x8 ab;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t row = 8 * (j >> 2) + 4 * h + (j & 3);
+      ab[j] = *reinterpret_cast<const short*>(vbuf + imm + row * kVPitch + col * 2);
+    }
+    return __builtin_bit_cast(bf16x8, ab);
+  }
+}
+
+template <bool CAUSAL, int VMODE>
+__global__ __launch_bounds__(kWaves * 64) void attention_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  const uint32_t r32 = lane & 31, h = lane >> 5;
+
+  // blockIdx -> (kv head, head in group, query block (heavy first), batch)
+  const uint32_t groups = (uint32_t)(a.H / a.HKV);
+  uint32_t bid = blockIdx.x;
+  const uint32_t kvh = bid % (uint32_t)a.HKV;
+  bid /= (uint32_t)a.HKV;
+  const uint32_t hg = bid % groups;
+  bid /= groups;
+  const uint32_t qb = (uint32_t)a.nqb - 1 - bid % (uint32_t)a.nqb;
+  const uint32_t b = bid / (uint32_t)a.nqb;
+  const uint32_t head = kvh * groups + hg;
+
+  const int32_t q0 = (int32_t)qb * kQBlock;
+  const int32_t qw0 = q0 + (int32_t)wave * kRowsPerWave;
+  const bool wave_valid = qw0 < a.S;
+  const int32_t q_end = q0 + kQBlock < a.S ? q0 + kQBlock : a.S;
+  const int32_t ntiles = (CAUSAL ? q_end : a.S) / kKeys;
+
+  // ---- Q fragments: lane (r32, h) holds columns [(2t+h)*8, +8) of row qw0 + r32, t = 0..7
+  bf16x8 qf[8];
+  {
+    const uint16_t* qrow = a.q + (((size_t)b * a.S + (size_t)(wave_valid ? qw0 + (int32_t)r32 : 0)) * a.H + head) * kD;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qrow + (2 * t + h) * 8);
+      if (!wave_valid) v = u32x4{0, 0, 0, 0};
+      qf[t] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  // ---- K/V staging: thread -> (row = tid / 16 [+32], 16-byte slot = tid % 16)
+  const uint32_t srow = tid >> 4, sslot = tid & 15;
+  const size_t kv_stride = (size_t)a.HKV * kD;  // elements between consecutive keys
+  const uint16_t* kbase = a.k + ((size_t)b * a.S * a.HKV + kvh) * kD + sslot * 8;
+  const uint16_t* vbase = a.v + ((size_t)b * a.S * a.HKV + kvh) * kD + sslot * 8;
+  u32x4 sk[2], sv[2];
+  auto stage_load = [&](int32_t tile) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const size_t row = (size_t)tile * kKeys + srow + 32 * p;
+      sk[p] = *reinterpret_cast<const u32x4*>(kbase + row * kv_stride);
+      sv[p] = *reinterpret_cast<const u32x4*>(vbase + row * kv_stride);
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const uint32_t row = srow + 32 * p;
+      *reinterpret_cast<u32x4*>(smem + buf * kKBytes + row * kKPitch + ((sslot ^ (row & 15)) << 4)) = sk[p];
+      *reinterpret_cast<u32x4*>(smem + 2 * kKBytes + buf * kVBytes + row * kVPitch + (sslot << 4)) = sv[p];
+    }
+  };
+
+  f32x16 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[i][e] = 0.0f;
+  float m_run = -1.0e30f, l_run = 0.0f;
+
+  // per-lane part of the transposing-read address: 16-lane group g = lane / 16 -> (h = g / 2, column half = g % 2),
+  // lane i of the group supplies the address of key row 4h + i / 4, columns 16 (g % 2) + 4 (i % 4) .. + 3
+  const uint32_t i16 = lane & 15, g16 = lane >> 4;
+  const uint32_t vt_lane_off = (4 * (g16 >> 1) + (i16 >> 2)) * kVPitch + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+
+  for (int32_t tile = 0; tile < ntiles; ++tile) {
+    const int buf = tile & 1;
+    const bool more = tile + 1 < ntiles;
+    if (more) stage_load(tile + 1);
+    const int32_t kv0 = tile * kKeys;
+    const bool active = wave_valid && (!CAUSAL || kv0 <= qw0 + kRowsPerWave - 1);
+    if (active) {
+      const unsigned char* kbuf = smem + buf * kKBytes;
+      const unsigned char* vbuf = smem + 2 * kKBytes + buf * kVBytes;
+      // ---- S^T = K Q^T
+      f32x16 s[2];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] = 0.0f;
+        const uint32_t krow = 32 * sub + r32;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbuf + krow * kKPitch + (((2 * t + h) ^ (krow & 15)) << 4));
+          s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], s[sub], 0, 0, 0);
+        }
+      }
+      // ---- causal mask on the diagonal tiles: key kv0 + 32 sub + crow(e, h) against query qw0 + r32
+      if (CAUSAL && kv0 + kKeys - 1 > qw0) {
+        const int32_t qi = qw0 + (int32_t)r32;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int32_t key = kv0 + 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * (int32_t)h;
+            if (key > qi) s[sub][e] = -INFINITY;
+          }
+      }
+      // ---- online softmax (base 2, scores scaled by c = scale * log2 e)
+      float mx = s[0][0];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx * a.c);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      float rs = 0.0f;
+      bf16x8 pf[2][2];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][e], a.c, -m_new));
+          rs += p;
+          pf[sub][e >> 3][e & 7] = (__bf16)p;
+        }
+      l_run = __builtin_fmaf(l_run, alpha, rs);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+      // ---- O^T += V^T P
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int imm = (32 * sub + 16 * u) * kVPitch + 32 * db * 2;
+            const bf16x8 vf = load_vt<VMODE>(vbuf, vt_lane_off, imm, lane);
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sub][u], o[db], 0, 0, 0);
+          }
+    }
+    if (more) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: normalise, bf16, per-wave LDS tile [32 rows][128 d], then whole rows out
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  unsigned char* obuf = smem + wave * (kRowsPerWave * kOPitch);
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      u32x2 w;
+      w.x = pack2<bf16_t>(o[db][4 * rr + 0] * inv, o[db][4 * rr + 1] * inv);
+      w.y = pack2<bf16_t>(o[db][4 * rr + 2] * inv, o[db][4 * rr + 3] * inv);
+      *reinterpret_cast<u32x2*>(obuf + r32 * kOPitch + (32 * db + 8 * rr + 4 * h) * 2) = w;
+    }
+  __syncthreads();
+  if (!wave_valid) return;
+  float sc = 1.0f, of = 0.0f;
+  if (a.codes) {
+    sc = a.scale[0];
+    of = a.offset ? rne(a.offset[0]) : 0.0f;
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const uint32_t slot = it * 64 + lane;
+    const uint32_t row = slot >> 3, seg = slot & 7;
+    Chunk<bf16_t, 16> z;
+    z.load(reinterpret_cast<const bf16_t*>(obuf + row * kOPitch + seg * 32));
+    const size_t at = (((size_t)b * a.S + (size_t)(qw0 + (int32_t)row)) * a.H + head) * kD + seg * 16;
+    if (a.ctx) z.store(reinterpret_cast<bf16_t*>(a.ctx) + at);
+    if (a.codes) {
+      float x[16], r[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[i] = z.get(i);
+      quantize_chunk<1, 16>(x, sc, of, r);
+      Chunk<int8_t, 16> y;
+      finalize_chunk<int8_t, 16>(r, a.lo, a.hi, y);
+      y.store(a.codes + at);
+    }
+  }
+}
+
+}  // namespace
+}  // namespace ffq
+
+using namespace ffq;
+
+extern "C" int ffq_attention(const void* q, const void* k, const void* v, int dt, int64_t batch, int64_t seq_len,
+                             int64_t q_heads, int64_t kv_heads, int64_t head_dim, double softmax_scale, int causal,
+                             void* ctx_out, int8_t* codes_out, const float* out_scale, const float* out_offset,
+                             double out_num_bits, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (batch < 0 || seq_len < 0 || q_heads <= 0 || kv_heads <= 0) return fail(FFQ_ERR_ARG, "bad extent");
+  if (dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "attention is built for bf16 activations");
+  if (head_dim != kD) return fail(FFQ_ERR_DTYPE, "attention is built for head_dim 128");
+  if (seq_len % kKeys != 0) return fail(FFQ_ERR_DTYPE, "attention needs seq_len %% 64 == 0");
+  if (q_heads % kv_heads != 0) return fail(FFQ_ERR_ARG, "q_heads must be a multiple of kv_heads");
+  if (batch == 0 || seq_len == 0) return FFQ_OK;
+  if (!q || !k || !v || (!ctx_out && !codes_out)) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (codes_out && !out_scale) return fail(FFQ_ERR_ARG, "codes need a scale");
+  if (codes_out && !(out_num_bits >= 1.0 && out_num_bits <= 8.0 && out_num_bits == (double)(int)out_num_bits))
+    return fail(FFQ_ERR_ARG, "codes need an integral bit-width in 1..8");
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (ctx_out && !aligned16(ctx_out)) || (codes_out && !aligned16(codes_out)))
+    return fail(FFQ_ERR_ARG, "buffers must be 16-byte aligned");
+  if (batch * seq_len * q_heads * head_dim >= ((int64_t)1 << 40)) return fail(FFQ_ERR_ARG, "too many elements for one launch");
+  AttnArgs a;
+  a.q = static_cast<const uint16_t*>(q); a.k = static_cast<const uint16_t*>(k); a.v = static_cast<const uint16_t*>(v);
+  a.ctx = static_cast<uint16_t*>(ctx_out); a.codes = codes_out; a.scale = out_scale; a.offset = out_offset;
+  a.B = (int32_t)batch; a.S = (int32_t)seq_len; a.H = (int32_t)q_heads; a.HKV = (int32_t)kv_heads;
+  a.nqb = (int32_t)((seq_len + kQBlock - 1) / kQBlock);
+  a.c = (float)(softmax_scale * 1.4426950408889634);
+  const double half = ldexp(1.0, (int)out_num_bits - 1);
+  a.lo = codes_out ? (float)-half : 0.0f;
+  a.hi = codes_out ? (float)(half - 1.0) : 0.0f;
+  const int64_t blocks = (int64_t)a.nqb * q_heads * batch;
+  if (blocks >= ((int64_t)1 << 31)) return fail(FFQ_ERR_ARG, "too many workgroups");
+  static const bool safe_v = getenv("FFQ_ATTN_GATHER_V") != nullptr;  // debugging: plain gathers instead of ds_read_b64_tr_b16
+  const dim3 grid((unsigned)blocks), block(kWaves * 64);
+#define FFQ_ATTN_LAUNCH(C, M)                                                                                        \
+  do {                                                                                                               \
+    static bool once = false;                                                                                        \
+    if (!once) {                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<C, M>),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);                              \
+      once = true;                                                                                                   \
+    }                                                                                                                \
+    attention_fwd_kernel<C, M><<<grid, block, kLdsBytes, s>>>(a);                                                    \
+  } while (0)
+  if (causal) {
+    if (safe_v) FFQ_ATTN_LAUNCH(true, 1); else FFQ_ATTN_LAUNCH(true, 0);
+  } else {
+    if (safe_v) FFQ_ATTN_LAUNCH(false, 1); else FFQ_ATTN_LAUNCH(false, 0);
+  }
+#undef FFQ_ATTN_LAUNCH
+  return check_launch("attention_fwd_kernel");
+}

@@ -307,6 +307,19 @@ def calibrate(model: LlamaModel, batches, sync_free: bool = True, disable_quanti
                 forward(ids)
 
 
+def attention_kernel_covers(cfg: LlamaConfig, seq_len: int, dtype: torch.dtype) -> bool:
+    """Shapes ``ops.attention`` (csrc/ffq_attention.hip) is built for; everything else takes torch's SDPA on the device."""
+    return cfg.head_dim == 128 and seq_len % 64 == 0 and seq_len > 1 and dtype == torch.bfloat16 and cfg.attention == "sdpa"
+
+
+def _sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cfg: LlamaConfig, b: int, s: int) -> torch.Tensor:
+    d = cfg.head_dim
+    return F.scaled_dot_product_attention(
+        q.view(b, s, cfg.num_heads, d).transpose(1, 2), k.view(b, s, cfg.num_kv_heads, d).transpose(1, 2),
+        v.view(b, s, cfg.num_kv_heads, d).transpose(1, 2), is_causal=s > 1, enable_gqa=cfg.num_kv_heads != cfg.num_heads,
+    ).transpose(1, 2).reshape(b, s, -1)
+
+
 class FusedForward:
     """Inference forward of a calibrated W8A8 Llama with A1 fused into the kernels that produce the
     quantized linears' inputs.
@@ -325,7 +338,7 @@ class FusedForward:
     per-channel activations, biases — instead of silently computing something else.
     """
 
-    def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True) -> None:
+    def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True, fuse_attention: bool = True) -> None:
         problems = self.unsupported(model)
         if problems:
             raise ff.exceptions.QuantizationError("FusedForward cannot run this model: " + "; ".join(problems[:4]))
@@ -334,6 +347,8 @@ class FusedForward:
         # gate_proj + up_proj + SiLU*up + the down_proj input quantizer in one launch (ops.mlp_gate_up_w8a8) where
         # both projections see the same activation codes and carry symmetric (zero-offset) weight quantizers
         self.fuse_mlp = fuse_mlp
+        # attention + the o_proj input quantizer in one launch (ops.attention) where the kernel covers the shape
+        self.fuse_attention = fuse_attention
         self._zero_offset: dict[int, tuple[int, bool]] = {}
         self._weight_cache: dict[int, tuple[tuple[int, int, int], torch.Tensor]] = {}
         # when set to a list, every int8 GEMM launch appends (output rows of weight processed, K, start event, end event)
@@ -463,12 +478,13 @@ class FusedForward:
             k = self._linear(codes[index[1]], attn.k_proj)
             v = self._linear(codes[index[2]], attn.v_proj)
             ff.ops.rope_(q, k, cos, sin, d)
-            ctx = F.scaled_dot_product_attention(
-                q.view(b, s, cfg.num_heads, d).transpose(1, 2), k.view(b, s, cfg.num_kv_heads, d).transpose(1, 2),
-                v.view(b, s, cfg.num_kv_heads, d).transpose(1, 2), is_causal=s > 1, enable_gqa=cfg.num_kv_heads != cfg.num_heads,
-            ).transpose(1, 2).reshape(b, s, -1)
             o_in = attn.o_proj.input_quantizer
-            o_codes = ff.ops.quantize_by_tile(ctx, o_in.scale, ctx.shape, o_in.num_bits, torch.int8, o_in.offset)
+            if self.fuse_attention and attention_kernel_covers(cfg, s, q.dtype):
+                # softmax(q k^T) v and o_proj's input quantizer in one launch: the bf16 context never visits HBM
+                _, o_codes = ff.ops.attention(q, k, v, d, causal=s > 1, quantizer=(o_in.scale, o_in.offset), num_bits=o_in.num_bits, want_context=False)
+            else:
+                ctx = _sdpa(q, k, v, cfg, b, s)
+                o_codes = ff.ops.quantize_by_tile(ctx, o_in.scale, ctx.shape, o_in.num_bits, torch.int8, o_in.offset)
             attn_out = self._linear(o_codes, attn.o_proj)
             pairs, index = fan["gate_up"]
             hidden, _, codes = ff.ops.add_rmsnorm_quantize(
@@ -547,10 +563,10 @@ class FusedCalibrationForward:
                 hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, ln1.weight, ln1.variance_epsilon, (), want_norm=True, sum_inplace=pending is not None)
                 q, k, v = self._linear(normed, attn.q_proj), self._linear(normed, attn.k_proj), self._linear(normed, attn.v_proj)
                 ff.ops.rope_(q, k, cos, sin, d)
-                ctx = F.scaled_dot_product_attention(
-                    q.view(b, s, cfg.num_heads, d).transpose(1, 2), k.view(b, s, cfg.num_kv_heads, d).transpose(1, 2),
-                    v.view(b, s, cfg.num_kv_heads, d).transpose(1, 2), is_causal=s > 1, enable_gqa=cfg.num_kv_heads != cfg.num_heads,
-                ).transpose(1, 2).reshape(b, s, -1)
+                if attention_kernel_covers(cfg, s, q.dtype):
+                    ctx, _ = ff.ops.attention(q, k, v, d, causal=s > 1)
+                else:
+                    ctx = _sdpa(q, k, v, cfg, b, s)
                 attn_out = self._linear(ctx, attn.o_proj)
                 hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, attn_out, ln2.weight, ln2.variance_epsilon, (), want_norm=True, sum_inplace=True)
                 gate, up = self._linear(normed, mlp.gate_proj), self._linear(normed, mlp.up_proj)

@@ -41,6 +41,7 @@ __all__ = [
     "add_rmsnorm_quantize",
     "silu_mul_quantize",
     "rope_",
+    "attention",
     "FLAG_INF",
     "FLAG_NAN",
 ]
@@ -742,6 +743,50 @@ def rope_(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor
             _ptr(cos), _ptr(sin), stream,
         )
     )
+
+
+def attention(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    head_dim: int,
+    causal: bool = True,
+    quantizer: tuple[torch.Tensor, torch.Tensor | None] | None = None,
+    num_bits: float = 8.0,
+    want_context: bool = True,
+    softmax_scale: float | None = None,
+) -> tuple[torch.Tensor | None, torch.Tensor | None]:
+    """Attention on the projections as they leave q/k/v_proj — ``q`` ``[batch, seq, heads * head_dim]``, ``k`` / ``v``
+    ``[batch, seq, kv_heads * head_dim]``, rotary embedding already applied — as one flash-style launch (reference
+    quantized_llama/attention.py:45-92), optionally with the static per-tensor input quantizer of ``o_proj`` (A1)
+    fused in. Returns ``(context [batch, seq, heads * head_dim] or None, int8 codes or None)``."""
+    if not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+        raise RuntimeError("attention expects contiguous projections")
+    if q.dim() != 3 or k.dim() != 3 or k.shape != v.shape or q.shape[:2] != k.shape[:2] or q.shape[2] % head_dim or k.shape[2] % head_dim:
+        raise RuntimeError("attention expects q [batch, seq, heads * head_dim] and k / v [batch, seq, kv_heads * head_dim]")
+    if not (q.dtype == k.dtype == v.dtype):
+        raise RuntimeError("attention expects one dtype")
+    if quantizer is None and not want_context:
+        raise RuntimeError("attention: nothing to compute (no context, no codes)")
+    scale = offset = codes = None
+    if quantizer is not None:
+        scale = quantizer[0].detach().reshape(-1).to(torch.float32)
+        offset = None if quantizer[1] is None else quantizer[1].detach().reshape(-1).to(torch.float32)
+        if scale.numel() != 1 or (offset is not None and offset.numel() != 1):
+            raise RuntimeError("the fused quantizer is per-tensor (one scale, one offset)")
+    lib, stream = _prepare(q, k, v, scale, offset)
+    if quantizer is not None:
+        codes = torch.empty(q.shape, dtype=torch.int8, device=q.device)
+    ctx = torch.empty_like(q) if want_context else None
+    b, s, _ = q.shape
+    lib.check(
+        lib.ffq_attention(
+            _ptr(q), _ptr(k), _ptr(v), _tag(q.dtype), b, s, q.shape[2] // head_dim, k.shape[2] // head_dim, head_dim,
+            float(head_dim**-0.5 if softmax_scale is None else softmax_scale), int(bool(causal)),
+            _ptr(ctx), _ptr(codes), _ptr(scale), _ptr(offset), float(num_bits), stream,
+        )
+    )
+    return ctx, codes
 
 
 # ---------------------------------------------------------------------------------------------

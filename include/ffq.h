@@ -326,6 +326,24 @@ int ffq_gptq_block(float* weights, float* quantized, float* errors, int64_t rows
                    int64_t col0, int64_t block_cols, const float* hinv, int64_t hinv_stride, const float* scale,
                    int64_t scale_numel, const float* offset, int64_t offset_numel, double num_bits, void* stream);
 
+/*
+ * The attention between q/k/v_proj and o_proj of the reference's quantized Llama —
+ * docs/examples/doc_helpers/quantized_llama/attention.py:45-92 (repeat_kv, matmul, * scaling, causal mask, fp32
+ * softmax, cast, matmul; the attn_weights / attn_probs / attn_output quantizers are stubs in the recipe) — with the
+ * input quantizer of o_proj (nn/linear.py:33 -> A1, static per-tensor) applied to the context in the same launch:
+ *   ctx[b, s, h, :] = softmax_j( q[b, s, h, :] . k[b, j, h / (q_heads / kv_heads), :] * softmax_scale ;  j <= s if causal ) @ v
+ *   codes = A1(ctx; out_scale, out_offset, out_num_bits)          (bit-identical to ffq_quantize_by_tile on this ctx)
+ * q: [batch, seq_len, q_heads, head_dim], k / v: [batch, seq_len, kv_heads, head_dim] as they leave the projections
+ * (rotary embedding already applied), ctx_out / codes_out: [batch, seq_len, q_heads * head_dim]; either output is
+ * nullable. bf16 operands, fp32 accumulation and softmax (one pass, online softmax; no seq x seq matrix in HBM), so
+ * ctx agrees with the eager chain to bf16 rounding (tolerance in tests/parity_cases.py::check_attention).
+ * head_dim == 128, seq_len % 64 == 0, bf16 only: anything else returns FFQ_ERR_DTYPE.
+ */
+int ffq_attention(const void* q, const void* k, const void* v, int dt, int64_t batch, int64_t seq_len,
+                  int64_t q_heads, int64_t kv_heads, int64_t head_dim, double softmax_scale, int causal,
+                  void* ctx_out, int8_t* codes_out, const float* out_scale, const float* out_offset,
+                  double out_num_bits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

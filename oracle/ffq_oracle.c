@@ -1030,3 +1030,80 @@ int ffq_gptq_block(float* weights, float* quantized, float* errors, int64_t rows
   free(w);
   return FFQ_OK;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Attention of the quantized Llama helper, docs/examples/doc_helpers/quantized_llama/         */
+/* attention.py:45-92, op by op with every tensor in bf16 as the eager chain keeps it:         */
+/*   repeat_kv (:57-58); weights = bf16(q @ k^T) (:60-64, fp32 accumulation in the matmul);    */
+/*   weights = bf16(weights * scaling) (:65); weights = bf16(weights + mask) (:67-68, mask =   */
+/*   0 / finfo(bf16).min above the diagonal); softmax in fp32, cast to bf16 (:70-74);          */
+/*   out = bf16(weights @ v) (:83-85); transpose / reshape to [batch, seq, heads * head_dim]   */
+/*   (:87-88). Then the input quantizer of o_proj (nn/linear.py:33 -> A1).                     */
+/* ------------------------------------------------------------------------------------------ */
+int ffq_attention(const void* q, const void* k, const void* v, int dt, int64_t batch, int64_t seq_len,
+                  int64_t q_heads, int64_t kv_heads, int64_t head_dim, double softmax_scale, int causal,
+                  void* ctx_out, int8_t* codes_out, const float* out_scale, const float* out_offset,
+                  double out_num_bits, void* stream) {
+  (void)stream;
+  if (batch < 0 || seq_len < 0 || q_heads <= 0 || kv_heads <= 0) return fail(FFQ_ERR_ARG, "bad extent");
+  if (dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "attention is built for bf16 activations");
+  if (head_dim != 128) return fail(FFQ_ERR_DTYPE, "attention is built for head_dim 128");
+  if (seq_len % 64 != 0) return fail(FFQ_ERR_DTYPE, "attention needs seq_len %% 64 == 0");
+  if (q_heads % kv_heads != 0) return fail(FFQ_ERR_ARG, "q_heads must be a multiple of kv_heads");
+  if (batch == 0 || seq_len == 0) return FFQ_OK;
+  if (!q || !k || !v || (!ctx_out && !codes_out)) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (codes_out && !out_scale) return fail(FFQ_ERR_ARG, "codes need a scale");
+  if (codes_out && !(out_num_bits >= 1.0 && out_num_bits <= 8.0 && out_num_bits == floor(out_num_bits)))
+    return fail(FFQ_ERR_ARG, "codes need an integral bit-width in 1..8");
+  const uint16_t* qp = (const uint16_t*)q;
+  const uint16_t* kp = (const uint16_t*)k;
+  const uint16_t* vp = (const uint16_t*)v;
+  const int64_t groups = q_heads / kv_heads;
+  const float scaling = (float)softmax_scale;
+  const float mask_min = bits_f32(0xFF7F0000u); /* torch.finfo(torch.bfloat16).min */
+  const double lo = -pow(2.0, out_num_bits - 1.0), hi = -lo - 1.0;
+  float* w = (float*)malloc((size_t)seq_len * sizeof(float));
+  float* acc = (float*)malloc((size_t)head_dim * sizeof(float));
+  for (int64_t b = 0; b < batch; ++b)
+    for (int64_t hd = 0; hd < q_heads; ++hd) {
+      const int64_t kvh = hd / groups;
+      for (int64_t i = 0; i < seq_len; ++i) {
+        const uint16_t* qrow = qp + ((b * seq_len + i) * q_heads + hd) * head_dim;
+        float mx = -INFINITY;
+        for (int64_t j = 0; j < seq_len; ++j) {
+          const uint16_t* krow = kp + ((b * seq_len + j) * kv_heads + kvh) * head_dim;
+          float dot = 0.0f;
+          for (int64_t d = 0; d < head_dim; ++d) dot += bf16_to_f32(qrow[d]) * bf16_to_f32(krow[d]);
+          float s = bf16_round(bf16_round(dot) * scaling);
+          if (causal) s = bf16_round(s + (j > i ? mask_min : 0.0f));
+          w[j] = s;
+          if (s > mx) mx = s;
+        }
+        float sum = 0.0f;
+        for (int64_t j = 0; j < seq_len; ++j) { w[j] = expf(w[j] - mx); sum += w[j]; }
+        for (int64_t d = 0; d < head_dim; ++d) acc[d] = 0.0f;
+        for (int64_t j = 0; j < seq_len; ++j) {
+          const float p = bf16_round(w[j] / sum);
+          if (p == 0.0f) continue;
+          const uint16_t* vrow = vp + ((b * seq_len + j) * kv_heads + kvh) * head_dim;
+          for (int64_t d = 0; d < head_dim; ++d) acc[d] += p * bf16_to_f32(vrow[d]);
+        }
+        const int64_t at = ((b * seq_len + i) * q_heads + hd) * head_dim;
+        for (int64_t d = 0; d < head_dim; ++d) {
+          const float z = bf16_round(acc[d]);
+          if (ctx_out) ((uint16_t*)ctx_out)[at + d] = f32_to_bf16(z);
+          if (codes_out) {
+            const float s = out_scale[0];
+            const float o = out_offset ? nearbyintf(out_offset[0]) : 0.0f;
+            float c = z / s;
+            c = c - o;
+            c = nearbyintf(c);
+            st(codes_out, FFQ_I8, at + d, clamp_nan((double)c, lo, hi));
+          }
+        }
+      }
+    }
+  free(w);
+  free(acc);
+  return FFQ_OK;
+}

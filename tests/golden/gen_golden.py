@@ -535,6 +535,44 @@ def g13_gptq():
     return cases
 
 
+def g14_attention():
+    """The attention of the reference's quantized Llama helper between the projections and o_proj
+    (quantized_llama/attention.py:57-88) in bf16 on CPU, with the ops the helper itself calls — HF's repeat_kv,
+    FFF.matmul, `* scaling`, the additive causal mask, FFF.softmax in fp32, FFF.matmul — followed by an 8-bit
+    asymmetric per-tensor quantizer standing for o_proj's input quantizer (nn/linear.py:33)."""
+    import fastforward.nn.functional as FFF
+    from transformers.models.llama.modeling_llama import repeat_kv
+
+    def quantize(t, bits=8):
+        lo, hi = t.float().min(), t.float().max()
+        scale, offset = parameters_for_range(lo, hi, bits, symmetric=False, allow_one_sided=True)
+        q = affine.quantize_per_tensor(t, scale, offset, bits, torch.int8)
+        return {"scale": scale.reshape(1).clone(), "offset": offset.reshape(1).clone(), "codes": q.raw_data.clone()}
+
+    out = {}
+    torch.manual_seed(1254)
+    d = 128
+    for name, (b, s_, heads, kv_heads, causal, spread) in {
+        "causal_gqa_128": (2, 128, 4, 2, True, 1.0), "causal_mha_192": (1, 192, 2, 2, True, 2.0),
+        "causal_gqa_320": (1, 320, 4, 1, True, 1.0), "full_gqa_64": (1, 64, 4, 2, False, 1.5),
+    }.items():
+        q = (torch.randn(b, s_, heads * d) * spread).to(torch.bfloat16)
+        k = (torch.randn(b, s_, kv_heads * d) * spread).to(torch.bfloat16)
+        v = torch.randn(b, s_, kv_heads * d).to(torch.bfloat16)
+        with ff.strict_quantization(False), torch.no_grad():
+            qs = q.view(b, s_, heads, d).transpose(1, 2)
+            ks = repeat_kv(k.view(b, s_, kv_heads, d).transpose(1, 2), heads // kv_heads)
+            vs = repeat_kv(v.view(b, s_, kv_heads, d).transpose(1, 2), heads // kv_heads)
+            weights = FFF.matmul(qs, ks.transpose(2, 3)) * (d**-0.5)
+            if causal:
+                mask = torch.full((s_, s_), torch.finfo(torch.bfloat16).min, dtype=torch.bfloat16).triu(1)
+                weights = weights + mask[None, None]
+            weights = FFF.softmax(weights.to(torch.float32), dim=-1).to(qs.dtype)
+            ctx = FFF.matmul(weights, vs).transpose(1, 2).contiguous().reshape(b, s_, -1)
+        out[name] = {"q": q, "k": k, "v": v, "head_dim": d, "causal": causal, "context": ctx.clone(), "quantized": quantize(ctx)}
+    return out
+
+
 def main() -> None:
     torch.set_num_threads(8)
     if len(sys.argv) > 1:  # regenerate only the named fixtures, e.g. `gen_golden.py g10_producers`
@@ -556,6 +594,7 @@ def main() -> None:
     torch.save(g11_backward(), HERE / "g11_backward.pt")
     torch.save(g12_mse_grid(), HERE / "g12_mse_grid.pt")
     torch.save(g13_gptq(), HERE / "g13_gptq.pt")
+    torch.save(g14_attention(), HERE / "g14_attention.pt")
     for f in sorted(HERE.glob("*.pt")):
         print(f"{f.name}: {f.stat().st_size / 1024:.0f} KiB")
 

@@ -240,6 +240,70 @@ def check_producers(device):
         ops.silu_mul_quantize(x, x[:1])
 
 
+def attention_reference64(q, k, v, head_dim, causal):
+    """softmax(q k^T / sqrt(d) [+ causal mask]) v in float64 on the bf16 inputs: [batch, seq, heads * head_dim]."""
+    b, s_, _ = q.shape
+    heads, kv_heads = q.shape[2] // head_dim, k.shape[2] // head_dim
+    qs = q.double().view(b, s_, heads, head_dim).transpose(1, 2)
+    ks = k.double().view(b, s_, kv_heads, head_dim).transpose(1, 2).repeat_interleave(heads // kv_heads, dim=1)
+    vs = v.double().view(b, s_, kv_heads, head_dim).transpose(1, 2).repeat_interleave(heads // kv_heads, dim=1)
+    w = qs @ ks.transpose(2, 3) * head_dim**-0.5
+    if causal:
+        w = w.masked_fill(torch.ones(s_, s_, dtype=torch.bool, device=q.device).triu(1), float("-inf"))
+    return (torch.softmax(w, dim=-1) @ vs).transpose(1, 2).reshape(b, s_, -1)
+
+
+# Attention is a floating-point kernel. The reference's eager chain rounds scores, scaled scores, probabilities and
+# the context to bf16 (attention.py:60-88) — with |score| up to ~30 in G14 a bf16 score carries an error of 2^-4, so
+# the reference itself sits up to 7e-2 away from the float64 value of the same bf16 inputs. The flash-style launch keeps
+# scores and the context sum in fp32 and rounds only the un-normalised probabilities and the result: it must stay
+# within ATTENTION_ATOL of the float64 value (|context| <= ~4.5 here: one bf16 ulp of the largest outputs) and may
+# never be less accurate than the reference is.
+ATTENTION_ATOL = 2.0**-6
+
+
+def check_attention(device, exact_chain=False):
+    """G14: the reference's attention chain + o_proj input quantizer. `exact_chain`: the implementation follows the
+    eager chain op by op (the oracle), so it must reproduce the fixture on nearly every element."""
+    g = golden("g14_attention.pt")
+    for name, c in g.items():
+        q, k, v = c["q"].to(device), c["k"].to(device), c["v"].to(device)
+        qp = c["quantized"]
+        quantizer = (qp["scale"].to(device), qp["offset"].to(device))
+        ctx, codes = ops.attention(q, k, v, c["head_dim"], causal=c["causal"], quantizer=quantizer)
+        want64 = attention_reference64(c["q"], c["k"], c["v"], c["head_dim"], c["causal"])
+        err_got = float((ctx.cpu().double() - want64).abs().max())
+        err_ref = float((c["context"].double() - want64).abs().max())
+        ulps = _ulps_bf16(ctx.cpu(), c["context"])
+        if not exact_chain:
+            assert err_got <= ATTENTION_ATOL and err_got <= err_ref + 2.0**-9, f"{name}: {err_got:.3e} from float64, reference {err_ref:.3e}"
+        else:
+            # (fp32 summation order inside the two matmuls is the only freedom: a rare 1-ulp flip of a score or a probability)
+            worst = float((ctx.cpu().float() - c["context"].float()).abs().max())
+            assert worst <= 2.0**-7 and float((ulps > 0).float().mean()) < 0.005, f"{name}: {worst:.3e} off, {float((ulps > 0).float().mean()):.4f} differ"
+        # the codes are exactly A1 of the context this call produced; where the context equals the reference's, so do the codes
+        assert torch.equal(codes, ops.quantize_by_tile(ctx, quantizer[0], ctx.shape, 8, torch.int8, quantizer[1])), name
+        same = ulps == 0
+        assert torch.equal(codes.cpu()[same], qp["codes"][same]), name
+        off = (codes.cpu().int() - qp["codes"].int()).abs()
+        bound = int((err_got + err_ref) / float(qp["scale"])) + 1
+        assert int(off.max()) <= bound, f"{name}: codes off by {int(off.max())} > {bound}"
+        # outputs are optional
+        only_ctx, none = ops.attention(q, k, v, c["head_dim"], causal=c["causal"])
+        assert none is None and torch.equal(only_ctx, ctx), name
+        none, only_codes = ops.attention(q, k, v, c["head_dim"], causal=c["causal"], quantizer=quantizer, want_context=False)
+        assert none is None and torch.equal(only_codes, codes), name
+    import pytest
+
+    x = torch.zeros(1, 64, 256, dtype=torch.bfloat16, device=device)
+    with pytest.raises(NotImplementedError):
+        ops.attention(x, x, x, 64)            # head_dim 64
+    with pytest.raises(NotImplementedError):
+        ops.attention(x[:, :48], x[:, :48], x[:, :48], 128)   # seq 48
+    with pytest.raises(RuntimeError):
+        ops.attention(x, x[:, :32], x[:, :32], 128)
+
+
 def _backward_terms64(c):
     """Per-element gradient terms of fixture case `c` in float64 (an independent statement of the formulas),
     as rows per tile: (dscale terms, doffset terms)."""

@@ -151,6 +151,29 @@ def test_fused_forward_matches_module_graph_on_gpu(hip_backend):
     check_fused_against_module_graph(golden("g7_tiny_llama.pt"), "cuda")
 
 
+@pytest.mark.gpu
+def test_fused_forward_with_the_attention_kernel_on_gpu(hip_backend):
+    """head_dim 128 and a sequence length the attention launch covers: FusedForward takes ops.attention (attention + the
+    o_proj input quantizer in one launch) and stays as close to the module graph as with torch's SDPA in its place."""
+    torch.manual_seed(7)
+    cfg = llama.LlamaConfig(hidden_size=512, intermediate_size=1024, num_layers=2, num_heads=4, num_kv_heads=2, vocab_size=512)
+    assert cfg.head_dim == 128
+    model = llama.build_model(cfg, "cuda", torch.bfloat16, seed=11, std=0.05)
+    llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
+    ids = torch.randint(0, cfg.vocab_size, (2, 192), device="cuda")
+    llama.calibrate(model, [ids, torch.randint(0, cfg.vocab_size, (2, 192), device="cuda")], fused=True)
+    assert llama.attention_kernel_covers(cfg, 192, torch.bfloat16)
+    with torch.no_grad(), ff.strict_quantization(False):
+        want = model(ids).float().cpu()
+    spread = float(want.std())
+    with_kernel = llama.FusedForward(model)(ids).float().cpu()
+    with_sdpa = llama.FusedForward(model, fuse_attention=False)(ids).float().cpu()
+    for got in (with_kernel, with_sdpa):
+        err = got - want
+        assert float(err.pow(2).mean().sqrt()) < 0.01 * spread and float(err.abs().max()) < 0.25 * spread
+    assert float((with_kernel - with_sdpa).pow(2).mean().sqrt()) < 0.01 * spread
+
+
 def check_fused_calibration(fixture, device):
     """Calibrating through FusedCalibrationForward (every quantizer's own forward with its estimator override, fused
     producers in between) gives the module graph's ranges: weight quantizers exactly, activation ranges within the

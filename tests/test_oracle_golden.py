@@ -51,6 +51,10 @@ def test_fused_producers_rmsnorm_silu_rope():
     parity_cases.check_producers("cpu")
 
 
+def test_attention_chain_and_fused_output_quantizer():
+    parity_cases.check_attention("cpu", exact_chain=True)
+
+
 def test_quantize_by_tile_backward():
     parity_cases.check_backward("cpu")
 

@@ -69,6 +69,10 @@ def test_fused_producers_rmsnorm_silu_rope():
     parity_cases.check_producers(DEV)
 
 
+def test_attention_and_fused_output_quantizer():
+    parity_cases.check_attention(DEV)
+
+
 def test_quantize_by_tile_backward():
     parity_cases.check_backward(DEV)
 
