@@ -46,6 +46,7 @@ from fastforward_amd import distributed as ffd  # noqa: E402
 from fastforward_amd import llama, ops  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide)
 INT8_PEAK_TOPS = 5000.0    # dense int8 MFMA peak = 2 x the 2.5 PF dense bf16 peak (same guide)
 
 
@@ -212,6 +213,29 @@ def hbm_kernels(device: torch.device) -> list[dict]:
     return rows
 
 
+def attention_kernel(config: llama.LlamaConfig, batch: int, seq_len: int, device: torch.device) -> dict | None:
+    """The second MFMA-bound launch of the step: causal attention + the o_proj input quantizer (csrc/ffq_attention.hip),
+    timed on the forward's shape with N(0,1) operands; flops = 4 * B * H * S^2 * D / 2 (the causal half), peak = dense bf16."""
+    if not llama.attention_kernel_covers(config, seq_len, torch.bfloat16):
+        return None
+    h, hk, d = config.num_heads, config.num_kv_heads, config.head_dim
+    qs = [torch.randn(batch, seq_len, h * d, device=device, dtype=torch.bfloat16) for _ in range(2)]
+    ks = [torch.randn(batch, seq_len, hk * d, device=device, dtype=torch.bfloat16) for _ in range(2)]
+    vs = [torch.randn(batch, seq_len, hk * d, device=device, dtype=torch.bfloat16) for _ in range(2)]
+    sc, of = torch.tensor([0.03], device=device), torch.tensor([-3.0], device=device)
+    ms = event_time_ms(lambda r: ops.attention(qs[r % 2], ks[r % 2], vs[r % 2], d, causal=True, quantizer=(sc, of), want_context=False), iters=10, reps=8)
+    flops = 4.0 * batch * h * seq_len * seq_len * d / 2
+    import torch.nn.functional as F
+    ms_sdpa = event_time_ms(lambda r: F.scaled_dot_product_attention(
+        qs[r % 2].view(batch, seq_len, h, d).transpose(1, 2), ks[r % 2].view(batch, seq_len, hk, d).transpose(1, 2),
+        vs[r % 2].view(batch, seq_len, hk, d).transpose(1, 2), is_causal=True, enable_gqa=h != hk), iters=5, reps=4)
+    return {"op": "causal GQA attention + o_proj input quantizer (bf16 q/k/v -> int8 codes), one launch per layer", "kernel": "attention_fwd_kernel<true>",
+            "bound": "mfma", "shape": {"batch": batch, "seq_len": seq_len, "q_heads": h, "kv_heads": hk, "head_dim": d},
+            "algorithmic_flops": flops, "ms": round(ms, 4), "achieved": round(flops / ms / 1e9, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flops / ms / 1e9 / BF16_PEAK_TFLOPS, 4),
+            "torch_sdpa_same_shape": {"ms": round(ms_sdpa, 4), "TFLOP/s": round(flops / ms_sdpa / 1e9, 1), "note": "attention only (AOTriton flash); the o_proj quantizer is a separate pass there"}}
+
+
 def cpu_baseline(config: llama.LlamaConfig, budget_s: float = 20.0) -> dict:
     """The reference's eager chain on this box's host cores: the 7 W8A8 linears of ONE decoder layer
     (quantize x, re-quantize W, dequantize both, bf16 F.linear) on a token sample sized to ~budget_s."""
@@ -372,6 +396,8 @@ def main() -> None:
         torch.cuda.empty_cache()
         result["roofline"] = gemm_roofline(config, args.batch * args.seq_len, device, fused, batch)
         result["hbm_kernels"] = hbm_kernels(device)
+        if fused is not None:
+            result["attention_kernel"] = attention_kernel(config, args.batch, args.seq_len, device)
         if world == 1:
             result["cpu_baseline"] = cpu_baseline(config)
     if rank == 0:

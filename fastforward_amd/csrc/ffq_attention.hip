@@ -28,6 +28,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+
 namespace ffq {
 namespace {
 
@@ -46,6 +47,7 @@ constexpr int kVPitch = 320;        // bytes per V row in LDS (64-byte skew per 
 constexpr int kKBytes = kKeys * kKPitch;
 constexpr int kVBytes = kKeys * kVPitch;
 constexpr int kLdsBytes = 2 * kKBytes + 2 * kVBytes;   // 73728
+constexpr float kDefer = 8.0f;      // log2 of the growth of a row maximum tolerated before O / l are rescaled
 constexpr int kOPitch = 272;        // bytes per output row in the epilogue image
 static_assert(kWaves * kRowsPerWave * kOPitch <= kLdsBytes, "epilogue image must fit the K/V ring");
 
@@ -63,30 +65,22 @@ struct AttnArgs {
   float lo, hi;           // clamp bounds of the codes
 };
 
-// V^T fragment of one MFMA: 8 keys x 1 column per lane = two transposing reads.
-template <int VMODE>
-__device__ __forceinline__ bf16x8 load_vt(const unsigned char* vbuf, uint32_t lane_off, int imm, uint32_t lane) {
-  if constexpr (VMODE == 0) {
-    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vbuf + lane_off + imm));
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vbuf + lane_off + imm + 8 * kVPitch));
-    const s16x8 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, ab);
-  } else {
-    // debugging form: plain 2-byte gathers of the same elements (no assumption about the transposing read)
-    const uint32_t h = lane >> 5, col = lane & 31;
-    s16x8 ab;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t row = 8 * (j >> 2) + 4 * h + (j & 3);
-      ab[j] = *reinterpret_cast<const short*>(vbuf + imm + row * kVPitch + col * 2);
-    }
-    return __builtin_bit_cast(bf16x8, ab);
-  }
+// V^T fragment of one MFMA: 8 keys x 1 column per lane = two transposing reads (ds_read_b64_tr_b16: lane i of a 16-lane
+// group supplies the address of 4 consecutive bf16 — key row i / 4, columns 4 (i % 4) .. + 3 of a [4 keys][16 columns]
+// block — and receives column i of that block, keys 0..3).
+__device__ __forceinline__ bf16x8 load_vt(const unsigned char* vbuf, uint32_t lane_off, int imm) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vbuf + lane_off + imm));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(vbuf + lane_off + imm + 8 * kVPitch));
+  const s16x8 ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, ab);
 }
 
-template <bool CAUSAL, int VMODE>
+template <bool CAUSAL>
 __global__ __launch_bounds__(kWaves * 64) void attention_fwd_kernel(AttnArgs a) {
+  constexpr int QBLOCK = kQBlock;                 // query rows per workgroup
+  constexpr int PASSES = kKeys / (kWaves * 4);    // staging passes: kWaves * 4 rows of 16 slots each
+
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -103,10 +97,10 @@ __global__ __launch_bounds__(kWaves * 64) void attention_fwd_kernel(AttnArgs a) 
   const uint32_t b = bid / (uint32_t)a.nqb;
   const uint32_t head = kvh * groups + hg;
 
-  const int32_t q0 = (int32_t)qb * kQBlock;
+  const int32_t q0 = (int32_t)qb * QBLOCK;
   const int32_t qw0 = q0 + (int32_t)wave * kRowsPerWave;
   const bool wave_valid = qw0 < a.S;
-  const int32_t q_end = q0 + kQBlock < a.S ? q0 + kQBlock : a.S;
+  const int32_t q_end = q0 + QBLOCK < a.S ? q0 + QBLOCK : a.S;
   const int32_t ntiles = (CAUSAL ? q_end : a.S) / kKeys;
 
   // ---- Q fragments: lane (r32, h) holds columns [(2t+h)*8, +8) of row qw0 + r32, t = 0..7
@@ -126,19 +120,19 @@ __global__ __launch_bounds__(kWaves * 64) void attention_fwd_kernel(AttnArgs a) 
   const size_t kv_stride = (size_t)a.HKV * kD;  // elements between consecutive keys
   const uint16_t* kbase = a.k + ((size_t)b * a.S * a.HKV + kvh) * kD + sslot * 8;
   const uint16_t* vbase = a.v + ((size_t)b * a.S * a.HKV + kvh) * kD + sslot * 8;
-  u32x4 sk[2], sv[2];
+  u32x4 sk[PASSES], sv[PASSES];
   auto stage_load = [&](int32_t tile) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const size_t row = (size_t)tile * kKeys + srow + 32 * p;
+    for (int p = 0; p < PASSES; ++p) {
+      const size_t row = (size_t)tile * kKeys + srow + kWaves * 4 * p;
       sk[p] = *reinterpret_cast<const u32x4*>(kbase + row * kv_stride);
       sv[p] = *reinterpret_cast<const u32x4*>(vbase + row * kv_stride);
     }
   };
   auto stage_store = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const uint32_t row = srow + 32 * p;
+    for (int p = 0; p < PASSES; ++p) {
+      const uint32_t row = srow + kWaves * 4 * p;
       *reinterpret_cast<u32x4*>(smem + buf * kKBytes + row * kKPitch + ((sslot ^ (row & 15)) << 4)) = sk[p];
       *reinterpret_cast<u32x4*>(smem + 2 * kKBytes + buf * kVBytes + row * kVPitch + (sslot << 4)) = sv[p];
     }
@@ -169,19 +163,29 @@ __global__ __launch_bounds__(kWaves * 64) void attention_fwd_kernel(AttnArgs a) 
     if (active) {
       const unsigned char* kbuf = smem + buf * kKBytes;
       const unsigned char* vbuf = smem + 2 * kKBytes + buf * kVBytes;
-      // ---- S^T = K Q^T
+      // ---- S^T = K Q^T: all 16 K fragments requested up front (one LDS latency per tile, not one per MFMA), the two
+      //      32-key halves accumulate alternately so consecutive MFMAs are independent
       f32x16 s[2];
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
+      for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[sub][e] = 0.0f;
-        const uint32_t krow = 32 * sub + r32;
+      bf16x8 kf[2][8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbuf + krow * kKPitch + (((2 * t + h) ^ (krow & 15)) << 4));
-          s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], s[sub], 0, 0, 0);
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          const uint32_t krow = 32 * sub + r32;
+          kf[sub][t] = *reinterpret_cast<const bf16x8*>(kbuf + krow * kKPitch + (((2 * t + h) ^ (krow & 15)) << 4));
         }
-      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+          s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][t], qf[t], s[sub], 0, 0, 0);
+      // keep that order: the scheduler otherwise pairs each read with its MFMA to save registers
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);  // 16 DS reads
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // 16 MFMAs
       // ---- causal mask on the diagonal tiles: key kv0 + 32 sub + crow(e, h) against query qw0 + r32
       if (CAUSAL && kv0 + kKeys - 1 > qw0) {
         const int32_t qi = qw0 + (int32_t)r32;
@@ -200,24 +204,32 @@ __global__ __launch_bounds__(kWaves * 64) void attention_fwd_kernel(AttnArgs a) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run, mx * a.c);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
+      // Deferred rescale: while no row's maximum grows by more than 2^kDefer the running maximum stays where it is (the
+      // probabilities of this tile are then bounded by 2^kDefer instead of 1, harmless in bf16 / fp32) and the 64
+      // accumulator registers are not touched. The decision is wave-uniform and taken before this tile's P exists, so
+      // everything at the old scale (O, l) is rescaled exactly once and nothing at the new scale is.
+      const float mxs = mx * a.c;
+      if (!__all(mxs - m_run <= kDefer)) {
+        const float m_new = fmaxf(m_run, mxs);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+      }
       float rs = 0.0f;
       bf16x8 pf[2][2];
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][e], a.c, -m_new));
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][e], a.c, -m_run));
           rs += p;
           pf[sub][e >> 3][e & 7] = (__bf16)p;
         }
-      l_run = __builtin_fmaf(l_run, alpha, rs);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+      l_run += rs;
       // ---- O^T += V^T P
 #pragma unroll
       for (int db = 0; db < 4; ++db)
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(kWaves * 64) void attention_fwd_kernel(AttnArgs a) 
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int imm = (32 * sub + 16 * u) * kVPitch + 32 * db * 2;
-            const bf16x8 vf = load_vt<VMODE>(vbuf, vt_lane_off, imm, lane);
+            const bf16x8 vf = load_vt(vbuf, vt_lane_off, imm);
             o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sub][u], o[db], 0, 0, 0);
           }
     }
@@ -308,23 +320,14 @@ extern "C" int ffq_attention(const void* q, const void* k, const void* v, int dt
   a.hi = codes_out ? (float)(half - 1.0) : 0.0f;
   const int64_t blocks = (int64_t)a.nqb * q_heads * batch;
   if (blocks >= ((int64_t)1 << 31)) return fail(FFQ_ERR_ARG, "too many workgroups");
-  static const bool safe_v = getenv("FFQ_ATTN_GATHER_V") != nullptr;  // debugging: plain gathers instead of ds_read_b64_tr_b16
-  const dim3 grid((unsigned)blocks), block(kWaves * 64);
-#define FFQ_ATTN_LAUNCH(C, M)                                                                                        \
-  do {                                                                                                               \
-    static bool once = false;                                                                                        \
-    if (!once) {                                                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<C, M>),                           \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);                              \
-      once = true;                                                                                                   \
-    }                                                                                                                \
-    attention_fwd_kernel<C, M><<<grid, block, kLdsBytes, s>>>(a);                                                    \
-  } while (0)
-  if (causal) {
-    if (safe_v) FFQ_ATTN_LAUNCH(true, 1); else FFQ_ATTN_LAUNCH(true, 0);
-  } else {
-    if (safe_v) FFQ_ATTN_LAUNCH(false, 1); else FFQ_ATTN_LAUNCH(false, 0);
+  static bool once = false;
+  if (!once) {  // 72 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    once = true;
   }
-#undef FFQ_ATTN_LAUNCH
+  const dim3 grid((unsigned)blocks), block(kWaves * 64);
+  if (causal) attention_fwd_kernel<true><<<grid, block, kLdsBytes, s>>>(a);
+  else attention_fwd_kernel<false><<<grid, block, kLdsBytes, s>>>(a);
   return check_launch("attention_fwd_kernel");
 }

@@ -421,6 +421,57 @@ def test_silu_mul_and_rope_match_oracle():
         assert torch.equal(gq.cpu(), wq) and torch.equal(gk.cpu(), wk)
 
 
+def test_attention_rescale_and_mask_paths_against_float64():
+    """The online softmax rescales its accumulators only when a row maximum grows by more than 2^8 (wave-uniform, rare):
+    keys that dominate at chosen positions force that branch in the middle of a sequence, for some rows of a wave and not
+    for others; a dominant FIRST key makes every later tile take the no-rescale path; large scores exercise the masked
+    (-inf) entries of the diagonal tiles. Checked against float64 on the same bf16 inputs, and against the oracle's eager chain."""
+    torch.manual_seed(21)
+    d, b, s_, heads, kv_heads = 128, 1, 512, 4, 2
+    for spikes, gain in (((70, 200, 450), 6.0), ((0,), 8.0), ((63, 64, 255, 256, 511), 5.0), ((), 3.0)):
+        q = torch.randn(b, s_, heads * d).to(torch.bfloat16)
+        k = torch.randn(b, s_, kv_heads * d).to(torch.bfloat16)
+        v = torch.randn(b, s_, kv_heads * d).to(torch.bfloat16)
+        if not spikes:
+            q, k = (q * gain).to(torch.bfloat16), (k * gain).to(torch.bfloat16)
+        for pos in spikes:  # a key with `gain` times the norm: about half of the later rows see their maximum jump here
+            k[0, pos] = (k[0, pos].float() * gain).to(torch.bfloat16)
+        want = parity_cases.attention_reference64(q, k, v, d, True)
+        got, _ = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), d, causal=True)
+        err = float((got.cpu().double() - want).abs().max())
+        assert err <= parity_cases.ATTENTION_ATOL, (spikes, err)
+        with use_backend(load_oracle()):
+            chain, _ = ops.attention(q, k, v, d, causal=True)
+        err_chain = float((chain.double() - want).abs().max())
+        assert err <= err_chain + 2.0**-9, (spikes, err, err_chain)
+
+
+def test_full_size_attention_properties():
+    """Llama-3-8B attention shape (B=8, S=2048, 32 query heads, 8 kv heads, D=128): codes == A1 of the context this call
+    produced; the context within one bf16 ulp-of-the-largest-output of torch's SDPA on the device; causality — changing
+    keys / values at positions > t leaves rows <= t bit-identical; batch / head independence — a sub-batch gives the same rows."""
+    torch.manual_seed(9)
+    b, s_, heads, kv_heads, d = 8, 2048, 32, 8, 128
+    q = torch.randn(b, s_, heads * d, device=DEV, dtype=torch.bfloat16)
+    k = torch.randn(b, s_, kv_heads * d, device=DEV, dtype=torch.bfloat16)
+    v = torch.randn(b, s_, kv_heads * d, device=DEV, dtype=torch.bfloat16)
+    sc, of = torch.tensor([0.03], device=DEV), torch.tensor([-3.0], device=DEV)
+    ctx, codes = ops.attention(q, k, v, d, causal=True, quantizer=(sc, of))
+    assert torch.equal(codes, ops.quantize_by_tile(ctx, sc, ctx.shape, 8, torch.int8, of))
+    sdpa = torch.nn.functional.scaled_dot_product_attention(
+        q.view(b, s_, heads, d).transpose(1, 2), k.view(b, s_, kv_heads, d).transpose(1, 2), v.view(b, s_, kv_heads, d).transpose(1, 2),
+        is_causal=True, enable_gqa=True).transpose(1, 2).reshape(b, s_, -1)
+    assert float((ctx.float() - sdpa.float()).abs().max()) <= parity_cases.ATTENTION_ATOL
+    t = 1000
+    k2, v2 = k.clone(), v.clone()
+    k2[:, t + 1:] = torch.randn_like(k2[:, t + 1:]) * 3
+    v2[:, t + 1:] = torch.randn_like(v2[:, t + 1:])
+    ctx2, _ = ops.attention(q, k2, v2, d, causal=True)
+    assert torch.equal(ctx2[:, : t + 1], ctx[:, : t + 1]) and not torch.equal(ctx2[:, t + 1:], ctx[:, t + 1:])
+    sub, _ = ops.attention(q[2:4].contiguous(), k[2:4].contiguous(), v[2:4].contiguous(), d, causal=True)
+    assert torch.equal(sub, ctx[2:4])
+
+
 def test_full_size_producers_properties():
     """Llama-3-8B activation sizes ([8, 2048, 4096] through RMSNorm, [8, 2048, 14336] through SiLU*up):
     codes == A1 of the produced value, the produced value within one bf16 ulp of the ATen chain on the

@@ -1,6 +1,5 @@
 """ffq_attention on the Llama-3-8B attention shape (B=8, S=2048, 32 q heads, 8 kv heads, D=128, causal):
-correctness against torch SDPA / float64 on a slice, then time vs torch SDPA.  FFQ_ATTN_GATHER_V=1 selects the
-debugging V path (plain gathers instead of ds_read_b64_tr_b16)."""
+correctness against float64 (and torch SDPA beside it) on small shapes, then time vs torch SDPA."""
 import os
 import sys
 import time
@@ -27,7 +26,6 @@ def ref64(q, k, v, d, causal=True):
     return (torch.softmax(w, -1) @ vs).transpose(1, 2).reshape(b, s, -1)
 
 
-print("mode:", "gather V" if os.environ.get("FFQ_ATTN_GATHER_V") else "ds_read_b64_tr_b16")
 for (b, s, h, hk, causal) in [(1, 64, 1, 1, True), (1, 128, 2, 1, True), (2, 320, 4, 2, True), (1, 512, 8, 2, True), (1, 256, 4, 4, False), (2, 1024, 8, 2, True)]:
     d = 128
     q = torch.randn(b, s, h * d, device=dev).to(torch.bfloat16)
