@@ -206,11 +206,13 @@ __global__ __launch_bounds__(kWaves * 64) void attention_fwd_kernel(AttnArgs a) 
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       // Deferred rescale: while no row's maximum grows by more than 2^kDefer the running maximum stays where it is (the
       // probabilities of this tile are then bounded by 2^kDefer instead of 1, harmless in bf16 / fp32) and the 64
-      // accumulator registers are not touched. The decision is wave-uniform and taken before this tile's P exists, so
-      // everything at the old scale (O, l) is rescaled exactly once and nothing at the new scale is.
+      // accumulator registers are not touched. The branch is wave-uniform, the new maximum is per row, and it is taken
+      // before this tile's P exists, so everything at the old scale (O, l) is rescaled exactly once and nothing at the
+      // new scale is.
       const float mxs = mx * a.c;
       if (!__all(mxs - m_run <= kDefer)) {
-        const float m_new = fmaxf(m_run, mxs);
+        // only the rows that grew move: a row's result never depends on what its neighbours in the wave hold
+        const float m_new = mxs - m_run > kDefer ? mxs : m_run;
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         l_run *= alpha;
