@@ -299,8 +299,8 @@ def quantize_llama(
 
 def calibrate(model: LlamaModel, batches, sync_free: bool = True, disable_quantization: bool = False, fused: bool = False) -> None:
     """RunningMinMax calibration over `batches` of token ids (reference quick-start :193,255). ``fused`` runs the
-    producers between the quantizers as one-pass kernels (:class:`FusedCalibrationForward`)."""
-    forward = FusedCalibrationForward(model) if fused else (lambda ids: model(ids, logits=False))
+    producers between the quantizers as one-pass kernels (:class:`FusedProducersForward`)."""
+    forward = FusedProducersForward(model) if fused else (lambda ids: model(ids, logits=False))
     with torch.no_grad(), ff.strict_quantization(False):
         with ff.estimate_ranges(model, ff.range_setting.running_minmax, sync_free=sync_free, disable_quantization=disable_quantization):
             for ids in batches:
@@ -516,15 +516,18 @@ class FusedForward:
             return model.lm_head(normed)
 
 
-class FusedCalibrationForward:
-    """The forward to run INSIDE ``ff.estimate_ranges(model, ...)``: producers fused, quantizers untouched.
+class FusedProducersForward:
+    """The forward for every case ``FusedForward`` refuses: producers fused, quantizers untouched.
 
     Range estimation needs every quantizer's own ``forward`` (that is where ``estimate_ranges`` installs its
-    override: update the running min/max, set the range, quantize — reference range_setting/common.py:218-238), so
-    nothing is fused INTO a quantizer here. What is fused is everything between them: residual add + RMSNorm, the
-    rotary embedding and SiLU*up run as the one-pass producers of csrc/ffq_producers.hip instead of eager ATen
-    chains, and the quantized linears take the codes straight to the int8 GEMM. Results equal the module graph up to
-    the summation order inside RMSNorm (see FusedForward).
+    override: update the running min/max, set the range, quantize — reference range_setting/common.py:218-238), and a
+    weight-only model (BASELINE configs 2 and 4) has no activation codes to fuse into anything, so nothing is fused
+    INTO a quantizer here. What is fused is everything between the linears: residual add + RMSNorm, the rotary
+    embedding, SiLU*up and attention run as the one-pass kernels of csrc/ffq_producers.hip / ffq_attention.hip instead
+    of eager ATen chains. A linear whose input and weight quantizers both produce int8 codes takes the codes straight to
+    the int8 GEMM; any other linear runs its module forward (``QuantizedLinear.forward``: quantizers, dispatcher,
+    float fallback on the dequantized operands — reference nn/linear.py:32-39). Results equal the module graph up to the
+    summation order inside RMSNorm and the attention launch's tolerance (see FusedForward).
     """
 
     def __init__(self, model: LlamaModel) -> None:
@@ -533,19 +536,24 @@ class FusedCalibrationForward:
             raise ff.exceptions.QuantizationError("hidden size / head dim outside the fused kernels' range")
         if next(model.parameters()).dtype != torch.bfloat16:
             raise ff.exceptions.QuantizationError("fused producers are built for bf16 models")
-        for name, linear in decoder_linears(model):
-            if linear.bias is not None or linear.input_quantizer.is_stub() or linear.weight_quantizer.is_stub():
-                raise ff.exceptions.QuantizationError(f"{name}: needs input and weight quantizers and no bias")
+        for name, q in ff.nn.named_quantizers(model, skip_stubs=False):
+            is_linear_slot = ".layers." in "." + name and any(f"{p}." in name for p in ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"))
+            if q is not None and not is_linear_slot and not q.is_stub():
+                raise ff.exceptions.QuantizationError(f"{name}: only the decoder linears' quantizers may be set (the producers between them are fused)")
         self.model = model
 
     @staticmethod
     def _linear(x: torch.Tensor, linear: torch.nn.Module) -> torch.Tensor:
-        """QuantizedLinear.forward with the quantizers' own forwards (overrides included) and the int8 GEMM."""
+        """QuantizedLinear.forward; int8 codes on both sides go to the int8 GEMM directly."""
+        if linear.bias is not None or linear.input_quantizer.is_stub() or linear.weight_quantizer.is_stub() or not linear.output_quantizer.is_stub():
+            return linear(x)
         xq = linear.input_quantizer(x)
         wq = linear.weight_quantizer(linear.weight)
         if not (isinstance(xq, ff.QuantizedTensor) and isinstance(wq, ff.QuantizedTensor)) or xq.raw_data.dtype != torch.int8 or wq.raw_data.dtype != torch.int8:
             return ff.nn.functional.linear(xq, wq, None, output_quantizer=linear.output_quantizer)  # e.g. disable_quantization=True
         xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
+        if xp.scale.numel() != 1:
+            return ff.nn.functional.linear(xq, wq, None, output_quantizer=linear.output_quantizer)
         return ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, wp.offset, None, out_dtype=torch.bfloat16)
 
     @torch.no_grad()
@@ -574,6 +582,9 @@ class FusedCalibrationForward:
                 pending = self._linear(product, mlp.down_proj)
             _, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, model.norm.weight, model.norm.variance_epsilon, (), want_sum=False, want_norm=True)
             return model.lm_head(normed) if logits else normed
+
+
+FusedCalibrationForward = FusedProducersForward  # the name the calibration path was introduced under
 
 
 def count_quantizers(model: LlamaModel) -> int:

@@ -179,6 +179,34 @@ def test_fused_forward_with_the_attention_kernel_on_gpu(hip_backend):
     assert e_sdpa < 0.01 and e_kernel < 0.079, (e_kernel, e_sdpa)
 
 
+def check_producers_forward_weight_only(fixture, device):
+    """BASELINE configs 2 / 4 (weight-only): no activation codes to fuse into anything, so the linears run their module
+    forward (float fallback on the dequantized weights) and only the producers between them are fused."""
+    cfg = llama.LlamaConfig(**fixture["config"])
+    model = llama.LlamaModel(cfg).to(torch.bfloat16).eval()
+    llama.load_hf_state_dict(model, fixture["weights"])
+    model.to(device)
+    llama.quantize_llama(model, w_bits=8, a_bits=None, quantized_dtype=torch.int8)
+    llama.calibrate(model, [fixture["calibration_ids"][0].to(device)])
+    ids = fixture["ids"].to(device)
+    with torch.no_grad(), ff.strict_quantization(False):
+        want = model(ids).float().cpu()
+        got = llama.FusedProducersForward(model)(ids, logits=True).float().cpu()
+    err, spread = got - want, float(want.std())
+    assert float(err.pow(2).mean().sqrt()) < 0.01 * spread and float(err.abs().max()) < 0.25 * spread
+    with pytest.raises(ff.exceptions.QuantizationError, match="FusedForward cannot run"):
+        llama.FusedForward(model)  # no activation quantizers: nothing it could fuse
+
+
+def test_producers_forward_weight_only(oracle_backend):
+    check_producers_forward_weight_only(golden("g7_tiny_llama.pt"), "cpu")
+
+
+@pytest.mark.gpu
+def test_producers_forward_weight_only_on_gpu(hip_backend):
+    check_producers_forward_weight_only(golden("g7_tiny_llama.pt"), "cuda")
+
+
 def check_fused_calibration(fixture, device):
     """Calibrating through FusedCalibrationForward (every quantizer's own forward with its estimator override, fused
     producers in between) gives the module graph's ranges: weight quantizers exactly, activation ranges within the

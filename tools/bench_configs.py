@@ -85,7 +85,11 @@ def cfg2() -> dict:
                 return model(batch)
 
         s = timed_forward(fwd)
-        out[f"forward_B{b}_S2048"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(b * 2048 / s, 1)}
+        out[f"forward_B{b}_S2048_module_graph"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(b * 2048 / s, 1)}
+        producers = llama.FusedProducersForward(model)
+        s = timed_forward(lambda: producers(batch, logits=True))
+        out[f"forward_B{b}_S2048"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(b * 2048 / s, 1),
+                                      "forward": "FusedProducersForward (RMSNorm / rotary / SiLU*up / attention as one-pass kernels; linears: module forward)"}
     # whole-model weight quantization: 6.98 G elements, 3 B/elem
     linears = [l for _, l in llama.decoder_linears(model)]
 
@@ -118,7 +122,7 @@ def cfg3(total_sequences: int) -> dict:
     s = time.perf_counter() - t0
     out = {"config": f"Llama-3-8B W8A8, RunningMinMax calibration over {steps * 8} sequences x 2048 tokens ({steps} steps of 8), quantize-while-calibrating (reference default)",
            "calibration": {"seconds": round(s, 2), "sequences_per_s": round(steps * 8 / s, 2), "tokens_per_s": round(steps * 8 * 2048 / s, 1),
-                           "range_floats_for_allreduce": payload, "forward": "FusedCalibrationForward (quantizers' own forwards with their estimator overrides; fused producers in between)"},
+                           "range_floats_for_allreduce": payload, "forward": "FusedProducersForward (quantizers' own forwards with their estimator overrides; fused producers in between)"},
            "calibration_module_graph_64_sequences": {"seconds": round(s_mg, 2), "sequences_per_s": round(64 / s_mg, 2)}}
     batch = batches[0]
     fused = llama.FusedForward(model)
@@ -192,7 +196,11 @@ def cfg4() -> dict:
             return model(batch)
 
     s = timed_forward(fwd)
-    out["forward_B8_S2048"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(8 * 2048 / s, 1)}
+    out["forward_B8_S2048_module_graph"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(8 * 2048 / s, 1)}
+    producers = llama.FusedProducersForward(model)
+    s = timed_forward(lambda: producers(batch, logits=True))
+    out["forward_B8_S2048"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(8 * 2048 / s, 1),
+                               "forward": "FusedProducersForward (RMSNorm / rotary / SiLU*up / attention as one-pass kernels; linears: module forward)"}
     return out
 
 
