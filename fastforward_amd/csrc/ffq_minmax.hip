@@ -43,6 +43,69 @@ struct MinMax {
   }
 };
 
+// bf16 / fp16 data: extrema on the RAW 16-bit patterns, two elements per VALU op and no conversion, no NaN test per
+// element (6 VALU ops per element become 2). Sign-magnitude patterns order like this:
+//   as signed int16   positives order like their values and beat every negative; among negatives the order is reversed
+//   as unsigned int16 negatives (>= 0x8000) beat every positive and order by magnitude
+// so  max = (signed max >= 0) ? signed max : signed min      (no positive element: the negative of least magnitude)
+//     min = (unsigned max >= 0x8000) ? unsigned max : unsigned min
+// and a NaN (exponent all ones, mantissa != 0) is the only pattern above +Inf in the signed order / above -Inf in the
+// unsigned order. Four v_pk_{max,min}_{i16,u16} per dword.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+template <typename T>
+struct PackedMinMax16 {
+  static_assert(sizeof(T) == 2, "16-bit floating point only");
+  static constexpr int kPosInf = TypeTag<T>::value == FFQ_BF16 ? 0x7F80 : 0x7C00;
+  s16x2 imax, imin;
+  u16x2 umax, umin;
+  bool any;
+  __device__ __forceinline__ void init() {
+    imax = s16x2{(short)-32768, (short)-32768}; imin = s16x2{(short)32767, (short)32767};
+    umax = u16x2{0, 0}; umin = u16x2{(unsigned short)0xFFFF, (unsigned short)0xFFFF};
+    any = false;
+  }
+  __device__ __forceinline__ void add(uint32_t w) {
+    const s16x2 si = __builtin_bit_cast(s16x2, w);
+    const u16x2 ui = __builtin_bit_cast(u16x2, w);
+    imax = __builtin_elementwise_max(imax, si); imin = __builtin_elementwise_min(imin, si);
+    umax = __builtin_elementwise_max(umax, ui); umin = __builtin_elementwise_min(umin, ui);
+    any = true;
+  }
+  __device__ __forceinline__ MinMax finish() const {
+    MinMax m;
+    m.init();
+    if (!any) return m;
+    const int smax = imax.x > imax.y ? imax.x : imax.y, smin = imin.x < imin.y ? imin.x : imin.y;
+    const unsigned xmax = umax.x > umax.y ? umax.x : umax.y, xmin = umin.x < umin.y ? umin.x : umin.y;
+    const uint16_t mx_bits = (uint16_t)(smax >= 0 ? smax : smin);
+    const uint16_t mn_bits = (uint16_t)(xmax >= 0x8000u ? xmax : xmin);
+    m.mx = to_f32(__builtin_bit_cast(T, mx_bits));
+    m.mn = to_f32(__builtin_bit_cast(T, mn_bits));
+    m.nan = smax > kPosInf || xmax > (0x8000u | (unsigned)kPosInf);
+    return m;
+  }
+};
+
+// E elements of one chunk into the accumulator of the data type: packed patterns for 16-bit floats, floats otherwise.
+template <typename T> struct Accum { typedef MinMax type; };
+template <> struct Accum<bf16_t> { typedef PackedMinMax16<bf16_t> type; };
+template <> struct Accum<f16_t> { typedef PackedMinMax16<f16_t> type; };
+template <typename T, int E>
+__device__ __forceinline__ void add_chunk(typename Accum<T>::type& acc, const Chunk<T, E>& x) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int i = 0; i < Chunk<T, E>::kWords; ++i) acc.add(x.w[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < E; ++i) acc.add(x.get(i));
+  }
+}
+template <typename T>
+__device__ __forceinline__ MinMax finish_accum(const typename Accum<T>::type& acc) {
+  if constexpr (sizeof(T) == 2) return acc.finish(); else return acc;
+}
+
 // butterfly over `width` lanes (power of two <= 64) of a wavefront
 template <int WIDTH>
 __device__ __forceinline__ void wave_reduce(MinMax& m) {
@@ -86,8 +149,8 @@ __global__ __launch_bounds__(kBlock) void minmax_scalar_partial_kernel(const T* 
                                                                        uint32_t nchunks, int64_t numel,
                                                                        Partial* __restrict__ partial) {
   __shared__ float lds[12];
-  MinMax m;
-  m.init();
+  typename Accum<T>::type acc;
+  acc.init();
   const uint32_t stride = gridDim.x * (uint32_t)(kBlock * U);
   for (uint32_t base = blockIdx.x * (uint32_t)(kBlock * U) + threadIdx.x; base < nchunks; base += stride) {
     Chunk<T, E> x[U];
@@ -99,12 +162,10 @@ __global__ __launch_bounds__(kBlock) void minmax_scalar_partial_kernel(const T* 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t c = base + u * kBlock;
-      if (c < nchunks) {
-#pragma unroll
-        for (int i = 0; i < E; ++i) m.add(x[u].get(i));
-      }
+      if (c < nchunks) add_chunk<T, E>(acc, x[u]);
     }
   }
+  MinMax m = finish_accum<T>(acc);
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // numel % E trailing elements
     for (int64_t i = (int64_t)nchunks * E; i < numel; ++i) m.add(to_f32(in[i]));
   }
@@ -148,8 +209,8 @@ __global__ __launch_bounds__(kBlock) void minmax_rows_kernel(const T* __restrict
   constexpr int TILES_PER_BLOCK = kBlock / P;
   const uint32_t t = blockIdx.x * TILES_PER_BLOCK + threadIdx.x / P;
   const uint32_t lane = threadIdx.x % P;
-  MinMax m;
-  m.init();
+  typename Accum<T>::type acc;
+  acc.init();
   if (t < a.ntiles) {
     const T* row = in + (size_t)t * a.chunks_per_run * E;
     uint32_t c = lane;
@@ -161,17 +222,15 @@ __global__ __launch_bounds__(kBlock) void minmax_rows_kernel(const T* __restrict
         if constexpr (NT) x[u].load_nt(row + (size_t)(c + u * P) * E); else x[u].load(row + (size_t)(c + u * P) * E);
       }
 #pragma unroll
-      for (int u = 0; u < UF; ++u)
-#pragma unroll
-        for (int i = 0; i < E; ++i) m.add(x[u].get(i));
+      for (int u = 0; u < UF; ++u) add_chunk<T, E>(acc, x[u]);
     }
     for (; c < a.chunks_per_run; c += P) {
       Chunk<T, E> x0;
       x0.load(row + (size_t)c * E);
-#pragma unroll
-      for (int i = 0; i < E; ++i) m.add(x0.get(i));
+      add_chunk<T, E>(acc, x0);
     }
   }
+  MinMax m = finish_accum<T>(acc);
   wave_reduce<P>(m);
   if (lane == 0 && t < a.ntiles) write_result<T>(mn_out, mx_out, t, m, a.accumulate, flags);
 }
@@ -184,14 +243,14 @@ __global__ __launch_bounds__(kBlock) void minmax_rows_split_kernel(const T* __re
   __shared__ float lds[12];
   const uint32_t t = blockIdx.y, splits = gridDim.x;
   const T* row = in + (size_t)t * chunks_per_run * E;
-  MinMax m;
-  m.init();
+  typename Accum<T>::type acc;
+  acc.init();
   for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < chunks_per_run; c += splits * kBlock) {
     Chunk<T, E> x;
     x.load(row + (size_t)c * E);
-#pragma unroll
-    for (int i = 0; i < E; ++i) m.add(x.get(i));
+    add_chunk<T, E>(acc, x);
   }
+  MinMax m = finish_accum<T>(acc);
   block_reduce(m, lds);
   if (threadIdx.x == 0) partial[(size_t)t * splits + blockIdx.x] = Partial{m.mn, m.mx, m.nan ? 1.0f : 0.0f, 0.0f};
 }
