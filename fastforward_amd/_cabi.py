@@ -19,7 +19,7 @@ from fastforward_amd.exceptions import QuantizationError
 
 FFQ_MAX_DIMS = 8
 FFQ_MAX_FANOUT = 3
-FFQ_ABI_VERSION = 2
+FFQ_ABI_VERSION = 3
 
 
 class Status(enum.IntEnum):
@@ -161,6 +161,12 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_add_rmsnorm_quantize": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _d, _vp, _fp, _vp]),
     "ffq_silu_mul_quantize": (_i, [_vp, _vp, _i, _i64, _vp, _fp, _vp]),
     "ffq_rope_inplace": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "ffq_quantize_rows_rowsum": (_i, [_vp, _i, _vp, _vp, _i64, _i64, _d, _vp, _vp, _vp]),
+    "ffq_linear_w8a8_rs": (
+        _i,
+        [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp],
+    ),
+    "ffq_mlp_gate_up_w8a8_rs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ffq_attention": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _d, _i, _vp, _vp, _vp, _vp, _d, _vp]),
 }
 

@@ -1362,6 +1362,16 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
                                const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
                                const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
                                void* workspace, size_t workspace_bytes, void* stream) {
+  return ffq_linear_w8a8_rs(xq, wq, nullptr, x_scale, x_offset, x_per_row, w_scale, w_offset, w_per_row, bias, bias_dt, out, out_dt,
+                            out_scale, out_offset, out_num_bits, M, N, K, workspace, workspace_bytes, stream);
+}
+
+// w_rowsum (nullable): sum_k wq[n, k] already known to the caller (ffq_quantize_rows_rowsum) — no reduction launch here
+extern "C" int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                                  const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset,
+                                  int w_per_row, const void* bias, int bias_dt, void* out, int out_dt,
+                                  const float* out_scale, const float* out_offset, double out_num_bits, int64_t M,
+                                  int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
@@ -1379,7 +1389,7 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
     return fail(FFQ_ERR_DTYPE, "real-valued output must be f32, bf16 or f16");
   }
   const size_t need = ffq_linear_w8a8_workspace_bytes(M, N, K);
-  if ((x_offset || w_offset) && (need > workspace_bytes || !workspace))
+  if (((x_offset && !w_rowsum) || w_offset) && (need > workspace_bytes || !workspace))
     return fail(FFQ_ERR_WORKSPACE, "w8a8 linear needs %zu workspace bytes, got %zu", need, workspace_bytes);
 
   LinearArgs a;
@@ -1412,8 +1422,12 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
       a.tiles_m = (int)((M + BM2 - 1) / BM2);
       a.tiles_n = (int)((N + 255) / 256);
       if (x_offset) {  // sum_k wq[n, k] for the zero-point term: one pass over the weight codes
-        rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(wq, (int)N, (int)K, ws + M);
-        a.rowsum_w = ws + M;
+        if (w_rowsum) {
+          a.rowsum_w = w_rowsum;
+        } else {
+          rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(wq, (int)N, (int)K, ws + M);
+          a.rowsum_w = ws + M;
+        }
       }
       const unsigned grid3 = (unsigned)(a.tiles_m * a.tiles_n);
       const size_t ring3 = (size_t)STAGES3 * (BM2 + 256) * BK2;
@@ -1518,8 +1532,12 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
     a.rowsum_x = ws;
   }
   if (x_offset) {  // needs sum_k wq[n,k]
-    rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(wq, (int)N, (int)K, ws + M);
-    a.rowsum_w = ws + M;
+    if (w_rowsum) {
+      a.rowsum_w = w_rowsum;
+    } else {
+      rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(wq, (int)N, (int)K, ws + M);
+      a.rowsum_w = ws + M;
+    }
   }
   const unsigned grid = (unsigned)(a.tiles_m * a.tiles_n);
   if (requant) {
@@ -1551,7 +1569,17 @@ extern "C" int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, con
                                     const float* x_offset, const float* gate_w_scale, const float* up_w_scale,
                                     int8_t* codes_out, const float* out_scale, const float* out_offset, double out_num_bits,
                                     int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  return ffq_mlp_gate_up_w8a8_rs(xq, gate_wq, up_wq, nullptr, nullptr, x_scale, x_offset, gate_w_scale, up_w_scale, codes_out, out_scale,
+                                 out_offset, out_num_bits, M, N, K, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const int32_t* gate_rowsum,
+                                       const int32_t* up_rowsum, const float* x_scale, const float* x_offset,
+                                       const float* gate_w_scale, const float* up_w_scale, int8_t* codes_out,
+                                       const float* out_scale, const float* out_offset, double out_num_bits, int64_t M,
+                                       int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool have_sums = gate_rowsum && up_rowsum;
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
   if (!xq || !gate_wq || !up_wq || !x_scale || !gate_w_scale || !up_w_scale || !codes_out || !out_scale)
@@ -1562,7 +1590,7 @@ extern "C" int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, con
   if (!(out_num_bits >= 1 && out_num_bits <= 8 && out_num_bits == floor(out_num_bits)))
     return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.", FFQ_I8, out_num_bits);
   const size_t need = ffq_mlp_gate_up_w8a8_workspace_bytes(M, N, K);
-  if (x_offset && (need > workspace_bytes || !workspace)) return fail(FFQ_ERR_WORKSPACE, "fused gate/up needs %zu workspace bytes, got %zu", need, workspace_bytes);
+  if (x_offset && !have_sums && (need > workspace_bytes || !workspace)) return fail(FFQ_ERR_WORKSPACE, "fused gate/up needs %zu workspace bytes, got %zu", need, workspace_bytes);
   LinearArgs a;
   a.xq = xq; a.wq = gate_wq; a.wq2 = up_wq;
   a.x_scale = x_scale; a.x_offset = x_offset;
@@ -1579,7 +1607,9 @@ extern "C" int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, con
   a.tiles_n = (int)(N / 128);
   static const int debug_bits = getenv("FFQ_GEMM_DEBUG") ? atoi(getenv("FFQ_GEMM_DEBUG")) : 0;
   a.debug = debug_bits;
-  if (x_offset) {
+  if (x_offset && have_sums) {
+    a.rowsum_w = gate_rowsum; a.rowsum_w2 = up_rowsum;
+  } else if (x_offset) {
     int32_t* ws = static_cast<int32_t*>(workspace);
     rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(gate_wq, (int)N, (int)K, ws);
     rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(up_wq, (int)N, (int)K, ws + N);

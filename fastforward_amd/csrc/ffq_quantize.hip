@@ -402,6 +402,73 @@ int quantize_impl(const void* data, int data_dt, const void* scale, int scale_dt
                         tiling, lo, hi, div_dt, sub_dt, out, out_dt, done, info.numel - done, stream);
 }
 
+// A1 for a [rows, cols] weight with one parameter pair per row, int8 container, that also leaves the row sums of the codes
+// (the zero-point term of A6) — one pass instead of A1 + a reduction over the codes. cols % 1024 == 0: the 64 chunks of a wave
+// lie in one row, so a wave reduces its 1024 codes in registers (v_dot4 on the packed bytes, a shuffle butterfly) and adds one
+// int32 to rowsum[row] (integer atomics: exact, order-independent; the caller zeroes the sums). Codes are those of
+// quantize_stream_kernel.
+template <bool HAS_OFFSET>
+__global__ __launch_bounds__(kBlock) void quantize_rows_rowsum_kernel(const bf16_t* __restrict__ in, int8_t* __restrict__ out,
+                                                                      const float* __restrict__ scale,
+                                                                      const float* __restrict__ offset,
+                                                                      int32_t* __restrict__ rowsum, StreamArgs a) {
+  const uint32_t c = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  const bool live = c < a.nchunks;  // nchunks % 64 == 0: whole waves are live or not
+  Chunk<bf16_t, 16> x;
+  if (live) x.load(in + (size_t)c * 16);
+  else {
+#pragma unroll
+    for (int i = 0; i < Chunk<bf16_t, 16>::kWords; ++i) x.w[i] = 0;
+  }
+  const uint32_t row = fdiv(live ? c : a.nchunks - 1, a.chunks_per_run);
+  const float s = scale[row];
+  const float o = HAS_OFFSET ? rne(offset[row]) : 0.0f;
+  float xf[16], r[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) xf[i] = x.get(i);
+  quantize_chunk<1, 16>(xf, s, o, r);
+  Chunk<int8_t, 16> y;
+  finalize_chunk<int8_t, 16>(r, a.lo, a.hi, y);
+  if (live) y.store(out + (size_t)c * 16);
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sum = __builtin_amdgcn_sdot4((int)y.w[i], 0x01010101, sum, false);
+  if (!live) sum = 0;
+  // wave sum on the VALU (DPP inclusive scan: row_shr 1 / 2 / 4 / 8, then row_bcast15 / row_bcast31): no LDS round trips in
+  // a wave that lives for one chunk; lane 63 ends up with the total
+  sum += __builtin_amdgcn_update_dpp(0, sum, 0x111, 0xf, 0xf, false);
+  sum += __builtin_amdgcn_update_dpp(0, sum, 0x112, 0xf, 0xf, false);
+  sum += __builtin_amdgcn_update_dpp(0, sum, 0x114, 0xf, 0xf, false);
+  sum += __builtin_amdgcn_update_dpp(0, sum, 0x118, 0xf, 0xf, false);
+  sum += __builtin_amdgcn_update_dpp(0, sum, 0x142, 0xa, 0xf, false);
+  sum += __builtin_amdgcn_update_dpp(0, sum, 0x143, 0xc, 0xf, false);
+  // one atomic per block where its 4 waves share a row (cols % 4096 == 0, or the block does not straddle a row end): 64 waves
+  // hammering the 16 sums of one cache line serialise in L2
+  __shared__ int wave_sum[4];
+  __shared__ uint32_t wave_row[4];
+  const uint32_t wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 63 && live) {
+    wave_sum[wave] = sum;
+    wave_row[wave] = row;
+  }
+  __syncthreads();
+  if (threadIdx.x == 63) {
+    // only the LAST block can be short (nchunks % 64 == 0): count the waves this block really has
+    const uint32_t waves = min(4u, (a.nchunks - blockIdx.x * (uint32_t)kBlock + 63u) / 64u);
+    int acc = wave_sum[0];
+    uint32_t cur = wave_row[0];
+    for (uint32_t w = 1; w < waves; ++w) {
+      if (wave_row[w] != cur) {
+        atomicAdd(rowsum + cur, acc);
+        acc = 0;
+        cur = wave_row[w];
+      }
+      acc += wave_sum[w];
+    }
+    atomicAdd(rowsum + cur, acc);
+  }
+}
+
 }  // namespace ffq
 
 extern "C" int ffq_quantize_by_tile(const void* data, int data_dt, const void* scale, int scale_dt,
@@ -410,4 +477,31 @@ extern "C" int ffq_quantize_by_tile(const void* data, int data_dt, const void* s
                                     void* out, int out_dt, void* stream) {
   return ffq::quantize_impl(data, data_dt, scale, scale_dt, scale_numel, offset, offset_dt, offset_numel,
                             tiling, num_bits, out, out_dt, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ffq_quantize_rows_rowsum(const void* data, int data_dt, const float* scale, const float* offset, int64_t rows,
+                                        int64_t cols, double num_bits, int8_t* codes, int32_t* rowsum, void* stream) {
+  using namespace ffq;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (rows < 0 || cols < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (data_dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "fused weight quantize + row sums is built for bf16 weights");
+  if (cols % 1024 != 0) return fail(FFQ_ERR_DTYPE, "fused weight quantize + row sums needs cols %% 1024 == 0");
+  if (!ffq_can_support_bitwidth(FFQ_I8, num_bits))
+    return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.", FFQ_I8, num_bits);
+  if (rows == 0 || cols == 0) return FFQ_OK;
+  if (!data || !scale || !codes || !rowsum) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (!aligned16(data) || !aligned16(codes)) return fail(FFQ_ERR_ARG, "buffers must be 16-byte aligned");
+  const int64_t nchunks = rows * cols / 16;
+  if (nchunks >= ((int64_t)1 << 32)) return fail(FFQ_ERR_ARG, "too many elements for one launch");
+  StreamArgs a;
+  const double lo = -pow(2.0, num_bits - 1.0);
+  a.lo = (float)lo; a.hi = (float)(-lo - 1.0);
+  a.nchunks = (uint32_t)nchunks;
+  a.scale_stride = 1; a.offset_stride = 1;
+  a.chunks_per_run = make_fastdiv((uint32_t)(cols / 16));
+  a.channels = make_fastdiv(1);
+  const unsigned grid = (unsigned)((nchunks + kBlock - 1) / kBlock);
+  if (offset) quantize_rows_rowsum_kernel<true><<<grid, kBlock, 0, s>>>(static_cast<const bf16_t*>(data), codes, scale, offset, rowsum, a);
+  else quantize_rows_rowsum_kernel<false><<<grid, kBlock, 0, s>>>(static_cast<const bf16_t*>(data), codes, scale, offset, rowsum, a);
+  return check_launch("quantize_rows_rowsum_kernel");
 }

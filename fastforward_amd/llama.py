@@ -338,7 +338,7 @@ class FusedForward:
     per-channel activations, biases — instead of silently computing something else.
     """
 
-    def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True, fuse_attention: bool = True) -> None:
+    def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True, fuse_attention: bool = True, fuse_rowsums: bool = False) -> None:
         problems = self.unsupported(model)
         if problems:
             raise ff.exceptions.QuantizationError("FusedForward cannot run this model: " + "; ".join(problems[:4]))
@@ -349,8 +349,17 @@ class FusedForward:
         self.fuse_mlp = fuse_mlp
         # attention + the o_proj input quantizer in one launch (ops.attention) where the kernel covers the shape
         self.fuse_attention = fuse_attention
+        # weight codes and the row sums of the zero-point term in one pass (ops.quantize_rows_rowsum) where the kernel applies.
+        # OFF by default: the one-pass kernel is 5 us per weight cheaper than A1 + the reduction launch, but the Llama-3-8B
+        # forward measures 1.2 % SLOWER with it (tools/ab_forward.py, same box, 3 runs) — the separate reduction reads the
+        # fresh codes right before the GEMM does and leaves them in the Infinity Cache; without it the GEMMs lose more than
+        # the reduction cost.
+        self.fuse_rowsums = fuse_rowsums
         self._zero_offset: dict[int, tuple[int, bool]] = {}
-        self._weight_cache: dict[int, tuple[tuple[int, int, int], torch.Tensor]] = {}
+        self._weight_cache: dict[int, tuple[tuple[int, int, int], tuple[torch.Tensor, torch.Tensor | None]]] = {}
+        self._rowsum_rows = sum(linear.weight.shape[0] for _, linear in decoder_linears(model))
+        self._rowsum_pool: torch.Tensor | None = None
+        self._rowsum_used = 0
         # when set to a list, every int8 GEMM launch appends (output rows of weight processed, K, start event, end event)
         # — the fused gate/up launch counts both matrices: bench.py times the GEMM launches of a real forward with it
         self.linear_events: list[tuple[int, int, torch.cuda.Event, torch.cuda.Event]] | None = None
@@ -432,29 +441,52 @@ class FusedForward:
             self._zero_offset[id(linear)] = hit
         return hit[1]
 
-    def _weight(self, linear: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None]:
-        """(int8 codes, scale, offset) of the linear's weight — A1 through the quantizer's own forward."""
+    def _rowsum_slice(self, rows: int, device: torch.device) -> torch.Tensor | None:
+        """`rows` zeroed int32 entries of the per-forward pool (one fill for all the weights of a forward), or None."""
+        pool, used = self._rowsum_pool, self._rowsum_used
+        if pool is None or used + rows > pool.numel() or pool.device != device:
+            return None
+        self._rowsum_used = used + rows
+        return pool[used:used + rows]
+
+    def _quantize_weight(self, linear: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor | None]:
+        """(int8 codes, int32 row sums of the codes or None) — A1 of the weight as the weight quantizer computes it
+        (reference nn/linear.py:34). Per-output-channel quantizers on a bf16 weight take the one-pass kernel that leaves the
+        row sums of the zero-point term beside the codes (ops.quantize_rows_rowsum); anything else goes through the
+        quantizer's own forward and the GEMM entry point reduces the codes itself."""
+        wq = linear.weight_quantizer
+        rows = linear.weight.shape[0]
+        if self.fuse_rowsums and wq.scale.numel() == rows and rows > 1 and (wq.offset is None or wq.offset.numel() == rows) and wq.num_bits <= 8:
+            offset = None if self._symmetric_weights(linear) else wq.offset  # an all-zero offset buffer: same codes
+            fused = ff.ops.quantize_rows_rowsum(linear.weight, wq.scale, offset, wq.num_bits, rowsum_out=self._rowsum_slice(rows, linear.weight.device))
+            if fused is not None:
+                return fused
+        return wq(linear.weight).raw_data, None
+
+    def _weight(self, linear: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor | None, torch.Tensor, torch.Tensor | None]:
+        """(int8 codes, row sums or None, scale, offset) of the linear's weight."""
         wq = linear.weight_quantizer
         if self.cache_weight_codes:
             key = (linear.weight._version, wq.scale._version, -1 if wq.offset is None else wq.offset._version)
             hit = self._weight_cache.get(id(linear))
             if hit is not None and hit[0] == key:
-                return hit[1], wq.scale, wq.offset
-            codes = wq(linear.weight).raw_data
-            self._weight_cache[id(linear)] = (key, codes)
-            return codes, wq.scale, wq.offset
-        return wq(linear.weight).raw_data, wq.scale, wq.offset
+                return hit[1][0], hit[1][1], wq.scale, wq.offset
+            produced = self._quantize_weight(linear)
+            self._weight_cache[id(linear)] = (key, produced)
+            return produced[0], produced[1], wq.scale, wq.offset
+        codes, rowsum = self._quantize_weight(linear)
+        return codes, rowsum, wq.scale, wq.offset
 
     def _linear(self, x_codes: torch.Tensor, linear: torch.nn.Module) -> torch.Tensor:
-        w_codes, w_scale, w_offset = self._weight(linear)
+        w_codes, w_rowsum, w_scale, w_offset = self._weight(linear)
         if w_offset is not None and self._symmetric_weights(linear):
             w_offset = None  # an all-zero offset buffer: same result, no device-side offset check in the kernel
         x_scale, x_offset = self._params(linear)
         if self.linear_events is None:
-            return ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16)
+            return ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16, w_rowsum=w_rowsum)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
-        out = ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16)
+        out = ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16, w_rowsum=w_rowsum)
         end.record()
         self.linear_events.append((w_codes.shape[0], w_codes.shape[1], start, end))
         return out
@@ -467,6 +499,9 @@ class FusedForward:
         hidden = model.embed_tokens(input_ids)
         cos, sin = rotary_tables(s, d, cfg.rope_theta, hidden.device, hidden.dtype)
         pending: torch.Tensor | None = None
+        if self.fuse_rowsums:  # the weight row sums of this forward: one zero fill, slices handed out as the weights are quantized
+            self._rowsum_pool = torch.zeros(self._rowsum_rows, dtype=torch.int32, device=hidden.device)
+            self._rowsum_used = 0
         for layer, fan in zip(model.layers, self._fan):
             attn, mlp = layer.self_attn, layer.mlp
             pairs, index = fan["qkv"]
@@ -494,13 +529,14 @@ class FusedForward:
             d_in = mlp.down_proj.input_quantizer
             d_codes = None
             if self.fuse_mlp and index[0] == index[1] and self._symmetric_weights(mlp.gate_proj) and self._symmetric_weights(mlp.up_proj):
-                g_codes, g_scale, _ = self._weight(mlp.gate_proj)
-                u_codes, u_scale, _ = self._weight(mlp.up_proj)
+                g_codes, g_rowsum, g_scale, _ = self._weight(mlp.gate_proj)
+                u_codes, u_rowsum, u_scale, _ = self._weight(mlp.up_proj)
                 x_scale, x_offset = self._params(mlp.gate_proj)
                 if self.linear_events is not None:
                     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     start.record()
-                d_codes = ff.ops.mlp_gate_up_w8a8(codes[index[0]], g_codes, u_codes, x_scale, x_offset, g_scale, u_scale, d_in.scale, d_in.offset, d_in.num_bits)
+                d_codes = ff.ops.mlp_gate_up_w8a8(codes[index[0]], g_codes, u_codes, x_scale, x_offset, g_scale, u_scale, d_in.scale, d_in.offset, d_in.num_bits,
+                                                  gate_rowsum=g_rowsum, up_rowsum=u_rowsum)
                 if self.linear_events is not None and d_codes is not None:
                     end.record()
                     self.linear_events.append((2 * g_codes.shape[0], g_codes.shape[1], start, end))

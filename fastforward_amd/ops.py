@@ -41,6 +41,7 @@ __all__ = [
     "add_rmsnorm_quantize",
     "silu_mul_quantize",
     "rope_",
+    "quantize_rows_rowsum",
     "attention",
     "FLAG_INF",
     "FLAG_NAN",
@@ -559,11 +560,13 @@ def linear_w8a8(
     out_scale: torch.Tensor | None = None,
     out_offset: torch.Tensor | None = None,
     out_num_bits: float = 8.0,
+    w_rowsum: torch.Tensor | None = None,
 ) -> torch.Tensor:
     """A6 — int8 codes in, real-valued (or re-quantized) linear output out.
 
     `x_codes` is [..., K] int8, `w_codes` is [N, K] int8. Scales/offsets are fp32 with one entry
-    (per-tensor) or one per row (per-token for x, per-output-channel for w).
+    (per-tensor) or one per row (per-token for x, per-output-channel for w). `w_rowsum` (int32 [N], optional): the row
+    sums of `w_codes` when the caller already has them (:func:`quantize_rows_rowsum`) — same result, one launch fewer.
     """
     if x_codes.dtype != torch.int8 or w_codes.dtype != torch.int8:
         raise TypeError("linear_w8a8 expects int8 codes")
@@ -590,9 +593,11 @@ def linear_w8a8(
     out = torch.empty((*xc.shape[:-1], N), dtype=out_dtype, device=xc.device)
     nbytes = lib.ffq_linear_w8a8_workspace_bytes(M, N, K)
     ws = _workspace(nbytes, xc.device)
+    if w_rowsum is not None and (w_rowsum.dtype != torch.int32 or w_rowsum.numel() != N or not w_rowsum.is_contiguous() or w_rowsum.device != wc.device):
+        raise RuntimeError(f"w_rowsum must be a contiguous int32 tensor with {N} entries on the codes' device")
     lib.check(
-        lib.ffq_linear_w8a8(
-            _ptr(xc), _ptr(wc), _ptr(xs), _ptr(xo), x_per_row, _ptr(ws_), _ptr(wo), w_per_row,
+        lib.ffq_linear_w8a8_rs(
+            _ptr(xc), _ptr(wc), _ptr(w_rowsum), _ptr(xs), _ptr(xo), x_per_row, _ptr(ws_), _ptr(wo), w_per_row,
             _ptr(bias_c), _tag(bias_c.dtype) if bias_c is not None else 0, _ptr(out), _tag(out_dtype),
             _ptr(os_), _ptr(oo), float(out_num_bits), M, N, K, _ptr(ws), nbytes, stream,
         )
@@ -611,6 +616,8 @@ def mlp_gate_up_w8a8(
     out_scale: torch.Tensor,
     out_offset: torch.Tensor | None,
     out_num_bits: float = 8.0,
+    gate_rowsum: torch.Tensor | None = None,
+    up_rowsum: torch.Tensor | None = None,
 ) -> torch.Tensor | None:
     """gate_proj + up_proj + ``silu(gate) * up`` + the down_proj input quantizer in ONE launch (reference
     quantized_llama/mlp.py:30-40): int8 codes of the product, equal to
@@ -639,14 +646,47 @@ def mlp_gate_up_w8a8(
     out = torch.empty((*xc.shape[:-1], N), dtype=torch.int8, device=xc.device)
     nbytes = lib.ffq_mlp_gate_up_w8a8_workspace_bytes(M, N, K)
     ws = _workspace(nbytes, xc.device)
-    status = lib.ffq_mlp_gate_up_w8a8(
-        _ptr(xc), _ptr(gc), _ptr(uc), _ptr(xs), _ptr(xo), _ptr(gs), _ptr(us), _ptr(out), _ptr(os_), _ptr(oo),
+    for rs in (gate_rowsum, up_rowsum):
+        if rs is not None and (rs.dtype != torch.int32 or rs.numel() != N or not rs.is_contiguous() or rs.device != gc.device):
+            raise RuntimeError(f"row sums must be contiguous int32 tensors with {N} entries on the codes' device")
+    status = lib.ffq_mlp_gate_up_w8a8_rs(
+        _ptr(xc), _ptr(gc), _ptr(uc), _ptr(gate_rowsum), _ptr(up_rowsum), _ptr(xs), _ptr(xo), _ptr(gs), _ptr(us), _ptr(out), _ptr(os_), _ptr(oo),
         float(out_num_bits), M, N, K, _ptr(ws), nbytes, stream,
     )
     if status == 6:
         return None
     lib.check(status)
     return out
+
+
+def quantize_rows_rowsum(
+    weight: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor | None, num_bits: float = 8.0, rowsum_out: torch.Tensor | None = None
+) -> tuple[torch.Tensor, torch.Tensor] | None:
+    """A1 of a ``[rows, cols]`` weight with one (scale, offset) per row into int8 codes AND the int32 row sums of those
+    codes (the zero-point term of the W8A8 linear), one pass. Codes equal ``quantize_by_tile(weight, scale, (1, cols), ...)``.
+    ``rowsum_out``: a ZEROED contiguous int32 ``[rows]`` tensor to receive the sums (the kernel adds into it; a forward hands
+    out slices of one buffer it zeroes once). Returns None where the one-pass kernel does not apply (not bf16,
+    ``cols % 1024 != 0``): take ``quantize_by_tile``."""
+    if weight.dim() != 2:
+        raise RuntimeError("quantize_rows_rowsum expects a [rows, cols] weight")
+    rows, cols = weight.shape
+    if weight.dtype != torch.bfloat16 or cols % 1024 or not weight.is_contiguous():
+        return None
+    sc = scale.detach().reshape(-1).to(torch.float32).contiguous()
+    of = None if offset is None else offset.detach().reshape(-1).to(torch.float32).contiguous()
+    if sc.numel() != rows or (of is not None and of.numel() != rows):
+        raise RuntimeError(f"expected one scale (and offset) per row ({rows}), got {sc.numel()}")
+    wd = weight.detach()
+    lib, stream = _prepare(wd, sc, of)
+    codes = torch.empty((rows, cols), dtype=torch.int8, device=wd.device)
+    if rowsum_out is None:
+        rowsum = torch.zeros((rows,), dtype=torch.int32, device=wd.device)
+    else:
+        rowsum = rowsum_out
+        if rowsum.dtype != torch.int32 or rowsum.shape != (rows,) or not rowsum.is_contiguous() or rowsum.device != wd.device:
+            raise RuntimeError(f"rowsum_out must be a zeroed contiguous int32 tensor with {rows} entries on the weight's device")
+    lib.check(lib.ffq_quantize_rows_rowsum(_ptr(wd), _tag(wd.dtype), _ptr(sc), _ptr(of), rows, cols, float(num_bits), _ptr(codes), _ptr(rowsum), stream))
+    return codes, rowsum
 
 
 def _fan(quantizers: Sequence[tuple[torch.Tensor, torch.Tensor | None]], num_bits: float, shape: Sequence[int], device: torch.device):

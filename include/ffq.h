@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define FFQ_MAX_DIMS 8
-#define FFQ_ABI_VERSION 2
+#define FFQ_ABI_VERSION 3
 
 typedef enum ffq_status {
   FFQ_OK = 0,
@@ -325,6 +325,29 @@ int ffq_pack_gguf_blocks(const int8_t* codes, const float* scales, int64_t nbloc
 int ffq_gptq_block(float* weights, float* quantized, float* errors, int64_t rows, int64_t row_stride,
                    int64_t col0, int64_t block_cols, const float* hinv, int64_t hinv_stride, const float* scale,
                    int64_t scale_numel, const float* offset, int64_t offset_numel, double num_bits, void* stream);
+
+/*
+ * Weight codes and their row sums in one pass (ABI version 3). A6's zero-point term needs sum_k wq[n, k] for every weight row
+ * whenever the activation quantizer has an offset; with the reference's semantics the weight is re-quantized on every
+ * forward (nn/linear.py:34), so the sums change with it. ffq_quantize_rows_rowsum is A1 for a [rows, cols] weight with one
+ * (scale, offset) per row (PerChannel(0), `offset` nullable), int8 container, that also ADDS sum_k codes[r, k] to rowsum[r]
+ * (exact integers: int32 atomics; the caller zeroes `rowsum` first — one fill for all the weights of a forward); codes are bit-identical to ffq_quantize_by_tile. bf16 data, cols % 1024 == 0, anything
+ * else returns FFQ_ERR_DTYPE and the caller takes ffq_quantize_by_tile. The *_rs forms of the two GEMM entry points take
+ * such sums (nullable: NULL = compute them from the codes as before) instead of launching their own reduction; results are
+ * identical to the forms without.
+ */
+int ffq_quantize_rows_rowsum(const void* data, int data_dt, const float* scale, const float* offset, int64_t rows,
+                             int64_t cols, double num_bits, int8_t* codes, int32_t* rowsum, void* stream);
+int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                       const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset, int w_per_row,
+                       const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
+                       const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const int32_t* gate_rowsum,
+                            const int32_t* up_rowsum, const float* x_scale, const float* x_offset,
+                            const float* gate_w_scale, const float* up_w_scale, int8_t* codes_out, const float* out_scale,
+                            const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * The attention between q/k/v_proj and o_proj of the reference's quantized Llama —

@@ -1107,3 +1107,69 @@ int ffq_attention(const void* q, const void* k, const void* v, int dt, int64_t b
   free(acc);
   return FFQ_OK;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* ABI version 3: weight codes + their row sums in one call, and the GEMM entry points that    */
+/* take such sums. The restatement is the composition the fused forms replace: A1              */
+/* (_quantizer_impl.py:154-169) per row, then sum_k codes; as the checker it REFUSES row sums   */
+/* that are not the sums of the codes it is given.                                              */
+/* ------------------------------------------------------------------------------------------ */
+int ffq_quantize_rows_rowsum(const void* data, int data_dt, const float* scale, const float* offset, int64_t rows,
+                             int64_t cols, double num_bits, int8_t* codes, int32_t* rowsum, void* stream) {
+  if (rows < 0 || cols < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (data_dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "fused weight quantize + row sums is built for bf16 weights");
+  if (cols % 1024 != 0) return fail(FFQ_ERR_DTYPE, "fused weight quantize + row sums needs cols %% 1024 == 0");
+  if (rows == 0 || cols == 0) return FFQ_OK;
+  if (!data || !scale || !codes || !rowsum) return fail(FFQ_ERR_ARG, "NULL buffer");
+  ffq_tiling t;
+  memset(&t, 0, sizeof t);
+  t.ndim = 2;
+  t.shape[0] = rows; t.shape[1] = cols;
+  t.tile[0] = 1; t.tile[1] = cols;
+  int rc = ffq_quantize_by_tile(data, data_dt, scale, FFQ_F32, rows, offset, FFQ_F32, offset ? rows : 0, &t, num_bits, codes,
+                                FFQ_I8, stream);
+  if (rc) return rc;
+  for (int64_t r = 0; r < rows; ++r) {
+    int32_t sum = 0;
+    for (int64_t c = 0; c < cols; ++c) sum += codes[r * cols + c];
+    rowsum[r] += sum; /* the caller zeroes the sums */
+  }
+  return FFQ_OK;
+}
+
+static int check_rowsum(const char* what, const int8_t* wq, const int32_t* rowsum, int64_t N, int64_t K) {
+  if (!rowsum) return FFQ_OK;
+  for (int64_t n = 0; n < N; ++n) {
+    int32_t sum = 0;
+    for (int64_t k = 0; k < K; ++k) sum += wq[n * K + k];
+    if (sum != rowsum[n]) return fail(FFQ_ERR_ARG, "%s row sum %lld is %d, the codes sum to %d", what, (long long)n, rowsum[n], sum);
+  }
+  return FFQ_OK;
+}
+
+int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                       const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset, int w_per_row,
+                       const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
+                       const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (wq && N > 0 && K > 0) {
+    int rc = check_rowsum("weight", wq, w_rowsum, N, K);
+    if (rc) return rc;
+  }
+  return ffq_linear_w8a8(xq, wq, x_scale, x_offset, x_per_row, w_scale, w_offset, w_per_row, bias, bias_dt, out, out_dt,
+                         out_scale, out_offset, out_num_bits, M, N, K, workspace, workspace_bytes, stream);
+}
+
+int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const int32_t* gate_rowsum,
+                            const int32_t* up_rowsum, const float* x_scale, const float* x_offset,
+                            const float* gate_w_scale, const float* up_w_scale, int8_t* codes_out, const float* out_scale,
+                            const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (gate_wq && up_wq && N > 0 && K > 0) {
+    int rc = check_rowsum("gate", gate_wq, gate_rowsum, N, K);
+    if (!rc) rc = check_rowsum("up", up_wq, up_rowsum, N, K);
+    if (rc) return rc;
+  }
+  return ffq_mlp_gate_up_w8a8(xq, gate_wq, up_wq, x_scale, x_offset, gate_w_scale, up_w_scale, codes_out, out_scale, out_offset,
+                              out_num_bits, M, N, K, workspace, workspace_bytes, stream);
+}

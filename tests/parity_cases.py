@@ -240,6 +240,47 @@ def check_producers(device):
         ops.silu_mul_quantize(x, x[:1])
 
 
+def check_rowsum_fusion(device):
+    """ABI version 3: weight codes + their row sums in one pass, and the GEMM entry points that take them — the same codes
+    as A1, the exact integer sums, and bit-identical GEMM results with and without the sums handed in."""
+    import pytest
+
+    torch.manual_seed(31)
+    for rows, cols, with_offset in ((256, 2048, False), (128, 1024, True), (384, 3072, True)):
+        w = (torch.randn(rows, cols) * 0.02).to(torch.bfloat16).to(device)
+        scale = (w.float().abs().amax(1) / 127).clamp_min(1e-8)
+        offset = (torch.randn(rows, device=device) * 3) if with_offset else None
+        got = ops.quantize_rows_rowsum(w, scale, offset)
+        assert got is not None
+        codes, rowsum = got
+        assert torch.equal(codes, ops.quantize_by_tile(w, scale, (1, cols), 8, torch.int8, offset))
+        assert torch.equal(rowsum.cpu(), codes.cpu().int().sum(1).to(torch.int32))
+        x = torch.randint(-128, 128, (3, 40, cols), dtype=torch.int8, device=device)
+        xs, xo = torch.tensor([0.02], device=device), torch.tensor([5.0], device=device)
+        w_off = None if offset is None else offset
+        a = ops.linear_w8a8(x, codes, xs, xo, scale, w_off)
+        b = ops.linear_w8a8(x, codes, xs, xo, scale, w_off, w_rowsum=rowsum)
+        assert torch.equal(a, b)
+        if not ops._native.library().is_device:  # the oracle is the checker: it refuses sums that are not the codes' sums
+            with pytest.raises(ValueError, match="row sum"):
+                ops.linear_w8a8(x, codes, xs, xo, scale, w_off, w_rowsum=rowsum + 1)
+    # the one-launch MLP front half with the sums of both weight matrices
+    k, n = 1024, 256
+    g = (torch.randn(n, k) * 0.02).to(torch.bfloat16).to(device)
+    u = (torch.randn(n, k) * 0.02).to(torch.bfloat16).to(device)
+    gs, us = g.float().abs().amax(1) / 127, u.float().abs().amax(1) / 127
+    (gc, grs), (uc, urs) = ops.quantize_rows_rowsum(g, gs, None), ops.quantize_rows_rowsum(u, us, None)
+    x = torch.randint(-128, 128, (2, 96, k), dtype=torch.int8, device=device)
+    xs, xo = torch.tensor([0.03], device=device), torch.tensor([-7.0], device=device)
+    ds, do = torch.tensor([0.01], device=device), torch.tensor([-30.0], device=device)
+    plain = ops.mlp_gate_up_w8a8(x, gc, uc, xs, xo, gs, us, ds, do)
+    with_sums = ops.mlp_gate_up_w8a8(x, gc, uc, xs, xo, gs, us, ds, do, gate_rowsum=grs, up_rowsum=urs)
+    assert plain is not None and torch.equal(plain, with_sums)
+    # outside the one-pass kernel's range: the caller takes quantize_by_tile
+    assert ops.quantize_rows_rowsum(torch.zeros(4, 1000, dtype=torch.bfloat16, device=device), torch.ones(4, device=device), None) is None
+    assert ops.quantize_rows_rowsum(torch.zeros(4, 1024, device=device), torch.ones(4, device=device), None) is None
+
+
 def attention_reference64(q, k, v, head_dim, causal):
     """softmax(q k^T / sqrt(d) [+ causal mask]) v in float64 on the bf16 inputs: [batch, seq, heads * head_dim]."""
     b, s_, _ = q.shape

@@ -51,6 +51,10 @@ def test_fused_producers_rmsnorm_silu_rope():
     parity_cases.check_producers("cpu")
 
 
+def test_weight_codes_with_row_sums():
+    parity_cases.check_rowsum_fusion("cpu")
+
+
 def test_attention_chain_and_fused_output_quantizer():
     parity_cases.check_attention("cpu", exact_chain=True)
 
