@@ -350,10 +350,10 @@ class FusedForward:
         # attention + the o_proj input quantizer in one launch (ops.attention) where the kernel covers the shape
         self.fuse_attention = fuse_attention
         # weight codes and the row sums of the zero-point term in one pass (ops.quantize_rows_rowsum) where the kernel applies.
-        # OFF by default: the one-pass kernel is 5 us per weight cheaper than A1 + the reduction launch, but the Llama-3-8B
-        # forward measures 1.2 % SLOWER with it (tools/ab_forward.py, same box, 3 runs) — the separate reduction reads the
-        # fresh codes right before the GEMM does and leaves them in the Infinity Cache; without it the GEMMs lose more than
-        # the reduction cost.
+        # OFF by default: in isolation the one-pass kernel is 5 us per weight cheaper than A1 + the reduction launch
+        # (tools/rowsum_time.py), but the Llama-3-8B forward measures 1.2 % SLOWER with it (tools/ab_forward.py, same box, 3
+        # runs): the int8 GEMMs that follow run slower by more than the reduction cost (tools/gemm_cache_probe.py: a GEMM
+        # preceded by more memory-bound work is faster — the chip is power-limited and the light pass lets it recover).
         self.fuse_rowsums = fuse_rowsums
         self._zero_offset: dict[int, tuple[int, bool]] = {}
         self._weight_cache: dict[int, tuple[tuple[int, int, int], tuple[torch.Tensor, torch.Tensor | None]]] = {}
