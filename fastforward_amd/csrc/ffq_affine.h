@@ -42,17 +42,22 @@ struct Divider {
   }
 };
 
-// round(x / s - o) for E elements sharing one parameter pair.
+// round(x / s - o) for E elements sharing one parameter pair; the divider (its 1/s costs an IEEE division) can be shared
+// between chunks that hold the same scale.
 template <int DIVMODE, int E>
-__device__ __forceinline__ void quantize_chunk(const float (&x)[E], float s, float o, float (&r)[E]) {
-  Divider<DIVMODE> d(s);
+__device__ __forceinline__ void quantize_chunk_with(const Divider<DIVMODE>& d, const float (&x)[E], float o, float (&r)[E]) {
   if (DIVMODE == 1 && d.safe) {
 #pragma unroll
     for (int i = 0; i < E; ++i) r[i] = rne(d.fast(x[i]) - o);
   } else {
 #pragma unroll
-    for (int i = 0; i < E; ++i) r[i] = rne(x[i] / s - o);  // separate roundings: -ffp-contract=off
+    for (int i = 0; i < E; ++i) r[i] = rne(x[i] / d.s - o);  // separate roundings: -ffp-contract=off
   }
+}
+template <int DIVMODE, int E>
+__device__ __forceinline__ void quantize_chunk(const float (&x)[E], float s, float o, float (&r)[E]) {
+  const Divider<DIVMODE> d(s);
+  quantize_chunk_with<DIVMODE, E>(d, x, o, r);
 }
 
 // clamp + cast of E rounded values. Float containers: v_med3_f32 with NaN passed through

@@ -95,46 +95,69 @@ struct Pack4Args {
   uint32_t scale_stride, offset_stride;
 };
 
-template <typename T, bool HAS_OFFSET>
+// ITEM = elements of each half a lane owns (pack4_item). With ITEM = 8 on 16-bit data every load / store instruction of a
+// wave covers whole 128-byte lines; with 16 a lane's 32 bytes take two instructions that each touch every line of the wave's
+// span and use half of it. Both halves of a packing block that lie in one tile (group >= block) share one reciprocal.
+template <typename T, bool HAS_OFFSET, int ITEM>
 __global__ __launch_bounds__(kBlock) void quantize_pack_int4_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                                    const float* __restrict__ offset,
                                                                    uint8_t* __restrict__ packed, Pack4Args a) {
-  const uint32_t item = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
-  if (item >= a.nitems) return;
-  const uint32_t b = fdiv(item, a.items_per_block);
-  const uint32_t j = item - b * a.items_per_block.div;
-  const uint32_t e_lo = b * a.block + j * 16, e_hi = e_lo + a.block / 2;
-  Chunk<T, 16> cl, ch;
-  cl.load(x + e_lo);
-  ch.load(x + e_hi);
-  const uint32_t t_lo = a.rows ? fdiv(e_lo / 16, a.chunks_per_run) : 0u;
-  const uint32_t t_hi = a.rows ? fdiv(e_hi / 16, a.chunks_per_run) : 0u;
-  const float s_lo = scale[t_lo * a.scale_stride], s_hi = scale[t_hi * a.scale_stride];
-  const float o_lo = HAS_OFFSET ? rne(offset[t_lo * a.offset_stride]) : 0.0f;
-  const float o_hi = HAS_OFFSET ? rne(offset[t_hi * a.offset_stride]) : 0.0f;
-  float xl[16], xh[16], rl[16], rh[16];
+  constexpr int U = 1;  // items per lane (2 measured slower: see pack4_item)
+  const uint32_t first = blockIdx.x * (uint32_t)(kBlock * U) + threadIdx.x;
+  Chunk<T, ITEM> cl[U], ch[U];
+  uint32_t b[U], j[U], e_lo[U], e_hi[U];
+  bool live[U];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { xl[i] = cl.get(i); xh[i] = ch.get(i); }
-  quantize_chunk<1, 16>(xl, s_lo, o_lo, rl);
-  quantize_chunk<1, 16>(xh, s_hi, o_hi, rh);
-  Chunk<uint8_t, 16> out;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    uint32_t word = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int l = (int)rl[4 * w + i], h = (int)rh[4 * w + i];  // v_cvt_i32_f32: NaN -> 0 (the int8 container's value)
-      l = (l < -8 ? -8 : (l > 7 ? 7 : l)) + 8;
-      h = (h < -8 ? -8 : (h > 7 ? 7 : h)) + 8;
-      word |= (uint32_t)(l | (h << 4)) << (8 * i);
+  for (int u = 0; u < U; ++u) {
+    const uint32_t item = first + u * kBlock;
+    live[u] = item < a.nitems;
+    b[u] = fdiv(live[u] ? item : 0u, a.items_per_block);
+    j[u] = (live[u] ? item : 0u) - b[u] * a.items_per_block.div;
+    e_lo[u] = b[u] * a.block + j[u] * ITEM;
+    e_hi[u] = e_lo[u] + a.block / 2;
+    if (live[u]) {
+      cl[u].load(x + e_lo[u]);
+      ch[u].load(x + e_hi[u]);
     }
-    out.w[w] = word;
   }
-  out.store(packed + (size_t)b * (a.block / 2) + j * 16);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (!live[u]) continue;
+    const uint32_t t_lo = a.rows ? fdiv(e_lo[u] / 16, a.chunks_per_run) : 0u;
+    const uint32_t t_hi = a.rows ? fdiv(e_hi[u] / 16, a.chunks_per_run) : 0u;
+    const float s_lo = scale[t_lo * a.scale_stride];
+    const float o_lo = HAS_OFFSET ? rne(offset[t_lo * a.offset_stride]) : 0.0f;
+    float xl[ITEM], xh[ITEM], rl[ITEM], rh[ITEM];
+#pragma unroll
+    for (int i = 0; i < ITEM; ++i) { xl[i] = cl[u].get(i); xh[i] = ch[u].get(i); }
+    const Divider<1> d_lo(s_lo);
+    quantize_chunk_with<1, ITEM>(d_lo, xl, o_lo, rl);
+    if (t_hi == t_lo) {  // both halves of the packing block inside one tile (group >= block): one reciprocal
+      quantize_chunk_with<1, ITEM>(d_lo, xh, o_lo, rh);
+    } else {
+      const float s_hi = scale[t_hi * a.scale_stride];
+      const float o_hi = HAS_OFFSET ? rne(offset[t_hi * a.offset_stride]) : 0.0f;
+      quantize_chunk<1, ITEM>(xh, s_hi, o_hi, rh);
+    }
+    Chunk<uint8_t, ITEM> out;
+#pragma unroll
+    for (int w = 0; w < ITEM / 4; ++w) {
+      uint32_t word = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int l = (int)rl[4 * w + i], h = (int)rh[4 * w + i];  // v_cvt_i32_f32: NaN -> 0 (the int8 container's value)
+        l = (l < -8 ? -8 : (l > 7 ? 7 : l)) + 8;
+        h = (h < -8 ? -8 : (h > 7 ? 7 : h)) + 8;
+        word |= (uint32_t)(l | (h << 4)) << (8 * i);
+      }
+      out.w[w] = word;
+    }
+    out.store(packed + (size_t)b[u] * (a.block / 2) + j[u] * ITEM);
+  }
 }
 
 // ---- A7 + A2 in one pass: nibbles -> codes -> (q + round(o)) * s (0.5 + 2 B/elem for bf16) -------------
-template <typename T, bool HAS_OFFSET>
+template <typename T, bool HAS_OFFSET, int ITEM>
 __global__ __launch_bounds__(kBlock) void unpack_dequantize_int4_kernel(const uint8_t* __restrict__ packed,
                                                                        const float* __restrict__ scale,
                                                                        const float* __restrict__ offset, T* __restrict__ out,
@@ -143,30 +166,41 @@ __global__ __launch_bounds__(kBlock) void unpack_dequantize_int4_kernel(const ui
   if (item >= a.nitems) return;
   const uint32_t b = fdiv(item, a.items_per_block);
   const uint32_t j = item - b * a.items_per_block.div;
-  const uint32_t e_lo = b * a.block + j * 16, e_hi = e_lo + a.block / 2;
-  Chunk<uint8_t, 16> in;
-  in.load(packed + (size_t)b * (a.block / 2) + j * 16);
+  const uint32_t e_lo = b * a.block + j * ITEM, e_hi = e_lo + a.block / 2;
+  Chunk<uint8_t, ITEM> in;
+  in.load(packed + (size_t)b * (a.block / 2) + j * ITEM);
   const uint32_t t_lo = a.rows ? fdiv(e_lo / 16, a.chunks_per_run) : 0u;
   const uint32_t t_hi = a.rows ? fdiv(e_hi / 16, a.chunks_per_run) : 0u;
   const float s_lo = scale[t_lo * a.scale_stride], s_hi = scale[t_hi * a.scale_stride];
   const float o_lo = HAS_OFFSET ? rne(offset[t_lo * a.offset_stride]) : 0.0f;
   const float o_hi = HAS_OFFSET ? rne(offset[t_hi * a.offset_stride]) : 0.0f;
-  float yl[16], yh[16];
+  float yl[ITEM], yh[ITEM];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < ITEM; ++i) {
     const uint32_t byte = (in.w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
     yl[i] = ((float)((int)(byte & 15u) - 8) + o_lo) * s_lo;  // add and multiply are separate fp32 roundings
     yh[i] = ((float)((int)(byte >> 4) - 8) + o_hi) * s_hi;
   }
-  Chunk<T, 16> cl, ch;
+  Chunk<T, ITEM> cl, ch;
   cl.pack(yl);
   ch.pack(yh);
   cl.store(out + e_lo);
   ch.store(out + e_hi);
 }
 
+// Elements of each half per lane. Measured on [14336, 4096] bf16, group 128 (tools/arith_ab.py, A/B on one box):
+// unpack+dequantize 5.03-5.10 TB/s with 16, 5.51-5.59 with 8 (its two 16-bit stores become whole-line instructions);
+// quantize+pack 5.25-5.31 with 16, 5.20-5.29 with 8 and 4.6-4.7 with 8 x 2 items per lane (a second reciprocal per 8
+// elements, and short blocks beat unrolled ones here as in A1) — so the two directions take different shapes.
+static int pack4_item(int dt, bool unpack) {
+  static const int forced = getenv("FFQ_PACK_ITEM") ? atoi(getenv("FFQ_PACK_ITEM")) : 0;
+  if (dt == FFQ_F32) return 16;
+  if (forced == 8 || forced == 16) return forced;
+  return unpack ? 8 : 16;
+}
+
 static int pack4_plan(const ffq_tiling* tiling, int64_t block, int64_t scale_numel, const float* offset, int64_t offset_numel,
-                      Pack4Args* a, int64_t* numel) {
+                      Pack4Args* a, int64_t* numel, int item = 16) {
   TileInfo info;
   int rc = analyse(tiling, &info);
   if (rc) return rc;
@@ -179,9 +213,9 @@ static int pack4_plan(const ffq_tiling* tiling, int64_t block, int64_t scale_num
   const bool layout_ok = info.layout == LAYOUT_SCALAR || (info.layout == LAYOUT_ROWS && info.run % 16 == 0);
   if (!layout_ok || block % 32 != 0 || info.numel >= ((int64_t)1 << 32))
     return fail(FFQ_ERR_DTYPE, "fused 4-bit kernels cover per-tensor / contiguous-run tiles (run %% 16 == 0) and block %% 32 == 0");
-  a->nitems = (uint32_t)(info.numel / 32);
+  a->nitems = (uint32_t)(info.numel / (2 * item));
   a->block = (uint32_t)block;
-  a->items_per_block = make_fastdiv((uint32_t)(block / 32));
+  a->items_per_block = make_fastdiv((uint32_t)(block / (2 * item)));
   a->rows = info.layout == LAYOUT_ROWS;
   a->chunks_per_run = make_fastdiv(a->rows ? (uint32_t)(info.run / 16) : 1u);
   a->scale_stride = scale_numel == 1 ? 0u : 1u;
@@ -316,22 +350,23 @@ extern "C" int ffq_quantize_pack_int4(const void* data, int data_dt, const float
   hipStream_t s = static_cast<hipStream_t>(stream);
   Pack4Args a;
   int64_t numel = 0;
-  int rc = pack4_plan(tiling, block, scale_numel, offset, offset_numel, &a, &numel);
+  const int item = pack4_item(data_dt, false);
+  int rc = pack4_plan(tiling, block, scale_numel, offset, offset_numel, &a, &numel, item);
   if (rc) return rc;
   if (numel == 0) return FFQ_OK;
   if (!data || !scale || !packed) return fail(FFQ_ERR_ARG, "NULL buffer");
   if (!(data_dt == FFQ_BF16 || data_dt == FFQ_F16 || data_dt == FFQ_F32) || !aligned16(data) || !aligned16(packed))
     return fail(FFQ_ERR_DTYPE, "fused quantize+pack is built for 16-byte aligned f32 / bf16 / f16 data");
   const unsigned grid = (a.nitems + kBlock - 1) / kBlock;
-#define FFQ_QP(T)                                                                                                   \
+#define FFQ_QP(T, I)                                                                                                \
   do {                                                                                                              \
-    if (offset) quantize_pack_int4_kernel<T, true><<<grid, kBlock, 0, s>>>(static_cast<const T*>(data), scale, offset, packed, a); \
-    else quantize_pack_int4_kernel<T, false><<<grid, kBlock, 0, s>>>(static_cast<const T*>(data), scale, offset, packed, a);       \
+    if (offset) quantize_pack_int4_kernel<T, true, I><<<grid, kBlock, 0, s>>>(static_cast<const T*>(data), scale, offset, packed, a); \
+    else quantize_pack_int4_kernel<T, false, I><<<grid, kBlock, 0, s>>>(static_cast<const T*>(data), scale, offset, packed, a);       \
   } while (0)
   switch (data_dt) {
-    case FFQ_BF16: FFQ_QP(bf16_t); break;
-    case FFQ_F16: FFQ_QP(f16_t); break;
-    default: FFQ_QP(float); break;
+    case FFQ_BF16: if (item == 8) FFQ_QP(bf16_t, 8); else FFQ_QP(bf16_t, 16); break;
+    case FFQ_F16: if (item == 8) FFQ_QP(f16_t, 8); else FFQ_QP(f16_t, 16); break;
+    default: FFQ_QP(float, 16); break;
   }
 #undef FFQ_QP
   return check_launch("quantize_pack_int4_kernel");
@@ -343,22 +378,23 @@ extern "C" int ffq_unpack_dequantize_int4(const uint8_t* packed, const float* sc
   hipStream_t s = static_cast<hipStream_t>(stream);
   Pack4Args a;
   int64_t numel = 0;
-  int rc = pack4_plan(tiling, block, scale_numel, offset, offset_numel, &a, &numel);
+  const int item = pack4_item(out_dt, true);
+  int rc = pack4_plan(tiling, block, scale_numel, offset, offset_numel, &a, &numel, item);
   if (rc) return rc;
   if (numel == 0) return FFQ_OK;
   if (!packed || !scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
   if (!(out_dt == FFQ_BF16 || out_dt == FFQ_F16 || out_dt == FFQ_F32) || !aligned16(out) || !aligned16(packed))
     return fail(FFQ_ERR_DTYPE, "fused unpack+dequantize is built for 16-byte aligned f32 / bf16 / f16 outputs");
   const unsigned grid = (a.nitems + kBlock - 1) / kBlock;
-#define FFQ_UD(T)                                                                                                   \
+#define FFQ_UD(T, I)                                                                                                \
   do {                                                                                                              \
-    if (offset) unpack_dequantize_int4_kernel<T, true><<<grid, kBlock, 0, s>>>(packed, scale, offset, static_cast<T*>(out), a); \
-    else unpack_dequantize_int4_kernel<T, false><<<grid, kBlock, 0, s>>>(packed, scale, offset, static_cast<T*>(out), a);       \
+    if (offset) unpack_dequantize_int4_kernel<T, true, I><<<grid, kBlock, 0, s>>>(packed, scale, offset, static_cast<T*>(out), a); \
+    else unpack_dequantize_int4_kernel<T, false, I><<<grid, kBlock, 0, s>>>(packed, scale, offset, static_cast<T*>(out), a);       \
   } while (0)
   switch (out_dt) {
-    case FFQ_BF16: FFQ_UD(bf16_t); break;
-    case FFQ_F16: FFQ_UD(f16_t); break;
-    default: FFQ_UD(float); break;
+    case FFQ_BF16: if (item == 8) FFQ_UD(bf16_t, 8); else FFQ_UD(bf16_t, 16); break;
+    case FFQ_F16: if (item == 8) FFQ_UD(f16_t, 8); else FFQ_UD(f16_t, 16); break;
+    default: FFQ_UD(float, 16); break;
   }
 #undef FFQ_UD
   return check_launch("unpack_dequantize_int4_kernel");
