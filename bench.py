@@ -151,6 +151,12 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
         per_shape = per_shape_random
     achieved = total_ops / total_ms / 1e9
     traffic, prof = pmc_traffic("w8a8_gemm256fp_kernel", "bf16_t")
+    # what back-to-back MFMAs alone sustain on toggling operands (no memory traffic): tools/probes/mfma_power.hip, committed run
+    ceiling = None
+    probe = ROOT / "profiles" / "r01_mfma_power_probe.txt"
+    if probe.exists():
+        rates = [float(line.split("toggling")[1].split("TOP/s")[0]) for line in probe.read_text().splitlines() if line.startswith("32x32x32 random bytes")]
+        ceiling = round(statistics.mean(rates), 1) if rates else None
     return {
         "bound": "mfma",
         "kernel": "w8a8_gemm256fp_kernel (v_mfma_i32_32x32x32_i8, 256x256 tiles, persistent one-block-per-CU tile loop, ping-pong wave groups, full-line LDS-DMA staging; plain and gate+up/SiLU-epilogue modes) + rowsum_i8_kernel",
@@ -159,6 +165,9 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
         "unit": "TFLOP/s",
         "unit_note": "integer multiply-accumulates (TOP/s); dense int8 MFMA peak",
         "frac": round(achieved / INT8_PEAK_TOPS, 4),
+        "mfma_only_ceiling_on_toggling_operands": ceiling,
+        "mfma_only_ceiling_note": None if ceiling is None else "TOP/s of v_mfma_i32_32x32x32_i8 issued back to back on random operands, no LDS / global traffic "
+                                  "(profiles/r01_mfma_power_probe.txt): the chip is power-limited on real data; frac stays against the nominal peak",
         "traffic": traffic,
         "traffic_note": None if traffic is None else f"HBM read+write bytes per launch, mean over the forward's launch mix; PMC passes of profiles/{prof}_pmc_*.json",
         "avg_launch_ms": round(total_ms / launches, 4),
@@ -265,7 +274,7 @@ def cpu_baseline(config: llama.LlamaConfig, budget_s: float = 20.0) -> dict:
     probe2 = layer(2 * probe_tokens)
     slope = max((probe2 - probe) / probe_tokens, 1e-9)
     fixed = max(probe - slope * probe_tokens, 0.0)
-    tokens = int(min(2048, max(128, (budget_s - fixed) / slope)))
+    tokens = int(min(8192, max(128, (budget_s - fixed) / slope)))
     tokens = 1 << (tokens.bit_length() - 1)
     seconds = layer(tokens)
     return {
