@@ -277,6 +277,9 @@ def cpu_baseline(config: llama.LlamaConfig, budget_s: float = 20.0) -> dict:
     tokens = int(min(8192, max(128, (budget_s - fixed) / slope)))
     tokens = 1 << (tokens.bit_length() - 1)
     seconds = layer(tokens)
+    while seconds < 10.0 and tokens < 8192:  # the probes over-estimate the slope: grow the sample to >= 10 s of CPU work
+        tokens *= 2
+        seconds = layer(tokens)
     return {
         "value": round(tokens / (seconds * config.num_layers), 3),
         "unit": "tokens/s",
