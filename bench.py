@@ -323,6 +323,11 @@ def main() -> None:
     # calibration: RunningMinMax on this rank's share, then ONE all-reduce of the activation ranges
     calib_steps = max(1, args.calib_seqs // args.batch)
     calib = [torch.randint(0, config.vocab_size, (args.batch, args.seq_len), device=device, generator=gen) for _ in range(calib_steps)]
+    # untimed pass over the first batch: code objects load, lazily shaped quantizer parameters materialise, the allocator
+    # grows (0.3-0.4 s, once per process). The timed calibration below starts from fresh estimators and overwrites every range.
+    ffd.calibrate_sharded(model, calib[:1], disable_quantization=False, fused=not args.module_graph)
+    if world > 1:
+        torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     payload = ffd.calibrate_sharded(model, calib, disable_quantization=False, fused=not args.module_graph)
