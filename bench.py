@@ -297,7 +297,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="sequences per GPU per step")
     ap.add_argument("--seq-len", type=int, default=2048)
-    ap.add_argument("--calib-seqs", type=int, default=16, help="calibration sequences per GPU (BASELINE config: 512 in total)")
+    ap.add_argument("--calib-seqs", type=int, default=64, help="calibration sequences per GPU (BASELINE config: 512 in total = 64 per GPU on 8 GPUs)")
     ap.add_argument("--model", choices=["llama3-8b", "llama3-70b", "tiny"], default="llama3-8b")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--module-graph", action="store_true", help="run the reference-shaped module graph (one quantizer call per linear input, "
