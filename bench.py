@@ -310,6 +310,7 @@ def main() -> None:
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
+    local_rank %= torch.cuda.device_count()  # identity with one GPU per rank; lets several ranks share a GPU in a gloo dry run
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     config = {"llama3-8b": llama.LlamaConfig.llama3_8b, "llama3-70b": llama.LlamaConfig.llama3_70b, "tiny": llama.LlamaConfig.tiny}[args.model]()

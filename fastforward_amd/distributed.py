@@ -51,8 +51,8 @@ def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, i
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # FFQ_DIST_BACKEND=gloo: several ranks on one GPU (a control-flow check; RCCL wants one device per rank)
+            backend = os.environ.get("FFQ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
