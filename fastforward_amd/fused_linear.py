@@ -1,4 +1,4 @@
-"""The W8A8 linear registered in the quantized-operator dispatcher (plug-in seam #2).
+"""The W8A8 linear — and mm / matmul / bmm — registered in the quantized-operator dispatcher (plug-in seam #2).
 
 The reference registers no kernel for ``"linear"``; every quantized linear therefore runs
 ``fallback.linear`` (src/fastforward/_gen/fallback.py:77-112): dequantize x, dequantize w, float
@@ -93,3 +93,92 @@ def fused_linear(input: QuantizedTensor, weight: QuantizedTensor, bias: Any = No
 
 fused_linear_predicate = Predicate(_supported)
 _registration = register("linear", fused_linear_predicate, fused_linear)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# mm / matmul / bmm: the same fallback pattern in the reference (src/fastforward/_gen/fallback.py:699-798: dequantize both
+# operands, float matmul, output quantizer), the same int8 contraction here. The right operand arrives as [K, N]; the GEMM
+# contracts K-contiguous rows, so its codes are transposed once (1 B/elem; free when the operand is itself a transposed
+# view of a K-contiguous tensor, e.g. ``k.transpose(-1, -2)``). Per-tensor or per-COLUMN parameters on the right operand
+# (PerChannel(-1): one pair per output column), per-tensor or per-row on the left; everything else takes the float fallback.
+# ---------------------------------------------------------------------------------------------------------------
+def _col_mode(tensor: QuantizedTensor) -> str | None:
+    """'tensor' or 'col' (one parameter pair per column of a [K, N] matrix) for the right operand of a matmul."""
+    params = tensor.quantization_context.quantization_params
+    tile = params.granularity.tile_size(tensor.shape)
+    if isinstance(tile, str) or tuple(tile) == tuple(tensor.shape):
+        return "tensor"
+    if tensor.dim() == 2 and tile[0] == tensor.shape[0] and tile[1] == 1:
+        return "col"
+    return None
+
+
+def _on_backend(*tensors: Any) -> bool:
+    try:
+        lib = _native.library()
+    except Exception:
+        return False
+    return all(t.is_cuda for t in tensors) if lib.is_device else all(t.device.type == "cpu" for t in tensors)
+
+
+def _bits_and_dtypes_ok(a: QuantizedTensor, b: QuantizedTensor) -> bool:
+    ap, bp = a.quantization_context.quantization_params, b.quantization_context.quantization_params
+    if ap.num_bits > 8 or bp.num_bits > 8 or ap.num_bits != int(ap.num_bits) or bp.num_bits != int(bp.num_bits):
+        return False
+    deq = ap.dequantize_dtype or torch.get_default_dtype()
+    return deq in (torch.bfloat16, torch.float16, torch.float32) and (bp.dequantize_dtype or deq) == deq
+
+
+def _supported_mm(input: Any = None, other: Any = None, mat2: Any = None, **_: Any) -> bool:
+    right = other if other is not None else mat2
+    if not (_static_affine(input) and _static_affine(right)) or not _on_backend(input, right):
+        return False
+    if right.dim() != 2 or input.dim() < 1 or input.shape[-1] != right.shape[0] or right.shape[0] % 16 or input.numel() == 0 or right.numel() == 0:
+        return False
+    return _bits_and_dtypes_ok(input, right) and _row_mode(input) is not None and _col_mode(right) is not None
+
+
+def _params_of(t: QuantizedTensor) -> tuple[torch.Tensor, torch.Tensor | None]:
+    p = t.quantization_context.quantization_params
+    return torch.as_tensor(p.scale, device=t.device), None if p.offset is None else torch.as_tensor(p.offset, device=t.device)
+
+
+def fused_mm(input: QuantizedTensor, other: QuantizedTensor | None = None, *, mat2: QuantizedTensor | None = None, output_quantizer: Any = None,
+             strict_quantization: bool | None = None) -> torch.Tensor:
+    right = other if other is not None else mat2
+    if strict_quantization and output_quantizer is None:
+        raise QuantizationError("'output_quantizer' must be provided if strict_quantization=True")
+    deq = input.quantization_context.quantization_params.dequantize_dtype or torch.get_default_dtype()
+    (xs, xo), (ws, wo) = _params_of(input), _params_of(right)
+    w_codes = _int8_codes(right).t().contiguous()  # [N, K]
+    out = ops.linear_w8a8(_int8_codes(input), w_codes, x_scale=xs, x_offset=xo, w_scale=ws, w_offset=wo, bias=None, out_dtype=deq)
+    return output_quantizer(out) if output_quantizer is not None else out
+
+
+def _supported_bmm(input: Any = None, mat2: Any = None, **_: Any) -> bool:
+    if not (_static_affine(input) and _static_affine(mat2)) or not _on_backend(input, mat2):
+        return False
+    if input.dim() != 3 or mat2.dim() != 3 or input.shape[0] != mat2.shape[0] or input.shape[2] != mat2.shape[1]:
+        return False
+    if input.shape[2] % 16 or input.numel() == 0 or mat2.numel() == 0 or input.shape[0] > 256:
+        return False
+    # one parameter pair for each operand: the batch shares it, every matrix of the batch is one GEMM
+    return _bits_and_dtypes_ok(input, mat2) and _row_mode(input) == "tensor" and _row_mode(mat2) == "tensor"
+
+
+def fused_bmm(input: QuantizedTensor, mat2: QuantizedTensor, *, output_quantizer: Any = None, strict_quantization: bool | None = None) -> torch.Tensor:
+    if strict_quantization and output_quantizer is None:
+        raise QuantizationError("'output_quantizer' must be provided if strict_quantization=True")
+    deq = input.quantization_context.quantization_params.dequantize_dtype or torch.get_default_dtype()
+    (xs, xo), (ws, wo) = _params_of(input), _params_of(mat2)
+    x_codes, w_codes = _int8_codes(input), _int8_codes(mat2).transpose(1, 2).contiguous()  # [B, N, K]
+    out = torch.stack([ops.linear_w8a8(x_codes[b], w_codes[b], x_scale=xs, x_offset=xo, w_scale=ws, w_offset=wo, bias=None, out_dtype=deq)
+                       for b in range(x_codes.shape[0])])
+    return output_quantizer(out) if output_quantizer is not None else out
+
+
+fused_mm_predicate = Predicate(_supported_mm)
+fused_bmm_predicate = Predicate(_supported_bmm)
+_registration_mm = register("mm", fused_mm_predicate, fused_mm)
+_registration_matmul = register("matmul", fused_mm_predicate, fused_mm)
+_registration_bmm = register("bmm", fused_bmm_predicate, fused_bmm)

@@ -240,6 +240,55 @@ def check_producers(device):
         ops.silu_mul_quantize(x, x[:1])
 
 
+def check_matmul_family(device):
+    """mm / matmul / bmm on quantized operands (reference fallback: src/fastforward/_gen/fallback.py:699-798 — dequantize both,
+    float op, output quantizer): the dispatcher takes the int8 contraction where the GEMM covers the granularities and the
+    float fallback elsewhere; both must agree with the float64 product of the dequantized operands like the linear does."""
+    torch.manual_seed(41)
+    F_ = ff.nn.functional
+
+    def quantized(t, **kw):
+        q = ff.nn.LinearQuantizer(8, quantized_dtype=torch.int8, device=device, **kw)
+        with ff.estimate_ranges(q, ff.range_setting.running_minmax):
+            return q(t.to(device))
+
+    def close(got, a, b, op):
+        want = op(a.dequantize().detach().double().cpu(), b.dequantize().detach().double().cpu())
+        assert got.dtype == torch.bfloat16 and got.shape == want.shape
+        torch.testing.assert_close(got.cpu().double(), want, atol=2.0**-7 * float(want.detach().abs().max()), rtol=2.0**-7)
+
+    x3 = torch.randn(5, 24, 64).to(torch.bfloat16)
+    x2 = torch.randn(40, 64).to(torch.bfloat16)
+    w = (torch.randn(64, 48) * 0.1).to(torch.bfloat16)
+    with ff.strict_quantization(False):
+        for x in (x3, x2):
+            for wkw in ({}, {"granularity": ff.PerChannel(-1)}, {"granularity": ff.PerChannel(-1), "symmetric": False}):
+                a, b = quantized(x, symmetric=False), quantized(w, **wkw)
+                assert ff.dispatcher.dispatch("matmul", input=a, other=b) is not None
+                close(F_.matmul(a, b), a, b, torch.matmul)
+                close(torch.matmul(a, b), a, b, torch.matmul)          # the __torch_function__ route
+                if x.dim() == 2:
+                    close(F_.mm(a, b), a, b, torch.mm)
+        # per-row parameters on the RIGHT operand (one pair per k): not a GEMM epilogue — float fallback, same answer
+        a, b = quantized(x2, symmetric=False), quantized(w, granularity=ff.PerChannel(0))
+        assert ff.dispatcher.dispatch("mm", input=a, mat2=b) is None
+        close(F_.mm(a, b), a, b, torch.mm)
+        # bmm: one parameter pair per operand
+        a, b = quantized(torch.randn(3, 10, 32).to(torch.bfloat16), symmetric=False), quantized(torch.randn(3, 32, 20).to(torch.bfloat16))
+        assert ff.dispatcher.dispatch("bmm", input=a, mat2=b) is not None
+        close(F_.bmm(a, b), a, b, torch.bmm)
+        # an output quantizer is applied to the result
+        out_q = ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=torch.int8, device=device)
+        a, b = quantized(x2, symmetric=False), quantized(w)
+        with ff.estimate_ranges(out_q, ff.range_setting.running_minmax):
+            y = F_.mm(a, b, output_quantizer=out_q)
+        assert isinstance(y, ff.QuantizedTensor)
+    import pytest
+
+    with pytest.raises(ff.exceptions.QuantizationError):
+        F_.mm(quantized(x2), quantized(w), strict_quantization=True)  # strict: an output quantizer is required
+
+
 def check_rowsum_fusion(device):
     """ABI version 3: weight codes + their row sums in one pass, and the GEMM entry points that take them — the same codes
     as A1, the exact integer sums, and bit-identical GEMM results with and without the sums handed in."""

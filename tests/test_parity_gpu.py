@@ -69,6 +69,10 @@ def test_fused_producers_rmsnorm_silu_rope():
     parity_cases.check_producers(DEV)
 
 
+def test_mm_matmul_bmm_through_the_dispatcher():
+    parity_cases.check_matmul_family(DEV)
+
+
 def test_weight_codes_with_row_sums():
     parity_cases.check_rowsum_fusion(DEV)
 
