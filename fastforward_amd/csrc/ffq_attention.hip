@@ -322,11 +322,10 @@ extern "C" int ffq_attention(const void* q, const void* k, const void* v, int dt
   a.hi = codes_out ? (float)(half - 1.0) : 0.0f;
   const int64_t blocks = (int64_t)a.nqb * q_heads * batch;
   if (blocks >= ((int64_t)1 << 31)) return fail(FFQ_ERR_ARG, "too many workgroups");
-  static bool once = false;
-  if (!once) {  // 72 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking
+  static uint64_t once = 0;
+  if (first_use_on_this_device(&once)) {  // 72 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    once = true;
   }
   const dim3 grid((unsigned)blocks), block(kWaves * 64);
   if (causal) attention_fwd_kernel<true><<<grid, block, kLdsBytes, s>>>(a);

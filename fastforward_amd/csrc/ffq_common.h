@@ -179,6 +179,17 @@ __device__ inline int64_t generic_tile_of(const GenericTiling& g, int64_t flat) 
   return tile;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: "done once" flags are bit masks indexed by the current
+// device, so a process that launches on several GPUs raises the attribute on each of them (ops.py:91).
+inline bool first_use_on_this_device(uint64_t* mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = (uint64_t)1 << (dev & 63);
+  if (__atomic_load_n(mask, __ATOMIC_RELAXED) & bit) return false;
+  __atomic_fetch_or(mask, bit, __ATOMIC_RELAXED);
+  return true;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 constexpr int kBlock = 256;       // 4 waves of 64 lanes

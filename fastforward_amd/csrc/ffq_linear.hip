@@ -1441,24 +1441,22 @@ extern "C" int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int3
       const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128;
 #define FFQ_GEMM3_FP(T, RQ)                                                                                \
   do {                                                                                                     \
-    static bool attr_set_fp = false;                                                                       \
-    if (!attr_set_fp) {                                                                                    \
+    static uint64_t attr_set_fp = 0;                                                                       \
+    if (first_use_on_this_device(&attr_set_fp)) {                                                                                    \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fp_kernel<T, RQ, false>),       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fp);                  \
-      attr_set_fp = true;                                                                                  \
     }                                                                                                      \
     w8a8_gemm256fp_kernel<T, RQ, false><<<grid_fp, 512, lds_fp, s>>>(a, (int)grid3);                       \
   } while (0)
 #define FFQ_GEMM3_W(T, RQ, WO)                                                                             \
   do {                                                                                                     \
     if (fp) { FFQ_GEMM3_FP(T, RQ); break; }                                                                \
-    static bool attr_set = false;                                                                          \
-    if (!attr_set) {                                                                                       \
+    static uint64_t attr_set = 0;                                                                          \
+    if (first_use_on_this_device(&attr_set)) {                                                                                       \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256pp_kernel<T, RQ, WO>),          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);                    \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fl_kernel<T, RQ, WO>),          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);                    \
-      attr_set = true;                                                                                     \
     }                                                                                                      \
     if (fl) w8a8_gemm256fl_kernel<T, RQ, WO><<<grid3, 512, lds3, s>>>(a);                                  \
     else w8a8_gemm256pp_kernel<T, RQ, WO><<<grid3, 512, lds3, s>>>(a);                                     \
@@ -1494,11 +1492,10 @@ extern "C" int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int3
     const size_t lds_bytes = ring_bytes > epilogue_bytes ? ring_bytes : epilogue_bytes;
 #define FFQ_GEMM2_NW(T, RQ, NW, WO)                                                                        \
   do {                                                                                                     \
-    static bool attr_set = false;                                                                          \
-    if (!attr_set) {                                                                                       \
+    static uint64_t attr_set = 0;                                                                          \
+    if (first_use_on_this_device(&attr_set)) {                                                                                       \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256_kernel<T, RQ, NW, WO>),        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);               \
-      attr_set = true;                                                                                     \
     }                                                                                                      \
     w8a8_gemm256_kernel<T, RQ, NW, WO><<<grid2, NW * 64, lds_bytes, s>>>(a);                               \
   } while (0)
@@ -1616,23 +1613,21 @@ extern "C" int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, 
     a.rowsum_w = ws; a.rowsum_w2 = ws + N;
   }
   const size_t lds = (size_t)STAGES3 * (BM2 + 256) * BK2;  // the ring (128 KiB) also holds the 36 KiB output tile
-  static bool attr_set = false;
-  if (!attr_set) {
+  static uint64_t attr_set = 0;
+  if (first_use_on_this_device(&attr_set)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256pp_kernel<int8_t, true, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fl_kernel<int8_t, true, false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   static const int use_fl = getenv("FFQ_GEMM_FL") ? atoi(getenv("FFQ_GEMM_FL")) : 1;
   static const int use_fp = getenv("FFQ_GEMM_FP") ? atoi(getenv("FFQ_GEMM_FP")) : 1;  // persistent tile loop: +4.9 % (A/B on one box)
   if (use_fl && use_fp && K % 128 == 0) {
-    static bool attr_set_fp = false;
+    static uint64_t attr_set_fp = 0;
     const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128;
-    if (!attr_set_fp) {
+    if (first_use_on_this_device(&attr_set_fp)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fp_kernel<int8_t, true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fp);
-      attr_set_fp = true;
     }
     const int total = a.tiles_m * a.tiles_n;
     w8a8_gemm256fp_kernel<int8_t, true, true><<<(unsigned)(total < 256 ? total : 256), 512, lds_fp, s>>>(a, total);

@@ -78,31 +78,61 @@ def _activation_estimators(model: torch.nn.Module) -> list[tuple[Quantizer, Runn
     return pairs
 
 
+def _range_entries(quantizer: Quantizer, estimator: RunningMinMaxEstimator) -> int:
+    """Number of (min, max) pairs this quantizer contributes to the exchange — a function of the MODEL, not of what this
+    rank happened to see, so that every rank builds a buffer of the same length: the estimator's own count when it saw
+    data, else the quantizer's materialised parameter count, else 1 for a per-tensor quantizer."""
+    if estimator.min is not None:
+        return estimator.min.numel()
+    scale = getattr(quantizer, "scale", None)
+    if isinstance(scale, torch.Tensor) and not isinstance(scale, torch.nn.parameter.UninitializedTensorMixin):
+        return scale.numel()
+    if getattr(quantizer, "per_tensor", False):
+        return 1
+    raise RuntimeError(
+        "all_reduce_ranges: a rank saw no data for a non-per-tensor activation quantizer that was never initialised, so the "
+        "size of its range is unknown on that rank; give every rank at least one calibration batch"
+    )
+
+
 def all_reduce_ranges(model: torch.nn.Module, group: dist.ProcessGroup | None = None) -> int:
     """Reduce the running (min, max) of all activation quantizers across ranks with one collective
-    and set the global range on every quantizer. Returns the number of floats exchanged."""
-    pairs = [(q, e) for q, e in _activation_estimators(model) if e.min is not None and e.max is not None]
+    and set the global range on every quantizer. Returns the number of floats exchanged.
+
+    The buffer is laid out from the model's quantizer list, identical on all ranks. An estimator that saw no data on
+    this rank (fewer batches than ranks, or a quantizer no batch reached) contributes the neutral elements +inf / -inf;
+    a quantizer that NO rank reached keeps its uninitialised range."""
+    pairs = _activation_estimators(model)
     if not pairs:
         return 0
-    device = pairs[0][1].min.device
-    mins = [e.min.detach().reshape(-1).to(torch.float32) for _, e in pairs]
-    maxs = [e.max.detach().reshape(-1).to(torch.float32) for _, e in pairs]
-    statuses = torch.stack([e.status if e.status is not None else torch.zeros(1, dtype=torch.int32, device=device) for _, e in pairs])
+    device = next((e.min.device for _, e in pairs if e.min is not None), None)
+    if device is None:
+        device = next((p.device for p in model.parameters()), torch.device("cpu"))
+    counts = [_range_entries(q, e) for q, e in pairs]
+    inf = float("inf")
+    mins = [e.min.detach().reshape(-1).to(torch.float32) if e.min is not None else torch.full((k,), inf, device=device) for (_, e), k in zip(pairs, counts)]
+    maxs = [e.max.detach().reshape(-1).to(torch.float32) if e.max is not None else torch.full((k,), -inf, device=device) for (_, e), k in zip(pairs, counts)]
+    statuses = torch.stack([e.status.to(device) if e.status is not None else torch.zeros(1, dtype=torch.int32, device=device) for _, e in pairs])
     any_inf = (statuses & ops.FLAG_INF).max().to(torch.float32).reshape(1)  # 1.0 if any quantizer saw +-Inf
     packed = torch.cat(mins + [-m for m in maxs] + [-any_inf])
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=group)  # THE collective of this path
-    n = sum(m.numel() for m in mins)
+    n = sum(counts)
     lo_all, hi_all, any_inf_anywhere = packed[:n], -packed[n : 2 * n], bool(-packed[-1].item() > 0)
     if any_inf_anywhere:
         raise NotImplementedError("Infinite")  # reference range_setting/minmax.py:233-234, any rank
+    unseen = (lo_all == inf) & (hi_all == -inf)  # the neutral elements survived: no rank saw data for that entry
+    any_unseen = bool(unseen.any()) if any(e.min is None for _, e in pairs) else False
     at = 0
-    for quantizer, estimator in pairs:
-        k = estimator.min.numel()
-        estimator.min = lo_all[at : at + k].to(estimator.min.dtype).contiguous()
-        estimator.max = hi_all[at : at + k].to(estimator.max.dtype).contiguous()
-        quantizer.quantization_range = (estimator.min, estimator.max)  # A5 on the global range
+    for (quantizer, estimator), k in zip(pairs, counts):
+        lo, hi = lo_all[at : at + k], hi_all[at : at + k]
         at += k
+        if estimator.min is None and any_unseen and bool(unseen[at - k : at].all()):
+            continue
+        dtype = estimator.min.dtype if estimator.min is not None else torch.float32
+        estimator.min = lo.to(dtype).contiguous()
+        estimator.max = hi.to(dtype).contiguous()
+        quantizer.quantization_range = (estimator.min, estimator.max)  # A5 on the global range
     return packed.numel()
 
 
@@ -130,7 +160,20 @@ def calibrate_sharded(
                     forward(batch)
                 else:
                     model(batch, logits=False) if _accepts_logits(model) else model(batch)
+            _estimate_unseen_weight_ranges(model)
             return all_reduce_ranges(model, group)
+
+
+def _estimate_unseen_weight_ranges(model: torch.nn.Module) -> None:
+    """A rank whose share held no batch never ran its weight quantizers. Their ranges depend on the replicated weights
+    only, so run each one once on its own weight (one estimator step of the same data every other rank saw: the same
+    running min / max) — the rank then holds the parameters everyone else holds without any exchange."""
+    for module in model.modules():
+        quantizer, weight = getattr(module, "weight_quantizer", None), getattr(module, "weight", None)
+        if not isinstance(quantizer, Quantizer) or not isinstance(weight, torch.Tensor):
+            continue
+        if any(isinstance(fn, RunningMinMaxEstimator) and fn.min is None for fn in quantizer.overrides):
+            quantizer(weight)
 
 
 def _accepts_logits(model: torch.nn.Module) -> bool:

@@ -41,12 +41,7 @@ def _row_mode(tensor: QuantizedTensor) -> str | None:
 def _supported(input: Any, weight: Any, bias: Any = None, **_: Any) -> bool:
     if not (_static_affine(input) and _static_affine(weight)):
         return False
-    try:
-        lib = _native.library()
-    except Exception:
-        return False
-    on_backend = (input.is_cuda and weight.is_cuda) if lib.is_device else (input.device.type == "cpu" and weight.device.type == "cpu")
-    if not on_backend or weight.dim() != 2 or input.dim() < 1:
+    if not _on_backend(input, weight) or weight.dim() != 2 or input.dim() < 1:
         return False
     if input.shape[-1] != weight.shape[1] or weight.shape[1] % 16 != 0 or input.numel() == 0:
         return False
@@ -114,11 +109,8 @@ def _col_mode(tensor: QuantizedTensor) -> str | None:
 
 
 def _on_backend(*tensors: Any) -> bool:
-    try:
-        lib = _native.library()
-    except Exception:
-        return False
-    return all(t.is_cuda for t in tensors) if lib.is_device else all(t.device.type == "cpu" for t in tensors)
+    """All operands on a HIP device and the backend library loadable — anything else takes the float fallback."""
+    return all(t.is_cuda for t in tensors) and _native.is_available()
 
 
 def _bits_and_dtypes_ok(a: QuantizedTensor, b: QuantizedTensor) -> bool:

@@ -363,8 +363,26 @@ class FusedForward:
         # when set to a list, every int8 GEMM launch appends (output rows of weight processed, K, start event, end event)
         # — the fused gate/up launch counts both matrices: bench.py times the GEMM launches of a real forward with it
         self.linear_events: list[tuple[int, int, torch.cuda.Event, torch.cuda.Event]] | None = None
-        # One host comparison per layer, once: consumers of the same tensor usually hold the same range.
+        # One host comparison per layer: consumers of the same tensor usually hold the same range. The table is keyed on the
+        # version counters of the input quantizers' parameters and rebuilt when a range is set again after construction
+        # (the range setter bumps them, nn/linear_quantizer.py::_write_parameters_for_range).
         self._fan: list[dict[str, tuple[list[tuple[torch.Tensor, torch.Tensor | None]], list[int]]]] = []
+        self._fan_signature: tuple[int, ...] = ()
+        self.refresh()
+
+    def _input_signature(self) -> tuple[int, ...]:
+        sig: list[int] = []
+        for _, linear in decoder_linears(self.model):
+            q = linear.input_quantizer
+            sig += [id(q.scale), q.scale._version, -1 if q.offset is None else q.offset._version]
+        return tuple(sig)
+
+    def refresh(self) -> None:
+        """Re-read everything this object derived from quantizer parameters on the host: which of q/k/v and gate/up share
+        an input range, and which weight offsets are all zero. Called at construction and, automatically, by the next
+        forward after any input-quantizer parameter changed (never inside a hipGraph capture: the reads synchronise)."""
+        model = self.model
+        self._fan = []
         for layer in model.layers:
             attn, mlp = layer.self_attn, layer.mlp
             self._fan.append({
@@ -373,6 +391,7 @@ class FusedForward:
             })
         for _, linear in decoder_linears(model):  # host reads happen here, never inside a (possibly graph-captured) forward
             self._symmetric_weights(linear)
+        self._fan_signature = self._input_signature()
 
     @staticmethod
     def _params(linear: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor | None]:
@@ -496,6 +515,10 @@ class FusedForward:
         model, cfg = self.model, self.model.config
         b, s = input_ids.shape
         d = cfg.head_dim
+        if self._input_signature() != self._fan_signature:  # a range was set again since the tables were built
+            if input_ids.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise ff.exceptions.QuantizationError("quantizer ranges changed after FusedForward was built: call refresh() before capturing a graph")
+            self.refresh()
         hidden = model.embed_tokens(input_ids)
         cos, sin = rotary_tables(s, d, cfg.rope_theta, hidden.device, hidden.dtype)
         pending: torch.Tensor | None = None

@@ -223,6 +223,11 @@ class LinearQuantizer(AbstractAffineQuantizer):
                     offset_out=None if self.offset is None else self.offset.data,
                     want_offset=False,
                 )
+                # the kernel wrote through raw pointers: tell autograd's version counters, which every cache keyed on
+                # `_version` (llama.FusedForward's weight codes, zero-offset and shared-range tables) relies on
+                torch.autograd.graph.increment_version(self.scale)
+                if self.offset is not None:
+                    torch.autograd.graph.increment_version(self.offset)
                 return
             scale, offset = ops.parameters_for_range(
                 lo, hi, self.num_bits, self.symmetric, self.allow_one_sided, want_offset=self.offset is not None

@@ -68,8 +68,29 @@ def _tag(dtype: torch.dtype) -> int:
         raise NotImplementedError(f"fastforward_amd: dtype {dtype} is not supported by the HIP backend") from None
 
 
+class _OnDevice:
+    """The backend library bound to a HIP device that is not the thread's current one: every C-ABI call runs under
+    ``torch.cuda.device(index)`` (kernels launch on the device of the stream they are given; ``hipFuncSetAttribute`` and
+    the launch itself act on the CURRENT device)."""
+
+    def __init__(self, lib, index: int) -> None:
+        self._lib, self._index = lib, index
+
+    def __getattr__(self, name: str):
+        attr = getattr(self._lib, name)
+        if not name.startswith("ffq_"):
+            return attr
+
+        def call(*args):
+            with torch.cuda.device(self._index):
+                return attr(*args)
+
+        return call
+
+
 def _prepare(*tensors: torch.Tensor | None):
-    """Check that all tensors live where the loaded backend computes; return (lib, stream)."""
+    """Check that all tensors live on one HIP device; return (library, stream handle of torch's current stream there).
+    There is no CPU implementation: host tensors raise BackendError."""
     lib = _native.library()
     device = None
     for t in tensors:
@@ -82,17 +103,14 @@ def _prepare(*tensors: torch.Tensor | None):
                 f"Expected all tensors to be on the same device, but found at least two devices, {device} and {t.device}!"
             )
     assert device is not None
-    if lib.is_device:
-        if device.type != "cuda":
-            raise BackendError(
-                f"fastforward_amd runs on the HIP device only (tensor on '{device}'); there is no CPU "
-                "implementation. Move the tensors to 'cuda'."
-            )
-        stream = torch.cuda.current_stream(device).cuda_stream
-    else:  # the CPU oracle, injected by the test-suite only
-        if device.type != "cpu":
-            raise BackendError("the injected oracle backend computes on host memory only")
-        stream = None
+    if device.type != "cuda":
+        raise BackendError(
+            f"fastforward_amd runs on the HIP device only (tensor on '{device}'); there is no CPU "
+            "implementation. Move the tensors to 'cuda'."
+        )
+    stream = torch.cuda.current_stream(device).cuda_stream
+    if device.index is not None and device.index != torch.cuda.current_device():
+        lib = _OnDevice(lib, device.index)
     return lib, stream
 
 

@@ -38,17 +38,12 @@ def load_oracle():
     return FFQLibrary(ORACLE_SO)
 
 
-@contextlib.contextmanager
 def use_backend(lib):
-    """Temporarily make `lib` the library fastforward_amd.ops calls into (test-only)."""
-    from fastforward_amd import _native
+    """Temporarily make `lib` the library fastforward_amd.ops calls into (test-only; oracle/inject.py)."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import inject
 
-    previous = _native._LIB
-    _native._LIB = lib
-    try:
-        yield lib
-    finally:
-        _native._LIB = previous
+    return inject.use_library(lib)
 
 
 @pytest.fixture(scope="session")

@@ -50,7 +50,7 @@ def _worker(rank: int, world: int, port: int, mode: str, out_queue) -> None:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         with use_backend(load_oracle()):
             cfg, model = _build()
-            batches = _batches(cfg)
+            batches = _batches(cfg, n=1 if mode == "starved" else 6)  # starved: rank 1 gets no batch at all
             if mode == "inf" and rank == 1:
                 with torch.no_grad():  # makes the input of down_proj infinite on this rank only
                     model.layers[0].mlp.up_proj.weight[0, 0] = float("inf")
@@ -63,7 +63,7 @@ def _worker(rank: int, world: int, port: int, mode: str, out_queue) -> None:
             gathered = [torch.zeros_like(fp) for _ in range(world)]
             dist.all_gather(gathered, fp)
             result = {"rank": rank, "payload": payload, "error": error, "same_on_all_ranks": all(torch.equal(g, gathered[0]) for g in gathered)}
-            if rank == 0 and mode == "exact":
+            if rank == 0 and mode in ("exact", "starved"):
                 _, sequential = _build()
                 from fastforward_amd import llama
 
@@ -113,3 +113,14 @@ def test_sharded_calibration_with_quantized_forward_agrees_across_ranks():
 def test_infinite_activation_on_one_rank_raises_on_every_rank():
     r0, r1 = _run("inf")
     assert r0["error"] == "Infinite" and r1["error"] == "Infinite"
+
+
+@pytest.mark.timeout(300)
+def test_rank_without_any_batch_still_takes_part_in_the_exchange():
+    """Fewer batches than ranks: the starved rank contributes the neutral elements (+inf, -inf) in a buffer of the same
+    length, receives the global ranges and ends with the same parameters as a sequential run (distributed.py:84)."""
+    r0, r1 = _run("starved")
+    assert r0["error"] is None and r1["error"] is None
+    assert r0["payload"] == r1["payload"] == 29
+    assert r0["same_on_all_ranks"] and r1["same_on_all_ranks"]
+    assert r0["equals_sequential"] and r0["forward_equal"]

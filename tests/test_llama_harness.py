@@ -133,6 +133,19 @@ def check_fused_against_module_graph(fixture, device):
     assert not torch.equal(fused(ids).float().cpu(), got)
     # hidden states of the final norm instead of logits
     assert fused(ids, logits=False).shape == (*ids.shape, model.config.hidden_size)
+    # a range that is set again AFTER construction: the raw-pointer parameter write bumps the version counters, so the
+    # cached weight codes, the zero-offset table and the shared-range table are rebuilt (llama.py:439 / :368)
+    down = model.layers[0].mlp.down_proj
+    lo, hi = down.weight.float().amin(1), down.weight.float().amax(1)
+    down.weight_quantizer.quantization_range = (torch.zeros_like(lo), hi * 0.5)  # one-sided: offset 0 -> 128, scale changes
+    k_in = model.layers[1].self_attn.k_proj.input_quantizer
+    k_lo, k_hi = k_in.quantization_range
+    k_in.quantization_range = (k_lo * 0.5, k_hi * 0.5)  # k_proj's input range now differs from q_proj's
+    fresh = llama.FusedForward(model)(ids).float().cpu()
+    assert torch.equal(fused(ids).float().cpu(), fresh) and torch.equal(cached(ids).float().cpu(), fresh)
+    with torch.no_grad(), ff.strict_quantization(False):
+        want2 = model(ids).float().cpu()
+    assert float((fresh - want2).pow(2).mean().sqrt()) < 0.01 * float(want2.std())
     # refusals: range estimation running, float containers for the weight codes
     with ff.estimate_ranges(model, ff.range_setting.running_minmax):
         with pytest.raises(ff.exceptions.QuantizationError, match="override"):
