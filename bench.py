@@ -1,6 +1,7 @@
 """bench.py — Llama-3-8B W8A8 quantized forward on N MI355X GPUs (one process per GPU).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N ...          # no launcher: starts N rank processes itself (torch.distributed.run children)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -82,23 +83,48 @@ def event_time_ms(fn, iters: int, reps: int = 8) -> float:
     return statistics.median(samples)
 
 
+def _pmc_tables(stem: str):
+    import glob
+
+    reads = sorted(glob.glob(str(ROOT / "profiles" / f"*{stem}FETCH_SIZE.json")))
+    writes = sorted(glob.glob(str(ROOT / "profiles" / f"*{stem}WRITE_SIZE.json")))
+    if not reads or not writes:
+        return None
+    return json.load(open(reads[-1])), json.load(open(writes[-1])), pathlib.Path(reads[-1]).name.split("_pmc_")[0]
+
+
 def pmc_traffic(*needles: str, stems: tuple[str, ...] = ("_pmc_", "_pmc_hbm_")) -> tuple[float | None, str | None]:
     """HBM bytes per launch (read + write) of the kernel whose name contains all `needles`, from the
     committed PMC passes (profiles/*_pmc_FETCH_SIZE.json / *_pmc_WRITE_SIZE.json, produced by
     tools/collect_profiles.sh: separate --pmc runs, FETCH_SIZE x2 on gfx950 as the microarch guide
     prescribes). bench.py cannot run rocprofv3 on itself, so this is a lookup, labelled with its source."""
-    import glob
-
     for stem in stems:
-        reads = sorted(glob.glob(str(ROOT / "profiles" / f"*{stem}FETCH_SIZE.json")))
-        writes = sorted(glob.glob(str(ROOT / "profiles" / f"*{stem}WRITE_SIZE.json")))
-        if not reads or not writes:
+        tables = _pmc_tables(stem)
+        if tables is None:
             continue
-        r, w = json.load(open(reads[-1])), json.load(open(writes[-1]))
+        r, w, prof = tables
         for name, row in r.items():
             if all(n in name for n in needles) and name in w:
-                return float(row["hbm_read_bytes"] + w[name]["hbm_write_bytes"]), pathlib.Path(reads[-1]).name.split("_pmc_")[0]
+                return float(row["hbm_read_bytes"] + w[name]["hbm_write_bytes"]), prof
     return None, None
+
+
+def pmc_traffic_mix(needle: str) -> tuple[float | None, dict, str | None]:
+    """Launch-count-weighted mean of the fabric bytes per launch over EVERY kernel variant whose name contains `needle`
+    (the PMC pass profiles the same forward, so its launch counts are the forward's launch mix), the per-variant
+    figures, and the profile the numbers come from."""
+    tables = _pmc_tables("_pmc_")
+    if tables is None:
+        return None, {}, None
+    r, w, prof = tables
+    total, launches, variants = 0.0, 0, {}
+    for name, row in r.items():
+        if needle in name and name in w:
+            b = float(row["hbm_read_bytes"] + w[name]["hbm_write_bytes"])
+            variants[name] = {"launches": row["launches"], "bytes_per_launch": b}
+            total += b * row["launches"]
+            launches += row["launches"]
+    return (total / launches if launches else None), variants, prof
 
 
 def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, fused: "llama.FusedForward | None", batch: torch.Tensor) -> dict:
@@ -150,7 +176,11 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
             launches += count
         per_shape = per_shape_random
     achieved = total_ops / total_ms / 1e9
-    traffic, prof = pmc_traffic("w8a8_gemm256fp_kernel", "bf16_t")
+    traffic, traffic_variants, prof = pmc_traffic_mix("w8a8_gemm256fp_kernel")
+    # algorithmic bytes of the same launch mix: int8 activation codes + int8 weight codes read once, output written once
+    # (bf16 for the plain launches; int8 codes for the gate+up launch, which reads two weight matrices)
+    alg_bytes = sum(c * (tokens * k + n * k + tokens * n * 2) for (n, k), c in {(h, h): 2, (kv, h): 2, (h, i): 1}.items()) + (tokens * h + 2 * i * h + tokens * i)
+    alg_launches = 6
     # what back-to-back MFMAs alone sustain on toggling operands (no memory traffic): tools/probes/mfma_power.hip, committed run
     ceiling = None
     probe = ROOT / "profiles" / "r01_mfma_power_probe.txt"
@@ -169,7 +199,11 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
         "mfma_only_ceiling_note": None if ceiling is None else "TOP/s of v_mfma_i32_32x32x32_i8 issued back to back on random operands, no LDS / global traffic "
                                   "(profiles/r01_mfma_power_probe.txt): the chip is power-limited on real data; frac stays against the nominal peak",
         "traffic": traffic,
-        "traffic_note": None if traffic is None else f"HBM read+write bytes per launch, mean over the forward's launch mix; PMC passes of profiles/{prof}_pmc_*.json",
+        "traffic_note": None if traffic is None else f"fabric (L2-miss) read+write bytes per launch from FETCH_SIZE x2 + WRITE_SIZE, launch-count-weighted mean over BOTH kernel variants of the forward "
+                        f"(plain bf16-out and the gate+up / SiLU / quantize launch); separate --pmc passes of profiles/{prof}_pmc_*.json. Infinity-Cache hits are counted, so this is L2->fabric traffic, an upper bound of HBM bytes",
+        "traffic_per_variant": traffic_variants,
+        "algorithmic_bytes_per_launch": alg_bytes / alg_launches,
+        "algorithmic_bytes_note": "codes of x and W read once + output written once, mean over the same launch mix (5 plain launches + 1 gate+up launch per layer)",
         "avg_launch_ms": round(total_ms / launches, 4),
         "algorithmic_ops_per_launch": total_ops / launches,
         "measured_on": source,
@@ -290,6 +324,27 @@ def cpu_baseline(config: llama.LlamaConfig, budget_s: float = 20.0) -> dict:
     }
 
 
+def relaunch_under_torchrun(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) as CHILDREN through
+    torch.distributed.run and hand back their exit code. Nothing in this process has touched a GPU yet (torch.cuda.device_count
+    does not initialise one), and the ranks are new processes, not an exec of this one."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("FFQ_DIST_BACKEND") != "gloo":  # gloo: the documented several-ranks-on-one-GPU dry run of the control flow
+        print(f"bench.py: --gpus {n} but this machine exposes {have} GPU(s); refusing to report a {n}-GPU number from fewer devices", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(pathlib.Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,7 +352,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="sequences per GPU per step")
     ap.add_argument("--seq-len", type=int, default=2048)
-    ap.add_argument("--calib-seqs", type=int, default=64, help="calibration sequences per GPU (BASELINE config: 512 in total = 64 per GPU on 8 GPUs)")
+    ap.add_argument("--calib-seqs", type=int, default=None, help="calibration sequences per GPU; default: BASELINE's 512 in total, i.e. 512 / N per GPU (512 on one GPU, 64 each on 8)")
     ap.add_argument("--model", choices=["llama3-8b", "llama3-70b", "tiny"], default="llama3-8b")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--module-graph", action="store_true", help="run the reference-shaped module graph (one quantizer call per linear input, "
@@ -305,10 +360,16 @@ def main() -> None:
     ap.add_argument("--cache-weight-codes", action="store_true", help="keep int8 weight codes across steps (NOT the headline: the reference re-quantizes)")
     ap.add_argument("--no-side-measurements", action="store_true", help="skip roofline / cpu_baseline legs")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
+        raise SystemExit(relaunch_under_torchrun(args.gpus))  # N fresh ranks; never a silent 1-GPU run
+    if args.calib_seqs is None:
+        args.calib_seqs = max(args.batch, 512 // args.gpus)
 
     rank, local_rank, world = ffd.init_process_group_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)")
     assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
     local_rank %= torch.cuda.device_count()  # identity with one GPU per rank; lets several ranks share a GPU in a gloo dry run
     torch.cuda.set_device(local_rank)
@@ -324,9 +385,13 @@ def main() -> None:
     # calibration: RunningMinMax on this rank's share, then ONE all-reduce of the activation ranges
     calib_steps = max(1, args.calib_seqs // args.batch)
     calib = [torch.randint(0, config.vocab_size, (args.batch, args.seq_len), device=device, generator=gen) for _ in range(calib_steps)]
-    # untimed pass over the first batch: code objects load, lazily shaped quantizer parameters materialise, the allocator
-    # grows (0.3-0.4 s, once per process). The timed calibration below starts from fresh estimators and overwrites every range.
+    # untimed pass over the first batch: code objects load, the allocator grows (0.3-0.4 s, once per process). Then every
+    # quantizer is reset, so the timed calibration starts from uninitialised ranges exactly like a first calibration:
+    # the estimators begin at (+inf, -inf) in the DATA dtype and every step takes the in-place A4 kernel (an estimator
+    # seeded from a previous fp32 range would merge through torch.min / torch.max instead; ADVICE r1, bench.py:329).
     ffd.calibrate_sharded(model, calib[:1], disable_quantization=False, fused=not args.module_graph)
+    for _, quantizer in ff.nn.named_quantizers(model):
+        quantizer.reset_parameters()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -379,6 +444,35 @@ def main() -> None:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the drop-in path beside the headline: what ff.quantize_model() + QuantizedLinear.forward give with no harness-level
+    # fusion (one quantizer call per linear input, eager RMSNorm / rotary / SiLU, the dispatcher's int8 linear) — same
+    # arithmetic, same batch, hipGraph-replayed; timed on rank 0 only, after the headline region
+    module_graph = None
+    if fused is not None and rank == 0 and not args.no_side_measurements:
+        def reference_shaped():
+            with torch.no_grad(), ff.strict_quantization(False):
+                return model(batch, logits=True)
+
+        reference_shaped()
+        torch.cuda.synchronize()
+        mg_steps = max(2, min(args.steps, 5))
+        mgraph, mside = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        mside.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(mside), torch.cuda.graph(mgraph, stream=mside):
+            mg_out = reference_shaped()
+        torch.cuda.current_stream().wait_stream(mside)
+        mgraph.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(mg_steps):
+            mgraph.replay()
+        torch.cuda.synchronize()
+        mg_elapsed = time.perf_counter() - t1
+        module_graph = {"value": round(args.batch * args.seq_len * mg_steps / mg_elapsed, 1), "unit": "tokens/s", "n_gpus": 1, "steps": mg_steps,
+                        "ms_per_step": round(mg_elapsed / mg_steps * 1e3, 3),
+                        "what": "the reference-shaped module graph (ff.quantize_model + QuantizedLinear.forward through the dispatcher, eager producers): the drop-in path with no harness-level fusion"}
+        del mgraph, mg_out
+
     tokens_per_step = args.batch * args.seq_len * world
     result = {
         "metric": "tokens/sec Llama-3-8B W8A8 quantized fwd; quant/dequant GB/s vs HBM peak",
@@ -405,7 +499,10 @@ def main() -> None:
             "launch": "hipGraph replay" if graph is not None else "eager",
             "forward": "module graph (reference-shaped)" if fused is None else "llama.FusedForward (A1 fused into RMSNorm / SiLU*up / attention, rotary in place)",
         },
-        "calibration": {"sequences_per_gpu": calib_steps * args.batch, "seconds": round(calib_s, 3),
+        "world_size": torch.distributed.get_world_size() if world > 1 else 1,
+        "collective_backend": (torch.distributed.get_backend() + (" (RCCL over xGMI)" if torch.distributed.get_backend() == "nccl" else "")) if world > 1 else None,
+        "module_graph_drop_in": module_graph,
+        "calibration": {"sequences_per_gpu": calib_steps * args.batch, "sequences_total": calib_steps * args.batch * world, "seconds": round(calib_s, 3),
                         "sequences_per_s_all_gpus": round(calib_steps * args.batch * world / calib_s, 2),
                         "allreduce_floats": payload, "collective": "1 x all_reduce(MIN) over RCCL" if world > 1 else "none (1 GPU)"},
     }

@@ -528,3 +528,58 @@ def test_mse_grid_error_decreases_with_a_finer_grid(oracle_backend, symmetric, n
             quantizer(data)
         errors.append(float(torch.sum((quantizer(data).dequantize() - data) ** 2)))
     assert errors[0] >= errors[1]
+
+
+# ---- GPTQ helpers (reference tests/quantization/test_gptq.py:25-140, assertions re-expressed) -----------------------------
+def _smoothed_4bit(granularity, weights, symmetric=False):
+    quantizer = ff.nn.LinearQuantizer(4, granularity=granularity, symmetric=symmetric)
+    with ff.strict_quantization(False), ff.estimate_ranges(quantizer, ff.range_setting.smoothed_minmax):
+        quantizer(weights)
+    return quantizer
+
+
+@pytest.mark.parametrize("granularity", [
+    ff.PerTensor(), ff.PerChannel(0), ff.PerChannel(1), ff.PerChannel((0, 1)), ff.PerBlock(1, 16, 0), ff.PerBlock((0, 1), (16, 16)), ff.PerTile((16, 16)),
+], ids=["tensor", "rows", "columns", "elements", "row_groups_of_16", "blocks_16x16", "tiles_16x16"])
+def test_gptq_column_operator_equals_the_whole_matrix_quantizer(granularity):
+    """One rule for every granularity (the [rows / tr, columns / tc] parameter grid): quantize-dequantizing column by
+    column gives the matrix the quantizer itself produces."""
+    from fastforward_amd.quantization.gptq import column_quantizer
+
+    torch.manual_seed(3)
+    w = torch.randn(64, 128)
+    quantizer = _smoothed_4bit(granularity, w)
+    with ff.strict_quantization(False):
+        whole = quantizer(w).dequantize()
+    by_column = torch.stack([column_quantizer(quantizer, w.shape, c)(w[:, c]) for c in range(w.shape[1])], dim=1)
+    assert torch.equal(by_column, whole)
+
+
+def test_gptq_partial_range_update_writes_one_group_and_clears_a_stale_offset():
+    from fastforward_amd.quantization.gptq import update_partial_range
+
+    torch.manual_seed(0)
+    gran = ff.PerBlock(1, 8, 0)
+    w = torch.randn(16, 32)
+    quantizer = _smoothed_4bit(gran, w)
+    before = quantizer.scale.detach().clone().view(16, 4)
+    piece = w[:, 16:24]
+    update_partial_range(quantizer, piece.min(-1).values, piece.max(-1).values, param_view_shape=(16, 4), param_view_index=(slice(None), 2))
+    s, o = ff.quantization.affine.parameters_for_range(piece.min(-1).values, piece.max(-1).values, num_bits=4, symmetric=False, allow_one_sided=True)
+    assert torch.equal(quantizer.scale.detach().view(16, 4)[:, 2], s) and torch.equal(quantizer.offset.detach().view(16, 4)[:, 2], o)
+    keep = [0, 1, 3]
+    assert torch.equal(quantizer.scale.detach().view(16, 4)[:, keep], before[:, keep])
+    # symmetric quantizer calibrated on positive weights carries the one-sided offset; a group whose new range spans zero
+    # gets offset 0 (parameters_for_range returns no offset there) and a range that covers the negative side
+    pos = torch.rand(16, 32) + 0.1
+    quantizer = _smoothed_4bit(gran, pos, symmetric=True)
+    assert bool((quantizer.offset != 0).any())
+    others = quantizer.offset.detach().clone().view(16, 4)[:, [0, 2, 3]]
+    piece = pos[:, 8:16].clone()
+    piece[:, 0] = -0.9
+    lo, hi = piece.min(-1).values, piece.max(-1).values
+    update_partial_range(quantizer, lo, hi, param_view_shape=(16, 4), param_view_index=(slice(None), 1))
+    assert not bool(quantizer.offset.detach().view(16, 4)[:, 1].any())
+    rmin, rmax = ff.quantization.affine.quantization_range(quantizer.scale.detach().view(16, 4)[:, 1], quantizer.offset.detach().view(16, 4)[:, 1], 4)
+    assert bool((rmin <= lo).all()) and bool((rmax >= hi - 1e-6).all())
+    assert torch.equal(quantizer.offset.detach().view(16, 4)[:, [0, 2, 3]], others)
