@@ -874,9 +874,44 @@ _LIBRARY.impl("quantize_dynamic_by_tile", quantize_dynamic_by_tile, "CompositeEx
 _LIBRARY.impl("quantize_by_tile_backward", quantize_by_tile_backward, "CompositeExplicitAutograd")
 
 
-def _meta_like(data: torch.Tensor, *_a: object, **_k: object) -> torch.Tensor:
-    return torch.empty_like(data)
+# Fake / Meta implementations of all four ops (reference _quantizer_impl.py:288-339): shapes, dtypes and devices of the
+# real outputs without touching data, so the ops trace under FakeTensor / torch.compile / torch.export.
+def _float_result(*dtypes: torch.dtype) -> torch.dtype:
+    out = dtypes[0]
+    for d in dtypes[1:]:
+        out = torch.promote_types(out, d)
+    return out if out.is_floating_point else torch.float32
 
 
-_LIBRARY.impl("quantize_by_tile", _meta_like, "Meta")
-_LIBRARY.impl("dequantize_by_tile", _meta_like, "Meta")
+def _meta_quantize_by_tile(data, scale, tile_size, num_bits, output_dtype, offset=None):  # type: ignore[no-untyped-def]
+    if output_dtype is None:
+        output_dtype = _float_result(data.dtype, scale.dtype, (offset if offset is not None else scale).dtype)
+    return torch.empty(data.shape, dtype=output_dtype, device=data.device)
+
+
+def _meta_dequantize_by_tile(data, scale, tile_size, offset=None, output_dtype=None):  # type: ignore[no-untyped-def]
+    if output_dtype is None:
+        output_dtype = _float_result(data.dtype, scale.dtype, *(() if offset is None else (offset.dtype,)))
+    return torch.empty(data.shape, dtype=output_dtype, device=data.device)
+
+
+def _meta_quantize_dynamic_by_tile(data, tile_size, num_bits, symmetric, allow_one_sided, output_dtype):  # type: ignore[no-untyped-def]
+    tile = 1
+    for extent in tile_size:
+        tile *= extent
+    ntiles = data.numel() // tile if tile else 0
+    if output_dtype is None:
+        output_dtype = data.dtype if data.dtype in (torch.float32, torch.float64) else torch.float32
+    params = lambda: torch.empty(ntiles, dtype=torch.float32, device=data.device)  # noqa: E731
+    return torch.empty(data.shape, dtype=output_dtype, device=data.device), params(), params()
+
+
+def _meta_quantize_by_tile_backward(data, output_grad, scale, tile_size, num_bits, offset=None):  # type: ignore[no-untyped-def]
+    doffset = torch.empty(0) if offset is None else torch.empty_like(scale)
+    return [torch.empty(data.shape, dtype=data.dtype, device=data.device), torch.empty_like(scale), doffset]
+
+
+_LIBRARY.impl("quantize_by_tile", _meta_quantize_by_tile, "Meta")
+_LIBRARY.impl("dequantize_by_tile", _meta_dequantize_by_tile, "Meta")
+_LIBRARY.impl("quantize_dynamic_by_tile", _meta_quantize_dynamic_by_tile, "Meta")
+_LIBRARY.impl("quantize_by_tile_backward", _meta_quantize_by_tile_backward, "Meta")

@@ -2,7 +2,10 @@
 
 Gradient semantics as in the reference (:1-16): all gradient approximation lives in the quantize
 functions; dequantize and dynamic-quantize pass gradients straight through.
-These three Functions are the only callers of the four ops (reference call sites :86,99,121,148).
+These three Functions are the only callers of the four ops (reference call sites :86,99,121,148), and they call
+them where the reference does: through the torch operator registry (``torch.ops.fastforward_amd.*``, registered in
+fastforward_amd/ops.py with the reference's schemas), so a kernel registered for another dispatch key, a FakeTensor
+trace or ``torch.library.opcheck`` sees exactly the calls the product makes.
 """
 
 from __future__ import annotations
@@ -11,8 +14,10 @@ from typing import Any, Literal
 
 import torch
 
-from fastforward_amd import ops
+from fastforward_amd import ops  # noqa: F401  (defines torch.ops.fastforward_amd.*)
 from fastforward_amd.common import tensor_or_none
+
+_OPS = torch.ops.fastforward_amd
 
 
 def _float_dtype_of(data: torch.Tensor) -> torch.dtype:
@@ -68,14 +73,14 @@ class QuantizeStaticAffine(torch.autograd.Function):
         tile_size = _resolve(data, tile_size)
         ctx.save_for_backward(data, scale, offset)
         ctx.tile_size, ctx.num_bits = tile_size, num_bits
-        return ops.quantize_by_tile(data, scale, tile_size, num_bits, quantized_dtype or data.dtype, offset)
+        return _OPS.quantize_by_tile(data, scale, list(tile_size), float(num_bits), quantized_dtype or data.dtype, offset)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx: Any, output_grad):  # type: ignore[no-untyped-def]
         data, scale, offset = ctx.saved_tensors
-        dinput, dscale, doffset = ops.quantize_by_tile_backward(
-            data, output_grad, scale, ctx.tile_size, ctx.num_bits, offset
+        dinput, dscale, doffset = _OPS.quantize_by_tile_backward(
+            data, output_grad, scale, list(ctx.tile_size), float(ctx.num_bits), offset
         )
         return dinput, dscale, (doffset if offset is not None else None), None, None, None
 
@@ -83,8 +88,8 @@ class QuantizeStaticAffine(torch.autograd.Function):
 class QuantizeDynamicAffine(torch.autograd.Function):
     @staticmethod
     def forward(ctx: Any, data, tile_size, num_bits, symmetric, allow_one_sided, quantized_dtype):  # type: ignore[no-untyped-def]
-        return ops.quantize_dynamic_by_tile(
-            data, _resolve(data, tile_size), num_bits, symmetric, allow_one_sided, quantized_dtype or data.dtype
+        return _OPS.quantize_dynamic_by_tile(
+            data, list(_resolve(data, tile_size)), float(num_bits), symmetric, allow_one_sided, quantized_dtype or data.dtype
         )
 
     @staticmethod
@@ -96,7 +101,7 @@ class QuantizeDynamicAffine(torch.autograd.Function):
 class DequantizeAffine(torch.autograd.Function):
     @staticmethod
     def forward(ctx: Any, data, scale, offset, tile_size, dtype):  # type: ignore[no-untyped-def]
-        return ops.dequantize_by_tile(data, scale, _resolve(data, tile_size), offset, dtype)
+        return _OPS.dequantize_by_tile(data, scale, list(_resolve(data, tile_size)), offset, dtype)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
