@@ -27,6 +27,10 @@
 
 #include <type_traits>
 
+#ifndef FFQ_X
+#define FFQ_X 0  // experiment selector of the persistent kernel (tools/gemm_variants.sh): 0 = the shipped schedule
+#endif
+
 namespace ffq {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -1187,6 +1191,9 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
     tn0 = (int)(in_group / group_rows) * BN_OUT;
   };
   auto set_sources = [&](int tm0, int tn0) {
+#if FFQ_X == 1  // every tile streams the operands of tile (0, 0): all L2 hits (wrong results: cost of the misses)
+    tm0 = 0; tn0 = 0;
+#endif
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int row = (wave * 4 + c) * 8 + d_row;
@@ -1216,6 +1223,13 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
 #pragma unroll
     for (int c = c0; c < c0 + 2; ++c)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_src[c] + ks * 128), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+  };
+
+  // piece p of a super-step: p < 4 the A chunk p, else the B chunk p - 4 (experiment schedules issue them one by one)
+  auto issue_piece = [&](int ks, int slot, int p) {
+    uint8_t* base = lds2 + slot * SLOT_BYTES + (p < 4 ? 0 : B_IMAGE);
+    const int c = p & 3;
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)((p < 4 ? a_src[c] : b_src[c]) + ks * 128), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
   };
 
   const uint32_t frag_row = lane & 31, frag_g = lane >> 5;
@@ -1249,12 +1263,37 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[j], fa[i], acc[i][j], 0, 0, 0);
+#if FFQ_X == 3  // every SIMD's computing wave issues its pieces at a different point of the cluster: no TA burst
+      if (i == wn) { __builtin_amdgcn_sched_barrier(0); dma(); dma2(); __builtin_amdgcn_sched_barrier(0); }
+#elif FFQ_X == 4  // no LDS-DMA inside the loop at all (wrong results: cost of the stream)
+      (void)dma; (void)dma2;
+#else
       if (i == 0) { __builtin_amdgcn_sched_barrier(0); dma(); __builtin_amdgcn_sched_barrier(0); }
       if (i == 2) { __builtin_amdgcn_sched_barrier(0); dma2(); __builtin_amdgcn_sched_barrier(0); }
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
   };
+  // experiment form: a hook after EVERY pair of MFMAs
+  auto cluster4 = [&](auto h0, auto h1, auto h2, auto h3) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i == 0) h0();
+      if (i == 1) h1();
+      if (i == 2) h2();
+      if (i == 3) h3();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  (void)cluster4; (void)issue_piece;
 
   const int ksuper = a.K / 128;
   int slot = 0;  // slot of the super-step about to be computed
@@ -1284,15 +1323,74 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
         fetch = has_next ? 0 : ks;
         if (has_next) set_sources(nm0, nn0);
       }
+#if FFQ_X >= 5 && FFQ_X <= 7
+      const int os = slot ^ 1;
+      auto none = [] {};
       read_frags(st, 0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
+#if FFQ_X == 5    // one piece behind every MFMA pair of the first two clusters
+      cluster4([&] { issue_piece(fetch, os, 0); }, [&] { issue_piece(fetch, os, 1); }, [&] { issue_piece(fetch, os, 4); }, [&] { issue_piece(fetch, os, 5); });
+#elif FFQ_X == 6  // half of the pieces in the clusters (one per other gap), half in the load segments
+      cluster4(none, [&] { issue_piece(fetch, os, 0); }, none, [&] { issue_piece(fetch, os, 4); });
+#else
+      cluster4(none, none, none, none);
+#endif
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 1);
+      __builtin_amdgcn_sched_barrier(0);
+#if FFQ_X == 6
+      issue_piece(fetch, os, 1); issue_piece(fetch, os, 5);
+      __builtin_amdgcn_sched_barrier(0);
+#elif FFQ_X == 7  // every piece in a load segment
+      issue_piece(fetch, os, 0); issue_piece(fetch, os, 1); issue_piece(fetch, os, 4); issue_piece(fetch, os, 5);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      __builtin_amdgcn_s_barrier();
+#if FFQ_X == 5
+      cluster4([&] { issue_piece(fetch, os, 2); }, [&] { issue_piece(fetch, os, 3); }, [&] { issue_piece(fetch, os, 6); }, [&] { issue_piece(fetch, os, 7); });
+#elif FFQ_X == 6
+      cluster4(none, [&] { issue_piece(fetch, os, 2); }, none, [&] { issue_piece(fetch, os, 6); });
+#else
+      cluster4(none, none, none, none);
+#endif
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 2);
+      __builtin_amdgcn_sched_barrier(0);
+#if FFQ_X == 6
+      issue_piece(fetch, os, 3); issue_piece(fetch, os, 7);
+      __builtin_amdgcn_sched_barrier(0);
+#elif FFQ_X == 7
+      issue_piece(fetch, os, 2); issue_piece(fetch, os, 3); issue_piece(fetch, os, 6); issue_piece(fetch, os, 7);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      __builtin_amdgcn_s_barrier();
+      cluster4(none, none, none, none);
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster4(none, none, none, none);
+      __builtin_amdgcn_s_barrier();
+#else
+      read_frags(st, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+#if FFQ_X == 2  // all eight pieces in the first cluster (one interval more for the second half to land)
+      cluster([&] { issue_a(fetch, slot ^ 1, 0); issue_a(fetch, slot ^ 1, 2); }, [&] { issue_b(fetch, slot ^ 1, 0); issue_b(fetch, slot ^ 1, 2); });
+#else
       cluster([&] { issue_a(fetch, slot ^ 1, 0); }, [&] { issue_b(fetch, slot ^ 1, 0); });
+#endif
       __builtin_amdgcn_s_barrier();
       read_frags(st, 1);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
+#if FFQ_X == 2
+      cluster([] {}, [] {});
+#else
       cluster([&] { issue_a(fetch, slot ^ 1, 2); }, [&] { issue_b(fetch, slot ^ 1, 2); });
+#endif
       __builtin_amdgcn_s_barrier();
       read_frags(st, 2);
       __builtin_amdgcn_sched_barrier(0);
@@ -1305,6 +1403,7 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
       __builtin_amdgcn_s_barrier();
       cluster([] {}, [] {});
       __builtin_amdgcn_s_barrier();
+#endif
       slot ^= 1;
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();  // same number of barriers for both groups

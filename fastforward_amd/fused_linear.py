@@ -91,6 +91,64 @@ _registration = register("linear", fused_linear_predicate, fused_linear)
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# Weight-only: a static-affine QuantizedTensor weight and a PLAIN bf16 input (BASELINE configs 2 and 4; reference
+# fallback.py:86-112 with strict quantization off: weight.dequantize() + F.linear). The kernel dequantizes the codes in
+# the GEMM's operand load (ops.linear_wq); weight granularities: per tensor, per output channel, or groups of G input
+# channels per output channel (PerBlock(block_dims=1, block_sizes=G, per_channel_dims=0), G % 64 == 0).
+# ---------------------------------------------------------------------------------------------------------------
+def _weight_group(weight: QuantizedTensor) -> int | None:
+    """Input channels sharing one parameter pair within a row ([N, K / group] parameters), or None if not covered."""
+    tile = weight.quantization_context.quantization_params.granularity.tile_size(weight.shape)
+    n, k = weight.shape
+    if isinstance(tile, str) or tuple(tile) == (n, k):
+        return k  # per tensor: one pair
+    if tile[0] == 1 and k % tile[1] == 0:
+        return int(tile[1])  # (1, K): per output channel; (1, G): groups along the input channels
+    return None
+
+
+def _supported_weight_only(input: Any, weight: Any, bias: Any = None, **_: Any) -> bool:
+    if isinstance(input, QuantizedTensor) or not isinstance(input, torch.Tensor) or not _static_affine(weight):
+        return False
+    if not _on_backend(input, weight) or weight.dim() != 2 or input.dim() < 1 or input.numel() == 0:
+        return False
+    if input.dtype != torch.bfloat16 or input.shape[-1] != weight.shape[1]:
+        return False
+    wp = weight.quantization_context.quantization_params
+    if wp.num_bits > 8 or wp.num_bits != int(wp.num_bits) or (wp.dequantize_dtype or input.dtype) != input.dtype:
+        return False
+    group = _weight_group(weight)
+    if group is None:
+        return False
+    k = weight.shape[1]
+    if k % 64 or k < 128 or (group != k and group % 64):
+        return False
+    return not (isinstance(bias, QuantizedTensor) and not _static_affine(bias))
+
+
+def fused_linear_weight_only(input: torch.Tensor, weight: QuantizedTensor, bias: Any = None, *, output_quantizer: Any = None, strict_quantization: bool | None = None) -> torch.Tensor:
+    if strict_quantization:  # the reference's messages, fallback.py:83-92
+        if output_quantizer is None:
+            raise QuantizationError("'output_quantizer' must be provided if strict_quantization=True")
+        raise QuantizationError("Expected 'input' to be an instance of 'QuantizedTensor' because strict_quantization=True.")
+    wp = weight.quantization_context.quantization_params
+    if isinstance(bias, QuantizedTensor):
+        bias = bias.dequantize()
+    out = ops.linear_wq(
+        input, _int8_codes(weight), torch.as_tensor(wp.scale, device=weight.device),
+        None if wp.offset is None else torch.as_tensor(wp.offset, device=weight.device),
+        group=_weight_group(weight), bias=bias, out_dtype=input.dtype,
+    )
+    if out is None:  # a shape the kernel does not cover after all: the reference's path
+        out = torch.nn.functional.linear(input, weight.dequantize(), bias)
+    return output_quantizer(out) if output_quantizer is not None else out
+
+
+fused_linear_weight_only_predicate = Predicate(_supported_weight_only)
+_registration_weight_only = register("linear", fused_linear_weight_only_predicate, fused_linear_weight_only)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # mm / matmul / bmm: the same fallback pattern in the reference (src/fastforward/_gen/fallback.py:699-798: dequantize both
 # operands, float matmul, output quantizer), the same int8 contraction here. The right operand arrives as [K, N]; the GEMM
 # contracts K-contiguous rows, so its codes are transposed once (1 B/elem; free when the operand is itself a transposed

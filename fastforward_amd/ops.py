@@ -37,6 +37,7 @@ __all__ = [
     "gptq_block",
     "grid_sqerror_by_tile",
     "linear_w8a8",
+    "linear_wq",
     "mlp_gate_up_w8a8",
     "add_rmsnorm_quantize",
     "silu_mul_quantize",
@@ -618,6 +619,53 @@ def linear_w8a8(
             _ptr(xc), _ptr(wc), _ptr(w_rowsum), _ptr(xs), _ptr(xo), x_per_row, _ptr(ws_), _ptr(wo), w_per_row,
             _ptr(bias_c), _tag(bias_c.dtype) if bias_c is not None else 0, _ptr(out), _tag(out_dtype),
             _ptr(os_), _ptr(oo), float(out_num_bits), M, N, K, _ptr(ws), nbytes, stream,
+        )
+    )
+    return out
+
+
+def linear_wq(
+    x: torch.Tensor,
+    w_codes: torch.Tensor,
+    w_scale: torch.Tensor,
+    w_offset: torch.Tensor | None,
+    group: int | None = None,
+    bias: torch.Tensor | None = None,
+    out_dtype: torch.dtype | None = None,
+) -> torch.Tensor | None:
+    """A6, weight-only — ``F.linear(x, dequantize(w_codes))`` with the dequantization inside the GEMM's operand load
+    (reference _gen/fallback.py:86-112: quantized weight, plain input).
+
+    `x` is [..., K] bf16, `w_codes` [N, K] int8 (codes of any bit-width <= 8), `w_scale` / `w_offset` fp32 with 1 entry
+    (per-tensor), N entries (per output channel) or N * K / group entries ([N, K / group] row-major: groups of `group`
+    input channels, PerBlock(1, group, 0)). The weight the matrix cores see is bit for bit A2's bf16 result.
+    Returns None when the kernel does not cover the problem (dtypes, K % 64, group % 64): the caller dequantizes and runs a
+    float GEMM as the reference does."""
+    if w_codes.dim() != 2:
+        raise RuntimeError("linear_wq expects a [N, K] weight")
+    N, K = w_codes.shape
+    if x.shape[-1] != K:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({x.numel() // max(x.shape[-1], 1)}x{x.shape[-1]} and {N}x{K}^T)")
+    group = K if group is None else int(group)
+    out_dtype = out_dtype or x.dtype
+    if x.dtype not in _TAGS or w_codes.dtype not in _TAGS or out_dtype not in _TAGS:
+        return None
+    M = x.numel() // K if K else 0
+    lib = _native.library()
+    if not lib.ffq_linear_wq_supported(_tag(x.dtype), _tag(w_codes.dtype), _tag(out_dtype), M, N, K, group):
+        return None
+    xc, wc = x.detach().contiguous(), w_codes.detach().contiguous()
+    sc = w_scale.detach().reshape(-1).to(torch.float32).contiguous()
+    of = None if w_offset is None else w_offset.detach().reshape(-1).to(torch.float32).contiguous()
+    if of is not None and of.numel() != sc.numel():
+        raise RuntimeError(f"scale has {sc.numel()} entries, offset {of.numel()}")
+    bias_c = None if bias is None else bias.detach().contiguous()
+    lib, stream = _prepare(xc, wc, sc, of, bias_c)
+    out = torch.empty((*xc.shape[:-1], N), dtype=out_dtype, device=xc.device)
+    lib.check(
+        lib.ffq_linear_wq(
+            _ptr(xc), _tag(xc.dtype), _ptr(wc), _tag(wc.dtype), _ptr(sc), _ptr(of), sc.numel(), group,
+            _ptr(bias_c), _tag(bias_c.dtype) if bias_c is not None else 0, _ptr(out), _tag(out_dtype), M, N, K, stream,
         )
     )
     return out

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define FFQ_MAX_DIMS 8
-#define FFQ_ABI_VERSION 3
+#define FFQ_ABI_VERSION 4
 
 typedef enum ffq_status {
   FFQ_OK = 0,
@@ -181,7 +181,8 @@ int ffq_unpack_int4(const uint8_t* packed, int64_t numel, int64_t block, void* c
  * The contraction runs on int8 MFMA with int32 accumulation; the zero-point terms use row sums.
  * If out_scale != NULL the result is re-quantized (A1, per-tensor) into `out` instead
  * (the `output_quantizer` of fallback.py:110-111), else `out` holds y in out_dt (bf16/f16/f32).
- * Tolerance vs the reference's bf16 eager path is stated in tests/test_linear_gpu.py.
+ * Tolerance vs the reference's bf16 eager path is stated in tests/parity_cases.py::check_linear (G6) and
+ * tests/test_parity_gpu.py::test_w8a8_linear_*; exact-integer checks at full BASELINE sizes: tests/test_fullsize_gpu.py.
  */
 size_t ffq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, const float* x_offset,
@@ -189,6 +190,23 @@ int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, co
                     const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
                     const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * A6 (weight-only) — the branch of `fallback.linear` taken by a quantized WEIGHT and a plain, non-quantized INPUT
+ * (_gen/fallback.py:77-112 with strict_quantization off, :86-100): y = F.linear(x, weight.dequantize(), bias).
+ * `x` is [M, K] bf16, `w_codes` [N, K] integer codes in an int8 container (any num_bits <= 8), `w_scale` / `w_offset`
+ * (nullable) hold `scale_numel` = 1 or N * (K / group) fp32 entries in tiles_to_rows order ([N, K / group] row-major):
+ * group == K is per-tensor / PerChannel(0), group < K is PerBlock(block_dims=1, block_sizes=group, per_channel_dims=0)
+ * (quantization/granularity.py:159-216; BASELINE config 4: group 128). The codes are dequantized in registers with A2's
+ * arithmetic, (float(q) + round_half_even(o)) * s in fp32 rounded once to bf16 — the B operand of the bf16 MFMA is bit
+ * for bit the reference's dequantized weight, accumulation is fp32; only the summation order differs from F.linear.
+ * ffq_linear_wq_supported() == 0 (K % 64 != 0, other dtypes, group % 64 != 0): the caller dequantizes (A2) and runs a
+ * float GEMM, as the reference does.
+ */
+int ffq_linear_wq_supported(int x_dt, int w_dt, int out_dt, int64_t M, int64_t N, int64_t K, int64_t group);
+int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, const float* w_scale, const float* w_offset,
+                  int64_t scale_numel, int64_t group, const void* bias, int bias_dt, void* out, int out_dt, int64_t M,
+                  int64_t N, int64_t K, void* stream);
 
 /*
  * Producer-fused A1 (ABI version 2). In the reference's quantized Llama helpers

@@ -672,6 +672,51 @@ int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, co
   return FFQ_OK;
 }
 
+/*
+ * A6, weight-only: fallback.linear with a quantized weight and a plain input (_gen/fallback.py:86-112, strict
+ * quantization off): weight.dequantize() — A2 into the weight's dequantize dtype, here the activation dtype — then
+ * torch.nn.functional.linear. The contraction is accumulated in double (the exact value of the same operands; a float
+ * GEMM's result depends on its summation order), bias added, rounded once to `out_dt`.
+ */
+int ffq_linear_wq_supported(int x_dt, int w_dt, int out_dt, int64_t M, int64_t N, int64_t K, int64_t group) {
+  (void)M; (void)N;
+  if (!(x_dt == FFQ_BF16 || x_dt == FFQ_F32 || x_dt == FFQ_F16) || w_dt != FFQ_I8 || !dt_is_float(out_dt)) return 0;
+  return group > 0 && K % group == 0;
+}
+
+int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, const float* w_scale, const float* w_offset,
+                  int64_t scale_numel, int64_t group, const void* bias, int bias_dt, void* out, int out_dt, int64_t M,
+                  int64_t N, int64_t K, void* stream) {
+  (void)stream;
+  if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (M == 0 || N == 0) return FFQ_OK;
+  if (!x || !w_codes || !w_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (!ffq_linear_wq_supported(x_dt, w_dt, out_dt, M, N, K, group)) return fail(FFQ_ERR_DTYPE, "weight-only linear: unsupported dtypes / group");
+  int64_t groups = K / group;
+  if (!(scale_numel == 1 || scale_numel == N * groups))
+    return fail(FFQ_ERR_PARAM_NUMEL, "weight-only linear: %lld parameters for %lld x %lld tiles", (long long)scale_numel, (long long)N, (long long)groups);
+  const int8_t* wq = (const int8_t*)w_codes;
+  double* wr = (double*)malloc(sizeof(double) * (size_t)(K > 0 ? K : 1));
+  if (!wr) return fail(FFQ_ERR_ARG, "out of memory");
+  for (int64_t n = 0; n < N; ++n) {
+    for (int64_t k = 0; k < K; ++k) {
+      int64_t t = scale_numel == 1 ? 0 : n * groups + k / group;
+      double o = w_offset ? (double)nearbyintf(w_offset[t]) : 0.0;
+      /* weight.dequantize(): (q + o) * s in fp32, cast to the dequantize dtype                       (A2) */
+      double v = op2(OP_MUL, op2(OP_ADD, (double)wq[n * K + k], o, FFQ_F32), (double)w_scale[t], FFQ_F32);
+      wr[k] = cast_to(v, FFQ_F32, x_dt);
+    }
+    for (int64_t m = 0; m < M; ++m) {
+      double acc = 0.0;
+      for (int64_t k = 0; k < K; ++k) acc += ld(x, x_dt, m * K + k) * wr[k];
+      if (bias) acc += ld(bias, bias_dt, n);
+      st(out, out_dt, m * N + n, round_to(acc, out_dt));
+    }
+  }
+  free(wr);
+  return FFQ_OK;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Producer-fused A1 (ABI version 2): the three elementwise producers of the reference's       */
 /* quantized Llama helpers, docs/examples/doc_helpers/quantized_llama/, each followed by A1.    */

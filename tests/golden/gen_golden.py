@@ -573,6 +573,45 @@ def g14_attention():
     return out
 
 
+def g15_weight_only_linear():
+    """QuantizedLinear with a weight quantizer only and a plain bf16 input: the non-quantized-input branch of the
+    reference's fallback.linear (_gen/fallback.py:86-112, strict quantization off). W8 per output channel (BASELINE
+    config 2), W4 in groups of 128 input channels (config 4: PerBlock(1, 128, 0)), W8 per tensor with an asymmetric
+    (offset-carrying) quantizer, and a biased layer; M and N deliberately not multiples of the kernel's 256-wide tiles."""
+    torch.manual_seed(4321)
+    cases = []
+    specs = [
+        ("w8_per_channel", 8, ("channel", 0), True, False, (2, 100, 512), 320),
+        ("w4_group128", 4, ("block", (1,), (128,), (0,)), True, False, (2, 100, 512), 320),
+        ("w8_per_tensor_asymmetric_bias", 8, ("tensor",), False, True, (3, 37, 256), 200),
+        ("w4_group64_asymmetric", 4, ("block", (1,), (64,), (0,)), False, False, (1, 130, 384), 256),
+    ]
+    for name, bits, spec, symmetric, bias, xshape, out_features in specs:
+        lin = torch.nn.Linear(xshape[-1], out_features, bias=bias).to(torch.bfloat16)
+        with torch.no_grad():
+            lin.weight.mul_(3.0)
+        x = torch.randn(*xshape).to(torch.bfloat16)
+        model = torch.nn.Sequential(lin)
+        ff.quantize_model(model)
+        lin.weight_quantizer = ff.nn.LinearQuantizer(bits, granularity=gran_of(spec), symmetric=symmetric)
+        with ff.strict_quantization(False):
+            with ff.estimate_ranges(model, ff.range_setting.running_minmax):
+                model(x)
+            y = model(x)
+            wq = lin.weight_quantizer(lin.weight)
+        w_hat = wq.dequantize()
+        y64 = torch.nn.functional.linear(x.double(), w_hat.double(), None if lin.bias is None else lin.bias.double())
+        offset = lin.weight_quantizer.offset
+        cases.append({
+            "name": name, "num_bits": bits, "granularity": spec, "symmetric": symmetric,
+            "x": x, "weight": lin.weight.detach().clone(), "bias": None if lin.bias is None else lin.bias.detach().clone(),
+            "w_scale": lin.weight_quantizer.scale.detach().clone(), "w_offset": None if offset is None else offset.detach().clone(),
+            "w_codes": wq.raw_data.to(torch.int8),
+            "y": y.detach().clone(), "y_float64": y64.float(),
+        })
+    return cases
+
+
 def main() -> None:
     torch.set_num_threads(8)
     if len(sys.argv) > 1:  # regenerate only the named fixtures, e.g. `gen_golden.py g10_producers`
@@ -595,6 +634,7 @@ def main() -> None:
     torch.save(g12_mse_grid(), HERE / "g12_mse_grid.pt")
     torch.save(g13_gptq(), HERE / "g13_gptq.pt")
     torch.save(g14_attention(), HERE / "g14_attention.pt")
+    torch.save(g15_weight_only_linear(), HERE / "g15_weight_only_linear.pt")
     for f in sorted(HERE.glob("*.pt")):
         print(f"{f.name}: {f.stat().st_size / 1024:.0f} KiB")
 

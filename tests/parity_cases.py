@@ -170,6 +170,42 @@ def check_linear(device):
         torch.testing.assert_close(y.detach().cpu().float(), c["y_float64"], atol=tol, rtol=tol)
 
 
+def check_weight_only_linear(device):
+    """Fixture G15: the reference's fallback.linear with a quantized weight and a plain bf16 input (strict off).
+
+    Integer side bit-exact (scale, offset, codes). Float side: the kernel multiplies EXACTLY the reference's dequantized
+    bf16 weight (A2 in the operand load) and accumulates in fp32; F.linear's own fp32 summation order is unspecified, so
+    the stated tolerance is one rounding of the output: |y - y64| <= 2^-8 |y64| (half a bf16 ulp) + 1e-4 against the
+    float64 value of the same operands, and one bf16 ulp against the reference's own bf16 output."""
+    from helpers import granularity_of
+
+    for c in golden("g15_weight_only_linear.pt"):
+        lin = torch.nn.Linear(c["weight"].shape[1], c["weight"].shape[0], bias=c["bias"] is not None).to(torch.bfloat16)
+        with torch.no_grad():
+            lin.weight.copy_(c["weight"])
+            if c["bias"] is not None:
+                lin.bias.copy_(c["bias"])
+        model = torch.nn.Sequential(lin).to(device)
+        ff.quantize_model(model)
+        lin.weight_quantizer = ff.nn.LinearQuantizer(c["num_bits"], granularity=granularity_of(c["granularity"]), symmetric=c["symmetric"],
+                                                     quantized_dtype=torch.int8, device=device)
+        x = c["x"].to(device)
+        with torch.no_grad(), ff.strict_quantization(False):
+            with ff.estimate_ranges(model, ff.range_setting.running_minmax):
+                model(x)
+            wq = lin.weight_quantizer(lin.weight)
+            assert ff.dispatcher.dispatch("linear", input=x, weight=wq, bias=lin.bias) is ff.fused_linear.fused_linear_weight_only, c["name"]
+            y = model(x)
+        assert same_with_nan(lin.weight_quantizer.scale.detach().cpu(), c["w_scale"]), c["name"]
+        if c["w_offset"] is not None:
+            assert same_with_nan(lin.weight_quantizer.offset.detach().cpu(), c["w_offset"]), c["name"]
+        assert torch.equal(wq.raw_data.cpu(), c["w_codes"]), c["name"]
+        assert y.dtype == torch.bfloat16 and y.shape == c["y"].shape
+        got = y.detach().cpu().float()
+        torch.testing.assert_close(got, c["y_float64"], rtol=2.0**-8, atol=1e-4, msg=lambda m: f'{c["name"]}: {m}')
+        torch.testing.assert_close(got, c["y"].float(), rtol=2.0**-7, atol=2e-4, msg=lambda m: f'{c["name"]} vs reference output: {m}')
+
+
 def _ulps_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """Distance in bf16 units-in-the-last-place between two bf16 tensors (finite values)."""
     def key(t):

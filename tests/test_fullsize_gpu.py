@@ -182,3 +182,30 @@ def test_70b_activation_properties(hidden):
     deq = q.dequantize()
     for dc, cc in zip(deq.chunk(16), q.raw_data.chunk(16)):
         assert torch.equal(dc, ((cc.float() + off) * quantizer.scale.detach()).to(torch.bfloat16))
+
+
+# ---- weight-only linear at full size: an input family on which EVERY fp32 summation order gives the same sum ---------
+@pytest.mark.parametrize("n,k", LLAMA8B + LLAMA70B, ids=lambda v: str(v))
+@pytest.mark.parametrize("group", [None, 128], ids=["per_channel", "group128"])
+def test_weight_only_linear_is_exact_where_the_sum_is_order_independent(n, k, group):
+    """T = 16384. Activations are small integers (exact in bf16), scales are powers of two, so every product is an integer
+    multiple of 2^-4 and every partial sum stays below 2^24 of those units: fp32 accumulation is exact in ANY order and the
+    bf16 output is the correctly rounded exact value — compared bit for bit with a float64 product of the same operands
+    (rocBLAS dgemm, chunked), for W8 per output channel (BASELINE config 2) and W4 group-128 (config 4)."""
+    g = torch.Generator(device=DEV).manual_seed(n * 3 + k + (group or 0))
+    bits = 8 if group is None else 4
+    amp = 4 if k > 16384 else 8
+    x = torch.randint(-amp, amp + 1, (T, k), device=DEV, generator=g).to(torch.bfloat16)
+    codes = torch.randint(-(2 ** (bits - 1)), 2 ** (bits - 1), (n, k), device=DEV, dtype=torch.int8, generator=g)
+    grp = k if group is None else group
+    exps = torch.randint(3, 5, (n * (k // grp),), device=DEV, generator=g)
+    scale = torch.pow(2.0, -exps.float())
+    y = ops.linear_wq(x, codes, scale, None, group=grp)
+    assert y is not None
+    w64 = (codes.double().view(n, k // grp, grp) * scale.double().view(n, k // grp, 1)).view(n, k)
+    chunk = 2048 if n * k <= 14336 * 4096 else 1024
+    for r0 in range(0, T, chunk):
+        ref = x[r0:r0 + chunk].double() @ w64.t()
+        assert float(ref.abs().max()) * 16 < 2**24
+        assert torch.equal(y[r0:r0 + chunk], ref.to(torch.bfloat16)), f"rows {r0}..: {int((y[r0:r0 + chunk] != ref.to(torch.bfloat16)).sum())} outputs differ"
+        del ref

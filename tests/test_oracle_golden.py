@@ -77,3 +77,7 @@ def test_gguf_block_writers():
 
 def test_gptq_matches_the_reference_bit_for_bit():
     parity_cases.check_gptq("cpu", exact=True)
+
+
+def test_weight_only_linear_matches_the_reference():
+    parity_cases.check_weight_only_linear("cpu")

@@ -614,3 +614,63 @@ def test_fused_gate_up_at_llama_size_and_in_the_forward():
     assert torch.equal(fused, want)
     assert float(want.float().std()) > 1  # not a saturated tensor
     assert ops.mlp_gate_up_w8a8(xq[:, :192], gq[:, :192], uq[:, :192], sx, ox, sg, su, so, oo, 8) is None  # K < 256: not covered
+
+
+# ---- weight-only linear (row *J: quantized weight x plain bf16 input, fallback.py:86-112) ---------------------------
+def test_weight_only_linear_fixture_from_the_reference():
+    parity_cases.check_weight_only_linear(DEV)
+
+
+def _wq_case(n, k, group, bits, offset, seed):
+    g = torch.Generator().manual_seed(seed)
+    lo, hi = -(2 ** (bits - 1)), 2 ** (bits - 1)
+    codes = torch.randint(lo, hi, (n, k), generator=g, dtype=torch.int8)
+    groups = k // group
+    scale = torch.rand(n * groups, generator=g) * 0.02 + 0.002
+    off = torch.round(torch.randn(n * groups, generator=g) * 3) + 0.25 if offset else None  # rounds half-even inside the kernel
+    return codes.to(DEV), scale.to(DEV), None if off is None else off.to(DEV)
+
+
+@pytest.mark.parametrize("k,group,bits,offset", [(512, 512, 8, False), (512, 128, 4, False), (384, 64, 4, True), (1024, 1024, 8, True), (256, 128, 8, True)])
+def test_weight_only_linear_operand_is_exactly_the_dequantized_weight(k, group, bits, offset):
+    """x = identity: every output is ONE product 1.0 * w^, so y[m, n] == dequantize_by_tile(codes)[n, m] bit for bit —
+    the in-register dequantization of the GEMM's operand load is A2 (checked against the A2 kernel itself)."""
+    n = 320
+    codes, scale, off = _wq_case(n, k, group, bits, offset, seed=k + group)
+    x = torch.eye(k, device=DEV, dtype=torch.bfloat16)
+    y = ops.linear_wq(x, codes, scale, off, group=group)
+    assert y is not None and y.dtype == torch.bfloat16
+    want = ops.dequantize_by_tile(codes, scale, (1, group), off, torch.bfloat16)
+    assert torch.equal(y, want.t()), mismatch_report(y.cpu(), want.t().cpu())
+
+
+@pytest.mark.parametrize("m,n,k,group", [(1, 256, 128, 128), (300, 130, 512, 512), (257, 515, 1024, 128), (2050, 2300, 192, 64), (4100, 1030, 1024, 1024), (77, 64, 4096, 128)])
+@pytest.mark.parametrize("offset,bias,out_dtype", [(False, False, torch.bfloat16), (True, True, torch.bfloat16), (False, True, torch.float32)])
+def test_weight_only_linear_matches_float64_of_the_same_operands(m, n, k, group, offset, bias, out_dtype):
+    """Ragged M / N, every K-loop length, grouped and per-channel parameters, offsets, bias, both output dtypes: within one
+    output rounding (+ fp32 accumulation) of the float64 product of x and the A2-dequantized weight."""
+    gen = torch.Generator().manual_seed(m * 3 + n + k)
+    codes, scale, off = _wq_case(n, k, group, 8 if group == k else 4, offset, seed=m + n + k)
+    x = torch.randn(m, k, generator=gen).to(torch.bfloat16).to(DEV)
+    b = torch.randn(n, generator=gen).to(torch.bfloat16).to(DEV) if bias else None
+    y = ops.linear_wq(x, codes, scale, off, group=group, bias=b, out_dtype=out_dtype)
+    assert y is not None and y.dtype == out_dtype and y.shape == (m, n)
+    w_hat = ops.dequantize_by_tile(codes, scale, (1, group), off, torch.bfloat16)
+    ref = x.double() @ w_hat.double().t() + (0 if b is None else b.double())
+    rtol = 2.0**-8 if out_dtype == torch.bfloat16 else 1e-5
+    torch.testing.assert_close(y.double(), ref, rtol=rtol, atol=1e-5 * float(ref.abs().max()) + 1e-6 * k)
+
+
+def test_weight_only_linear_refuses_what_it_does_not_cover():
+    codes, scale, off = _wq_case(64, 192, 96, 4, False, seed=1)  # groups of 96: not a multiple of 64
+    x = torch.randn(8, 192, device=DEV, dtype=torch.bfloat16)
+    assert ops.linear_wq(x, codes, scale, off, group=96) is None
+    assert ops.linear_wq(x.float(), codes, scale[:64], None) is None  # fp32 activations: the float fallback's job
+    # ... and the dispatcher then runs the reference's path (dequantize + F.linear) with the same result as ever
+    w = torch.randn(64, 192, device=DEV, dtype=torch.bfloat16)
+    q = ff.nn.LinearQuantizer(4, granularity=ff.PerBlock(1, 96, 0), quantized_dtype=torch.int8, device=DEV)
+    with ff.estimate_ranges(q, ff.range_setting.running_minmax), torch.no_grad():
+        wq = q(w)
+    assert ff.dispatcher.dispatch("linear", input=x, weight=wq) is None
+    with ff.strict_quantization(False), torch.no_grad():
+        assert torch.equal(ff.nn.functional.linear(x, wq), torch.nn.functional.linear(x, wq.dequantize()))

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Build experiment variants of the weight-only GEMM: tools/wq_variants.sh TAG "-DWL_X=n" [TAG2 "..."]...
+# -> fastforward_amd/csrc/_build/libffq_TAG.so. Time with FFQ_LIB=<that> python tools/wq_time.py
+set -e
+cd "$(dirname "$0")/../fastforward_amd/csrc"
+make -s -j8
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wno-unused-function"
+while [ $# -ge 2 ]; do
+  TAG=$1; DEFS=$2; shift 2
+  ( /opt/rocm/bin/hipcc $FLAGS $DEFS -c ffq_wlinear.hip -o _build/ffq_wlinear_$TAG.o && \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o _build/libffq_$TAG.so $(ls _build/ffq_*.o | grep -v "ffq_wlinear\|ffq_linear_x") _build/ffq_wlinear_$TAG.o && echo built $TAG ) &
+done
+wait
