@@ -270,7 +270,8 @@ def quantize_by_tile_backward(
             _ptr(doffset), _ptr(ws), nbytes, stream,
         )
         if status == 0:
-            return [dinput, dscale.reshape(scale.shape), torch.Tensor() if doffset is None else doffset.reshape(scale.shape)]
+            # no offset: an empty placeholder on the inputs' device (the reference returns a bare torch.Tensor(), :221-222)
+            return [dinput, dscale.reshape(scale.shape), scale.new_empty(0) if doffset is None else doffset.reshape(scale.shape)]
         if status != 6:  # FFQ_ERR_DTYPE: a tiling the kernel does not cover
             lib.check(status)
     return _quantize_by_tile_backward_composite(data, output_grad, scale, tile_size, num_bits, offset)
@@ -303,7 +304,7 @@ def _quantize_by_tile_backward_composite(
     clipped = below | above
     dinput = rows_to_tiles(torch.where(clipped, torch.zeros_like(grows), grows), data.shape, tile)
     if offset is None:
-        doffset = torch.Tensor()
+        doffset = scale.new_empty(0)
     else:
         doffset = torch.where(clipped, s[:, None] * grows, torch.zeros_like(s[:, None] * grows)).sum(1).reshape(param_shape)
     bound = torch.where(below, s.new_tensor([lo]), s.new_tensor([hi])) + o[:, None].to(s.dtype)
@@ -955,7 +956,7 @@ def _meta_quantize_dynamic_by_tile(data, tile_size, num_bits, symmetric, allow_o
 
 
 def _meta_quantize_by_tile_backward(data, output_grad, scale, tile_size, num_bits, offset=None):  # type: ignore[no-untyped-def]
-    doffset = torch.empty(0) if offset is None else torch.empty_like(scale)
+    doffset = scale.new_empty(0) if offset is None else torch.empty_like(scale)
     return [torch.empty(data.shape, dtype=data.dtype, device=data.device), torch.empty_like(scale), doffset]
 
 

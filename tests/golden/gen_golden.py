@@ -7,7 +7,9 @@ tree_unflatten, tree_leaves" > /tmp/ffshim/optree/__init__.py
     PYTHONPATH=/root/reference/src:/tmp/ffshim python tests/golden/gen_golden.py
 
 (`optree` is the one eagerly imported dependency of the reference that is not installed here; the
-two-line shim re-exports torch's own pytree functions and lives outside the repository.)
+two-line shim re-exports torch's own pytree functions and lives outside the repository. G17 additionally needs
+/tmp/ffshim/ffstub.py — a meta-path finder that fabricates empty `gguf` / `onnx*` packages so that
+`fastforward.export.stages.gguf` imports; the packing functions it then calls are the reference's own, pure torch.)
 
 Nothing of the reference travels: the fixtures hold inputs (or the seed that regenerates them with
 torch's CPU generator) and the outputs the reference produced. Files are torch.save'd dicts of
@@ -612,6 +614,53 @@ def g15_weight_only_linear():
     return cases
 
 
+def g16_smoothed_minmax():
+    """SmoothedMinMax trajectories (range_setting/minmax.py:67-92): exponential moving average of the per-batch extrema,
+    the first batch adopted as is; five scaled batches, gamma in {1.0, 0.9, 0.3}, per tensor / per row / per column,
+    fp32 and bf16 data, symmetric and asymmetric quantizers. Codes of every step and the final parameters."""
+    out = []
+    for spec, dtype, symmetric, gamma in itertools.product((("tensor",), ("channel", (0,)), ("channel", (-1,))), (torch.float32, torch.bfloat16), (True, False), (1.0, 0.9, 0.3)):
+        g = torch.Generator().manual_seed(77)
+        base = torch.randn(16, 24, generator=g)
+        batches = [(base * (1.0 + 0.5 * ((i * 7) % 5)) + 0.1 * i).to(dtype) for i in range(5)]
+        quantizer = ff.nn.LinearQuantizer(4, symmetric=symmetric, granularity=gran_of(spec))
+        outputs, ranges = [], []
+        with ff.estimate_ranges(torch.nn.ModuleList([quantizer]), ff.range_setting.smoothed_minmax, gamma=gamma):
+            for b in batches:
+                outputs.append(quantizer(b).raw_data.clone())
+                ranges.append((quantizer.scale.detach().clone(), None if quantizer.offset is None else quantizer.offset.detach().clone()))
+        out.append({
+            "granularity": list(spec), "symmetric": symmetric, "num_bits": 4, "gamma": gamma, "batches": batches,
+            "scale": quantizer.scale.detach().clone(),
+            "offset": None if quantizer.offset is None else quantizer.offset.detach().clone(),
+            "codes_per_step": outputs, "params_per_step": ranges,
+        })
+    return out
+
+
+def g17_gguf_blocks():
+    """The reference's GGUF block-32 packers themselves (export/stages/gguf/_packing.py:23-79, pure torch): Q4_0 and Q8_0
+    records for seeded codes and scales, including codes outside the nibble range (clamped, :49), -128 (clipped to -127,
+    :77) and scales that round in fp16. The package's __init__ pulls in `gguf` / `onnx`, absent here: a permissive stub
+    importer (outside the repository, see the module docstring) lets the package import; the packers are untouched."""
+    import ffstub  # noqa: F401  (outside the repository: /tmp/ffshim/ffstub.py)
+
+    from fastforward.export.stages.gguf._packing import pack_q4_0_blocks, pack_q8_0_blocks
+
+    g = torch.Generator().manual_seed(31)
+    n = 96
+    codes4 = torch.randint(-8, 8, (n, 32), generator=g, dtype=torch.int8)
+    codes4[0, :4] = torch.tensor([-9, 8, 100, -100], dtype=torch.int8)  # out of range: clamped to [0, 15] after + 8
+    codes8 = torch.randint(-128, 128, (n, 32), generator=g, dtype=torch.int8)
+    codes8[1, :3] = torch.tensor([-128, 127, -127], dtype=torch.int8)
+    scales = torch.rand(n, generator=g) * 0.05 + 1e-3
+    scales[2] = 65504.0  # fp16 max
+    scales[3] = 1e-8     # underflows to an fp16 subnormal / zero
+    scales[4] = 0.1      # not representable in fp16: rounds
+    return {"codes4": codes4, "codes8": codes8, "scales": scales,
+            "q4_0": pack_q4_0_blocks(codes4, scales), "q8_0": pack_q8_0_blocks(codes8, scales)}
+
+
 def main() -> None:
     torch.set_num_threads(8)
     if len(sys.argv) > 1:  # regenerate only the named fixtures, e.g. `gen_golden.py g10_producers`
@@ -635,6 +684,8 @@ def main() -> None:
     torch.save(g13_gptq(), HERE / "g13_gptq.pt")
     torch.save(g14_attention(), HERE / "g14_attention.pt")
     torch.save(g15_weight_only_linear(), HERE / "g15_weight_only_linear.pt")
+    torch.save(g16_smoothed_minmax(), HERE / "g16_smoothed_minmax.pt")
+    torch.save(g17_gguf_blocks(), HERE / "g17_gguf_blocks.pt")
     for f in sorted(HERE.glob("*.pt")):
         print(f"{f.name}: {f.stat().st_size / 1024:.0f} KiB")
 

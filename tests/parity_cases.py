@@ -501,7 +501,33 @@ def check_mse_grid(device):
                 assert same_with_nan(quantizer.offset.detach().cpu(), c["offset"]), c["name"]
 
 
+def check_smoothed_minmax(device):
+    """Fixture G16: the reference's SmoothedMinMax estimator (range_setting/minmax.py:67-92) over five batches — codes of
+    every step, parameters after every step and at the end, bit for bit."""
+    n = 0
+    for c in golden("g16_smoothed_minmax.pt"):
+        quantizer = ff.nn.LinearQuantizer(c["num_bits"], symmetric=c["symmetric"], granularity=granularity_of(c["granularity"]), device=device)
+        with ff.estimate_ranges(torch.nn.ModuleList([quantizer]), ff.range_setting.smoothed_minmax, gamma=c["gamma"]):
+            for batch, expected, (scale, offset) in zip(c["batches"], c["codes_per_step"], c["params_per_step"]):
+                got = quantizer(batch.to(device)).raw_data.cpu()
+                assert same_with_nan(got, expected), f'{c["granularity"]} gamma={c["gamma"]}: {mismatch_report(got, expected)}'
+                assert same_with_nan(quantizer.scale.detach().cpu(), scale)
+                if offset is not None:
+                    assert same_with_nan(quantizer.offset.detach().cpu(), offset)
+        assert same_with_nan(quantizer.scale.detach().cpu(), c["scale"])
+        if c["offset"] is not None:
+            assert same_with_nan(quantizer.offset.detach().cpu(), c["offset"])
+        n += 1
+    assert n == 36
+
+
 def check_gguf_blocks(device):
+    # Fixture G17: records produced by the reference's own pack_q4_0_blocks / pack_q8_0_blocks (_packing.py:23-79),
+    # including out-of-range codes, -128 and scales that round / overflow / underflow in fp16 — byte for byte
+    g17 = golden("g17_gguf_blocks.pt")
+    assert torch.equal(ops.pack_q4_0_blocks(g17["codes4"].to(device), g17["scales"].to(device)).cpu(), g17["q4_0"])
+    assert torch.equal(ops.pack_q8_0_blocks(g17["codes8"].to(device), g17["scales"].to(device)).cpu(), g17["q8_0"])
+
     """The reference's assertions for its GGUF block-32 packers (tests/export/stages/gguf/test_packing.py), re-expressed:
     record widths, positive fp16 scale, +8 nibble offset with low/high halves, llama.cpp's dequantization formulas
     reproduce scale * code, -128 is clipped to -127 in Q8_0."""

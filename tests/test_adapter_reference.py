@@ -48,3 +48,50 @@ def test_reference_ops_run_on_this_backend(oracle_backend, tmp_path):
     finally:
         sys.path.remove(REFERENCE)
         sys.path.remove(str(tmp_path))
+
+
+def test_dispatcher_hooks_serve_the_reference_operators(oracle_backend, tmp_path):
+    """install() also registers linear (W8A8 and weight-only), mm, matmul and bmm in the REFERENCE's dispatcher
+    (src/fastforward/dispatcher.py:233-265; fallbacks _gen/fallback.py:77-112, 699-798): the reference's own
+    ff.nn.functional.* then run this package's kernels, and agree with the reference's float fallback within its own
+    half-precision tolerance (tests/quantization/test_tiled_affine.py:43-55)."""
+    shim = tmp_path / "optree"
+    shim.mkdir()
+    (shim / "__init__.py").write_text("from torch.utils._pytree import tree_map, tree_flatten, tree_unflatten, tree_leaves\n")
+    sys.path[:0] = [REFERENCE, str(tmp_path)]
+    try:
+        import fastforward as ff_ref
+
+        from fastforward_amd import adapter
+
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(12, 128, generator=g)
+        w = torch.randn(48, 128, generator=g) * 0.1
+        qx = ff_ref.quantization.affine.quantize_per_tensor(x, 0.03, 2.0, 8)
+        qw = ff_ref.quantization.affine.quantize_per_channel(w, torch.full((48,), 0.002), None, 0, 8)
+        qwt = ff_ref.quantization.affine.quantize_per_tensor(w.t().contiguous(), 0.002, None, 8)
+        xb = torch.randn(3, 12, 64, generator=g)
+        wb = torch.randn(3, 64, 20, generator=g)
+        qxb = ff_ref.quantization.affine.quantize_per_tensor(xb, 0.03, None, 8)
+        qwb = ff_ref.quantization.affine.quantize_per_tensor(wb, 0.03, None, 8)
+        x16 = torch.randn(5, 128, generator=g).to(torch.bfloat16)
+        w16 = (torch.randn(32, 128, generator=g) * 0.1).to(torch.bfloat16)
+        qw16 = ff_ref.quantization.affine.quantize_per_channel(w16, torch.full((32,), 0.003), None, 0, 8)
+        F = ff_ref.nn.functional
+        with ff_ref.strict_quantization(False):
+            before = [F.linear(qx, qw), F.mm(qx, qwt), F.matmul(qx, qwt), F.bmm(qxb, qwb), F.linear(x16, qw16)]
+            attached = adapter.install(device_types=("cpu",), register_linear=True)
+            assert {"dispatcher:linear", "dispatcher:linear(weight-only)", "dispatcher:mm", "dispatcher:matmul", "dispatcher:bmm"} <= set(attached)
+            assert ff_ref.dispatcher.dispatch("linear", input=qx, weight=qw) is adapter._reference_linear
+            assert ff_ref.dispatcher.dispatch("linear", input=x16, weight=qw16) is adapter._reference_weight_only_linear
+            assert ff_ref.dispatcher.dispatch("mm", input=qx, mat2=qwt) is adapter._reference_mm
+            assert ff_ref.dispatcher.dispatch("matmul", input=qx, other=qwt) is adapter._reference_mm
+            assert ff_ref.dispatcher.dispatch("bmm", input=qxb, mat2=qwb) is adapter._reference_bmm
+            assert ff_ref.dispatcher.dispatch("linear", input=x, weight=w) is None  # nothing quantized: not ours
+            after = [F.linear(qx, qw), F.mm(qx, qwt), F.matmul(qx, qwt), F.bmm(qxb, qwb), F.linear(x16, qw16)]
+        for a, b in zip(after, before):
+            assert a.shape == b.shape and a.dtype == b.dtype
+            torch.testing.assert_close(a.float(), b.float(), atol=1e-1, rtol=1.3e-2)
+    finally:
+        sys.path.remove(REFERENCE)
+        sys.path.remove(str(tmp_path))

@@ -583,3 +583,57 @@ def test_gptq_partial_range_update_writes_one_group_and_clears_a_stale_offset():
     rmin, rmax = ff.quantization.affine.quantization_range(quantizer.scale.detach().view(16, 4)[:, 1], quantizer.offset.detach().view(16, 4)[:, 1], 4)
     assert bool((rmin <= lo).all()) and bool((rmax >= hi - 1e-6).all())
     assert torch.equal(quantizer.offset.detach().view(16, 4)[:, [0, 2, 3]], others)
+
+
+# ---- freeze_parameters (reference quantization/freeze.py:74-125; assertions of tests/quantization/test_freeze.py re-expressed) ----
+def _two_quantized_linears():
+    torch.manual_seed(4)
+    model = torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.Linear(16, 16))
+    ff.quantize_model(model)
+    for layer in model:
+        layer.weight_quantizer = ff.nn.LinearQuantizer(4, granularity=ff.PerChannel(0))
+        layer.weight_quantizer.quantization_range = (layer.weight.detach().amin(1), layer.weight.detach().amax(1))
+    return model
+
+
+def test_freeze_parameters_snaps_parameters_in_place_and_retires_their_quantizers():
+    from fastforward_amd.quantization.freeze import freeze_parameters
+
+    model = _two_quantized_linears()
+    with ff.strict_quantization(False):
+        want = [layer.weight_quantizer(layer.weight).dequantize().detach().clone() for layer in model]
+    before = [layer.weight.detach().clone() for layer in model]
+    metadata = [layer.weight_quantizer.quant_metadata for layer in model]
+    pointers = [layer.weight.data_ptr() for layer in model]
+    with freeze_parameters(model):
+        model(torch.randn(2, 16))
+    for layer, w, b, meta, ptr in zip(model, want, before, metadata, pointers):
+        assert torch.equal(layer.weight.detach(), w) and not torch.equal(layer.weight.detach(), b)  # quantized values, in place
+        assert layer.weight.data_ptr() == ptr and isinstance(layer.weight, torch.nn.Parameter)
+        assert isinstance(layer.weight_quantizer, ff.nn.QuantizerStub) and layer.weight_quantizer.quant_metadata == meta
+    assert not list(ff.nn.named_quantizers(model))  # everything that was called is a stub now
+    # a model without quantizers passes through untouched
+    plain = torch.nn.Sequential(torch.nn.Linear(4, 4))
+    with freeze_parameters(plain):
+        plain(torch.randn(2, 4))
+
+
+def test_freeze_parameters_can_keep_the_quantizers_and_skips_disabled_ones():
+    from fastforward_amd.quantization.freeze import freeze_parameters
+
+    model = _two_quantized_linears()
+    kept = [layer.weight_quantizer for layer in model]
+    with freeze_parameters(model, remove_quantizers=False):
+        model(torch.randn(2, 16))
+    assert [layer.weight_quantizer for layer in model] == kept
+    assert all(not list(q.overrides) for q in kept)  # the freeze overrides are gone when the context exits
+    with ff.strict_quantization(False):  # frozen weights sit on the grid: quantizing them again changes nothing
+        for layer in model:
+            assert torch.equal(layer.weight_quantizer(layer.weight).dequantize(), layer.weight)
+    model = _two_quantized_linears()
+    before = [layer.weight.detach().clone() for layer in model]
+    kept = [layer.weight_quantizer for layer in model]
+    with ff.disable_quantization(model), freeze_parameters(model):
+        model(torch.randn(2, 16))
+    assert all(torch.equal(layer.weight.detach(), b) for layer, b in zip(model, before))
+    assert [layer.weight_quantizer for layer in model] == kept

@@ -81,3 +81,7 @@ def test_gptq_matches_the_reference_bit_for_bit():
 
 def test_weight_only_linear_matches_the_reference():
     parity_cases.check_weight_only_linear("cpu")
+
+
+def test_smoothed_minmax_trajectories():
+    parity_cases.check_smoothed_minmax("cpu")

@@ -91,6 +91,48 @@ def test_mse_grid_range_estimator():
 
 def test_gguf_block_writers():
     parity_cases.check_gguf_blocks(DEV)
+
+
+def test_smoothed_minmax_trajectories():
+    parity_cases.check_smoothed_minmax(DEV)
+
+
+def test_freeze_parameters_and_fuse_qdq_weights_on_the_device():
+    """SURVEY 8(f) row 1 on the GPU: both ways of folding weight quantizers into the weights (reference
+    quantization/freeze.py:74-125, fuse.py:199-242) write exactly A2(A1(w)) into the parameters, in place; afterwards the
+    weights sit on their grids (re-quantizing is the identity) and the forward no longer depends on the weight quantizers."""
+    from fastforward_amd.quantization.freeze import freeze_parameters
+
+    def build():
+        torch.manual_seed(12)
+        model = torch.nn.Sequential(torch.nn.Linear(256, 192), torch.nn.Linear(192, 64)).to(DEV, torch.bfloat16)
+        ff.quantize_model(model)
+        for layer, gran, bits in zip(model, (ff.PerChannel(0), ff.PerBlock(1, 64, 0)), (8, 4)):
+            layer.weight_quantizer = ff.nn.LinearQuantizer(bits, granularity=gran, quantized_dtype=torch.int8, device=DEV)
+        x = torch.randn(8, 256, device=DEV, dtype=torch.bfloat16)
+        with torch.no_grad(), ff.strict_quantization(False), ff.estimate_ranges(model, ff.range_setting.running_minmax):
+            model(x)
+        return model, x
+
+    for how in ("freeze", "fuse", "fuse_and_stub"):
+        model, x = build()
+        with torch.no_grad(), ff.strict_quantization(False):
+            want_w = [layer.weight_quantizer(layer.weight).dequantize().clone() for layer in model]
+            want_y = model(x)
+        pointers = [layer.weight.data_ptr() for layer in model]
+        if how == "freeze":
+            with freeze_parameters(model), torch.no_grad():
+                model(x)
+        else:
+            ff.quantization.fuse_qdq_weights(model, stub_quantizers=how == "fuse_and_stub")
+        for layer, w, ptr in zip(model, want_w, pointers):
+            assert torch.equal(layer.weight.detach(), w) and layer.weight.data_ptr() == ptr
+            assert layer.weight_quantizer.is_stub() == (how != "fuse")
+        with torch.no_grad(), ff.strict_quantization(False):
+            assert torch.equal(model(x), want_y)  # same forward: the weights were already what the quantizers made of them
+            if how == "fuse":
+                for layer, w in zip(model, want_w):
+                    assert torch.equal(layer.weight_quantizer(layer.weight).dequantize(), w)  # idempotent on the grid
     # a weight-sized tensor: Q4_0 bytes of group-32 codes == the nibbles of pack_int4 next to the fp16 scales
     torch.manual_seed(2)
     w = (torch.randn(4096, 4096, device=DEV) * 0.02).to(torch.bfloat16)
