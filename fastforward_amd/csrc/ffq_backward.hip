@@ -9,7 +9,8 @@
 // The reference runs ~14 ATen passes with fp32 temporaries. Here: ONE streaming pass (x and g in, dinput
 // out, 6 B/elem for bf16) that leaves one (dscale, doffset) partial per 2048-element block or per
 // 8-element chunk, and a finalize pass over the partials in a FIXED order — the sums are deterministic
-// (no floating-point atomics), their summation order is this file's own.
+// (no floating-point atomics), their summation order is this file's own. Tilings the streaming pass does not cover
+// (strided channels, N-d tiles) take quantize_backward_tiles_kernel: the same arithmetic, walked tile by tile.
 #include "ffq_common.h"
 #include "ffq_vec.h"
 
@@ -119,6 +120,61 @@ __global__ __launch_bounds__(kBlock) void backward_finalize_small_kernel(const P
   if (doffset) doffset[t] = dof;
 }
 
+// Any tiling (strided channels such as PerChannel(-1), N-d tiles): tile-major walk, one block per tile (or one LANE per
+// tile when tiles are shorter than a wave), dinput written element by element, the two sums reduced in a fixed order and
+// written straight into dscale / doffset — no workspace, no atomics. Latency-bound (an index decomposition per element):
+// the coverage path, the streaming kernel above stays the fast one.
+template <typename T, bool HAS_OFFSET>
+__global__ __launch_bounds__(kBlock) void quantize_backward_tiles_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                                        T* __restrict__ dinput, const float* __restrict__ scale,
+                                                                        const float* __restrict__ offset, float* __restrict__ dscale,
+                                                                        float* __restrict__ doffset, TileWalk w, int64_t ntiles,
+                                                                        float lo, float hi, uint32_t scale_stride,
+                                                                        uint32_t offset_stride, int lane_per_tile) {
+  __shared__ Partial2 wave_part[kBlock / 64];
+  const int64_t tile = lane_per_tile ? (int64_t)blockIdx.x * kBlock + threadIdx.x : (int64_t)blockIdx.x;
+  float ds = 0.0f, dof = 0.0f;
+  if (tile < ntiles) {
+    const float s = scale[tile * scale_stride];
+    const float ro = HAS_OFFSET ? rne(offset[tile * offset_stride]) : 0.0f;
+    const int64_t origin = tile_origin(w.g, tile);
+    const int64_t first = lane_per_tile ? 0 : threadIdx.x, step = lane_per_tile ? 1 : kBlock;
+    for (int64_t e = first; e < w.tile_elems; e += step) {
+      const int64_t at = tile_element(w.g, origin, e);
+      const float xv = to_f32(x[at]), gv = to_f32(g[at]);
+      const float u = xv / s - ro;
+      const float q = rne(u);
+      const bool below = q < lo, above = q > hi;
+      const bool clip = below || above;
+      dinput[at] = from_f32<T>(clip ? 0.0f : gv);
+      const float bound = (below ? lo : hi) + ro;
+      ds = ds + (clip ? bound : q - u) * gv;
+      if constexpr (HAS_OFFSET) dof = dof + (clip ? s * gv : 0.0f);
+    }
+  }
+  if (lane_per_tile) {
+    if (tile < ntiles) {
+      dscale[tile] = ds;
+      if (HAS_OFFSET) doffset[tile] = dof;
+    }
+    return;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    ds = ds + __shfl_xor(ds, d, 64);
+    dof = dof + __shfl_xor(dof, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = Partial2{ds, dof};
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Partial2 p = wave_part[0];
+#pragma unroll
+    for (int v = 1; v < kBlock / 64; ++v) { p.ds = p.ds + wave_part[v].ds; p.dof = p.dof + wave_part[v].dof; }
+    dscale[tile] = p.ds;
+    if (HAS_OFFSET) doffset[tile] = p.dof;
+  }
+}
+
 static bool backward_plan(const TileInfo& info, uint32_t* nchunks, int* per_block, uint32_t* units, uint32_t* nparts) {
   if (info.numel % 8 != 0 || info.numel / 8 >= ((int64_t)1 << 32) - kBlock) return false;
   const int64_t chunks = info.numel / 8;
@@ -170,9 +226,28 @@ extern "C" int ffq_quantize_by_tile_backward(const void* data, const void* outpu
   if (offset && !doffset) return fail(FFQ_ERR_ARG, "doffset is required when offset is given");
   uint32_t nchunks, units, nparts;
   int per_block;
-  if (!backward_plan(info, &nchunks, &per_block, &units, &nparts) || !aligned16(data) || !aligned16(output_grad) || !aligned16(dinput))
-    return fail(FFQ_ERR_DTYPE, "backward kernel covers per-tensor tiles and contiguous-run tiles with numel %% 8 == 0");
-  if (scale_numel == 1 && info.ntiles != 1) return fail(FFQ_ERR_DTYPE, "backward kernel needs one scale per tile");
+  const double lo_d = -pow(2.0, num_bits - 1.0);
+  if (!backward_plan(info, &nchunks, &per_block, &units, &nparts) || !aligned16(data) || !aligned16(output_grad) || !aligned16(dinput) ||
+      (scale_numel == 1 && info.ntiles != 1)) {
+    // strided channels, N-d tiles, odd sizes, broadcast parameters: the by-tile kernel
+    const TileWalk w = make_tile_walk(tiling);
+    const int lane_per_tile = w.tile_elems < 64;
+    const int64_t blocks = lane_per_tile ? (info.ntiles + kBlock - 1) / kBlock : info.ntiles;
+    if (blocks >= ((int64_t)1 << 31)) return fail(FFQ_ERR_DTYPE, "too many tiles for the by-tile backward kernel");
+    const uint32_t ss = scale_numel == 1 ? 0u : 1u, os = offset_numel == 1 ? 0u : 1u;
+#define FFQ_BWD_TILES(T)                                                                                             \
+  do {                                                                                                               \
+    if (offset) quantize_backward_tiles_kernel<T, true><<<(unsigned)blocks, kBlock, 0, s>>>(static_cast<const T*>(data), static_cast<const T*>(output_grad), static_cast<T*>(dinput), scale, offset, dscale, doffset, w, info.ntiles, (float)lo_d, (float)(-lo_d - 1.0), ss, os, lane_per_tile); \
+    else quantize_backward_tiles_kernel<T, false><<<(unsigned)blocks, kBlock, 0, s>>>(static_cast<const T*>(data), static_cast<const T*>(output_grad), static_cast<T*>(dinput), scale, offset, dscale, doffset, w, info.ntiles, (float)lo_d, (float)(-lo_d - 1.0), ss, os, lane_per_tile); \
+  } while (0)
+    switch (dt) {
+      case FFQ_F32: FFQ_BWD_TILES(float); break;
+      case FFQ_BF16: FFQ_BWD_TILES(bf16_t); break;
+      default: FFQ_BWD_TILES(f16_t); break;
+    }
+#undef FFQ_BWD_TILES
+    return check_launch("quantize_backward_tiles_kernel");
+  }
   const size_t need = (size_t)nparts * sizeof(Partial2);
   if (!workspace || workspace_bytes < need) return fail(FFQ_ERR_WORKSPACE, "backward needs %zu workspace bytes, got %zu", need, workspace_bytes);
   BwdArgs a;

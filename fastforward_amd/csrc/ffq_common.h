@@ -190,6 +190,41 @@ inline bool first_use_on_this_device(uint64_t* mask) {
   return true;
 }
 
+// The inverse walk: flat offset of element `e` (row-major inside the tile) of tile `tile` (row-major over the tile grid),
+// i.e. element (tile, e) of the reference's tiles_to_rows view (quantization/tiled_tensor.py:71-98) without materialising
+// it. Used by the by-tile kernels that cover ANY tiling (strided channels, N-d tiles): one block or one lane per tile.
+struct TileWalk {
+  GenericTiling g;
+  int64_t tile_elems;
+};
+inline TileWalk make_tile_walk(const ffq_tiling* t) {
+  TileWalk w;
+  w.g = make_generic(t);
+  w.tile_elems = 1;
+  for (int k = 0; k < t->ndim; ++k) w.tile_elems *= t->tile[k];
+  return w;
+}
+__device__ inline int64_t tile_origin(const GenericTiling& g, int64_t tile) {  // flat offset of the tile's first element
+  int64_t flat = 0, stride = 1;
+  for (int k = g.ndim - 1; k >= 0; --k) {
+    const int64_t grid = g.shape[k] / g.tile[k];
+    const int64_t tc = (tile / g.gstride[k]) % grid;
+    flat += tc * g.tile[k] * stride;
+    stride *= g.shape[k];
+  }
+  return flat;
+}
+__device__ inline int64_t tile_element(const GenericTiling& g, int64_t origin, int64_t e) {
+  int64_t flat = origin, stride = 1;
+  for (int k = g.ndim - 1; k >= 0; --k) {
+    const int64_t ec = e % g.tile[k];
+    e /= g.tile[k];
+    flat += ec * stride;
+    stride *= g.shape[k];
+  }
+  return flat;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 constexpr int kBlock = 256;       // 4 waves of 64 lanes

@@ -131,6 +131,70 @@ __global__ __launch_bounds__(kBlock) void grid_finalize_kernel(const float* __re
   }
 }
 
+// Any tiling: one block per tile (one lane per tile below a wave's worth of elements) walks the tile once per batch of 16
+// candidates; fixed-order sums written straight to err[cand][tile]. The coverage path for strided channels / N-d tiles.
+template <typename T, bool HAS_OFFSET>
+__global__ __launch_bounds__(kBlock) void grid_sqerror_tiles_kernel(const T* __restrict__ x, const float* __restrict__ scales,
+                                                                   const float* __restrict__ offsets, float* __restrict__ err,
+                                                                   TileWalk w, uint32_t ntiles, uint32_t ncand, float lo, float hi,
+                                                                   int accumulate, int lane_per_tile) {
+  __shared__ float wave_part[kBlock / 64][kCandBatch];
+  const int64_t tile = lane_per_tile ? (int64_t)blockIdx.x * kBlock + threadIdx.x : (int64_t)blockIdx.x;
+  const bool live = tile < (int64_t)ntiles;
+  const int64_t origin = live ? tile_origin(w.g, tile) : 0;
+  const int64_t first = lane_per_tile ? 0 : threadIdx.x, step = lane_per_tile ? 1 : kBlock;
+  for (uint32_t cb = 0; cb < ncand; cb += kCandBatch) {
+    float acc[kCandBatch], sc[kCandBatch], ro[kCandBatch];
+#pragma unroll
+    for (int k = 0; k < kCandBatch; ++k) {
+      acc[k] = 0.0f;
+      const bool on = live && cb + k < ncand;
+      sc[k] = on ? scales[(size_t)(cb + k) * ntiles + tile] : 1.0f;
+      ro[k] = (on && HAS_OFFSET) ? rne(offsets[(size_t)(cb + k) * ntiles + tile]) : 0.0f;
+    }
+    if (live) {
+      for (int64_t e = first; e < w.tile_elems; e += step) {
+        const float xv = to_f32(x[tile_element(w.g, origin, e)]);
+#pragma unroll
+        for (int k = 0; k < kCandBatch; ++k) {
+          const float r = rne(xv / sc[k] - ro[k]);
+          const float q = r != r ? r : __builtin_amdgcn_fmed3f(r, lo, hi);
+          const float y = round_to<T>((q + ro[k]) * sc[k]);
+          const float d = round_to<T>(y - xv);
+          acc[k] = acc[k] + round_to<T>(d * d);
+        }
+      }
+    }
+    if (lane_per_tile) {
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < kCandBatch; ++k)
+          if (cb + k < ncand) {
+            float* dst = err + (size_t)(cb + k) * ntiles + tile;
+            *dst = accumulate ? *dst + acc[k] : acc[k];
+          }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int k = 0; k < kCandBatch; ++k) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) acc[k] = acc[k] + __shfl_xor(acc[k], d, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < kCandBatch; ++k) wave_part[threadIdx.x >> 6][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < kCandBatch && cb + threadIdx.x < ncand) {
+      const float v = ((wave_part[0][threadIdx.x] + wave_part[1][threadIdx.x]) + wave_part[2][threadIdx.x]) + wave_part[3][threadIdx.x];
+      float* dst = err + (size_t)(cb + threadIdx.x) * ntiles + tile;
+      *dst = accumulate ? *dst + v : v;
+    }
+  }
+}
+
 static bool grid_plan(const TileInfo& info, GridArgs* a, uint32_t* units, uint32_t* nblocks) {
   if (info.numel % 8 != 0 || info.numel / 8 >= ((int64_t)1 << 32) - kBlock) return false;
   const int64_t chunks = info.numel / 8;
@@ -183,9 +247,27 @@ extern "C" int ffq_grid_sqerror_by_tile(const void* data, int dt, const float* s
   if (!data || !scales || !err) return fail(FFQ_ERR_ARG, "NULL buffer");
   GridArgs a;
   uint32_t units, nblocks;
-  if (!grid_plan(info, &a, &units, &nblocks) || !aligned16(data) || info.ntiles * ncand >= ((int64_t)1 << 31))
-    return fail(FFQ_ERR_DTYPE, "grid error kernel covers per-tensor tiles and contiguous-run tiles of 8 * 2^k <= 512 or a multiple of 2048 elements");
   const double lo = -pow(2.0, num_bits - 1.0);
+  if (info.ntiles * ncand >= ((int64_t)1 << 31)) return fail(FFQ_ERR_DTYPE, "too many (tile, candidate) pairs");
+  if (!grid_plan(info, &a, &units, &nblocks) || !aligned16(data)) {
+    // strided channels, N-d tiles, run lengths the streaming kernel does not cover: the by-tile kernel
+    const TileWalk w = make_tile_walk(tiling);
+    const int lane_per_tile = w.tile_elems < 64;
+    const int64_t blocks = lane_per_tile ? (info.ntiles + kBlock - 1) / kBlock : info.ntiles;
+    if (blocks >= ((int64_t)1 << 31)) return fail(FFQ_ERR_DTYPE, "too many tiles for the by-tile grid kernel");
+#define FFQ_GRID_TILES(T)                                                                                                 \
+  do {                                                                                                                    \
+    if (offsets) grid_sqerror_tiles_kernel<T, true><<<(unsigned)blocks, kBlock, 0, s>>>(static_cast<const T*>(data), scales, offsets, err, w, (uint32_t)info.ntiles, (uint32_t)ncand, (float)lo, (float)(-lo - 1.0), accumulate, lane_per_tile); \
+    else grid_sqerror_tiles_kernel<T, false><<<(unsigned)blocks, kBlock, 0, s>>>(static_cast<const T*>(data), scales, offsets, err, w, (uint32_t)info.ntiles, (uint32_t)ncand, (float)lo, (float)(-lo - 1.0), accumulate, lane_per_tile); \
+  } while (0)
+    switch (dt) {
+      case FFQ_F32: FFQ_GRID_TILES(float); break;
+      case FFQ_BF16: FFQ_GRID_TILES(bf16_t); break;
+      default: FFQ_GRID_TILES(f16_t); break;
+    }
+#undef FFQ_GRID_TILES
+    return check_launch("grid_sqerror_tiles_kernel");
+  }
   a.lo = (float)lo; a.hi = (float)(-lo - 1.0);
   a.ntiles = (uint32_t)info.ntiles;
   a.ncand = (uint32_t)ncand;

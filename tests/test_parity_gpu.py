@@ -716,3 +716,62 @@ def test_weight_only_linear_refuses_what_it_does_not_cover():
     assert ff.dispatcher.dispatch("linear", input=x, weight=wq) is None
     with ff.strict_quantization(False), torch.no_grad():
         assert torch.equal(ff.nn.functional.linear(x, wq), torch.nn.functional.linear(x, wq.dequantize()))
+
+
+# ---- A8 and the grid estimator on strided channels / N-d tiles: HIP by-tile kernels, no device-ATen composite ---------
+_ODD_TILINGS = [((96, 160), (96, 1)), ((64, 48, 40), (16, 8, 4)), ((33, 17), (1, 1)), ((6, 64, 20), (6, 1, 20)), ((128, 96), (32, 32)), ((1000, 24), (1000, 1)), ((7, 9), (7, 9))]
+
+
+@pytest.mark.parametrize("shape,tile", _ODD_TILINGS, ids=str)
+@pytest.mark.parametrize("dtype,with_offset", [(torch.float32, True), (torch.bfloat16, True), (torch.float32, False)])
+def test_backward_by_tile_kernel_covers_every_tiling(shape, tile, dtype, with_offset, monkeypatch):
+    """PerChannel(-1), PerChannel(1) on 3-D, N-d tiles, element-wise tiles, 2-D blocks: the HIP library itself produces the
+    gradients (the composite of device tensor ops is never called) and they equal the op-for-op formulas."""
+    torch.manual_seed(sum(shape))
+    x = (torch.randn(shape, device=DEV) * 2).to(dtype)
+    g = torch.randn(shape, device=DEV).to(dtype)
+    ntiles = 1
+    for s_, t_ in zip(shape, tile):
+        ntiles *= s_ // t_
+    scale = torch.rand(ntiles, device=DEV) * 0.05 + 0.02
+    offset = (torch.rand(ntiles, device=DEV) * 6 - 3) if with_offset else None
+    want = ops._quantize_by_tile_backward_composite(x, g, scale, tile, 4.0, offset)
+
+    def never(*a, **k):
+        raise AssertionError("the composite was called: the HIP kernel did not cover this tiling")
+
+    monkeypatch.setattr(ops, "_quantize_by_tile_backward_composite", never)
+    got = ops.quantize_by_tile_backward(x, g, scale, tile, 4.0, offset)
+    assert torch.equal(got[0], want[0])
+    from fastforward_amd.quantization.tiled_tensor import tiles_to_rows
+    mag = tiles_to_rows(g.float().abs(), torch.Size(tile)).sum(1)
+    assert bool(((got[1] - want[1]).abs() <= 4e-6 * 12 * mag + 1e-6).all())
+    if with_offset:
+        assert bool(((got[2] - want[2]).abs() <= 4e-6 * 0.07 * mag + 1e-6).all())
+    else:
+        assert got[2].numel() == 0
+
+
+@pytest.mark.parametrize("shape,tile", _ODD_TILINGS[:5], ids=str)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_grid_error_by_tile_kernel_covers_every_tiling(shape, tile, dtype):
+    torch.manual_seed(sum(shape) + 1)
+    x = torch.randn(shape, device=DEV).to(dtype)
+    ntiles = 1
+    for s_, t_ in zip(shape, tile):
+        ntiles *= s_ // t_
+    ncand = 19
+    scales = torch.rand(ncand, ntiles, device=DEV) * 0.3 + 0.05
+    offsets = torch.round(torch.randn(ncand, ntiles, device=DEV) * 2)
+    got = ops.grid_sqerror_by_tile(x, scales, offsets, tile, 4.0)
+    assert got is not None, "the HIP kernel did not cover this tiling"
+    from fastforward_amd.quantization.tiled_tensor import tiles_to_rows
+    want = torch.empty_like(got)
+    for c in range(ncand):  # the reference's loop: quantize, dequantize, squared error per tile (min_error.py:218-231)
+        q = ops.quantize_by_tile(x, scales[c], tile, 4, dtype, offsets[c])
+        d = ops.dequantize_by_tile(q, scales[c], tile, offsets[c], dtype)
+        want[c] = tiles_to_rows(((d - x) ** 2), torch.Size(tile)).float().sum(1)
+    rtol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    torch.testing.assert_close(got, want, rtol=rtol, atol=1e-6)
+    again = ops.grid_sqerror_by_tile(x, scales, offsets, tile, 4.0, out=got.clone())
+    torch.testing.assert_close(again, 2 * got, rtol=1e-6, atol=0)
