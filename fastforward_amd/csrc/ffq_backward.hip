@@ -11,6 +11,9 @@
 // 8-element chunk, and a finalize pass over the partials in a FIXED order — the sums are deterministic
 // (no floating-point atomics), their summation order is this file's own. Tilings the streaming pass does not cover
 // (strided channels, N-d tiles) take quantize_backward_tiles_kernel: the same arithmetic, walked tile by tile.
+#ifndef FFQ_NT_STREAMS
+#define FFQ_NT_STREAMS 1  // nt loads (ffq_vec.h)
+#endif
 #include "ffq_common.h"
 #include "ffq_vec.h"
 
@@ -41,8 +44,8 @@ __global__ __launch_bounds__(kBlock) void quantize_backward_kernel(const T* __re
   float ds = 0.0f, dof = 0.0f;
   if (c < a.nchunks) {
     Chunk<T, E> cx, cg;
-    cx.load(x + (size_t)c * E);
-    cg.load(g + (size_t)c * E);
+    cx.FFQ_SLOAD(x + (size_t)c * E);
+    cg.FFQ_SLOAD(g + (size_t)c * E);
     const uint32_t t = a.rows ? fdiv(c, a.chunks_per_run) : 0u;
     const float s = scale[t * a.scale_stride];
     const float o = HAS_OFFSET ? offset[t * a.offset_stride] : 0.0f;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void quantize_backward_kernel(const T* __re
     }
     Chunk<T, E> out;
     out.pack(di);
-    out.store(dinput + (size_t)c * E);
+    out.FFQ_SSTORE(dinput + (size_t)c * E);
   }
   if (!a.per_block) {
     if (c < a.nchunks) partials[c] = Partial2{ds, dof};

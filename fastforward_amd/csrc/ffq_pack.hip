@@ -5,6 +5,9 @@
 //   the low nibbles and the second half to the high nibbles: byte[j] = qs[j] | qs[j + block/2] << 4.
 // The reference itself keeps 4-bit codes unpacked; this pair makes W4 weights occupy 0.5 B/elem in
 // HBM while `unpack(pack(q)) == q` holds exactly.
+#ifndef FFQ_NT_STREAMS
+#define FFQ_NT_STREAMS 3  // nt loads and stores (ffq_vec.h)
+#endif
 #include "ffq_affine.h"
 #include "ffq_common.h"
 #include "ffq_vec.h"
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(kBlock) void quantize_pack_int4_kernel(const T* __r
     e_lo[u] = b[u] * a.block + j[u] * ITEM;
     e_hi[u] = e_lo[u] + a.block / 2;
     if (live[u]) {
-      cl[u].load(x + e_lo[u]);
-      ch[u].load(x + e_hi[u]);
+      cl[u].FFQ_SLOAD(x + e_lo[u]);
+      ch[u].FFQ_SLOAD(x + e_hi[u]);
     }
   }
 #pragma unroll
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void quantize_pack_int4_kernel(const T* __r
       }
       out.w[w] = word;
     }
-    out.store(packed + (size_t)b[u] * (a.block / 2) + j[u] * ITEM);
+    out.FFQ_SSTORE(packed + (size_t)b[u] * (a.block / 2) + j[u] * ITEM);
   }
 }
 
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void unpack_dequantize_int4_kernel(const ui
   const uint32_t j = item - b * a.items_per_block.div;
   const uint32_t e_lo = b * a.block + j * ITEM, e_hi = e_lo + a.block / 2;
   Chunk<uint8_t, ITEM> in;
-  in.load(packed + (size_t)b * (a.block / 2) + j * ITEM);
+  in.FFQ_SLOAD(packed + (size_t)b * (a.block / 2) + j * ITEM);
   const uint32_t t_lo = a.rows ? fdiv(e_lo / 16, a.chunks_per_run) : 0u;
   const uint32_t t_hi = a.rows ? fdiv(e_hi / 16, a.chunks_per_run) : 0u;
   const float s_lo = scale[t_lo * a.scale_stride], s_hi = scale[t_hi * a.scale_stride];
@@ -184,8 +187,8 @@ __global__ __launch_bounds__(kBlock) void unpack_dequantize_int4_kernel(const ui
   Chunk<T, ITEM> cl, ch;
   cl.pack(yl);
   ch.pack(yh);
-  cl.store(out + e_lo);
-  ch.store(out + e_hi);
+  cl.FFQ_SSTORE(out + e_lo);
+  ch.FFQ_SSTORE(out + e_hi);
 }
 
 // Elements of each half per lane. Measured on [14336, 4096] bf16, group 128 (tools/arith_ab.py, A/B on one box):

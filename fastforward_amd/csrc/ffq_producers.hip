@@ -11,6 +11,9 @@
 // in registers with the same roundings (every ATen op rounds to the tensor dtype), optionally stored,
 // and pushed through the A1 arithmetic of ffq_affine.h for up to three static per-tensor quantizers.
 // HBM-bound like A1: algorithmic bytes per element are stated at each kernel.
+#ifndef FFQ_NT_STREAMS
+#define FFQ_NT_STREAMS 1  // nt loads (ffq_vec.h)
+#endif
 #include "ffq_affine.h"
 #include "ffq_common.h"
 #include "ffq_vec.h"
@@ -72,7 +75,7 @@ __device__ __forceinline__ void fan_store(const FanOut& f, const FanParams& p, c
       quantize_chunk<1, 16>(z, p.s[j], p.o[j], r);
       finalize_chunk<int8_t, 16>(r, f.lo, f.hi, y[j]);
     }
-    y[j].store(f.codes[j] + at);
+    y[j].FFQ_SSTORE(f.codes[j] + at);
   }
 }
 
@@ -101,14 +104,14 @@ __global__ __launch_bounds__(kBlock) void add_rmsnorm_quantize_kernel(const bf16
 #pragma unroll
   for (int u = 0; u < CPL; ++u) {
     const uint32_t c = lane + LPR * u;
-    if (c < chunks_per_row) h[u].load(x + base + (size_t)c * 16);
+    if (c < chunks_per_row) h[u].FFQ_SLOAD(x + base + (size_t)c * 16);
   }
   if (delta) {
     Chunk<bf16_t, 16> d[CPL];
 #pragma unroll
     for (int u = 0; u < CPL; ++u) {
       const uint32_t c = lane + LPR * u;
-      if (c < chunks_per_row) d[u].load(delta + base + (size_t)c * 16);
+      if (c < chunks_per_row) d[u].FFQ_SLOAD(delta + base + (size_t)c * 16);
     }
 #pragma unroll
     for (int u = 0; u < CPL; ++u) {

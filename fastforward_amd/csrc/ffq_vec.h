@@ -7,6 +7,25 @@
 
 #include "ffq_common.h"
 
+// Streaming tensors (read once / written once per launch) of the producer, W4 and backward kernels carry non-temporal
+// hints where an A/B on the MI355X showed a gain (tools/arith_ab.py, profiles/r02_nt_ab.txt; [14336, 4096] bf16):
+//   backward: nt loads 5.44 -> 6.02 TB/s (nt stores on top: 5.9);  W4 quantize+pack: nt loads + stores 4.5 -> 5.4;
+//   W4 unpack+dequantize: both 5.59 -> 5.75;  add+RMSNorm+quantize: nt loads 5.47 -> 5.62 (stores: no gain);  SiLU*up: none.
+// A translation unit picks its policy by defining FFQ_NT_STREAMS (bit 0: loads, bit 1: stores) before including this header.
+#ifndef FFQ_NT_STREAMS
+#define FFQ_NT_STREAMS 0
+#endif
+#if FFQ_NT_STREAMS & 1
+#define FFQ_SLOAD load_nt
+#else
+#define FFQ_SLOAD load
+#endif
+#if FFQ_NT_STREAMS & 2
+#define FFQ_SSTORE store_nt
+#else
+#define FFQ_SSTORE store
+#endif
+
 namespace ffq {
 
 struct bf16_t { uint16_t bits; };

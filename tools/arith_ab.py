@@ -7,8 +7,8 @@ from fastforward_amd._cabi import FFQLibrary
 from bench import event_time_ms
 dev = "cuda"
 libs = {"current": _native.library()}
-if len(sys.argv) > 1:
-    libs["other"] = FFQLibrary(sys.argv[1])
+for path in sys.argv[1:]:
+    libs[pathlib.Path(path).stem.replace("libffq_", "")] = FFQLibrary(path)
 shape = (14336, 4096)
 n = shape[0] * shape[1]
 ws = [(torch.randn(shape, device=dev) * 0.02).to(torch.bfloat16) for _ in range(6)]
@@ -25,6 +25,7 @@ cases = {
     "W4 group-128 unpack+dequantize (2.5 B/elem)": (2.5, lambda r: ops.unpack_dequantize_int4(packed[r % 6], g4, shape, (1, 128), None, block=128)),
     "add+RMSNorm+quantize (7 B/elem)": (7, lambda r: ops.add_rmsnorm_quantize(ws[r % 6], ws[(r + 1) % 6], gamma, 1e-5, [(s1, o1)])),
     "SiLU*up+quantize (5 B/elem)": (5, lambda r: ops.silu_mul_quantize(ws[r % 6], ws[(r + 1) % 6], [(s1, o1)])),
+    "backward per-channel (6 B/elem)": (6, lambda r: ops.quantize_by_tile_backward(ws[r % 6], ws[(r + 1) % 6], scale, (1, shape[1]), 8.0, None)),
 }
 for rep in range(2):
     for name, (bpe, fn) in cases.items():
