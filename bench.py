@@ -148,6 +148,18 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
         ms = event_time_ms(lambda r: ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.bfloat16), iters=5, reps=4)
         per_shape_random[name] = {"N": n, "K": k, "ms": round(ms, 4), "TOP/s": round(2.0 * tokens * n * k / ms / 1e9, 1)}
         del xq, wq
+    # reference point, not a product path: the vendor library's own int8 GEMM (torch._int_mm -> hipBLASLt, int32 output, no
+    # scale / zero-point epilogue) on the same uniform random codes — what hand-tuned assembly reaches on this chip
+    vendor = {}
+    for name, (n, k, count) in shapes.items():
+        try:
+            xq = torch.randint(-128, 128, (tokens, k), device=device, dtype=torch.int8)
+            wt = torch.randint(-128, 128, (n, k), device=device, dtype=torch.int8).t()
+            ms = event_time_ms(lambda r: torch._int_mm(xq, wt), iters=5, reps=4)
+            vendor[name] = {"ms": round(ms, 4), "TOP/s": round(2.0 * tokens * n * k / ms / 1e9, 1)}
+            del xq, wt
+        except Exception as e:  # noqa: BLE001  (not every build exposes an int8 GEMM)
+            vendor[name] = {"unavailable": f"{type(e).__name__}: {str(e)[:80]}"}
     per_shape, total_ops, total_ms, launches, source = {}, 0.0, 0.0, 0, "uniform random operands (module-graph forward: no per-launch events)"
     if fused is not None:
         fused(batch)  # warm
@@ -209,6 +221,8 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
         "measured_on": source,
         "per_shape": per_shape,
         "per_shape_uniform_random": per_shape_random,
+        "vendor_int8_gemm_same_shapes_uniform_random": vendor,
+        "vendor_note": "torch._int_mm (hipBLASLt's tuned assembly, int32 output, no epilogue) on the same shapes and fill: a reference point for what the chip sustains, never on the product path",
     }
 
 

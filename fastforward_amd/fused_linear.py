@@ -15,6 +15,9 @@ The kernel accepts both calling conventions the dispatcher produces (SURVEY §3.
 
 from __future__ import annotations
 
+import contextlib
+import os
+
 from typing import Any
 
 import torch
@@ -96,6 +99,27 @@ _registration = register("linear", fused_linear_predicate, fused_linear)
 # the GEMM's operand load (ops.linear_wq); weight granularities: per tensor, per output channel, or groups of G input
 # channels per output channel (PerBlock(block_dims=1, block_sizes=G, per_channel_dims=0), G % 64 == 0).
 # ---------------------------------------------------------------------------------------------------------------
+# Which GEMM a weight-only linear takes. Measured on the MI355X at T = 16384 on the Llama-3-8B shapes
+# (tools/wq_time.py, profiles/r02_wq_time.txt): the hand-written kernel 1.15 PFLOP/s (group-128: 1.05), A2 into a bf16
+# tensor + the vendor's hand-tuned bf16 GEMM 1.55 PFLOP/s — the dequantization pass it saves (3 B/elem, 3.7 ms per
+# forward) is worth less than the GEMM gap (51 ms). The dispatcher therefore only claims weight-only linears when asked
+# to: ``with ff.fused_linear.weight_only_kernel(True)`` or FFQ_WEIGHT_ONLY_KERNEL=1; otherwise they run the reference's
+# path (fallback.py:86-112: A2 + F.linear). Both produce the same operands bit for bit.
+_WEIGHT_ONLY_KERNEL = os.environ.get("FFQ_WEIGHT_ONLY_KERNEL", "0") not in ("0", "", "false", "no")
+
+
+@contextlib.contextmanager
+def weight_only_kernel(enabled: bool = True):
+    """Route weight-only quantized linears (plain bf16 input, quantized weight) to the hand-written bf16 x int8-code
+    kernel (``ops.linear_wq``) inside the block."""
+    global _WEIGHT_ONLY_KERNEL
+    previous, _WEIGHT_ONLY_KERNEL = _WEIGHT_ONLY_KERNEL, bool(enabled)
+    try:
+        yield
+    finally:
+        _WEIGHT_ONLY_KERNEL = previous
+
+
 def _weight_group(weight: QuantizedTensor) -> int | None:
     """Input channels sharing one parameter pair within a row ([N, K / group] parameters), or None if not covered."""
     tile = weight.quantization_context.quantization_params.granularity.tile_size(weight.shape)
@@ -108,7 +132,7 @@ def _weight_group(weight: QuantizedTensor) -> int | None:
 
 
 def _supported_weight_only(input: Any, weight: Any, bias: Any = None, **_: Any) -> bool:
-    if isinstance(input, QuantizedTensor) or not isinstance(input, torch.Tensor) or not _static_affine(weight):
+    if not _WEIGHT_ONLY_KERNEL or isinstance(input, QuantizedTensor) or not isinstance(input, torch.Tensor) or not _static_affine(weight):
         return False
     if not _on_backend(input, weight) or weight.dim() != 2 or input.dim() < 1 or input.numel() == 0:
         return False

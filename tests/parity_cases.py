@@ -194,8 +194,12 @@ def check_weight_only_linear(device):
             with ff.estimate_ranges(model, ff.range_setting.running_minmax):
                 model(x)
             wq = lin.weight_quantizer(lin.weight)
-            assert ff.dispatcher.dispatch("linear", input=x, weight=wq, bias=lin.bias) is ff.fused_linear.fused_linear_weight_only, c["name"]
-            y = model(x)
+            assert ff.dispatcher.dispatch("linear", input=x, weight=wq, bias=lin.bias) is None  # opt-in (see fused_linear.py)
+            y_default = model(x)  # the reference's path: A2 + F.linear
+            with ff.fused_linear.weight_only_kernel(True):
+                assert ff.dispatcher.dispatch("linear", input=x, weight=wq, bias=lin.bias) is ff.fused_linear.fused_linear_weight_only, c["name"]
+                y = model(x)
+        torch.testing.assert_close(y_default.detach().cpu().float(), c["y"].float(), rtol=2.0**-7, atol=2e-4)
         assert same_with_nan(lin.weight_quantizer.scale.detach().cpu(), c["w_scale"]), c["name"]
         if c["w_offset"] is not None:
             assert same_with_nan(lin.weight_quantizer.offset.detach().cpu(), c["w_offset"]), c["name"]

@@ -713,9 +713,10 @@ def test_weight_only_linear_refuses_what_it_does_not_cover():
     q = ff.nn.LinearQuantizer(4, granularity=ff.PerBlock(1, 96, 0), quantized_dtype=torch.int8, device=DEV)
     with ff.estimate_ranges(q, ff.range_setting.running_minmax), torch.no_grad():
         wq = q(w)
-    assert ff.dispatcher.dispatch("linear", input=x, weight=wq) is None
-    with ff.strict_quantization(False), torch.no_grad():
-        assert torch.equal(ff.nn.functional.linear(x, wq), torch.nn.functional.linear(x, wq.dequantize()))
+    with ff.fused_linear.weight_only_kernel(True):
+        assert ff.dispatcher.dispatch("linear", input=x, weight=wq) is None
+        with ff.strict_quantization(False), torch.no_grad():
+            assert torch.equal(ff.nn.functional.linear(x, wq), torch.nn.functional.linear(x, wq.dequantize()))
 
 
 # ---- A8 and the grid estimator on strided channels / N-d tiles: HIP by-tile kernels, no device-ATen composite ---------

@@ -89,7 +89,11 @@ def cfg2() -> dict:
         producers = llama.FusedProducersForward(model)
         s = timed_forward(lambda: producers(batch, logits=True))
         out[f"forward_B{b}_S2048"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(b * 2048 / s, 1),
-                                      "forward": "FusedProducersForward (RMSNorm / rotary / SiLU*up / attention as one-pass kernels; linears: module forward)"}
+                                      "forward": "FusedProducersForward (RMSNorm / rotary / SiLU*up / attention as one-pass kernels; linears: module forward = A1 + A2 + the vendor's bf16 GEMM, the default)"}
+        with ff.fused_linear.weight_only_kernel(True):  # the hand-written bf16 x int8-code GEMM (A2 in the operand load) for every decoder linear
+            s = timed_forward(lambda: producers(batch, logits=True))
+        out[f"forward_B{b}_S2048_hand_written_weight_only_gemm"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(b * 2048 / s, 1),
+                                                                   "forward": "same, decoder linears through ops.linear_wq (no vendor GEMM on the quantized path; lm_head stays float)"}
     # whole-model weight quantization: 6.98 G elements, 3 B/elem
     linears = [l for _, l in llama.decoder_linears(model)]
 
@@ -200,7 +204,11 @@ def cfg4() -> dict:
     producers = llama.FusedProducersForward(model)
     s = timed_forward(lambda: producers(batch, logits=True))
     out["forward_B8_S2048"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(8 * 2048 / s, 1),
-                               "forward": "FusedProducersForward (RMSNorm / rotary / SiLU*up / attention as one-pass kernels; linears: module forward)"}
+                               "forward": "FusedProducersForward (RMSNorm / rotary / SiLU*up / attention as one-pass kernels; linears: module forward = A1 + A2 + the vendor's bf16 GEMM, the default)"}
+    with ff.fused_linear.weight_only_kernel(True):
+        s = timed_forward(lambda: producers(batch, logits=True))
+    out["forward_B8_S2048_hand_written_weight_only_gemm"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(8 * 2048 / s, 1),
+                                                            "forward": "same, decoder linears through ops.linear_wq with group-128 parameters dequantized in the operand load"}
     return out
 
 
