@@ -486,6 +486,27 @@ def main() -> None:
                         "ms_per_step": round(mg_elapsed / mg_steps * 1e3, 3),
                         "what": "the reference-shaped module graph (ff.quantize_model + QuantizedLinear.forward through the dispatcher, eager producers): the drop-in path with no harness-level fusion"}
         del mgraph, mg_out
+        # in between: every quantizer still runs its own forward (its own launch, overrides and hooks intact), only the
+        # float producers between the linears are one-pass kernels (llama.FusedProducersForward)
+        producers = llama.FusedProducersForward(model)
+        producers(batch, logits=True)
+        torch.cuda.synchronize()
+        pgraph, pside = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        pside.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(pside), torch.cuda.graph(pgraph, stream=pside):
+            p_out = producers(batch, logits=True)
+        torch.cuda.current_stream().wait_stream(pside)
+        pgraph.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(mg_steps):
+            pgraph.replay()
+        torch.cuda.synchronize()
+        p_elapsed = time.perf_counter() - t1
+        module_graph["producers_fused_quantizers_untouched"] = {
+            "value": round(args.batch * args.seq_len * mg_steps / p_elapsed, 1), "unit": "tokens/s", "ms_per_step": round(p_elapsed / mg_steps * 1e3, 3),
+            "what": "llama.FusedProducersForward: quantizer modules called as they are, RMSNorm / rotary / SiLU*up / attention as one-pass kernels"}
+        del pgraph, p_out
 
     tokens_per_step = args.batch * args.seq_len * world
     result = {

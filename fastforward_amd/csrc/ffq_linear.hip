@@ -1448,6 +1448,12 @@ __global__ __launch_bounds__(256) void rowsum_i8_kernel(const int8_t* __restrict
 
 }  // namespace ffq
 
+namespace ffq {
+// ffq_linear4w.hip: the one-wave-per-SIMD form of the plain GEMM (experiment, FFQ_GEMM_4W=1)
+int linear4w_try(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale, const float* x_offset, const float* w_scale,
+                 int w_per_row, void* out, int64_t M, int64_t N, int64_t K, int32_t* workspace, hipStream_t s);
+}  // namespace ffq
+
 using namespace ffq;
 
 extern "C" size_t ffq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
@@ -1510,6 +1516,10 @@ extern "C" int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int3
   a.debug = debug_bits;
 
   int32_t* ws = static_cast<int32_t*>(workspace);
+  static const int use_4w = getenv("FFQ_GEMM_4W") ? atoi(getenv("FFQ_GEMM_4W")) : 0;
+  if (use_4w && !requant && out_dt == FFQ_BF16 && !w_offset && !bias && !x_per_row &&
+      linear4w_try(xq, wq, w_rowsum, x_scale, x_offset, w_scale, w_per_row, out, M, N, K, ws, s) == 0)
+    return check_launch("w8a8_gemm4w_kernel");
   // the direct-to-LDS kernels compute the weight row sums themselves; they need K % 64 == 0
   static const int force_v1 = getenv("FFQ_GEMM_V1") ? 1 : 0;
   static const int force_nw = getenv("FFQ_GEMM_NW") ? atoi(getenv("FFQ_GEMM_NW")) : 0;

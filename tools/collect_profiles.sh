@@ -5,7 +5,7 @@
 # Raw outputs are summarised in place and deleted (gpurun copies back at most 64 MiB).
 set -u
 export TMPDIR=/tmp
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/profiles
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats -d $OUT/bench_trace -o bench -- python3 bench.py > $OUT/${TAG}_bench_under_rocprof.log 2>&1
