@@ -1294,6 +1294,41 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
     __builtin_amdgcn_s_setprio(0);
   };
   (void)cluster4; (void)issue_piece;
+#if FFQ_X == 8  // two k-steps per phase: 16 MFMAs per cluster, half as many barriers
+  v4i fa2[4], fb2[2];
+  auto read_frags2 = [&](const uint8_t* st, int kk) {  // fragment sets kk and kk + 1
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const v4i*>(st + b_off[j][kk]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const v4i*>(st + a_off[i][kk]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb2[j] = *reinterpret_cast<const v4i*>(st + b_off[j][kk + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa2[i] = *reinterpret_cast<const v4i*>(st + a_off[i][kk + 1]);
+  };
+  auto cluster16 = [&](auto piece) {  // piece(p) after every MFMA pair, p = 0..7
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb2[j], fa2[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(4 + i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+#endif
 
   const int ksuper = a.K / 128;
   int slot = 0;  // slot of the super-step about to be computed
@@ -1323,7 +1358,23 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
         fetch = has_next ? 0 : ks;
         if (has_next) set_sources(nm0, nn0);
       }
-#if FFQ_X >= 5 && FFQ_X <= 7
+#if FFQ_X == 8
+      {
+        const int os8 = slot ^ 1;
+        read_frags2(st, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        cluster16([&](int p8) { issue_piece(fetch, os8, p8); });
+        __builtin_amdgcn_s_barrier();
+        read_frags2(st, 2);
+        if (wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slower group waits before the barrier that opens the faster group's next reads
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        cluster16([](int) {});
+        if (wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the faster group: one segment later
+        __builtin_amdgcn_s_barrier();
+      }
+#elif FFQ_X >= 5 && FFQ_X <= 7
       const int os = slot ^ 1;
       auto none = [] {};
       read_frags(st, 0);

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import weakref
 
 from typing import Any
 
@@ -73,6 +74,35 @@ def _int8_codes(tensor: QuantizedTensor) -> torch.Tensor:
     return ops.quantize_by_tile(raw, one, raw.shape, 8, torch.int8)
 
 
+# A symmetric quantizer carries an offset BUFFER that is all zeros unless its data is one-sided (reference
+# nn/linear_quantizer.py:164-170). Knowing that on the host lets the GEMM skip the weight-offset terms and take its
+# persistent form; the answer is read ONCE per (tensor object, version) — the range setter bumps the version — and never
+# while a hipGraph is being captured (then the offset is simply passed on: same result, the kernel checks it on the device).
+_ZERO_OFFSETS: dict[int, tuple[Any, int, bool | None]] = {}
+
+
+def _known_zero(offset: Any) -> bool:
+    if not isinstance(offset, torch.Tensor):
+        return False
+    hit = _ZERO_OFFSETS.get(id(offset))
+    seen = hit is not None and hit[0]() is offset and hit[1] == offset._version
+    if seen and hit[2] is not None:
+        return hit[2]
+    if offset.is_cuda and torch.cuda.is_current_stream_capturing():
+        return False
+    if len(_ZERO_OFFSETS) > 4096:  # entries of tensors that are gone
+        for key in [k for k, v in _ZERO_OFFSETS.items() if v[0]() is None]:
+            del _ZERO_OFFSETS[key]
+    if not seen:
+        # first sighting of this version: no host read yet. A range estimator re-sets the range on every call (a new
+        # version each time), and a read-back per linear would serialise the sync-free calibration with the host.
+        _ZERO_OFFSETS[id(offset)] = (weakref.ref(offset), offset._version, None)
+        return False
+    zero = not bool(offset.detach().any())  # the version was stable across two calls: read it once
+    _ZERO_OFFSETS[id(offset)] = (weakref.ref(offset), offset._version, zero)
+    return zero
+
+
 def fused_linear(input: QuantizedTensor, weight: QuantizedTensor, bias: Any = None, *, output_quantizer: Any = None, strict_quantization: bool | None = None) -> torch.Tensor:
     if strict_quantization and output_quantizer is None:
         raise QuantizationError("'output_quantizer' must be provided if strict_quantization=True")
@@ -80,10 +110,11 @@ def fused_linear(input: QuantizedTensor, weight: QuantizedTensor, bias: Any = No
     deq = xp.dequantize_dtype or torch.get_default_dtype()
     if isinstance(bias, QuantizedTensor):
         bias = bias.dequantize()
+    w_offset = None if wp.offset is None or _known_zero(wp.offset) else torch.as_tensor(wp.offset, device=weight.device)
     out = ops.linear_w8a8(
         _int8_codes(input), _int8_codes(weight),
         x_scale=torch.as_tensor(xp.scale, device=input.device), x_offset=None if xp.offset is None else torch.as_tensor(xp.offset, device=input.device),
-        w_scale=torch.as_tensor(wp.scale, device=weight.device), w_offset=None if wp.offset is None else torch.as_tensor(wp.offset, device=weight.device),
+        w_scale=torch.as_tensor(wp.scale, device=weight.device), w_offset=w_offset,
         bias=bias, out_dtype=deq,
     )
     return output_quantizer(out) if output_quantizer is not None else out
