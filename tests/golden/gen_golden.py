@@ -661,6 +661,38 @@ def g17_gguf_blocks():
             "q4_0": pack_q4_0_blocks(codes4, scales), "q8_0": pack_q8_0_blocks(codes8, scales)}
 
 
+def g18_linear_large():
+    """A W8A8 QuantizedLinear large enough for the 256 x 256-tile persistent GEMM (2048 tokens, N = 2048, K = 512: 64
+    tiles): the reference's fallback.linear (dequantize, dequantize, F.linear in bf16). Inputs are regenerated from seeds
+    (datagen.make_data); stored are the parameters, row sums of all codes (any flipped code shows) and every 32nd output
+    row with its float64 recomputation."""
+    x = make_data(181, (2, 1024, 512), torch.bfloat16, "normal")
+    w = (make_data(182, (2048, 512), torch.float32, "normal") * 0.05).to(torch.bfloat16)
+    lin = torch.nn.Linear(512, 2048, bias=False).to(torch.bfloat16)
+    with torch.no_grad():
+        lin.weight.copy_(w)
+    model = torch.nn.Sequential(lin)
+    ff.quantize_model(model)
+    lin.weight_quantizer = ff.nn.LinearQuantizer(8, granularity=ff.PerChannel(0))
+    lin.input_quantizer = ff.nn.LinearQuantizer(8, symmetric=False)
+    with ff.strict_quantization(False):
+        with ff.estimate_ranges(model, ff.range_setting.running_minmax):
+            model(x)
+        y = model(x)
+        xq, wq = lin.input_quantizer(x), lin.weight_quantizer(lin.weight)
+    rows = torch.arange(0, 2048, 32)
+    y2 = y.detach().reshape(2048, 2048)
+    y64 = torch.nn.functional.linear(xq.dequantize().double().reshape(2048, 512)[rows], wq.dequantize().double())
+    return {
+        "x_seed": 181, "w_seed": 182, "w_factor": 0.05, "x_shape": [2, 1024, 512], "w_shape": [2048, 512],
+        "x_scale": lin.input_quantizer.scale.detach().clone(), "x_offset": lin.input_quantizer.offset.detach().clone(),
+        "w_scale": lin.weight_quantizer.scale.detach().clone(),
+        "x_code_row_sums": xq.raw_data.reshape(2048, 512).to(torch.int64).sum(1), "w_code_row_sums": wq.raw_data.to(torch.int64).sum(1),
+        "x_code_abs_sum": int(xq.raw_data.to(torch.int64).abs().sum()), "w_code_abs_sum": int(wq.raw_data.to(torch.int64).abs().sum()),
+        "rows": rows, "y_rows": y2[rows].clone(), "y_rows_float64": y64.float(),
+    }
+
+
 def main() -> None:
     torch.set_num_threads(8)
     if len(sys.argv) > 1:  # regenerate only the named fixtures, e.g. `gen_golden.py g10_producers`
@@ -686,6 +718,7 @@ def main() -> None:
     torch.save(g15_weight_only_linear(), HERE / "g15_weight_only_linear.pt")
     torch.save(g16_smoothed_minmax(), HERE / "g16_smoothed_minmax.pt")
     torch.save(g17_gguf_blocks(), HERE / "g17_gguf_blocks.pt")
+    torch.save(g18_linear_large(), HERE / "g18_linear_large.pt")
     for f in sorted(HERE.glob("*.pt")):
         print(f"{f.name}: {f.stat().st_size / 1024:.0f} KiB")
 

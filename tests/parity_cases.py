@@ -210,6 +210,38 @@ def check_weight_only_linear(device):
         torch.testing.assert_close(got, c["y"].float(), rtol=2.0**-7, atol=2e-4, msg=lambda m: f'{c["name"]} vs reference output: {m}')
 
 
+def check_linear_large(device):
+    """Fixture G18: the reference's W8A8 QuantizedLinear at a size the 256 x 256-tile persistent GEMM takes (2048 tokens,
+    N = 2048, K = 512). Parameters and all codes (through their row sums) bit-exact; the output within the reference's own
+    half-precision tolerance of its bf16 eager result and within 2^-7 of the float64 value of the same operands."""
+    from datagen import make_data
+
+    c = golden("g18_linear_large.pt")
+    x = make_data(c["x_seed"], tuple(c["x_shape"]), torch.bfloat16, "normal").to(device)
+    w = (make_data(c["w_seed"], tuple(c["w_shape"]), torch.float32, "normal") * c["w_factor"]).to(torch.bfloat16)
+    lin = torch.nn.Linear(w.shape[1], w.shape[0], bias=False).to(torch.bfloat16)
+    with torch.no_grad():
+        lin.weight.copy_(w)
+    model = torch.nn.Sequential(lin).to(device)
+    ff.quantize_model(model)
+    lin.weight_quantizer = ff.nn.LinearQuantizer(8, granularity=ff.PerChannel(0), quantized_dtype=torch.int8, device=device)
+    lin.input_quantizer = ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=torch.int8, device=device)
+    with torch.no_grad(), ff.strict_quantization(False):
+        with ff.estimate_ranges(model, ff.range_setting.running_minmax):
+            model(x)
+        y = model(x)
+        xq, wq = lin.input_quantizer(x), lin.weight_quantizer(lin.weight)
+    assert same_with_nan(lin.input_quantizer.scale.detach().cpu(), c["x_scale"]) and same_with_nan(lin.input_quantizer.offset.detach().cpu(), c["x_offset"])
+    assert same_with_nan(lin.weight_quantizer.scale.detach().cpu(), c["w_scale"])
+    xc, wc = xq.raw_data.reshape(-1, w.shape[1]).cpu().to(torch.int64), wq.raw_data.cpu().to(torch.int64)
+    assert torch.equal(xc.sum(1), c["x_code_row_sums"]) and int(xc.abs().sum()) == c["x_code_abs_sum"]
+    assert torch.equal(wc.sum(1), c["w_code_row_sums"]) and int(wc.abs().sum()) == c["w_code_abs_sum"]
+    got = y.detach().reshape(-1, w.shape[0]).cpu()[c["rows"]].float()
+    atol, rtol = linear_tolerances(torch.bfloat16)
+    torch.testing.assert_close(got, c["y_rows"].float(), atol=atol, rtol=rtol)
+    torch.testing.assert_close(got, c["y_rows_float64"], atol=2.0**-7, rtol=2.0**-7)
+
+
 def _ulps_bf16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """Distance in bf16 units-in-the-last-place between two bf16 tensors (finite values)."""
     def key(t):

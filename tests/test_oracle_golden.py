@@ -85,3 +85,7 @@ def test_weight_only_linear_matches_the_reference():
 
 def test_smoothed_minmax_trajectories():
     parity_cases.check_smoothed_minmax("cpu")
+
+
+def test_large_linear_fixture():
+    parity_cases.check_linear_large("cpu")

@@ -97,6 +97,10 @@ def test_smoothed_minmax_trajectories():
     parity_cases.check_smoothed_minmax(DEV)
 
 
+def test_large_linear_fixture_takes_the_persistent_gemm():
+    parity_cases.check_linear_large(DEV)
+
+
 def test_freeze_parameters_and_fuse_qdq_weights_on_the_device():
     """SURVEY 8(f) row 1 on the GPU: both ways of folding weight quantizers into the weights (reference
     quantization/freeze.py:74-125, fuse.py:199-242) write exactly A2(A1(w)) into the parameters, in place; afterwards the
