@@ -613,7 +613,10 @@ class FusedProducersForward:
         xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
         if xp.scale.numel() != 1:
             return ff.nn.functional.linear(xq, wq, None, output_quantizer=linear.output_quantizer)
-        return ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, wp.offset, None, out_dtype=torch.bfloat16)
+        # an all-zero offset buffer of a symmetric weight quantizer (learned once per stable version, never during range
+        # estimation or graph capture: fused_linear._known_zero) lets the GEMM take its persistent form
+        w_offset = None if wp.offset is None or ff.fused_linear._known_zero(wp.offset) else wp.offset
+        return ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, None, out_dtype=torch.bfloat16)
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, logits: bool = False) -> torch.Tensor:
