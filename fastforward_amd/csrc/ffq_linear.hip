@@ -1190,9 +1190,32 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
     tm0 = (int)(group * GROUP_M2 + in_group % group_rows) * BM2;
     tn0 = (int)(in_group / group_rows) * BN_OUT;
   };
+#if FFQ_X == 9
+  // prefetch by touch: wave w requests ONE dword of each 128-byte line of rows [64 w, 64 w + 64) of the A tile (w < 4) or
+  // the B tile (w >= 4) of super-step ks + 3 — 8 x 64 = all 512 lines of that super-step — so that its real pieces, issued
+  // two super-steps later, hit L2 (the 19 % that miss today hold up the vmcnt(0) wait of every super-step)
+  const int8_t* touch_src = nullptr;
+  uint8_t* const touch_lds = lds2 + 2 * SLOT_BYTES + wave * 256;
+#endif
   auto set_sources = [&](int tm0, int tn0) {
 #if FFQ_X == 1  // every tile streams the operands of tile (0, 0): all L2 hits (wrong results: cost of the misses)
     tm0 = 0; tn0 = 0;
+#endif
+#if FFQ_X == 9
+    {
+      const int row = (wave & 3) * 64 + lane;
+      if (wave < 4) {
+        int ra = tm0 + row;
+        ra = ra < a.M ? ra : a.M - 1;
+        touch_src = a.xq + (size_t)ra * a.K;
+      } else if constexpr (MLP) {
+        touch_src = ((row & 32) ? a.wq2 : a.wq) + (size_t)(tn0 + (row >> 6) * 32 + (row & 31)) * a.K;
+      } else {
+        int rb = tn0 + row;
+        rb = rb < a.N ? rb : a.N - 1;
+        touch_src = a.wq + (size_t)rb * a.K;
+      }
+    }
 #endif
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1452,7 +1475,13 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the fetched super-step landed (and older epilogue stores)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
+#if FFQ_X == 9
+      // issued AFTER this super-step's wait: it has until the next one (eight intervals) to come back. Not across tile
+      // boundaries (the sources already point at the next tile during the last super-step).
+      cluster([&] { if (ks + 3 < ksuper) __builtin_amdgcn_global_load_lds((gbl_void_t*)(touch_src + (ks + 3) * 128), (lds_void_t*)touch_lds, 4, 0, 0); }, [] {});
+#else
       cluster([] {}, [] {});
+#endif
       __builtin_amdgcn_s_barrier();
 #endif
       slot ^= 1;
@@ -1598,7 +1627,7 @@ extern "C" int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int3
       static const int use_fp = getenv("FFQ_GEMM_FP") ? atoi(getenv("FFQ_GEMM_FP")) : 1;  // persistent tile loop: +4.9 % (A/B on one box)
       const bool fp = fl && use_fp && !w_offset;
       const unsigned grid_fp = grid3 < 256u ? grid3 : 256u;  // persistent: one block per CU
-      const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128;
+      const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128 + (FFQ_X == 9 ? 2048 : 0);
 #define FFQ_GEMM3_FP(T, RQ)                                                                                \
   do {                                                                                                     \
     static uint64_t attr_set_fp = 0;                                                                       \
@@ -1784,7 +1813,7 @@ extern "C" int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, 
   static const int use_fp = getenv("FFQ_GEMM_FP") ? atoi(getenv("FFQ_GEMM_FP")) : 1;  // persistent tile loop: +4.9 % (A/B on one box)
   if (use_fl && use_fp && K % 128 == 0) {
     static uint64_t attr_set_fp = 0;
-    const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128;
+    const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128 + (FFQ_X == 9 ? 2048 : 0);
     if (first_use_on_this_device(&attr_set_fp)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fp_kernel<int8_t, true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fp);
