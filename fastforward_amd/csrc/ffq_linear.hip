@@ -21,6 +21,7 @@
 #include "ffq_affine.h"
 #include "ffq_common.h"
 #include "ffq_vec.h"
+#include "ffq_silu.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -557,9 +558,10 @@ __global__ __launch_bounds__(NW * 64, 2) void w8a8_gemm256_kernel(LinearArgs a) 
 // is formed in registers with exactly the roundings of the three-launch path (GEMM epilogue -> bf16 tensors ->
 // silu_mul_quantize_kernel), goes through ONE block-wide LDS tile [256][128 B] and leaves as full 128-byte lines
 // of int8 codes: a quarter of the bytes of one bf16 projection, instead of two.
-template <bool SAFE>
+// `silu_table`: the LDS table of ffq_silu.h (the persistent kernel fills it once per launch), or nullptr = evaluate silu.
+template <bool SAFE, bool TABLE>
 __device__ __forceinline__ void mlp_epilogue_body(const LinearArgs& a, v16i (&acc)[4][2], int (&rsw)[2], uint8_t* lds2, int wave,
-                                             int lane, int wm, int wn, int m0, int n0) {
+                                             int lane, int wm, int wn, int m0, int n0, const uint16_t* silu_table) {
   constexpr int PITCH = 144;  // 128 B of codes + 16 B pad
   const float sx = a.x_scale[0];
   const float ox = a.x_offset ? rne(a.x_offset[0]) : 0.0f;
@@ -587,22 +589,47 @@ __device__ __forceinline__ void mlp_epilogue_body(const LinearArgs& a, v16i (&ac
       rsg[t] = rs_lds[cb + t];
       rsu[t] = rs_lds[32 + cb + t];
     }
+    // the bf16 tensors the two projections would have written (packed pairs), then bf16(silu(gate)) for all 8 pairs of
+    // this column group: the table reads go out back to back, ONE wave-uniform branch covers the values outside its window
+    uint32_t wg[4][2], ws[4][2];
+    uint32_t bad = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int t = 0; t < 4; t += 2) {
+        const float g0 = (sx * swg[t]) * ((float)acc[i][0][4 * q + t] + ox * rsg[t]);
+        const float g1 = (sx * swg[t + 1]) * ((float)acc[i][0][4 * q + t + 1] + ox * rsg[t + 1]);
+        wg[i][t >> 1] = pack2<bf16_t>(g0, g1);
+#if FFQ_X == 10  // ablation: what the exact expf + IEEE division of silu cost in the MLP-mode launch (-7.5 %)
+        ws[i][t >> 1] = pack2<bf16_t>(g0 * 0.5f, g1 * 0.5f);
+#else
+        if constexpr (TABLE) {
+          ws[i][t >> 1] = silu_pair_lookup(wg[i][t >> 1], silu_table, bad);  // ffq_silu.h
+        } else {                                                             // ATen's silu in fp32, rounded to bf16
+          const uint32_t w = wg[i][t >> 1];
+          ws[i][t >> 1] = pack2<bf16_t>(silu_exact(__builtin_bit_cast(float, w << 16)), silu_exact(__builtin_bit_cast(float, w & 0xFFFF0000u)));
+        }
+#endif
+      }
+    }
+    if constexpr (TABLE) {
+      if (__builtin_expect(silu_any_outside(bad), 0)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) ws[i][h] = silu_pair_patch(wg[i][h], ws[i][h]);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int c[4];
 #pragma unroll
       for (int t = 0; t < 4; t += 2) {
-        float g0 = (sx * swg[t]) * ((float)acc[i][0][4 * q + t] + ox * rsg[t]);
-        float g1 = (sx * swg[t + 1]) * ((float)acc[i][0][4 * q + t + 1] + ox * rsg[t + 1]);
-        float u0 = (sx * swu[t]) * ((float)acc[i][1][4 * q + t] + ox * rsu[t]);
-        float u1 = (sx * swu[t + 1]) * ((float)acc[i][1][4 * q + t + 1] + ox * rsu[t + 1]);
-        uint32_t w = pack2<bf16_t>(g0, g1);  // the bf16 tensors the two projections would have written
-        g0 = __builtin_bit_cast(float, w << 16); g1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
-        w = pack2<bf16_t>(u0, u1);
-        u0 = __builtin_bit_cast(float, w << 16); u1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
-        float a0 = g0 / (1.0f + expf(-g0)), a1 = g1 / (1.0f + expf(-g1));  // ATen's silu in fp32
-        w = pack2<bf16_t>(a0, a1);
-        a0 = __builtin_bit_cast(float, w << 16); a1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
+        uint32_t w = pack2<bf16_t>((sx * swu[t]) * ((float)acc[i][1][4 * q + t] + ox * rsu[t]),
+                                   (sx * swu[t + 1]) * ((float)acc[i][1][4 * q + t + 1] + ox * rsu[t + 1]));
+        const float u0 = __builtin_bit_cast(float, w << 16), u1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
+        w = ws[i][t >> 1];
+        const float a0 = __builtin_bit_cast(float, w << 16), a1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
         float z0 = a0 * u0, z1 = a1 * u1;
         w = pack2<bf16_t>(z0, z1);
         z0 = __builtin_bit_cast(float, w << 16); z1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
@@ -630,11 +657,12 @@ __device__ __forceinline__ void mlp_epilogue_body(const LinearArgs& a, v16i (&ac
   }
 }
 
+template <bool TABLE = false>
 __device__ __forceinline__ void mlp_epilogue(const LinearArgs& a, v16i (&acc)[4][2], int (&rsw)[2], uint8_t* lds2, int wave,
-                                             int lane, int wm, int wn, int m0, int n0) {
+                                             int lane, int wm, int wn, int m0, int n0, const uint16_t* silu_table = nullptr) {
   const float as = __builtin_fabsf(a.out_scale[0]);
-  if (as > 0x1p-40f && as < 0x1p40f) mlp_epilogue_body<true>(a, acc, rsw, lds2, wave, lane, wm, wn, m0, n0);
-  else mlp_epilogue_body<false>(a, acc, rsw, lds2, wave, lane, wm, wn, m0, n0);
+  if (as > 0x1p-40f && as < 0x1p40f) mlp_epilogue_body<true, TABLE>(a, acc, rsw, lds2, wave, lane, wm, wn, m0, n0, silu_table);
+  else mlp_epilogue_body<false, TABLE>(a, acc, rsw, lds2, wave, lane, wm, wn, m0, n0, silu_table);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1177,6 +1205,10 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
   const uint32_t xcd_count = tq + (xcd < tr ? 1u : 0u);
   const int my_tiles = j_in_xcd < xcd_count ? (int)((xcd_count - j_in_xcd + blocks_in_xcd - 1) / blocks_in_xcd) : 0;
   if (my_tiles == 0) return;
+  // MLP mode: silu over bf16 as a 16 KiB table behind the two operand slots, filled once per launch (ffq_silu.h);
+  // the barriers of the first tile's K-loop publish it long before the first epilogue reads it
+  uint16_t* const silu_table = reinterpret_cast<uint16_t*>(lds2 + 2 * SLOT_BYTES);
+  if constexpr (MLP) silu_table_fill(silu_table, (uint32_t)tid, 512u);
 
   const int d_row = lane >> 3;
   const int8_t* a_src[4];
@@ -1190,32 +1222,9 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
     tm0 = (int)(group * GROUP_M2 + in_group % group_rows) * BM2;
     tn0 = (int)(in_group / group_rows) * BN_OUT;
   };
-#if FFQ_X == 9
-  // prefetch by touch: wave w requests ONE dword of each 128-byte line of rows [64 w, 64 w + 64) of the A tile (w < 4) or
-  // the B tile (w >= 4) of super-step ks + 3 — 8 x 64 = all 512 lines of that super-step — so that its real pieces, issued
-  // two super-steps later, hit L2 (the 19 % that miss today hold up the vmcnt(0) wait of every super-step)
-  const int8_t* touch_src = nullptr;
-  uint8_t* const touch_lds = lds2 + 2 * SLOT_BYTES + wave * 256;
-#endif
   auto set_sources = [&](int tm0, int tn0) {
 #if FFQ_X == 1  // every tile streams the operands of tile (0, 0): all L2 hits (wrong results: cost of the misses)
     tm0 = 0; tn0 = 0;
-#endif
-#if FFQ_X == 9
-    {
-      const int row = (wave & 3) * 64 + lane;
-      if (wave < 4) {
-        int ra = tm0 + row;
-        ra = ra < a.M ? ra : a.M - 1;
-        touch_src = a.xq + (size_t)ra * a.K;
-      } else if constexpr (MLP) {
-        touch_src = ((row & 32) ? a.wq2 : a.wq) + (size_t)(tn0 + (row >> 6) * 32 + (row & 31)) * a.K;
-      } else {
-        int rb = tn0 + row;
-        rb = rb < a.N ? rb : a.N - 1;
-        touch_src = a.wq + (size_t)rb * a.K;
-      }
-    }
 #endif
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1475,13 +1484,7 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the fetched super-step landed (and older epilogue stores)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-#if FFQ_X == 9
-      // issued AFTER this super-step's wait: it has until the next one (eight intervals) to come back. Not across tile
-      // boundaries (the sources already point at the next tile during the last super-step).
-      cluster([&] { if (ks + 3 < ksuper) __builtin_amdgcn_global_load_lds((gbl_void_t*)(touch_src + (ks + 3) * 128), (lds_void_t*)touch_lds, 4, 0, 0); }, [] {});
-#else
       cluster([] {}, [] {});
-#endif
       __builtin_amdgcn_s_barrier();
 #endif
       slot ^= 1;
@@ -1496,7 +1499,7 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
         rsw[0] = a.rowsum_w[n0 + wn * 32 + (lane & 31)];
         rsw[1] = a.rowsum_w2[n0 + wn * 32 + (lane & 31)];
       }
-      mlp_epilogue(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0);
+      mlp_epilogue<true>(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table);
     } else {
       gemm256_epilogue_slabs<TOut, REQUANT>(a, acc, scratch, wave, lane, wm, wn, m0, n0);
     }
@@ -1627,7 +1630,7 @@ extern "C" int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int3
       static const int use_fp = getenv("FFQ_GEMM_FP") ? atoi(getenv("FFQ_GEMM_FP")) : 1;  // persistent tile loop: +4.9 % (A/B on one box)
       const bool fp = fl && use_fp && !w_offset;
       const unsigned grid_fp = grid3 < 256u ? grid3 : 256u;  // persistent: one block per CU
-      const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128 + (FFQ_X == 9 ? 2048 : 0);
+      const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128;
 #define FFQ_GEMM3_FP(T, RQ)                                                                                \
   do {                                                                                                     \
     static uint64_t attr_set_fp = 0;                                                                       \
@@ -1813,7 +1816,7 @@ extern "C" int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, 
   static const int use_fp = getenv("FFQ_GEMM_FP") ? atoi(getenv("FFQ_GEMM_FP")) : 1;  // persistent tile loop: +4.9 % (A/B on one box)
   if (use_fl && use_fp && K % 128 == 0) {
     static uint64_t attr_set_fp = 0;
-    const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128 + (FFQ_X == 9 ? 2048 : 0);
+    const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128 + kSiluBytes;  // two operand slots + the silu table
     if (first_use_on_this_device(&attr_set_fp)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fp_kernel<int8_t, true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fp);

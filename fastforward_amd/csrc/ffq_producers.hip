@@ -16,9 +16,11 @@
 #endif
 #include "ffq_affine.h"
 #include "ffq_common.h"
+#include "ffq_silu.h"
 #include "ffq_vec.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace ffq {
 
@@ -205,6 +207,60 @@ __global__ __launch_bounds__(kBlock) void silu_mul_quantize_kernel(const bf16_t*
   fan_store(f, p, z, (size_t)c * 16);
 }
 
+// P2 for large tensors: silu through the 16 KiB LDS table of ffq_silu.h (a function of a bf16 argument has 65536 values;
+// the exact expf + IEEE division made the kernel above VALU-bound at half the HBM rate). 512 threads fill the table with
+// silu_exact (16 entries each), then walk the tensor grid-stride with the next chunk's loads in flight.
+constexpr int kSiluBlock = 512;
+__global__ __launch_bounds__(kSiluBlock) void silu_mul_quantize_table_kernel(const bf16_t* __restrict__ gate,
+                                                                             const bf16_t* __restrict__ up,
+                                                                             bf16_t* __restrict__ product_out, FanOut f,
+                                                                             uint32_t nchunks) {
+  __shared__ uint16_t table[kSiluEntries];
+  const uint32_t stride = gridDim.x * (uint32_t)kSiluBlock;
+  uint32_t c = blockIdx.x * (uint32_t)kSiluBlock + threadIdx.x;
+  Chunk<bf16_t, 16> g, u;
+  if (c < nchunks) {
+    g.load(gate + (size_t)c * 16);
+    u.load(up + (size_t)c * 16);
+  }
+  silu_table_fill(table, threadIdx.x, kSiluBlock);
+  const FanParams p = load_fan(f);
+  __syncthreads();
+  while (c < nchunks) {
+    const uint32_t cn = c + stride;
+    Chunk<bf16_t, 16> gn, un;   // a ring of two chunks or non-temporal loads: no faster (A/B on one box)
+    if (cn < nchunks) {
+      gn.load(gate + (size_t)cn * 16);
+      un.load(up + (size_t)cn * 16);
+    }
+    uint32_t a[8];              // F.silu rounds to bf16
+    uint32_t bad = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = silu_pair_lookup(g.w[j], table, bad);
+    if (__builtin_expect(silu_any_outside(bad), 0)) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = silu_pair_patch(g.w[j], a[j]);
+    }
+    float z[16];
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const uint32_t w = a[i >> 1];
+      z[i] = __builtin_bit_cast(float, w << 16) * u.get(i);
+      z[i + 1] = __builtin_bit_cast(float, w & 0xFFFF0000u) * u.get(i + 1);
+      bf16_round2(z[i], z[i + 1]);  // the product rounds again
+    }
+    if (product_out) {
+      Chunk<bf16_t, 16> zc;
+      zc.pack(z);
+      zc.store(product_out + (size_t)c * 16);
+    }
+    fan_store(f, p, z, (size_t)c * 16);
+    g = gn;
+    u = un;
+    c = cn;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // P3: rotary embedding in place on the q/k projections as they leave the GEMM ([tokens, heads * D]):
 //     out = bf16(bf16(q * cos) + bf16(rotate_half(q) * sin))          (attention.py:20-41)
@@ -324,6 +380,11 @@ extern "C" int ffq_silu_mul_quantize(const void* gate, const void* up, int dt, i
   if (!aligned16(gate) || !aligned16(up) || (product_out && !aligned16(product_out)))
     return fail(FFQ_ERR_ARG, "buffers must be 16-byte aligned");
   const uint32_t nchunks = (uint32_t)(numel / 16);
+  if (nchunks >= 8u * kSiluBlock * 256u) {  // >= 4 chunks per thread of the two-blocks-per-CU grid: the table pays
+    silu_mul_quantize_table_kernel<<<512, kSiluBlock, 0, s>>>(
+        static_cast<const bf16_t*>(gate), static_cast<const bf16_t*>(up), static_cast<bf16_t*>(product_out), f, nchunks);
+    return check_launch("silu_mul_quantize_table_kernel");
+  }
   silu_mul_quantize_kernel<<<(nchunks + kBlock - 1) / kBlock, kBlock, 0, s>>>(
       static_cast<const bf16_t*>(gate), static_cast<const bf16_t*>(up), static_cast<bf16_t*>(product_out), f, nchunks);
   return check_launch("silu_mul_quantize_kernel");

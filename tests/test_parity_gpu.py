@@ -662,6 +662,51 @@ def test_fused_gate_up_at_llama_size_and_in_the_forward():
     assert ops.mlp_gate_up_w8a8(xq[:, :192], gq[:, :192], uq[:, :192], sx, ox, sg, su, so, oo, 8) is None  # K < 256: not covered
 
 
+def test_silu_table_equals_aten_on_every_bf16_pattern():
+    """csrc/ffq_silu.h: silu of a bf16 tensor is a 65536-valued function; the large-tensor kernel reads it from an LDS table it
+    fills itself (2^-24 <= |x| < 2^8), x / 2 below the window and the exact expression above it. All 65536 patterns (incl.
+    denormals, +-0, +-Inf, NaNs) against ATen's silu on the device, through the kernel that takes the table path."""
+    patterns = torch.arange(-32768, 32768, dtype=torch.int16).view(torch.bfloat16)
+    gate = patterns.repeat(512).to(DEV)  # 33.5 M elements: above the table kernel's threshold
+    s, o = torch.tensor([0.05], device=DEV), torch.tensor([-7.0], device=DEV)
+    for up in (torch.ones_like(gate), torch.randn(gate.shape, device=DEV).to(torch.bfloat16)):
+        product, codes = ops.silu_mul_quantize(gate, up, [(s, o)], want_product=True)
+        ref = torch.nn.functional.silu(gate) * up
+        nan = ref.isnan()
+        assert torch.equal(product.isnan(), nan)
+        assert torch.equal(product[~nan].view(torch.int16), ref[~nan].view(torch.int16))
+        assert torch.equal(codes[0], ops.quantize_by_tile(product, s, product.shape, 8, torch.int8, o))
+    # the small-tensor kernel (exact expression per element) on the same patterns
+    once = gate[:65536].contiguous()
+    small, _ = ops.silu_mul_quantize(once, torch.ones_like(once), [(s, o)], want_product=True)
+    ref = torch.nn.functional.silu(once)
+    assert torch.equal(small.isnan(), ref.isnan())
+    assert torch.equal(small[~ref.isnan()].view(torch.int16), ref[~ref.isnan()].view(torch.int16))
+
+
+def test_fused_gate_up_silu_table_window_and_fallbacks():
+    """MLP-mode GEMM: per-channel gate scales spread over 2^-44 .. 2^11 push gate_proj's bf16 output below, inside and above
+    the window of the silu table of the persistent kernel; the three-launch path evaluates silu exactly per element."""
+    gen = torch.Generator().manual_seed(77)
+    m, n, k = 2048, 1024, 256
+    xq = torch.randint(-128, 128, (m, k), generator=gen, dtype=torch.int8).to(DEV)
+    gq = torch.randint(-128, 128, (n, k), generator=gen, dtype=torch.int8).to(DEV)
+    uq = torch.randint(-128, 128, (n, k), generator=gen, dtype=torch.int8).to(DEV)
+    sx, ox = torch.tensor([1.0], device=DEV), torch.tensor([2.0], device=DEV)
+    sg = (torch.exp2(torch.arange(n) % 56 - 44.0) * (1 + torch.rand(n, generator=gen))).to(DEV)
+    su = (torch.rand(n, generator=gen) * 2e-5 + 1e-5).to(DEV)
+    so, oo = torch.tensor([0.03], device=DEV), torch.tensor([1.0], device=DEV)
+    fused = ops.mlp_gate_up_w8a8(xq, gq, uq, sx, ox, sg, su, so, oo, 8)
+    gate = ops.linear_w8a8(xq, gq, sx, ox, sg, None, out_dtype=torch.bfloat16)
+    up = ops.linear_w8a8(xq, uq, sx, ox, su, None, out_dtype=torch.bfloat16)
+    mag = gate.float().abs()
+    assert bool((mag < 2.0**-24).any()) and bool((mag >= 256).any()) and bool(((mag > 1e-3) & (mag < 10)).any())
+    product, (want,) = ops.silu_mul_quantize(gate, up, [(so, oo)], 8, want_product=True)
+    assert torch.equal(product, torch.nn.functional.silu(gate) * up)
+    assert fused is not None and torch.equal(fused, want), f"{int((fused != want).sum())} of {want.numel()} codes differ"
+    assert float(want.float().std()) > 1
+
+
 # ---- weight-only linear (row *J: quantized weight x plain bf16 input, fallback.py:86-112) ---------------------------
 def test_weight_only_linear_fixture_from_the_reference():
     parity_cases.check_weight_only_linear(DEV)

@@ -25,4 +25,14 @@ for name, n, k, cnt in (("qo", 4096, 4096, 2), ("kv", 1024, 4096, 2), ("gateup",
     ms = event_time_ms(lambda r: ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.bfloat16), iters=5, reps=4)
     print(f"{name:7s} N={n:5d} K={k:5d} {ms:.4f} ms {2*T*n*k/ms/1e9:8.1f} TOP/s")
     tot_ops += cnt * 2 * T * n * k; tot_ms += cnt * ms
+# gate+up with the SiLU*up + quantize epilogue (one launch); realistic magnitudes so that silu sees ordinary values
+n, k = 14336, 4096
+xq = torch.randint(-128, 128, (T, k), device=dev, dtype=torch.int8)
+gq = torch.randint(-128, 128, (n, k), device=dev, dtype=torch.int8)
+uq = torch.randint(-128, 128, (n, k), device=dev, dtype=torch.int8)
+sx, ox = torch.tensor([0.02], device=dev), torch.tensor([4.0], device=dev)
+sg = torch.rand(n, device=dev) * 0.00002 + 0.00002
+so, oo = torch.tensor([0.03], device=dev), torch.tensor([-3.0], device=dev)
+ms = event_time_ms(lambda r: ops.mlp_gate_up_w8a8(xq, gq, uq, sx, ox, sg, sg, so, oo, 8), iters=5, reps=4)
+print(f"mlp     N={2*n:5d} K={k:5d} {ms:.4f} ms {4*T*n*k/ms/1e9:8.1f} TOP/s")
 print(f"layer mix: {tot_ops/tot_ms/1e9:.1f} TOP/s  ({tot_ms:.3f} ms per layer)")
