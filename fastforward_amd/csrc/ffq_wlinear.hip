@@ -525,7 +525,8 @@ __global__ __launch_bounds__(512, 2) void wq_bf16_gemm256_kernel(WLinearArgs a) 
         const int row = c / SEGS, seg = c % SEGS;
         const int mm = wave_m0 + i * 32 + row;
         const u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * PITCH + seg * 16);
-        if (mm < a.M) *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * a.N + wave_n0) * sizeof(TOut) + seg * 16) = v;
+        // non-temporal, as in ffq_linear.hip: the output must not push the operand panels out of L2
+        if (mm < a.M) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * a.N + wave_n0) * sizeof(TOut) + seg * 16));
       }
     } else {  // ragged right edge / unaligned rows: element stores (correctness path)
       for (int c = lane; c < 32 * 64; c += 64) {
