@@ -5,12 +5,6 @@ cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 mkdir -p gpurun_out/step_trace
 rocprofv3 --kernel-trace --stats -d gpurun_out/step_trace -o step -- python3 bench.py --steps 40 --warmup 3 --calib-seqs 8 --no-side-measurements > gpurun_out/step_trace/bench.json 2> gpurun_out/step_trace/err.log
 tail -1 gpurun_out/step_trace/bench.json | cut -c1-200
-python3 - <<'PY'
-import csv, glob, collections
-f = glob.glob("gpurun_out/step_trace/**/*kernel_stats.csv", recursive=True)
-rows = list(csv.DictReader(open(f[0])))
-tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"total kernel time {tot/1e6:.1f} ms")
-for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:28]:
-    print(f'{r["Name"][:90]:90s} {int(r["Calls"]):7d} {float(r["TotalDurationNs"])/1e6:9.2f} ms {float(r["AverageNs"])/1e3:9.1f} us {100*float(r["TotalDurationNs"])/tot:5.1f} %')
-PY
+python3 tools/rocprof_summary.py gpurun_out/step_trace/step_results.db gpurun_out/step_trace/forward_step_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 40 --warmup 3 --calib-seqs 8 --no-side-measurements (the forward dominates: 40 timed steps)"
+rm -f gpurun_out/step_trace/step_results.db
+head -24 gpurun_out/step_trace/forward_step_kernel_stats.md | cut -c1-160
