@@ -73,6 +73,27 @@ def test_plain_gemm_equals_integer_ground_truth_at_full_size(n, k):
         del acc, v, y
 
 
+@pytest.mark.parametrize("m,n,k", [(4099, 2048, 512), (2050, 2304, 256), (4100, 1032, 1024), (16383, 1096, 384), (2304, 4104, 640)], ids=lambda v: str(v))
+def test_persistent_gemm_ragged_edges_bf16(m, n, k):
+    """The persistent kernel's half-precision epilogue on shapes whose last row tile / last column tile / last wave are cut
+    (whole-line non-temporal stores through the LDS slab where a wave's 64 columns are inside, scalar stores where not, row
+    predicates): every output equals the fp32 epilogue restated on the exact accumulator."""
+    g = torch.Generator(device=DEV).manual_seed(m + 3 * n + k)
+    xq = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+    wq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    sx, ox = torch.tensor([0.021], device=DEV), torch.tensor([-6.6], device=DEV)
+    sw = torch.rand(n, device=DEV, generator=g) * 1e-3 + 2e-4
+    got = ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.bfloat16)
+    acc = exact_accumulators(xq, wq.double(), slice(0, m))
+    rsw = wq.sum(dim=1, dtype=torch.int64)
+    want = ((sx * sw)[None, :] * (acc.float() + torch.round(ox) * rsw.float()[None, :])).to(torch.bfloat16)
+    assert got.shape == (m, n) and torch.equal(got, want), f"{int((got != want).sum())} of {want.numel()} outputs differ"
+    # same launch geometry, fp32 and fp16 outputs
+    assert torch.equal(ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.float32), (sx * sw)[None, :] * (acc.float() + torch.round(ox) * rsw.float()[None, :]))
+    assert torch.equal(ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.float16),
+                       ((sx * sw)[None, :] * (acc.float() + torch.round(ox) * rsw.float()[None, :])).to(torch.float16))
+
+
 @pytest.mark.parametrize("n,k", [(14336, 4096), (28672, 8192)], ids=lambda v: str(v))
 def test_mlp_mode_equals_integer_ground_truth_at_full_size(n, k):
     """gate_proj + up_proj + SiLU*up + quantize in one launch at T = 16384 (8B and 70B): the int8 codes equal
