@@ -1530,6 +1530,391 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// "fq": the persistent kernel above on v_mfma_i32_16x16x64_i8. Same 256 x 256 x 128 super-steps, same LDS image, swizzle,
+// LDS-DMA stream, ping-pong phases, barriers and waits; the matrix instruction differs. Two 16x16x64 do the work of one
+// 32x32x32 from the same operand registers in the same 32 cycles, and the chip runs them faster: a timing-only build of the
+// kernel above with its MFMAs swapped one for two measured +5 % on every shape (power: the chip is power-limited on this
+// loop; `profiles/r01_mfma_power_probe.txt` had the bare instruction at +2-3 %).
+//   * wave tile 128 x 64 = 8 x 4 accumulator tiles of 16 x 16 (4 registers each, 128 in all, as before);
+//   * fragments: lane (r = lane % 16, g = lane / 16) holds bytes [16 g, 16 g + 16) of row r of a 64-byte k-chunk — one
+//     ds_read_b128 at slot (4 kq + g) ^ swizzle(row); the existing swizzle keeps those reads conflict-free;
+//   * a phase = one k-chunk (kq = phase / 2) x one half of the rows (mi in [4 (phase % 2), +4)): even phases read the 4
+//     weight fragments of the chunk and 4 activation fragments, odd phases the other 4 activation fragments; 16 MFMAs each;
+//   * accumulator layout (operands swapped as before, so a lane owns ONE output row): tile (mi, nj), register t:
+//     row m = 16 mi + lane % 16, column n = 16 nj + 4 (lane / 16) + t.
+// -------------------------------------------------------------------------------------------------
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// Epilogue of the plain mode for that layout: the slab scheme of gemm256_epilogue_slabs (32 rows x 64 columns per wave and
+// round, whole 128-byte lines out with the non-temporal hint), two row tiles per slab.
+template <typename TOut, bool REQUANT>
+__device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4i32 (&acc)[8][4], uint8_t* scratch, int wave, int lane,
+                                                         int wm, int wn, int m0, int n0) {
+  TOut* out = static_cast<TOut*>(a.out);
+  float oscale = 1.0f, ooff = 0.0f;
+  if constexpr (REQUANT) {
+    oscale = a.out_scale[0];
+    ooff = a.out_offset ? rne(a.out_offset[0]) : 0.0f;
+  }
+  constexpr int ROW_BYTES = 144;
+  constexpr int WAVE_BYTES = 32 * ROW_BYTES + 3 * 64 * 4;
+  uint8_t* region = scratch + wave * WAVE_BYTES;
+  float* colp = reinterpret_cast<float*>(region + 32 * ROW_BYTES);  // [3][64]: weight scale, weight row sum, bias
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int wave_n0 = n0 + wn * 64;
+  const int wave_m0 = m0 + wm * 128;
+  const bool lds_path = sizeof(TOut) == 2 && (a.N & 7) == 0 && wave_n0 + 64 <= a.N;
+  {
+    int n = wave_n0 + lane;
+    n = n < a.N ? n : a.N - 1;
+    colp[lane] = a.w_scale[a.w_per_row ? n : 0];
+    colp[64 + lane] = a.rowsum_w ? (float)a.rowsum_w[n] : 0.0f;
+    colp[128 + lane] = a.bias ? (float)load_any(a.bias, a.bias_dt, n) : 0.0f;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private: only this wave's own writes
+  // every global load of the epilogue BEFORE its first store (see gemm256_epilogue_slabs)
+  float sx8[8], ox8[8];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    int m = wave_m0 + mi * 16 + r16;
+    m = m < a.M ? m : a.M - 1;
+    sx8[mi] = a.x_scale[a.x_per_row ? m : 0];
+    ox8[mi] = a.x_offset ? rne(a.x_offset[a.x_per_row ? m : 0]) : 0.0f;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) asm volatile("" : "+v"(sx8[mi]), "+v"(ox8[mi]));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int mi = 2 * i + hh;
+      const int m = wave_m0 + mi * 16 + r16;
+      const bool m_ok = m < a.M;
+      const float sx = sx8[mi], ox = ox8[mi];
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) {
+        const int nb = nj * 16 + 4 * g4;
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 sw4 = *reinterpret_cast<const f32x4*>(colp + nb);
+        const f32x4 rs4 = *reinterpret_cast<const f32x4*>(colp + 64 + nb);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(colp + 128 + nb);
+        float y[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float v = (float)acc[mi][nj][t] + ox * rs4[t];
+          float r = (sx * sw4[t]) * v;
+          if (a.bias) r = r + b4[t];
+          if constexpr (REQUANT) {
+            r = bf16_bits_to_f32(f32_to_bf16_bits(r));
+            r = clamp_nan(rne(r / oscale - ooff), a.out_lo, a.out_hi);
+          }
+          y[t] = r;
+        }
+        if constexpr (sizeof(TOut) == 2) {
+          if (lds_path) {
+            u32x2 pk;
+            pk.x = pack2<TOut>(y[0], y[1]);
+            pk.y = pack2<TOut>(y[2], y[3]);
+            *reinterpret_cast<u32x2*>(region + (16 * hh + r16) * ROW_BYTES + nb * 2) = pk;
+            continue;
+          }
+        }
+        if (m_ok) {
+          const size_t at = (size_t)m * a.N + wave_n0 + nb;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (wave_n0 + nb + t < a.N) store_out<TOut>(out + at + t, y[t]);
+        }
+      }
+    }
+    if (lds_path) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = lane + 64 * t;
+        const int row = c >> 3, seg = c & 7;
+        const int mm = wave_m0 + i * 32 + row;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * ROW_BYTES + seg * 16);
+        if (mm < a.M && !(a.debug & 1))
+          FFQ_EPI_STORE(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * a.N + wave_n0) * 2 + seg * 16));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is re-written by the next i
+    }
+  }
+}
+
+// Epilogue of the MLP mode for that layout (see mlp_epilogue_body): column tiles nj = 0, 1 hold gate_proj and nj + 2 up_proj
+// of the same 16 output columns; silu through the LDS table of ffq_silu.h.
+template <bool SAFE>
+__device__ __forceinline__ void mlp_epilogue16_body(const LinearArgs& a, v4i32 (&acc)[8][4], int (&rsw)[2], uint8_t* lds2, int wave,
+                                                    int lane, int wm, int wn, int m0, int n0, const uint16_t* silu_table) {
+  constexpr int PITCH = 144;  // 128 B of codes + 16 B pad
+  const float sx = a.x_scale[0];
+  const float ox = a.x_offset ? rne(a.x_offset[0]) : 0.0f;
+  const float so = a.out_scale[0];
+  const float oo = a.out_offset ? rne(a.out_offset[0]) : 0.0f;
+  const Divider<1> div(so);
+  __syncthreads();  // every wave is done with the operand ring
+  float* rs_lds = reinterpret_cast<float*>(lds2 + 256 * PITCH) + wave * 64;
+  if (lane < 32) {
+    rs_lds[lane] = (float)rsw[0];
+    rs_lds[32 + lane] = (float)rsw[1];
+  }
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int col0 = n0 + wn * 32;  // this wave's 32 output columns
+  const int lo = (int)a.out_lo, hi = (int)a.out_hi;
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj) {
+    const int cb = 16 * nj + 4 * g4;  // this lane's 4 columns: col0 + cb + (0..3)
+    float swg[4], swu[4], rsg[4], rsu[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = col0 + cb + t;  // N % 128 == 0: always inside
+      swg[t] = a.w_scale[n];
+      swu[t] = a.w_scale2[n];
+      rsg[t] = rs_lds[cb + t];
+      rsu[t] = rs_lds[32 + cb + t];
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      // bf16(silu(bf16 gate)) of the 8 pairs of four row tiles: the table reads back to back, one branch for the window
+      uint32_t wg[4][2], ws[4][2];
+      uint32_t bad = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int mi = 4 * half + q;
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+          const float g0 = (sx * swg[t]) * ((float)acc[mi][nj][t] + ox * rsg[t]);
+          const float g1 = (sx * swg[t + 1]) * ((float)acc[mi][nj][t + 1] + ox * rsg[t + 1]);
+          wg[q][t >> 1] = pack2<bf16_t>(g0, g1);
+          ws[q][t >> 1] = silu_pair_lookup(wg[q][t >> 1], silu_table, bad);
+        }
+      }
+      if (__builtin_expect(silu_any_outside(bad), 0)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) ws[q][h2] = silu_pair_patch(wg[q][h2], ws[q][h2]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int mi = 4 * half + q;
+        int c[4];
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+          uint32_t w = pack2<bf16_t>((sx * swu[t]) * ((float)acc[mi][nj + 2][t] + ox * rsu[t]),
+                                     (sx * swu[t + 1]) * ((float)acc[mi][nj + 2][t + 1] + ox * rsu[t + 1]));
+          const float u0 = __builtin_bit_cast(float, w << 16), u1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
+          w = ws[q][t >> 1];
+          const float a0 = __builtin_bit_cast(float, w << 16), a1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
+          float z0 = a0 * u0, z1 = a1 * u1;
+          w = pack2<bf16_t>(z0, z1);
+          z0 = __builtin_bit_cast(float, w << 16); z1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
+          const float r0 = SAFE ? rne(div.fast(z0) - oo) : rne(z0 / so - oo);
+          const float r1 = SAFE ? rne(div.fast(z1) - oo) : rne(z1 / so - oo);
+          const int c0 = (int)r0, c1 = (int)r1;  // v_cvt_i32_f32: NaN -> 0, the int8 container's value
+          c[t] = c0 < lo ? lo : (c0 > hi ? hi : c0);
+          c[t + 1] = c1 < lo ? lo : (c1 > hi ? hi : c1);
+        }
+        const int row = wm * 128 + mi * 16 + r16;
+        *reinterpret_cast<uint32_t*>(lds2 + row * PITCH + wn * 32 + cb) = pack_bytes(c[0], c[1], c[2], c[3]);
+      }
+    }
+  }
+  __syncthreads();
+  int8_t* out = static_cast<int8_t*>(a.out);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = wave * 32 + t * 8 + (lane >> 3), seg = lane & 7;
+    const int m = m0 + row;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(lds2 + row * PITCH + seg * 16);
+    if (m < a.M && !(a.debug & 1)) FFQ_EPI_STORE(v, reinterpret_cast<u32x4*>(out + (size_t)m * a.N + n0 + seg * 16));
+  }
+}
+
+template <typename TOut, bool REQUANT, bool MLP>
+__global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, int total_tiles) {
+  constexpr int BN2 = 256, WAVES_N = 4;
+  constexpr int BN_OUT = MLP ? 128 : 256;
+  constexpr int SLOT_BYTES = (BM2 + BN2) * 128;
+  constexpr int B_IMAGE = BM2 * 128;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds2[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // tile walk of the fp kernel: XCD x owns a contiguous range of the grouped tile order, its blocks walk it round-robin
+  const uint32_t nblk = gridDim.x;
+  const uint32_t xcd = blockIdx.x & 7u, j_in_xcd = blockIdx.x >> 3;
+  const uint32_t blocks_in_xcd = (nblk >> 3) + (xcd < (nblk & 7u) ? 1u : 0u);
+  const uint32_t tq = (uint32_t)total_tiles >> 3, tr = (uint32_t)total_tiles & 7u;
+  const uint32_t xcd_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const uint32_t xcd_count = tq + (xcd < tr ? 1u : 0u);
+  const int my_tiles = j_in_xcd < xcd_count ? (int)((xcd_count - j_in_xcd + blocks_in_xcd - 1) / blocks_in_xcd) : 0;
+  if (my_tiles == 0) return;
+  uint16_t* const silu_table = reinterpret_cast<uint16_t*>(lds2 + 2 * SLOT_BYTES);
+  if constexpr (MLP) silu_table_fill(silu_table, (uint32_t)tid, 512u);
+
+  const int d_row = lane >> 3;
+  const int8_t* a_src[4];
+  const int8_t* b_src[4];
+  int m0 = 0, n0 = 0;
+  auto tile_origin = [&](int it, int& tm0, int& tn0) {
+    const uint32_t tile_id = xcd_first + j_in_xcd + (uint32_t)it * blocks_in_xcd;
+    const uint32_t per_group = GROUP_M2 * (uint32_t)a.tiles_n;
+    const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
+    const uint32_t group_rows = min((uint32_t)GROUP_M2, (uint32_t)a.tiles_m - group * GROUP_M2);
+    tm0 = (int)(group * GROUP_M2 + in_group % group_rows) * BM2;
+    tn0 = (int)(in_group / group_rows) * BN_OUT;
+  };
+  auto set_sources = [&](int tm0, int tn0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int row = (wave * 4 + c) * 8 + d_row;
+      const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
+      int ra = tm0 + row;
+      ra = ra < a.M ? ra : a.M - 1;
+      a_src[c] = a.xq + (size_t)ra * a.K + d_slot * 16;
+      if constexpr (MLP) {
+        const int rb = tn0 + (row >> 6) * 32 + (row & 31);
+        b_src[c] = ((row & 32) ? a.wq2 : a.wq) + (size_t)rb * a.K + d_slot * 16;
+      } else {
+        int rb = tn0 + row;
+        rb = rb < a.N ? rb : a.N - 1;
+        b_src[c] = a.wq + (size_t)rb * a.K + d_slot * 16;
+      }
+    }
+  };
+  auto issue_a = [&](int ks, int slot, int c0) {
+    uint8_t* base = lds2 + slot * SLOT_BYTES;
+#pragma unroll
+    for (int c = c0; c < c0 + 2; ++c)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[c] + ks * 128), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+  };
+  auto issue_b = [&](int ks, int slot, int c0) {
+    uint8_t* base = lds2 + slot * SLOT_BYTES + B_IMAGE;
+#pragma unroll
+    for (int c = c0; c < c0 + 2; ++c)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_src[c] + ks * 128), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+  };
+
+  // fragment byte offsets inside a slot: [row tile][k-chunk]
+  const uint32_t r16 = lane & 15, g4 = lane >> 4;
+  uint32_t a_off[8][2], b_off[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const uint32_t row = wm * 128 + mi * 16 + r16;
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) a_off[mi][kq] = row * 128 + (((kq * 4 + g4) ^ ((row >> 1) & 7u)) << 4);
+  }
+#pragma unroll
+  for (int nj = 0; nj < 4; ++nj) {
+    const uint32_t row = wn * 64 + nj * 16 + r16;
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) b_off[nj][kq] = B_IMAGE + row * 128 + (((kq * 4 + g4) ^ ((row >> 1) & 7u)) << 4);
+  }
+
+  v4i32 acc[8][4];
+  v4i fa[4], fb[4];
+  auto read_frags = [&](const uint8_t* st, int phase) {  // phase 0..3 of a super-step (compile-time after unrolling)
+    const int kq = phase >> 1, mh = phase & 1;
+    if (mh == 0) {
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) fb[nj] = *reinterpret_cast<const v4i*>(st + b_off[nj][kq]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fa[q] = *reinterpret_cast<const v4i*>(st + a_off[4 * mh + q][kq]);
+  };
+  auto cluster = [&](int mh, auto dma, auto dma2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) {
+        if (mh == 0) acc[q][nj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[nj], fa[q], acc[q][nj], 0, 0, 0);
+        else acc[4 + q][nj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[nj], fa[q], acc[4 + q][nj], 0, 0, 0);
+      }
+      if (q == 0) { __builtin_amdgcn_sched_barrier(0); dma(); __builtin_amdgcn_sched_barrier(0); }
+      if (q == 2) { __builtin_amdgcn_sched_barrier(0); dma2(); __builtin_amdgcn_sched_barrier(0); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  const int ksuper = a.K / 128;
+  int slot = 0;  // slot of the super-step about to be computed
+  tile_origin(0, m0, n0);
+  set_sources(m0, n0);
+  issue_a(0, 0, 0); issue_a(0, 0, 2); issue_b(0, 0, 0); issue_b(0, 0, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int it = 0; it < my_tiles; ++it) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mi][nj][e] = 0;
+    int nm0 = m0, nn0 = n0;
+    const bool has_next = it + 1 < my_tiles;
+    if (has_next) tile_origin(it + 1, nm0, nn0);
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // the upper group runs one interval behind
+    for (int ks = 0; ks < ksuper; ++ks) {
+      const uint8_t* st = lds2 + slot * SLOT_BYTES;
+      int fetch = ks + 1;
+      if (ks == ksuper - 1) {
+        fetch = has_next ? 0 : ks;
+        if (has_next) set_sources(nm0, nn0);
+      }
+      read_frags(st, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(0, [&] { issue_a(fetch, slot ^ 1, 0); }, [&] { issue_b(fetch, slot ^ 1, 0); });
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(1, [&] { issue_a(fetch, slot ^ 1, 2); }, [&] { issue_b(fetch, slot ^ 1, 2); });
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(0, [] {}, [] {});
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the fetched super-step landed (and older epilogue stores)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(1, [] {}, [] {});
+      __builtin_amdgcn_s_barrier();
+      slot ^= 1;
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();  // same number of barriers for both groups
+    uint8_t* scratch = lds2 + (slot ^ 1) * SLOT_BYTES;  // the consumed slot: epilogue scratch
+    __syncthreads();
+    if constexpr (MLP) {
+      int rsw[2] = {0, 0};
+      if (a.rowsum_w) {
+        rsw[0] = a.rowsum_w[n0 + wn * 32 + (lane & 31)];
+        rsw[1] = a.rowsum_w2[n0 + wn * 32 + (lane & 31)];
+      }
+      const float as = __builtin_fabsf(a.out_scale[0]);
+      if (as > 0x1p-40f && as < 0x1p40f) mlp_epilogue16_body<true>(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table);
+      else mlp_epilogue16_body<false>(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table);
+    } else {
+      gemm256_epilogue_slabs16<TOut, REQUANT>(a, acc, scratch, wave, lane, wm, wn, m0, n0);
+    }
+    __syncthreads();  // the scratch slot is the next tile's DMA target
+    m0 = nm0; n0 = nn0;
+  }
+}
+
 // one wavefront per row: sum of K int8 codes
 __global__ __launch_bounds__(256) void rowsum_i8_kernel(const int8_t* __restrict__ q, int rows, int K,
                                                         int32_t* __restrict__ sums) {
@@ -1651,6 +2036,7 @@ extern "C" int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int3
       const bool fl = use_fl && K % 128 == 0;
       static const int use_fp = getenv("FFQ_GEMM_FP") ? atoi(getenv("FFQ_GEMM_FP")) : 1;  // persistent tile loop: +4.9 % (A/B on one box)
       const bool fp = fl && use_fp && !w_offset;
+      static const int use_fq = getenv("FFQ_GEMM_FQ") ? atoi(getenv("FFQ_GEMM_FQ")) : 1;  // v_mfma_i32_16x16x64_i8 form of the persistent kernel
       const unsigned grid_fp = grid3 < 256u ? grid3 : 256u;  // persistent: one block per CU
       const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128;
 #define FFQ_GEMM3_FP(T, RQ)                                                                                \
@@ -1659,8 +2045,11 @@ extern "C" int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int3
     if (first_use_on_this_device(&attr_set_fp)) {                                                                                    \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fp_kernel<T, RQ, false>),       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fp);                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fq_kernel<T, RQ, false>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fp);                  \
     }                                                                                                      \
-    w8a8_gemm256fp_kernel<T, RQ, false><<<grid_fp, 512, lds_fp, s>>>(a, (int)grid3);                       \
+    if (use_fq) w8a8_gemm256fq_kernel<T, RQ, false><<<grid_fp, 512, lds_fp, s>>>(a, (int)grid3);           \
+    else w8a8_gemm256fp_kernel<T, RQ, false><<<grid_fp, 512, lds_fp, s>>>(a, (int)grid3);                  \
   } while (0)
 #define FFQ_GEMM3_W(T, RQ, WO)                                                                             \
   do {                                                                                                     \
@@ -1842,9 +2231,13 @@ extern "C" int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, 
     if (first_use_on_this_device(&attr_set_fp)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fp_kernel<int8_t, true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fp);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fq_kernel<int8_t, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fp);
     }
     const int total = a.tiles_m * a.tiles_n;
-    w8a8_gemm256fp_kernel<int8_t, true, true><<<(unsigned)(total < 256 ? total : 256), 512, lds_fp, s>>>(a, total);
+    static const int use_fq = getenv("FFQ_GEMM_FQ") ? atoi(getenv("FFQ_GEMM_FQ")) : 1;
+    if (use_fq) w8a8_gemm256fq_kernel<int8_t, true, true><<<(unsigned)(total < 256 ? total : 256), 512, lds_fp, s>>>(a, total);
+    else w8a8_gemm256fp_kernel<int8_t, true, true><<<(unsigned)(total < 256 ? total : 256), 512, lds_fp, s>>>(a, total);
     return check_launch("w8a8_gemm256fp_kernel (mlp mode)");
   }
   if (use_fl && K % 128 == 0) w8a8_gemm256fl_kernel<int8_t, true, false, true><<<(unsigned)(a.tiles_m * a.tiles_n), 512, lds, s>>>(a);
