@@ -1835,7 +1835,10 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
-      for (int nj = 0; nj < 4; ++nj) {
+      for (int n_ = 0; n_ < 4; ++n_) {
+        // snake order: every MFMA shares one operand with its predecessor, also across the row-tile change
+        // (MLP mode +1.3-3.2 %, down +1-2.3 %, A/B on one box: operand reads cost power, and power is what limits this loop)
+        const int nj = (q & 1) ? 3 - n_ : n_;
         if (mh == 0) acc[q][nj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[nj], fa[q], acc[q][nj], 0, 0, 0);
         else acc[4 + q][nj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[nj], fa[q], acc[4 + q][nj], 0, 0, 0);
       }
