@@ -109,7 +109,7 @@ def pmc_traffic(*needles: str, stems: tuple[str, ...] = ("_pmc_", "_pmc_hbm_")) 
     return None, None
 
 
-def pmc_traffic_mix(needle: str) -> tuple[float | None, dict, str | None]:
+def pmc_traffic_mix(needle: "str | tuple[str, ...]") -> tuple[float | None, dict, str | None]:
     """Launch-count-weighted mean of the fabric bytes per launch over EVERY kernel variant whose name contains `needle`
     (the PMC pass profiles the same forward, so its launch counts are the forward's launch mix), the per-variant
     figures, and the profile the numbers come from."""
@@ -118,8 +118,9 @@ def pmc_traffic_mix(needle: str) -> tuple[float | None, dict, str | None]:
         return None, {}, None
     r, w, prof = tables
     total, launches, variants = 0.0, 0, {}
+    needles = needle if isinstance(needle, tuple) else (needle,)
     for name, row in r.items():
-        if needle in name and name in w:
+        if any(n in name for n in needles) and name in w:
             b = float(row["hbm_read_bytes"] + w[name]["hbm_write_bytes"])
             variants[name] = {"launches": row["launches"], "bytes_per_launch": b}
             total += b * row["launches"]
@@ -188,7 +189,7 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
             launches += count
         per_shape = per_shape_random
     achieved = total_ops / total_ms / 1e9
-    traffic, traffic_variants, prof = pmc_traffic_mix("w8a8_gemm256fp_kernel")
+    traffic, traffic_variants, prof = pmc_traffic_mix(("w8a8_gemm256fq_kernel", "w8a8_gemm256fp_kernel"))  # the persistent kernel: 16x16x64 form, or the 32x32x32 form under FFQ_GEMM_FQ=0
     # algorithmic bytes of the same launch mix: int8 activation codes + int8 weight codes read once, output written once
     # (bf16 for the plain launches; int8 codes for the gate+up launch, which reads two weight matrices)
     alg_bytes = sum(c * (tokens * k + n * k + tokens * n * 2) for (n, k), c in {(h, h): 2, (kv, h): 2, (h, i): 1}.items()) + (tokens * h + 2 * i * h + tokens * i)
@@ -197,18 +198,18 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
     ceiling = None
     probe = ROOT / "profiles" / "r01_mfma_power_probe.txt"
     if probe.exists():
-        rates = [float(line.split("toggling")[1].split("TOP/s")[0]) for line in probe.read_text().splitlines() if line.startswith("32x32x32 random bytes")]
+        rates = [float(line.split("toggling")[1].split("TOP/s")[0]) for line in probe.read_text().splitlines() if line.startswith("16x16x64 random bytes")]
         ceiling = round(statistics.mean(rates), 1) if rates else None
     return {
         "bound": "mfma",
-        "kernel": "w8a8_gemm256fp_kernel (v_mfma_i32_32x32x32_i8, 256x256 tiles, persistent one-block-per-CU tile loop, ping-pong wave groups, full-line LDS-DMA staging; plain and gate+up/SiLU-epilogue modes) + rowsum_i8_kernel",
+        "kernel": "w8a8_gemm256fq_kernel (v_mfma_i32_16x16x64_i8, 256x256 tiles, persistent one-block-per-CU tile loop, ping-pong wave groups, full-line LDS-DMA staging; plain and gate+up/SiLU-epilogue modes) + rowsum_i8_kernel",
         "achieved": round(achieved, 1),
         "peak": INT8_PEAK_TOPS,
         "unit": "TFLOP/s",
         "unit_note": "integer multiply-accumulates (TOP/s); dense int8 MFMA peak",
         "frac": round(achieved / INT8_PEAK_TOPS, 4),
         "mfma_only_ceiling_on_toggling_operands": ceiling,
-        "mfma_only_ceiling_note": None if ceiling is None else "TOP/s of v_mfma_i32_32x32x32_i8 issued back to back on random operands, no LDS / global traffic "
+        "mfma_only_ceiling_note": None if ceiling is None else "TOP/s of v_mfma_i32_16x16x64_i8 issued back to back on random operands, no LDS / global traffic "
                                   "(profiles/r01_mfma_power_probe.txt): the chip is power-limited on real data; frac stays against the nominal peak",
         "traffic": traffic,
         "traffic_note": None if traffic is None else f"fabric (L2-miss) read+write bytes per launch from FETCH_SIZE x2 + WRITE_SIZE, launch-count-weighted mean over BOTH kernel variants of the forward "
@@ -256,7 +257,7 @@ def hbm_kernels(device: torch.device) -> list[dict]:
     gamma = torch.ones(shape[1], device=device, dtype=torch.bfloat16)
     add("residual add + RMSNorm + quantize (bf16, bf16 -> bf16 sum, int8 codes)", "add_rmsnorm_quantize_kernel<1,4>", ("add_rmsnorm_quantize_kernel<1, 4>",), 7,
         lambda r: ops.add_rmsnorm_quantize(ws[r % 6], ws[(r + 1) % 6], gamma, 1e-5, [(s1, o1)]))
-    add("SiLU(gate) * up + quantize (bf16, bf16 -> int8 codes)", "silu_mul_quantize_kernel", ("silu_mul_quantize_kernel",), 5,
+    add("SiLU(gate) * up + quantize (bf16, bf16 -> int8 codes)", "silu_mul_quantize_table_kernel", ("silu_mul_quantize_table_kernel",), 5,
         lambda r: ops.silu_mul_quantize(ws[r % 6], ws[(r + 1) % 6], [(s1, o1)]))
     # W4 group-128: A1 + A7 and A7 + A2 in one pass each (2.5 B/elem), and the backward of fake quantization (6 B/elem)
     g4 = torch.rand(n // 128, device=device) * 0.002 + 0.002
