@@ -61,6 +61,7 @@ struct LinearArgs {
   int x_per_row, w_per_row;
   int M, N, K;
   int tiles_m, tiles_n;
+  int group_m;  // row tiles per group of the persistent kernels' tile walk (A panels shared by a group's column tiles)
   // MLP mode of the v3 kernel (gate and up projections in one launch): the second weight matrix
   const int8_t* wq2; const float* w_scale2; const int32_t* rowsum_w2;
   int debug;  // FFQ_GEMM_DEBUG ablation bits (tools/gemm_time.py): 1 = no global stores, 2 = no epilogue at all.
@@ -1764,10 +1765,11 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   int m0 = 0, n0 = 0;
   auto tile_origin = [&](int it, int& tm0, int& tn0) {
     const uint32_t tile_id = xcd_first + j_in_xcd + (uint32_t)it * blocks_in_xcd;
-    const uint32_t per_group = GROUP_M2 * (uint32_t)a.tiles_n;
+    const uint32_t gm = (uint32_t)a.group_m;
+    const uint32_t per_group = gm * (uint32_t)a.tiles_n;
     const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
-    const uint32_t group_rows = min((uint32_t)GROUP_M2, (uint32_t)a.tiles_m - group * GROUP_M2);
-    tm0 = (int)(group * GROUP_M2 + in_group % group_rows) * BM2;
+    const uint32_t group_rows = min(gm, (uint32_t)a.tiles_m - group * gm);
+    tm0 = (int)(group * gm + in_group % group_rows) * BM2;
     tn0 = (int)(in_group / group_rows) * BN_OUT;
   };
   auto set_sources = [&](int tm0, int tn0) {
@@ -2023,6 +2025,11 @@ extern "C" int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int3
     if (!force_v2 && !force_nw && K / BK2 >= 4) {
       a.tiles_m = (int)((M + BM2 - 1) / BM2);
       a.tiles_n = (int)((N + 255) / 256);
+      // 8 row tiles per group; 4 for long contractions (down_proj, K = 14336: +3 %, at the vendor kernel's 2.6 POP/s; A/B of
+      // 2 / 3 / 4 / 6 / 8 / 16 / 32 on one box) — the group's A panels are 256 x K bytes each
+      a.group_m = K >= 8192 ? 4 : GROUP_M2;
+      static const int force_gm = getenv("FFQ_GROUP_M") ? atoi(getenv("FFQ_GROUP_M")) : 0;
+      if (force_gm > 0) a.group_m = force_gm;
       if (x_offset) {  // sum_k wq[n, k] for the zero-point term: one pass over the weight codes
         if (w_rowsum) {
           a.rowsum_w = w_rowsum;
@@ -2208,6 +2215,9 @@ extern "C" int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, 
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.tiles_m = (int)((M + BM2 - 1) / BM2);
   a.tiles_n = (int)(N / 128);
+  a.group_m = K >= 8192 ? 4 : GROUP_M2;
+  static const int force_gm = getenv("FFQ_GROUP_M") ? atoi(getenv("FFQ_GROUP_M")) : 0;
+  if (force_gm > 0) a.group_m = force_gm;
   static const int debug_bits = getenv("FFQ_GEMM_DEBUG") ? atoi(getenv("FFQ_GEMM_DEBUG")) : 0;
   a.debug = debug_bits;
   if (x_offset && have_sums) {

@@ -12,7 +12,10 @@ from bench import event_time_ms
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 dev = "cuda"
 tot_ops = tot_ms = 0
-for name, n, k, cnt in (("qo", 4096, 4096, 2), ("kv", 1024, 4096, 2), ("gateup", 14336, 4096, 2), ("down", 4096, 14336, 1)):
+SHAPES = (("qo", 4096, 4096, 2), ("kv", 1024, 4096, 2), ("gateup", 14336, 4096, 2), ("down", 4096, 14336, 1))
+if os.environ.get("GT_MODEL") == "70b":
+    SHAPES = (("qo", 8192, 8192, 2), ("kv", 1024, 8192, 2), ("gateup", 28672, 8192, 2), ("down", 8192, 28672, 1))
+for name, n, k, cnt in SHAPES:
     xq = torch.randint(-128, 128, (T, k), device=dev, dtype=torch.int8)
     wq = torch.randint(-128, 128, (n, k), device=dev, dtype=torch.int8)
     if os.environ.get("GT_FILL") == "zero":
@@ -26,7 +29,7 @@ for name, n, k, cnt in (("qo", 4096, 4096, 2), ("kv", 1024, 4096, 2), ("gateup",
     print(f"{name:7s} N={n:5d} K={k:5d} {ms:.4f} ms {2*T*n*k/ms/1e9:8.1f} TOP/s")
     tot_ops += cnt * 2 * T * n * k; tot_ms += cnt * ms
 # gate+up with the SiLU*up + quantize epilogue (one launch); realistic magnitudes so that silu sees ordinary values
-n, k = 14336, 4096
+n, k = (28672, 8192) if os.environ.get("GT_MODEL") == "70b" else (14336, 4096)
 xq = torch.randint(-128, 128, (T, k), device=dev, dtype=torch.int8)
 gq = torch.randint(-128, 128, (n, k), device=dev, dtype=torch.int8)
 uq = torch.randint(-128, 128, (n, k), device=dev, dtype=torch.int8)
