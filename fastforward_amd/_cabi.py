@@ -19,7 +19,7 @@ from fastforward_amd.exceptions import QuantizationError
 
 FFQ_MAX_DIMS = 8
 FFQ_MAX_FANOUT = 3
-FFQ_ABI_VERSION = 4
+FFQ_ABI_VERSION = 5
 
 
 class Status(enum.IntEnum):
@@ -166,6 +166,7 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
         _i,
         [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp],
     ),
+    "ffq_linear_w8a8_residual": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ffq_mlp_gate_up_w8a8_rs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ffq_linear_wq_supported": (_i, [_i, _i, _i, _i64, _i64, _i64, _i64]),
     "ffq_linear_wq": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i64, _i64, _vp, _i, _vp, _i, _i64, _i64, _i64, _vp]),

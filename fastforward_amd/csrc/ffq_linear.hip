@@ -55,6 +55,7 @@ struct LinearArgs {
   const float* w_scale; const float* w_offset;
   const int32_t* rowsum_x; const int32_t* rowsum_w;
   const void* bias; int bias_dt;
+  const void* residual;  // nullable, [M, N] of out_dt (half types): out = residual + T(linear), two roundings as the eager add (fq kernel only)
   void* out; int out_dt;
   const float* out_scale; const float* out_offset;
   float out_lo, out_hi;
@@ -1547,9 +1548,13 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
 // -------------------------------------------------------------------------------------------------
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
+template <typename T> __device__ __forceinline__ float half_bits_to_f32(uint32_t bits);  // 16-bit pattern -> value
+template <> __device__ __forceinline__ float half_bits_to_f32<bf16_t>(uint32_t bits) { return __builtin_bit_cast(float, bits << 16); }
+template <> __device__ __forceinline__ float half_bits_to_f32<f16_t>(uint32_t bits) { return (float)__builtin_bit_cast(_Float16, (uint16_t)bits); }
+
 // Epilogue of the plain mode for that layout: the slab scheme of gemm256_epilogue_slabs (32 rows x 64 columns per wave and
 // round, whole 128-byte lines out with the non-temporal hint), two row tiles per slab.
-template <typename TOut, bool REQUANT>
+template <typename TOut, bool REQUANT, bool RESID>
 __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4i32 (&acc)[8][4], uint8_t* scratch, int wave, int lane,
                                                          int wm, int wn, int m0, int n0) {
   TOut* out = static_cast<TOut*>(a.out);
@@ -1585,6 +1590,23 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
   }
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) asm volatile("" : "+v"(sx8[mi]), "+v"(ox8[mi]));
+  // residual rows of the slab about to leave, requested one slab ahead and BEFORE the previous slab's stores go out: the
+  // wait for them is a counted vmcnt that leaves those (younger) stores in flight
+  [[maybe_unused]] u32x4 res_cur[4], res_nxt[4];
+  [[maybe_unused]] auto load_residual = [&](int i, u32x4 (&dst)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = lane + 64 * t;
+      const int row = c >> 3, seg = c & 7;
+      int mm = wave_m0 + i * 32 + row;
+      mm = mm < a.M ? mm : a.M - 1;
+      dst[t] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(static_cast<const uint8_t*>(a.residual) + ((size_t)mm * a.N + wave_n0) * 2 + seg * 16));
+    }
+  };
+  constexpr bool with_residual = RESID && sizeof(TOut) == 2 && !REQUANT;  // the launcher admits only shapes whose waves all take the LDS path
+  if constexpr (with_residual) {
+    if (lds_path) load_residual(0, res_cur);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -1630,15 +1652,38 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
       }
     }
     if (lds_path) {
+      if constexpr (with_residual) {
+        if (i < 3) load_residual(i + 1, res_nxt);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int c = lane + 64 * t;
         const int row = c >> 3, seg = c & 7;
         const int mm = wave_m0 + i * 32 + row;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * ROW_BYTES + seg * 16);
+        u32x4 v = *reinterpret_cast<const u32x4*>(region + row * ROW_BYTES + seg * 16);
+        if constexpr (with_residual) {
+          {  // residual + T(linear) in the output dtype: the linear's rounding, then the add's (decoder.py:60-90)
+            const u32x4 r = res_cur[t];
+            const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, rw[4] = {r.x, r.y, r.z, r.w};
+            uint32_t ow[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float s0 = half_bits_to_f32<TOut>(vw[e] & 0xFFFFu) + half_bits_to_f32<TOut>(rw[e] & 0xFFFFu);
+              const float s1 = half_bits_to_f32<TOut>(vw[e] >> 16) + half_bits_to_f32<TOut>(rw[e] >> 16);
+              ow[e] = pack2<TOut>(s0, s1);
+            }
+            v.x = ow[0]; v.y = ow[1]; v.z = ow[2]; v.w = ow[3];
+          }
+        }
+        // non-temporal both ways (the residual read above, the sum written here): 134 MB streaming through the L2s would
+        // push the operand panels out (ordinary accesses: +28 us on o_proj, +66 us on down_proj at T = 16384)
         if (mm < a.M && !(a.debug & 1))
           FFQ_EPI_STORE(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * a.N + wave_n0) * 2 + seg * 16));
+      }
+      if constexpr (with_residual) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) res_cur[t] = res_nxt[t];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is re-written by the next i
     }
@@ -1735,7 +1780,7 @@ __device__ __forceinline__ void mlp_epilogue16_body(const LinearArgs& a, v4i32 (
   }
 }
 
-template <typename TOut, bool REQUANT, bool MLP>
+template <typename TOut, bool REQUANT, bool MLP, bool RESID = false>
 __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, int total_tiles) {
   constexpr int BN2 = 256, WAVES_N = 4;
   constexpr int BN_OUT = MLP ? 128 : 256;
@@ -1913,7 +1958,7 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
       if (as > 0x1p-40f && as < 0x1p40f) mlp_epilogue16_body<true>(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table);
       else mlp_epilogue16_body<false>(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table);
     } else {
-      gemm256_epilogue_slabs16<TOut, REQUANT>(a, acc, scratch, wave, lane, wm, wn, m0, n0);
+      gemm256_epilogue_slabs16<TOut, REQUANT, RESID>(a, acc, scratch, wave, lane, wm, wn, m0, n0);
     }
     __syncthreads();  // the scratch slot is the next tile's DMA target
     m0 = nm0; n0 = nn0;
@@ -1966,12 +2011,39 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* 
                             out_scale, out_offset, out_num_bits, M, N, K, workspace, workspace_bytes, stream);
 }
 
+static int linear_w8a8_launch(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                              const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset,
+                              int w_per_row, const void* bias, int bias_dt, const void* residual, void* out, int out_dt,
+                              const float* out_scale, const float* out_offset, double out_num_bits, int64_t M,
+                              int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+
 // w_rowsum (nullable): sum_k wq[n, k] already known to the caller (ffq_quantize_rows_rowsum) — no reduction launch here
 extern "C" int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
                                   const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset,
                                   int w_per_row, const void* bias, int bias_dt, void* out, int out_dt,
                                   const float* out_scale, const float* out_offset, double out_num_bits, int64_t M,
                                   int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  return linear_w8a8_launch(xq, wq, w_rowsum, x_scale, x_offset, x_per_row, w_scale, w_offset, w_per_row, bias, bias_dt, nullptr, out, out_dt,
+                            out_scale, out_offset, out_num_bits, M, N, K, workspace, workspace_bytes, stream);
+}
+
+// out = residual + T(linear): the residual add behind o_proj / down_proj (decoder.py:60-90) in the GEMM's epilogue. Covered
+// where the persistent kernel runs with whole-line stores; FFQ_ERR_DTYPE elsewhere (the caller adds with a separate pass).
+extern "C" int ffq_linear_w8a8_residual(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                                        const float* x_offset, const float* w_scale, const void* residual, void* out, int out_dt,
+                                        int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!residual) return fail(FFQ_ERR_ARG, "NULL residual");
+  if (!(out_dt == FFQ_BF16 || out_dt == FFQ_F16)) return fail(FFQ_ERR_DTYPE, "the fused residual add is built for bf16 / fp16 outputs");
+  if (!aligned16(residual) || !aligned16(out)) return fail(FFQ_ERR_ARG, "buffers must be 16-byte aligned");
+  return linear_w8a8_launch(xq, wq, w_rowsum, x_scale, x_offset, 0, w_scale, nullptr, 1, nullptr, 0, residual, out, out_dt,
+                            nullptr, nullptr, 8.0, M, N, K, workspace, workspace_bytes, stream);
+}
+
+static int linear_w8a8_launch(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                              const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset,
+                              int w_per_row, const void* bias, int bias_dt, const void* residual, void* out, int out_dt,
+                              const float* out_scale, const float* out_offset, double out_num_bits, int64_t M,
+                              int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
@@ -1999,6 +2071,7 @@ extern "C" int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int3
   a.rowsum_x = nullptr; a.rowsum_w = nullptr;
   a.wq2 = nullptr; a.w_scale2 = nullptr; a.rowsum_w2 = nullptr;
   a.bias = bias; a.bias_dt = bias_dt;
+  a.residual = residual;
   a.out = out; a.out_dt = out_dt;
   a.out_scale = out_scale; a.out_offset = out_offset;
   const double lo = -pow(2.0, out_num_bits - 1.0);
@@ -2011,6 +2084,14 @@ extern "C" int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int3
   a.debug = debug_bits;
 
   int32_t* ws = static_cast<int32_t*>(workspace);
+  if (residual) {  // only the persistent 16x16x64 kernel's whole-line epilogue adds it: the same conditions as its dispatch below
+    static const int fq_on = (getenv("FFQ_GEMM_FQ") ? atoi(getenv("FFQ_GEMM_FQ")) : 1) && (getenv("FFQ_GEMM_FP") ? atoi(getenv("FFQ_GEMM_FP")) : 1) &&
+                             (getenv("FFQ_GEMM_FL") ? atoi(getenv("FFQ_GEMM_FL")) : 1) && !getenv("FFQ_GEMM_V1") && !getenv("FFQ_GEMM_V2") &&
+                             !getenv("FFQ_GEMM_NW") && !getenv("FFQ_GEMM_4W");
+    const int64_t tiles = ((M + BM2 - 1) / BM2) * ((N + 255) / 256);
+    if (!fq_on || K % 128 != 0 || K < 256 || M < 128 || N % 64 != 0 || tiles < 64)
+      return fail(FFQ_ERR_DTYPE, "fused residual add: shape outside the persistent kernel (K %% 128, N %% 64, >= 64 tiles)");
+  }
   static const int use_4w = getenv("FFQ_GEMM_4W") ? atoi(getenv("FFQ_GEMM_4W")) : 0;
   if (use_4w && !requant && out_dt == FFQ_BF16 && !w_offset && !bias && !x_per_row &&
       linear4w_try(xq, wq, w_rowsum, x_scale, x_offset, w_scale, w_per_row, out, M, N, K, ws, s) == 0)
@@ -2075,6 +2156,19 @@ extern "C" int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int3
     else w8a8_gemm256pp_kernel<T, RQ, WO><<<grid3, 512, lds3, s>>>(a);                                     \
   } while (0)
 #define FFQ_GEMM3(T, RQ) do { if (w_offset) FFQ_GEMM3_W(T, RQ, true); else FFQ_GEMM3_W(T, RQ, false); } while (0)
+#define FFQ_GEMM3_RESID(T)                                                                                 \
+  do {                                                                                                     \
+    static uint64_t attr_set_res = 0;                                                                      \
+    if (first_use_on_this_device(&attr_set_res)) {                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&w8a8_gemm256fq_kernel<T, false, false, true>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fp);                  \
+    }                                                                                                      \
+    w8a8_gemm256fq_kernel<T, false, false, true><<<grid_fp, 512, lds_fp, s>>>(a, (int)grid3);              \
+  } while (0)
+      if (residual) {  // admitted above only where fp && use_fq hold
+        if (out_dt == FFQ_BF16) FFQ_GEMM3_RESID(bf16_t); else FFQ_GEMM3_RESID(f16_t);
+        return check_launch("w8a8_gemm256fq_kernel (residual)");
+      }
       if (requant) {
         switch (out_dt) {
           case FFQ_I8: FFQ_GEMM3(int8_t, true); break;
@@ -2205,6 +2299,7 @@ extern "C" int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, 
   a.xq = xq; a.wq = gate_wq; a.wq2 = up_wq;
   a.x_scale = x_scale; a.x_offset = x_offset;
   a.w_scale = gate_w_scale; a.w_scale2 = up_w_scale; a.w_offset = nullptr;
+  a.residual = nullptr;
   a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.rowsum_w2 = nullptr;
   a.bias = nullptr; a.bias_dt = 0;
   a.out = codes_out; a.out_dt = FFQ_I8;

@@ -338,7 +338,8 @@ class FusedForward:
     per-channel activations, biases — instead of silently computing something else.
     """
 
-    def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True, fuse_attention: bool = True, fuse_rowsums: bool = False) -> None:
+    def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True, fuse_attention: bool = True, fuse_rowsums: bool = False,
+                 fuse_residual: bool = False) -> None:
         problems = self.unsupported(model)
         if problems:
             raise ff.exceptions.QuantizationError("FusedForward cannot run this model: " + "; ".join(problems[:4]))
@@ -355,6 +356,12 @@ class FusedForward:
         # runs): the int8 GEMMs that follow run slower by more than the reduction cost (tools/gemm_cache_probe.py: a GEMM
         # preceded by more memory-bound work is faster — the chip is power-limited and the light pass lets it recover).
         self.fuse_rowsums = fuse_rowsums
+        # the residual adds behind o_proj / down_proj inside those GEMMs' epilogues (ops.linear_w8a8_residual): the RMSNorm that
+        # follows then reads ONE tensor and writes only codes (3 B/elem instead of 7). OFF by default: measured neutral — the
+        # epilogue's residual reads cost the GEMM 27-32 us per launch (their latency is only one 32-row slab deep), the RMSNorm
+        # saves 35 us (tools/residual_time.py: pair 301.6 -> 299.0 us on o_proj, 823.1 -> 815.8 us on down_proj; forward 130.8 vs
+        # 130.9 ms, tools/ab_forward.py)
+        self.fuse_residual = fuse_residual
         self._zero_offset: dict[int, tuple[int, bool]] = {}
         self._weight_cache: dict[int, tuple[tuple[int, int, int], tuple[torch.Tensor, torch.Tensor | None]]] = {}
         self._rowsum_rows = sum(linear.weight.shape[0] for _, linear in decoder_linears(model))
@@ -496,16 +503,27 @@ class FusedForward:
         codes, rowsum = self._quantize_weight(linear)
         return codes, rowsum, wq.scale, wq.offset
 
-    def _linear(self, x_codes: torch.Tensor, linear: torch.nn.Module) -> torch.Tensor:
+    def _linear(self, x_codes: torch.Tensor, linear: torch.nn.Module, residual: torch.Tensor | None = None) -> torch.Tensor | None:
+        """The int8 GEMM of one quantized linear. With `residual` (the decoder's residual stream, bf16): residual +=
+        linear(...) inside the GEMM's epilogue where the kernel covers it, and None is returned; otherwise the linear's own
+        output (which the RMSNorm kernel that follows adds to the stream). The weight is quantized once either way."""
         w_codes, w_rowsum, w_scale, w_offset = self._weight(linear)
         if w_offset is not None and self._symmetric_weights(linear):
             w_offset = None  # an all-zero offset buffer: same result, no device-side offset check in the kernel
         x_scale, x_offset = self._params(linear)
-        if self.linear_events is None:
+        fusable = (residual is not None and w_offset is None and w_scale.numel() == w_codes.shape[0] and x_scale.numel() == 1
+                   and residual.dtype == torch.bfloat16 and residual.is_contiguous())
+
+        def launch() -> torch.Tensor | None:
+            if fusable and ff.ops.linear_w8a8_residual(x_codes, w_codes, x_scale, x_offset, w_scale, residual, w_rowsum=w_rowsum, inplace=True) is not None:
+                return None
             return ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16, w_rowsum=w_rowsum)
+
+        if self.linear_events is None:
+            return launch()
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
-        out = ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16, w_rowsum=w_rowsum)
+        out = launch()
         end.record()
         self.linear_events.append((w_codes.shape[0], w_codes.shape[1], start, end))
         return out
@@ -521,7 +539,7 @@ class FusedForward:
             self.refresh()
         hidden = model.embed_tokens(input_ids)
         cos, sin = rotary_tables(s, d, cfg.rope_theta, hidden.device, hidden.dtype)
-        pending: torch.Tensor | None = None
+        pending: torch.Tensor | None = None  # down_proj's output where its residual add was NOT fused into the GEMM
         if self.fuse_rowsums:  # the weight row sums of this forward: one zero fill, slices handed out as the weights are quantized
             self._rowsum_pool = torch.zeros(self._rowsum_rows, dtype=torch.int32, device=hidden.device)
             self._rowsum_used = 0
@@ -543,11 +561,11 @@ class FusedForward:
             else:
                 ctx = _sdpa(q, k, v, cfg, b, s)
                 o_codes = ff.ops.quantize_by_tile(ctx, o_in.scale, ctx.shape, o_in.num_bits, torch.int8, o_in.offset)
-            attn_out = self._linear(o_codes, attn.o_proj)
+            attn_out = self._linear(o_codes, attn.o_proj, residual=hidden if self.fuse_residual else None)  # None: already in `hidden`
             pairs, index = fan["gate_up"]
             hidden, _, codes = ff.ops.add_rmsnorm_quantize(
                 hidden, attn_out, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon,
-                pairs, mlp.gate_proj.input_quantizer.num_bits, sum_inplace=True,
+                pairs, mlp.gate_proj.input_quantizer.num_bits, sum_inplace=attn_out is not None,
             )
             d_in = mlp.down_proj.input_quantizer
             d_codes = None
@@ -567,7 +585,7 @@ class FusedForward:
                 gate = self._linear(codes[index[0]], mlp.gate_proj)
                 up = self._linear(codes[index[1]], mlp.up_proj)
                 _, (d_codes,) = ff.ops.silu_mul_quantize(gate, up, [(d_in.scale, d_in.offset)], d_in.num_bits)
-            pending = self._linear(d_codes, mlp.down_proj)
+            pending = self._linear(d_codes, mlp.down_proj, residual=hidden if self.fuse_residual else None)  # None: already in `hidden`
         _, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, model.norm.weight, model.norm.variance_epsilon, (), want_sum=False, want_norm=True)
         if not logits:
             return normed

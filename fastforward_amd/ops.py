@@ -39,6 +39,7 @@ __all__ = [
     "linear_w8a8",
     "linear_wq",
     "mlp_gate_up_w8a8",
+    "linear_w8a8_residual",
     "add_rmsnorm_quantize",
     "silu_mul_quantize",
     "rope_",
@@ -623,6 +624,55 @@ def linear_w8a8(
         )
     )
     return out
+
+
+def linear_w8a8_residual(
+    x_codes: torch.Tensor,
+    w_codes: torch.Tensor,
+    x_scale: torch.Tensor,
+    x_offset: torch.Tensor | None,
+    w_scale: torch.Tensor,
+    residual: torch.Tensor,
+    w_rowsum: torch.Tensor | None = None,
+    inplace: bool = False,
+) -> torch.Tensor | None:
+    """``residual + linear_w8a8(x, w)`` with the add inside the GEMM's epilogue — the residual connection behind o_proj /
+    down_proj (reference quantized_llama/decoder.py:60-90): the linear's output rounded to the residual's dtype (bf16 / fp16),
+    then the add's rounding, exactly the two eager ops. Per-tensor activation parameters, per-output-channel symmetric
+    weights, no bias. ``inplace`` writes the sum over `residual` (the decoder's residual stream). Returns None where the
+    persistent kernel does not cover the shape (the caller runs :func:`linear_w8a8` and adds)."""
+    if x_codes.dtype != torch.int8 or w_codes.dtype != torch.int8:
+        raise TypeError("linear_w8a8_residual expects int8 codes")
+    xc, wc = x_codes.detach().contiguous(), w_codes.detach().contiguous()
+    K, N = xc.shape[-1], wc.shape[0]
+    M = xc.numel() // K if K else 0
+    if wc.dim() != 2 or wc.shape[1] != K:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({M}x{K} and {tuple(wc.shape)}^T)")
+    if residual.dtype not in (torch.bfloat16, torch.float16) or residual.shape != (*xc.shape[:-1], N) or not residual.is_contiguous():
+        raise RuntimeError(f"residual must be a contiguous bf16 / fp16 tensor of shape {(*xc.shape[:-1], N)}")
+    res = residual.detach()
+
+    def f32(t: torch.Tensor | None, n: int) -> torch.Tensor | None:
+        if t is None:
+            return None
+        t = t.detach().reshape(-1).to(torch.float32).contiguous()
+        if t.numel() != n:
+            raise RuntimeError(f"expected {n} parameter entries, got {t.numel()}")
+        return t
+
+    xs, xo, ws_ = f32(x_scale, 1), f32(x_offset, 1), f32(w_scale, N)
+    lib, stream = _prepare(xc, wc, xs, xo, ws_, res)
+    if w_rowsum is not None and (w_rowsum.dtype != torch.int32 or w_rowsum.numel() != N or not w_rowsum.is_contiguous() or w_rowsum.device != wc.device):
+        raise RuntimeError(f"w_rowsum must be a contiguous int32 tensor with {N} entries on the codes' device")
+    out = res if inplace else torch.empty_like(res)
+    nbytes = lib.ffq_linear_w8a8_workspace_bytes(M, N, K)
+    ws = _workspace(nbytes, xc.device)
+    status = lib.ffq_linear_w8a8_residual(_ptr(xc), _ptr(wc), _ptr(w_rowsum), _ptr(xs), _ptr(xo), _ptr(ws_), _ptr(res), _ptr(out), _tag(res.dtype),
+                                          M, N, K, _ptr(ws), nbytes, stream)
+    if status == 6:
+        return None
+    lib.check(status)
+    return residual if inplace else out
 
 
 def linear_wq(

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define FFQ_MAX_DIMS 8
-#define FFQ_ABI_VERSION 4
+#define FFQ_ABI_VERSION 5
 
 typedef enum ffq_status {
   FFQ_OK = 0,
@@ -361,6 +361,18 @@ int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int32_t* w_rows
                        const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
                        const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
                        void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * ABI version 5. The residual add behind o_proj and down_proj of the reference's decoder layer
+ * (docs/examples/doc_helpers/quantized_llama/decoder.py:60-90: hidden = residual + self_attn(...), hidden = residual + mlp(...))
+ * inside the epilogue of A6: out = residual + T(linear(x, w)) with T = `out_dt` (bf16 / fp16) — the linear's output rounded
+ * to T as nn/linear.py:32-39 leaves it, then ONE more rounding for the add, exactly the two eager ops. Per-tensor activation
+ * parameters, per-output-channel symmetric weights, no bias (the Llama recipe). `out` may be `residual` itself (each element
+ * is read before it is written, by the same lane). Shapes the persistent kernel does not cover return FFQ_ERR_DTYPE and the
+ * caller runs ffq_linear_w8a8_rs and adds.
+ */
+int ffq_linear_w8a8_residual(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                             const float* x_offset, const float* w_scale, const void* residual, void* out, int out_dt,
+                             int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const int32_t* gate_rowsum,
                             const int32_t* up_rowsum, const float* x_scale, const float* x_offset,
                             const float* gate_w_scale, const float* up_w_scale, int8_t* codes_out, const float* out_scale,

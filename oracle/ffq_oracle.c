@@ -1205,6 +1205,26 @@ int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int32_t* w_rows
                          out_scale, out_offset, out_num_bits, M, N, K, workspace, workspace_bytes, stream);
 }
 
+/* ABI 5: out = residual + T(linear) — the linear as above into a temporary of the output dtype, then the eager add
+ * (decoder.py:60-90): float(residual) + float(y), one rounding to T. The oracle covers every shape. */
+int ffq_linear_w8a8_residual(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                             const float* x_offset, const float* w_scale, const void* residual, void* out, int out_dt,
+                             int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!residual) return fail(FFQ_ERR_ARG, "NULL residual");
+  if (!(out_dt == FFQ_BF16 || out_dt == FFQ_F16)) return fail(FFQ_ERR_DTYPE, "the fused residual add is built for bf16 / fp16 outputs");
+  if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (M == 0 || N == 0) return FFQ_OK;
+  uint16_t* y = (uint16_t*)malloc((size_t)M * (size_t)N * 2);
+  if (!y) return fail(FFQ_ERR_WORKSPACE, "out of memory");
+  int rc = ffq_linear_w8a8_rs(xq, wq, w_rowsum, x_scale, x_offset, 0, w_scale, NULL, 1, NULL, 0, y, out_dt, NULL, NULL, 8.0, M, N, K,
+                              workspace, workspace_bytes, stream);
+  if (!rc) {
+    for (int64_t i = 0; i < M * N; ++i) st(out, out_dt, i, op2(OP_ADD, ld(residual, out_dt, i), ld(y, out_dt, i), out_dt));
+  }
+  free(y);
+  return rc;
+}
+
 int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const int32_t* gate_rowsum,
                             const int32_t* up_rowsum, const float* x_scale, const float* x_offset,
                             const float* gate_w_scale, const float* up_w_scale, int8_t* codes_out, const float* out_scale,

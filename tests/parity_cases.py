@@ -210,6 +210,27 @@ def check_weight_only_linear(device):
         torch.testing.assert_close(got, c["y"].float(), rtol=2.0**-7, atol=2e-4, msg=lambda m: f'{c["name"]} vs reference output: {m}')
 
 
+def check_linear_residual(device, shapes=((130, 64, 128), (256, 192, 256))):
+    """ABI 5: residual + linear inside the GEMM epilogue (reference quantized_llama/decoder.py:60-90 after nn/linear.py:32-39)
+    equals the two eager ops on the same launch's plain output, bit for bit: T(linear) then T(residual + .). Where the
+    backend does not cover the shape it says so (None) instead of computing something else."""
+    for m, n, k in shapes:
+        g = torch.Generator().manual_seed(m + n + k)
+        xq = torch.randint(-128, 128, (m, k), generator=g, dtype=torch.int8).to(device)
+        wq = torch.randint(-128, 128, (n, k), generator=g, dtype=torch.int8).to(device)
+        sx, ox = torch.tensor([0.017]).to(device), torch.tensor([5.0]).to(device)
+        sw = (torch.rand(n, generator=g) * 1e-3 + 2e-4).to(device)
+        for dtype in (torch.bfloat16, torch.float16):
+            residual = (torch.randn(m, n, generator=g) * 3).to(dtype).to(device)
+            plain = ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=dtype)
+            fused = ops.linear_w8a8_residual(xq, wq, sx, ox, sw, residual)
+            if fused is None:
+                continue
+            assert fused.dtype == dtype and torch.equal(fused, residual + plain), f"{(m, n, k)} {dtype}: {int((fused != residual + plain).sum())} differ"
+            stream = residual.clone()
+            assert ops.linear_w8a8_residual(xq, wq, sx, ox, sw, stream, inplace=True) is stream and torch.equal(stream, fused)
+
+
 def check_linear_large(device):
     """Fixture G18: the reference's W8A8 QuantizedLinear at a size the 256 x 256-tile persistent GEMM takes (2048 tokens,
     N = 2048, K = 512). Parameters and all codes (through their row sums) bit-exact; the output within the reference's own

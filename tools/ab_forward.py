@@ -12,7 +12,7 @@ llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
 gen = torch.Generator(device=dev).manual_seed(4321)
 batch = torch.randint(0, cfg.vocab_size, (8, 2048), device=dev, generator=gen)
 llama.calibrate(model, [torch.randint(0, cfg.vocab_size, (8, 2048), device=dev, generator=gen) for _ in range(2)], fused=True)
-variants = {"default": {}, "fuse_rowsums=True": {"fuse_rowsums": True}, "fuse_attention=False": {"fuse_attention": False}, "fuse_mlp=False": {"fuse_mlp": False}}
+variants = {"default": {}, "fuse_residual=True": {"fuse_residual": True}, "fuse_rowsums=True": {"fuse_rowsums": True}, "fuse_attention=False": {"fuse_attention": False}, "fuse_mlp=False": {"fuse_mlp": False}}
 for rep in range(2):
     for name, kw in variants.items():
         f = llama.FusedForward(model, **kw)
