@@ -2089,7 +2089,7 @@ static int linear_w8a8_launch(const int8_t* xq, const int8_t* wq, const int32_t*
                              (getenv("FFQ_GEMM_FL") ? atoi(getenv("FFQ_GEMM_FL")) : 1) && !getenv("FFQ_GEMM_V1") && !getenv("FFQ_GEMM_V2") &&
                              !getenv("FFQ_GEMM_NW") && !getenv("FFQ_GEMM_4W");
     const int64_t tiles = ((M + BM2 - 1) / BM2) * ((N + 255) / 256);
-    if (!fq_on || K % 128 != 0 || K < 256 || M < 128 || N % 64 != 0 || tiles < 64)
+    if (!fq_on || K % 128 != 0 || K < 256 || M < 128 || N < 128 || N % 64 != 0 || tiles < 64)
       return fail(FFQ_ERR_DTYPE, "fused residual add: shape outside the persistent kernel (K %% 128, N %% 64, >= 64 tiles)");
   }
   static const int use_4w = getenv("FFQ_GEMM_4W") ? atoi(getenv("FFQ_GEMM_4W")) : 0;
@@ -2193,6 +2193,7 @@ static int linear_w8a8_launch(const int8_t* xq, const int8_t* wq, const int32_t*
     const int bn = nw * 32;
     a.tiles_m = (int)((M + BM2 - 1) / BM2);
     a.tiles_n = (int)((N + bn - 1) / bn);
+    if (residual) return fail(FFQ_ERR_LAUNCH, "internal: the residual add reached a kernel that does not implement it");
     const unsigned grid2 = (unsigned)(a.tiles_m * a.tiles_n);
     const size_t ring_bytes = (size_t)STAGES2 * (BM2 + bn) * BK2;
     const size_t epilogue_bytes = (size_t)nw * (128 * 144 + 256);  // one padded 128 x 64 bf16 tile per wave
@@ -2231,6 +2232,7 @@ static int linear_w8a8_launch(const int8_t* xq, const int8_t* wq, const int32_t*
     return check_launch("w8a8_gemm256_kernel");
   }
   // 128^2 kernel (small problems, K tails): row sums by a separate one-pass reduction
+  if (residual) return fail(FFQ_ERR_LAUNCH, "internal: the residual add reached a kernel that does not implement it");
   if (w_offset) {  // needs sum_k xq[m,k]
     rowsum_i8_kernel<<<(unsigned)((M + 3) / 4), 256, 0, s>>>(xq, (int)M, (int)K, ws);
     a.rowsum_x = ws;

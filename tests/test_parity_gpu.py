@@ -715,6 +715,10 @@ def test_linear_with_the_residual_add_in_its_epilogue():
     wq = torch.zeros(64, 128, dtype=torch.int8, device=DEV)
     one = torch.ones(1, device=DEV)
     assert ops.linear_w8a8_residual(xq, wq, one, None, torch.ones(64, device=DEV), torch.zeros(130, 64, device=DEV, dtype=torch.bfloat16)) is None
+    # enough tiles but fewer than 128 columns: the persistent kernel is not the one that would run
+    xq = torch.zeros(16384, 256, dtype=torch.int8, device=DEV)
+    wq = torch.zeros(64, 256, dtype=torch.int8, device=DEV)
+    assert ops.linear_w8a8_residual(xq, wq, one, None, torch.ones(64, device=DEV), torch.zeros(16384, 64, device=DEV, dtype=torch.bfloat16)) is None
 
 
 # ---- weight-only linear (row *J: quantized weight x plain bf16 input, fallback.py:86-112) ---------------------------
