@@ -1826,8 +1826,10 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   if constexpr (MLP) silu_table_fill(silu_table, (uint32_t)tid, 512u);
 
   const int d_row = lane >> 3;
-  const int8_t* a_src[4];
-  const int8_t* b_src[4];
+  // DMA sources as (wave-uniform base pointer + 32-bit lane offset): the k offset of a super-step goes into the uniform
+  // part, so the loop spends SALU, not VALU, on addresses (global_load_lds saddr form; VALU is not hidden under MFMAs)
+  uint32_t a_voff[4], b_voff[4];
+  const int8_t* b_base[4];
   int m0 = 0, n0 = 0;
   auto tile_origin = [&](int it, int& tm0, int& tn0) {
     const uint32_t tile_id = xcd_first + j_in_xcd + (uint32_t)it * blocks_in_xcd;
@@ -1845,14 +1847,17 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
       const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
       int ra = tm0 + row;
       ra = ra < a.M ? ra : a.M - 1;
-      a_src[c] = a.xq + (size_t)ra * a.K + d_slot * 16;
+      a_voff[c] = (uint32_t)ra * (uint32_t)a.K + d_slot * 16;   // M * K < 2^32 (checked by the launcher)
       if constexpr (MLP) {
         const int rb = tn0 + (row >> 6) * 32 + (row & 31);
-        b_src[c] = ((row & 32) ? a.wq2 : a.wq) + (size_t)rb * a.K + d_slot * 16;
+        // rows 32..63 of a wave's 64 come from the up matrix: row & 32 is the same for all lanes of a piece (8 rows per piece)
+        b_base[c] = (((wave * 4 + c) * 8) & 32) ? a.wq2 : a.wq;
+        b_voff[c] = (uint32_t)rb * (uint32_t)a.K + d_slot * 16;
       } else {
         int rb = tn0 + row;
         rb = rb < a.N ? rb : a.N - 1;
-        b_src[c] = a.wq + (size_t)rb * a.K + d_slot * 16;
+        b_base[c] = a.wq;
+        b_voff[c] = (uint32_t)rb * (uint32_t)a.K + d_slot * 16;
       }
     }
   };
@@ -1860,13 +1865,13 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
     uint8_t* base = lds2 + slot * SLOT_BYTES;
 #pragma unroll
     for (int c = c0; c < c0 + 2; ++c)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[c] + ks * 128), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((a.xq + ks * 128) + a_voff[c]), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
   };
   auto issue_b = [&](int ks, int slot, int c0) {
     uint8_t* base = lds2 + slot * SLOT_BYTES + B_IMAGE;
 #pragma unroll
     for (int c = c0; c < c0 + 2; ++c)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_src[c] + ks * 128), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)((b_base[c] + ks * 128) + b_voff[c]), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
   };
 
   // fragment byte offsets inside a slot: [row tile][k-chunk]
@@ -2110,7 +2115,8 @@ static int linear_w8a8_launch(const int8_t* xq, const int8_t* wq, const int32_t*
                              (getenv("FFQ_GEMM_FL") ? atoi(getenv("FFQ_GEMM_FL")) : 1) && !getenv("FFQ_GEMM_V1") && !getenv("FFQ_GEMM_V2") &&
                              !getenv("FFQ_GEMM_NW") && !getenv("FFQ_GEMM_4W");
     const int64_t tiles = ((M + BM2 - 1) / BM2) * ((N + 255) / 256);
-    if (!fq_on || K % 128 != 0 || K < 256 || M < 128 || N < 128 || N % 64 != 0 || tiles < 64)
+    if (!fq_on || K % 128 != 0 || K < 256 || M < 128 || N < 128 || N % 64 != 0 || tiles < 64 ||
+        (uint64_t)M * (uint64_t)K >= (1ull << 32) || (uint64_t)N * (uint64_t)K >= (1ull << 32))
       return fail(FFQ_ERR_DTYPE, "fused residual add: shape outside the persistent kernel (K %% 128, N %% 64, >= 64 tiles)");
   }
   static const int use_4w = getenv("FFQ_GEMM_4W") ? atoi(getenv("FFQ_GEMM_4W")) : 0;
@@ -2148,7 +2154,9 @@ static int linear_w8a8_launch(const int8_t* xq, const int8_t* wq, const int32_t*
       const bool fl = use_fl && K % 128 == 0;
       static const int use_fp = getenv("FFQ_GEMM_FP") ? atoi(getenv("FFQ_GEMM_FP")) : 1;  // persistent tile loop: +4.9 % (A/B on one box)
       const bool fp = fl && use_fp && !w_offset;
-      static const int use_fq = getenv("FFQ_GEMM_FQ") ? atoi(getenv("FFQ_GEMM_FQ")) : 1;  // v_mfma_i32_16x16x64_i8 form of the persistent kernel
+      static const int fq_env = getenv("FFQ_GEMM_FQ") ? atoi(getenv("FFQ_GEMM_FQ")) : 1;  // v_mfma_i32_16x16x64_i8 form of the persistent kernel
+      // (its DMA addresses are a uniform base + a 32-bit lane offset: operands below 4 GiB each, else the 32x32x32 form)
+      const bool use_fq = fq_env && (uint64_t)M * (uint64_t)K < (1ull << 32) && (uint64_t)N * (uint64_t)K < (1ull << 32);
       const unsigned grid_fp = grid3 < 256u ? grid3 : 256u;  // persistent: one block per CU
       const size_t lds_fp = (size_t)2 * (BM2 + 256) * 128;
 #define FFQ_GEMM3_FP(T, RQ)                                                                                \
@@ -2366,7 +2374,8 @@ extern "C" int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fp);
     }
     const int total = a.tiles_m * a.tiles_n;
-    static const int use_fq = getenv("FFQ_GEMM_FQ") ? atoi(getenv("FFQ_GEMM_FQ")) : 1;
+    static const int fq_env = getenv("FFQ_GEMM_FQ") ? atoi(getenv("FFQ_GEMM_FQ")) : 1;
+    const bool use_fq = fq_env && (uint64_t)M * (uint64_t)K < (1ull << 32) && (uint64_t)N * (uint64_t)K < (1ull << 32);
     if (use_fq) w8a8_gemm256fq_kernel<int8_t, true, true><<<(unsigned)(total < 256 ? total : 256), 512, lds_fp, s>>>(a, total);
     else w8a8_gemm256fp_kernel<int8_t, true, true><<<(unsigned)(total < 256 ? total : 256), 512, lds_fp, s>>>(a, total);
     return check_launch("w8a8_gemm256fp_kernel (mlp mode)");
