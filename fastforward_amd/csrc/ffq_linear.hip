@@ -1546,6 +1546,9 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fp_kernel(LinearArgs a, in
 //   * accumulator layout (operands swapped as before, so a lane owns ONE output row): tile (mi, nj), register t:
 //     row m = 16 mi + lane % 16, column n = 16 nj + 4 (lane / 16) + t.
 // -------------------------------------------------------------------------------------------------
+#ifndef FFQ_Y
+#define FFQ_Y 3  // 3 = LDS-DMA as inline assembly in the saddr form (default); 0 = the builtin
+#endif
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
 template <typename T> __device__ __forceinline__ float half_bits_to_f32(uint32_t bits);  // 16-bit pattern -> value
@@ -1864,14 +1867,28 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   auto issue_a = [&](int ks, int slot, int c0) {
     uint8_t* base = lds2 + slot * SLOT_BYTES;
 #pragma unroll
-    for (int c = c0; c < c0 + 2; ++c)
+    for (int c = c0; c < c0 + 2; ++c) {
+#if FFQ_Y == 3  // the saddr form spelled out (the builtin gets it in one of the loop's two unrolled bodies only)
+      const int8_t* ub = a.xq + ks * 128;
+      const uint32_t lds_addr = (uint32_t)(uintptr_t)(base + (wave * 4 + c) * 1024);
+      asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(a_voff[c]), "s"(ub), "s"(lds_addr) : "memory", "m0");
+#else
       __builtin_amdgcn_global_load_lds((gbl_void_t*)((a.xq + ks * 128) + a_voff[c]), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+#endif
+    }
   };
   auto issue_b = [&](int ks, int slot, int c0) {
     uint8_t* base = lds2 + slot * SLOT_BYTES + B_IMAGE;
 #pragma unroll
-    for (int c = c0; c < c0 + 2; ++c)
+    for (int c = c0; c < c0 + 2; ++c) {
+#if FFQ_Y == 3
+      const int8_t* ub = b_base[c] + ks * 128;
+      const uint32_t lds_addr = (uint32_t)(uintptr_t)(base + (wave * 4 + c) * 1024);
+      asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(b_voff[c]), "s"(ub), "s"(lds_addr) : "memory", "m0");
+#else
       __builtin_amdgcn_global_load_lds((gbl_void_t*)((b_base[c] + ks * 128) + b_voff[c]), (lds_void_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+#endif
+    }
   };
 
   // fragment byte offsets inside a slot: [row tile][k-chunk]
