@@ -19,7 +19,7 @@ from fastforward_amd.exceptions import QuantizationError
 
 FFQ_MAX_DIMS = 8
 FFQ_MAX_FANOUT = 3
-FFQ_ABI_VERSION = 5
+FFQ_ABI_VERSION = 6
 
 
 class Status(enum.IntEnum):
@@ -146,7 +146,7 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_linear_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "ffq_linear_w8a8": (
         _i,
-        [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp],
+        [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _d, _i, _i64, _i64, _i64, _vp, _sz, _vp],
     ),
     "ffq_gptq_block": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _d, _vp]),
     "ffq_pack_gguf_blocks": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
@@ -157,17 +157,11 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_quantize_backward_workspace_bytes": (_sz, [_tp]),
     "ffq_quantize_by_tile_backward": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _i64, _tp, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ffq_mlp_gate_up_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64]),
-    "ffq_mlp_gate_up_w8a8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "ffq_mlp_gate_up_w8a8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ffq_add_rmsnorm_quantize": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _d, _vp, _fp, _vp]),
     "ffq_silu_mul_quantize": (_i, [_vp, _vp, _i, _i64, _vp, _fp, _vp]),
     "ffq_rope_inplace": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _i64, _vp, _vp, _vp]),
     "ffq_quantize_rows_rowsum": (_i, [_vp, _i, _vp, _vp, _i64, _i64, _d, _vp, _vp, _vp]),
-    "ffq_linear_w8a8_rs": (
-        _i,
-        [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp],
-    ),
-    "ffq_linear_w8a8_residual": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i64, _i64, _vp, _sz, _vp]),
-    "ffq_mlp_gate_up_w8a8_rs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ffq_linear_wq_supported": (_i, [_i, _i, _i, _i64, _i64, _i64, _i64]),
     "ffq_linear_wq": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i64, _i64, _vp, _i, _vp, _i, _i64, _i64, _i64, _vp]),
     "ffq_attention": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _d, _i, _vp, _vp, _vp, _vp, _d, _vp]),

@@ -322,11 +322,9 @@ extern "C" int ffq_attention(const void* q, const void* k, const void* v, int dt
   a.hi = codes_out ? (float)(half - 1.0) : 0.0f;
   const int64_t blocks = (int64_t)a.nqb * q_heads * batch;
   if (blocks >= ((int64_t)1 << 31)) return fail(FFQ_ERR_ARG, "too many workgroups");
-  static uint64_t once = 0;
-  if (first_use_on_this_device(&once)) {  // 72 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-  }
+  static uint64_t once_causal = 0, once_full = 0;  // 72 KiB of dynamic LDS: above the 64 KiB a kernel gets without asking
+  if (causal) ensure_dynamic_lds(&once_causal, reinterpret_cast<const void*>(attention_fwd_kernel<true>), kLdsBytes);
+  else ensure_dynamic_lds(&once_full, reinterpret_cast<const void*>(attention_fwd_kernel<false>), kLdsBytes);
   const dim3 grid((unsigned)blocks), block(kWaves * 64);
   if (causal) attention_fwd_kernel<true><<<grid, block, kLdsBytes, s>>>(a);
   else attention_fwd_kernel<false><<<grid, block, kLdsBytes, s>>>(a);

@@ -179,15 +179,17 @@ __device__ inline int64_t generic_tile_of(const GenericTiling& g, int64_t flat) 
   return tile;
 }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: "done once" flags are bit masks indexed by the current
-// device, so a process that launches on several GPUs raises the attribute on each of them (ops.py:91).
-inline bool first_use_on_this_device(uint64_t* mask) {
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: "done" flags are bit masks indexed by the current device,
+// so a process that launches on several GPUs raises the attribute on each of them. The bit is set AFTER the attribute call
+// returned (a second host thread that finds it clear repeats the call, which is harmless; one that finds it set may launch);
+// devices beyond the mask's 64 bits are not cached at all.
+inline void ensure_dynamic_lds(uint64_t* mask, const void* kernel, int bytes) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const uint64_t bit = (uint64_t)1 << (dev & 63);
-  if (__atomic_load_n(mask, __ATOMIC_RELAXED) & bit) return false;
-  __atomic_fetch_or(mask, bit, __ATOMIC_RELAXED);
-  return true;
+  const uint64_t bit = (dev >= 0 && dev < 64) ? (uint64_t)1 << dev : 0;
+  if (bit && (__atomic_load_n(mask, __ATOMIC_ACQUIRE) & bit)) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (bit) __atomic_fetch_or(mask, bit, __ATOMIC_RELEASE);
 }
 
 // The inverse walk: flat offset of element `e` (row-major inside the tile) of tile `tile` (row-major over the tile grid),

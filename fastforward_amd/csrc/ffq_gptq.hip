@@ -86,10 +86,6 @@ extern "C" int ffq_gptq_block(float* weights, float* quantized, float* errors, i
   a.offset_stride = offset_numel == 1 ? 0 : 1;
   const double lo = -pow(2.0, num_bits - 1.0);
   a.lo = (float)lo; a.hi = (float)(-lo - 1.0);
-  static uint64_t attr_set = 0;
-  if (first_use_on_this_device(&attr_set)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gptq_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 0);
-  }
   gptq_block_kernel<<<(unsigned)((rows + kBlock - 1) / kBlock), kBlock, 0, s>>>(a);
   return check_launch("gptq_block_kernel");
 }

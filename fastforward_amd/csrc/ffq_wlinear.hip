@@ -589,9 +589,7 @@ extern "C" int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w
 #define FFQ_WL_LAUNCH(G, O, T)                                                                                              \
   do {                                                                                                                      \
     static uint64_t attr_set = 0;                                                                                           \
-    if (first_use_on_this_device(&attr_set))                                                                                \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wq_bf16_gemm256_kernel<G, O, T>),                            \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                                \
+    ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_bf16_gemm256_kernel<G, O, T>), (int)lds_bytes);         \
     wq_bf16_gemm256_kernel<G, O, T><<<grid, 512, lds_bytes, s>>>(a);                                                        \
   } while (0)
 #define FFQ_WL_DISPATCH(T)                                                                                                  \

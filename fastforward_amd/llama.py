@@ -338,8 +338,7 @@ class FusedForward:
     per-channel activations, biases — instead of silently computing something else.
     """
 
-    def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True, fuse_attention: bool = True, fuse_rowsums: bool = False,
-                 fuse_residual: bool = False) -> None:
+    def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True, fuse_attention: bool = True, fuse_rowsums: bool = False) -> None:
         problems = self.unsupported(model)
         if problems:
             raise ff.exceptions.QuantizationError("FusedForward cannot run this model: " + "; ".join(problems[:4]))
@@ -356,12 +355,6 @@ class FusedForward:
         # runs): the int8 GEMMs that follow run slower by more than the reduction cost (tools/gemm_cache_probe.py: a GEMM
         # preceded by more memory-bound work is faster — the chip is power-limited and the light pass lets it recover).
         self.fuse_rowsums = fuse_rowsums
-        # the residual adds behind o_proj / down_proj inside those GEMMs' epilogues (ops.linear_w8a8_residual): the RMSNorm that
-        # follows then reads ONE tensor and writes only codes (3 B/elem instead of 7). OFF by default: measured neutral — the
-        # epilogue's residual reads cost the GEMM 27-32 us per launch (their latency is only one 32-row slab deep), the RMSNorm
-        # saves 35 us (tools/residual_time.py: pair 301.6 -> 299.0 us on o_proj, 823.1 -> 815.8 us on down_proj; forward 130.8 vs
-        # 130.9 ms, tools/ab_forward.py)
-        self.fuse_residual = fuse_residual
         self._zero_offset: dict[int, tuple[int, bool]] = {}
         self._weight_cache: dict[int, tuple[tuple[int, int, int], tuple[torch.Tensor, torch.Tensor | None]]] = {}
         self._rowsum_rows = sum(linear.weight.shape[0] for _, linear in decoder_linears(model))
@@ -503,27 +496,17 @@ class FusedForward:
         codes, rowsum = self._quantize_weight(linear)
         return codes, rowsum, wq.scale, wq.offset
 
-    def _linear(self, x_codes: torch.Tensor, linear: torch.nn.Module, residual: torch.Tensor | None = None) -> torch.Tensor | None:
-        """The int8 GEMM of one quantized linear. With `residual` (the decoder's residual stream, bf16): residual +=
-        linear(...) inside the GEMM's epilogue where the kernel covers it, and None is returned; otherwise the linear's own
-        output (which the RMSNorm kernel that follows adds to the stream). The weight is quantized once either way."""
+    def _linear(self, x_codes: torch.Tensor, linear: torch.nn.Module) -> torch.Tensor:
+        """The int8 GEMM of one quantized linear (the RMSNorm kernel that follows adds its output to the residual stream)."""
         w_codes, w_rowsum, w_scale, w_offset = self._weight(linear)
         if w_offset is not None and self._symmetric_weights(linear):
-            w_offset = None  # an all-zero offset buffer: same result, no device-side offset check in the kernel
+            w_offset = None  # an all-zero offset buffer: same result without the GEMM's device-side offset check
         x_scale, x_offset = self._params(linear)
-        fusable = (residual is not None and w_offset is None and w_scale.numel() == w_codes.shape[0] and x_scale.numel() == 1
-                   and residual.dtype == torch.bfloat16 and residual.is_contiguous())
-
-        def launch() -> torch.Tensor | None:
-            if fusable and ff.ops.linear_w8a8_residual(x_codes, w_codes, x_scale, x_offset, w_scale, residual, w_rowsum=w_rowsum, inplace=True) is not None:
-                return None
-            return ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16, w_rowsum=w_rowsum)
-
         if self.linear_events is None:
-            return launch()
+            return ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16, w_rowsum=w_rowsum)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
-        out = launch()
+        out = ff.ops.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, None, out_dtype=torch.bfloat16, w_rowsum=w_rowsum)
         end.record()
         self.linear_events.append((w_codes.shape[0], w_codes.shape[1], start, end))
         return out
@@ -539,7 +522,7 @@ class FusedForward:
             self.refresh()
         hidden = model.embed_tokens(input_ids)
         cos, sin = rotary_tables(s, d, cfg.rope_theta, hidden.device, hidden.dtype)
-        pending: torch.Tensor | None = None  # down_proj's output where its residual add was NOT fused into the GEMM
+        pending: torch.Tensor | None = None  # down_proj's output: the next RMSNorm launch adds it to the residual stream
         if self.fuse_rowsums:  # the weight row sums of this forward: one zero fill, slices handed out as the weights are quantized
             self._rowsum_pool = torch.zeros(self._rowsum_rows, dtype=torch.int32, device=hidden.device)
             self._rowsum_used = 0
@@ -561,11 +544,11 @@ class FusedForward:
             else:
                 ctx = _sdpa(q, k, v, cfg, b, s)
                 o_codes = ff.ops.quantize_by_tile(ctx, o_in.scale, ctx.shape, o_in.num_bits, torch.int8, o_in.offset)
-            attn_out = self._linear(o_codes, attn.o_proj, residual=hidden if self.fuse_residual else None)  # None: already in `hidden`
+            attn_out = self._linear(o_codes, attn.o_proj)
             pairs, index = fan["gate_up"]
             hidden, _, codes = ff.ops.add_rmsnorm_quantize(
                 hidden, attn_out, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon,
-                pairs, mlp.gate_proj.input_quantizer.num_bits, sum_inplace=attn_out is not None,
+                pairs, mlp.gate_proj.input_quantizer.num_bits, sum_inplace=True,
             )
             d_in = mlp.down_proj.input_quantizer
             d_codes = None
@@ -585,7 +568,7 @@ class FusedForward:
                 gate = self._linear(codes[index[0]], mlp.gate_proj)
                 up = self._linear(codes[index[1]], mlp.up_proj)
                 _, (d_codes,) = ff.ops.silu_mul_quantize(gate, up, [(d_in.scale, d_in.offset)], d_in.num_bits)
-            pending = self._linear(d_codes, mlp.down_proj, residual=hidden if self.fuse_residual else None)  # None: already in `hidden`
+            pending = self._linear(d_codes, mlp.down_proj)
         _, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, model.norm.weight, model.norm.variance_epsilon, (), want_sum=False, want_norm=True)
         if not logits:
             return normed
@@ -631,10 +614,9 @@ class FusedProducersForward:
         xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
         if xp.scale.numel() != 1:
             return ff.nn.functional.linear(xq, wq, None, output_quantizer=linear.output_quantizer)
-        # an all-zero offset buffer of a symmetric weight quantizer (learned once per stable version, never during range
-        # estimation or graph capture: fused_linear._known_zero) lets the GEMM take its persistent form
-        w_offset = None if wp.offset is None or ff.fused_linear._known_zero(wp.offset) else wp.offset
-        return ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, None, out_dtype=torch.bfloat16)
+        # (an all-zero offset buffer of a symmetric weight quantizer is recognised by the GEMM on the device: no host read,
+        # also while a range estimator rewrites the parameters on every step)
+        return ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, wp.offset, None, out_dtype=torch.bfloat16)
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, logits: bool = False) -> torch.Tensor:

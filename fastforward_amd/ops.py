@@ -39,7 +39,6 @@ __all__ = [
     "linear_w8a8",
     "linear_wq",
     "mlp_gate_up_w8a8",
-    "linear_w8a8_residual",
     "add_rmsnorm_quantize",
     "silu_mul_quantize",
     "rope_",
@@ -582,12 +581,19 @@ def linear_w8a8(
     out_offset: torch.Tensor | None = None,
     out_num_bits: float = 8.0,
     w_rowsum: torch.Tensor | None = None,
+    requant_from: torch.dtype | None = None,
 ) -> torch.Tensor:
     """A6 — int8 codes in, real-valued (or re-quantized) linear output out.
 
     `x_codes` is [..., K] int8, `w_codes` is [N, K] int8. Scales/offsets are fp32 with one entry
     (per-tensor) or one per row (per-token for x, per-output-channel for w). `w_rowsum` (int32 [N], optional): the row
     sums of `w_codes` when the caller already has them (:func:`quantize_rows_rowsum`) — same result, one launch fewer.
+
+    With `out_scale` (and optionally `out_offset`) the output quantizer of reference _gen/fallback.py:110-111 runs in
+    the GEMM's epilogue: the linear's result is rounded to `requant_from` (the dtype the reference's float GEMM returns:
+    the input's dequantize dtype; default bf16), A1 is applied to it, and `out` holds the codes in the container
+    `out_dtype` — exactly ``quantize_by_tile(linear_w8a8(..., out_dtype=requant_from), out_scale, shape, bits, out_dtype,
+    out_offset)`` without the real-valued tensor's round trip through HBM.
     """
     if x_codes.dtype != torch.int8 or w_codes.dtype != torch.int8:
         raise TypeError("linear_w8a8 expects int8 codes")
@@ -616,63 +622,15 @@ def linear_w8a8(
     ws = _workspace(nbytes, xc.device)
     if w_rowsum is not None and (w_rowsum.dtype != torch.int32 or w_rowsum.numel() != N or not w_rowsum.is_contiguous() or w_rowsum.device != wc.device):
         raise RuntimeError(f"w_rowsum must be a contiguous int32 tensor with {N} entries on the codes' device")
+    y_dt = _tag(requant_from or torch.bfloat16) if os_ is not None else 0
     lib.check(
-        lib.ffq_linear_w8a8_rs(
+        lib.ffq_linear_w8a8(
             _ptr(xc), _ptr(wc), _ptr(w_rowsum), _ptr(xs), _ptr(xo), x_per_row, _ptr(ws_), _ptr(wo), w_per_row,
             _ptr(bias_c), _tag(bias_c.dtype) if bias_c is not None else 0, _ptr(out), _tag(out_dtype),
-            _ptr(os_), _ptr(oo), float(out_num_bits), M, N, K, _ptr(ws), nbytes, stream,
+            _ptr(os_), _ptr(oo), float(out_num_bits), y_dt, M, N, K, _ptr(ws), nbytes, stream,
         )
     )
     return out
-
-
-def linear_w8a8_residual(
-    x_codes: torch.Tensor,
-    w_codes: torch.Tensor,
-    x_scale: torch.Tensor,
-    x_offset: torch.Tensor | None,
-    w_scale: torch.Tensor,
-    residual: torch.Tensor,
-    w_rowsum: torch.Tensor | None = None,
-    inplace: bool = False,
-) -> torch.Tensor | None:
-    """``residual + linear_w8a8(x, w)`` with the add inside the GEMM's epilogue — the residual connection behind o_proj /
-    down_proj (reference quantized_llama/decoder.py:60-90): the linear's output rounded to the residual's dtype (bf16 / fp16),
-    then the add's rounding, exactly the two eager ops. Per-tensor activation parameters, per-output-channel symmetric
-    weights, no bias. ``inplace`` writes the sum over `residual` (the decoder's residual stream). Returns None where the
-    persistent kernel does not cover the shape (the caller runs :func:`linear_w8a8` and adds)."""
-    if x_codes.dtype != torch.int8 or w_codes.dtype != torch.int8:
-        raise TypeError("linear_w8a8_residual expects int8 codes")
-    xc, wc = x_codes.detach().contiguous(), w_codes.detach().contiguous()
-    K, N = xc.shape[-1], wc.shape[0]
-    M = xc.numel() // K if K else 0
-    if wc.dim() != 2 or wc.shape[1] != K:
-        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({M}x{K} and {tuple(wc.shape)}^T)")
-    if residual.dtype not in (torch.bfloat16, torch.float16) or residual.shape != (*xc.shape[:-1], N) or not residual.is_contiguous():
-        raise RuntimeError(f"residual must be a contiguous bf16 / fp16 tensor of shape {(*xc.shape[:-1], N)}")
-    res = residual.detach()
-
-    def f32(t: torch.Tensor | None, n: int) -> torch.Tensor | None:
-        if t is None:
-            return None
-        t = t.detach().reshape(-1).to(torch.float32).contiguous()
-        if t.numel() != n:
-            raise RuntimeError(f"expected {n} parameter entries, got {t.numel()}")
-        return t
-
-    xs, xo, ws_ = f32(x_scale, 1), f32(x_offset, 1), f32(w_scale, N)
-    lib, stream = _prepare(xc, wc, xs, xo, ws_, res)
-    if w_rowsum is not None and (w_rowsum.dtype != torch.int32 or w_rowsum.numel() != N or not w_rowsum.is_contiguous() or w_rowsum.device != wc.device):
-        raise RuntimeError(f"w_rowsum must be a contiguous int32 tensor with {N} entries on the codes' device")
-    out = res if inplace else torch.empty_like(res)
-    nbytes = lib.ffq_linear_w8a8_workspace_bytes(M, N, K)
-    ws = _workspace(nbytes, xc.device)
-    status = lib.ffq_linear_w8a8_residual(_ptr(xc), _ptr(wc), _ptr(w_rowsum), _ptr(xs), _ptr(xo), _ptr(ws_), _ptr(res), _ptr(out), _tag(res.dtype),
-                                          M, N, K, _ptr(ws), nbytes, stream)
-    if status == 6:
-        return None
-    lib.check(status)
-    return residual if inplace else out
 
 
 def linear_wq(
@@ -747,7 +705,7 @@ def mlp_gate_up_w8a8(
     M = xc.numel() // K if K else 0
     if gc.shape[1] != K:
         raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({M}x{K} and {tuple(gc.shape)}^T)")
-    if N % 128 or K % 64 or K < 256:
+    if N % 128 or K % 128 or K < 256:
         return None
 
     def f32(t: torch.Tensor | None, n: int) -> torch.Tensor | None:
@@ -766,7 +724,7 @@ def mlp_gate_up_w8a8(
     for rs in (gate_rowsum, up_rowsum):
         if rs is not None and (rs.dtype != torch.int32 or rs.numel() != N or not rs.is_contiguous() or rs.device != gc.device):
             raise RuntimeError(f"row sums must be contiguous int32 tensors with {N} entries on the codes' device")
-    status = lib.ffq_mlp_gate_up_w8a8_rs(
+    status = lib.ffq_mlp_gate_up_w8a8(
         _ptr(xc), _ptr(gc), _ptr(uc), _ptr(gate_rowsum), _ptr(up_rowsum), _ptr(xs), _ptr(xo), _ptr(gs), _ptr(us), _ptr(out), _ptr(os_), _ptr(oo),
         float(out_num_bits), M, N, K, _ptr(ws), nbytes, stream,
     )

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define FFQ_MAX_DIMS 8
-#define FFQ_ABI_VERSION 5
+#define FFQ_ABI_VERSION 6
 
 typedef enum ffq_status {
   FFQ_OK = 0,
@@ -179,16 +179,22 @@ int ffq_unpack_int4(const uint8_t* packed, int64_t numel, int64_t block, void* c
  *   y[m,n] = sx[m'] * sw[n'] * sum_k (xq[m,k] + ox[m']) * (wq[n,k] + ow[n'])  (+ bias[n])
  * with ox/ow = round_half_even(offset) (A2), m' = m if x_per_row else 0, n' likewise.
  * The contraction runs on int8 MFMA with int32 accumulation; the zero-point terms use row sums.
- * If out_scale != NULL the result is re-quantized (A1, per-tensor) into `out` instead
- * (the `output_quantizer` of fallback.py:110-111), else `out` holds y in out_dt (bf16/f16/f32).
+ * If out_scale != NULL the result is re-quantized in the same launch (the `output_quantizer` of fallback.py:110-111,
+ * per-tensor A1): y is rounded once to `y_dt` — the dtype the float GEMM of the reference returns, i.e. the input's
+ * dequantize dtype (nn/linear.py:32-39) — and codes = clamp(rne(y / out_scale - rne(out_offset))) go to `out` in the
+ * container `out_dt`; bit-identical to ffq_quantize_by_tile on the tensor the launch without out_scale writes. Else `out`
+ * holds y in out_dt (bf16/f16/f32) and y_dt is ignored.
+ * `w_rowsum` (nullable): sum_k wq[n, k] when the caller already has it (ffq_quantize_rows_rowsum) — one reduction launch
+ * fewer, same result. A weight offset whose rounded entries are all zero (the offset BUFFER of a symmetric quantizer,
+ * nn/linear_quantizer.py:164-170) is detected on the device and costs nothing but a 1-block check.
  * Tolerance vs the reference's bf16 eager path is stated in tests/parity_cases.py::check_linear (G6) and
  * tests/test_parity_gpu.py::test_w8a8_linear_*; exact-integer checks at full BASELINE sizes: tests/test_fullsize_gpu.py.
  */
 size_t ffq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);
-int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, const float* x_offset,
-                    int x_per_row, const float* w_scale, const float* w_offset, int w_per_row,
+int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                    const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset, int w_per_row,
                     const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
-                    const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
+                    const float* out_offset, double out_num_bits, int y_dt, int64_t M, int64_t N, int64_t K,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /*
@@ -312,13 +318,15 @@ int ffq_grid_sqerror_by_tile(const void* data, int dt, const float* scales, cons
  *   codes = A1( bf16(silu(bf16(gate_linear(x)))) * bf16(up_linear(x)) ;  out_scale, out_offset )
  * == ffq_silu_mul_quantize(ffq_linear_w8a8(x, gate -> bf16), ffq_linear_w8a8(x, up -> bf16)) exactly, without the two
  * bf16 projections ever visiting HBM. x: per-tensor (scale, offset); weights: per-output-channel scales, no offset
- * (symmetric); N % 128 == 0, K % 64 == 0, K >= 256.
+ * (symmetric); N % 128 == 0, K % 128 == 0, K >= 256. gate_rowsum / up_rowsum (nullable, both or neither): the row
+ * sums of the weight codes when the caller has them.
  */
 size_t ffq_mlp_gate_up_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);
-int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const float* x_scale,
-                         const float* x_offset, const float* gate_w_scale, const float* up_w_scale,
-                         int8_t* codes_out, const float* out_scale, const float* out_offset, double out_num_bits,
-                         int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const int32_t* gate_rowsum,
+                         const int32_t* up_rowsum, const float* x_scale, const float* x_offset,
+                         const float* gate_w_scale, const float* up_w_scale, int8_t* codes_out, const float* out_scale,
+                         const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * GGUF block-32 records — pack_q4_0_blocks / pack_q8_0_blocks, export/stages/gguf/_packing.py:23-72: `codes` is
@@ -350,34 +358,11 @@ int ffq_gptq_block(float* weights, float* quantized, float* errors, int64_t rows
  * forward (nn/linear.py:34), so the sums change with it. ffq_quantize_rows_rowsum is A1 for a [rows, cols] weight with one
  * (scale, offset) per row (PerChannel(0), `offset` nullable), int8 container, that also ADDS sum_k codes[r, k] to rowsum[r]
  * (exact integers: int32 atomics; the caller zeroes `rowsum` first — one fill for all the weights of a forward); codes are bit-identical to ffq_quantize_by_tile. bf16 data, cols % 1024 == 0, anything
- * else returns FFQ_ERR_DTYPE and the caller takes ffq_quantize_by_tile. The *_rs forms of the two GEMM entry points take
- * such sums (nullable: NULL = compute them from the codes as before) instead of launching their own reduction; results are
- * identical to the forms without.
+ * else returns FFQ_ERR_DTYPE and the caller takes ffq_quantize_by_tile. The two GEMM entry points take such sums (nullable:
+ * NULL = compute them from the codes) instead of launching their own reduction; results are identical.
  */
 int ffq_quantize_rows_rowsum(const void* data, int data_dt, const float* scale, const float* offset, int64_t rows,
                              int64_t cols, double num_bits, int8_t* codes, int32_t* rowsum, void* stream);
-int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
-                       const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset, int w_per_row,
-                       const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
-                       const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
-                       void* workspace, size_t workspace_bytes, void* stream);
-/*
- * ABI version 5. The residual add behind o_proj and down_proj of the reference's decoder layer
- * (docs/examples/doc_helpers/quantized_llama/decoder.py:60-90: hidden = residual + self_attn(...), hidden = residual + mlp(...))
- * inside the epilogue of A6: out = residual + T(linear(x, w)) with T = `out_dt` (bf16 / fp16) — the linear's output rounded
- * to T as nn/linear.py:32-39 leaves it, then ONE more rounding for the add, exactly the two eager ops. Per-tensor activation
- * parameters, per-output-channel symmetric weights, no bias (the Llama recipe). `out` may be `residual` itself (each element
- * is read before it is written, by the same lane). Shapes the persistent kernel does not cover return FFQ_ERR_DTYPE and the
- * caller runs ffq_linear_w8a8_rs and adds.
- */
-int ffq_linear_w8a8_residual(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
-                             const float* x_offset, const float* w_scale, const void* residual, void* out, int out_dt,
-                             int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
-int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const int32_t* gate_rowsum,
-                            const int32_t* up_rowsum, const float* x_scale, const float* x_offset,
-                            const float* gate_w_scale, const float* up_w_scale, int8_t* codes_out, const float* out_scale,
-                            const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
-                            void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * The attention between q/k/v_proj and o_proj of the reference's quantized Llama —

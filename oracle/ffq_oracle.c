@@ -622,16 +622,31 @@ size_t ffq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
  * accumulated in double, i.e. the exact value a float GEMM approximates; tests compare with the
  * tolerance stated there.
  */
-int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, const float* x_offset,
-                    int x_per_row, const float* w_scale, const float* w_offset, int w_per_row,
+static int check_rowsum(const char* what, const int8_t* wq, const int32_t* rowsum, int64_t N, int64_t K) {
+  if (!rowsum) return FFQ_OK;
+  for (int64_t n = 0; n < N; ++n) {
+    int32_t sum = 0;
+    for (int64_t k = 0; k < K; ++k) sum += wq[n * K + k];
+    if (sum != rowsum[n]) return fail(FFQ_ERR_ARG, "%s row sum %lld is %d, the codes sum to %d", what, (long long)n, rowsum[n], sum);
+  }
+  return FFQ_OK;
+}
+
+int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                    const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset, int w_per_row,
                     const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
-                    const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
+                    const float* out_offset, double out_num_bits, int y_dt, int64_t M, int64_t N, int64_t K,
                     void* workspace, size_t workspace_bytes, void* stream) {
   (void)workspace; (void)workspace_bytes; (void)stream;
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
   if (!xq || !wq || !x_scale || !w_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
-  int deq_dt = out_scale ? FFQ_BF16 : out_dt;
+  if (K > 0) {  /* sums handed in by the caller must be the sums of the codes */
+    int rc = check_rowsum("weight", wq, w_rowsum, N, K);
+    if (rc) return rc;
+  }
+  /* with an output quantizer, y_dt is the dtype F.linear returns (the input's dequantize dtype, nn/linear.py:32-39) */
+  int deq_dt = out_scale ? y_dt : out_dt;
   if (!dt_is_float(deq_dt)) return fail(FFQ_ERR_DTYPE, "real-valued output must be a float dtype");
   if (out_scale && !ffq_can_support_bitwidth(out_dt, out_num_bits))
     return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.",
@@ -988,18 +1003,19 @@ int ffq_grid_sqerror_by_tile(const void* data, int dt, const float* scales, cons
 /* mlp.py:30-40 composed from the restatements above: two A6 linears (bf16 outputs), SiLU * up, A1 */
 size_t ffq_mlp_gate_up_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K) { (void)K; return ffq_linear_w8a8_workspace_bytes(M, N, 0); }
 
-int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const float* x_scale,
-                         const float* x_offset, const float* gate_w_scale, const float* up_w_scale,
-                         int8_t* codes_out, const float* out_scale, const float* out_offset, double out_num_bits,
-                         int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const int32_t* gate_rowsum,
+                         const int32_t* up_rowsum, const float* x_scale, const float* x_offset,
+                         const float* gate_w_scale, const float* up_w_scale, int8_t* codes_out, const float* out_scale,
+                         const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
+                         void* workspace, size_t workspace_bytes, void* stream) {
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
-  if (N % 128 != 0 || K % 64 != 0 || K / 64 < 4)
-    return fail(FFQ_ERR_DTYPE, "fused gate/up kernel needs N %% 128 == 0, K %% 64 == 0, K >= 256 and 16-byte aligned buffers");
+  if (N % 128 != 0 || K % 128 != 0 || K < 256)
+    return fail(FFQ_ERR_DTYPE, "fused gate/up kernel needs N %% 128 == 0, K %% 128 == 0, K >= 256 and 16-byte aligned buffers");
   uint16_t* g = (uint16_t*)malloc((size_t)M * N * 2);
   uint16_t* u = (uint16_t*)malloc((size_t)M * N * 2);
-  int rc = ffq_linear_w8a8(xq, gate_wq, x_scale, x_offset, 0, gate_w_scale, NULL, 1, NULL, 0, g, FFQ_BF16, NULL, NULL, 8.0, M, N, K, workspace, workspace_bytes, stream);
-  if (!rc) rc = ffq_linear_w8a8(xq, up_wq, x_scale, x_offset, 0, up_w_scale, NULL, 1, NULL, 0, u, FFQ_BF16, NULL, NULL, 8.0, M, N, K, workspace, workspace_bytes, stream);
+  int rc = ffq_linear_w8a8(xq, gate_wq, gate_rowsum, x_scale, x_offset, 0, gate_w_scale, NULL, 1, NULL, 0, g, FFQ_BF16, NULL, NULL, 8.0, FFQ_BF16, M, N, K, workspace, workspace_bytes, stream);
+  if (!rc) rc = ffq_linear_w8a8(xq, up_wq, up_rowsum, x_scale, x_offset, 0, up_w_scale, NULL, 1, NULL, 0, u, FFQ_BF16, NULL, NULL, 8.0, FFQ_BF16, M, N, K, workspace, workspace_bytes, stream);
   if (!rc) {
     ffq_fanout fan;
     memset(&fan, 0, sizeof fan);
@@ -1180,61 +1196,4 @@ int ffq_quantize_rows_rowsum(const void* data, int data_dt, const float* scale, 
     rowsum[r] += sum; /* the caller zeroes the sums */
   }
   return FFQ_OK;
-}
-
-static int check_rowsum(const char* what, const int8_t* wq, const int32_t* rowsum, int64_t N, int64_t K) {
-  if (!rowsum) return FFQ_OK;
-  for (int64_t n = 0; n < N; ++n) {
-    int32_t sum = 0;
-    for (int64_t k = 0; k < K; ++k) sum += wq[n * K + k];
-    if (sum != rowsum[n]) return fail(FFQ_ERR_ARG, "%s row sum %lld is %d, the codes sum to %d", what, (long long)n, rowsum[n], sum);
-  }
-  return FFQ_OK;
-}
-
-int ffq_linear_w8a8_rs(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
-                       const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset, int w_per_row,
-                       const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
-                       const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
-                       void* workspace, size_t workspace_bytes, void* stream) {
-  if (wq && N > 0 && K > 0) {
-    int rc = check_rowsum("weight", wq, w_rowsum, N, K);
-    if (rc) return rc;
-  }
-  return ffq_linear_w8a8(xq, wq, x_scale, x_offset, x_per_row, w_scale, w_offset, w_per_row, bias, bias_dt, out, out_dt,
-                         out_scale, out_offset, out_num_bits, M, N, K, workspace, workspace_bytes, stream);
-}
-
-/* ABI 5: out = residual + T(linear) — the linear as above into a temporary of the output dtype, then the eager add
- * (decoder.py:60-90): float(residual) + float(y), one rounding to T. The oracle covers every shape. */
-int ffq_linear_w8a8_residual(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
-                             const float* x_offset, const float* w_scale, const void* residual, void* out, int out_dt,
-                             int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!residual) return fail(FFQ_ERR_ARG, "NULL residual");
-  if (!(out_dt == FFQ_BF16 || out_dt == FFQ_F16)) return fail(FFQ_ERR_DTYPE, "the fused residual add is built for bf16 / fp16 outputs");
-  if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
-  if (M == 0 || N == 0) return FFQ_OK;
-  uint16_t* y = (uint16_t*)malloc((size_t)M * (size_t)N * 2);
-  if (!y) return fail(FFQ_ERR_WORKSPACE, "out of memory");
-  int rc = ffq_linear_w8a8_rs(xq, wq, w_rowsum, x_scale, x_offset, 0, w_scale, NULL, 1, NULL, 0, y, out_dt, NULL, NULL, 8.0, M, N, K,
-                              workspace, workspace_bytes, stream);
-  if (!rc) {
-    for (int64_t i = 0; i < M * N; ++i) st(out, out_dt, i, op2(OP_ADD, ld(residual, out_dt, i), ld(y, out_dt, i), out_dt));
-  }
-  free(y);
-  return rc;
-}
-
-int ffq_mlp_gate_up_w8a8_rs(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const int32_t* gate_rowsum,
-                            const int32_t* up_rowsum, const float* x_scale, const float* x_offset,
-                            const float* gate_w_scale, const float* up_w_scale, int8_t* codes_out, const float* out_scale,
-                            const float* out_offset, double out_num_bits, int64_t M, int64_t N, int64_t K,
-                            void* workspace, size_t workspace_bytes, void* stream) {
-  if (gate_wq && up_wq && N > 0 && K > 0) {
-    int rc = check_rowsum("gate", gate_wq, gate_rowsum, N, K);
-    if (!rc) rc = check_rowsum("up", up_wq, up_rowsum, N, K);
-    if (rc) return rc;
-  }
-  return ffq_mlp_gate_up_w8a8(xq, gate_wq, up_wq, x_scale, x_offset, gate_w_scale, up_w_scale, codes_out, out_scale, out_offset,
-                              out_num_bits, M, N, K, workspace, workspace_bytes, stream);
 }

@@ -194,12 +194,13 @@ def check_weight_only_linear(device):
             with ff.estimate_ranges(model, ff.range_setting.running_minmax):
                 model(x)
             wq = lin.weight_quantizer(lin.weight)
-            assert ff.dispatcher.dispatch("linear", input=x, weight=wq, bias=lin.bias) is None  # opt-in (see fused_linear.py)
-            y_default = model(x)  # the reference's path: A2 + F.linear
-            with ff.fused_linear.weight_only_kernel(True):
-                assert ff.dispatcher.dispatch("linear", input=x, weight=wq, bias=lin.bias) is ff.fused_linear.fused_linear_weight_only, c["name"]
-                y = model(x)
-        torch.testing.assert_close(y_default.detach().cpu().float(), c["y"].float(), rtol=2.0**-7, atol=2e-4)
+            with ff.fused_linear.weight_only_kernel(False):  # the A/B arm: nobody claims it, the reference's path runs (A2 + F.linear)
+                assert ff.dispatcher.dispatch("linear", input=x, weight=wq, bias=lin.bias) is None
+                y_reference_path = model(x)
+            # default: the hand-written bf16 x weight-code GEMM
+            assert ff.dispatcher.dispatch("linear", input=x, weight=wq, bias=lin.bias) is ff.fused_linear.fused_linear_weight_only, c["name"]
+            y = model(x)
+        torch.testing.assert_close(y_reference_path.detach().cpu().float(), c["y"].float(), rtol=2.0**-7, atol=2e-4)
         assert same_with_nan(lin.weight_quantizer.scale.detach().cpu(), c["w_scale"]), c["name"]
         if c["w_offset"] is not None:
             assert same_with_nan(lin.weight_quantizer.offset.detach().cpu(), c["w_offset"]), c["name"]
@@ -208,27 +209,6 @@ def check_weight_only_linear(device):
         got = y.detach().cpu().float()
         torch.testing.assert_close(got, c["y_float64"], rtol=2.0**-8, atol=1e-4, msg=lambda m: f'{c["name"]}: {m}')
         torch.testing.assert_close(got, c["y"].float(), rtol=2.0**-7, atol=2e-4, msg=lambda m: f'{c["name"]} vs reference output: {m}')
-
-
-def check_linear_residual(device, shapes=((130, 64, 128), (256, 192, 256))):
-    """ABI 5: residual + linear inside the GEMM epilogue (reference quantized_llama/decoder.py:60-90 after nn/linear.py:32-39)
-    equals the two eager ops on the same launch's plain output, bit for bit: T(linear) then T(residual + .). Where the
-    backend does not cover the shape it says so (None) instead of computing something else."""
-    for m, n, k in shapes:
-        g = torch.Generator().manual_seed(m + n + k)
-        xq = torch.randint(-128, 128, (m, k), generator=g, dtype=torch.int8).to(device)
-        wq = torch.randint(-128, 128, (n, k), generator=g, dtype=torch.int8).to(device)
-        sx, ox = torch.tensor([0.017]).to(device), torch.tensor([5.0]).to(device)
-        sw = (torch.rand(n, generator=g) * 1e-3 + 2e-4).to(device)
-        for dtype in (torch.bfloat16, torch.float16):
-            residual = (torch.randn(m, n, generator=g) * 3).to(dtype).to(device)
-            plain = ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=dtype)
-            fused = ops.linear_w8a8_residual(xq, wq, sx, ox, sw, residual)
-            if fused is None:
-                continue
-            assert fused.dtype == dtype and torch.equal(fused, residual + plain), f"{(m, n, k)} {dtype}: {int((fused != residual + plain).sum())} differ"
-            stream = residual.clone()
-            assert ops.linear_w8a8_residual(xq, wq, sx, ox, sw, stream, inplace=True) is stream and torch.equal(stream, fused)
 
 
 def check_linear_large(device):

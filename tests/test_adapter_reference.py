@@ -82,13 +82,22 @@ def test_dispatcher_hooks_serve_the_reference_operators(oracle_backend, tmp_path
             before = [F.linear(qx, qw), F.mm(qx, qwt), F.matmul(qx, qwt), F.bmm(qxb, qwb), F.linear(x16, qw16)]
             attached = adapter.install(device_types=("cpu",), register_linear=True)
             assert {"dispatcher:linear", "dispatcher:linear(weight-only)", "dispatcher:mm", "dispatcher:matmul", "dispatcher:bmm"} <= set(attached)
-            assert ff_ref.dispatcher.dispatch("linear", input=qx, weight=qw) is adapter._reference_linear
-            assert ff_ref.dispatcher.dispatch("linear", input=x16, weight=qw16) is adapter._reference_weight_only_linear
-            assert ff_ref.dispatcher.dispatch("mm", input=qx, mat2=qwt) is adapter._reference_mm
-            assert ff_ref.dispatcher.dispatch("matmul", input=qx, other=qwt) is adapter._reference_mm
-            assert ff_ref.dispatcher.dispatch("bmm", input=qxb, mat2=qwb) is adapter._reference_bmm
+            assert ff_ref.dispatcher.dispatch("linear", input=qx, weight=qw) == adapter.REFERENCE_KERNELS.linear
+            assert ff_ref.dispatcher.dispatch("linear", input=x16, weight=qw16) == adapter.REFERENCE_KERNELS.weight_only_linear
+            assert ff_ref.dispatcher.dispatch("mm", input=qx, mat2=qwt) == adapter.REFERENCE_KERNELS.mm
+            assert ff_ref.dispatcher.dispatch("matmul", input=qx, other=qwt) == adapter.REFERENCE_KERNELS.mm
+            assert ff_ref.dispatcher.dispatch("bmm", input=qxb, mat2=qwb) == adapter.REFERENCE_KERNELS.bmm
             assert ff_ref.dispatcher.dispatch("linear", input=x, weight=w) is None  # nothing quantized: not ours
             after = [F.linear(qx, qw), F.mm(qx, qwt), F.matmul(qx, qwt), F.bmm(qxb, qwb), F.linear(x16, qw16)]
+            # the reference's own LinearQuantizer as output quantizer (fallback.py:110-111): fused into the GEMM's epilogue by the
+            # same code path this package's dispatcher uses; the result is the reference's QuantizedTensor with the same codes
+            oq = ff_ref.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=torch.int8)
+            oq.quantization_range = (float(before[0].min()), float(before[0].max()))
+            with torch.no_grad():
+                fused = F.linear(qx, qw, output_quantizer=oq)
+                two_pass = oq(after[0])
+            assert isinstance(fused, ff_ref.QuantizedTensor) and fused.raw_data.dtype == torch.int8
+            assert torch.equal(fused.raw_data, two_pass.raw_data) and torch.equal(fused.dequantize(), two_pass.dequantize())
         for a, b in zip(after, before):
             assert a.shape == b.shape and a.dtype == b.dtype
             torch.testing.assert_close(a.float(), b.float(), atol=1e-1, rtol=1.3e-2)

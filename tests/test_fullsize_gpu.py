@@ -128,24 +128,61 @@ def test_mlp_mode_equals_integer_ground_truth_at_full_size(n, k):
 
 @pytest.mark.parametrize("n,k", [(4096, 4096), (8192, 28672)], ids=lambda v: str(v))
 def test_weight_offset_and_per_token_paths_at_full_size(n, k):
-    """The non-persistent kernel forms (real weight offsets: in-loop activation row sums; per-token activation
-    parameters) against the exact integer contraction at T = 16384."""
+    """Real weight offsets (the ow * sum_k xq and K * ox * ow terms from the side reduction over the activation codes) and
+    per-token activation parameters in the persistent kernel at T = 16384: every output equals the fp32 epilogue restated
+    on the exact integer contraction and the exact row sums."""
     xq, wq, g = _codes(n, k, n - k)
     sx = torch.rand(T, device=DEV, generator=g) * 0.01 + 0.01
     ox = torch.round(torch.randn(T, device=DEV, generator=g) * 20)
     sw = torch.rand(n, device=DEV, generator=g) * 1e-3 + 2e-4
     ow = torch.round(torch.randn(n, device=DEV, generator=g) * 3)
     got = ops.linear_w8a8(xq, wq, sx, ox, sw, ow, out_dtype=torch.float32)
-    rsw = wq.sum(dim=1, dtype=torch.int64).double()
-    rsx = xq.sum(dim=1, dtype=torch.int64).double()
+    got16 = ops.linear_w8a8(xq, wq, sx, ox, sw, ow, out_dtype=torch.bfloat16)
+    rsw = wq.sum(dim=1, dtype=torch.int64).float()
+    rsx = xq.sum(dim=1, dtype=torch.int64).float()
     wq64 = wq.double()
-    for r0 in range(0, T, 2048 if n * k <= 4096 * 4096 else 1024):
-        rows = slice(r0, r0 + (2048 if n * k <= 4096 * 4096 else 1024))
-        acc = exact_accumulators(xq, wq64, rows).double()
-        full = acc + ox[rows].double()[:, None] * rsw[None, :] + ow.double()[None, :] * rsx[rows][:, None] + k * ox[rows].double()[:, None] * ow.double()[None, :]
-        ref = full * sx[rows].double()[:, None] * sw.double()[None, :]
-        torch.testing.assert_close(got[rows].double(), ref, rtol=2e-6, atol=2e-6 * float(ref.abs().max()))
-        del acc, full, ref
+    step = 2048 if n * k <= 4096 * 4096 else 1024
+    for r0 in range(0, T, step):
+        rows = slice(r0, r0 + step)
+        acc = exact_accumulators(xq, wq64, rows)
+        assert int(acc.abs().max()) < 2**24
+        # csrc/ffq_linear.hip: v = float(acc) + ox * rsw;  v += ow * rsx;  v += (K * ox) * ow;  y = (sx * sw) * v
+        v = acc.float() + ox[rows, None] * rsw[None, :]
+        v = v + ow[None, :] * rsx[rows, None]
+        v = v + (float(k) * ox[rows, None]) * ow[None, :]
+        y = (sx[rows, None] * sw[None, :]) * v
+        assert torch.equal(got[rows], y), f"rows {r0}..: {int((got[rows] != y).sum())} outputs differ"
+        assert torch.equal(got16[rows], y.to(torch.bfloat16))
+        del acc, v, y
+
+
+@pytest.mark.parametrize("n,k", LLAMA8B + [(28672, 8192)], ids=lambda v: str(v))
+def test_requantizing_epilogue_at_full_size(n, k):
+    """The output quantizer inside the GEMM's epilogue (fallback.py:110-111) at T = 16384: int8 codes == A1 (the kernel pinned
+    by G1-G3) of the bf16 tensor the plain launch's epilogue forms from the exact accumulators."""
+    xq, wq, g = _codes(n, k, 5 * n + k)
+    sx, ox = torch.tensor([0.0173], device=DEV), torch.tensor([11.3], device=DEV)
+    sw = torch.rand(n, device=DEV, generator=g) * 1e-3 + 2e-4
+    rsw = wq.sum(dim=1, dtype=torch.int64).float()
+    wq64 = wq.double()
+    chunk = 2048 if n * k <= 14336 * 4096 else 1024
+
+    def plain_output(rows):
+        return ((sx * sw)[None, :] * (exact_accumulators(xq, wq64, rows).float() + torch.round(ox) * rsw[None, :])).to(torch.bfloat16)
+
+    # a grid that resolves the output (about 50 steps per standard deviation... of which 256 exist: the tails clip)
+    so, oo = (plain_output(slice(0, chunk)).float().std() / 50).reshape(1), torch.tensor([-7.4], device=DEV)
+    got = ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.int8, out_scale=so, out_offset=oo, out_num_bits=8, requant_from=torch.bfloat16)
+    differing = 0
+    for r0 in range(0, T, chunk):
+        rows = slice(r0, r0 + chunk)
+        y = plain_output(rows)
+        want = ops.quantize_by_tile(y, so, y.shape, 8, torch.int8, oo)
+        differing += int((got[rows] != want).sum())
+        if r0 == 0:
+            assert float(want.float().std()) > 30 and int(want.max()) == 127 and int(want.min()) == -128  # a real grid that also clips
+        del y, want
+    assert differing == 0, f"{differing} of {got.numel()} codes differ"
 
 
 # ---- A1 / A2 / A4 on the 70B tensors (the 8B ones: tests/test_parity_gpu.py) ------------------------------------------

@@ -1,0 +1,210 @@
+"""The int8 GEMM family of csrc/ffq_linear.hip beyond the fixed BASELINE shapes: seeded random shapes, contraction
+lengths that take the tail kernel, real and all-zero weight offsets, and the output quantizer inside the epilogue.
+
+Ground truth is never another launch of the kernel under test: the accumulator is a float64 matmul of the codes on the
+device (exact below 2^53), the fp32 epilogue is restated with elementwise torch ops (one IEEE operation each, the order of
+csrc/ffq_linear.hip), and A1 of the re-quantizing epilogue is the A1 kernel (pinned by fixtures G1-G3) on that restated
+tensor. Reference path: src/fastforward/_gen/fallback.py:77-112 (dequantize, dequantize, F.linear, output quantizer).
+"""
+
+import random
+
+import pytest
+import torch
+
+import fastforward_amd as ff
+
+from fastforward_amd import ops
+from fastforward_amd.quantization.affine import function as affine_function
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _backend(hip_backend):
+    yield
+
+
+def _accumulators(xq: torch.Tensor, wq: torch.Tensor) -> torch.Tensor:
+    """sum_k xq[m, k] * wq[n, k], exact, as fp32 (|acc| < 2^24 for the sizes used here is asserted by the callers)."""
+    out = torch.empty(xq.shape[0], wq.shape[0], device=xq.device, dtype=torch.float32)
+    w64 = wq.double().T.contiguous()
+    for r0 in range(0, xq.shape[0], 4096):
+        acc = (xq[r0:r0 + 4096].double() @ w64).round()
+        assert float(acc.abs().max()) < 2**24
+        out[r0:r0 + 4096] = acc.float()
+    return out
+
+
+def _epilogue(acc, xq, wq, sx, ox, sw, ow, bias=None):
+    """csrc/ffq_linear.hip: v = float(acc) + ox * rowsum_w[n];  v += ow[n] * rowsum_x[m];  v += (K * ox) * ow[n];
+    y = (sx * sw[n]) * v (+ bias) — every step its own fp32 rounding."""
+    k = xq.shape[1]
+    v = acc
+    oxr = None if ox is None else torch.round(ox).reshape(-1, 1)
+    if oxr is not None:
+        v = v + oxr * wq.sum(dim=1, dtype=torch.int64).float()[None, :]
+    if ow is not None:
+        owr = torch.round(ow).reshape(1, -1)
+        v = v + owr * xq.sum(dim=1, dtype=torch.int64).float()[:, None]
+        v = v + (float(k) * (oxr if oxr is not None else torch.zeros(1, 1, device=acc.device))) * owr
+    y = (sx.reshape(-1, 1) * sw.reshape(1, -1)) * v
+    return y if bias is None else y + bias.float()[None, :]
+
+
+def _random_case(rng: random.Random, seed: int):
+    m = rng.choice([rng.randint(1, 300), rng.randint(129, 6000), 256 * rng.randint(1, 40), rng.randint(4000, 20000)])
+    n = rng.choice([8 * rng.randint(1, 40), 64 * rng.randint(2, 64), 128 * rng.randint(1, 40), rng.randint(1, 3000)])
+    k = rng.choice([16 * rng.randint(1, 40), 64 * rng.randint(1, 64), 128 * rng.randint(2, 48)])
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    xq = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+    wq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    return m, n, k, g, xq, wq
+
+
+@pytest.mark.parametrize("block", range(10))
+def test_gemm_fuzz(block):
+    """120 seeded random problems (12 per block): every size class of M / N / K, with and without activation offsets,
+    per-channel weight offsets that are real, all zero (the symmetric quantizer's buffer) or absent, per-token activation
+    parameters, bias, bf16 / fp16 / fp32 outputs; MLP mode where the shape admits it. Every output bit is checked."""
+    rng = random.Random(1000 + block)
+    for case in range(12):
+        m, n, k, g, xq, wq = _random_case(rng, 100 * block + case)
+        per_token = rng.random() < 0.2
+        sx = torch.rand(m if per_token else 1, device=DEV, generator=g) * 0.02 + 0.005
+        ox = None if rng.random() < 0.2 else torch.round(torch.randn(m if per_token else 1, device=DEV, generator=g) * 20)
+        sw = torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+        kind = rng.choice(["none", "none", "zero", "real"])
+        ow = None if kind == "none" else (torch.zeros(n, device=DEV) if kind == "zero" else torch.round(torch.randn(n, device=DEV, generator=g) * 3))
+        bias = torch.randn(n, device=DEV, generator=g).to(torch.bfloat16) if rng.random() < 0.25 else None
+        dtype = rng.choice([torch.bfloat16, torch.bfloat16, torch.float16, torch.float32])
+        acc = _accumulators(xq, wq)
+        want = _epilogue(acc, xq, wq, sx, ox, sw, ow, bias).to(dtype)
+        got = ops.linear_w8a8(xq, wq, sx, ox, sw, ow, bias=bias, out_dtype=dtype)
+        tag = f"block {block} case {case}: M={m} N={n} K={k} {dtype} ox={'-' if ox is None else ox.numel()} ow={kind} bias={bias is not None}"
+        assert torch.equal(got, want), f"{tag}: {int((got != want).sum())} of {want.numel()} outputs differ"
+        if n % 128 == 0 and k % 128 == 0 and k >= 256 and not per_token:
+            uq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+            su = torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+            so, oo = torch.tensor([0.02], device=DEV), torch.tensor([float(rng.randint(-10, 10))], device=DEV)
+            codes = ops.mlp_gate_up_w8a8(xq, wq, uq, sx, ox, sw, su, so, oo, 8)
+            assert codes is not None, tag
+            gate = _epilogue(acc, xq, wq, sx, ox, sw, None).to(torch.bfloat16)
+            up = _epilogue(_accumulators(xq, uq), xq, uq, sx, ox, su, None).to(torch.bfloat16)
+            z = torch.nn.functional.silu(gate) * up
+            assert torch.equal(codes, ops.quantize_by_tile(z, so, z.shape, 8, torch.int8, oo)), f"{tag}: MLP mode differs"
+
+
+@pytest.mark.parametrize("k", [320, 448, 576])
+@pytest.mark.parametrize("weight_offset", [None, "zero", "real"])
+def test_contraction_lengths_that_are_not_a_multiple_of_128(k, weight_offset):
+    """K = 64 (mod 128) at >= 64 tiles of 256 x 256: the persistent kernel's super-steps do not divide such a K, the
+    launcher routes it to the tail kernel (round 2 had an untested 64-byte-row ping-pong kernel here); MLP mode declines."""
+    m, n = 4096, 2048
+    g = torch.Generator(device=DEV).manual_seed(k)
+    xq = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+    wq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    sx, ox = torch.tensor([0.011], device=DEV), torch.tensor([7.0], device=DEV)
+    sw = torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+    ow = None if weight_offset is None else (torch.zeros(n, device=DEV) if weight_offset == "zero" else torch.round(torch.randn(n, device=DEV, generator=g) * 4))
+    want = _epilogue(_accumulators(xq, wq), xq, wq, sx, ox, sw, ow)
+    for dtype in (torch.bfloat16, torch.float32):
+        got = ops.linear_w8a8(xq, wq, sx, ox, sw, ow, out_dtype=dtype)
+        assert torch.equal(got, want.to(dtype)), f"{int((got != want.to(dtype)).sum())} outputs differ"
+    so, oo = torch.tensor([0.02], device=DEV), torch.tensor([3.0], device=DEV)
+    assert ops.mlp_gate_up_w8a8(xq, wq, wq, sx, ox, sw, sw, so, oo, 8) is None
+
+
+def test_all_zero_weight_offsets_cost_no_row_sums_and_change_nothing():
+    """The offset BUFFER of a symmetric quantizer (reference nn/linear_quantizer.py:164-170) at a persistent-kernel shape:
+    same bits as no offset at all; one non-zero entry switches the exact ow terms on (for every column)."""
+    m, n, k = 4096, 4096, 1024
+    g = torch.Generator(device=DEV).manual_seed(3)
+    xq = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+    wq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    sx, ox = torch.tensor([0.011], device=DEV), torch.tensor([-3.0], device=DEV)
+    sw = torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+    plain = ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.bfloat16)
+    zeros = torch.zeros(n, device=DEV)
+    assert torch.equal(ops.linear_w8a8(xq, wq, sx, ox, sw, zeros, out_dtype=torch.bfloat16), plain)
+    assert torch.equal(ops.linear_w8a8(xq, wq, sx, ox, sw, zeros + 0.4, out_dtype=torch.bfloat16), plain)  # rounds to zero (A2 rounds offsets)
+    one_hot = zeros.clone()
+    one_hot[n - 1] = 2.0
+    want = _epilogue(_accumulators(xq, wq), xq, wq, sx, ox, sw, one_hot).to(torch.bfloat16)
+    got = ops.linear_w8a8(xq, wq, sx, ox, sw, one_hot, out_dtype=torch.bfloat16)
+    assert torch.equal(got, want) and not torch.equal(got[:, -1], plain[:, -1]) and torch.equal(got[:, :-1], plain[:, :-1])
+
+
+# ---- the output quantizer inside the GEMM's epilogue (fallback.py:110-111) ----------------------------------------------------
+_REQUANT_SHAPES = [(40, 72, 256), (300, 200, 144), (2048, 2048, 512), (4099, 2304, 384)]
+
+
+@pytest.mark.parametrize("m,n,k", _REQUANT_SHAPES, ids=str)
+@pytest.mark.parametrize("container", [torch.int8, torch.bfloat16, torch.float32], ids=str)
+@pytest.mark.parametrize("y_dtype", [torch.bfloat16, torch.float16, torch.float32], ids=str)
+def test_requantizing_epilogue_is_a1_of_the_plain_output(m, n, k, container, y_dtype):
+    """codes == quantize_by_tile(y) where y is the linear's output in the dtype the reference's float GEMM returns, formed
+    from the EXACT accumulators (tail kernel and persistent kernel shapes, ragged edges, 8 and 4 bits, with / without offset)."""
+    g = torch.Generator(device=DEV).manual_seed(m + n + k)
+    xq = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+    wq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    sx, ox = torch.tensor([0.013], device=DEV), torch.tensor([5.0], device=DEV)
+    sw = torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+    y = _epilogue(_accumulators(xq, wq), xq, wq, sx, ox, sw, None).to(y_dtype)
+    spread = float(y.float().std())
+    for bits, so, oo in ((8, spread / 40, torch.tensor([-17.6], device=DEV)), (4, spread / 3, None), (8, spread * 30, torch.tensor([0.5], device=DEV))):
+        so = torch.tensor([so], device=DEV)
+        want = ops.quantize_by_tile(y, so, y.shape, bits, container, oo)
+        got = ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=container, out_scale=so, out_offset=oo, out_num_bits=bits, requant_from=y_dtype)
+        assert got.dtype == container and torch.equal(got, want), f"{bits} bits: {int((got != want).sum())} of {want.numel()} codes differ"
+        assert int(want.float().max() - want.float().min()) >= (0 if so > spread else 7)  # the fine grids are real grids, not saturated tensors
+
+
+def test_requantizing_epilogue_refuses_a_container_that_cannot_hold_the_codes():
+    xq = torch.zeros(16, 64, dtype=torch.int8, device=DEV)
+    one = torch.ones(1, device=DEV)
+    with pytest.raises(RuntimeError, match="not enough to store"):
+        ops.linear_w8a8(xq, xq, one, None, one, None, out_dtype=torch.int8, out_scale=one, out_num_bits=12)
+
+
+@pytest.mark.parametrize("quantized_dtype", [torch.int8, None], ids=["int8_container", "data_dtype_container"])
+def test_dispatcher_runs_a_static_output_quantizer_inside_the_gemm(quantized_dtype, monkeypatch):
+    """``ff.nn.functional.linear(xq, wq, output_quantizer=q)`` with a static per-tensor LinearQuantizer: ONE GEMM launch whose
+    epilogue quantizes — no quantizer forward (``quantize_affine``) runs for the output — and the QuantizedTensor it returns equals the
+    two-pass result (GEMM, then the quantizer's own forward) bit for bit: codes, parameters, dequantize dtype."""
+    torch.manual_seed(9)
+    lin = torch.nn.Linear(512, 768, bias=True).to(DEV, torch.bfloat16)
+    x = torch.randn(6, 200, 512, device=DEV, dtype=torch.bfloat16)
+    wq_ = ff.nn.LinearQuantizer(8, granularity=ff.PerChannel(0), quantized_dtype=torch.int8, device=DEV)
+    xq_ = ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=torch.int8, device=DEV)
+    oq = ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=quantized_dtype, device=DEV)
+    with torch.no_grad(), ff.estimate_ranges(torch.nn.ModuleList([wq_, xq_]), ff.range_setting.running_minmax):
+        qw, qx = wq_(lin.weight), xq_(x)
+    with torch.no_grad(), ff.strict_quantization(False):
+        y = ff.nn.functional.linear(qx, qw, lin.bias)
+        with ff.estimate_ranges(oq, ff.range_setting.running_minmax):
+            oq(y)
+        two_pass = oq(y)
+        calls = []  # every A1 a quantizer's forward runs goes through this function (quantization/affine/function.py)
+        real = affine_function.quantize_affine
+        monkeypatch.setattr(affine_function, "quantize_affine", lambda *a, **k: calls.append(tuple(a[0].shape)) or real(*a, **k))
+        fused = ff.nn.functional.linear(qx, qw, lin.bias, output_quantizer=oq)
+        assert calls == [], "the output quantizer ran as its own pass"
+        # with gradients possibly wanted, or an override active, the quantizer runs as a module (its own forward)
+        with ff.disable_quantization(torch.nn.ModuleList([oq])):
+            assert not isinstance(ff.nn.functional.linear(qx, qw, lin.bias, output_quantizer=oq), ff.QuantizedTensor)
+    with ff.strict_quantization(False):
+        with_grad = ff.nn.functional.linear(qx, qw, lin.bias, output_quantizer=oq)  # grad mode on: scale is a Parameter
+    assert len(calls) == 1
+    for got in (fused, with_grad):
+        assert isinstance(got, ff.QuantizedTensor) and got.raw_data.dtype == two_pass.raw_data.dtype
+        assert torch.equal(got.raw_data, two_pass.raw_data)
+        gp, tp = got.quantization_context.quantization_params, two_pass.quantization_context.quantization_params
+        assert gp.dequantize_dtype == tp.dequantize_dtype == torch.bfloat16 and gp.num_bits == tp.num_bits
+        assert torch.equal(got.dequantize(), two_pass.dequantize())
+    # mm takes the same epilogue
+    with torch.no_grad(), ff.strict_quantization(False):
+        qwt = ff.quantization.affine.quantize_per_tensor(lin.weight.t().contiguous(), torch.tensor([0.001], device=DEV), None, 8, torch.int8)
+        y_mm = ff.nn.functional.mm(qx.reshape(-1, 512), qwt)
+        assert torch.equal(ff.nn.functional.mm(qx.reshape(-1, 512), qwt, output_quantizer=oq).raw_data, oq(y_mm).raw_data)

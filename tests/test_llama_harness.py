@@ -125,8 +125,6 @@ def check_fused_against_module_graph(fixture, device):
     assert float(err.pow(2).mean().sqrt()) < 0.01 * spread and float(err.abs().max()) < 0.25 * spread
     # the MLP front half in one launch is the same arithmetic as gate GEMM, up GEMM and the SiLU*up producer
     assert torch.equal(llama.FusedForward(model, fuse_mlp=False)(ids).float().cpu(), got)
-    # the residual adds inside the o_proj / down_proj GEMMs (ABI 5; the tiny shapes of this fixture fall back on the device): same logits
-    assert torch.equal(llama.FusedForward(model, fuse_residual=True)(ids).float().cpu(), got)
     cached = llama.FusedForward(model, cache_weight_codes=True)
     assert torch.equal(cached(ids).float().cpu(), got) and torch.equal(cached(ids).float().cpu(), got)
     with torch.no_grad():  # a changed weight invalidates its cached codes
@@ -303,6 +301,3 @@ def test_llama3_70b_shaped_layers_calibrate_and_run_fused(hip_backend):
     # a few bf16 values by an ulp, a few int8 codes flip, two 8192-wide layers amplify that): 0.014 spreads measured on the
     # MI355X at this width, 0.004 at the tiny model's 256
     assert float((with_sdpa - want).pow(2).mean().sqrt()) < 0.02 * spread
-    # the residual adds inside the o_proj / down_proj GEMMs' epilogues (ops.linear_w8a8_residual; covered at this width):
-    # the same two roundings as the RMSNorm kernel's add, so the logits are the same bits
-    assert torch.equal(llama.FusedForward(model, fuse_residual=True)(ids).float(), got)

@@ -89,7 +89,3 @@ def test_smoothed_minmax_trajectories():
 
 def test_large_linear_fixture():
     parity_cases.check_linear_large("cpu")
-
-
-def test_linear_with_the_residual_add_in_its_epilogue_oracle():
-    parity_cases.check_linear_residual("cpu")

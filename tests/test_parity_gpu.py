@@ -707,20 +707,6 @@ def test_fused_gate_up_silu_table_window_and_fallbacks():
     assert float(want.float().std()) > 1
 
 
-def test_linear_with_the_residual_add_in_its_epilogue():
-    """The persistent kernel's residual epilogue on the shapes it covers (K % 128 == 0, N % 64 == 0, >= 64 tiles of 256 x 256;
-    ragged row tiles included) and the 'not covered' answer elsewhere."""
-    parity_cases.check_linear_residual(DEV, shapes=((2048, 2048, 256), (4099, 2048, 512), (16384, 4096, 1024), (2050, 2304, 384), (130, 64, 128)))
-    xq = torch.zeros(130, 128, dtype=torch.int8, device=DEV)
-    wq = torch.zeros(64, 128, dtype=torch.int8, device=DEV)
-    one = torch.ones(1, device=DEV)
-    assert ops.linear_w8a8_residual(xq, wq, one, None, torch.ones(64, device=DEV), torch.zeros(130, 64, device=DEV, dtype=torch.bfloat16)) is None
-    # enough tiles but fewer than 128 columns: the persistent kernel is not the one that would run
-    xq = torch.zeros(16384, 256, dtype=torch.int8, device=DEV)
-    wq = torch.zeros(64, 256, dtype=torch.int8, device=DEV)
-    assert ops.linear_w8a8_residual(xq, wq, one, None, torch.ones(64, device=DEV), torch.zeros(16384, 64, device=DEV, dtype=torch.bfloat16)) is None
-
-
 # ---- weight-only linear (row *J: quantized weight x plain bf16 input, fallback.py:86-112) ---------------------------
 def test_weight_only_linear_fixture_from_the_reference():
     parity_cases.check_weight_only_linear(DEV)
@@ -776,10 +762,9 @@ def test_weight_only_linear_refuses_what_it_does_not_cover():
     q = ff.nn.LinearQuantizer(4, granularity=ff.PerBlock(1, 96, 0), quantized_dtype=torch.int8, device=DEV)
     with ff.estimate_ranges(q, ff.range_setting.running_minmax), torch.no_grad():
         wq = q(w)
-    with ff.fused_linear.weight_only_kernel(True):
-        assert ff.dispatcher.dispatch("linear", input=x, weight=wq) is None
-        with ff.strict_quantization(False), torch.no_grad():
-            assert torch.equal(ff.nn.functional.linear(x, wq), torch.nn.functional.linear(x, wq.dequantize()))
+    assert ff.dispatcher.dispatch("linear", input=x, weight=wq) is None
+    with ff.strict_quantization(False), torch.no_grad():
+        assert torch.equal(ff.nn.functional.linear(x, wq), torch.nn.functional.linear(x, wq.dequantize()))
 
 
 # ---- A8 and the grid estimator on strided channels / N-d tiles: HIP by-tile kernels, no device-ATen composite ---------
