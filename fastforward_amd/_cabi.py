@@ -162,8 +162,9 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_silu_mul_quantize": (_i, [_vp, _vp, _i, _i64, _vp, _fp, _vp]),
     "ffq_rope_inplace": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _i64, _vp, _vp, _vp]),
     "ffq_quantize_rows_rowsum": (_i, [_vp, _i, _vp, _vp, _i64, _i64, _d, _vp, _vp, _vp]),
-    "ffq_linear_wq_supported": (_i, [_i, _i, _i, _i64, _i64, _i64, _i64]),
-    "ffq_linear_wq": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i64, _i64, _vp, _i, _vp, _i, _i64, _i64, _i64, _vp]),
+    "ffq_linear_wq_supported": (_i, [_i, _i, _i, _i64, _i64, _i64, _i64, _i64]),
+    "ffq_linear_wq_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "ffq_linear_wq": (_i, [_vp, _i, _vp, _i, _i64, _vp, _vp, _i64, _i64, _vp, _i, _vp, _i, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ffq_attention": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _d, _i, _vp, _vp, _vp, _vp, _d, _vp]),
 }
 

@@ -3,541 +3,481 @@
 // Replaces the branch of fallback.linear that a QuantizedTensor WEIGHT and a plain (non-quantized) INPUT take:
 // src/fastforward/_gen/fallback.py:77-112 with strict_quantization off (:86-100): the reference dequantizes the weight
 // codes into a bf16 tensor in HBM (A2: (q + round(o)) * s, rounded to the data dtype; 1 B read + 2 B written per
-// element and 2 B read again by the GEMM, every forward) and calls F.linear. Here the codes are the B operand of the
-// GEMM as they are: they travel HBM -> L2 -> LDS as int8 (1 B/elem, once) and are dequantized in registers on the way into
-// v_mfma_f32_32x32x16_bf16, with EXACTLY A2's arithmetic ((float(q) + round(o)) * s in fp32, one RNE rounding to bf16) —
-// the matrix the MFMA multiplies is bit for bit the reference's dequantized weight; only the fp32 summation order of the
-// contraction differs. Granularities: one (scale, offset) per tensor, per output channel (PerChannel(0)), or per group of
-// G input channels of an output channel (PerBlock(block_dims=1, block_sizes=G, per_channel_dims=0), G a multiple of 64:
-// BASELINE config 4's group-128), parameters in the row order of tiles_to_rows ([N, K / G] row-major).
+// element and 2 B read again by the GEMM, every forward) and calls F.linear. Here the codes are the GEMM's B operand as they
+// are stored — int8 containers (1 B/elem) or PACKED 4-bit nibbles in the GGUF Q4_0 order of the reference's exporter
+// (export/stages/gguf/_packing.py:44-53; 0.5 B/elem: BASELINE config 4's "sub-byte pack/unpack kernel path") — and the
+// matrix the MFMA multiplies is bit for bit the reference's dequantized weight: EXACTLY A2's arithmetic
+// ((float(q) + round(o)) * s in fp32, one RNE rounding to bf16); only the fp32 summation order of the contraction differs.
+// Granularities: one (scale, offset) per tensor, per output channel (PerChannel(0)), or per group of G input channels of
+// an output channel (PerBlock(block_dims=1, block_sizes=G, per_channel_dims=0), G a multiple of 64: config 4's group-128),
+// parameters in the row order of tiles_to_rows ([N, K / G] row-major).
 //
-// Tile 256(M) x 256(N) x 64(K), 8 wavefronts (2 x 4), each owning 128 x 64 of the output = 4 x 2 MFMA tiles (128 fp32
-// accumulators per lane). Operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4): activations as whole 128-byte
-// lines (8 rows per instruction), weight codes as 64-byte row pieces; the bank swizzle sits on the per-lane SOURCE address
-// and, identically, on the ds_read address. Three LDS stages of 48 KiB: the pieces of K-step kt + 2 are issued during
-// K-step kt and waited for with a counted s_waitcnt one step later, so an L2 miss has more than a whole K-step to land.
-// K-loop = the ping-pong template of ffq_linear.hip: a K-step is four phases of {LOAD segment | raw s_barrier | 8 MFMAs
-// under s_setprio | raw s_barrier}; waves 4-7 run one interval behind waves 0-3, so on every SIMD one wave feeds the
-// matrix pipe while its partner reads fragments AND converts the next 16 weight codes per lane to bf16 (VALU in the
-// shadow of the partner's MFMAs). Contraction-order trick: a lane reads 16 consecutive code bytes (two MFMA k-steps)
-// and the matching 2 x 16 bytes of bf16 activations; both operands see the same permutation of k, which a dot product
-// does not notice — no transposes, 16-byte LDS reads only.
+// Round 3 design (round 2's kernel converted the codes per WAVE on the LDS->register path: every code was converted by the two
+// waves that share a column range, 128 VALU instructions per wave and 64-deep K-step beside 32 MFMAs, and ran at 1.15 PFLOP/s
+// against 1.36 for its own skeleton without the conversion):
+//   * the skeleton is the persistent int8 kernel of ffq_linear.hip restated for bf16: 256 x 256 output tile per block,
+//     8 wavefronts (2 x 4) of 128 x 64 = 8 x 4 accumulator tiles of v_mfma_f32_16x16x32_bf16, a super-step = 64 k = 128 bytes
+//     of every activation row (whole cache lines by LDS-DMA, saddr form, swizzle on the source address), two 64 KiB LDS
+//     slots, ping-pong wave groups (LOAD segment | raw s_barrier | 16 MFMAs under s_setprio | raw s_barrier, waves 4-7 one
+//     interval behind), one block per CU walking its tiles XCD-aware with the K-loop running across tile boundaries;
+//   * the codes are converted ONCE PER BLOCK: every lane fetches 16 code bytes of two weight rows per super-step straight
+//     into registers (inline-asm loads in the saddr form, counted by hand: hipcc waits vmcnt(0) for an ordinary load next
+//     to an LDS-DMA stream), two super-steps ahead of their use; one super-step ahead it converts them — 2 VALU per code,
+//     64 per lane and super-step beside 64 MFMAs, placed inside the first two MFMA clusters — and writes the bf16 image of
+//     the B tile into the LDS slot (4 ds_write_b128 per lane, conflict-free under the image's swizzle slot ^= row & 7);
+//     all eight waves then read B fragments from that image exactly as they read A fragments;
+//   * packed nibbles: a lane's 16 bytes hold its 16 codes in one nibble position; it moves them into the high half of each
+//     byte ((n ^ 8) << 4 = 16 * code as a signed byte), converts with the byte-select form of v_cvt_f32_i32 and multiplies
+//     by s / 16 — power-of-two scalings commute with the one rounding of (q + o) * s (scales below 2^-120, where s / 16
+//     would lose bits, take the codes themselves on that lane);
+//   * large token counts may instead hand the kernel a bf16 image of the weight made by A2 in a separate pass
+//     (ffq_linear_wq's `workspace`): the conversion then costs nothing per row tile; the B operand is that tensor by LDS-DMA.
 #include "ffq_common.h"
 #include "ffq_vec.h"
 
-#include <type_traits>
+#include <stdlib.h>
 
-#ifndef WL_X
-#define WL_X 8  // schedule selector (tools/wq_variants.sh builds the others): 8 = conversion inside the clusters, the shipped one
-#endif
+#include <type_traits>
 
 namespace ffq {
 
 typedef int wl_v4i __attribute__((ext_vector_type(4)));
-typedef float wl_v16f __attribute__((ext_vector_type(16)));
+typedef float wl_v4f __attribute__((ext_vector_type(4)));
 typedef __bf16 wl_v8bf __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void wl_lds_t;
 typedef __attribute__((address_space(1))) const void wl_gbl_t;
 
-constexpr int WL_BM = 256, WL_BN = 256, WL_BK = 64, WL_STAGES = 3;
-constexpr int WL_A_BYTES = WL_BM * WL_BK * 2;              // 32 KiB of bf16 activations per stage
-constexpr int WL_B_BYTES = WL_BN * WL_BK;                  // 16 KiB of int8 codes per stage
-constexpr int WL_STAGE_BYTES = WL_A_BYTES + WL_B_BYTES;    // 48 KiB
-constexpr int WL_PARAM_BYTES = 2 * WL_BN * 4;              // grouped mode: 256 scales + 256 rounded-later offsets per stage
+constexpr int WL_BM = 256, WL_BN = 256, WL_BK = 64;
+constexpr int WL_IMAGE = 256 * 128;            // one operand image: 256 rows x 128 bytes
+constexpr int WL_SLOT = 2 * WL_IMAGE;          // A image then B image: 64 KiB
 constexpr int WL_GROUP_M = 8;
+constexpr int64_t WL_TWO_PASS_MIN_TOKENS = 4096;  // from this many tokens on, A2 as its own pass + the bf16-image GEMM
+
+enum { WL_B_BF16 = 0, WL_B_I8 = 1, WL_B_I4 = 2 };
 
 struct WLinearArgs {
-  const uint16_t* x;      // [M, K] bf16
-  const int8_t* wq;       // [N, K] codes, int8 container
+  const uint8_t* x;       // [M, K] bf16
+  const uint8_t* w;       // WL_B_BF16: [N, K] bf16; WL_B_I8: [N, K] int8 codes; WL_B_I4: [N, K / 2] packed nibbles
   const float* w_scale;   // [N * groups] (or [1])
   const float* w_offset;  // same shape, or NULL
   const void* bias; int bias_dt;
   void* out; int out_dt;  // bf16 or f32
   int M, N, K;
   int groups;             // parameters per output channel along K (1 = per channel / per tensor)
-  int steps_per_group;    // K-steps of 64 that share one group
+  int steps_per_group;    // super-steps of 64 that share one group
   int per_row;            // 0: one parameter pair for the whole tensor
-  int tiles_m, tiles_n;
+  int pack_shift;         // WL_B_I4: log2(packing block)
+  int tiles_m, tiles_n, group_m;
 };
 
-// 4 codes (one dword) -> 4 bf16 (two dwords) of (float(q) + ro) * s
-struct wl_pair { int lo, hi; };
+// 4 codes in the bytes of `w` (signed bytes; for nibbles: 16 * code, see the header) -> 4 bf16 of (float(b) + c) * s
 template <bool OFFSET>
-__device__ __forceinline__ wl_pair dequantize4(uint32_t w, float s, float ro) {
-#if WL_X == 6 || WL_X == 9  // integer -> float by byte permutation: [0x4B 00 00 u] = 2^23 + u with u = q + 128, then ONE exact add
-  const uint32_t u = w ^ 0x80808080u;
-  const float c = ro - 8388736.0f;  // -(2^23 + 128) + ro: integers far below 2^24, every sum below is exact
-  const float f0 = __builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, u, 0x070C0C00u)) + c;
-  const float f1 = __builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, u, 0x070C0C01u)) + c;
-  const float f2 = __builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, u, 0x070C0C02u)) + c;
-  const float f3 = __builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, u, 0x070C0C03u)) + c;
-#else
+__device__ __forceinline__ void dequantize4(uint32_t w, float s, float c, uint32_t& lo, uint32_t& hi) {
   float f0 = (float)(int)(int8_t)(w), f1 = (float)(int)(int8_t)(w >> 8), f2 = (float)(int)(int8_t)(w >> 16), f3 = (float)(int)(int8_t)(w >> 24);
-  if constexpr (OFFSET) { f0 = f0 + ro; f1 = f1 + ro; f2 = f2 + ro; f3 = f3 + ro; }
-#endif
-  wl_pair r;
-  r.lo = (int)pack2<bf16_t>(f0 * s, f1 * s);
-  r.hi = (int)pack2<bf16_t>(f2 * s, f3 * s);
-  return r;
+  if constexpr (OFFSET) { f0 = f0 + c; f1 = f1 + c; f2 = f2 + c; f3 = f3 + c; }
+  lo = pack2<bf16_t>(f0 * s, f1 * s);
+  hi = pack2<bf16_t>(f2 * s, f3 * s);
 }
 
-// 8 weight codes (two dwords) -> 8 bf16 of A2's value (float(q) + ro) * s, as the 4 dwords of an MFMA operand
-template <bool OFFSET>
-__device__ __forceinline__ wl_v4i dequantize8(uint32_t lo, uint32_t hi, float s, float ro) {
-#if WL_X == 2  // ablation: no conversion (wrong results)
-  wl_v4i raw4; raw4[0] = (int)lo; raw4[1] = (int)hi; raw4[2] = (int)lo; raw4[3] = (int)hi;
-  return raw4;
-#endif
-#if WL_X == 6 || WL_X >= 8
-  wl_v4i o4;
-  const wl_pair a4 = dequantize4<OFFSET>(lo, s, ro), b4 = dequantize4<OFFSET>(hi, s, ro);
-  o4[0] = a4.lo; o4[1] = a4.hi; o4[2] = b4.lo; o4[3] = b4.hi;
-  return o4;
-#endif
-  float f[8];
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    f[b] = (float)(int)(int8_t)(lo >> (8 * b));
-    f[4 + b] = (float)(int)(int8_t)(hi >> (8 * b));
-  }
-  wl_v4i out;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    float a = f[2 * p], b = f[2 * p + 1];
-    if constexpr (OFFSET) { a = a + ro; b = b + ro; }
-    out[p] = (int)pack2<bf16_t>(a * s, b * s);
-  }
-  return out;
-}
-
-template <bool GROUPED, bool OFFSET, typename TOut>
-__global__ __launch_bounds__(512, 2) void wq_bf16_gemm256_kernel(WLinearArgs a) {
+template <int BKIND, bool GROUPED, bool OFFSET, typename TOut>
+__global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  uint8_t* const params_lds = lds + WL_STAGES * WL_STAGE_BYTES;  // grouped mode only
-
-  // XCD-aware grouped tile order (as ffq_linear.hip): an XCD owns a contiguous range of tiles, visited 8 row-tiles deep
-  const uint32_t nblk = gridDim.x;
-  const uint32_t xcd = blockIdx.x & 7u, slot_in_xcd = blockIdx.x >> 3;
-  const uint32_t q8 = nblk >> 3, r8 = nblk & 7u;
-  const uint32_t tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot_in_xcd;
-  const uint32_t per_group = WL_GROUP_M * (uint32_t)a.tiles_n;
-  const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
-  const uint32_t group_rows = min((uint32_t)WL_GROUP_M, (uint32_t)a.tiles_m - group * WL_GROUP_M);
-  const int m0 = (int)(group * WL_GROUP_M + in_group % group_rows) * WL_BM;
-  const int n0 = (int)(in_group / group_rows) * WL_BN;
+  constexpr bool CODES = BKIND != WL_B_BF16;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;  // wm is also the ping-pong group
-  const int frag_row = lane & 31, frag_g = lane >> 5;
 
-  // ---- parameters of this lane's two weight rows (not grouped: registers for the whole tile, loaded before any DMA flies)
-  float sc[2] = {1.0f, 1.0f}, ro[2] = {0.0f, 0.0f};
-  if constexpr (!GROUPED) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int n = n0 + wn * 64 + j * 32 + frag_row;
-      n = n < a.N ? n : a.N - 1;
-      sc[j] = a.w_scale[a.per_row ? n : 0];
-      if constexpr (OFFSET) ro[j] = rne(a.w_offset[a.per_row ? n : 0]);
-    }
-    // consume the loads HERE: hipcc waits vmcnt(0) for an ordinary load's first use, and inside the K-loop that wait
-    // would drain the LDS-DMA pipeline on every iteration
-    asm volatile("" ::"v"(sc[0]), "v"(sc[1]), "v"(ro[0]), "v"(ro[1]));
-  }
-
-  // ---- DMA sources. A: wave w copies the 8-row pieces {4w .. 4w+3} (rows 32w .. 32w+31, 128 B each); lane l lands at
-  // 16-B slot l of the piece: row l / 8, physical slot l % 8, logical slot = physical ^ ((row >> 1) & 7).
-  // B: wave w copies the 16-row pieces {2w, 2w+1} (rows 32w .. 32w+31, 64 B each): row l / 4, physical slot l % 4,
-  // logical = physical ^ ((row >> 2) & 3).
-  const uint8_t* a_src[4];
-  const uint8_t* b_src[2];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int row = wave * 32 + c * 8 + (lane >> 3);
-    const int slot = (lane & 7) ^ ((row >> 1) & 7);
-    int gm = m0 + row;
-    gm = gm < a.M ? gm : a.M - 1;  // rows past the edge re-read the last row and are never stored
-    a_src[c] = reinterpret_cast<const uint8_t*>(a.x) + ((size_t)gm * a.K) * 2 + slot * 16;
-  }
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int row = wave * 32 + c * 16 + (lane >> 2);
-    const int slot = (lane & 3) ^ ((row >> 2) & 3);
-    int gn = n0 + row;
-    gn = gn < a.N ? gn : a.N - 1;
-    b_src[c] = reinterpret_cast<const uint8_t*>(a.wq) + (size_t)gn * a.K + slot * 16;
-  }
-  // grouped mode: wave w < 4 fetches the scales of rows 64w .. 64w+63 of the K-step's group, wave w >= 4 the offsets
-  // (the scales once more when there is no offset: every wave issues the same number of pieces, one constant vmcnt)
-  const float* p_src = nullptr;
-  if constexpr (GROUPED) {
-    int gn = n0 + (wave & 3) * 64 + lane;
-    gn = gn < a.N ? gn : a.N - 1;
-    p_src = ((wave >= 4 && a.w_offset) ? a.w_offset : a.w_scale) + (size_t)gn * a.groups;
-  }
-  const int ksteps = a.K / WL_BK;
-  auto stage_of = [](int kt) { return kt % WL_STAGES; };
-  // pieces of K-step kt (steps past the end re-load the last one into a stage nobody reads any more)
-#if WL_X == 10
-  // buffer form of the LDS-DMA: the tile's base in a wave-uniform descriptor (SGPRs), one 32-bit per-lane offset, the
-  // K-step in the scalar offset — no 64-bit per-lane address arithmetic, half the address registers read per piece.
-  // Rows past the matrix edge fall outside the descriptor's range and read as zeros.
-  const size_t a_left = (size_t)(a.M - m0) * a.K * 2, b_left = (size_t)(a.N - n0) * a.K;
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<const uint8_t*>(a.x) + (size_t)m0 * a.K * 2), 0, (int)(a_left < 0x7FFFFFFFu ? a_left : 0x7FFFFFFFu), 0x00020000);
-  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<const uint8_t*>(a.wq) + (size_t)n0 * a.K), 0, (int)(b_left < 0x7FFFFFFFu ? b_left : 0x7FFFFFFFu), 0x00020000);
-  uint32_t a_voff[4], b_voff[2];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int row = wave * 32 + c * 8 + (lane >> 3);
-    a_voff[c] = (uint32_t)row * (uint32_t)a.K * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
-  }
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int row = wave * 32 + c * 16 + (lane >> 2);
-    b_voff[c] = (uint32_t)row * (uint32_t)a.K + (uint32_t)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
-  }
-#endif
-  auto issue_a = [&](int kt, int c0) {
-    const int st = stage_of(kt);
-    kt = kt < ksteps ? kt : ksteps - 1;
-    uint8_t* base = lds + st * WL_STAGE_BYTES;
-#pragma unroll
-    for (int c = c0; c < c0 + 2; ++c)
-#if WL_X == 10
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (wl_lds_t*)(base + (wave * 4 + c) * 1024), 16, a_voff[c], kt * (WL_BK * 2), 0, 0);
-#else
-      __builtin_amdgcn_global_load_lds((wl_gbl_t*)(a_src[c] + (size_t)kt * (WL_BK * 2)), (wl_lds_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
-#endif
+  // tile walk of ffq_linear.hip: XCD x (= blockIdx % 8) owns a contiguous range of the grouped tile order, its blocks walk it
+  // round-robin, i.e. the order in which a non-persistent launch would dispatch them
+  const uint32_t nblk = gridDim.x;
+  const uint32_t xcd = blockIdx.x & 7u, j_in_xcd = blockIdx.x >> 3;
+  const uint32_t blocks_in_xcd = (nblk >> 3) + (xcd < (nblk & 7u) ? 1u : 0u);
+  const uint32_t tq = (uint32_t)total_tiles >> 3, tr = (uint32_t)total_tiles & 7u;
+  const uint32_t xcd_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const uint32_t xcd_count = tq + (xcd < tr ? 1u : 0u);
+  const int my_tiles = j_in_xcd < xcd_count ? (int)((xcd_count - j_in_xcd + blocks_in_xcd - 1) / blocks_in_xcd) : 0;
+  if (my_tiles == 0) return;
+  auto tile_origin = [&](int it, int& tm0, int& tn0) {
+    it = it < my_tiles ? it : my_tiles - 1;  // streams running past the block's last tile re-read it (never used)
+    const uint32_t tile_id = xcd_first + j_in_xcd + (uint32_t)it * blocks_in_xcd;
+    const uint32_t gm = (uint32_t)a.group_m;
+    const uint32_t per_group = gm * (uint32_t)a.tiles_n;
+    const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
+    const uint32_t group_rows = min(gm, (uint32_t)a.tiles_m - group * gm);
+    tm0 = (int)(group * gm + in_group % group_rows) * WL_BM;
+    tn0 = (int)(in_group / group_rows) * WL_BN;
   };
-  auto issue_b = [&](int kt) {
-    const int st = stage_of(kt);
-    kt = kt < ksteps ? kt : ksteps - 1;
-    uint8_t* base = lds + st * WL_STAGE_BYTES + WL_A_BYTES;
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#if WL_X == 10
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (wl_lds_t*)(base + (wave * 2 + c) * 1024), 16, b_voff[c], kt * WL_BK, 0, 0);
-#else
-      __builtin_amdgcn_global_load_lds((wl_gbl_t*)(b_src[c] + (size_t)kt * WL_BK), (wl_lds_t*)(base + (wave * 2 + c) * 1024), 16, 0, 0);
-#endif
-    if constexpr (GROUPED) {
-      const int g = kt / a.steps_per_group;
-      __builtin_amdgcn_global_load_lds((wl_gbl_t*)(p_src + g), (wl_lds_t*)(params_lds + st * WL_PARAM_BYTES + wave * 256), 4, 0, 0);
-    }
+  // first byte of row `row0` of a matrix with `row_bytes` per row, kept in SGPRs (see ffq_linear.hip::row_base)
+  auto row_base = [&](const uint8_t* base, int row0, uint32_t row_bytes) {
+    const uint64_t off = (uint64_t)(uint32_t)row0 * (uint64_t)row_bytes;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)off), hi = __builtin_amdgcn_readfirstlane((uint32_t)(off >> 32));
+    return base + (((uint64_t)hi << 32) | lo);
   };
 
-  // ---- fragment addresses inside a stage. MFMA (j, t) of a K-step (j = 32-wide half, t = 16-wide quarter of it):
-  // lane (r, g) contracts k = 32 j + 16 g + 8 t + (0..7): activations from logical slot 4 j + 2 g + t of its row, codes from
-  // the low / high half of logical slot 2 j + g. Adding 32 rows leaves both swizzles unchanged: one base per (j, t).
-  uint32_t a_off[4], b_off[2];
-  {
-    const uint32_t row = wm * 128 + frag_row;
+  // ---- operand streams. Element e = (tile, super-step): the block computes e, LDS-DMA fetches the images of e + 1, the
+  // conversion handles the codes of e + 1, the code loads run at e + 2.
+  const uint32_t x_row_bytes = (uint32_t)a.K * 2u;
+  const uint32_t w_row_bytes = BKIND == WL_B_BF16 ? (uint32_t)a.K * 2u : BKIND == WL_B_I8 ? (uint32_t)a.K : (uint32_t)a.K / 2u;
+  const int d_row = lane >> 3;
+  uint32_t a_voff[4];
+  const uint8_t* a_base = a.x;
+  [[maybe_unused]] uint32_t b_voff[4];          // WL_B_BF16: the B image by LDS-DMA, as A
+  [[maybe_unused]] const uint8_t* b_base = a.w;
+  auto set_image_sources = [&](int tm0, int tn0) {
+    a_base = row_base(a.x, tm0, x_row_bytes);
+    if constexpr (!CODES) b_base = row_base(a.w, tn0, w_row_bytes);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) a_off[v] = row * 128 + ((((uint32_t)(4 * (v >> 1) + 2 * frag_g + (v & 1))) ^ ((row >> 1) & 7u)) << 4);
-    const uint32_t brow = wn * 64 + frag_row;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) b_off[j] = WL_A_BYTES + brow * 64 + ((((uint32_t)(2 * j + frag_g)) ^ ((brow >> 2) & 3u)) << 4);
-  }
-
-  wl_v16f acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-  wl_v4i fa[4], raw[2], nxt[2], fb[2];
-  // LOAD segment of phase p = 2 j + t. Everything it converts is already in registers: the 16 code bytes of a pair of
-  // phases are fetched one pair AHEAD (odd phases issue the reads of the next pair — the last phase of a K-step those of
-  // the NEXT step's first pair, plus that step's parameters in grouped mode), so the LDS latency hides behind the
-  // conversion of the current phase instead of preceding it.
-  auto fetch_codes = [&](const uint8_t* st, int j) {
-#pragma unroll
-    for (int f = 0; f < 2; ++f) nxt[f] = *reinterpret_cast<const wl_v4i*>(st + b_off[j] + f * (32 * 64));
-  };
-  auto fetch_params = [&](const uint8_t* pst) {
-    if constexpr (GROUPED) {
-      const float* ps = reinterpret_cast<const float*>(pst);
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        sc[f] = ps[wn * 64 + f * 32 + frag_row];
-        if constexpr (OFFSET) ro[f] = rne(ps[256 + wn * 64 + f * 32 + frag_row]);
+    for (int c = 0; c < 4; ++c) {
+      const int row = (wave * 4 + c) * 8 + d_row;
+      const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
+      const int ra = tm0 + row < a.M ? row : a.M - 1 - tm0;  // rows past the edge re-read the last row and are never stored
+      a_voff[c] = (uint32_t)ra * x_row_bytes + d_slot * 16;
+      if constexpr (!CODES) {
+        const int rb = tn0 + row < a.N ? row : a.N - 1 - tn0;
+        b_voff[c] = (uint32_t)rb * w_row_bytes + d_slot * 16;
       }
     }
   };
-  auto load_segment = [&](const uint8_t* st, const uint8_t* st_next, const uint8_t* pst_next, auto phase) {
-    constexpr int p = decltype(phase)::value;
-#if WL_X == 5  // the CONVERTING wave is the prioritised one
-    __builtin_amdgcn_s_setprio(1);
-#endif
+  auto issue_a = [&](int ks, int slot, int c0) {
+    uint8_t* base = lds + slot * WL_SLOT;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const wl_v4i*>(st + a_off[p] + i * (32 * 128));
-    if constexpr (p == 0 || p == 2) {
-      raw[0] = nxt[0]; raw[1] = nxt[1];
+    for (int c = c0; c < c0 + 2; ++c) {
+      asm volatile("" : "+v"(a_voff[c]));  // keeps the saddr form in every unrolled body (ffq_linear.hip)
+      __builtin_amdgcn_global_load_lds((wl_gbl_t*)((a_base + ks * 128) + a_voff[c]), (wl_lds_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_b = [&](int ks, int slot, int c0) {
+    if constexpr (!CODES) {
+      uint8_t* base = lds + slot * WL_SLOT + WL_IMAGE;
 #pragma unroll
-      for (int f = 0; f < 2; ++f) fb[f] = dequantize8<OFFSET>((uint32_t)raw[f].x, (uint32_t)raw[f].y, sc[f], ro[f]);
+      for (int c = c0; c < c0 + 2; ++c) {
+        asm volatile("" : "+v"(b_voff[c]));
+        __builtin_amdgcn_global_load_lds((wl_gbl_t*)((b_base + ks * 128) + b_voff[c]), (wl_lds_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- the code stream (CODES). Instruction j of a lane covers row 32 w + 16 j + lane / 4 of the tile, piece p = lane % 4:
+  // the 16 codes [16 p, 16 p + 16) of that row's 64-code slab — four lanes fetch one row's 64 contiguous bytes.
+  [[maybe_unused]] const uint32_t c_piece = (uint32_t)lane & 3u;
+  [[maybe_unused]] uint32_t c_voff[2];            // byte offset of the lane's row inside the tile's rows
+  [[maybe_unused]] uint32_t p_voff[2];            // byte offset of the lane's row inside the tile's parameter rows
+  [[maybe_unused]] const uint8_t* c_base = a.w;   // first code byte of the tile's first row
+  [[maybe_unused]] const float* ps_base = a.w_scale;
+  [[maybe_unused]] const float* po_base = a.w_offset;
+  [[maybe_unused]] u32x4 raw[2];                  // the 16 code bytes of each row, in flight / waiting for their conversion
+  [[maybe_unused]] float sc[2] = {1.0f, 1.0f}, ro[2] = {0.0f, 0.0f};
+  [[maybe_unused]] uint32_t nib_shift = 0;        // WL_B_I4: 0 = the low nibbles of the bytes, 4 = the high ones (stream state)
+  [[maybe_unused]] int grp = 0, grp_phase = 0;    // GROUPED: parameter group of the code stream's super-step, and the step inside it
+  auto set_code_sources = [&](int tn0) {
+    if constexpr (CODES) {
+      c_base = row_base(a.w, tn0, w_row_bytes);
+      const uint32_t param_row = a.per_row ? (uint32_t)a.groups : 0u;
+      ps_base = reinterpret_cast<const float*>(row_base(reinterpret_cast<const uint8_t*>(a.w_scale), tn0, param_row * 4u));
+      if constexpr (OFFSET) po_base = reinterpret_cast<const float*>(row_base(reinterpret_cast<const uint8_t*>(a.w_offset), tn0, param_row * 4u));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = wave * 32 + j * 16 + (lane >> 2);
+        const int rb = tn0 + row < a.N ? row : a.N - 1 - tn0;
+        c_voff[j] = (uint32_t)rb * w_row_bytes;
+        p_voff[j] = (uint32_t)rb * param_row * 4u;
+      }
+    }
+  };
+  // requests the codes (and, where they change, the parameters) of super-step `ks` of the tile the code sources point at
+  auto load_codes = [&](int ks, bool new_tile) {
+    if constexpr (CODES) {
+      uint32_t byte0;  // first byte of the lane's piece inside its row
+      if constexpr (BKIND == WL_B_I8) {
+        byte0 = (uint32_t)ks * 64u + c_piece * 16u;
+      } else {
+        // codes k0 .. k0 + 15 of the row live in ONE half of ONE packing block (block >= 32): byte j of a block holds code j
+        // in its low and code j + block / 2 in its high nibble (ffq_pack_int4, _packing.py:44-53)
+        const uint32_t k0 = (uint32_t)ks * 64u + c_piece * 16u, lb = (uint32_t)a.pack_shift;
+        const uint32_t within = k0 & ((1u << lb) - 1u);
+        nib_shift = (within >> (lb - 1u)) * 4u;
+        byte0 = ((k0 >> lb) << (lb - 1u)) + (within & ((1u << (lb - 1u)) - 1u));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t vo = c_voff[j] + byte0;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw[j]) : "v"(vo), "s"(c_base) : "memory");
+      }
+      // the stream visits the super-steps of a tile in order (0, 1, 2, ...): group bookkeeping by counting, no division
+      bool new_params = new_tile;
+      if constexpr (GROUPED) {
+        if (new_tile) { grp = 0; grp_phase = 0; }
+        else if (++grp_phase == a.steps_per_group) { grp_phase = 0; ++grp; new_params = true; }
+      }
+      if (new_params) {  // wave-uniform
+        const uint32_t g4 = GROUPED ? (uint32_t)grp * 4u : 0u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const uint32_t vo = p_voff[j] + g4;
+          asm volatile("global_load_dword %0, %1, %2" : "=v"(sc[j]) : "v"(vo), "s"(ps_base) : "memory");
+          if constexpr (OFFSET) asm volatile("global_load_dword %0, %1, %2" : "=v"(ro[j]) : "v"(vo), "s"(po_base) : "memory");
+        }
+      }
+    }
+  };
+  // everything requested so far has landed: the registers of the code stream are re-defined HERE for the compiler (the
+  // loads above are invisible to its wait insertion)
+  auto wait_all_vmem = [&]() {
+    if constexpr (CODES) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(sc[0]), "+v"(sc[1]), "+v"(ro[0]), "+v"(ro[1]) : : "memory");
     } else {
-      if constexpr (p == 1) fetch_codes(st, 1);
-      else fetch_codes(st_next, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+  // row j's 16 codes -> 16 bf16 of A2's value -> the B image of `slot` (logical 16-byte slots 2 p and 2 p + 1 of the row)
+  [[maybe_unused]] const uint32_t c_row0 = (uint32_t)(wave * 32 + (lane >> 2));
+  auto convert_row = [&](int j, int slot) {
+    if constexpr (CODES) {
+      const uint32_t row = c_row0 + 16u * (uint32_t)j;
+      uint32_t w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+      float s = sc[j], c = OFFSET ? rne(ro[j]) : 0.0f;
+      if constexpr (BKIND == WL_B_I4) {
+        // nibble n = code + 8 -> (n ^ 8) << 4 in the byte's high half = 16 * code as a signed byte; (16 q + 16 o) * (s / 16)
+        // is (q + o) * s with the same single rounding wherever s / 16 is exact — on lanes with a tiny scale the bytes are
+        // taken down to q itself (arithmetic >> 4 of every byte) and s stays
+        const bool tiny = __builtin_fabsf(s) < 0x1p-120f && s != 0.0f;
 #pragma unroll
-      for (int f = 0; f < 2; ++f) fb[f] = dequantize8<OFFSET>((uint32_t)raw[f].z, (uint32_t)raw[f].w, sc[f], ro[f]);
-      if constexpr (p == 3) {
-        __builtin_amdgcn_sched_barrier(0);
-        fetch_params(pst_next);  // first used by the next K-step's conversions
+        for (int d = 0; d < 4; ++d) {
+          uint32_t b = (((w[d] >> nib_shift) << 4) & 0xF0F0F0F0u) ^ 0x80808080u;
+          if (__builtin_expect(tiny, 0)) {
+            const uint32_t b0 = (uint32_t)(((int32_t)(b << 24)) >> 28) & 0xFFu, b1 = (uint32_t)(((int32_t)(b << 16)) >> 28) & 0xFFu;
+            const uint32_t b2 = (uint32_t)(((int32_t)(b << 8)) >> 28) & 0xFFu, b3 = (uint32_t)(((int32_t)b) >> 28) & 0xFFu;
+            b = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+          }
+          w[d] = b;
+        }
+        if (!tiny) { s = s * 0.0625f; c = c * 16.0f; }
       }
+      uint32_t o[8];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) dequantize4<OFFSET>(w[d], s, c, o[2 * d], o[2 * d + 1]);
+      uint8_t* image = lds + slot * WL_SLOT + WL_IMAGE + row * 128u;
+      const uint32_t sw = row & 7u;
+      *reinterpret_cast<u32x4*>(image + (((2u * c_piece) ^ sw) << 4)) = u32x4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<u32x4*>(image + (((2u * c_piece + 1u) ^ sw) << 4)) = u32x4{o[4], o[5], o[6], o[7]};
     }
-    __builtin_amdgcn_sched_barrier(0);
-#if WL_X == 5
-    __builtin_amdgcn_s_setprio(0);
-#endif
-  };
-  auto cluster = [&](auto dma) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#if WL_X != 4 && WL_X != 5
-    __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_v8bf, fb[j]), __builtin_bit_cast(wl_v8bf, fa[i]), acc[i][j], 0, 0, 0);
-#if WL_X == 3  // ablation: no LDS-DMA inside the loop (wrong results)
-      (void)dma;
-#else
-      if (i == 1) { __builtin_amdgcn_sched_barrier(0); dma(); __builtin_amdgcn_sched_barrier(0); }
-#endif
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(0);
   };
 
-#if WL_X >= 8
-  // Conversion inside the clusters: the computing wave converts the codes of its OWN next phase in the shadow of its MFMAs
-  // (four VALU operations behind each MFMA), the load segment only reads.
-  wl_v4i fbn[2];
-  auto load_segment2 = [&](const uint8_t* st, const uint8_t* st_next, const uint8_t* pst_next, auto phase) {
-    constexpr int p = decltype(phase)::value;
-    fb[0] = fbn[0]; fb[1] = fbn[1];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const wl_v4i*>(st + a_off[p] + i * (32 * 128));
-    if constexpr (p == 1) fetch_codes(st, 1);
-    if constexpr (p == 0 || p == 2) { raw[0] = nxt[0]; raw[1] = nxt[1]; }
-    if constexpr (p == 3) { fetch_codes(st_next, 0); fetch_params(pst_next); }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto cluster2 = [&](auto dma, auto phase) {
-    constexpr int p = decltype(phase)::value;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_v8bf, fb[j]), __builtin_bit_cast(wl_v8bf, fa[i]), acc[i][j], 0, 0, 0);
-      {  // quarter i of the next phase's 16 codes: fragment i / 2, dword (i & 1) of its 8 bytes
-        constexpr bool from_next = (p & 1) == 1;  // odd phases convert the low half of the pair fetched ahead
-        const wl_v4i& src = from_next ? nxt[i >> 1] : raw[i >> 1];
-        const uint32_t w = (uint32_t)(from_next ? ((i & 1) ? src.y : src.x) : ((i & 1) ? src.w : src.z));
-        const wl_pair c4 = dequantize4<OFFSET>(w, sc[i >> 1], ro[i >> 1]);
-        fbn[i >> 1][2 * (i & 1)] = c4.lo;
-        fbn[i >> 1][2 * (i & 1) + 1] = c4.hi;
-      }
-      if (i == 1) { __builtin_amdgcn_sched_barrier(0); dma(); __builtin_amdgcn_sched_barrier(0); }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-#endif
-
-  // ---- prologue: K-steps 0 and 1 entirely; step 0 has landed when only step 1's pieces are outstanding
-  issue_a(0, 0); issue_a(0, 2); issue_b(0);
-  issue_a(1, 0); issue_a(1, 2); issue_b(1);
-  if constexpr (GROUPED) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  fetch_codes(lds, 0);
-  fetch_params(params_lds);
-#if WL_X >= 8
-  raw[0] = nxt[0]; raw[1] = nxt[1];
-#pragma unroll
-  for (int f = 0; f < 2; ++f) fbn[f] = dequantize8<OFFSET>((uint32_t)raw[f].x, (uint32_t)raw[f].y, sc[f], ro[f]);
-#endif
-  if (wm == 1) __builtin_amdgcn_s_barrier();  // the upper group runs one interval behind
-
-  // ---- K-loop. During step kt the clusters issue the pieces of step kt + 2 into the stage step kt - 1 occupied (its
-  // last reads were retired by the slower group one barrier before the faster group's first cluster: WAR). The load
-  // segment of phase 2 waits until only THIS step's four pieces are in flight — step kt + 1 has landed — one barrier
-  // before phase 3's look-ahead reads it (RAW: wait -> barrier -> read; the slower group's wait precedes the barrier that
-  // opens the faster group's phase 3).
-  for (int kt = 0; kt < ksteps; ++kt) {
-    const uint8_t* st = lds + stage_of(kt) * WL_STAGE_BYTES;
-    const uint8_t* st_next = lds + stage_of(kt + 1) * WL_STAGE_BYTES;
-    const uint8_t* pst_next = params_lds + stage_of(kt + 1) * WL_PARAM_BYTES;
-#if WL_X == 11  // conversion in the clusters, pieces at the end of the (now light) load segments
-    load_segment2(st, st_next, pst_next, std::integral_constant<int, 0>{});
-    issue_a(kt + 2, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    cluster2([] {}, std::integral_constant<int, 0>{});
-    __builtin_amdgcn_s_barrier();
-    load_segment2(st, st_next, pst_next, std::integral_constant<int, 1>{});
-    issue_a(kt + 2, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    cluster2([] {}, std::integral_constant<int, 1>{});
-    __builtin_amdgcn_s_barrier();
-    load_segment2(st, st_next, pst_next, std::integral_constant<int, 2>{});
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    issue_b(kt + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    cluster2([] {}, std::integral_constant<int, 2>{});
-    __builtin_amdgcn_s_barrier();
-    load_segment2(st, st_next, pst_next, std::integral_constant<int, 3>{});
-    __builtin_amdgcn_s_barrier();
-    cluster2([] {}, std::integral_constant<int, 3>{});
-    __builtin_amdgcn_s_barrier();
-    continue;
-#elif WL_X >= 8
-    load_segment2(st, st_next, pst_next, std::integral_constant<int, 0>{});
-    __builtin_amdgcn_s_barrier();
-    cluster2([&] { issue_a(kt + 2, 0); }, std::integral_constant<int, 0>{});
-    __builtin_amdgcn_s_barrier();
-    load_segment2(st, st_next, pst_next, std::integral_constant<int, 1>{});
-    __builtin_amdgcn_s_barrier();
-    cluster2([&] { issue_a(kt + 2, 2); }, std::integral_constant<int, 1>{});
-    __builtin_amdgcn_s_barrier();
-    load_segment2(st, st_next, pst_next, std::integral_constant<int, 2>{});
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    cluster2([&] { issue_b(kt + 2); }, std::integral_constant<int, 2>{});
-    __builtin_amdgcn_s_barrier();
-    load_segment2(st, st_next, pst_next, std::integral_constant<int, 3>{});
-    __builtin_amdgcn_s_barrier();
-    cluster2([] {}, std::integral_constant<int, 3>{});
-    __builtin_amdgcn_s_barrier();
-    continue;
-#elif WL_X == 1  // pieces issued at the end of the load segments instead of inside the clusters
-    load_segment(st, st_next, pst_next, std::integral_constant<int, 0>{});
-    issue_a(kt + 2, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    cluster([] {});
-    __builtin_amdgcn_s_barrier();
-    load_segment(st, st_next, pst_next, std::integral_constant<int, 1>{});
-    issue_a(kt + 2, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    cluster([] {});
-    __builtin_amdgcn_s_barrier();
-    load_segment(st, st_next, pst_next, std::integral_constant<int, 2>{});
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    issue_b(kt + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    cluster([] {});
-    __builtin_amdgcn_s_barrier();
-#else
-    load_segment(st, st_next, pst_next, std::integral_constant<int, 0>{});
-    __builtin_amdgcn_s_barrier();
-    cluster([&] { issue_a(kt + 2, 0); });
-    __builtin_amdgcn_s_barrier();
-    load_segment(st, st_next, pst_next, std::integral_constant<int, 1>{});
-    __builtin_amdgcn_s_barrier();
-    cluster([&] { issue_a(kt + 2, 2); });
-    __builtin_amdgcn_s_barrier();
-    load_segment(st, st_next, pst_next, std::integral_constant<int, 2>{});
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    cluster([&] { issue_b(kt + 2); });
-    __builtin_amdgcn_s_barrier();
-#endif
-    load_segment(st, st_next, pst_next, std::integral_constant<int, 3>{});
-    __builtin_amdgcn_s_barrier();
-    cluster([] {});
-    __builtin_amdgcn_s_barrier();
-  }
-  if (wm == 0) __builtin_amdgcn_s_barrier();  // same number of barriers for both groups
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing dummy pieces must not land in the epilogue's LDS
-  __syncthreads();
-
-  // ---- epilogue. The weight fragment is the MFMA's first operand, so with the 32x32 C/D layout lane l holds, for each
-  // (i, j, q): C[m = i*32 + (l & 31)][n = j*32 + 8 q + 4 (l >> 5) + (0..3)]: four consecutive output columns of one row.
-  // One 32-row slab per wave at a time goes through LDS (144-B pitch) and leaves as 16-byte stores of whole 128-B lines.
-  TOut* out = static_cast<TOut*>(a.out);
-  constexpr int PITCH = 64 * (int)sizeof(TOut) + 16;
-  constexpr int WAVE_BYTES = 32 * PITCH + 256;             // one 32-row slab + the wave's 64 bias values
-  uint8_t* slab = lds + wave * WAVE_BYTES;
-  float* bias_lds = reinterpret_cast<float*>(slab + 32 * PITCH);
-  const int wave_n0 = n0 + wn * 64, wave_m0 = m0 + wm * 128;
-  const bool full = wave_n0 + 64 <= a.N && (a.N * (int)sizeof(TOut)) % 16 == 0;
-  const bool has_bias = a.bias != nullptr;
+  // ---- fragment byte offsets inside a slot: [row tile][32-k chunk]. A image (LDS-DMA): slot ^= (row >> 1) & 7; B image:
+  // the same when it arrives by LDS-DMA, slot ^= row & 7 when the conversion writes it (conflict-free 16-byte stores)
+  const uint32_t r16 = lane & 15, g4 = lane >> 4;
+  // both swizzles depend on the row only through r16 (row tiles are 16 rows apart, the terms are taken mod 8 of row / 2 or
+  // row): one register per k-chunk and operand, the row tile goes into the instruction's offset field (mi * 2048 bytes)
+  uint32_t a_off[2], b_off[2];
   {
-    const int n = wave_n0 + lane;
-    bias_lds[lane] = has_bias ? (float)load_any(a.bias, a.bias_dt, n < a.N ? n : a.N - 1) : 0.0f;
+    const uint32_t arow = wm * 128 + r16, brow = wn * 64 + r16;
+    const uint32_t bsw = CODES ? (brow & 7u) : ((brow >> 1) & 7u);
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+      a_off[kq] = arow * 128 + (((kq * 4 + g4) ^ ((arow >> 1) & 7u)) << 4);
+      b_off[kq] = WL_IMAGE + brow * 128 + (((kq * 4 + g4) ^ bsw) << 4);
+    }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private: only this wave's own writes
-#pragma unroll 1
-  for (int i = 0; i < 4; ++i) {
+
+  wl_v4f acc[8][4];
+  wl_v4i fa[4], fb[4];
+  auto read_frags = [&](const uint8_t* st, int phase) {  // phase 0..3 of a super-step (compile-time after unrolling)
+    const int kq = phase >> 1, mh = phase & 1;
+    if (mh == 0) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int nj = 0; nj < 4; ++nj) fb[nj] = *reinterpret_cast<const wl_v4i*>(st + b_off[kq] + nj * 2048);
+    }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int nb = j * 32 + 8 * q + 4 * frag_g;
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_lds + nb);
-        float y[4];
+    for (int q = 0; q < 4; ++q) fa[q] = *reinterpret_cast<const wl_v4i*>(st + a_off[kq] + (4 * mh + q) * 2048);
+  };
+  auto mfma_row = [&](int mh, int q) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          // runtime i: pick the accumulator tile without dynamic register indexing
-          const float v = i == 0 ? acc[0][j][4 * q + t] : i == 1 ? acc[1][j][4 * q + t] : i == 2 ? acc[2][j][4 * q + t] : acc[3][j][4 * q + t];
-          y[t] = has_bias ? v + b4[t] : v;
-        }
-        if constexpr (sizeof(TOut) == 2) {
-          u32x2 pk;
-          pk.x = pack2<TOut>(y[0], y[1]);
-          pk.y = pack2<TOut>(y[2], y[3]);
-          *reinterpret_cast<u32x2*>(slab + frag_row * PITCH + nb * 2) = pk;
-        } else {
-          u32x4 pk;
-          pk.x = __builtin_bit_cast(uint32_t, y[0]); pk.y = __builtin_bit_cast(uint32_t, y[1]);
-          pk.z = __builtin_bit_cast(uint32_t, y[2]); pk.w = __builtin_bit_cast(uint32_t, y[3]);
-          *reinterpret_cast<u32x4*>(slab + frag_row * PITCH + nb * 4) = pk;
-        }
-      }
+    for (int n_ = 0; n_ < 4; ++n_) {
+      const int nj = (q & 1) ? 3 - n_ : n_;  // snake order: every MFMA shares one operand with its predecessor
+      if (mh == 0) acc[q][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wl_v8bf, fb[nj]), __builtin_bit_cast(wl_v8bf, fa[q]), acc[q][nj], 0, 0, 0);
+      else acc[4 + q][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wl_v8bf, fb[nj]), __builtin_bit_cast(wl_v8bf, fa[q]), acc[4 + q][nj], 0, 0, 0);
+    }
+  };
+  // An MFMA cluster: 16 MFMAs under s_setprio 1. `vmem` (LDS-DMA pieces / code loads) is issued behind the first four;
+  // `work` (the conversion of one row's codes: 32 VALU + 2 ds_write_b128) is interleaved with all sixteen, two VALU
+  // instructions behind each MFMA (a wave hides about 2.5 issue slots under a 16-cycle MFMA; in one lump the conversion
+  // would run with the matrix pipe idle — the partner wave only reads LDS meanwhile).
+  auto cluster = [&](int mh, auto vmem, auto work, auto has_work) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (full) {
-      constexpr int SEGS = 64 * (int)sizeof(TOut) / 16;   // 16-byte segments per row: 8 (bf16) or 16 (f32)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (decltype(has_work)::value) {
+      mfma_row(mh, 0);
+      mfma_row(mh, 1);
+      mfma_row(mh, 2);
+      mfma_row(mh, 3);
+      vmem();
+      work();
 #pragma unroll
-      for (int t = 0; t < 32 * SEGS / 64; ++t) {
-        const int c = lane + 64 * t;
-        const int row = c / SEGS, seg = c % SEGS;
-        const int mm = wave_m0 + i * 32 + row;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(slab + row * PITCH + seg * 16);
-        // non-temporal, as in ffq_linear.hip: the output must not push the operand panels out of L2
-        if (mm < a.M) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * a.N + wave_n0) * sizeof(TOut) + seg * 16));
+      for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two VALU
       }
-    } else {  // ragged right edge / unaligned rows: element stores (correctness path)
-      for (int c = lane; c < 32 * 64; c += 64) {
-        const int row = c >> 6, col = c & 63;
-        const int mm = wave_m0 + i * 32 + row;
-        if (mm < a.M && wave_n0 + col < a.N)
-          out[(size_t)mm * a.N + wave_n0 + col] = *reinterpret_cast<const TOut*>(slab + row * PITCH + col * sizeof(TOut));
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // the two LDS-DMA pieces
+#pragma unroll
+      for (int g = 0; g < 12; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);    // the two LDS stores last
+    } else {
+      mfma_row(mh, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      vmem();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_row(mh, 1);
+      mfma_row(mh, 2);
+      mfma_row(mh, 3);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  constexpr std::integral_constant<bool, CODES> kConverts{};
+  constexpr std::false_type kNoWork{};
+
+  const int ksuper = a.K / WL_BK;  // >= 2 (checked by the launcher)
+  int m0 = 0, n0 = 0;
+  tile_origin(0, m0, n0);
+  set_image_sources(m0, n0);
+  // ---- prologue: element 0 staged entirely, the codes of element 1 requested
+  if constexpr (CODES) {
+    set_code_sources(n0);
+    load_codes(0, true);
+    wait_all_vmem();
+    convert_row(0, 0);
+    convert_row(1, 0);
+    load_codes(1, false);
+  }
+  issue_a(0, 0, 0); issue_a(0, 0, 2); issue_b(0, 0, 0); issue_b(0, 0, 2);
+  wait_all_vmem();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int slot = 0;  // slot of the super-step about to be computed
+  for (int it = 0; it < my_tiles; ++it) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mi][nj][e] = 0.0f;
+    int nm0, nn0;
+    tile_origin(it + 1, nm0, nn0);
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // the upper group runs one interval behind
+    for (int ks = 0; ks < ksuper; ++ks) {
+      const uint8_t* st = lds + slot * WL_SLOT;
+      // images / conversion: element e + 1; code loads: element e + 2
+      const bool last = ks == ksuper - 1;
+      const int fetch = last ? 0 : ks + 1;
+      if (last) set_image_sources(nm0, nn0);
+      int code_ks = ks + 2;
+      bool code_new_tile = false;
+      if (code_ks >= ksuper) {
+        code_ks -= ksuper;
+        if (ks == ksuper - 2) { set_code_sources(nn0); code_new_tile = true; }
+      }
+      read_frags(st, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(0, [&] { issue_a(fetch, slot ^ 1, 0); issue_b(fetch, slot ^ 1, 0); }, [&] { convert_row(0, slot ^ 1); }, kConverts);
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(1, [&] { issue_a(fetch, slot ^ 1, 2); issue_b(fetch, slot ^ 1, 2); }, [&] { convert_row(1, slot ^ 1); }, kConverts);
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(0, [&] { load_codes(code_ks, code_new_tile); }, [] {}, kNoWork);
+      __builtin_amdgcn_s_barrier();
+      read_frags(st, 3);
+      wait_all_vmem();  // the fetched images and codes landed (and older epilogue stores); the B image's ds_writes retired at the last cluster's lgkmcnt(0)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cluster(1, [] {}, [] {}, kNoWork);
+      __builtin_amdgcn_s_barrier();
+      slot ^= 1;
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();  // same number of barriers for both groups
+    // ---- epilogue in the A image of the slot just consumed. The weight fragment is the MFMA's first operand: lane l holds,
+    // for tile (mi, nj), register t: row m = 16 mi + l % 16, column n = 16 nj + 4 (l / 16) + t — four consecutive output
+    // columns of one row.
+    __syncthreads();
+    {
+      TOut* out = static_cast<TOut*>(a.out);
+      constexpr int PITCH = 64 * (int)sizeof(TOut) + 16;
+      constexpr int SLAB = sizeof(TOut) == 2 ? 32 : 16;       // rows per round: the eight waves' slabs share one 64 KiB slot
+      constexpr int WAVE_BYTES = SLAB * PITCH + 256;          // one slab + the wave's 64 bias values
+      static_assert(8 * WAVE_BYTES <= WL_SLOT, "the epilogue scratch must fit the consumed slot");
+      uint8_t* region = lds + (slot ^ 1) * WL_SLOT + wave * WAVE_BYTES;
+      float* bias_lds = reinterpret_cast<float*>(region + SLAB * PITCH);
+      const int wave_n0 = n0 + wn * 64, wave_m0 = m0 + wm * 128;
+      const bool full = wave_n0 + 64 <= a.N && (a.N * (int)sizeof(TOut)) % 16 == 0;
+      const bool has_bias = a.bias != nullptr;
+      {
+        const int n = wave_n0 + lane;
+        bias_lds[lane] = has_bias ? (float)load_any(a.bias, a.bias_dt, n < a.N ? n : a.N - 1) : 0.0f;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private: only this wave's own writes
+#pragma unroll
+      for (int i = 0; i < 128 / SLAB; ++i) {
+#pragma unroll
+        for (int hh = 0; hh < SLAB / 16; ++hh) {
+          const int mi = (SLAB / 16) * i + hh;
+#pragma unroll
+          for (int nj = 0; nj < 4; ++nj) {
+            const int nb = nj * 16 + 4 * g4;
+            const wl_v4f b4 = *reinterpret_cast<const wl_v4f*>(bias_lds + nb);
+            float y[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) y[t] = has_bias ? acc[mi][nj][t] + b4[t] : acc[mi][nj][t];
+            if constexpr (sizeof(TOut) == 2) {
+              u32x2 pk;
+              pk.x = pack2<TOut>(y[0], y[1]);
+              pk.y = pack2<TOut>(y[2], y[3]);
+              *reinterpret_cast<u32x2*>(region + (16 * hh + r16) * PITCH + nb * 2) = pk;
+            } else {
+              u32x4 pk;
+              pk.x = __builtin_bit_cast(uint32_t, y[0]); pk.y = __builtin_bit_cast(uint32_t, y[1]);
+              pk.z = __builtin_bit_cast(uint32_t, y[2]); pk.w = __builtin_bit_cast(uint32_t, y[3]);
+              *reinterpret_cast<u32x4*>(region + (16 * hh + r16) * PITCH + nb * 4) = pk;
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (full) {
+          constexpr int SEGS = 64 * (int)sizeof(TOut) / 16;  // 16-byte segments per row: 8 (bf16) or 16 (f32)
+#pragma unroll
+          for (int t = 0; t < SLAB * SEGS / 64; ++t) {
+            const int c = lane + 64 * t;
+            const int row = c / SEGS, seg = c % SEGS;
+            const int mm = wave_m0 + i * SLAB + row;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * PITCH + seg * 16);
+            // non-temporal, as in ffq_linear.hip: the output must not push the operand panels out of L2
+            if (mm < a.M) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * a.N + wave_n0) * sizeof(TOut) + seg * 16));
+          }
+        } else {  // ragged right edge / unaligned rows: element stores (correctness path)
+          for (int c = lane; c < SLAB * 64; c += 64) {
+            const int row = c >> 6, col = c & 63;
+            const int mm = wave_m0 + i * SLAB + row;
+            if (mm < a.M && wave_n0 + col < a.N)
+              out[(size_t)mm * a.N + wave_n0 + col] = *reinterpret_cast<const TOut*>(region + row * PITCH + col * sizeof(TOut));
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is re-written by the next i
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is re-written by the next i
+    __syncthreads();  // the scratch slot is the next tile's staging target
+    m0 = nm0; n0 = nn0;
   }
+  wait_all_vmem();  // the trailing requests of the streams must not outlive the block's LDS / registers
 }
 
 }  // namespace ffq
@@ -545,24 +485,57 @@ __global__ __launch_bounds__(512, 2) void wq_bf16_gemm256_kernel(WLinearArgs a) 
 using namespace ffq;
 
 // 1 if ffq_linear_wq covers the problem with the MFMA kernel, 0 if the caller has to dequantize and use a float GEMM.
-extern "C" int ffq_linear_wq_supported(int x_dt, int w_dt, int out_dt, int64_t M, int64_t N, int64_t K, int64_t group) {
-  if (x_dt != FFQ_BF16 || w_dt != FFQ_I8 || !(out_dt == FFQ_BF16 || out_dt == FFQ_F32)) return 0;
+// `w_dt`: FFQ_I8 = one code per byte (pack_block = 0); FFQ_U8 = packed 4-bit codes as ffq_pack_int4 writes them with a
+// power-of-two `pack_block` >= 32.
+extern "C" int ffq_linear_wq_supported(int x_dt, int w_dt, int out_dt, int64_t M, int64_t N, int64_t K, int64_t group, int64_t pack_block) {
+  if (x_dt != FFQ_BF16 || !(out_dt == FFQ_BF16 || out_dt == FFQ_F32)) return 0;
   if (M <= 0 || N <= 0 || K < 2 * WL_BK || K % WL_BK != 0) return 0;
   if (group <= 0 || K % group != 0) return 0;
   if (group != K && group % WL_BK != 0) return 0;
-  if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return 0;
-  return 1;
+  if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX || (uint64_t)256 * (uint64_t)K * 2u + 128u >= (1ull << 32)) return 0;
+  if (w_dt == FFQ_I8) return pack_block == 0;
+  if (w_dt == FFQ_U8) return pack_block >= 32 && (pack_block & (pack_block - 1)) == 0 && K % pack_block == 0;
+  return 0;
 }
 
-extern "C" int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, const float* w_scale, const float* w_offset,
-                             int64_t scale_numel, int64_t group, const void* bias, int bias_dt, void* out, int out_dt, int64_t M,
-                             int64_t N, int64_t K, void* stream) {
+// workspace of the two-pass form (A2 of the whole weight into a bf16 image, then the GEMM on that image): N * K * 2 bytes.
+// The caller may pass less (or NULL): the one-pass kernel then runs for every M.
+extern "C" size_t ffq_linear_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M < WL_TWO_PASS_MIN_TOKENS || N <= 0 || K <= 0) return 0;
+  return (size_t)N * (size_t)K * 2u;
+}
+
+template <int BKIND, bool GROUPED, bool OFFSET, typename TOut>
+static void wq_launch(const WLinearArgs& a, hipStream_t s) {
+  const int total = a.tiles_m * a.tiles_n;
+  const unsigned grid = (unsigned)(total < 256 ? total : 256);
+  const size_t lds_bytes = (size_t)2 * WL_SLOT;
+  static uint64_t attr_set = 0;
+  ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_gemm256_kernel<BKIND, GROUPED, OFFSET, TOut>), (int)lds_bytes);
+  wq_gemm256_kernel<BKIND, GROUPED, OFFSET, TOut><<<grid, 512, lds_bytes, s>>>(a, total);
+}
+
+template <int BKIND>
+static void wq_dispatch(const WLinearArgs& a, bool grouped, bool offset, hipStream_t s) {
+  if constexpr (BKIND == WL_B_BF16) {
+    if (a.out_dt == FFQ_BF16) wq_launch<BKIND, false, false, bf16_t>(a, s); else wq_launch<BKIND, false, false, float>(a, s);
+  } else {
+#define FFQ_WL_T(G, O) do { if (a.out_dt == FFQ_BF16) wq_launch<BKIND, G, O, bf16_t>(a, s); else wq_launch<BKIND, G, O, float>(a, s); } while (0)
+    if (grouped) { if (offset) FFQ_WL_T(true, true); else FFQ_WL_T(true, false); }
+    else { if (offset) FFQ_WL_T(false, true); else FFQ_WL_T(false, false); }
+#undef FFQ_WL_T
+  }
+}
+
+extern "C" int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, int64_t pack_block, const float* w_scale,
+                             const float* w_offset, int64_t scale_numel, int64_t group, const void* bias, int bias_dt, void* out,
+                             int out_dt, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
   if (!x || !w_codes || !w_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
-  if (!ffq_linear_wq_supported(x_dt, w_dt, out_dt, M, N, K, group))
-    return fail(FFQ_ERR_DTYPE, "weight-only linear: needs bf16 activations, int8-container codes, bf16 / f32 output, K %% 64 == 0, K >= 128 and groups of a multiple of 64 input channels");
+  if (!ffq_linear_wq_supported(x_dt, w_dt, out_dt, M, N, K, group, pack_block))
+    return fail(FFQ_ERR_DTYPE, "weight-only linear: needs bf16 activations, int8-container or packed 4-bit codes, bf16 / f32 output, K %% 64 == 0, K >= 128 and groups of a multiple of 64 input channels");
   if (!aligned16(x) || !aligned16(w_codes) || !aligned16(out)) return fail(FFQ_ERR_DTYPE, "weight-only linear needs 16-byte aligned buffers");
   if (bias && !dt_valid(bias_dt)) return fail(FFQ_ERR_ARG, "bad bias dtype");
   const int64_t groups = K / group;
@@ -571,8 +544,8 @@ extern "C" int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w
   if (scale_numel == 1 && groups != 1) return fail(FFQ_ERR_PARAM_NUMEL, "one parameter pair needs group == K");
 
   WLinearArgs a;
-  a.x = static_cast<const uint16_t*>(x);
-  a.wq = static_cast<const int8_t*>(w_codes);
+  a.x = static_cast<const uint8_t*>(x);
+  a.w = static_cast<const uint8_t*>(w_codes);
   a.w_scale = w_scale; a.w_offset = w_offset;
   a.bias = bias; a.bias_dt = bias_dt;
   a.out = out; a.out_dt = out_dt;
@@ -580,26 +553,37 @@ extern "C" int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w
   a.groups = (int)groups;
   a.steps_per_group = (int)(group / WL_BK);
   a.per_row = scale_numel != 1;
+  a.pack_shift = 0;
+  for (int64_t b = pack_block; b > 1; b >>= 1) ++a.pack_shift;
   a.tiles_m = (int)((M + WL_BM - 1) / WL_BM);
   a.tiles_n = (int)((N + WL_BN - 1) / WL_BN);
-  const unsigned grid = (unsigned)(a.tiles_m * a.tiles_n);
-  const size_t lds_bytes = (size_t)WL_STAGES * WL_STAGE_BYTES + (size_t)WL_STAGES * WL_PARAM_BYTES;
-  const bool grouped = groups > 1;
-  const bool offset = w_offset != nullptr;
-#define FFQ_WL_LAUNCH(G, O, T)                                                                                              \
-  do {                                                                                                                      \
-    static uint64_t attr_set = 0;                                                                                           \
-    ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_bf16_gemm256_kernel<G, O, T>), (int)lds_bytes);         \
-    wq_bf16_gemm256_kernel<G, O, T><<<grid, 512, lds_bytes, s>>>(a);                                                        \
-  } while (0)
-#define FFQ_WL_DISPATCH(T)                                                                                                  \
-  do {                                                                                                                      \
-    if (grouped) { if (offset) FFQ_WL_LAUNCH(true, true, T); else FFQ_WL_LAUNCH(true, false, T); }                          \
-    else { if (offset) FFQ_WL_LAUNCH(false, true, T); else FFQ_WL_LAUNCH(false, false, T); }                                \
-  } while (0)
-  if (out_dt == FFQ_BF16) FFQ_WL_DISPATCH(bf16_t);
-  else FFQ_WL_DISPATCH(float);
-#undef FFQ_WL_DISPATCH
-#undef FFQ_WL_LAUNCH
-  return check_launch("wq_bf16_gemm256_kernel");
+  a.group_m = K >= 4096 ? 4 : WL_GROUP_M;  // row tiles whose A panels (256 x 2 K bytes each) a group's column tiles share in their XCD's L2
+#ifdef FFQ_EXPERIMENTS  // tuning builds only (tools/): the shipped library reads no environment
+  if (const char* gm = getenv("FFQ_WQ_GROUP_M")) a.group_m = atoi(gm);
+#endif
+  const bool grouped = groups > 1, offset = w_offset != nullptr;
+
+  const size_t image_bytes = (size_t)N * (size_t)K * 2u;
+  if (M >= WL_TWO_PASS_MIN_TOKENS && workspace && workspace_bytes >= image_bytes && aligned16(workspace)) {
+    // two-pass form: A2 of the whole weight once (3 or 2.5 B/elem, ~2 % of the GEMM at 16 k tokens), then the GEMM with both
+    // operands by LDS-DMA — no conversion work per row tile
+    ffq_tiling t;
+    t.ndim = 2;
+    t.shape[0] = N; t.shape[1] = K;
+    t.tile[0] = scale_numel == 1 ? N : 1; t.tile[1] = scale_numel == 1 ? K : group;
+    int rc;
+    if (w_dt == FFQ_U8)
+      rc = ffq_unpack_dequantize_int4(static_cast<const uint8_t*>(w_codes), w_scale, scale_numel, w_offset, w_offset ? scale_numel : 0, &t, pack_block, workspace, FFQ_BF16, stream);
+    else
+      rc = ffq_dequantize_by_tile(w_codes, FFQ_I8, w_scale, FFQ_F32, scale_numel, w_offset, FFQ_F32, w_offset ? scale_numel : 0, &t, workspace, FFQ_BF16, stream);
+    if (rc == FFQ_OK) {
+      a.w = static_cast<const uint8_t*>(workspace);
+      wq_dispatch<WL_B_BF16>(a, false, false, s);
+      return check_launch("wq_gemm256_kernel (bf16 image)");
+    }
+    if (rc != FFQ_ERR_DTYPE) return rc;  // a tiling the stand-alone dequantize kernels decline: the one-pass kernel below covers it
+  }
+  if (w_dt == FFQ_U8) wq_dispatch<WL_B_I4>(a, grouped, offset, s);
+  else wq_dispatch<WL_B_I8>(a, grouped, offset, s);
+  return check_launch("wq_gemm256_kernel");
 }

@@ -217,7 +217,7 @@ class DispatcherKernels:
             return None
         n, k = weight.shape
         lib = _native.library()
-        ok = lib.ffq_linear_wq_supported(ops._tag(x_dtype), ops._tag(torch.int8), ops._tag(x_dtype), max(int(tokens), 1), n, k, group)
+        ok = lib.ffq_linear_wq_supported(ops._tag(x_dtype), ops._tag(torch.int8), ops._tag(x_dtype), max(int(tokens), 1), n, k, group, 0)
         return group if ok else None
 
     def supported_linear(self, input: Any = None, weight: Any = None, bias: Any = None, **_: Any) -> bool:

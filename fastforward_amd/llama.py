@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import dataclasses
 import math
+import types
 
 import torch
 import torch.nn.functional as F
@@ -590,7 +591,7 @@ class FusedProducersForward:
     summation order inside RMSNorm and the attention launch's tolerance (see FusedForward).
     """
 
-    def __init__(self, model: LlamaModel) -> None:
+    def __init__(self, model: LlamaModel, weight_storage: str = "requantize") -> None:
         cfg = model.config
         if cfg.hidden_size % 16 or cfg.hidden_size > 8192 or cfg.head_dim % 16 or cfg.intermediate_size % 16:
             raise ff.exceptions.QuantizationError("hidden size / head dim outside the fused kernels' range")
@@ -600,19 +601,63 @@ class FusedProducersForward:
             is_linear_slot = ".layers." in "." + name and any(f"{p}." in name for p in ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"))
             if q is not None and not is_linear_slot and not q.is_stub():
                 raise ff.exceptions.QuantizationError(f"{name}: only the decoder linears' quantizers may be set (the producers between them are fused)")
+        if weight_storage not in ("requantize", "codes", "packed"):
+            raise ValueError("weight_storage is 'requantize', 'codes' or 'packed'")
         self.model = model
+        # How a WEIGHT-ONLY linear (stub input quantizer, static LinearQuantizer on the weight: BASELINE configs 2 / 4) gets its
+        # weight codes. "requantize": the weight quantizer runs on every call (reference nn/linear.py:34). "codes" / "packed":
+        # the codes are kept per (weight, scale, offset) version — int8 containers, or for <= 4-bit weights the packed nibbles
+        # of export/stages/gguf/_packing.py:44-53 (0.5 B per weight: config 4's storage), which the GEMM consumes as they are
+        # (ops.linear_wq(pack_block=...)); frozen inference weights do not change between forwards.
+        self.weight_storage = weight_storage
+        self._stored: dict[int, tuple[tuple[int, int, int], torch.Tensor, int]] = {}
 
-    @staticmethod
-    def _linear(x: torch.Tensor, linear: torch.nn.Module) -> torch.Tensor:
-        """QuantizedLinear.forward; int8 codes on both sides go to the int8 GEMM directly."""
-        if linear.bias is not None or linear.input_quantizer.is_stub() or linear.weight_quantizer.is_stub() or not linear.output_quantizer.is_stub():
+    def _stored_weight(self, linear: torch.nn.Module) -> tuple[torch.Tensor, int] | None:
+        """(codes or packed nibbles, packing block) of a weight-only linear's weight under ``weight_storage``, or None when
+        the linear is not of that kind (then its module forward runs)."""
+        from fastforward_amd.nn import LinearQuantizer
+
+        wq = linear.weight_quantizer
+        if (self.weight_storage == "requantize" or type(wq) is not LinearQuantizer or wq.has_uninitialized_params or next(iter(wq.overrides), None) is not None
+                or ff.fused_linear.KERNELS.weight_group(_Shaped(linear.weight, wq)) is None):
+            return None
+        key = (linear.weight._version, wq.scale._version, -1 if wq.offset is None else wq.offset._version)
+        hit = self._stored.get(id(linear))
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        group = ff.fused_linear.KERNELS.weight_group(_Shaped(linear.weight, wq))
+        block = 0
+        if self.weight_storage == "packed" and wq.num_bits == 4 and group % 32 == 0 and (group & (group - 1)) == 0:
+            block = min(group, 128)  # A1 (4 bits) + the nibble packing in one pass: the int8 codes never exist
+            tile = wq.granularity.tile_size(linear.weight.shape)
+            stored = ff.ops.quantize_pack_int4(linear.weight, wq.scale, linear.weight.shape if isinstance(tile, str) else tile, wq.offset, block=block)
+        else:
+            stored = wq(linear.weight).raw_data
+        if stored.dtype not in (torch.int8, torch.uint8):
+            return None
+        self._stored[id(linear)] = (key, stored, block)
+        return stored, block
+
+    def _linear(self, x: torch.Tensor, linear: torch.nn.Module) -> torch.Tensor:
+        """QuantizedLinear.forward; int8 codes on both sides go to the int8 GEMM directly, stored weight codes of a weight-only
+        linear to the bf16 x weight-code GEMM."""
+        if linear.bias is not None or linear.weight_quantizer.is_stub() or not linear.output_quantizer.is_stub():
+            return linear(x)
+        if linear.input_quantizer.is_stub():
+            stored = self._stored_weight(linear) if x.dtype == torch.bfloat16 else None
+            if stored is not None:
+                wq = linear.weight_quantizer
+                group = ff.fused_linear.KERNELS.weight_group(_Shaped(linear.weight, wq))
+                out = ff.ops.linear_wq(x, stored[0], wq.scale, wq.offset, group=group, pack_block=stored[1], out_dtype=x.dtype)
+                if out is not None:
+                    return out
             return linear(x)
         xq = linear.input_quantizer(x)
         wq = linear.weight_quantizer(linear.weight)
         if not (isinstance(xq, ff.QuantizedTensor) and isinstance(wq, ff.QuantizedTensor)) or xq.raw_data.dtype != torch.int8 or wq.raw_data.dtype != torch.int8:
             return ff.nn.functional.linear(xq, wq, None, output_quantizer=linear.output_quantizer)  # e.g. disable_quantization=True
         xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
-        if xp.scale.numel() != 1:
+        if xp.scale.numel() != 1 or ff.fused_linear.KERNELS.row_mode(wq) is None:
             return ff.nn.functional.linear(xq, wq, None, output_quantizer=linear.output_quantizer)
         # (an all-zero offset buffer of a symmetric weight quantizer is recognised by the GEMM on the device: no host read,
         # also while a range estimator rewrites the parameters on every step)
@@ -647,6 +692,14 @@ class FusedProducersForward:
 
 
 FusedCalibrationForward = FusedProducersForward  # the name the calibration path was introduced under
+
+
+class _Shaped:
+    """Just enough of a quantized weight for ``DispatcherKernels.weight_group``: a shape and its quantizer's granularity."""
+
+    def __init__(self, weight: torch.Tensor, quantizer: torch.nn.Module) -> None:
+        self.shape = weight.shape
+        self.quantization_context = types.SimpleNamespace(quantization_params=types.SimpleNamespace(granularity=quantizer.granularity))
 
 
 def count_quantizers(model: LlamaModel) -> int:

@@ -641,18 +641,31 @@ def linear_wq(
     group: int | None = None,
     bias: torch.Tensor | None = None,
     out_dtype: torch.dtype | None = None,
+    pack_block: int = 0,
+    two_pass: bool | None = None,
 ) -> torch.Tensor | None:
-    """A6, weight-only — ``F.linear(x, dequantize(w_codes))`` with the dequantization inside the GEMM's operand load
+    """A6, weight-only — ``F.linear(x, dequantize(w_codes))`` with the dequantization inside the GEMM's operand path
     (reference _gen/fallback.py:86-112: quantized weight, plain input).
 
-    `x` is [..., K] bf16, `w_codes` [N, K] int8 (codes of any bit-width <= 8), `w_scale` / `w_offset` fp32 with 1 entry
-    (per-tensor), N entries (per output channel) or N * K / group entries ([N, K / group] row-major: groups of `group`
-    input channels, PerBlock(1, group, 0)). The weight the matrix cores see is bit for bit A2's bf16 result.
+    `x` is [..., K] bf16. `w_codes` is [N, K] int8 (codes of any bit-width <= 8) or, with ``pack_block`` > 0, the uint8
+    output of :func:`pack_int4` / :func:`quantize_pack_int4` for an [N, K] weight packed with that block (two 4-bit codes per
+    byte, [N * K / 2] or [N, K / 2]). `w_scale` / `w_offset` fp32 with 1 entry (per-tensor), N entries (per output channel)
+    or N * K / group entries ([N, K / group] row-major: groups of `group` input channels, PerBlock(1, group, 0)).
+    The weight the matrix cores see is bit for bit A2's bf16 result. ``two_pass``: None = the library's rule (from 4096
+    tokens on A2 runs once per call into a scratch tensor and the GEMM streams that image), False = always convert inside
+    the GEMM, True = offer the scratch tensor regardless of M (the library still decides).
     Returns None when the kernel does not cover the problem (dtypes, K % 64, group % 64): the caller dequantizes and runs a
     float GEMM as the reference does."""
-    if w_codes.dim() != 2:
-        raise RuntimeError("linear_wq expects a [N, K] weight")
-    N, K = w_codes.shape
+    packed = pack_block > 0
+    if packed:
+        K = x.shape[-1]
+        if w_codes.dtype != torch.uint8 or K == 0 or (w_codes.numel() * 2) % K:
+            raise RuntimeError("packed weights are the uint8 output of pack_int4 for an [N, K] weight")
+        N = w_codes.numel() * 2 // K
+    else:
+        if w_codes.dim() != 2:
+            raise RuntimeError("linear_wq expects a [N, K] weight")
+        N, K = w_codes.shape
     if x.shape[-1] != K:
         raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({x.numel() // max(x.shape[-1], 1)}x{x.shape[-1]} and {N}x{K}^T)")
     group = K if group is None else int(group)
@@ -661,7 +674,7 @@ def linear_wq(
         return None
     M = x.numel() // K if K else 0
     lib = _native.library()
-    if not lib.ffq_linear_wq_supported(_tag(x.dtype), _tag(w_codes.dtype), _tag(out_dtype), M, N, K, group):
+    if not lib.ffq_linear_wq_supported(_tag(x.dtype), _tag(w_codes.dtype), _tag(out_dtype), M, N, K, group, int(pack_block)):
         return None
     xc, wc = x.detach().contiguous(), w_codes.detach().contiguous()
     sc = w_scale.detach().reshape(-1).to(torch.float32).contiguous()
@@ -671,10 +684,12 @@ def linear_wq(
     bias_c = None if bias is None else bias.detach().contiguous()
     lib, stream = _prepare(xc, wc, sc, of, bias_c)
     out = torch.empty((*xc.shape[:-1], N), dtype=out_dtype, device=xc.device)
+    nbytes = 0 if two_pass is False else (N * K * 2 if two_pass else lib.ffq_linear_wq_workspace_bytes(M, N, K))
+    ws = _workspace(nbytes, xc.device)
     lib.check(
         lib.ffq_linear_wq(
-            _ptr(xc), _tag(xc.dtype), _ptr(wc), _tag(wc.dtype), _ptr(sc), _ptr(of), sc.numel(), group,
-            _ptr(bias_c), _tag(bias_c.dtype) if bias_c is not None else 0, _ptr(out), _tag(out_dtype), M, N, K, stream,
+            _ptr(xc), _tag(xc.dtype), _ptr(wc), _tag(wc.dtype), int(pack_block), _ptr(sc), _ptr(of), sc.numel(), group,
+            _ptr(bias_c), _tag(bias_c.dtype) if bias_c is not None else 0, _ptr(out), _tag(out_dtype), M, N, K, _ptr(ws), nbytes, stream,
         )
     )
     return out

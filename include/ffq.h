@@ -200,19 +200,27 @@ int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum,
 /*
  * A6 (weight-only) — the branch of `fallback.linear` taken by a quantized WEIGHT and a plain, non-quantized INPUT
  * (_gen/fallback.py:77-112 with strict_quantization off, :86-100): y = F.linear(x, weight.dequantize(), bias).
- * `x` is [M, K] bf16, `w_codes` [N, K] integer codes in an int8 container (any num_bits <= 8), `w_scale` / `w_offset`
- * (nullable) hold `scale_numel` = 1 or N * (K / group) fp32 entries in tiles_to_rows order ([N, K / group] row-major):
- * group == K is per-tensor / PerChannel(0), group < K is PerBlock(block_dims=1, block_sizes=group, per_channel_dims=0)
- * (quantization/granularity.py:159-216; BASELINE config 4: group 128). The codes are dequantized in registers with A2's
- * arithmetic, (float(q) + round_half_even(o)) * s in fp32 rounded once to bf16 — the B operand of the bf16 MFMA is bit
- * for bit the reference's dequantized weight, accumulation is fp32; only the summation order differs from F.linear.
- * ffq_linear_wq_supported() == 0 (K % 64 != 0, other dtypes, group % 64 != 0): the caller dequantizes (A2) and runs a
- * float GEMM, as the reference does.
+ * `x` is [M, K] bf16. `w_codes` holds the weight's integer codes (any num_bits <= 8) either one per byte
+ * (`w_dt` = FFQ_I8, [N, K], `pack_block` = 0) or, for 4-bit codes, PACKED two per byte exactly as ffq_pack_int4 writes them
+ * (`w_dt` = FFQ_U8, [N, K / 2], `pack_block` = the packing block: a power of two >= 32 dividing K — the GGUF Q4_0 nibble
+ * order of export/stages/gguf/_packing.py:44-53 applied along each row; BASELINE config 4 packs with its group size 128).
+ * `w_scale` / `w_offset` (nullable) hold `scale_numel` = 1 or N * (K / group) fp32 entries in tiles_to_rows order
+ * ([N, K / group] row-major): group == K is per-tensor / PerChannel(0), group < K is PerBlock(block_dims=1,
+ * block_sizes=group, per_channel_dims=0) (quantization/granularity.py:159-216; config 4: group 128).
+ * The codes are dequantized with A2's arithmetic, (float(q) + round_half_even(o)) * s in fp32 rounded once to bf16 — the B
+ * operand of the bf16 MFMA is bit for bit the reference's dequantized weight, accumulation is fp32; only the summation order
+ * differs from F.linear. One launch converts the codes once per 256-row tile on their way into LDS; with `workspace` of at
+ * least ffq_linear_wq_workspace_bytes() (non-zero from 4096 tokens on: N * K * 2 bytes) the weight is dequantized once per
+ * CALL by A2 into that workspace and the GEMM streams the bf16 image — same operands, same results up to summation order
+ * (identical tile walk: bit-identical in fact), faster at large M. workspace may be NULL.
+ * ffq_linear_wq_supported() == 0 (K % 64 != 0, K < 128, other dtypes, group % 64 != 0): the caller dequantizes (A2) and
+ * runs a float GEMM, as the reference does.
  */
-int ffq_linear_wq_supported(int x_dt, int w_dt, int out_dt, int64_t M, int64_t N, int64_t K, int64_t group);
-int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, const float* w_scale, const float* w_offset,
-                  int64_t scale_numel, int64_t group, const void* bias, int bias_dt, void* out, int out_dt, int64_t M,
-                  int64_t N, int64_t K, void* stream);
+int ffq_linear_wq_supported(int x_dt, int w_dt, int out_dt, int64_t M, int64_t N, int64_t K, int64_t group, int64_t pack_block);
+size_t ffq_linear_wq_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, int64_t pack_block, const float* w_scale,
+                  const float* w_offset, int64_t scale_numel, int64_t group, const void* bias, int bias_dt, void* out,
+                  int out_dt, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Producer-fused A1 (ABI version 2). In the reference's quantized Llama helpers

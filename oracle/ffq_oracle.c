@@ -693,24 +693,37 @@ int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum,
  * torch.nn.functional.linear. The contraction is accumulated in double (the exact value of the same operands; a float
  * GEMM's result depends on its summation order), bias added, rounded once to `out_dt`.
  */
-int ffq_linear_wq_supported(int x_dt, int w_dt, int out_dt, int64_t M, int64_t N, int64_t K, int64_t group) {
+int ffq_linear_wq_supported(int x_dt, int w_dt, int out_dt, int64_t M, int64_t N, int64_t K, int64_t group, int64_t pack_block) {
   (void)M; (void)N;
-  if (!(x_dt == FFQ_BF16 || x_dt == FFQ_F32 || x_dt == FFQ_F16) || w_dt != FFQ_I8 || !dt_is_float(out_dt)) return 0;
-  return group > 0 && K % group == 0;
+  if (!(x_dt == FFQ_BF16 || x_dt == FFQ_F32 || x_dt == FFQ_F16) || !dt_is_float(out_dt)) return 0;
+  if (!(group > 0 && K % group == 0)) return 0;
+  if (w_dt == FFQ_I8) return pack_block == 0;
+  if (w_dt == FFQ_U8) return pack_block >= 2 && pack_block % 2 == 0 && K % pack_block == 0;
+  return 0;
 }
 
-int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, const float* w_scale, const float* w_offset,
-                  int64_t scale_numel, int64_t group, const void* bias, int bias_dt, void* out, int out_dt, int64_t M,
-                  int64_t N, int64_t K, void* stream) {
-  (void)stream;
+size_t ffq_linear_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) { (void)M; (void)N; (void)K; return 0; }
+
+/* code (n, k) of a weight stored one code per byte, or packed two per byte as ffq_pack_int4 writes a row of K codes with
+ * block `pack_block` (_packing.py:44-53: byte j of a block = code j | code (j + block / 2) << 4, both + 8) */
+static double wq_code(const void* w_codes, int64_t pack_block, int64_t n, int64_t k, int64_t K) {
+  if (pack_block == 0) return (double)((const int8_t*)w_codes)[n * K + k];
+  int64_t half = pack_block / 2, blk = k / pack_block, within = k % pack_block;
+  uint8_t byte = ((const uint8_t*)w_codes)[n * (K / 2) + blk * half + within % half];
+  return (double)((int)((within / half) ? (byte >> 4) : (byte & 15)) - 8);
+}
+
+int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, int64_t pack_block, const float* w_scale,
+                  const float* w_offset, int64_t scale_numel, int64_t group, const void* bias, int bias_dt, void* out,
+                  int out_dt, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)stream; (void)workspace; (void)workspace_bytes;
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
   if (!x || !w_codes || !w_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
-  if (!ffq_linear_wq_supported(x_dt, w_dt, out_dt, M, N, K, group)) return fail(FFQ_ERR_DTYPE, "weight-only linear: unsupported dtypes / group");
+  if (!ffq_linear_wq_supported(x_dt, w_dt, out_dt, M, N, K, group, pack_block)) return fail(FFQ_ERR_DTYPE, "weight-only linear: unsupported dtypes / group / packing");
   int64_t groups = K / group;
   if (!(scale_numel == 1 || scale_numel == N * groups))
     return fail(FFQ_ERR_PARAM_NUMEL, "weight-only linear: %lld parameters for %lld x %lld tiles", (long long)scale_numel, (long long)N, (long long)groups);
-  const int8_t* wq = (const int8_t*)w_codes;
   double* wr = (double*)malloc(sizeof(double) * (size_t)(K > 0 ? K : 1));
   if (!wr) return fail(FFQ_ERR_ARG, "out of memory");
   for (int64_t n = 0; n < N; ++n) {
@@ -718,7 +731,7 @@ int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, const 
       int64_t t = scale_numel == 1 ? 0 : n * groups + k / group;
       double o = w_offset ? (double)nearbyintf(w_offset[t]) : 0.0;
       /* weight.dequantize(): (q + o) * s in fp32, cast to the dequantize dtype                       (A2) */
-      double v = op2(OP_MUL, op2(OP_ADD, (double)wq[n * K + k], o, FFQ_F32), (double)w_scale[t], FFQ_F32);
+      double v = op2(OP_MUL, op2(OP_ADD, wq_code(w_codes, pack_block, n, k, K), o, FFQ_F32), (double)w_scale[t], FFQ_F32);
       wr[k] = cast_to(v, FFQ_F32, x_dt);
     }
     for (int64_t m = 0; m < M; ++m) {

@@ -258,12 +258,19 @@ def test_weight_only_linear_is_exact_where_the_sum_is_order_independent(n, k, gr
     grp = k if group is None else group
     exps = torch.randint(3, 5, (n * (k // grp),), device=DEV, generator=g)
     scale = torch.pow(2.0, -exps.float())
-    y = ops.linear_wq(x, codes, scale, None, group=grp)
-    assert y is not None
     w64 = (codes.double().view(n, k // grp, grp) * scale.double().view(n, k // grp, 1)).view(n, k)
     chunk = 2048 if n * k <= 14336 * 4096 else 1024
-    for r0 in range(0, T, chunk):
-        ref = x[r0:r0 + chunk].double() @ w64.t()
-        assert float(ref.abs().max()) * 16 < 2**24
-        assert torch.equal(y[r0:r0 + chunk], ref.to(torch.bfloat16)), f"rows {r0}..: {int((y[r0:r0 + chunk] != ref.to(torch.bfloat16)).sum())} outputs differ"
-        del ref
+    # the codes as int8 (converted inside the GEMM / by A2 as its own pass) and, for W4, as packed nibbles (config 4's storage)
+    forms = [("int8, one pass", codes, dict(two_pass=False)), ("int8, two passes", codes, dict(two_pass=True))]
+    if bits == 4:
+        packed = ops.pack_int4(codes, block=128)
+        forms += [("packed nibbles, one pass", packed, dict(pack_block=128, two_pass=False)), ("packed nibbles, two passes", packed, dict(pack_block=128, two_pass=True))]
+    for label, weight, kwargs in forms:
+        y = ops.linear_wq(x, weight, scale, None, group=grp, **kwargs)
+        assert y is not None, label
+        for r0 in range(0, T, chunk):
+            ref = x[r0:r0 + chunk].double() @ w64.t()
+            assert float(ref.abs().max()) * 16 < 2**24
+            assert torch.equal(y[r0:r0 + chunk], ref.to(torch.bfloat16)), f"{label}, rows {r0}..: {int((y[r0:r0 + chunk] != ref.to(torch.bfloat16)).sum())} outputs differ"
+            del ref
+        del y

@@ -722,34 +722,61 @@ def _wq_case(n, k, group, bits, offset, seed):
     return codes.to(DEV), scale.to(DEV), None if off is None else off.to(DEV)
 
 
-@pytest.mark.parametrize("k,group,bits,offset", [(512, 512, 8, False), (512, 128, 4, False), (384, 64, 4, True), (1024, 1024, 8, True), (256, 128, 8, True)])
+def _wq_forms(codes, group, bits, m):
+    """The ways one weight reaches the kernel: int8 container, packed nibbles (4-bit codes; the GGUF block sizes and the group
+    size as packing block), each converted inside the GEMM (one pass) or by A2 as its own pass (two passes, offered from 4096
+    tokens on) -> (label, kwargs of ops.linear_wq, weight tensor)."""
+    forms = [("int8", dict(two_pass=False), codes)]
+    if m >= 4096:
+        forms.append(("int8, two passes", dict(two_pass=True), codes))
+    if bits == 4:
+        k = codes.shape[1]
+        for block in sorted({32, 64, 128, min(group, 256)}):
+            if k % block == 0:
+                forms.append((f"packed block {block}", dict(pack_block=block, two_pass=False), ops.pack_int4(codes, block=block)))
+        if m >= 4096:
+            forms.append(("packed block 128, two passes", dict(pack_block=128, two_pass=True), ops.pack_int4(codes, block=128)))
+    return forms
+
+
+@pytest.mark.parametrize("k,group,bits,offset", [(512, 512, 8, False), (512, 128, 4, False), (384, 64, 4, True), (1024, 1024, 8, True), (256, 128, 8, True), (1024, 256, 4, True)])
 def test_weight_only_linear_operand_is_exactly_the_dequantized_weight(k, group, bits, offset):
     """x = identity: every output is ONE product 1.0 * w^, so y[m, n] == dequantize_by_tile(codes)[n, m] bit for bit —
-    the in-register dequantization of the GEMM's operand load is A2 (checked against the A2 kernel itself)."""
+    the conversion of the GEMM's B operand (int8 codes or packed nibbles of every packing block) is A2, checked against the
+    A2 kernel itself. Scales down to 2^-126 included: the nibble path scales by s / 16 only where that is exact."""
     n = 320
     codes, scale, off = _wq_case(n, k, group, bits, offset, seed=k + group)
+    scale[::7] *= 2.0**-115  # tiny (some denormal after / 16) scales on a subset of the tiles
+    scale[3] = 0.0
     x = torch.eye(k, device=DEV, dtype=torch.bfloat16)
-    y = ops.linear_wq(x, codes, scale, off, group=group)
-    assert y is not None and y.dtype == torch.bfloat16
     want = ops.dequantize_by_tile(codes, scale, (1, group), off, torch.bfloat16)
-    assert torch.equal(y, want.t()), mismatch_report(y.cpu(), want.t().cpu())
+    for label, kwargs, weight in _wq_forms(codes, group, bits, k):
+        y = ops.linear_wq(x, weight, scale, off, group=group, **kwargs)
+        assert y is not None and y.dtype == torch.bfloat16, label
+        assert torch.equal(y, want.t()), label + ": " + mismatch_report(y.cpu(), want.t().cpu())
 
 
-@pytest.mark.parametrize("m,n,k,group", [(1, 256, 128, 128), (300, 130, 512, 512), (257, 515, 1024, 128), (2050, 2300, 192, 64), (4100, 1030, 1024, 1024), (77, 64, 4096, 128)])
+@pytest.mark.parametrize("m,n,k,group", [(1, 256, 128, 128), (300, 130, 512, 512), (257, 515, 1024, 128), (2050, 2300, 192, 64), (4100, 1030, 1024, 1024), (77, 64, 4096, 128), (4200, 520, 640, 128)])
 @pytest.mark.parametrize("offset,bias,out_dtype", [(False, False, torch.bfloat16), (True, True, torch.bfloat16), (False, True, torch.float32)])
 def test_weight_only_linear_matches_float64_of_the_same_operands(m, n, k, group, offset, bias, out_dtype):
-    """Ragged M / N, every K-loop length, grouped and per-channel parameters, offsets, bias, both output dtypes: within one
-    output rounding (+ fp32 accumulation) of the float64 product of x and the A2-dequantized weight."""
+    """Ragged M / N, every K-loop length, grouped and per-channel parameters, offsets, bias, both output dtypes, every storage
+    form of the weight: within one output rounding (+ fp32 accumulation) of the float64 product of x and the A2-dequantized
+    weight — and all forms agree bit for bit (same operands, same tile walk, same summation order)."""
     gen = torch.Generator().manual_seed(m * 3 + n + k)
-    codes, scale, off = _wq_case(n, k, group, 8 if group == k else 4, offset, seed=m + n + k)
+    bits = 8 if group == k else 4
+    codes, scale, off = _wq_case(n, k, group, bits, offset, seed=m + n + k)
     x = torch.randn(m, k, generator=gen).to(torch.bfloat16).to(DEV)
     b = torch.randn(n, generator=gen).to(torch.bfloat16).to(DEV) if bias else None
-    y = ops.linear_wq(x, codes, scale, off, group=group, bias=b, out_dtype=out_dtype)
-    assert y is not None and y.dtype == out_dtype and y.shape == (m, n)
     w_hat = ops.dequantize_by_tile(codes, scale, (1, group), off, torch.bfloat16)
     ref = x.double() @ w_hat.double().t() + (0 if b is None else b.double())
     rtol = 2.0**-8 if out_dtype == torch.bfloat16 else 1e-5
-    torch.testing.assert_close(y.double(), ref, rtol=rtol, atol=1e-5 * float(ref.abs().max()) + 1e-6 * k)
+    first = None
+    for label, kwargs, weight in _wq_forms(codes, group, bits, m):
+        y = ops.linear_wq(x, weight, scale, off, group=group, bias=b, out_dtype=out_dtype, **kwargs)
+        assert y is not None and y.dtype == out_dtype and y.shape == (m, n), label
+        torch.testing.assert_close(y.double(), ref, rtol=rtol, atol=1e-5 * float(ref.abs().max()) + 1e-6 * k, msg=lambda msg: f"{label}: {msg}")
+        first = y if first is None else first
+        assert torch.equal(y, first), f"{label} differs from the int8-container form"
 
 
 def test_weight_only_linear_refuses_what_it_does_not_cover():
@@ -757,6 +784,7 @@ def test_weight_only_linear_refuses_what_it_does_not_cover():
     x = torch.randn(8, 192, device=DEV, dtype=torch.bfloat16)
     assert ops.linear_wq(x, codes, scale, off, group=96) is None
     assert ops.linear_wq(x.float(), codes, scale[:64], None) is None  # fp32 activations: the float fallback's job
+    assert ops.linear_wq(x, ops.pack_int4(codes, block=24), scale, off, group=192, pack_block=24) is None  # packing blocks: powers of two >= 32
     # ... and the dispatcher then runs the reference's path (dequantize + F.linear) with the same result as ever
     w = torch.randn(64, 192, device=DEV, dtype=torch.bfloat16)
     q = ff.nn.LinearQuantizer(4, granularity=ff.PerBlock(1, 96, 0), quantized_dtype=torch.int8, device=DEV)

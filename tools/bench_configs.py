@@ -7,7 +7,7 @@
   cfg3  cfg2 + A8 per-tensor: RunningMinMax calibration over 512 sequences x 2048 (64 steps of 8):
         sequences/s, then the timed W8A8 forward (same as bench.py; repeated here for one table)
   cfg4  W4 PerBlock(128) weights: quantize+pack GB/s (2.5 B/elem), unpack+dequantize GB/s (2.5 B/elem),
-        forward tokens/s (codes re-quantized every step, float fallback GEMM as in the reference)
+        forward tokens/s (hand-written weight-code GEMM; packed-nibble storage; the vendor-GEMM arm for comparison)
   cfg5  Llama-3-70B shapes, cfg3 recipe, this GPU's share of the 512 sequences (64 on an 8-GPU node):
         calibration wall time; the all-reduce payload (what 8 ranks would exchange)
 
@@ -76,7 +76,7 @@ def cfg2() -> dict:
     model = llama.build_model(config, DEV, torch.bfloat16, seed=1234 + 1)
     llama.quantize_llama(model, w_bits=8, a_bits=None, quantized_dtype=torch.int8)
     llama.calibrate(model, [ids(config, 1, 256, 1)])  # weight ranges only (no activation quantizers)
-    out = {"config": "Llama-3-8B W8 per-channel weight-only, bf16 activations (float fallback GEMM on dequantized weights, as the reference)"}
+    out = {"config": "Llama-3-8B W8 per-channel weight-only, bf16 activations"}
     for b in (1, 8):
         batch = ids(config, b, 2048, 2 + b)
 
@@ -89,11 +89,15 @@ def cfg2() -> dict:
         producers = llama.FusedProducersForward(model)
         s = timed_forward(lambda: producers(batch, logits=True))
         out[f"forward_B{b}_S2048"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(b * 2048 / s, 1),
-                                      "forward": "FusedProducersForward (RMSNorm / rotary / SiLU*up / attention as one-pass kernels; linears: module forward = A1 + A2 + the vendor's bf16 GEMM, the default)"}
-        with ff.fused_linear.weight_only_kernel(True):  # the hand-written bf16 x int8-code GEMM (A2 in the operand load) for every decoder linear
+                                      "forward": "FusedProducersForward (RMSNorm / rotary / SiLU*up / attention as one-pass kernels); decoder linears: weight quantizer every call (A1), then the hand-written bf16 x weight-code GEMM (ops.linear_wq: A2 once per call + bf16-image GEMM from 4096 tokens on, conversion inside the GEMM below) — no vendor GEMM on the quantized path; lm_head stays float"}
+        with ff.fused_linear.weight_only_kernel(False):  # A/B arm: the reference's own path for such linears (A2 + F.linear = the vendor's bf16 GEMM)
             s = timed_forward(lambda: producers(batch, logits=True))
-        out[f"forward_B{b}_S2048_hand_written_weight_only_gemm"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(b * 2048 / s, 1),
-                                                                   "forward": "same, decoder linears through ops.linear_wq (no vendor GEMM on the quantized path; lm_head stays float)"}
+        out[f"forward_B{b}_S2048_vendor_gemm_arm"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(b * 2048 / s, 1),
+                                                     "forward": "same, decoder linears through the float fallback (fallback.py:86-112: A2 + F.linear on the vendor's GEMM)"}
+        stored = llama.FusedProducersForward(model, weight_storage="codes")
+        s = timed_forward(lambda: stored(batch, logits=True))
+        out[f"forward_B{b}_S2048_stored_codes"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(b * 2048 / s, 1),
+                                                  "forward": "same as the first, int8 weight codes kept across steps (SURVEY 8(f) row 1): no per-step A1"}
     # whole-model weight quantization: 6.98 G elements, 3 B/elem
     linears = [l for _, l in llama.decoder_linears(model)]
 
@@ -207,11 +211,17 @@ def cfg4() -> dict:
     producers = llama.FusedProducersForward(model)
     s = timed_forward(lambda: producers(batch, logits=True))
     out["forward_B8_S2048"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(8 * 2048 / s, 1),
-                               "forward": "FusedProducersForward (RMSNorm / rotary / SiLU*up / attention as one-pass kernels; linears: module forward = A1 + A2 + the vendor's bf16 GEMM, the default)"}
-    with ff.fused_linear.weight_only_kernel(True):
+                               "forward": "FusedProducersForward; decoder linears: weight quantizer every call (A1, int8 container), then ops.linear_wq with group-128 parameters — no vendor GEMM on the quantized path"}
+    with ff.fused_linear.weight_only_kernel(False):
         s = timed_forward(lambda: producers(batch, logits=True))
-    out["forward_B8_S2048_hand_written_weight_only_gemm"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(8 * 2048 / s, 1),
-                                                            "forward": "same, decoder linears through ops.linear_wq with group-128 parameters dequantized in the operand load"}
+    out["forward_B8_S2048_vendor_gemm_arm"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(8 * 2048 / s, 1),
+                                               "forward": "same, decoder linears through the float fallback (A2 + F.linear on the vendor's GEMM)"}
+    packed = llama.FusedProducersForward(model, weight_storage="packed")
+    s = timed_forward(lambda: packed(batch, logits=True))
+    stored_bytes = sum(t[1].numel() * t[1].element_size() for t in packed._stored.values())
+    out["forward_B8_S2048_packed_nibbles"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(8 * 2048 / s, 1), "stored_weight_bytes": stored_bytes,
+                                              "bytes_per_weight": round(stored_bytes / config.quantized_weight_elems(), 3),
+                                              "forward": "weights STORED as packed nibbles (quantize+pack once, 0.5 B per weight), consumed by ops.linear_wq(pack_block=128) as they are: unpack + A2 into the GEMM's bf16 image (two-pass form) or inside the GEMM"}
     return out
 
 
