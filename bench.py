@@ -29,6 +29,7 @@ eager ATen chain (oracle/eager_chain.py, a port) timed on this box's host cores 
 from __future__ import annotations
 
 import argparse
+import dataclasses
 import json
 import os
 import pathlib
@@ -90,7 +91,25 @@ def _pmc_tables(stem: str):
     writes = sorted(glob.glob(str(ROOT / "profiles" / f"*{stem}WRITE_SIZE.json")))
     if not reads or not writes:
         return None
-    return json.load(open(reads[-1])), json.load(open(writes[-1])), pathlib.Path(reads[-1]).name.split("_pmc_")[0]
+    r, w = json.load(open(reads[-1])), json.load(open(writes[-1]))
+    stamp = r.pop("__kernel_source_sha16__", None)
+    w.pop("__kernel_source_sha16__", None)
+    PMC_STAMPS[pathlib.Path(reads[-1]).name] = stamp
+    return r, w, pathlib.Path(reads[-1]).name.split("_pmc_")[0]
+
+
+PMC_STAMPS: dict[str, "str | None"] = {}  # profile file -> fingerprint of the kernel sources it was measured on (None: older profile)
+
+
+def kernel_source_sha16() -> str:
+    """Fingerprint of csrc/*.hip + *.h as tools/pmc_summary.py stamps it into the PMC profiles."""
+    import hashlib
+
+    root = ROOT / "fastforward_amd" / "csrc"
+    h = hashlib.sha256()
+    for f in sorted(list(root.glob("*.hip")) + list(root.glob("*.h"))):
+        h.update(f.name.encode() + b"\0" + f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(*needles: str, stems: tuple[str, ...] = ("_pmc_", "_pmc_hbm_")) -> tuple[float | None, str | None]:
@@ -192,8 +211,10 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
     traffic, traffic_variants, prof = pmc_traffic_mix(("w8a8_gemm256fq_kernel", "w8a8_gemm256fp_kernel"))  # the persistent kernel: 16x16x64 form, or the 32x32x32 form under FFQ_GEMM_FQ=0
     # algorithmic bytes of the same launch mix: int8 activation codes + int8 weight codes read once, output written once
     # (bf16 for the plain launches; int8 codes for the gate+up launch, which reads two weight matrices)
-    alg_bytes = sum(c * (tokens * k + n * k + tokens * n * 2) for (n, k), c in {(h, h): 2, (kv, h): 2, (h, i): 1}.items()) + (tokens * h + 2 * i * h + tokens * i)
-    alg_launches = 6
+    # (shape, launches per layer) as a LIST: with kv == h (an MHA config such as --model tiny) dict keys would collide
+    plain_launches = [((h, h), 2), ((kv, h), 2), ((h, i), 1)]
+    alg_bytes = sum(c * (tokens * k + n * k + tokens * n * 2) for (n, k), c in plain_launches) + (tokens * h + 2 * i * h + tokens * i)
+    alg_launches = sum(c for _, c in plain_launches) + 1
     # what back-to-back MFMAs alone sustain on toggling operands (no memory traffic): tools/probes/mfma_power.hip, committed run
     ceiling = None
     probe = ROOT / "profiles" / "r01_mfma_power_probe.txt"
@@ -212,6 +233,8 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
         "mfma_only_ceiling_note": None if ceiling is None else "TOP/s of v_mfma_i32_16x16x64_i8 issued back to back on random operands, no LDS / global traffic "
                                   "(profiles/r01_mfma_power_probe.txt): the chip is power-limited on real data; frac stays against the nominal peak",
         "traffic": traffic,
+        "traffic_lookup": {"kernel_source_sha16_now": kernel_source_sha16(), "profiles": dict(PMC_STAMPS),
+                           "note": "traffic figures are lookups of committed rocprofv3 --pmc passes (a process cannot profile itself); a profile whose stamp differs from kernel_source_sha16_now was measured on older kernel sources"},
         "traffic_note": None if traffic is None else f"fabric (L2-miss) read+write bytes per launch from FETCH_SIZE x2 + WRITE_SIZE, launch-count-weighted mean over BOTH kernel variants of the forward "
                         f"(plain bf16-out and the gate+up / SiLU / quantize launch); separate --pmc passes of profiles/{prof}_pmc_*.json. Infinity-Cache hits are counted, so this is L2->fabric traffic, an upper bound of HBM bytes",
         "traffic_per_variant": traffic_variants,
@@ -329,11 +352,24 @@ def cpu_baseline(config: llama.LlamaConfig, budget_s: float = 20.0) -> dict:
     while seconds < 10.0 and tokens < 8192:  # the probes over-estimate the slope: grow the sample to >= 10 s of CPU work
         tokens *= 2
         seconds = layer(tokens)
+    # the per-op CPU numbers behind BASELINE.md §3's table, on the headline weight shape (all shapes: profiles/r03_micro.md)
+    w = weights[4]  # gate_proj [intermediate, hidden]
+    tile = (1, w.shape[1])
+    codes = eager_chain.quantize(w, params[4], tile, 8, torch.int8)
+    per_op = {}
+    for name, fn in (("A1 quantize bf16->int8", lambda: eager_chain.quantize(w, params[4], tile, 8, torch.int8)),
+                     ("A2 dequantize int8->bf16", lambda: eager_chain.dequantize(codes, params[4], tile, None, torch.bfloat16)),
+                     ("A4 min/max", lambda: eager_chain.minmax(w, tile))):
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        per_op[name] = round((time.perf_counter() - t0) * 1e3, 2)
     return {
         "value": round(tokens / (seconds * config.num_layers), 3),
         "unit": "tokens/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
+        "per_op_ms": {"shape": list(w.shape), "granularity": "per output channel", **per_op},
         "sample": f"eager ATen chain (oracle/eager_chain.py) of the 7 W8A8 linears of ONE decoder layer at Llama-3-8B shapes on {tokens} tokens: {seconds:.2f} s, scaled by {config.num_layers} layers (attention/norms excluded, so this flatters the CPU)",
         "host_cpus": os.cpu_count(),
     }
@@ -341,8 +377,8 @@ def cpu_baseline(config: llama.LlamaConfig, budget_s: float = 20.0) -> dict:
 
 def relaunch_under_torchrun(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) as CHILDREN through
-    torch.distributed.run and hand back their exit code. Nothing in this process has touched a GPU yet (torch.cuda.device_count
-    does not initialise one), and the ranks are new processes, not an exec of this one."""
+    torch.distributed.run and hand back their exit code. The ranks are NEW child processes — never an exec of this process —
+    so whatever this process has or has not done with the GPU is irrelevant to them."""
     import socket
     import subprocess
 
@@ -369,6 +405,7 @@ def main() -> None:
     ap.add_argument("--seq-len", type=int, default=2048)
     ap.add_argument("--calib-seqs", type=int, default=None, help="calibration sequences per GPU; default: BASELINE's 512 in total, i.e. 512 / N per GPU (512 on one GPU, 64 each on 8)")
     ap.add_argument("--model", choices=["llama3-8b", "llama3-70b", "tiny"], default="llama3-8b")
+    ap.add_argument("--layers", type=int, default=None, help="override the number of decoder layers (smoke runs of the 70B shapes)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--module-graph", action="store_true", help="run the reference-shaped module graph (one quantizer call per linear input, "
                     "eager RMSNorm / rotary / SiLU) instead of llama.FusedForward (A1 fused into those producers)")
@@ -390,6 +427,8 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     config = {"llama3-8b": llama.LlamaConfig.llama3_8b, "llama3-70b": llama.LlamaConfig.llama3_70b, "tiny": llama.LlamaConfig.tiny}[args.model]()
+    if args.layers is not None:
+        config = dataclasses.replace(config, num_layers=args.layers)
 
     # synthetic model + data (seeds per SURVEY §8d: 1234 + config index; ranks hold identical replicas)
     model = llama.build_model(config, device, torch.bfloat16, seed=1234 + 2)
@@ -415,6 +454,9 @@ def main() -> None:
     torch.cuda.synchronize()
     calib_s = time.perf_counter() - t0
     del calib
+    # self-check of the sharded calibration (N > 1): every rank must hold bit-identical parameters after the one all-reduce
+    ranges_identical, ranks_seen = ffd.ranges_agree_across_ranks(model)
+    exchange = dict(ffd.last_exchange)
 
     fused = None if args.module_graph else llama.FusedForward(model, cache_weight_codes=args.cache_weight_codes)
 
@@ -459,57 +501,56 @@ def main() -> None:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # the drop-in path beside the headline: what ff.quantize_model() + QuantizedLinear.forward give with no harness-level
-    # fusion (one quantizer call per linear input, eager RMSNorm / rotary / SiLU, the dispatcher's int8 linear) — same
-    # arithmetic, same batch, hipGraph-replayed; timed on rank 0 only, after the headline region
+    # the drop-in path beside the headline: what ff.quantize_model() gives with NO harness — the module graph itself, every
+    # quantizer its own module call, the dispatcher's int8 linear; its Llama modules run RMSNorm / SiLU*up / rotary / attention as
+    # one-pass kernels wherever the slots between them are untouched stubs (llama.py), or, inside llama.eager_modules(), as the
+    # reference helpers' eager ATen chains. Same arithmetic, same batch, hipGraph-replayed; rank 0 only, after the headline region
     module_graph = None
     if fused is not None and rank == 0 and not args.no_side_measurements:
-        def reference_shaped():
+        mg_steps = max(2, min(args.steps, 5))
+
+        def replayed(fn) -> float:
+            """Seconds per call of `fn`, replayed from a hipGraph."""
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.cuda.graph(g, stream=side):
+                out = fn()
+            torch.cuda.current_stream().wait_stream(side)
+            g.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(mg_steps):
+                g.replay()
+            torch.cuda.synchronize()
+            seconds = (time.perf_counter() - t1) / mg_steps
+            del g, out
+            return seconds
+
+        def module_forward():
             with torch.no_grad(), ff.strict_quantization(False):
                 return model(batch, logits=True)
 
-        for _ in range(2):  # twice: the dispatcher's linear reads "is this weight offset all zero" once per stable version, never under capture
-            reference_shaped()
-        torch.cuda.synchronize()
-        mg_steps = max(2, min(args.steps, 5))
-        mgraph, mside = torch.cuda.CUDAGraph(), torch.cuda.Stream()
-        mside.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(mside), torch.cuda.graph(mgraph, stream=mside):
-            mg_out = reference_shaped()
-        torch.cuda.current_stream().wait_stream(mside)
-        mgraph.replay()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(mg_steps):
-            mgraph.replay()
-        torch.cuda.synchronize()
-        mg_elapsed = time.perf_counter() - t1
-        module_graph = {"value": round(args.batch * args.seq_len * mg_steps / mg_elapsed, 1), "unit": "tokens/s", "n_gpus": 1, "steps": mg_steps,
-                        "ms_per_step": round(mg_elapsed / mg_steps * 1e3, 3),
-                        "what": "the reference-shaped module graph (ff.quantize_model + QuantizedLinear.forward through the dispatcher, eager producers): the drop-in path with no harness-level fusion"}
-        del mgraph, mg_out
-        # in between: every quantizer still runs its own forward (its own launch, overrides and hooks intact), only the
-        # float producers between the linears are one-pass kernels (llama.FusedProducersForward)
+        def eager_forward():
+            with llama.eager_modules():
+                return module_forward()
+
+        tokens = args.batch * args.seq_len
+        s_mod = replayed(module_forward)
+        module_graph = {"value": round(tokens / s_mod, 1), "unit": "tokens/s", "n_gpus": 1, "steps": mg_steps, "ms_per_step": round(s_mod * 1e3, 3),
+                        "what": "model(batch) on the module graph ff.quantize_model() built: one quantizer call per linear input and weight, the dispatcher's int8 linear, the quantized Llama modules' own forwards (one-pass RMSNorm / SiLU*up / rotary / attention kernels between untouched stub slots) — no harness"}
+        s_eager = replayed(eager_forward)
+        module_graph["eager_producer_chains"] = {
+            "value": round(tokens / s_eager, 1), "unit": "tokens/s", "ms_per_step": round(s_eager * 1e3, 3),
+            "what": "the same module graph inside llama.eager_modules(): RMSNorm / rotary / SiLU / SDPA as the eager ATen chains of the reference's helper modules"}
+        # every quantizer still runs its own forward; additionally the residual adds ride in the RMSNorm launches (llama.FusedProducersForward)
         producers = llama.FusedProducersForward(model)
-        for _ in range(2):
-            producers(batch, logits=True)
-        torch.cuda.synchronize()
-        pgraph, pside = torch.cuda.CUDAGraph(), torch.cuda.Stream()
-        pside.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(pside), torch.cuda.graph(pgraph, stream=pside):
-            p_out = producers(batch, logits=True)
-        torch.cuda.current_stream().wait_stream(pside)
-        pgraph.replay()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(mg_steps):
-            pgraph.replay()
-        torch.cuda.synchronize()
-        p_elapsed = time.perf_counter() - t1
+        s_prod = replayed(lambda: producers(batch, logits=True))
         module_graph["producers_fused_quantizers_untouched"] = {
-            "value": round(args.batch * args.seq_len * mg_steps / p_elapsed, 1), "unit": "tokens/s", "ms_per_step": round(p_elapsed / mg_steps * 1e3, 3),
+            "value": round(tokens / s_prod, 1), "unit": "tokens/s", "ms_per_step": round(s_prod * 1e3, 3),
             "what": "llama.FusedProducersForward: quantizer modules called as they are, RMSNorm / rotary / SiLU*up / attention as one-pass kernels"}
-        del pgraph, p_out
 
     tokens_per_step = args.batch * args.seq_len * world
     result = {
@@ -542,7 +583,12 @@ def main() -> None:
         "module_graph_drop_in": module_graph,
         "calibration": {"sequences_per_gpu": calib_steps * args.batch, "sequences_total": calib_steps * args.batch * world, "seconds": round(calib_s, 3),
                         "sequences_per_s_all_gpus": round(calib_steps * args.batch * world / calib_s, 2),
-                        "allreduce_floats": payload, "collective": "1 x all_reduce(MIN) over RCCL" if world > 1 else "none (1 GPU)"},
+                        "allreduce_floats": payload, "collective": "1 x all_reduce(MIN) over RCCL" if world > 1 else "none (1 GPU)",
+                        # self-validation of the sharded path (N > 1): ranks that took part, wall time of the one collective, and
+                        # whether every rank ended with bit-identical quantizer parameters (two extra all-reduces on the fingerprint)
+                        "ranks_seen": ranks_seen, "ranges_identical_across_ranks": ranges_identical,
+                        "all_reduce_us": round(float(exchange["seconds"]) * 1e6, 1) if exchange else None,
+                        "all_reduce_backend": exchange.get("backend") if exchange else None},
     }
     if rank == 0 and not args.no_side_measurements:
         del graph

@@ -29,6 +29,7 @@ Inference after calibration is pure data parallelism: replicas, no collective.
 from __future__ import annotations
 
 import os
+import time
 
 from typing import Iterable, Sequence
 
@@ -57,6 +58,11 @@ def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, i
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+# what the most recent range exchange of this process looked like (bench.py reports it): wall time of the all_reduce itself
+# between two device drains, payload, ranks, backend
+last_exchange: dict[str, object] = {}
 
 
 def shard(items: Sequence, rank: int, world: int) -> list:
@@ -116,7 +122,15 @@ def all_reduce_ranges(model: torch.nn.Module, group: dist.ProcessGroup | None = 
     any_inf = (statuses & ops.FLAG_INF).max().to(torch.float32).reshape(1)  # 1.0 if any quantizer saw +-Inf
     packed = torch.cat(mins + [-m for m in maxs] + [-any_inf])
     if dist.is_initialized() and dist.get_world_size(group) > 1:
+        timed = packed.is_cuda
+        if timed:  # the caller reads a flag off the result right below anyway: one more drain costs nothing and gives the time
+            torch.cuda.synchronize(packed.device)
+        t0 = time.perf_counter()
         dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=group)  # THE collective of this path
+        if timed:
+            torch.cuda.synchronize(packed.device)
+        last_exchange.update(seconds=time.perf_counter() - t0, floats=int(packed.numel()), world_size=dist.get_world_size(group),
+                             backend=dist.get_backend(group))
     n = sum(counts)
     lo_all, hi_all, any_inf_anywhere = packed[:n], -packed[n : 2 * n], bool(-packed[-1].item() > 0)
     if any_inf_anywhere:
@@ -191,3 +205,19 @@ def ranges_fingerprint(model: torch.nn.Module) -> torch.Tensor:
             if isinstance(t, torch.Tensor) and not isinstance(t, torch.nn.parameter.UninitializedTensorMixin):
                 parts.append(t.detach().reshape(-1).to(torch.float32))
     return torch.cat(parts) if parts else torch.zeros(0)
+
+
+def ranges_agree_across_ranks(model: torch.nn.Module, group: dist.ProcessGroup | None = None) -> tuple[bool, int]:
+    """(every rank holds bit-identical quantizer parameters, number of ranks that took part). Two more small collectives on
+    the fingerprint vector (element-wise MIN and MAX over ranks agree exactly where all ranks agree) and a SUM of ones;
+    a self-check for multi-GPU runs, not part of the calibration path."""
+    fingerprint = ranges_fingerprint(model)
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return True, 1
+    bits = fingerprint.view(torch.int32).clone()  # compare bit patterns: NaNs and signed zeros included
+    lo, hi = bits.clone(), bits.clone()
+    ones = torch.ones(1, dtype=torch.int32, device=bits.device)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM, group=group)
+    return bool(torch.equal(lo, hi)), int(ones.item())

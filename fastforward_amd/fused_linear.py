@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import contextlib
 import dataclasses
+import weakref
 
 from typing import Any, Callable
 
@@ -70,25 +71,61 @@ def _on_backend(*tensors: Any) -> bool:
     return all(t.is_cuda for t in tensors) and _native.is_available()
 
 
-# Which GEMM a weight-only linear takes: the hand-written bf16 x weight-code kernel (default since round 3), or — inside
-# ``with weight_only_kernel(False)`` — the reference's own path (fallback.py:86-112: A2 into a bf16 tensor + F.linear,
-# i.e. the vendor's GEMM), kept as the A/B arm of tools/bench_configs.py. Both see the same operands bit for bit.
+# Which GEMM a weight-only linear takes: the hand-written bf16 x weight-code kernel (default since round 3) from
+# `_WEIGHT_ONLY_MIN_TOKENS` tokens on, the reference's own path below that and inside ``with weight_only_kernel(False)``
+# (fallback.py:86-112: A2 into a bf16 tensor + F.linear, i.e. the vendor's GEMM — also the A/B arm of tools/bench_configs.py).
+# Both see the same operands bit for bit. Why a token threshold: the kernel is built around 256 x 256 output tiles, one
+# persistent block per CU; at 2048 tokens a 4096-wide projection is 128 tiles for 256 CUs and it runs at half the vendor
+# library's rate (601 vs 1151 TFLOP/s; at 16384 tokens 1.28-1.38 vs 1.45-1.53 PFLOP/s: profiles/r03_wq_time.txt).
 _WEIGHT_ONLY_KERNEL = True
+_WEIGHT_ONLY_MIN_TOKENS = 4096
 
 
 @contextlib.contextmanager
-def weight_only_kernel(enabled: bool = True):
-    """Route weight-only quantized linears (plain bf16 input, quantized weight) to the hand-written GEMM (default) or,
-    with ``enabled=False``, leave them to the float fallback (A2 + ``F.linear``) inside the block."""
-    global _WEIGHT_ONLY_KERNEL
-    previous, _WEIGHT_ONLY_KERNEL = _WEIGHT_ONLY_KERNEL, bool(enabled)
+def weight_only_kernel(enabled: bool = True, min_tokens: int | None = None):
+    """Route weight-only quantized linears (plain bf16 input, quantized weight) to the hand-written GEMM (default, from
+    `min_tokens` tokens on) or, with ``enabled=False``, leave them to the float fallback (A2 + ``F.linear``) inside the block."""
+    global _WEIGHT_ONLY_KERNEL, _WEIGHT_ONLY_MIN_TOKENS
+    previous = (_WEIGHT_ONLY_KERNEL, _WEIGHT_ONLY_MIN_TOKENS)
+    _WEIGHT_ONLY_KERNEL = bool(enabled)
+    if min_tokens is not None:
+        _WEIGHT_ONLY_MIN_TOKENS = int(min_tokens)
     try:
         yield
     finally:
-        _WEIGHT_ONLY_KERNEL = previous
+        _WEIGHT_ONLY_KERNEL, _WEIGHT_ONLY_MIN_TOKENS = previous
 
 
 _FLOATS = (torch.bfloat16, torch.float16, torch.float32)
+
+# A symmetric quantizer carries an offset BUFFER that is all zeros unless its data is one-sided (reference
+# nn/linear_quantizer.py:164-170). The int8 GEMM recognises that on the device (a one-block check ahead of the launch and a
+# slightly heavier epilogue: no host read, which is what a range estimator that rewrites the parameters on every step needs);
+# for parameters that have STOPPED changing the answer is read once on the host and such offsets are not passed at all.
+# Keyed on (tensor object, version): the range setter bumps the version; never read while a hipGraph is being captured, and
+# not at the first sighting of a version (calibration: every step is a first sighting).
+_ZERO_OFFSETS: dict[int, tuple[Any, int, bool | None]] = {}
+
+
+def known_zero_offset(offset: Any) -> bool:
+    """True when `offset` is known (from an earlier call with the same version) to round to all zeros."""
+    if not isinstance(offset, torch.Tensor):
+        return False
+    hit = _ZERO_OFFSETS.get(id(offset))
+    seen = hit is not None and hit[0]() is offset and hit[1] == offset._version
+    if seen and hit[2] is not None:
+        return hit[2]
+    if offset.is_cuda and torch.cuda.is_current_stream_capturing():
+        return False
+    if len(_ZERO_OFFSETS) > 4096:  # entries of tensors that are gone
+        for key in [k for k, v in _ZERO_OFFSETS.items() if v[0]() is None]:
+            del _ZERO_OFFSETS[key]
+    if not seen:
+        _ZERO_OFFSETS[id(offset)] = (weakref.ref(offset), offset._version, None)
+        return False
+    zero = not bool(torch.round(offset.detach()).any())  # the version was stable across two calls: one read
+    _ZERO_OFFSETS[id(offset)] = (weakref.ref(offset), offset._version, zero)
+    return zero
 
 
 class DispatcherKernels:
@@ -169,7 +206,8 @@ class DispatcherKernels:
     @classmethod
     def _scale_offset(cls, t: Any) -> tuple[torch.Tensor, torch.Tensor | None]:
         p = cls._params(t)
-        return torch.as_tensor(p.scale, device=t.device), None if p.offset is None else torch.as_tensor(p.offset, device=t.device)
+        offset = None if p.offset is None or known_zero_offset(p.offset) else torch.as_tensor(p.offset, device=t.device)
+        return torch.as_tensor(p.scale, device=t.device), offset
 
     @classmethod
     def _deq_dtype(cls, t: Any) -> torch.dtype:
@@ -210,10 +248,10 @@ class DispatcherKernels:
 
     # ---- linear ---------------------------------------------------------------------------------------------------------
     def _wq_covers(self, x_dtype: torch.dtype, weight: Any, tokens: int) -> int | None:
-        """The group size when the bf16 x weight-code GEMM covers (activation dtype, weight tiling, K): the rule is the
-        library's own (``ffq_linear_wq_supported``), asked for int8 codes."""
+        """The group size when the bf16 x weight-code GEMM takes (activation dtype, weight tiling, K, tokens): coverage is the
+        library's own rule (``ffq_linear_wq_supported``, asked for int8 codes), the token threshold this module's policy."""
         group = self.weight_group(weight)
-        if group is None or x_dtype not in ops._TAGS:
+        if group is None or x_dtype not in ops._TAGS or tokens < _WEIGHT_ONLY_MIN_TOKENS:
             return None
         n, k = weight.shape
         lib = _native.library()

@@ -19,6 +19,7 @@ traffic between hot-path calls, not the product.
 
 from __future__ import annotations
 
+import contextlib
 import dataclasses
 import math
 import types
@@ -178,6 +179,38 @@ class LlamaModel(torch.nn.Module):
 
 
 # ---- quantized counterparts: same stub slots as the reference's helpers ---------------------------
+# The reference's helper modules run RMSNorm, SiLU * up, the rotary embedding and attention as eager ATen chains between their
+# quantizer slots (docs/examples/doc_helpers/quantized_llama/). Where EVERY slot between two operations is still a stub (the
+# Llama recipe sets none of them) those chains have exactly one meaning, and the modules below run them as the one-pass
+# kernels of csrc/ffq_producers.hip / ffq_attention.hip: the module graph that ``ff.quantize_model`` builds is itself fast,
+# no harness needed. Any quantizer installed in one of the slots, an active override, a CPU tensor, a non-bf16 dtype or a
+# caller that wants gradients sends the module back to the eager chain. ``with llama.eager_modules():`` forces the eager
+# chains (the reference-shaped arm of the tests and of bench.py).
+_ONE_PASS_MODULES = True
+
+
+@contextlib.contextmanager
+def eager_modules(eager: bool = True):
+    """Run the quantized Llama modules' forwards as the reference's eager ATen chains inside the block."""
+    global _ONE_PASS_MODULES
+    previous, _ONE_PASS_MODULES = _ONE_PASS_MODULES, not eager
+    try:
+        yield
+    finally:
+        _ONE_PASS_MODULES = previous
+
+
+def _untouched(*quantizers: torch.nn.Module | None) -> bool:
+    return all(q is None or (q.is_stub() and next(iter(q.overrides), None) is None) for q in quantizers)
+
+
+def _one_pass(*tensors: torch.Tensor) -> bool:
+    from fastforward_amd import _native
+
+    return (_ONE_PASS_MODULES and all(type(t) is torch.Tensor and t.is_cuda and t.dtype == torch.bfloat16 for t in tensors)
+            and not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors)) and _native.is_available())
+
+
 class QuantizedLlamaRMSNorm(QuantizedModule, LlamaRMSNorm):
     """Float under strict_quantization(False), like reference rms_norm.py:17-35."""
 
@@ -187,7 +220,14 @@ class QuantizedLlamaRMSNorm(QuantizedModule, LlamaRMSNorm):
         self.output_quantizer = QuantizerStub(output_quantizer=True)
         self.weight_quantizer = QuantizerStub(weight_quantizer=True)
 
+    def _fusable(self, hidden_states: torch.Tensor) -> bool:
+        width = hidden_states.shape[-1]
+        return (_untouched(self.input_quantizer, self.output_quantizer, self.weight_quantizer) and _one_pass(hidden_states, self.weight)
+                and width % 16 == 0 and width <= 8192)
+
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        if self._fusable(hidden_states):
+            return ff.ops.add_rmsnorm_quantize(hidden_states, None, self.weight, self.variance_epsilon, (), want_sum=False, want_norm=True)[1]
         with ff.strict_quantization(False):
             return self.output_quantizer(LlamaRMSNorm.forward(self, self.input_quantizer(hidden_states)))
 
@@ -200,7 +240,32 @@ class QuantizedLlamaAttention(QuantizedModule, LlamaAttention):
         self.input_quantizer = QuantizerStub(input_quantizer=True)
 
     def forward(self, hidden_states: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
-        return LlamaAttention.forward(self, self.input_quantizer(hidden_states), cos, sin)
+        hidden_states = self.input_quantizer(hidden_states)
+        cfg = self.config
+        if hidden_states.dim() == 3 and _one_pass(hidden_states) and attention_kernel_covers(cfg, hidden_states.shape[1], hidden_states.dtype):
+            q, k, v = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
+            if _one_pass(q, k, v, cos, sin) and cos.dim() == 2 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous():
+                # rotary embedding in place on the projections, then softmax(q k^T) v as one flash-style launch
+                ff.ops.rope_(q, k, cos, sin, cfg.head_dim)
+                ctx, _ = ff.ops.attention(q, k, v, cfg.head_dim, causal=hidden_states.shape[1] > 1)
+                return self.o_proj(ctx)
+            return self._attend(q, k, v, cos, sin)
+        return LlamaAttention.forward(self, hidden_states, cos, sin)
+
+    def _attend(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+        """The rest of LlamaAttention.forward for projections that are already computed."""
+        cfg = self.config
+        b, s = q.shape[0], q.shape[1]
+        q = q.view(b, s, cfg.num_heads, cfg.head_dim).transpose(1, 2)
+        k = k.view(b, s, cfg.num_kv_heads, cfg.head_dim).transpose(1, 2)
+        v = v.view(b, s, cfg.num_kv_heads, cfg.head_dim).transpose(1, 2)
+        q = q * cos + _rotate_half(q) * sin
+        k = k * cos + _rotate_half(k) * sin
+        if cfg.attention == "eager":
+            attn = self._eager_attention(q, k, v)
+        else:
+            attn = F.scaled_dot_product_attention(q, k, v, is_causal=s > 1, enable_gqa=cfg.num_kv_heads != cfg.num_heads)
+        return self.o_proj(attn.transpose(1, 2).reshape(b, s, -1))
 
 
 class QuantizedLlamaMLP(QuantizedModule, LlamaMLP):
@@ -214,6 +279,11 @@ class QuantizedLlamaMLP(QuantizedModule, LlamaMLP):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = self.input_quantizer(x)
+        if _untouched(self.gate_act_quantizer, self.gated_up_proj_output_quantizer):
+            gate, up = self.gate_proj(x), self.up_proj(x)
+            if _one_pass(gate, up) and gate.shape == up.shape:
+                return self.down_proj(ff.ops.silu_mul_quantize(gate, up, (), want_product=True)[0])  # silu(gate) * up, one pass
+            return self.down_proj(F.silu(gate) * up)
         gated = self.gated_up_proj_output_quantizer(self.gate_act_quantizer(F.silu(self.gate_proj(x))) * self.up_proj(x))
         return self.down_proj(gated)
 
@@ -228,13 +298,66 @@ class QuantizedLlamaDecoderLayer(QuantizedModule, LlamaDecoderLayer):
         self.mlp_res_act_quantizer = QuantizerStub(output_quantizer=True)
 
     def forward(self, hidden_states: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
-        hidden_states = self.input_quantizer(hidden_states)
-        hidden_states = self.attn_res_act_quantizer(hidden_states + self.self_attn(self.input_layernorm(hidden_states), cos, sin))
-        return self.mlp_res_act_quantizer(hidden_states + self.mlp(self.post_attention_layernorm(hidden_states)))
+        return self.forward_deferred(hidden_states, None, cos, sin, defer=False)[0]
+
+    def accepts_pending(self, hidden_states: torch.Tensor) -> bool:
+        """True when this layer can take (residual stream, a term not yet added to it): its entry slot is an untouched stub
+        and its first RMSNorm runs as the one-pass kernel, which then performs the add."""
+        norm = self.input_layernorm
+        return _untouched(self.input_quantizer) and isinstance(norm, QuantizedLlamaRMSNorm) and hidden_states.is_contiguous() and norm._fusable(hidden_states)
+
+    def forward_deferred(self, hidden_states: torch.Tensor, pending: torch.Tensor | None, cos: torch.Tensor, sin: torch.Tensor,
+                         defer: bool) -> tuple[torch.Tensor, torch.Tensor | None]:
+        """The layer on a residual stream whose last term may still be pending (`hidden_states + pending` is the value; the
+        caller checked :meth:`accepts_pending`). Returns (stream, pending'): with `defer` and an untouched output slot the
+        MLP's output is handed on un-added — the next layer's first RMSNorm launch (or the model's final one) adds it —
+        else pending' is None. Between QuantizedLlamaModel and its layers only; ``forward`` is the ordinary entry."""
+        if pending is not None:
+            norm = self.input_layernorm
+            hidden_states, normed, _ = ff.ops.add_rmsnorm_quantize(hidden_states, pending, norm.weight, norm.variance_epsilon, (), want_sum=True,
+                                                                   want_norm=True, sum_inplace=True)
+        else:
+            hidden_states = self.input_quantizer(hidden_states)
+            normed = self.input_layernorm(hidden_states)
+        attn_out = self.self_attn(normed, cos, sin)
+        norm = self.post_attention_layernorm
+        if (_untouched(self.attn_res_act_quantizer) and isinstance(norm, QuantizedLlamaRMSNorm) and hidden_states.shape == attn_out.shape
+                and hidden_states.is_contiguous() and attn_out.is_contiguous() and norm._fusable(hidden_states) and _one_pass(attn_out)):
+            # the residual add and the RMSNorm behind it as one pass (both values are needed: the sum is the next residual)
+            hidden_states, normed, _ = ff.ops.add_rmsnorm_quantize(hidden_states, attn_out, norm.weight, norm.variance_epsilon, (), want_sum=True, want_norm=True)
+        else:
+            hidden_states = self.attn_res_act_quantizer(hidden_states + attn_out)
+            normed = norm(hidden_states)
+        mlp_out = self.mlp(normed)
+        if defer and _untouched(self.mlp_res_act_quantizer) and _one_pass(mlp_out) and mlp_out.shape == hidden_states.shape and mlp_out.is_contiguous():
+            return hidden_states, mlp_out
+        return self.mlp_res_act_quantizer(hidden_states + mlp_out), None
 
 
 class QuantizedLlamaModel(QuantizedModule, LlamaModel):
-    pass
+    def forward(self, input_ids: torch.Tensor, logits: bool = True) -> torch.Tensor:
+        """LlamaModel.forward; between quantized decoder layers whose boundary slots are untouched stubs the MLP's residual add is
+        left to the next layer's first RMSNorm launch (``forward_deferred``): one pass instead of an eager add plus a norm."""
+        hidden_states = self.embed_tokens(input_ids)
+        cos, sin = rotary_tables(input_ids.shape[1], self.config.head_dim, self.config.rope_theta, hidden_states.device, hidden_states.dtype)
+        layers = list(self.layers)
+        pending: torch.Tensor | None = None
+        for i, layer in enumerate(layers):
+            if isinstance(layer, QuantizedLlamaDecoderLayer):
+                nxt = layers[i + 1] if i + 1 < len(layers) else None
+                if nxt is None:
+                    consumer = isinstance(self.norm, QuantizedLlamaRMSNorm) and hidden_states.is_contiguous() and self.norm._fusable(hidden_states)
+                else:
+                    consumer = isinstance(nxt, QuantizedLlamaDecoderLayer) and nxt.accepts_pending(hidden_states)
+                hidden_states, pending = layer.forward_deferred(hidden_states, pending, cos, sin, defer=consumer)
+            else:
+                hidden_states = layer(hidden_states if pending is None else hidden_states + pending, cos, sin)
+                pending = None
+        if pending is not None:
+            hidden_states = ff.ops.add_rmsnorm_quantize(hidden_states, pending, self.norm.weight, self.norm.variance_epsilon, (), want_sum=False, want_norm=True)[1]
+        else:
+            hidden_states = self.norm(hidden_states)
+        return self.lm_head(hidden_states) if logits else hidden_states
 
 
 class QuantizedEmbedding(QuantizedModule, torch.nn.Embedding):
@@ -659,9 +782,10 @@ class FusedProducersForward:
         xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
         if xp.scale.numel() != 1 or ff.fused_linear.KERNELS.row_mode(wq) is None:
             return ff.nn.functional.linear(xq, wq, None, output_quantizer=linear.output_quantizer)
-        # (an all-zero offset buffer of a symmetric weight quantizer is recognised by the GEMM on the device: no host read,
-        # also while a range estimator rewrites the parameters on every step)
-        return ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, wp.offset, None, out_dtype=torch.bfloat16)
+        # an all-zero offset buffer of a symmetric weight quantizer: known from an earlier call once its version is stable, else
+        # recognised by the GEMM on the device (no host read while a range estimator rewrites the parameters on every step)
+        w_offset = None if wp.offset is None or ff.fused_linear.known_zero_offset(wp.offset) else wp.offset
+        return ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, None, out_dtype=torch.bfloat16)
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, logits: bool = False) -> torch.Tensor:

@@ -190,7 +190,8 @@ def gptq(
         sweep.push_errors_right(start, stop)
 
     back = torch.argsort(order)
-    module.weight.data.copy_(sweep.snapped[:, back].view(shape).to(module.weight.dtype))
+    with torch.no_grad():  # an in-place write autograd sees (the reference: module.weight.copy_): every cache keyed on
+        module.weight.copy_(sweep.snapped[:, back].view(shape).to(module.weight.dtype))  # `_version` notices the new weights
     logger.info("[GPTQ][wbits=%d][%s] loss=%.6f", quantizer.num_bits, layer_name, torch.mean(torch.abs(sweep.errors[:, back])).item())
 
 
@@ -215,7 +216,8 @@ def update_partial_range(
         min_range, max_range, num_bits=weight_quantizer.num_bits, symmetric=weight_quantizer.symmetric,
         allow_one_sided=weight_quantizer.allow_one_sided,
     )
-    weight_quantizer.scale.data.view(param_view_shape)[param_view_index] = scale.to(weight_quantizer.scale.dtype)
-    if weight_quantizer.offset is not None:
-        target = weight_quantizer.offset.data.view(param_view_shape)
-        target[param_view_index] = 0.0 if offset is None else offset.to(target.dtype)
+    with torch.no_grad():  # indexed writes through views of the parameters themselves (not .data): their version counters move,
+        weight_quantizer.scale.view(param_view_shape)[param_view_index] = scale.to(weight_quantizer.scale.dtype)  # which the code caches rely on
+        if weight_quantizer.offset is not None:
+            target = weight_quantizer.offset.view(param_view_shape)
+            target[param_view_index] = 0.0 if offset is None else offset.to(target.dtype)

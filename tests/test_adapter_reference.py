@@ -59,10 +59,11 @@ def test_dispatcher_hooks_serve_the_reference_operators(oracle_backend, tmp_path
     shim.mkdir()
     (shim / "__init__.py").write_text("from torch.utils._pytree import tree_map, tree_flatten, tree_unflatten, tree_leaves\n")
     sys.path[:0] = [REFERENCE, str(tmp_path)]
+    policy = None
     try:
         import fastforward as ff_ref
 
-        from fastforward_amd import adapter
+        from fastforward_amd import adapter, fused_linear
 
         g = torch.Generator().manual_seed(1)
         x = torch.randn(12, 128, generator=g)
@@ -83,6 +84,9 @@ def test_dispatcher_hooks_serve_the_reference_operators(oracle_backend, tmp_path
             attached = adapter.install(device_types=("cpu",), register_linear=True)
             assert {"dispatcher:linear", "dispatcher:linear(weight-only)", "dispatcher:mm", "dispatcher:matmul", "dispatcher:bmm"} <= set(attached)
             assert ff_ref.dispatcher.dispatch("linear", input=qx, weight=qw) == adapter.REFERENCE_KERNELS.linear
+            assert ff_ref.dispatcher.dispatch("linear", input=x16, weight=qw16) is None  # 5 tokens: below the weight-only kernel's token threshold
+            policy = fused_linear.weight_only_kernel(True, min_tokens=0)
+            policy.__enter__()
             assert ff_ref.dispatcher.dispatch("linear", input=x16, weight=qw16) == adapter.REFERENCE_KERNELS.weight_only_linear
             assert ff_ref.dispatcher.dispatch("mm", input=qx, mat2=qwt) == adapter.REFERENCE_KERNELS.mm
             assert ff_ref.dispatcher.dispatch("matmul", input=qx, other=qwt) == adapter.REFERENCE_KERNELS.mm
@@ -102,5 +106,7 @@ def test_dispatcher_hooks_serve_the_reference_operators(oracle_backend, tmp_path
             assert a.shape == b.shape and a.dtype == b.dtype
             torch.testing.assert_close(a.float(), b.float(), atol=1e-1, rtol=1.3e-2)
     finally:
+        if policy is not None:
+            policy.__exit__(None, None, None)
         sys.path.remove(REFERENCE)
         sys.path.remove(str(tmp_path))

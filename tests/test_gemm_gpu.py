@@ -208,3 +208,29 @@ def test_dispatcher_runs_a_static_output_quantizer_inside_the_gemm(quantized_dty
         qwt = ff.quantization.affine.quantize_per_tensor(lin.weight.t().contiguous(), torch.tensor([0.001], device=DEV), None, 8, torch.int8)
         y_mm = ff.nn.functional.mm(qx.reshape(-1, 512), qwt)
         assert torch.equal(ff.nn.functional.mm(qx.reshape(-1, 512), qwt, output_quantizer=oq).raw_data, oq(y_mm).raw_data)
+
+
+def test_grouped_weights_with_quantized_inputs_take_the_weight_code_gemm():
+    """W4 group-128 x A8 (SURVEY 8(b) Seam 2 lists PerBlock(in, 128) weights): group-wise parameters cannot leave an int8
+    contraction, so the dispatcher kernel dequantizes the input codes (A2 — the reference's own first step, fallback.py:94-100)
+    and runs the bf16 x weight-code GEMM: the reference's operands bit for bit, no float fallback, no vendor GEMM."""
+    torch.manual_seed(11)
+    tokens, n, k = 4096, 768, 512
+    x = torch.randn(tokens, k, device=DEV, dtype=torch.bfloat16)
+    w = (torch.randn(n, k, device=DEV) * 0.05).to(torch.bfloat16)
+    wq_ = ff.nn.LinearQuantizer(4, granularity=ff.PerBlock(1, 128, 0), quantized_dtype=torch.int8, device=DEV)
+    xq_ = ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=torch.int8, device=DEV)
+    with torch.no_grad(), ff.estimate_ranges(torch.nn.ModuleList([wq_, xq_]), ff.range_setting.running_minmax):
+        qw, qx = wq_(w), xq_(x)
+    assert ff.dispatcher.dispatch("linear", input=qx, weight=qw) is ff.fused_linear.fused_linear
+    with torch.no_grad():
+        assert ff.dispatcher.dispatch("linear", input=xq_(x[:64]), weight=qw) is None  # below the token threshold: the float fallback
+    with torch.no_grad(), ff.strict_quantization(False):
+        got = ff.nn.functional.linear(qx, qw)
+        with ff.fused_linear.weight_only_kernel(False):
+            assert ff.dispatcher.dispatch("linear", input=qx, weight=qw) is None
+            reference_path = ff.nn.functional.linear(qx, qw)  # dequantize, dequantize, F.linear
+    assert got.dtype == torch.bfloat16
+    exact = qx.dequantize().double() @ qw.dequantize().double().t()
+    torch.testing.assert_close(got.double(), exact, rtol=2.0**-8, atol=1e-5 * float(exact.abs().max()))
+    torch.testing.assert_close(got.float(), reference_path.float(), rtol=2.0**-7, atol=2e-4 * float(exact.abs().max()))

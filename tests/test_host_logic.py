@@ -564,7 +564,10 @@ def test_gptq_partial_range_update_writes_one_group_and_clears_a_stale_offset():
     quantizer = _smoothed_4bit(gran, w)
     before = quantizer.scale.detach().clone().view(16, 4)
     piece = w[:, 16:24]
+    versions = (quantizer.scale._version, quantizer.offset._version)
     update_partial_range(quantizer, piece.min(-1).values, piece.max(-1).values, param_view_shape=(16, 4), param_view_index=(slice(None), 2))
+    # the writes move the parameters' version counters: caches keyed on them (llama.FusedForward's weight codes) see the change
+    assert quantizer.scale._version > versions[0] and quantizer.offset._version > versions[1]
     s, o = ff.quantization.affine.parameters_for_range(piece.min(-1).values, piece.max(-1).values, num_bits=4, symmetric=False, allow_one_sided=True)
     assert torch.equal(quantizer.scale.detach().view(16, 4)[:, 2], s) and torch.equal(quantizer.offset.detach().view(16, 4)[:, 2], o)
     keep = [0, 1, 3]

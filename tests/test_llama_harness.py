@@ -116,13 +116,19 @@ def build_bf16(fixture, device):
 def check_fused_against_module_graph(fixture, device):
     model = build_bf16(fixture, device)
     ids = fixture["ids"].to(device)
-    with torch.no_grad(), ff.strict_quantization(False):
+    with torch.no_grad(), ff.strict_quantization(False), llama.eager_modules():  # the reference helpers' eager ATen chains
         want = model(ids).float().cpu()
+    with torch.no_grad(), ff.strict_quantization(False):  # the module graph as built: one-pass kernels between stub slots on the GPU
+        as_built = model(ids).float().cpu()
     fused = llama.FusedForward(model)
     got = fused(ids).float().cpu()
     err, spread = got - want, float(want.std())
     # same integer arithmetic, same bf16 roundings; only the fp32 summation order inside RMSNorm differs
     assert float(err.pow(2).mean().sqrt()) < 0.01 * spread and float(err.abs().max()) < 0.25 * spread
+    if device == "cpu":
+        assert torch.equal(as_built, want)  # no HIP tensors: the modules run the eager chains
+    else:
+        assert float((as_built - want).pow(2).mean().sqrt()) < 0.01 * spread and float((as_built - want).abs().max()) < 0.25 * spread
     # the MLP front half in one launch is the same arithmetic as gate GEMM, up GEMM and the SiLU*up producer
     assert torch.equal(llama.FusedForward(model, fuse_mlp=False)(ids).float().cpu(), got)
     cached = llama.FusedForward(model, cache_weight_codes=True)
@@ -176,7 +182,7 @@ def test_fused_forward_with_the_attention_kernel_on_gpu(hip_backend):
     ids = torch.randint(0, cfg.vocab_size, (2, 192), device="cuda")
     llama.calibrate(model, [ids, torch.randint(0, cfg.vocab_size, (2, 192), device="cuda")], fused=True)
     assert llama.attention_kernel_covers(cfg, 192, torch.bfloat16)
-    with torch.no_grad(), ff.strict_quantization(False):
+    with torch.no_grad(), ff.strict_quantization(False), llama.eager_modules():  # the independent reference: eager ATen chains
         want = model(ids).float().cpu()
     spread = float(want.std())
     with_kernel = llama.FusedForward(model)(ids).float().cpu()
@@ -202,7 +208,7 @@ def check_producers_forward_weight_only(fixture, device):
     llama.quantize_llama(model, w_bits=8, a_bits=None, quantized_dtype=torch.int8)
     llama.calibrate(model, [fixture["calibration_ids"][0].to(device)])
     ids = fixture["ids"].to(device)
-    with torch.no_grad(), ff.strict_quantization(False):
+    with torch.no_grad(), ff.strict_quantization(False), llama.eager_modules():  # the independent reference: eager ATen chains
         want = model(ids).float().cpu()
         got = llama.FusedProducersForward(model)(ids, logits=True).float().cpu()
     err, spread = got - want, float(want.std())
@@ -286,7 +292,7 @@ def test_llama3_70b_shaped_layers_calibrate_and_run_fused(hip_backend):
         assert linear.weight_quantizer.scale.numel() == linear.weight.shape[0]
         assert bool((linear.weight_quantizer.scale > 0).all()) and linear.input_quantizer.scale.numel() == 1
     ids = batches[0]
-    with torch.no_grad(), ff.strict_quantization(False):
+    with torch.no_grad(), ff.strict_quantization(False), llama.eager_modules():  # the independent reference: eager ATen chains
         want = model(ids).float()
     fused = llama.FusedForward(model)
     fused.linear_events = []
@@ -301,3 +307,26 @@ def test_llama3_70b_shaped_layers_calibrate_and_run_fused(hip_backend):
     # a few bf16 values by an ulp, a few int8 codes flip, two 8192-wide layers amplify that): 0.014 spreads measured on the
     # MI355X at this width, 0.004 at the tiny model's 256
     assert float((with_sdpa - want).pow(2).mean().sqrt()) < 0.02 * spread
+
+
+def test_gptq_invalidates_cached_weight_codes(oracle_backend):
+    """gptq() rewrites a layer's weight in place; the write goes through an autograd-visible op (as the reference's
+    module.weight.copy_), so a FusedForward built BEFORE with cache_weight_codes=True re-quantizes that layer instead of
+    serving stale codes (gptq.py wrote through .data, which leaves `_version` alone)."""
+    from fastforward_amd.quantization.gptq import gptq
+
+    model = build_bf16(golden("g7_tiny_llama.pt"), "cpu")
+    ids = golden("g7_tiny_llama.pt")["ids"]
+    cached = llama.FusedForward(model, cache_weight_codes=True)
+    before = cached(ids).float()
+    layer = model.layers[0].mlp.down_proj
+    torch.manual_seed(0)
+    inputs = torch.randn(2, 32, layer.weight.shape[1], dtype=torch.bfloat16)
+    w_version = layer.weight._version
+    with torch.no_grad():
+        layer.weight.data.mul_(1.25)  # a write NO cache can see (through .data) that moves the weights off their grid ...
+        assert layer.weight._version == w_version
+        gptq(layer, [((inputs,), {})])  # ... then gptq snaps them onto the grid again: its write must be seen
+    assert layer.weight._version > w_version
+    after = cached(ids).float()
+    assert torch.equal(after, llama.FusedForward(model)(ids).float()) and not torch.equal(after, before)

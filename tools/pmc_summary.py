@@ -6,7 +6,18 @@ FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB. On gfx950 FETCH_SIZE c
 requests as 64 bytes for wide coalesced reads (MI355X_MICROARCH.md, HBM section): the "hbm_read_bytes"
 field below applies the prescribed x2 correction; WRITE_SIZE is taken as reported.
 """
-import collections, csv, json, re, sys
+import collections, csv, hashlib, json, pathlib, re, sys
+
+
+def kernel_source_sha16() -> str:
+    """Fingerprint of the kernel sources the profiled library was built from (bench.py compares it with the tree it runs in,
+    so a traffic lookup taken from an older build is visibly stale; the GPU box has no .git to ask)."""
+    root = pathlib.Path(__file__).resolve().parent.parent / "fastforward_amd" / "csrc"
+    h = hashlib.sha256()
+    for f in sorted(list(root.glob("*.hip")) + list(root.glob("*.h"))):
+        h.update(f.name.encode() + b"\0" + f.read_bytes())
+    return h.hexdigest()[:16]
+
 
 src, counter, dst = sys.argv[1:4]
 agg = collections.defaultdict(list)
@@ -26,5 +37,6 @@ for k, v in agg.items():
     if counter == "WRITE_SIZE":
         row["hbm_write_bytes"] = round(mean_kib * 1024)
     out[k] = row
+out["__kernel_source_sha16__"] = kernel_source_sha16()
 json.dump(out, open(dst, "w"), indent=1)
 print(f"wrote {dst}: {len(out)} kernels")
