@@ -207,7 +207,7 @@ def _untouched(*quantizers: torch.nn.Module | None) -> bool:
 def _one_pass(*tensors: torch.Tensor) -> bool:
     from fastforward_amd import _native
 
-    return (_ONE_PASS_MODULES and all(type(t) is torch.Tensor and t.is_cuda and t.dtype == torch.bfloat16 for t in tensors)
+    return (_ONE_PASS_MODULES and all(type(t) in (torch.Tensor, torch.nn.Parameter) and t.is_cuda and t.dtype == torch.bfloat16 for t in tensors)
             and not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors)) and _native.is_available())
 
 

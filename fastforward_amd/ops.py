@@ -834,6 +834,8 @@ def add_rmsnorm_quantize(
         )
     )
     del keep
+    if sum_inplace and dc is not None:
+        torch.autograd.graph.increment_version(x)  # written through a raw pointer
     return total, norm, codes
 
 
@@ -873,6 +875,9 @@ def rope_(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor
             _ptr(cos), _ptr(sin), stream,
         )
     )
+    # written through raw pointers: tell the version counters (whatever is keyed on them, e.g. the activation-code memo, must miss)
+    torch.autograd.graph.increment_version(q)
+    torch.autograd.graph.increment_version(k)
 
 
 def attention(

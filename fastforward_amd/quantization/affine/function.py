@@ -16,6 +16,7 @@ import torch
 from fastforward_amd import flags
 from fastforward_amd.exceptions import QuantizationError
 from fastforward_amd.quantization import granularity as granularities
+from fastforward_amd.quantization.affine._memo import RECENT
 from fastforward_amd.quantization.affine._autograd import (
     dequantize_affine,
     quantize_affine,
@@ -99,9 +100,12 @@ class AffineQuantizationFunction(QuantizationFunction[Any]):
         from fastforward_amd.quantized_tensor import QuantizedTensor
 
         tile = params.granularity.tile_size(data.shape)
-        raw = quantize_affine(
-            data, params.scale, params.offset, tile, params.num_bits, params.quantized_dtype or data.dtype
-        )
+        container = params.quantized_dtype or data.dtype
+        # the same activation quantized again by a quantizer with equal parameters (q / k / v, gate / up): the earlier codes
+        raw = RECENT.lookup(data, params, tile, container)
+        if raw is None:
+            raw = quantize_affine(data, params.scale, params.offset, tile, params.num_bits, container)
+            RECENT.remember(data, params, tile, container, raw)
         # the dequantize dtype is stamped at quantize time                      (reference :137)
         stamped = params.with_changes(dequantize_dtype=params.dequantize_dtype or data.dtype)
         return QuantizedTensor(raw, QuantizationContext(cls, stamped))

@@ -852,3 +852,40 @@ def test_grid_error_by_tile_kernel_covers_every_tiling(shape, tile, dtype):
     torch.testing.assert_close(got, want, rtol=rtol, atol=1e-6)
     again = ops.grid_sqerror_by_tile(x, scales, offsets, tile, 4.0, out=got.clone())
     torch.testing.assert_close(again, 2 * got, rtol=1e-6, atol=0)
+
+
+def test_equal_quantizers_share_one_launch_on_the_same_activation():
+    """q_proj / k_proj / v_proj quantize the same hidden state with their own input quantizers (reference nn/linear.py:33);
+    once their parameters have stopped changing and are known to be equal, the later ones reuse the first one's codes
+    (quantization/affine/_memo.py) — same bits, fewer launches; any write to the tensor or to a parameter ends the reuse."""
+    from fastforward_amd.quantization.affine._memo import RECENT
+
+    torch.manual_seed(5)
+    x = torch.randn(4, 64, 256, device=DEV, dtype=torch.bfloat16)
+    qs = [ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=torch.int8, device=DEV) for _ in range(3)]
+    with torch.no_grad():
+        with ff.estimate_ranges(torch.nn.ModuleList(qs), ff.range_setting.running_minmax):
+            for q in qs:
+                q(x)  # calibration: parameters rewritten on every call, never "stable" -> no host reads, no reuse
+        want = ops.quantize_by_tile(x, qs[0].scale, x.shape, 8, torch.int8, qs[0].offset)
+        RECENT.clear()
+        hits = RECENT.hits
+        first = [q(x).raw_data for q in qs]       # the final versions were sighted by the last calibration call: verdicts may be read here
+        second = [q(x).raw_data for q in qs]
+        third = [q(x).raw_data for q in qs]
+        assert RECENT.hits >= hits + 4 and third[1].data_ptr() == third[0].data_ptr() == third[2].data_ptr()
+        for codes in first + second + third:
+            assert torch.equal(codes, want)
+        # a new tensor, a write autograd can see, a raw-pointer write of this package: all miss
+        y = x.clone()
+        before = RECENT.hits
+        a = qs[0](y).raw_data
+        y.mul_(0.5)
+        b = qs[1](y).raw_data
+        assert RECENT.hits == before and torch.equal(b, ops.quantize_by_tile(y, qs[1].scale, y.shape, 8, torch.int8, qs[1].offset)) and not torch.equal(a, b)
+        # a parameter that moves: the other quantizers no longer share with it, and its own codes follow the new range
+        lo, hi = qs[2].quantization_range
+        qs[2].quantization_range = (lo * 0.5, hi * 0.5)
+        c = [q(x).raw_data for q in qs]
+        assert torch.equal(c[0], want) and torch.equal(c[1], want) and not torch.equal(c[2], want)
+        assert torch.equal(c[2], ops.quantize_by_tile(x, qs[2].scale, x.shape, 8, torch.int8, qs[2].offset))
