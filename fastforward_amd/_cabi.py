@@ -117,6 +117,24 @@ class FanOut(ctypes.Structure):
         return f
 
 
+FFQ_MAX_BATCH = 8
+
+
+class RowsBatch(ctypes.Structure):
+    """``ffq_rows_batch``: several row-quantized bf16 weights for one A1 launch."""
+
+    _fields_ = [
+        ("count", ctypes.c_int32),
+        ("num_bits", ctypes.c_double),
+        ("data", ctypes.c_void_p * FFQ_MAX_BATCH),
+        ("scale", ctypes.c_void_p * FFQ_MAX_BATCH),
+        ("offset", ctypes.c_void_p * FFQ_MAX_BATCH),
+        ("codes", ctypes.c_void_p * FFQ_MAX_BATCH),
+        ("rows", ctypes.c_int64 * FFQ_MAX_BATCH),
+        ("cols", ctypes.c_int64 * FFQ_MAX_BATCH),
+    ]
+
+
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _i64 = ctypes.c_int64
@@ -165,6 +183,8 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_linear_wq_supported": (_i, [_i, _i, _i, _i64, _i64, _i64, _i64, _i64]),
     "ffq_linear_wq_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "ffq_linear_wq": (_i, [_vp, _i, _vp, _i, _i64, _vp, _vp, _i64, _i64, _vp, _i, _vp, _i, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "ffq_force_generic_kernels": (_i, [_i]),
+    "ffq_quantize_rows_batch": (_i, [ctypes.POINTER(RowsBatch), _i, _vp]),
     "ffq_attention": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _d, _i, _vp, _vp, _vp, _vp, _d, _vp]),
 }
 

@@ -20,6 +20,9 @@ namespace ffq {
 // ---------------------------------------------------------------------------------------------
 char* err_buf();
 int fail(int code, const char* fmt, ...);
+// ffq_force_generic_kernels (include/ffq.h): the one-element-per-lane kernels instead of the streaming ones, for tests that
+// compare the two families. The library reads NO environment variables (tuning knobs exist only under -DFFQ_EXPERIMENTS).
+bool generic_kernels_forced();
 int check_launch(const char* what);
 
 // ---------------------------------------------------------------------------------------------

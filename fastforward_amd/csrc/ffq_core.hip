@@ -196,3 +196,13 @@ int ffq_dequantize_result_dtype(int data_dt, int scale_dt, int offset_dt, int ha
 }
 
 }  // extern "C"
+
+// ---- test hook: kernel-family selection (no environment variables in the product) ------------------------------------------
+namespace ffq {
+static int g_force_generic = 0;
+bool generic_kernels_forced() { return __atomic_load_n(&g_force_generic, __ATOMIC_RELAXED) != 0; }
+}  // namespace ffq
+
+extern "C" int ffq_force_generic_kernels(int on) {
+  return __atomic_exchange_n(&ffq::g_force_generic, on ? 1 : 0, __ATOMIC_RELAXED);
+}

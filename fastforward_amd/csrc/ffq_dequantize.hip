@@ -199,9 +199,10 @@ template <typename TIn, typename TOut, int E>
 static int dq_launch_stream(const TIn* in, TOut* out, const float* scale, int64_t scale_numel,
                             const float* offset, int64_t offset_numel, const TileInfo& info,
                             hipStream_t stream) {
-  const char* e = getenv("FFQ_STREAM_U");
-  int u = e ? atoi(e) : 0;
-  if (u == 0) u = 1;
+  int u = 1;
+#ifdef FFQ_EXPERIMENTS
+  if (const char* e = getenv("FFQ_STREAM_U")) u = atoi(e) ? atoi(e) : 1;
+#endif
   switch (u) {
     case 1: return dq_launch_stream_u<TIn, TOut, E, 1>(in, out, scale, scale_numel, offset, offset_numel, info, stream);
     case 4: return dq_launch_stream_u<TIn, TOut, E, 4>(in, out, scale, scale_numel, offset, offset_numel, info, stream);
@@ -259,7 +260,11 @@ static int dq_dispatch_fast(const void* data, const void* scale, int64_t scale_n
   int rc = FFQ_OK;
   // 8 codes per chunk: an 8 B load and ONE dense 16 B store per lane beats 16 codes per chunk (16 B
   // load, two half-dense 16 B stores): 30.1 vs 32.1 us on [14336, 4096] int8 -> bf16 (FFQ_DQ_E16=1 to compare)
+#ifdef FFQ_EXPERIMENTS
   const char* e16 = getenv("FFQ_DQ_E16");
+#else
+  const char* e16 = nullptr;
+#endif
   if (sizeof(TIn) == 1 && e16 && e16[0] == '1') {
     rc = dq_dispatch_fast_e<TIn, TOut, 16>(data, scale, scale_numel, offset, offset_numel, info, out, stream, done);
     if (rc || *done) return rc;
@@ -308,7 +313,7 @@ int dequantize_impl(const void* data, int data_dt, const void* scale, int scale_
   if (!data || !scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
 
   const bool fast_types = add_dt == FFQ_F32 && mul_dt == FFQ_F32 && scale_dt == FFQ_F32 &&
-                          (!offset || offset_dt == FFQ_F32) && getenv("FFQ_FORCE_GENERIC") == nullptr;
+                          (!offset || offset_dt == FFQ_F32) && !generic_kernels_forced();
   int64_t done = 0;
   if (fast_types) {
     switch (data_dt) {

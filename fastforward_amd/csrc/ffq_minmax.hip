@@ -378,7 +378,7 @@ static MinMaxPlan plan_for(const TileInfo& info, int data_dt) {
   p.partials = 0;
   p.workspace = sizeof(GenericCell) * (size_t)info.ntiles;
   const bool fast_dt = data_dt == FFQ_F32 || data_dt == FFQ_BF16 || data_dt == FFQ_F16;
-  if (!fast_dt || info.numel >= ((int64_t)1 << 32) - 4096 || getenv("FFQ_FORCE_GENERIC")) return p;
+  if (!fast_dt || info.numel >= ((int64_t)1 << 32) - 4096 || generic_kernels_forced()) return p;
   if (info.layout == LAYOUT_SCALAR) {
     const uint32_t nchunks = (uint32_t)(info.numel / kE);
     uint32_t blocks = (nchunks + kBlock * 4 - 1) / (kBlock * 4);

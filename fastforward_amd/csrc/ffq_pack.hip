@@ -196,7 +196,11 @@ __global__ __launch_bounds__(kBlock) void unpack_dequantize_int4_kernel(const ui
 // quantize+pack 5.25-5.31 with 16, 5.20-5.29 with 8 and 4.6-4.7 with 8 x 2 items per lane (a second reciprocal per 8
 // elements, and short blocks beat unrolled ones here as in A1) — so the two directions take different shapes.
 static int pack4_item(int dt, bool unpack) {
+#ifdef FFQ_EXPERIMENTS
   static const int forced = getenv("FFQ_PACK_ITEM") ? atoi(getenv("FFQ_PACK_ITEM")) : 0;
+#else
+  constexpr int forced = 0;
+#endif
   if (dt == FFQ_F32) return 16;
   if (forced == 8 || forced == 16) return forced;
   return unpack ? 8 : 16;

@@ -176,14 +176,18 @@ __global__ __launch_bounds__(kBlock) void quantize_generic_kernel(const void* __
   }
 }
 
-// FFQ_DIV_MODE=0 forces the compiler's IEEE division sequence in the streaming kernels;
+// (-DFFQ_EXPERIMENTS builds) FFQ_DIV_MODE=0 forces the compiler's IEEE division sequence in the streaming kernels;
 // the default is the Markstein iteration (bit-identical, see Divider).
 static int div_mode() {
+#ifdef FFQ_EXPERIMENTS
   static const int mode = [] {
     const char* e = getenv("FFQ_DIV_MODE");
     return e ? atoi(e) : 1;
   }();
   return mode;
+#else
+  return 1;
+#endif
 }
 
 static unsigned grid_for(int64_t work_items, int per_block) {
@@ -217,8 +221,12 @@ static int launch_generic(const void* data, int data_dt, const void* scale, int 
 // bf16 -> int8 [14336, 4096]: E=16/U=1 29.2 us vs E=16/U=2 32.4 us vs E=8/U=4 34.3 us; U=1 also wins for
 // bf16 -> bf16 (38.5 vs 41.0 us at U=4) and per-tensor activations (33.2 vs 39.2 us).
 static int stream_u_override() {
+#ifdef FFQ_EXPERIMENTS
   const char* e = getenv("FFQ_STREAM_U");
   return e ? atoi(e) : 0;
+#else
+  return 0;
+#endif
 }
 
 template <typename TIn, typename TOut, int E, int U>
@@ -387,7 +395,7 @@ int quantize_impl(const void* data, int data_dt, const void* scale, int scale_dt
 
   const bool fast_types = num_bits == floor(num_bits) && num_bits >= 1 && num_bits <= 32 &&
                           div_dt == FFQ_F32 && sub_dt == FFQ_F32 && scale_dt == FFQ_F32 &&
-                          (!offset || offset_dt == FFQ_F32) && getenv("FFQ_FORCE_GENERIC") == nullptr;
+                          (!offset || offset_dt == FFQ_F32) && !generic_kernels_forced();
   int64_t done = 0;
   if (fast_types) {
     switch (data_dt) {
@@ -469,6 +477,49 @@ __global__ __launch_bounds__(kBlock) void quantize_rows_rowsum_kernel(const bf16
   }
 }
 
+
+// ---- A1 of SEVERAL row-quantized weights in one launch (ffq_quantize_rows_batch) ---------------------------------------------------
+// The reference re-quantizes all seven linears' weights of a decoder layer on every forward (nn/linear.py:34): seven launches,
+// two of them (k_proj / v_proj, 4 M elements) far too short to reach the streaming rate (34 % of the HBM peak, profiles/r03_micro.md).
+// One grid covers all members: every member's chunk count is a multiple of the block size, so a block lies inside ONE member and
+// finds it with a handful of scalar compares; the arithmetic is quantize_stream_kernel's ROWS case (bf16 -> int8, one (scale,
+// offset) per row, Markstein division).
+struct BatchMember {
+  const bf16_t* in;
+  int8_t* out;
+  const float* scale;
+  const float* offset;
+  uint32_t first_block;     // blocks [first_block, next member's first_block) belong to this member
+  FastDiv chunks_per_row;   // cols / 16
+};
+struct BatchArgs {
+  BatchMember m[FFQ_MAX_BATCH];
+  int count;
+  float lo, hi;
+};
+
+__global__ __launch_bounds__(kBlock) void quantize_rows_batch_kernel(BatchArgs a) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < FFQ_MAX_BATCH; ++i)
+    if (i < a.count && blockIdx.x >= a.m[i].first_block) k = i;
+  // (k is wave-uniform: the selects below stay in scalar registers)
+  const BatchMember& mem = a.m[k];
+  const uint32_t c = (blockIdx.x - mem.first_block) * (uint32_t)kBlock + threadIdx.x;
+  Chunk<bf16_t, 16> x;
+  x.load(mem.in + (size_t)c * 16);
+  const uint32_t row = fdiv(c, mem.chunks_per_row);
+  const float s = mem.scale[row];
+  const float o = mem.offset ? rne(mem.offset[row]) : 0.0f;
+  float xf[16], r[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) xf[i] = x.get(i);
+  quantize_chunk<1, 16>(xf, s, o, r);
+  Chunk<int8_t, 16> y;
+  finalize_chunk<int8_t, 16>(r, a.lo, a.hi, y);
+  y.store(mem.out + (size_t)c * 16);
+}
+
 }  // namespace ffq
 
 extern "C" int ffq_quantize_by_tile(const void* data, int data_dt, const void* scale, int scale_dt,
@@ -504,4 +555,37 @@ extern "C" int ffq_quantize_rows_rowsum(const void* data, int data_dt, const flo
   if (offset) quantize_rows_rowsum_kernel<true><<<grid, kBlock, 0, s>>>(static_cast<const bf16_t*>(data), codes, scale, offset, rowsum, a);
   else quantize_rows_rowsum_kernel<false><<<grid, kBlock, 0, s>>>(static_cast<const bf16_t*>(data), codes, scale, offset, rowsum, a);
   return check_launch("quantize_rows_rowsum_kernel");
+}
+
+extern "C" int ffq_quantize_rows_batch(const ffq_rows_batch* batch, int data_dt, void* stream) {
+  using namespace ffq;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!batch || batch->count < 0 || batch->count > FFQ_MAX_BATCH) return fail(FFQ_ERR_ARG, "batch count must be 0..%d", FFQ_MAX_BATCH);
+  if (batch->count == 0) return FFQ_OK;
+  if (data_dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "batched weight quantization is built for bf16 weights");
+  if (!ffq_can_support_bitwidth(FFQ_I8, batch->num_bits))
+    return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.", FFQ_I8, batch->num_bits);
+  BatchArgs a;
+  a.count = batch->count;
+  const double lo = -pow(2.0, batch->num_bits - 1.0);
+  a.lo = (float)lo; a.hi = (float)(-lo - 1.0);
+  uint64_t blocks = 0;
+  for (int i = 0; i < batch->count; ++i) {
+    const int64_t rows = batch->rows[i], cols = batch->cols[i];
+    if (rows <= 0 || cols <= 0 || cols % 16 != 0 || (rows * cols / 16) % kBlock != 0)
+      return fail(FFQ_ERR_DTYPE, "batched weight quantization needs rows * cols %% %d == 0 and cols %% 16 == 0", 16 * kBlock);
+    if (!batch->data[i] || !batch->scale[i] || !batch->codes[i]) return fail(FFQ_ERR_ARG, "NULL buffer in batch member %d", i);
+    if (!aligned16(batch->data[i]) || !aligned16(batch->codes[i])) return fail(FFQ_ERR_ARG, "buffers must be 16-byte aligned");
+    a.m[i].in = static_cast<const bf16_t*>(batch->data[i]);
+    a.m[i].out = batch->codes[i];
+    a.m[i].scale = batch->scale[i];
+    a.m[i].offset = batch->offset[i];
+    a.m[i].first_block = (uint32_t)blocks;
+    a.m[i].chunks_per_row = make_fastdiv((uint32_t)(cols / 16));
+    blocks += (uint64_t)(rows * cols / 16) / kBlock;
+    if (blocks >= ((uint64_t)1 << 31)) return fail(FFQ_ERR_ARG, "too many elements for one launch");
+  }
+  for (int i = batch->count; i < FFQ_MAX_BATCH; ++i) a.m[i] = a.m[0];
+  quantize_rows_batch_kernel<<<(unsigned)blocks, kBlock, 0, s>>>(a);
+  return check_launch("quantize_rows_batch_kernel");
 }

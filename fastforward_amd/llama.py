@@ -462,7 +462,8 @@ class FusedForward:
     per-channel activations, biases — instead of silently computing something else.
     """
 
-    def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True, fuse_attention: bool = True, fuse_rowsums: bool = False) -> None:
+    def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True, fuse_attention: bool = True, fuse_rowsums: bool = False,
+                 batch_weight_quantization: bool = True) -> None:
         problems = self.unsupported(model)
         if problems:
             raise ff.exceptions.QuantizationError("FusedForward cannot run this model: " + "; ".join(problems[:4]))
@@ -479,6 +480,9 @@ class FusedForward:
         # runs): the int8 GEMMs that follow run slower by more than the reduction cost (tools/gemm_cache_probe.py: a GEMM
         # preceded by more memory-bound work is faster — the chip is power-limited and the light pass lets it recover).
         self.fuse_rowsums = fuse_rowsums
+        # the seven weights of a layer re-quantized by one launch instead of seven (ops.quantize_rows_batch)
+        self.batch_weight_quantization = batch_weight_quantization
+        self._layer_codes: dict[int, torch.Tensor] = {}
         self._zero_offset: dict[int, tuple[int, bool]] = {}
         self._weight_cache: dict[int, tuple[tuple[int, int, int], tuple[torch.Tensor, torch.Tensor | None]]] = {}
         self._rowsum_rows = sum(linear.weight.shape[0] for _, linear in decoder_linears(model))
@@ -599,12 +603,41 @@ class FusedForward:
         quantizer's own forward and the GEMM entry point reduces the codes itself."""
         wq = linear.weight_quantizer
         rows = linear.weight.shape[0]
+        ready = self._layer_codes.pop(id(linear), None)  # quantized with the rest of its layer in one launch (_quantize_layer)
+        if ready is not None:
+            return ready, None
         if self.fuse_rowsums and wq.scale.numel() == rows and rows > 1 and (wq.offset is None or wq.offset.numel() == rows) and wq.num_bits <= 8:
             offset = None if self._symmetric_weights(linear) else wq.offset  # an all-zero offset buffer: same codes
             fused = ff.ops.quantize_rows_rowsum(linear.weight, wq.scale, offset, wq.num_bits, rowsum_out=self._rowsum_slice(rows, linear.weight.device))
             if fused is not None:
                 return fused
         return wq(linear.weight).raw_data, None
+
+    def _quantize_layer(self, layer: torch.nn.Module) -> None:
+        """A1 of all the layer's weights that are re-quantized this forward, as ONE launch (ops.quantize_rows_batch): seven
+        launches otherwise, two of them (k_proj / v_proj) too short to stream at rate. Fills `_layer_codes`; weights the batched
+        kernel does not cover (not per-channel bf16, odd sizes) are left to `_quantize_weight`."""
+        self._layer_codes = {}
+        if not self.batch_weight_quantization or self.fuse_rowsums:
+            return
+        attn, mlp = layer.self_attn, layer.mlp
+        todo = []
+        for linear in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj):
+            wq = linear.weight_quantizer
+            if self.cache_weight_codes:
+                key = (linear.weight._version, wq.scale._version, -1 if wq.offset is None else wq.offset._version)
+                hit = self._weight_cache.get(id(linear))
+                if hit is not None and hit[0] == key:
+                    continue
+            rows = linear.weight.shape[0]
+            if wq.scale.numel() == rows and rows > 1 and (wq.offset is None or wq.offset.numel() == rows) and wq.num_bits == attn.q_proj.weight_quantizer.num_bits:
+                todo.append(linear)
+        if len(todo) < 2:
+            return
+        offsets = [None if self._symmetric_weights(l) else l.weight_quantizer.offset for l in todo]  # an all-zero offset buffer: same codes
+        codes = ff.ops.quantize_rows_batch([l.weight for l in todo], [l.weight_quantizer.scale for l in todo], offsets, todo[0].weight_quantizer.num_bits)
+        if codes is not None:
+            self._layer_codes = {id(l): c for l, c in zip(todo, codes)}
 
     def _weight(self, linear: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor | None, torch.Tensor, torch.Tensor | None]:
         """(int8 codes, row sums or None, scale, offset) of the linear's weight."""
@@ -652,6 +685,7 @@ class FusedForward:
             self._rowsum_used = 0
         for layer, fan in zip(model.layers, self._fan):
             attn, mlp = layer.self_attn, layer.mlp
+            self._quantize_layer(layer)
             pairs, index = fan["qkv"]
             bits = attn.q_proj.input_quantizer.num_bits
             hidden, _, codes = ff.ops.add_rmsnorm_quantize(

@@ -18,7 +18,7 @@ from typing import Sequence
 import torch
 
 from fastforward_amd import _native
-from fastforward_amd._cabi import FLAG_INF, FLAG_NAN, DType, FanOut, Tiling
+from fastforward_amd._cabi import FFQ_MAX_BATCH, FLAG_INF, FLAG_NAN, DType, FanOut, RowsBatch, Tiling
 from fastforward_amd.exceptions import BackendError
 
 __all__ = [
@@ -43,6 +43,7 @@ __all__ = [
     "silu_mul_quantize",
     "rope_",
     "quantize_rows_rowsum",
+    "quantize_rows_batch",
     "attention",
     "FLAG_INF",
     "FLAG_NAN",
@@ -777,6 +778,39 @@ def quantize_rows_rowsum(
             raise RuntimeError(f"rowsum_out must be a zeroed contiguous int32 tensor with {rows} entries on the weight's device")
     lib.check(lib.ffq_quantize_rows_rowsum(_ptr(wd), _tag(wd.dtype), _ptr(sc), _ptr(of), rows, cols, float(num_bits), _ptr(codes), _ptr(rowsum), stream))
     return codes, rowsum
+
+
+def quantize_rows_batch(
+    weights: Sequence[torch.Tensor], scales: Sequence[torch.Tensor], offsets: Sequence[torch.Tensor | None], num_bits: float = 8.0
+) -> list[torch.Tensor] | None:
+    """A1 of up to 8 ``[rows, cols]`` bf16 weights with one (scale, offset) per row into int8 codes, ONE launch; each result
+    equals ``quantize_by_tile(weight, scale, (1, cols), num_bits, torch.int8, offset)``. The seven linears of a decoder layer
+    are re-quantized on every forward (reference nn/linear.py:34); as seven launches the short ones (k_proj / v_proj) run far
+    below the streaming rate. Returns None where the one-launch kernel does not apply (then quantize member by member)."""
+    if not weights or len(weights) > FFQ_MAX_BATCH or not (len(weights) == len(scales) == len(offsets)):
+        return None
+    sc, of = [], []
+    for w, s, o in zip(weights, scales, offsets):
+        if w.dim() != 2 or w.dtype != torch.bfloat16 or not w.is_contiguous() or w.shape[1] % 16 or (w.numel() // 16) % 256:
+            return None
+        s32 = s.detach().reshape(-1).to(torch.float32).contiguous()
+        o32 = None if o is None else o.detach().reshape(-1).to(torch.float32).contiguous()
+        if s32.numel() != w.shape[0] or (o32 is not None and o32.numel() != w.shape[0]):
+            return None
+        sc.append(s32)
+        of.append(o32)
+    lib, stream = _prepare(*[w.detach() for w in weights], *sc, *[o for o in of if o is not None])
+    codes = [torch.empty(w.shape, dtype=torch.int8, device=w.device) for w in weights]
+    batch = RowsBatch()
+    batch.count, batch.num_bits = len(weights), float(num_bits)
+    for i, (w, s, o, c) in enumerate(zip(weights, sc, of, codes)):
+        batch.data[i], batch.scale[i], batch.offset[i], batch.codes[i] = _ptr(w.detach()), _ptr(s), _ptr(o), _ptr(c)
+        batch.rows[i], batch.cols[i] = w.shape
+    status = lib.ffq_quantize_rows_batch(ctypes.byref(batch), _tag(torch.bfloat16), stream)
+    if status == 6:
+        return None
+    lib.check(status)
+    return codes
 
 
 def _fan(quantizers: Sequence[tuple[torch.Tensor, torch.Tensor | None]], num_bits: float, shape: Sequence[int], device: torch.device):

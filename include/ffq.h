@@ -373,6 +373,26 @@ int ffq_quantize_rows_rowsum(const void* data, int data_dt, const float* scale, 
                              int64_t cols, double num_bits, int8_t* codes, int32_t* rowsum, void* stream);
 
 /*
+ * A1 of several row-quantized weights in ONE launch: member i is a [rows[i], cols[i]] bf16 matrix with one (scale, offset) per
+ * row (PerChannel(0); `offset[i]` nullable), codes into an int8 container — bit-identical to ffq_quantize_by_tile on each member.
+ * The reference re-quantizes every linear's weight on every forward (nn/linear.py:34): a decoder layer's seven weights are one
+ * call here instead of seven launches, two of which (k_proj / v_proj) are too short to reach the streaming rate on their own.
+ * rows[i] * cols[i] must be a multiple of 4096 and cols[i] of 16, else FFQ_ERR_DTYPE (the caller quantizes member by member).
+ */
+#define FFQ_MAX_BATCH 8
+typedef struct {
+  int32_t count;
+  double num_bits;
+  const void* data[FFQ_MAX_BATCH];
+  const float* scale[FFQ_MAX_BATCH];
+  const float* offset[FFQ_MAX_BATCH];
+  int8_t* codes[FFQ_MAX_BATCH];
+  int64_t rows[FFQ_MAX_BATCH];
+  int64_t cols[FFQ_MAX_BATCH];
+} ffq_rows_batch;
+int ffq_quantize_rows_batch(const ffq_rows_batch* batch, int data_dt, void* stream);
+
+/*
  * The attention between q/k/v_proj and o_proj of the reference's quantized Llama —
  * docs/examples/doc_helpers/quantized_llama/attention.py:45-92 (repeat_kv, matmul, * scaling, causal mask, fp32
  * softmax, cast, matmul; the attn_weights / attn_probs / attn_output quantizers are stubs in the recipe) — with the
@@ -389,6 +409,14 @@ int ffq_attention(const void* q, const void* k, const void* v, int dt, int64_t b
                   int64_t q_heads, int64_t kv_heads, int64_t head_dim, double softmax_scale, int causal,
                   void* ctx_out, int8_t* codes_out, const float* out_scale, const float* out_offset,
                   double out_num_bits, void* stream);
+
+/*
+ * Test hook. The streaming kernels (fp32 parameters, one 16-byte chunk per lane, Markstein division) and the generic kernels
+ * (any dtype mix / tiling, one element per lane, the compiler's IEEE division, every eager rounding reproduced) must agree
+ * wherever both apply; ffq_force_generic_kernels(1) routes A1 / A2 / A4 to the generic family until it is called with 0.
+ * Returns the previous setting. Process-wide; the library reads no environment variables.
+ */
+int ffq_force_generic_kernels(int on);
 
 #ifdef __cplusplus
 }

@@ -1210,3 +1210,22 @@ int ffq_quantize_rows_rowsum(const void* data, int data_dt, const float* scale, 
   }
   return FFQ_OK;
 }
+
+/* test hook of the HIP library (kernel-family selection): the oracle has one implementation, nothing to select */
+int ffq_force_generic_kernels(int on) { (void)on; return 0; }
+
+/* A1 of several row-quantized weights: the composition the one-launch form replaces (_quantizer_impl.py:154-169 per member) */
+int ffq_quantize_rows_batch(const ffq_rows_batch* batch, int data_dt, void* stream) {
+  if (!batch || batch->count < 0 || batch->count > FFQ_MAX_BATCH) return fail(FFQ_ERR_ARG, "batch count must be 0..%d", FFQ_MAX_BATCH);
+  for (int i = 0; i < batch->count; ++i) {
+    ffq_tiling t;
+    memset(&t, 0, sizeof t);
+    t.ndim = 2;
+    t.shape[0] = batch->rows[i]; t.shape[1] = batch->cols[i];
+    t.tile[0] = 1; t.tile[1] = batch->cols[i];
+    int rc = ffq_quantize_by_tile(batch->data[i], data_dt, batch->scale[i], FFQ_F32, batch->rows[i], batch->offset[i], FFQ_F32,
+                                  batch->offset[i] ? batch->rows[i] : 0, &t, batch->num_bits, batch->codes[i], FFQ_I8, stream);
+    if (rc) return rc;
+  }
+  return FFQ_OK;
+}

@@ -48,3 +48,14 @@ def test_pure_host_queries_of_the_hip_library():
     bad = Tiling.make((10, 4), (3, 4))
     assert lib.ffq_num_tiles(ctypes.byref(bad)) == -2  # FFQ_ERR_TILE_DIVIDE
     assert b"must divide" in lib.ffq_last_error()
+
+
+def test_the_shipped_library_reads_no_environment():
+    """Round 2 shipped ten getenv switches in the GEMM launcher and a few in the streaming kernels. Tuning knobs now exist only in
+    -DFFQ_EXPERIMENTS builds (tools/build_experiments.sh); the test hook is an entry point (ffq_force_generic_kernels)."""
+    import subprocess
+
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", str(HIP_SO)], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    lib = FFQLibrary(HIP_SO)
+    assert lib.ffq_force_generic_kernels(1) == 0 and lib.ffq_force_generic_kernels(0) == 1 and lib.ffq_force_generic_kernels(0) == 0

@@ -152,13 +152,20 @@ def test_gptq_block_kernel():
     parity_cases.check_gptq(DEV, exact=False)
 
 
-def test_golden_sweeps_with_ieee_division_kernels(monkeypatch):
-    """FFQ_DIV_MODE is read once per process; the generic kernels always use the IEEE sequence."""
-    monkeypatch.setenv("FFQ_FORCE_GENERIC", "1")
+@pytest.fixture()
+def generic_kernels(hip_lib):
+    """switch(on): route A1 / A2 / A4 to the generic one-element-per-lane kernels (the library's test hook; no env vars)."""
+    yield lambda on: hip_lib.ffq_force_generic_kernels(int(on))
+    hip_lib.ffq_force_generic_kernels(0)
+
+
+def test_golden_sweeps_with_ieee_division_kernels(generic_kernels):
+    """The generic kernels always use the compiler's IEEE division sequence."""
+    generic_kernels(True)
     parity_cases.check_sweeps(DEV, name_filter=lambda n: "sweep3d" in n)
 
 
-def test_fast_division_is_bit_identical_to_ieee_division(monkeypatch):
+def test_fast_division_is_bit_identical_to_ieee_division(generic_kernels):
     """The streaming kernels' FMA-iteration divide vs the compiler's IEEE divide (generic kernel).
 
     Quotients are placed in [2^18, 2^25) where one ulp is 1/32 ... 2, so that a last-bit error in
@@ -186,15 +193,14 @@ def test_fast_division_is_bit_identical_to_ieee_division(monkeypatch):
     regimes.append((torch.randn(n, 8, device=DEV, generator=g), sb))
     for x, s in regimes:
         for offset in (None, torch.full_like(s, 3.0)):
-            monkeypatch.delenv("FFQ_FORCE_GENERIC", raising=False)
+            generic_kernels(False)
             fast = ops.quantize_by_tile(x, s, (1, 8), 26, torch.int32, offset)
             fast_f = ops.quantize_by_tile(x, s, (1, 8), 25, torch.float32, offset)
-            monkeypatch.setenv("FFQ_FORCE_GENERIC", "1")
+            generic_kernels(True)
             slow = ops.quantize_by_tile(x, s, (1, 8), 26, torch.int32, offset)
             slow_f = ops.quantize_by_tile(x, s, (1, 8), 25, torch.float32, offset)
             assert torch.equal(fast, slow), mismatch_report(fast.cpu(), slow.cpu())
             assert same_with_nan(fast_f.cpu(), slow_f.cpu()), mismatch_report(fast_f.cpu(), slow_f.cpu())
-    monkeypatch.delenv("FFQ_FORCE_GENERIC", raising=False)
 
 
 # ---- 2. HIP vs oracle on seeded inputs ------------------------------------------------------------
@@ -889,3 +895,26 @@ def test_equal_quantizers_share_one_launch_on_the_same_activation():
         c = [q(x).raw_data for q in qs]
         assert torch.equal(c[0], want) and torch.equal(c[1], want) and not torch.equal(c[2], want)
         assert torch.equal(c[2], ops.quantize_by_tile(x, qs[2].scale, x.shape, 8, torch.int8, qs[2].offset))
+
+
+def test_batched_weight_quantization_equals_member_by_member():
+    """ffq_quantize_rows_batch: the seven weights of a Llama-3-8B decoder layer (and a ragged mix with real offsets) in one
+    launch; every member's codes equal its own A1 launch bit for bit. Shapes the kernel declines return None."""
+    torch.manual_seed(12)
+    shapes = [(4096, 4096), (1024, 4096), (1024, 4096), (4096, 4096), (14336, 4096), (14336, 4096), (4096, 14336)]
+    ws = [(torch.randn(s, device=DEV) * 0.02).to(torch.bfloat16) for s in shapes]
+    scales = [w.float().abs().amax(1) / 127 for w in ws]
+    offsets = [None] * 7
+    got = ops.quantize_rows_batch(ws, scales, offsets, 8)
+    assert got is not None
+    for w, s, c in zip(ws, scales, got):
+        assert torch.equal(c, ops.quantize_by_tile(w, s, (1, w.shape[1]), 8, torch.int8))
+    small = [(torch.randn(256, 1024, device=DEV)).to(torch.bfloat16), (torch.randn(512, 48, device=DEV) * 3).to(torch.bfloat16), (torch.randn(16, 4096, device=DEV)).to(torch.bfloat16)]
+    sc = [torch.rand(w.shape[0], device=DEV) * 0.05 + 0.01 for w in small]
+    of = [torch.round(torch.randn(256, device=DEV) * 5) + 0.5, None, torch.zeros(16, device=DEV)]
+    got = ops.quantize_rows_batch(small, sc, of, 4)
+    assert got is not None
+    for w, s, o, c in zip(small, sc, of, got):
+        assert torch.equal(c, ops.quantize_by_tile(w, s, (1, w.shape[1]), 4, torch.int8, o))
+    assert ops.quantize_rows_batch([small[0][:, :40].contiguous()], [sc[0]], [None]) is None  # 40 columns: not a multiple of 16
+    assert ops.quantize_rows_batch([small[0].float()], [sc[0]], [None]) is None                # fp32 weights: member by member

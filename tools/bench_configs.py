@@ -108,7 +108,19 @@ def cfg2() -> dict:
     ms = event_ms(quantize_all, reps=5)
     elems = config.quantized_weight_elems()
     out["weight_quantize_all_linears"] = {"ms": round(ms, 3), "elements": elems, "GB_per_s": round(elems * 3 / ms / 1e6, 1),
-                                          "frac_of_hbm_peak": round(elems * 3 / ms / 1e6 / HBM_PEAK_GBS, 4), "launches": len(linears)}
+                                          "frac_of_hbm_peak": round(elems * 3 / ms / 1e6 / HBM_PEAK_GBS, 4), "launches": len(linears),
+                                          "what": "every weight quantizer's own forward: one A1 launch per linear"}
+    layers = [[l for l in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj, layer.self_attn.o_proj, layer.mlp.gate_proj,
+                           layer.mlp.up_proj, layer.mlp.down_proj)] for layer in model.layers]
+
+    def quantize_all_batched():
+        for group in layers:
+            ops.quantize_rows_batch([l.weight for l in group], [l.weight_quantizer.scale for l in group], [None] * len(group), 8)
+
+    ms = event_ms(quantize_all_batched, reps=5)
+    out["weight_quantize_all_linears_batched"] = {"ms": round(ms, 3), "elements": elems, "GB_per_s": round(elems * 3 / ms / 1e6, 1),
+                                                  "frac_of_hbm_peak": round(elems * 3 / ms / 1e6 / HBM_PEAK_GBS, 4), "launches": len(layers),
+                                                  "what": "ops.quantize_rows_batch: the seven weights of a decoder layer per launch (what llama.FusedForward runs each step)"}
     return out
 
 
