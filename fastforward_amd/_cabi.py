@@ -174,6 +174,8 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_grid_sqerror_by_tile": (_i, [_vp, _i, _vp, _vp, _i64, _tp, _d, _vp, _i, _vp, _sz, _vp]),
     "ffq_quantize_backward_workspace_bytes": (_sz, [_tp]),
     "ffq_quantize_by_tile_backward": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _i64, _tp, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ffq_mlp_gate_up_wq_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "ffq_mlp_gate_up_wq": (_i, [_vp, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ffq_mlp_gate_up_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "ffq_mlp_gate_up_w8a8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ffq_add_rmsnorm_quantize": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _d, _vp, _fp, _vp]),

@@ -34,6 +34,7 @@
 //     (ffq_linear_wq's `workspace`): the conversion then costs nothing per row tile; the B operand is that tensor by LDS-DMA.
 #include "ffq_common.h"
 #include "ffq_vec.h"
+#include "ffq_silu.h"
 
 #include <stdlib.h>
 
@@ -68,6 +69,10 @@ struct WLinearArgs {
   int per_row;            // 0: one parameter pair for the whole tensor
   int pack_shift;         // WL_B_I4: log2(packing block)
   int tiles_m, tiles_n, group_m;
+  // MLP mode (ffq_mlp_gate_up_wq): `w` / `w_scale` / `w_offset` describe gate_proj, these up_proj; N = rows of each = output columns
+  const uint8_t* w2;
+  const float* w_scale2;
+  const float* w_offset2;
 };
 
 // 4 codes in the bytes of `w` (signed bytes; for nibbles: 16 * code, see the header) -> 4 bf16 of (float(b) + c) * s
@@ -79,10 +84,15 @@ __device__ __forceinline__ void dequantize4(uint32_t w, float s, float c, uint32
   hi = pack2<bf16_t>(f2 * s, f3 * s);
 }
 
-template <int BKIND, bool GROUPED, bool OFFSET, typename TOut>
+// MLP: the B tile holds 128 gate_proj rows and the same 128 up_proj rows, interleaved in runs of 32 so that a wave's column tiles
+// nj = 0, 1 are gate and nj + 2 up of the SAME 32 output columns; the epilogue writes bf16(silu(bf16(gate))) * bf16(up) — exactly
+// what ffq_silu_mul_quantize makes of the two plain launches' bf16 outputs (reference quantized_llama/mlp.py:30-40) — as one
+// 256 x 128 bf16 tile: the two projections never visit HBM.
+template <int BKIND, bool GROUPED, bool OFFSET, typename TOut, bool MLP = false>
 __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr bool CODES = BKIND != WL_B_BF16;
+  constexpr int BN_OUT = MLP ? 128 : WL_BN;  // output columns (= rows of each weight matrix) per tile
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,6 +108,8 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
   const uint32_t xcd_count = tq + (xcd < tr ? 1u : 0u);
   const int my_tiles = j_in_xcd < xcd_count ? (int)((xcd_count - j_in_xcd + blocks_in_xcd - 1) / blocks_in_xcd) : 0;
   if (my_tiles == 0) return;
+  [[maybe_unused]] uint16_t* const silu_table = reinterpret_cast<uint16_t*>(lds + 2 * WL_SLOT);  // MLP: behind the two slots
+  if constexpr (MLP) silu_table_fill(silu_table, (uint32_t)tid, 512u);  // published by the first tile's barriers
   auto tile_origin = [&](int it, int& tm0, int& tn0) {
     it = it < my_tiles ? it : my_tiles - 1;  // streams running past the block's last tile re-read it (never used)
     const uint32_t tile_id = xcd_first + j_in_xcd + (uint32_t)it * blocks_in_xcd;
@@ -106,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
     const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
     const uint32_t group_rows = min(gm, (uint32_t)a.tiles_m - group * gm);
     tm0 = (int)(group * gm + in_group % group_rows) * WL_BM;
-    tn0 = (int)(in_group / group_rows) * WL_BN;
+    tn0 = (int)(in_group / group_rows) * BN_OUT;
   };
   // first byte of row `row0` of a matrix with `row_bytes` per row, kept in SGPRs (see ffq_linear.hip::row_base)
   auto row_base = [&](const uint8_t* base, int row0, uint32_t row_bytes) {
@@ -123,10 +135,9 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
   uint32_t a_voff[4];
   const uint8_t* a_base = a.x;
   [[maybe_unused]] uint32_t b_voff[4];          // WL_B_BF16: the B image by LDS-DMA, as A
-  [[maybe_unused]] const uint8_t* b_base = a.w;
+  [[maybe_unused]] const uint8_t* b_base[4] = {a.w, a.w, a.w, a.w};  // per piece (MLP: gate or up matrix)
   auto set_image_sources = [&](int tm0, int tn0) {
     a_base = row_base(a.x, tm0, x_row_bytes);
-    if constexpr (!CODES) b_base = row_base(a.w, tn0, w_row_bytes);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int row = (wave * 4 + c) * 8 + d_row;
@@ -134,8 +145,17 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
       const int ra = tm0 + row < a.M ? row : a.M - 1 - tm0;  // rows past the edge re-read the last row and are never stored
       a_voff[c] = (uint32_t)ra * x_row_bytes + d_slot * 16;
       if constexpr (!CODES) {
-        const int rb = tn0 + row < a.N ? row : a.N - 1 - tn0;
-        b_voff[c] = (uint32_t)rb * w_row_bytes + d_slot * 16;
+        if constexpr (MLP) {
+          // tile rows [64 q, 64 q + 32) are gate rows tn0 + 32 q + (0..31), the next 32 the same rows of up; row & 32 is the
+          // same for all lanes of a piece (8 rows per piece). N % 128 == 0: always inside
+          const int rb = (row >> 6) * 32 + (row & 31);
+          b_base[c] = row_base((((wave * 4 + c) * 8) & 32) ? a.w2 : a.w, tn0, w_row_bytes);
+          b_voff[c] = (uint32_t)rb * w_row_bytes + d_slot * 16;
+        } else {
+          const int rb = tn0 + row < a.N ? row : a.N - 1 - tn0;
+          b_base[c] = row_base(a.w, tn0, w_row_bytes);
+          b_voff[c] = (uint32_t)rb * w_row_bytes + d_slot * 16;
+        }
       }
     }
   };
@@ -153,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
 #pragma unroll
       for (int c = c0; c < c0 + 2; ++c) {
         asm volatile("" : "+v"(b_voff[c]));
-        __builtin_amdgcn_global_load_lds((wl_gbl_t*)((b_base + ks * 128) + b_voff[c]), (wl_lds_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((wl_gbl_t*)((b_base[c] + ks * 128) + b_voff[c]), (wl_lds_t*)(base + (wave * 4 + c) * 1024), 16, 0, 0);
       }
     }
   };
@@ -172,13 +192,16 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
   [[maybe_unused]] int grp = 0, grp_phase = 0;    // GROUPED: parameter group of the code stream's super-step, and the step inside it
   auto set_code_sources = [&](int tn0) {
     if constexpr (CODES) {
-      c_base = row_base(a.w, tn0, w_row_bytes);
+      // MLP: a wave's 32 tile rows are all gate rows (even waves) or all up rows (odd waves) of the tile's 128 output columns
+      const bool second = MLP && (wave & 1);
+      c_base = row_base(second ? a.w2 : a.w, tn0, w_row_bytes);
       const uint32_t param_row = a.per_row ? (uint32_t)a.groups : 0u;
-      ps_base = reinterpret_cast<const float*>(row_base(reinterpret_cast<const uint8_t*>(a.w_scale), tn0, param_row * 4u));
-      if constexpr (OFFSET) po_base = reinterpret_cast<const float*>(row_base(reinterpret_cast<const uint8_t*>(a.w_offset), tn0, param_row * 4u));
+      ps_base = reinterpret_cast<const float*>(row_base(reinterpret_cast<const uint8_t*>(second ? a.w_scale2 : a.w_scale), tn0, param_row * 4u));
+      if constexpr (OFFSET) po_base = reinterpret_cast<const float*>(row_base(reinterpret_cast<const uint8_t*>(second ? a.w_offset2 : a.w_offset), tn0, param_row * 4u));
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int row = wave * 32 + j * 16 + (lane >> 2);
+        const int trow = wave * 32 + j * 16 + (lane >> 2);
+        const int row = MLP ? (trow >> 6) * 32 + (trow & 31) : trow;
         const int rb = tn0 + row < a.N ? row : a.N - 1 - tn0;
         c_voff[j] = (uint32_t)rb * w_row_bytes;
         p_voff[j] = (uint32_t)rb * param_row * 4u;
@@ -412,27 +435,61 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
     __syncthreads();
     {
       TOut* out = static_cast<TOut*>(a.out);
-      constexpr int PITCH = 64 * (int)sizeof(TOut) + 16;
+      constexpr int COLS = MLP ? 32 : 64;                     // output columns per wave
+      constexpr int NJ = COLS / 16;                           // column tiles that leave the wave
+      constexpr int PITCH = COLS * (int)sizeof(TOut) + 16;
       constexpr int SLAB = sizeof(TOut) == 2 ? 32 : 16;       // rows per round: the eight waves' slabs share one 64 KiB slot
-      constexpr int WAVE_BYTES = SLAB * PITCH + 256;          // one slab + the wave's 64 bias values
+      constexpr int WAVE_BYTES = SLAB * PITCH + 256;          // one slab + the wave's bias values
       static_assert(8 * WAVE_BYTES <= WL_SLOT, "the epilogue scratch must fit the consumed slot");
       uint8_t* region = lds + (slot ^ 1) * WL_SLOT + wave * WAVE_BYTES;
       float* bias_lds = reinterpret_cast<float*>(region + SLAB * PITCH);
-      const int wave_n0 = n0 + wn * 64, wave_m0 = m0 + wm * 128;
-      const bool full = wave_n0 + 64 <= a.N && (a.N * (int)sizeof(TOut)) % 16 == 0;
-      const bool has_bias = a.bias != nullptr;
-      {
+      const int wave_n0 = n0 + wn * COLS, wave_m0 = m0 + wm * 128;
+      const bool full = wave_n0 + COLS <= a.N && (a.N * (int)sizeof(TOut)) % 16 == 0;
+      const bool has_bias = !MLP && a.bias != nullptr;
+      if (lane < COLS) {
         const int n = wave_n0 + lane;
         bias_lds[lane] = has_bias ? (float)load_any(a.bias, a.bias_dt, n < a.N ? n : a.N - 1) : 0.0f;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private: only this wave's own writes
+      if constexpr (MLP) {
+        // z = bf16(silu(bf16(gate))) * bf16(up), rounded to bf16: the accumulator tiles nj = 0, 1 take the product (as the float of
+        // that bf16 value), tiles 2, 3 (up) are spent. silu through the LDS table of ffq_silu.h (all 65536 bf16 patterns checked
+        // against ATen), the reads of a row tile issued back to back, one wave-uniform branch for values outside its window.
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          uint32_t wg[2][2], ws[2][2], bad = 0;
+#pragma unroll
+          for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              wg[nj][h] = pack2<bf16_t>(acc[mi][nj][2 * h], acc[mi][nj][2 * h + 1]);
+              ws[nj][h] = silu_pair_lookup(wg[nj][h], silu_table, bad);
+            }
+          if (__builtin_expect(silu_any_outside(bad), 0)) {
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+              for (int h = 0; h < 2; ++h) ws[nj][h] = silu_pair_patch(wg[nj][h], ws[nj][h]);
+          }
+#pragma unroll
+          for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint32_t wu = pack2<bf16_t>(acc[mi][nj + 2][2 * h], acc[mi][nj + 2][2 * h + 1]);
+              const float a0 = __builtin_bit_cast(float, ws[nj][h] << 16), a1 = __builtin_bit_cast(float, ws[nj][h] & 0xFFFF0000u);
+              const float u0 = __builtin_bit_cast(float, wu << 16), u1 = __builtin_bit_cast(float, wu & 0xFFFF0000u);
+              acc[mi][nj][2 * h] = a0 * u0;          // rounded to bf16 by the slab write below: one rounding, as the eager multiply
+              acc[mi][nj][2 * h + 1] = a1 * u1;
+            }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 128 / SLAB; ++i) {
 #pragma unroll
         for (int hh = 0; hh < SLAB / 16; ++hh) {
           const int mi = (SLAB / 16) * i + hh;
 #pragma unroll
-          for (int nj = 0; nj < 4; ++nj) {
+          for (int nj = 0; nj < NJ; ++nj) {
             const int nb = nj * 16 + 4 * g4;
             const wl_v4f b4 = *reinterpret_cast<const wl_v4f*>(bias_lds + nb);
             float y[4];
@@ -453,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (full) {
-          constexpr int SEGS = 64 * (int)sizeof(TOut) / 16;  // 16-byte segments per row: 8 (bf16) or 16 (f32)
+          constexpr int SEGS = COLS * (int)sizeof(TOut) / 16;  // 16-byte segments per row: 8 (bf16) / 16 (f32); 4 in MLP mode
 #pragma unroll
           for (int t = 0; t < SLAB * SEGS / 64; ++t) {
             const int c = lane + 64 * t;
@@ -464,8 +521,8 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
             if (mm < a.M) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * a.N + wave_n0) * sizeof(TOut) + seg * 16));
           }
         } else {  // ragged right edge / unaligned rows: element stores (correctness path)
-          for (int c = lane; c < SLAB * 64; c += 64) {
-            const int row = c >> 6, col = c & 63;
+          for (int c = lane; c < SLAB * COLS; c += 64) {
+            const int row = c / COLS, col = c % COLS;
             const int mm = wave_m0 + i * SLAB + row;
             if (mm < a.M && wave_n0 + col < a.N)
               out[(size_t)mm * a.N + wave_n0 + col] = *reinterpret_cast<const TOut*>(region + row * PITCH + col * sizeof(TOut));
@@ -505,22 +562,23 @@ extern "C" size_t ffq_linear_wq_workspace_bytes(int64_t M, int64_t N, int64_t K)
   return (size_t)N * (size_t)K * 2u;
 }
 
-template <int BKIND, bool GROUPED, bool OFFSET, typename TOut>
+template <int BKIND, bool GROUPED, bool OFFSET, typename TOut, bool MLP = false>
 static void wq_launch(const WLinearArgs& a, hipStream_t s) {
   const int total = a.tiles_m * a.tiles_n;
   const unsigned grid = (unsigned)(total < 256 ? total : 256);
-  const size_t lds_bytes = (size_t)2 * WL_SLOT;
+  const size_t lds_bytes = (size_t)2 * WL_SLOT + (MLP ? kSiluBytes : 0);
   static uint64_t attr_set = 0;
-  ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_gemm256_kernel<BKIND, GROUPED, OFFSET, TOut>), (int)lds_bytes);
-  wq_gemm256_kernel<BKIND, GROUPED, OFFSET, TOut><<<grid, 512, lds_bytes, s>>>(a, total);
+  ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_gemm256_kernel<BKIND, GROUPED, OFFSET, TOut, MLP>), (int)lds_bytes);
+  wq_gemm256_kernel<BKIND, GROUPED, OFFSET, TOut, MLP><<<grid, 512, lds_bytes, s>>>(a, total);
 }
 
-template <int BKIND>
+template <int BKIND, bool MLP = false>
 static void wq_dispatch(const WLinearArgs& a, bool grouped, bool offset, hipStream_t s) {
   if constexpr (BKIND == WL_B_BF16) {
-    if (a.out_dt == FFQ_BF16) wq_launch<BKIND, false, false, bf16_t>(a, s); else wq_launch<BKIND, false, false, float>(a, s);
+    if (MLP || a.out_dt == FFQ_BF16) wq_launch<BKIND, false, false, bf16_t, MLP>(a, s);
+    else if constexpr (!MLP) wq_launch<BKIND, false, false, float, false>(a, s);
   } else {
-#define FFQ_WL_T(G, O) do { if (a.out_dt == FFQ_BF16) wq_launch<BKIND, G, O, bf16_t>(a, s); else wq_launch<BKIND, G, O, float>(a, s); } while (0)
+#define FFQ_WL_T(G, O) do { if (MLP || a.out_dt == FFQ_BF16) wq_launch<BKIND, G, O, bf16_t, MLP>(a, s); else if constexpr (!MLP) wq_launch<BKIND, G, O, float, false>(a, s); } while (0)
     if (grouped) { if (offset) FFQ_WL_T(true, true); else FFQ_WL_T(true, false); }
     else { if (offset) FFQ_WL_T(false, true); else FFQ_WL_T(false, false); }
 #undef FFQ_WL_T
@@ -547,6 +605,7 @@ extern "C" int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w
   a.x = static_cast<const uint8_t*>(x);
   a.w = static_cast<const uint8_t*>(w_codes);
   a.w_scale = w_scale; a.w_offset = w_offset;
+  a.w2 = nullptr; a.w_scale2 = nullptr; a.w_offset2 = nullptr;
   a.bias = bias; a.bias_dt = bias_dt;
   a.out = out; a.out_dt = out_dt;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
@@ -586,4 +645,75 @@ extern "C" int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w
   if (w_dt == FFQ_U8) wq_dispatch<WL_B_I4>(a, grouped, offset, s);
   else wq_dispatch<WL_B_I8>(a, grouped, offset, s);
   return check_launch("wq_gemm256_kernel");
+}
+
+// ---- gate_proj + up_proj + SiLU * up of a weight-only quantized MLP in one launch ---------------------------------------------------
+// workspace of the two-pass form: the bf16 images of BOTH matrices
+extern "C" size_t ffq_mlp_gate_up_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M < WL_TWO_PASS_MIN_TOKENS || N <= 0 || K <= 0) return 0;
+  return (size_t)2 * (size_t)N * (size_t)K * 2u;
+}
+
+extern "C" int ffq_mlp_gate_up_wq(const void* x, int x_dt, const void* gate_codes, const void* up_codes, int w_dt, int64_t pack_block,
+                                  const float* gate_scale, const float* gate_offset, const float* up_scale, const float* up_offset,
+                                  int64_t scale_numel, int64_t group, void* out, int64_t M, int64_t N, int64_t K, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (M == 0 || N == 0) return FFQ_OK;
+  if (!x || !gate_codes || !up_codes || !gate_scale || !up_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if ((gate_offset == nullptr) != (up_offset == nullptr)) return fail(FFQ_ERR_ARG, "gate and up need offsets both or neither");
+  if (N % 128 != 0 || !ffq_linear_wq_supported(x_dt, w_dt, FFQ_BF16, M, N, K, group, pack_block))
+    return fail(FFQ_ERR_DTYPE, "fused weight-only gate/up: needs N %% 128 == 0 and what ffq_linear_wq needs");
+  if (!aligned16(x) || !aligned16(gate_codes) || !aligned16(up_codes) || !aligned16(out)) return fail(FFQ_ERR_DTYPE, "weight-only linear needs 16-byte aligned buffers");
+  const int64_t groups = K / group;
+  if (!(scale_numel == 1 || scale_numel == N * groups))
+    return fail(FFQ_ERR_PARAM_NUMEL, "weight-only linear: %lld parameters for %lld x %lld tiles", (long long)scale_numel, (long long)N, (long long)groups);
+  if (scale_numel == 1 && groups != 1) return fail(FFQ_ERR_PARAM_NUMEL, "one parameter pair needs group == K");
+
+  WLinearArgs a;
+  a.x = static_cast<const uint8_t*>(x);
+  a.w = static_cast<const uint8_t*>(gate_codes); a.w2 = static_cast<const uint8_t*>(up_codes);
+  a.w_scale = gate_scale; a.w_offset = gate_offset;
+  a.w_scale2 = up_scale; a.w_offset2 = up_offset;
+  a.bias = nullptr; a.bias_dt = 0;
+  a.out = out; a.out_dt = FFQ_BF16;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.groups = (int)groups;
+  a.steps_per_group = (int)(group / WL_BK);
+  a.per_row = scale_numel != 1;
+  a.pack_shift = 0;
+  for (int64_t b = pack_block; b > 1; b >>= 1) ++a.pack_shift;
+  a.tiles_m = (int)((M + WL_BM - 1) / WL_BM);
+  a.tiles_n = (int)(N / 128);
+  a.group_m = K >= 4096 ? 4 : WL_GROUP_M;
+  const bool grouped = groups > 1, offset = gate_offset != nullptr;
+
+  const size_t image_bytes = (size_t)N * (size_t)K * 2u;
+  if (M >= WL_TWO_PASS_MIN_TOKENS && workspace && workspace_bytes >= 2 * image_bytes && aligned16(workspace)) {
+    ffq_tiling t;
+    t.ndim = 2;
+    t.shape[0] = N; t.shape[1] = K;
+    t.tile[0] = scale_numel == 1 ? N : 1; t.tile[1] = scale_numel == 1 ? K : group;
+    uint8_t* image = static_cast<uint8_t*>(workspace);
+    int rc = FFQ_OK;
+    for (int which = 0; which < 2 && rc == FFQ_OK; ++which) {
+      const void* codes = which ? up_codes : gate_codes;
+      const float* sc = which ? up_scale : gate_scale;
+      const float* of = which ? up_offset : gate_offset;
+      if (w_dt == FFQ_U8)
+        rc = ffq_unpack_dequantize_int4(static_cast<const uint8_t*>(codes), sc, scale_numel, of, of ? scale_numel : 0, &t, pack_block, image + which * image_bytes, FFQ_BF16, stream);
+      else
+        rc = ffq_dequantize_by_tile(codes, FFQ_I8, sc, FFQ_F32, scale_numel, of, FFQ_F32, of ? scale_numel : 0, &t, image + which * image_bytes, FFQ_BF16, stream);
+    }
+    if (rc == FFQ_OK) {
+      a.w = image; a.w2 = image + image_bytes;
+      wq_dispatch<WL_B_BF16, true>(a, false, false, s);
+      return check_launch("wq_gemm256_kernel (mlp mode, bf16 images)");
+    }
+    if (rc != FFQ_ERR_DTYPE) return rc;
+  }
+  if (w_dt == FFQ_U8) wq_dispatch<WL_B_I4, true>(a, grouped, offset, s);
+  else wq_dispatch<WL_B_I8, true>(a, grouped, offset, s);
+  return check_launch("wq_gemm256_kernel (mlp mode)");
 }

@@ -211,6 +211,48 @@ def _one_pass(*tensors: torch.Tensor) -> bool:
             and not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors)) and _native.is_available())
 
 
+def _weight_only_gate_up(x: torch.Tensor, gate_proj: torch.nn.Module, up_proj: torch.nn.Module,
+                         stored: tuple[tuple[torch.Tensor, int], tuple[torch.Tensor, int]] | None = None) -> torch.Tensor | None:
+    """``silu(gate_proj(x)) * up_proj(x)`` of a WEIGHT-ONLY quantized MLP (plain bf16 `x`, quantized weights: BASELINE configs 2
+    and 4) as one launch of the weight-code GEMM with the SiLU * up epilogue (ops.mlp_gate_up_wq) — the value
+    ``silu_mul_quantize(gate_proj(x), up_proj(x))`` has when both projections go through the dispatcher's weight-only kernel,
+    bit for bit. None whenever that is not the situation (any set activation quantizer, a bias, parameters the kernel does not
+    cover, fewer tokens than the dispatcher's weight-only threshold): the caller then runs the two module forwards.
+    `stored`: (codes, packing block) of the two weights when the caller keeps them; else each weight quantizer runs here, as
+    QuantizedLinear.forward would run it (reference nn/linear.py:34)."""
+    from fastforward_amd import fused_linear
+    from fastforward_amd.nn import QuantizedLinear
+
+    kernels = fused_linear.KERNELS
+    if not _one_pass(x) or not x.is_contiguous():
+        return None
+    for lin in (gate_proj, up_proj):
+        if (not isinstance(lin, QuantizedLinear) or lin.bias is not None or lin.weight_quantizer.is_stub()
+                or not _untouched(lin.input_quantizer, lin.output_quantizer)):
+            return None
+    tokens = x.numel() // x.shape[-1]
+    if not fused_linear._WEIGHT_ONLY_KERNEL or tokens < fused_linear._WEIGHT_ONLY_MIN_TOKENS:
+        return None
+    if stored is not None:
+        gq, uq = gate_proj.weight_quantizer, up_proj.weight_quantizer
+        group = kernels.weight_group(_Shaped(gate_proj.weight, gq))
+        if group is None or group != kernels.weight_group(_Shaped(up_proj.weight, uq)) or stored[0][1] != stored[1][1]:
+            return None
+        return ff.ops.mlp_gate_up_wq(x, stored[0][0], stored[1][0], gq.scale, gq.offset, uq.scale, uq.offset, group=group, pack_block=stored[0][1])
+    gw, uw = gate_proj.weight_quantizer(gate_proj.weight), up_proj.weight_quantizer(up_proj.weight)
+    product = None
+    if kernels.supported_weight_only(x, gw) and kernels.supported_weight_only(x, uw) and kernels.weight_group(gw) == kernels.weight_group(uw):
+        (gs, go), (us, uo) = kernels._scale_offset(gw), kernels._scale_offset(uw)
+        product = ff.ops.mlp_gate_up_wq(x, kernels._int8_codes(gw), kernels._int8_codes(uw), gs, go, us, uo, group=kernels.weight_group(gw))
+    if product is None:  # the weights are quantized already: finish the two linears as QuantizedLinear.forward would
+        gate = ff.nn.functional.linear(x, gw, None, output_quantizer=gate_proj.output_quantizer)
+        up = ff.nn.functional.linear(x, uw, None, output_quantizer=up_proj.output_quantizer)
+        if not (_one_pass(gate, up) and gate.shape == up.shape):
+            return F.silu(gate) * up
+        product = ff.ops.silu_mul_quantize(gate, up, (), want_product=True)[0]
+    return product
+
+
 class QuantizedLlamaRMSNorm(QuantizedModule, LlamaRMSNorm):
     """Float under strict_quantization(False), like reference rms_norm.py:17-35."""
 
@@ -280,6 +322,9 @@ class QuantizedLlamaMLP(QuantizedModule, LlamaMLP):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = self.input_quantizer(x)
         if _untouched(self.gate_act_quantizer, self.gated_up_proj_output_quantizer):
+            product = _weight_only_gate_up(x, self.gate_proj, self.up_proj) if type(x) is torch.Tensor else None
+            if product is not None:
+                return self.down_proj(product)
             gate, up = self.gate_proj(x), self.up_proj(x)
             if _one_pass(gate, up) and gate.shape == up.shape:
                 return self.down_proj(ff.ops.silu_mul_quantize(gate, up, (), want_product=True)[0])  # silu(gate) * up, one pass
@@ -821,6 +866,21 @@ class FusedProducersForward:
         w_offset = None if wp.offset is None or ff.fused_linear.known_zero_offset(wp.offset) else wp.offset
         return ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, None, out_dtype=torch.bfloat16)
 
+    def _gate_up(self, normed: torch.Tensor, mlp: torch.nn.Module) -> torch.Tensor:
+        """silu(gate_proj(x)) * up_proj(x): one launch for a weight-only MLP the GEMM covers, else the two linears + SiLU * up."""
+        gate_proj, up_proj = mlp.gate_proj, mlp.up_proj
+        if gate_proj.input_quantizer.is_stub() and up_proj.input_quantizer.is_stub():
+            stored = None
+            if self.weight_storage != "requantize":
+                both = (self._stored_weight(gate_proj), self._stored_weight(up_proj))
+                stored = both if both[0] is not None and both[1] is not None else None
+            if stored is not None or self.weight_storage == "requantize":
+                product = _weight_only_gate_up(normed, gate_proj, up_proj, stored)
+                if product is not None:
+                    return product
+        gate, up = self._linear(normed, gate_proj), self._linear(normed, up_proj)
+        return ff.ops.silu_mul_quantize(gate, up, (), want_product=True)[0]
+
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, logits: bool = False) -> torch.Tensor:
         model, cfg = self.model, self.model.config
@@ -842,8 +902,7 @@ class FusedProducersForward:
                     ctx = _sdpa(q, k, v, cfg, b, s)
                 attn_out = self._linear(ctx, attn.o_proj)
                 hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, attn_out, ln2.weight, ln2.variance_epsilon, (), want_norm=True, sum_inplace=True)
-                gate, up = self._linear(normed, mlp.gate_proj), self._linear(normed, mlp.up_proj)
-                product, _ = ff.ops.silu_mul_quantize(gate, up, (), want_product=True)
+                product = self._gate_up(normed, mlp)
                 pending = self._linear(product, mlp.down_proj)
             _, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, model.norm.weight, model.norm.variance_epsilon, (), want_sum=False, want_norm=True)
             return model.lm_head(normed) if logits else normed

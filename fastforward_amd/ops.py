@@ -696,6 +696,58 @@ def linear_wq(
     return out
 
 
+def mlp_gate_up_wq(
+    x: torch.Tensor,
+    gate_codes: torch.Tensor,
+    up_codes: torch.Tensor,
+    gate_scale: torch.Tensor,
+    gate_offset: torch.Tensor | None,
+    up_scale: torch.Tensor,
+    up_offset: torch.Tensor | None,
+    group: int | None = None,
+    pack_block: int = 0,
+    two_pass: bool | None = None,
+) -> torch.Tensor | None:
+    """``silu(gate_proj(x)) * up_proj(x)`` of a weight-only quantized MLP (reference quantized_llama/mlp.py:30-40 over
+    _gen/fallback.py:86-112) in one launch: bit for bit ``silu_mul_quantize(linear_wq(x, gate), linear_wq(x, up), want_product=True)``
+    without the two bf16 projections in HBM. Operands as :func:`linear_wq` (both weights in the same form); bf16 only.
+    None when the kernel does not cover the problem."""
+    K = x.shape[-1]
+    if pack_block > 0:
+        if gate_codes.dtype != torch.uint8 or K == 0 or (gate_codes.numel() * 2) % K:
+            raise RuntimeError("packed weights are the uint8 output of pack_int4 for an [N, K] weight")
+        N = gate_codes.numel() * 2 // K
+    else:
+        if gate_codes.dim() != 2 or gate_codes.shape[1] != K:
+            raise RuntimeError("mlp_gate_up_wq expects [N, K] weights")
+        N = gate_codes.shape[0]
+    if gate_codes.shape != up_codes.shape or gate_codes.dtype != up_codes.dtype:
+        raise RuntimeError("gate and up weights differ in shape or dtype")
+    group = K if group is None else int(group)
+    if x.dtype != torch.bfloat16 or gate_codes.dtype not in _TAGS or N % 128 or (gate_offset is None) != (up_offset is None):
+        return None
+    M = x.numel() // K if K else 0
+    lib = _native.library()
+    if not lib.ffq_linear_wq_supported(_tag(x.dtype), _tag(gate_codes.dtype), _tag(torch.bfloat16), M, N, K, group, int(pack_block)):
+        return None
+    xc, gc, uc = x.detach().contiguous(), gate_codes.detach().contiguous(), up_codes.detach().contiguous()
+    flat = lambda t: None if t is None else t.detach().reshape(-1).to(torch.float32).contiguous()  # noqa: E731
+    gs, go, us, uo = flat(gate_scale), flat(gate_offset), flat(up_scale), flat(up_offset)
+    if gs.numel() != us.numel() or (go is not None and (go.numel() != gs.numel() or uo.numel() != gs.numel())):
+        raise RuntimeError("gate and up parameters differ in count")
+    lib, stream = _prepare(xc, gc, uc, gs, go, us, uo)
+    out = torch.empty((*xc.shape[:-1], N), dtype=torch.bfloat16, device=xc.device)
+    nbytes = 0 if two_pass is False else (2 * N * K * 2 if two_pass else lib.ffq_mlp_gate_up_wq_workspace_bytes(M, N, K))
+    ws = _workspace(nbytes, xc.device)
+    lib.check(
+        lib.ffq_mlp_gate_up_wq(
+            _ptr(xc), _tag(xc.dtype), _ptr(gc), _ptr(uc), _tag(gc.dtype), int(pack_block), _ptr(gs), _ptr(go), _ptr(us), _ptr(uo),
+            gs.numel(), group, _ptr(out), M, N, K, _ptr(ws), nbytes, stream,
+        )
+    )
+    return out
+
+
 def mlp_gate_up_w8a8(
     x_codes: torch.Tensor,
     gate_codes: torch.Tensor,

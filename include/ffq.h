@@ -223,6 +223,21 @@ int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, int64_
                   int out_dt, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The MLP front half of a WEIGHT-ONLY quantized Llama (docs/examples/doc_helpers/quantized_llama/mlp.py:30-40 with plain bf16
+ * activations: BASELINE configs 2 and 4) in one launch: gate_proj and up_proj as ffq_linear_wq computes them (same operands, same
+ * summation order), then bf16(silu(bf16(gate))) * bf16(up) rounded to bf16 —
+ *   out == product of ffq_silu_mul_quantize(ffq_linear_wq(x, gate), ffq_linear_wq(x, up))    bit for bit,
+ * without the two [M, N] bf16 projections ever visiting HBM. Both weights share dtype, packing, granularity (`scale_numel`,
+ * `group`); offsets both or neither; N % 128 == 0; otherwise as ffq_linear_wq. `out` is [M, N] bf16. With a workspace of
+ * ffq_mlp_gate_up_wq_workspace_bytes() (both bf16 images) the two-pass form runs from 4096 tokens on.
+ */
+size_t ffq_mlp_gate_up_wq_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int ffq_mlp_gate_up_wq(const void* x, int x_dt, const void* gate_codes, const void* up_codes, int w_dt, int64_t pack_block,
+                       const float* gate_scale, const float* gate_offset, const float* up_scale, const float* up_offset,
+                       int64_t scale_numel, int64_t group, void* out, int64_t M, int64_t N, int64_t K, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/*
  * Producer-fused A1 (ABI version 2). In the reference's quantized Llama helpers
  * (docs/examples/doc_helpers/quantized_llama/) every quantized linear quantizes its own input
  * (nn/linear.py:33), and those inputs leave three elementwise producers that run as eager ATen

@@ -1229,3 +1229,31 @@ int ffq_quantize_rows_batch(const ffq_rows_batch* batch, int data_dt, void* stre
   }
   return FFQ_OK;
 }
+
+/*
+ * mlp.py:30-40 on a weight-only quantized model: down_proj's argument act_fn(gate_proj(x)) * up_proj(x), the two
+ * projections being fallback.linear with a quantized weight (_gen/fallback.py:86-112) in bf16 — restated as exactly that
+ * composition of the functions above.
+ */
+size_t ffq_mlp_gate_up_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) { (void)M; (void)N; (void)K; return 0; }
+
+int ffq_mlp_gate_up_wq(const void* x, int x_dt, const void* gate_codes, const void* up_codes, int w_dt, int64_t pack_block,
+                       const float* gate_scale, const float* gate_offset, const float* up_scale, const float* up_offset,
+                       int64_t scale_numel, int64_t group, void* out, int64_t M, int64_t N, int64_t K, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes;
+  if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (M == 0 || N == 0) return FFQ_OK;
+  if (!x || !gate_codes || !up_codes || !gate_scale || !up_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if ((gate_offset == NULL) != (up_offset == NULL)) return fail(FFQ_ERR_ARG, "gate and up need offsets both or neither");
+  if (N % 128 != 0) return fail(FFQ_ERR_DTYPE, "fused weight-only gate/up: needs N %% 128 == 0");
+  size_t bytes = (size_t)M * (size_t)N * 2u;
+  void* g = malloc(bytes);
+  void* u = malloc(bytes);
+  if (!g || !u) { free(g); free(u); return fail(FFQ_ERR_ARG, "out of memory"); }
+  int rc = ffq_linear_wq(x, x_dt, gate_codes, w_dt, pack_block, gate_scale, gate_offset, scale_numel, group, NULL, 0, g, FFQ_BF16, M, N, K, NULL, 0, stream);
+  if (rc == FFQ_OK) rc = ffq_linear_wq(x, x_dt, up_codes, w_dt, pack_block, up_scale, up_offset, scale_numel, group, NULL, 0, u, FFQ_BF16, M, N, K, NULL, 0, stream);
+  if (rc == FFQ_OK) rc = ffq_silu_mul_quantize(g, u, FFQ_BF16, M * N, out, NULL, stream);
+  free(g); free(u);
+  return rc;
+}

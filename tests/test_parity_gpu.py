@@ -785,6 +785,56 @@ def test_weight_only_linear_matches_float64_of_the_same_operands(m, n, k, group,
         assert torch.equal(y, first), f"{label} differs from the int8-container form"
 
 
+@pytest.mark.parametrize("m,n,k,group,bits,offset", [(1, 128, 128, 128, 8, False), (300, 256, 512, 512, 8, False), (257, 640, 1024, 128, 4, True),
+                                                     (4100, 1152, 1024, 1024, 8, True), (4200, 384, 640, 128, 4, False), (2050, 2304, 192, 64, 4, True)])
+def test_weight_only_gate_up_launch_is_the_two_linears_and_silu_mul(m, n, k, group, bits, offset):
+    """ops.mlp_gate_up_wq == silu_mul_quantize(linear_wq(x, gate), linear_wq(x, up)) bit for bit (reference mlp.py:30-40 over
+    fallback.py:86-112), for every storage form of the weights, ragged M, one- and two-pass: the projections are the same
+    accumulators in the same order, the epilogue the same SiLU (table == ATen on all bf16 patterns) and the same roundings."""
+    gc, gs, go = _wq_case(n, k, group, bits, offset, seed=m + n)
+    uc, us, uo = _wq_case(n, k, group, bits, offset, seed=m + n + 1)
+    gen = torch.Generator().manual_seed(m + k)
+    x = (torch.randn(m, k, generator=gen) * 1.5).to(torch.bfloat16).to(DEV)
+    x[0, :] *= 40.0  # gate values outside the table's window on one row: the patch path
+    gate = ops.linear_wq(x, gc, gs, go, group=group, two_pass=False)
+    up = ops.linear_wq(x, uc, us, uo, group=group, two_pass=False)
+    want, _ = ops.silu_mul_quantize(gate, up, (), want_product=True)
+    assert float(want.float().abs().max()) > 0
+    for (label, kwargs, gw), (_, _, uw) in zip(_wq_forms(gc, group, bits, m), _wq_forms(uc, group, bits, m)):
+        got = ops.mlp_gate_up_wq(x, gw, uw, gs, go, us, uo, group=group, **kwargs)
+        assert got is not None and got.dtype == torch.bfloat16 and got.shape == (m, n), label
+        assert torch.equal(got, want), label + ": " + mismatch_report(got.cpu(), want.cpu())
+    # default policy (library decides about the two passes) agrees as well
+    assert torch.equal(ops.mlp_gate_up_wq(x, gc, uc, gs, go, us, uo, group=group), want)
+    # not covered: N % 128 != 0, fp32 activations
+    assert ops.mlp_gate_up_wq(x, gc[:64], uc[:64], gs[: 64 * (k // group)], None if go is None else go[: 64 * (k // group)], us[: 64 * (k // group)],
+                              None if uo is None else uo[: 64 * (k // group)], group=group) is None
+    assert ops.mlp_gate_up_wq(x.float(), gc, uc, gs, go, us, uo, group=group) is None
+
+
+def test_weight_only_gate_up_against_the_oracle_composition(oracle_lib):
+    """The C restatement (two ffq_linear_wq in double + its silu_mul) on a small case: products within one bf16 rounding of the
+    exact projections' product wherever the projections themselves agree after rounding."""
+    from fastforward_amd import _cabi
+    import ctypes
+
+    m, n, k, group = 48, 128, 256, 128
+    gc, gs, go = _wq_case(n, k, group, 4, True, seed=5)
+    uc, us, uo = _wq_case(n, k, group, 4, True, seed=6)
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(9)).to(torch.bfloat16)
+    got = ops.mlp_gate_up_wq(x.to(DEV), gc, uc, gs, go, us, uo, group=group).cpu()
+    lib = oracle_lib
+    out = torch.empty(m, n, dtype=torch.bfloat16)
+    host = [t.cpu().contiguous() for t in (gc, uc, gs, go, us, uo)]
+    rc = lib.ffq_mlp_gate_up_wq(x.data_ptr(), _cabi.FFQ_BF16, host[0].data_ptr(), host[1].data_ptr(), _cabi.FFQ_I8, 0, host[2].data_ptr(), host[3].data_ptr(),
+                                host[4].data_ptr(), host[5].data_ptr(), host[2].numel(), group, out.data_ptr(), m, n, k, None, 0, None)
+    assert rc == 0
+    # the GEMM accumulates in fp32 in its own order: a projection may land on the neighbouring bf16 -> compare loosely, and
+    # exactly where the HIP projections equal the oracle's
+    torch.testing.assert_close(got.float(), out.float(), rtol=2.0**-6, atol=2.0**-6 * float(out.float().abs().max()))
+    assert (got == out).float().mean() > 0.9
+
+
 def test_weight_only_linear_refuses_what_it_does_not_cover():
     codes, scale, off = _wq_case(64, 192, 96, 4, False, seed=1)  # groups of 96: not a multiple of 64
     x = torch.randn(8, 192, device=DEV, dtype=torch.bfloat16)

@@ -52,4 +52,27 @@ for name, n, k, cnt in (("qo", 4096, 4096, 2), ("kv", 1024, 4096, 2), ("gateup",
     for key, v in ms.items():
         tot[key] = tot.get(key, 0.0) + cnt * v
     flops += cnt * f
+# the MLP front half: two launches + SiLU * up against the one-launch form (ops.mlp_gate_up_wq), same weights
+n, k = 14336, 4096
+x = torch.randn(T, k, device=dev, dtype=torch.bfloat16)
+pair = []
+for i in range(2):
+    w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
+    lo, hi = ops.minmax_by_tile(w, (1, k))
+    s8, _ = ops.parameters_for_range(lo, hi, 8, True, False, want_offset=False)
+    pair.append((ops.quantize_by_tile(w, s8, (1, k), 8, torch.int8), s8, w))
+(gc, gs, gw), (uc, us, uw) = pair
+del pair
+mlp = {
+    "2 x linear_wq + silu_mul": lambda r: ops.silu_mul_quantize(ops.linear_wq(x, gc, gs, None), ops.linear_wq(x, uc, us, None), (), want_product=True),
+    "mlp_gate_up_wq one-pass": lambda r: ops.mlp_gate_up_wq(x, gc, uc, gs, None, us, None, two_pass=False),
+    "mlp_gate_up_wq": lambda r: ops.mlp_gate_up_wq(x, gc, uc, gs, None, us, None),
+    "2 x (A2 + vendor) + silu_mul": lambda r: ops.silu_mul_quantize(torch.nn.functional.linear(x, ops.dequantize_by_tile(gc, gs, (1, k), None, torch.bfloat16)),
+                                                                  torch.nn.functional.linear(x, ops.dequantize_by_tile(uc, us, (1, k), None, torch.bfloat16)), (), want_product=True),
+}
+if check:
+    assert torch.equal(mlp["mlp_gate_up_wq"](0), mlp["2 x linear_wq + silu_mul"](0)[0]) and torch.equal(mlp["mlp_gate_up_wq one-pass"](0), mlp["mlp_gate_up_wq"](0))
+    print("  check mlp_gate_up_wq == silu_mul(linear_wq, linear_wq): ok")
+f = 2.0 * T * 2 * n * k
+print("gate+up+silu*up (w8): " + "  ".join(f"{key} {v:.4f} ms {f / v / 1e9:6.0f} TF |" for key, v in ((key, event_time_ms(fn, iters=5, reps=4)) for key, fn in mlp.items())))
 print(f"layer mix at T = {T}: " + "  ".join(f"{key} {flops / v / 1e9:.0f} TFLOP/s ({v:.3f} ms) |" for key, v in tot.items()))
