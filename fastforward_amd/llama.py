@@ -850,9 +850,18 @@ class FusedProducersForward:
             if stored is not None:
                 wq = linear.weight_quantizer
                 group = ff.fused_linear.KERNELS.weight_group(_Shaped(linear.weight, wq))
-                out = ff.ops.linear_wq(x, stored[0], wq.scale, wq.offset, group=group, pack_block=stored[1], out_dtype=x.dtype)
-                if out is not None:
-                    return out
+                if x.numel() // x.shape[-1] >= ff.fused_linear._WEIGHT_ONLY_MIN_TOKENS:
+                    out = ff.ops.linear_wq(x, stored[0], wq.scale, wq.offset, group=group, pack_block=stored[1], out_dtype=x.dtype)
+                    if out is not None:
+                        return out
+                # below the dispatcher's weight-only threshold (fused_linear.weight_only_kernel: 256 x 256 tiles leave most of
+                # the chip idle there): the reference's own route from the stored codes — A2 (or unpack + A2), float GEMM
+                tile = (1, group)
+                if stored[1]:
+                    weight = ff.ops.unpack_dequantize_int4(stored[0], wq.scale, linear.weight.shape, tile, wq.offset, block=stored[1], output_dtype=x.dtype)
+                else:
+                    weight = ff.ops.dequantize_by_tile(stored[0], wq.scale, tile, wq.offset, x.dtype)
+                return F.linear(x, weight)
             return linear(x)
         xq = linear.input_quantizer(x)
         wq = linear.weight_quantizer(linear.weight)

@@ -226,6 +226,45 @@ def test_producers_forward_weight_only_on_gpu(hip_backend):
     check_producers_forward_weight_only(golden("g7_tiny_llama.pt"), "cuda")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("w_bits,block", [(8, None), (4, 128)])
+def test_weight_only_storage_forms_agree_bit_for_bit(hip_backend, w_bits, block):
+    """BASELINE configs 2 / 4 on a small Llama: the weight quantizer on every call ("requantize"), kept int8 codes, kept
+    packed nibbles — below the dispatcher's token threshold (A2 + float GEMM on every route) and above it (the weight-code
+    GEMM with its one-launch gate/up/SiLU mode on every route) — produce the SAME logits: one set of codes, one dequantized
+    weight, one summation order per route. The module graph agrees as well (its MLP takes the same one-launch mode)."""
+    cfg = llama.LlamaConfig.tiny()
+    model = llama.build_model(cfg, "cuda", torch.bfloat16, seed=5, std=0.05)
+    llama.quantize_llama(model, w_bits=w_bits, a_bits=None, quantized_dtype=torch.int8,
+                         weight_granularity=None if block is None else ff.PerBlock(1, block, 0))
+    ids = torch.randint(0, cfg.vocab_size, (2, 96), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    llama.calibrate(model, [ids])
+    launches = []
+    real = ff.ops.mlp_gate_up_wq
+
+    def counted(*a, **k):
+        out = real(*a, **k)
+        launches.append(out is not None)
+        return out
+
+    for min_tokens in (1 << 30, 0):
+        with ff.fused_linear.weight_only_kernel(True, min_tokens=min_tokens), torch.no_grad(), ff.strict_quantization(False):
+            ff.ops.mlp_gate_up_wq = counted
+            try:
+                launches.clear()
+                want = llama.FusedProducersForward(model)(ids, logits=True)
+                assert (len(launches) == cfg.num_layers and all(launches)) if min_tokens == 0 else not launches
+                forms = ["codes"] + (["packed"] if w_bits == 4 else [])
+                for form in forms:
+                    got = llama.FusedProducersForward(model, weight_storage=form)(ids, logits=True)
+                    assert torch.equal(got, want), (form, min_tokens, float((got.float() - want.float()).abs().max()))
+                module = model(ids, logits=True)
+            finally:
+                ff.ops.mlp_gate_up_wq = real
+        # the module graph adds the residual before the next RMSNorm in its own order: same linears, close logits
+        torch.testing.assert_close(module.float(), want.float(), rtol=0, atol=0.02 * float(want.float().std()) + 1e-3)
+
+
 def check_fused_calibration(fixture, device):
     """Calibrating through FusedCalibrationForward (every quantizer's own forward with its estimator override, fused
     producers in between) gives the module graph's ranges: weight quantizers exactly, activation ranges within the

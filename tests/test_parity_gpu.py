@@ -826,7 +826,7 @@ def test_weight_only_gate_up_against_the_oracle_composition(oracle_lib):
     lib = oracle_lib
     out = torch.empty(m, n, dtype=torch.bfloat16)
     host = [t.cpu().contiguous() for t in (gc, uc, gs, go, us, uo)]
-    rc = lib.ffq_mlp_gate_up_wq(x.data_ptr(), _cabi.FFQ_BF16, host[0].data_ptr(), host[1].data_ptr(), _cabi.FFQ_I8, 0, host[2].data_ptr(), host[3].data_ptr(),
+    rc = lib.ffq_mlp_gate_up_wq(x.data_ptr(), int(_cabi.DType.BF16), host[0].data_ptr(), host[1].data_ptr(), int(_cabi.DType.I8), 0, host[2].data_ptr(), host[3].data_ptr(),
                                 host[4].data_ptr(), host[5].data_ptr(), host[2].numel(), group, out.data_ptr(), m, n, k, None, 0, None)
     assert rc == 0
     # the GEMM accumulates in fp32 in its own order: a projection may land on the neighbouring bf16 -> compare loosely, and
