@@ -253,6 +253,47 @@ def _weight_only_gate_up(x: torch.Tensor, gate_proj: torch.nn.Module, up_proj: t
     return product
 
 
+def _w8a8_gate_up_down_input(x: torch.Tensor, gate_proj: torch.nn.Module, up_proj: torch.nn.Module, down_proj: torch.nn.Module):
+    """The input of ``down_proj``'s GEMM on a W8A8 model — ``down_proj.input_quantizer(silu(gate_proj(x)) * up_proj(x))`` — from ONE
+    launch of the int8 GEMM's gate/up mode (ops.mlp_gate_up_w8a8: both projections, SiLU * up and A1 in its epilogue; equal to the
+    module-by-module result bit for bit, tests/test_fullsize_gpu.py), when every quantizer involved is a plain static one:
+    per-tensor 8-bit int8 input quantizers on gate / up that produced the SAME codes (the activation-code memo served the second
+    from the first), per-output-channel symmetric int8 weights, a fusable input quantizer on down_proj
+    (DispatcherKernels._requant's rule: initialised, per tensor, no override, fp32 parameters, not exporting).
+    Returns (QuantizedTensor for down_proj's GEMM, None) on success, else (None, (gate, up)) with the two projections finished
+    the ordinary way from the quantized operands already produced (nothing runs twice) — or (None, None) when the situation
+    is not even close (the caller runs the module forwards)."""
+    from fastforward_amd import fused_linear
+    from fastforward_amd.nn import QuantizedLinear
+
+    kernels = fused_linear.KERNELS
+    if not _one_pass(x) or not x.is_contiguous():
+        return None, None
+    for lin in (gate_proj, up_proj, down_proj):
+        if not isinstance(lin, QuantizedLinear) or lin.bias is not None or lin.weight_quantizer.is_stub() or lin.input_quantizer.is_stub():
+            return None, None
+    if not _untouched(gate_proj.output_quantizer, up_proj.output_quantizer):
+        return None, None
+    fused = kernels._requant(down_proj.input_quantizer, x.dtype)
+    if fused is None or fused["out_dtype"] != torch.int8:
+        return None, None
+    xg, xu = gate_proj.input_quantizer(x), up_proj.input_quantizer(x)
+    gw, uw = gate_proj.weight_quantizer(gate_proj.weight), up_proj.weight_quantizer(up_proj.weight)
+    codes = None
+    if (kernels.supported_linear(xg, gw) and kernels.supported_linear(xu, uw) and kernels.row_mode(xg) == "tensor"
+            and kernels.row_mode(gw) == "row" and kernels.row_mode(uw) == "row"
+            and xg.raw_data.dtype == torch.int8 and gw.raw_data.dtype == torch.int8 and uw.raw_data.dtype == torch.int8
+            and xu.raw_data.data_ptr() == xg.raw_data.data_ptr() and xu.raw_data.shape == xg.raw_data.shape and xu.raw_data.dtype == xg.raw_data.dtype):
+        (xs, xo), (gs, go), (us, uo) = kernels._scale_offset(xg), kernels._scale_offset(gw), kernels._scale_offset(uw)
+        if go is None and uo is None and kernels._deq_dtype(xg) == x.dtype:
+            codes = ff.ops.mlp_gate_up_w8a8(xg.raw_data, gw.raw_data, uw.raw_data, xs, xo, gs, us, fused["out_scale"], fused["out_offset"], fused["out_num_bits"])
+    if codes is not None:
+        return kernels._wrap(None, codes, down_proj.input_quantizer, x.dtype), None
+    gate = ff.nn.functional.linear(xg, gw, None, output_quantizer=gate_proj.output_quantizer)
+    up = ff.nn.functional.linear(xu, uw, None, output_quantizer=up_proj.output_quantizer)
+    return None, (gate, up)
+
+
 class QuantizedLlamaRMSNorm(QuantizedModule, LlamaRMSNorm):
     """Float under strict_quantization(False), like reference rms_norm.py:17-35."""
 
@@ -289,10 +330,34 @@ class QuantizedLlamaAttention(QuantizedModule, LlamaAttention):
             if _one_pass(q, k, v, cos, sin) and cos.dim() == 2 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous():
                 # rotary embedding in place on the projections, then softmax(q k^T) v as one flash-style launch
                 ff.ops.rope_(q, k, cos, sin, cfg.head_dim)
-                ctx, _ = ff.ops.attention(q, k, v, cfg.head_dim, causal=hidden_states.shape[1] > 1)
-                return self.o_proj(ctx)
+                causal = hidden_states.shape[1] > 1
+                o_proj = self.o_proj
+                fused = self._o_proj_input_in_epilogue(q.dtype)
+                if fused is not None:
+                    # o_proj's input quantizer (nn/linear.py:33) as the attention launch's epilogue: its codes == A1 of the
+                    # bf16 context the launch would have written (tested), which never visits HBM
+                    from fastforward_amd import fused_linear
+
+                    _, codes = ff.ops.attention(q, k, v, cfg.head_dim, causal=causal, quantizer=(fused["out_scale"], fused["out_offset"]),
+                                                num_bits=fused["out_num_bits"], want_context=False)
+                    quantized = fused_linear.KERNELS._wrap(None, codes, o_proj.input_quantizer, q.dtype)
+                    return ff.nn.functional.linear(quantized, o_proj.weight_quantizer(o_proj.weight), None, output_quantizer=o_proj.output_quantizer)
+                ctx, _ = ff.ops.attention(q, k, v, cfg.head_dim, causal=causal)
+                return o_proj(ctx)
             return self._attend(q, k, v, cos, sin)
         return LlamaAttention.forward(self, hidden_states, cos, sin)
+
+    def _o_proj_input_in_epilogue(self, dtype: torch.dtype) -> dict | None:
+        """Parameters of o_proj's input quantizer when the attention launch can apply it (a plain static per-tensor 8-bit int8
+        LinearQuantizer without overrides: DispatcherKernels._requant's rule; o_proj an ordinary QuantizedLinear without bias)."""
+        from fastforward_amd import fused_linear
+        from fastforward_amd.nn import QuantizedLinear
+
+        o_proj = self.o_proj
+        if not isinstance(o_proj, QuantizedLinear) or o_proj.bias is not None or o_proj.weight_quantizer.is_stub() or o_proj.input_quantizer.is_stub():
+            return None
+        fused = fused_linear.KERNELS._requant(o_proj.input_quantizer, dtype)
+        return fused if fused is not None and fused["out_dtype"] == torch.int8 else None
 
     def _attend(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
         """The rest of LlamaAttention.forward for projections that are already computed."""
@@ -325,7 +390,11 @@ class QuantizedLlamaMLP(QuantizedModule, LlamaMLP):
             product = _weight_only_gate_up(x, self.gate_proj, self.up_proj) if type(x) is torch.Tensor else None
             if product is not None:
                 return self.down_proj(product)
-            gate, up = self.gate_proj(x), self.up_proj(x)
+            quantized, parts = _w8a8_gate_up_down_input(x, self.gate_proj, self.up_proj, self.down_proj) if type(x) is torch.Tensor else (None, None)
+            if quantized is not None:  # down_proj's GEMM on the codes its input quantizer would have produced
+                down = self.down_proj
+                return ff.nn.functional.linear(quantized, down.weight_quantizer(down.weight), None, output_quantizer=down.output_quantizer)
+            gate, up = parts if parts is not None else (self.gate_proj(x), self.up_proj(x))
             if _one_pass(gate, up) and gate.shape == up.shape:
                 return self.down_proj(ff.ops.silu_mul_quantize(gate, up, (), want_product=True)[0])  # silu(gate) * up, one pass
             return self.down_proj(F.silu(gate) * up)

@@ -265,6 +265,53 @@ def test_weight_only_storage_forms_agree_bit_for_bit(hip_backend, w_bits, block)
         torch.testing.assert_close(module.float(), want.float(), rtol=0, atol=0.02 * float(want.float().std()) + 1e-3)
 
 
+@pytest.mark.gpu
+def test_module_graph_one_launch_mlp_and_attention_epilogue_are_exact(hip_backend, monkeypatch):
+    """W8A8 module graph, no harness: QuantizedLlamaMLP takes the int8 GEMM's gate/up mode (both projections, SiLU * up and
+    down_proj's input quantizer in one launch) and QuantizedLlamaAttention lets the attention launch apply o_proj's input
+    quantizer — once the activation-code memo serves gate / up from the same codes. Both must reproduce the module-by-module
+    logits BIT FOR BIT (same accumulators, same roundings; reference mlp.py:30-40, nn/linear.py:32-39)."""
+    cfg = llama.LlamaConfig(hidden_size=512, intermediate_size=1024, num_layers=2, num_heads=4, num_kv_heads=2, vocab_size=512)
+    assert llama.attention_kernel_covers(cfg, 192, torch.bfloat16)
+    model = llama.build_model(cfg, "cuda", torch.bfloat16, seed=21, std=0.05)
+    llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    ids = torch.randint(0, cfg.vocab_size, (2, 192), device="cuda", generator=gen)
+    llama.calibrate(model, [ids, torch.randint(0, cfg.vocab_size, (2, 192), device="cuda", generator=gen)])
+    # gate / up input quantizers saw the same data: equal parameters -> the memo shares their codes from the third sighting on
+    taken = {"mlp": 0, "attn": 0}
+    real_mlp, real_attn = ff.ops.mlp_gate_up_w8a8, ff.ops.attention
+
+    def mlp(*a, **k):
+        out = real_mlp(*a, **k)
+        taken["mlp"] += out is not None
+        return out
+
+    def attn(*a, **k):
+        taken["attn"] += k.get("quantizer") is not None and k.get("want_context") is False
+        return real_attn(*a, **k)
+
+    monkeypatch.setattr(ff.ops, "mlp_gate_up_w8a8", mlp)
+    monkeypatch.setattr(ff.ops, "attention", attn)
+    with torch.no_grad(), ff.strict_quantization(False):
+        for _ in range(3):
+            got = model(ids, logits=True)
+        taken.update(mlp=0, attn=0)
+        got = model(ids, logits=True)
+        assert taken == {"mlp": cfg.num_layers, "attn": cfg.num_layers}, taken
+        monkeypatch.setattr(llama, "_w8a8_gate_up_down_input", lambda *a, **k: (None, None))
+        monkeypatch.setattr(llama.QuantizedLlamaAttention, "_o_proj_input_in_epilogue", lambda self, dtype: None)
+        want = model(ids, logits=True)
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    # with an estimator installed on any of the quantizers involved the fusions step aside (no parameters may be baked in)
+    monkeypatch.undo()
+    monkeypatch.setattr(ff.ops, "mlp_gate_up_w8a8", mlp)
+    taken.update(mlp=0)
+    with torch.no_grad(), ff.strict_quantization(False), ff.estimate_ranges(model, ff.range_setting.running_minmax, sync_free=True):
+        model(ids, logits=False)
+    assert taken["mlp"] == 0
+
+
 def check_fused_calibration(fixture, device):
     """Calibrating through FusedCalibrationForward (every quantizer's own forward with its estimator override, fused
     producers in between) gives the module graph's ranges: weight quantizers exactly, activation ranges within the
