@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 from fastforward_amd import ops, _native
 import os
-if os.environ.get("FFQ_LIB"):  # experiment builds (tools/gemm_variants.sh)
+if os.environ.get("FFQ_LIB"):  # experiment builds (tools/build_experiments.sh)
     from fastforward_amd._cabi import FFQLibrary
     _native._LIB = FFQLibrary(os.environ["FFQ_LIB"])
 from bench import event_time_ms

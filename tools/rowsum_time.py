@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from fastforward_amd import ops
 from bench import event_time_ms
 dev = "cuda"
