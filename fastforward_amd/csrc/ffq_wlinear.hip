@@ -69,6 +69,7 @@ struct WLinearArgs {
   int per_row;            // 0: one parameter pair for the whole tensor
   int pack_shift;         // WL_B_I4: log2(packing block)
   int tiles_m, tiles_n, group_m;
+  int group_cols;  // 0: groups of `group_m` row tiles x all column tiles (the weight is re-streamed per group); 1: groups of `group_m` column tiles x all row tiles (the activations are)
   // MLP mode (ffq_mlp_gate_up_wq): `w` / `w_scale` / `w_offset` describe gate_proj, these up_proj; N = rows of each = output columns
   const uint8_t* w2;
   const float* w_scale2;
@@ -114,11 +115,16 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
     it = it < my_tiles ? it : my_tiles - 1;  // streams running past the block's last tile re-read it (never used)
     const uint32_t tile_id = xcd_first + j_in_xcd + (uint32_t)it * blocks_in_xcd;
     const uint32_t gm = (uint32_t)a.group_m;
-    const uint32_t per_group = gm * (uint32_t)a.tiles_n;
+    // the operand that a group re-reads in full should be the SMALLER one: it is what has to stay in the 256 MiB Infinity
+    // Cache between groups while the other streams through once (launcher's choice, `group_cols`)
+    const uint32_t across = a.group_cols ? (uint32_t)a.tiles_m : (uint32_t)a.tiles_n;   // tiles of a group along the re-read operand
+    const uint32_t along = a.group_cols ? (uint32_t)a.tiles_n : (uint32_t)a.tiles_m;    // the dimension groups are cut from
+    const uint32_t per_group = gm * across;
     const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
-    const uint32_t group_rows = min(gm, (uint32_t)a.tiles_m - group * gm);
-    tm0 = (int)(group * gm + in_group % group_rows) * WL_BM;
-    tn0 = (int)(in_group / group_rows) * BN_OUT;
+    const uint32_t group_size = min(gm, along - group * gm);
+    const uint32_t inner = group * gm + in_group % group_size, outer = in_group / group_size;
+    tm0 = (int)(a.group_cols ? outer : inner) * WL_BM;
+    tn0 = (int)(a.group_cols ? inner : outer) * BN_OUT;
   };
   // first byte of row `row0` of a matrix with `row_bytes` per row, kept in SGPRs (see ffq_linear.hip::row_base)
   auto row_base = [&](const uint8_t* base, int row0, uint32_t row_bytes) {
@@ -617,8 +623,10 @@ extern "C" int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w
   a.tiles_m = (int)((M + WL_BM - 1) / WL_BM);
   a.tiles_n = (int)((N + WL_BN - 1) / WL_BN);
   a.group_m = K >= 4096 ? 4 : WL_GROUP_M;  // row tiles whose A panels (256 x 2 K bytes each) a group's column tiles share in their XCD's L2
+  a.group_cols = 0;
 #ifdef FFQ_EXPERIMENTS  // tuning builds only (tools/): the shipped library reads no environment
   if (const char* gm = getenv("FFQ_WQ_GROUP_M")) a.group_m = atoi(gm);
+  if (const char* gc = getenv("FFQ_WQ_GROUP_COLS")) a.group_cols = atoi(gc);
 #endif
   const bool grouped = groups > 1, offset = w_offset != nullptr;
 
@@ -687,6 +695,12 @@ extern "C" int ffq_mlp_gate_up_wq(const void* x, int x_dt, const void* gate_code
   a.tiles_m = (int)((M + WL_BM - 1) / WL_BM);
   a.tiles_n = (int)(N / 128);
   a.group_m = K >= 4096 ? 4 : WL_GROUP_M;
+  // both weight images together (2 N K x 2 B) against the activations (M K x 2 B): re-read the smaller one per group
+  a.group_cols = 2 * N > M ? 1 : 0;
+#ifdef FFQ_EXPERIMENTS
+  if (const char* gm = getenv("FFQ_WQ_GROUP_M")) a.group_m = atoi(gm);
+  if (const char* gc = getenv("FFQ_WQ_GROUP_COLS")) a.group_cols = atoi(gc);
+#endif
   const bool grouped = groups > 1, offset = gate_offset != nullptr;
 
   const size_t image_bytes = (size_t)N * (size_t)K * 2u;
