@@ -540,7 +540,7 @@ def main() -> None:
         tokens = args.batch * args.seq_len
         s_mod = replayed(module_forward)
         module_graph = {"value": round(tokens / s_mod, 1), "unit": "tokens/s", "n_gpus": 1, "steps": mg_steps, "ms_per_step": round(s_mod * 1e3, 3),
-                        "what": "model(batch) on the module graph ff.quantize_model() built: one quantizer call per linear input and weight, the dispatcher's int8 linear, the quantized Llama modules' own forwards (one-pass RMSNorm / SiLU*up / rotary / attention kernels between untouched stub slots) — no harness"}
+                        "what": "model(batch) on the module graph ff.quantize_model() built: one quantizer call per linear input and weight, the dispatcher's int8 linear, the quantized Llama modules' own forwards (one-pass RMSNorm / rotary / attention kernels between untouched stub slots, the MLP's gate + up + SiLU*up + down_proj input quantizer as one launch of the int8 GEMM, o_proj's input quantizer in the attention launch) — no harness"}
         s_eager = replayed(eager_forward)
         module_graph["eager_producer_chains"] = {
             "value": round(tokens / s_eager, 1), "unit": "tokens/s", "ms_per_step": round(s_eager * 1e3, 3),
