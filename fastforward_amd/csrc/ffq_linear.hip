@@ -229,8 +229,9 @@ __global__ __launch_bounds__(256) void w8a8_gemm_kernel(LinearArgs a) {
 //     barrier interval behind waves 0-3, so one wave of a SIMD feeds the matrix pipe while its partner reads LDS.
 //     A phase = one 64-byte k-chunk (kq = phase / 2) x one half of the rows: even phases read the 4 weight fragments of
 //     the chunk and 4 activation fragments, odd phases the other 4 activation fragments. The 8 LDS-DMA pieces per wave
-//     of a super-step sit inside the first two clusters and are waited for with vmcnt(0) one phase before their first read
-//     (RAW: wait -> barrier -> read; WAR: read retired -> barrier -> DMA issue).
+//     of a super-step are issued in the LOAD segments of phases 0 and 1 (by the group that is not computing, behind its
+//     fragment reads) and are waited for with vmcnt(0) one phase before their first read
+//     (RAW: wait -> barrier -> read; WAR: the target slot's last reads were issued a barrier interval before the pieces).
 //   * Persistent tile loop: one block per CU walks its tiles in the order a plain launch would dispatch them (XCD-aware,
 //     `group_m` row tiles deep). The K-loop runs straight across tile boundaries: the last iteration of a tile prefetches
 //     the first super-step of the next tile, which lands under the epilogue. The epilogue works in the slot the tile has
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
 #pragma unroll
     for (int q = 0; q < 4; ++q) fa[q] = *reinterpret_cast<const v4i*>(st + a_off[4 * mh + q][kq]);
   };
-  auto cluster = [&](int mh, auto dma, auto dma2) {
+  auto cluster = [&](int mh) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -605,8 +606,6 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
         if (mh == 0) acc[q][nj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[nj], fa[q], acc[q][nj], 0, 0, 0);
         else acc[4 + q][nj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb[nj], fa[q], acc[4 + q][nj], 0, 0, 0);
       }
-      if (q == 0) { __builtin_amdgcn_sched_barrier(0); dma(); __builtin_amdgcn_sched_barrier(0); }
-      if (q == 2) { __builtin_amdgcn_sched_barrier(0); dma2(); __builtin_amdgcn_sched_barrier(0); }
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
@@ -640,26 +639,38 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
         fetch = has_next ? 0 : ks;
         if (has_next) set_sources(nm0, nn0);
       }
+      // The eight LDS-DMA pieces of a wave are issued in the LOAD segments of phases 0 and 1 — by the group that is NOT
+      // computing, behind its own fragment reads (lgkmcnt(0)) and ahead of the barrier. An LDS-DMA instruction blocks its wave's
+      // instruction stream for 60+ cycles: inside a cluster (rounds 1-2) that let the matrix pipe run dry behind every piece
+      // (round 3, A/B on one box, bit-identical: layer mix 2.52 -> 2.61 POP/s, down_proj +4.3 %, MLP mode +2.1 %; round 2's
+      // "pieces in the LOAD segments: -6 %" had them AHEAD of the reads, where they delay the fragments). WAR on the target slot:
+      // its last readers, the other group's reads of the previous super-step, were issued a whole barrier interval earlier.
       read_frags(st, 0);
       __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue_a(fetch, slot ^ 1, 0); issue_b(fetch, slot ^ 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-      cluster(0, [&] { issue_a(fetch, slot ^ 1, 0); }, [&] { issue_b(fetch, slot ^ 1, 0); });
+      cluster(0);
       __builtin_amdgcn_s_barrier();
       read_frags(st, 1);
       __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue_a(fetch, slot ^ 1, 2); issue_b(fetch, slot ^ 1, 2);
+      __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-      cluster(1, [&] { issue_a(fetch, slot ^ 1, 2); }, [&] { issue_b(fetch, slot ^ 1, 2); });
+      cluster(1);
       __builtin_amdgcn_s_barrier();
       read_frags(st, 2);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-      cluster(0, [] {}, [] {});
+      cluster(0);
       __builtin_amdgcn_s_barrier();
       read_frags(st, 3);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the fetched super-step landed (and older epilogue stores)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-      cluster(1, [] {}, [] {});
+      cluster(1);
       __builtin_amdgcn_s_barrier();
       slot ^= 1;
     }

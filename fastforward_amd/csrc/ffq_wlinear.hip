@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
       else acc[4 + q][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wl_v8bf, fb[nj]), __builtin_bit_cast(wl_v8bf, fa[q]), acc[4 + q][nj], 0, 0, 0);
     }
   };
-  // An MFMA cluster: 16 MFMAs under s_setprio 1. `vmem` (LDS-DMA pieces / code loads) is issued behind the first four;
+  // An MFMA cluster: 16 MFMAs under s_setprio 1. `vmem` (the register loads of the code stream) is issued behind the first four;
   // `work` (the conversion of one row's codes: 32 VALU + 2 ds_write_b128) is interleaved with all sixteen, two VALU
   // instructions behind each MFMA (a wave hides about 2.5 issue slots under a 16-cycle MFMA; in one lump the conversion
   // would run with the matrix pipe idle — the partner wave only reads LDS meanwhile).
@@ -411,15 +411,28 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
         code_ks -= ksuper;
         if (ks == ksuper - 2) { set_code_sources(nn0); code_new_tile = true; }
       }
+      // The LDS-DMA pieces are issued by the group that is NOT computing: behind its fragment reads (lgkmcnt(0): the LDS is no
+      // longer serving them) and ahead of the barrier, in the first two LOAD segments of the super-step. An LDS-DMA instruction
+      // blocks its wave's instruction stream for 60+ cycles; inside a cluster that is the matrix pipe running dry behind every
+      // piece (round 3, A/B on one box: two-pass layer mix 1.35 -> 1.41 PFLOP/s; 3 + 3 + 2 pieces over three segments 1.39-1.40,
+      // all in the first 1.35, none in the first 1.31). WAR on the target slot: its last readers (the other group's fragment reads
+      // of the previous super-step) were issued a whole barrier interval earlier than these pieces, which themselves follow this
+      // wave's own completed reads.
       read_frags(st, 0);
       __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue_a(fetch, slot ^ 1, 0); issue_b(fetch, slot ^ 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-      cluster(0, [&] { issue_a(fetch, slot ^ 1, 0); issue_b(fetch, slot ^ 1, 0); }, [&] { convert_row(0, slot ^ 1); }, kConverts);
+      cluster(0, [] {}, [&] { convert_row(0, slot ^ 1); }, kConverts);
       __builtin_amdgcn_s_barrier();
       read_frags(st, 1);
       __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue_a(fetch, slot ^ 1, 2); issue_b(fetch, slot ^ 1, 2);
+      __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
-      cluster(1, [&] { issue_a(fetch, slot ^ 1, 2); issue_b(fetch, slot ^ 1, 2); }, [&] { convert_row(1, slot ^ 1); }, kConverts);
+      cluster(1, [] {}, [&] { convert_row(1, slot ^ 1); }, kConverts);
       __builtin_amdgcn_s_barrier();
       read_frags(st, 2);
       __builtin_amdgcn_sched_barrier(0);
