@@ -116,6 +116,44 @@ def test_contraction_lengths_that_are_not_a_multiple_of_128(k, weight_offset):
     assert ops.mlp_gate_up_w8a8(xq, wq, wq, sx, ox, sw, sw, so, oo, 8) is None
 
 
+@pytest.mark.parametrize("k", [256, 384, 512, 640])
+def test_shortest_k_loops_of_the_persistent_kernels(k):
+    """2-5 super-steps per tile at 4 tiles per block (1024 tiles of 256 x 256): the K-loop of the persistent kernels runs across
+    tile boundaries, so with a contraction this short nearly every LDS-DMA piece in flight belongs to ANOTHER tile than the one
+    being computed — the slot hand-over (pieces issued by the non-computing wave group, waited for one phase before the first
+    read) is exercised at its tightest. int8: exact accumulators (plain and gate/up mode); bf16 x weight codes: every storage
+    form against one another and within a rounding of float64."""
+    m, n = 8192, 8192
+    g = torch.Generator(device=DEV).manual_seed(k)
+    xq = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+    wq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    sx, ox = torch.tensor([0.013], device=DEV), torch.tensor([-5.0], device=DEV)
+    sw = torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+    acc = _accumulators(xq, wq)
+    want = _epilogue(acc, xq, wq, sx, ox, sw, None).to(torch.bfloat16)
+    assert torch.equal(ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.bfloat16), want)
+    uq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    so, oo = torch.tensor([0.05], device=DEV), torch.tensor([2.0], device=DEV)
+    codes = ops.mlp_gate_up_w8a8(xq, wq, uq, sx, ox, sw, sw, so, oo, 8)
+    up = _epilogue(_accumulators(xq, uq), xq, uq, sx, ox, sw, None).to(torch.bfloat16)
+    z = torch.nn.functional.silu(want) * up
+    assert torch.equal(codes, ops.quantize_by_tile(z, so, z.shape, 8, torch.int8, oo))
+    del acc, up, z, codes
+    # the weight-code GEMM: small integers x power-of-two scales -> every partial sum is exact in fp32, any order
+    x = torch.randint(-4, 5, (m, k), device=DEV, generator=g).to(torch.bfloat16)
+    w4 = torch.randint(-8, 8, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    s4 = torch.full((n * (k // 128),), 0.25, device=DEV)
+    exact = (x.double() @ (w4.double() * 0.25).t()).to(torch.bfloat16)
+    for kwargs, weight in ((dict(two_pass=False), w4), (dict(two_pass=True), w4), (dict(two_pass=False, pack_block=128), ops.pack_int4(w4, block=128)),
+                           (dict(two_pass=True, pack_block=128), ops.pack_int4(w4, block=128))):
+        got = ops.linear_wq(x, weight, s4, None, group=128, **kwargs)
+        assert torch.equal(got, exact), kwargs
+    u4 = torch.randint(-8, 8, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    fused = ops.mlp_gate_up_wq(x, w4, u4, s4, None, s4, None, group=128)
+    parts, _ = ops.silu_mul_quantize(exact, ops.linear_wq(x, u4, s4, None, group=128), (), want_product=True)
+    assert torch.equal(fused, parts)
+
+
 def test_all_zero_weight_offsets_cost_no_row_sums_and_change_nothing():
     """The offset BUFFER of a symmetric quantizer (reference nn/linear_quantizer.py:164-170) at a persistent-kernel shape:
     same bits as no offset at all; one non-zero entry switches the exact ow terms on (for every column)."""
