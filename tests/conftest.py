@@ -10,6 +10,7 @@ bench.py's cpu_baseline leg — never by the package.
 from __future__ import annotations
 
 import contextlib
+import os
 import pathlib
 import subprocess
 import sys
@@ -33,6 +34,9 @@ def pytest_configure(config: pytest.Config) -> None:
 def load_oracle():
     from fastforward_amd._cabi import FFQLibrary
 
+    override = os.environ.get("FFQ_ORACLE_SO")  # e.g. a sanitizer build of the oracle (oracle/sanitize.sh): the checker checked
+    if override:
+        return FFQLibrary(pathlib.Path(override))
     if not ORACLE_SO.exists() or ORACLE_SO.stat().st_mtime < (ROOT / "oracle" / "ffq_oracle.c").stat().st_mtime:
         subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
     return FFQLibrary(ORACLE_SO)
