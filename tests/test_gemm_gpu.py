@@ -154,6 +154,27 @@ def test_shortest_k_loops_of_the_persistent_kernels(k):
     assert torch.equal(fused, parts)
 
 
+def test_repeated_launches_are_bit_identical():
+    """Race hunt (tools/gemm_stress.py in small): the persistent kernels hand LDS slots between wave groups with raw barriers and
+    counted waits only — 40 repeats of each launch form at a long-K and a short-K shape must reproduce the first result exactly."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for m, n, k in ((16384, 4096, 14336), (8192, 8192, 256)):
+        xq = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+        wq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+        sx, ox = torch.tensor([0.02], device=DEV), torch.tensor([3.0], device=DEV)
+        sw = torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+        so, oo = torch.tensor([0.05], device=DEV), torch.tensor([-2.0], device=DEV)
+        xb = torch.randn(m, k, device=DEV, generator=g).to(torch.bfloat16)
+        forms = [lambda: ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.bfloat16),
+                 lambda: ops.mlp_gate_up_w8a8(xq, wq, wq, sx, ox, sw, sw, so, oo, 8),
+                 lambda: ops.linear_wq(xb, wq, sw, None, two_pass=True),
+                 lambda: ops.linear_wq(xb, wq, sw, None, two_pass=False),
+                 lambda: ops.mlp_gate_up_wq(xb, wq, wq, sw, None, sw, None)]
+        for i, fn in enumerate(forms):
+            first = fn()
+            assert all(torch.equal(fn(), first) for _ in range(40)), (m, n, k, i)
+
+
 def test_all_zero_weight_offsets_cost_no_row_sums_and_change_nothing():
     """The offset BUFFER of a symmetric quantizer (reference nn/linear_quantizer.py:164-170) at a persistent-kernel shape:
     same bits as no offset at all; one non-zero entry switches the exact ow terms on (for every column)."""
