@@ -19,7 +19,7 @@ from fastforward_amd.exceptions import QuantizationError
 
 FFQ_MAX_DIMS = 8
 FFQ_MAX_FANOUT = 3
-FFQ_ABI_VERSION = 6
+FFQ_ABI_VERSION = 7
 
 
 class Status(enum.IntEnum):
@@ -175,7 +175,7 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_quantize_backward_workspace_bytes": (_sz, [_tp]),
     "ffq_quantize_by_tile_backward": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _i64, _tp, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ffq_mlp_gate_up_wq_workspace_bytes": (_sz, [_i64, _i64, _i64]),
-    "ffq_mlp_gate_up_wq": (_i, [_vp, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "ffq_mlp_gate_up_wq": (_i, [_vp, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _i64, _vp]),
     "ffq_mlp_gate_up_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "ffq_mlp_gate_up_w8a8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ffq_add_rmsnorm_quantize": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _d, _vp, _fp, _vp]),
@@ -184,7 +184,9 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_quantize_rows_rowsum": (_i, [_vp, _i, _vp, _vp, _i64, _i64, _d, _vp, _vp, _vp]),
     "ffq_linear_wq_supported": (_i, [_i, _i, _i, _i64, _i64, _i64, _i64, _i64]),
     "ffq_linear_wq_workspace_bytes": (_sz, [_i64, _i64, _i64]),
-    "ffq_linear_wq": (_i, [_vp, _i, _vp, _i, _i64, _vp, _vp, _i64, _i64, _vp, _i, _vp, _i, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "ffq_linear_wq_split": (_i64, [_i64, _i64, _i64, _i]),
+    "ffq_linear_wq_tickets": (_i64, [_i64, _i64, _i64, _i]),
+    "ffq_linear_wq": (_i, [_vp, _i, _vp, _i, _i64, _vp, _vp, _i64, _i64, _vp, _i, _vp, _i, _i64, _i64, _i64, _vp, _sz, _vp, _i64, _vp]),
     "ffq_force_generic_kernels": (_i, [_i]),
     "ffq_quantize_rows_batch": (_i, [ctypes.POINTER(RowsBatch), _i, _vp]),
     "ffq_attention": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _d, _i, _vp, _vp, _vp, _vp, _d, _vp]),

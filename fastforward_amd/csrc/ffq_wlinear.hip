@@ -40,9 +40,14 @@
 
 #include <type_traits>
 
+#ifndef FFQ_WL_CLUSTER_MODE
+#define FFQ_WL_CLUSTER_MODE 1  // how a conversion cluster mixes its VALU work with its MFMAs: 0 = the compiler's choice, 1 = three / 2 = two VALU behind each MFMA
+#endif
+
 namespace ffq {
 
 typedef int wl_v4i __attribute__((ext_vector_type(4)));
+typedef unsigned int wl_v4u __attribute__((ext_vector_type(4)));
 typedef float wl_v4f __attribute__((ext_vector_type(4)));
 typedef __bf16 wl_v8bf __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void wl_lds_t;
@@ -52,6 +57,7 @@ constexpr int WL_BM = 256, WL_BN = 256, WL_BK = 64;
 constexpr int WL_IMAGE = 256 * 128;            // one operand image: 256 rows x 128 bytes
 constexpr int WL_SLOT = 2 * WL_IMAGE;          // A image then B image: 64 KiB
 constexpr int WL_GROUP_M = 8;
+constexpr size_t WL_UNIT_SLAB = (size_t)32 * 8 * 64 * 16;  // split-K: one unit's partial accumulators, [32 pieces][8][64 lanes] x 16 B = 256 KiB
 constexpr int64_t WL_TWO_PASS_MIN_TOKENS = 4096;  // from this many tokens on, A2 as its own pass + the bf16-image GEMM
 
 enum { WL_B_BF16 = 0, WL_B_I8 = 1, WL_B_I4 = 2 };
@@ -74,6 +80,12 @@ struct WLinearArgs {
   const uint8_t* w2;
   const float* w_scale2;
   const float* w_offset2;
+  // split-K (fewer tiles than CUs): a work unit is (tile, slice of the K range), `split` slices per tile, all units of the launch
+  // resident at once; the units of a tile exchange partial accumulators through `slabs` and each finishes a share of the tile
+  // (kernel epilogue). `tickets`: two counters per tile (arrived, left), zero on entry and on exit
+  int split;
+  float* slabs;
+  int* tickets;
 };
 
 // 4 codes in the bytes of `w` (signed bytes; for nibbles: 16 * code, see the header) -> 4 bf16 of (float(b) + c) * s
@@ -104,16 +116,25 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
   const uint32_t nblk = gridDim.x;
   const uint32_t xcd = blockIdx.x & 7u, j_in_xcd = blockIdx.x >> 3;
   const uint32_t blocks_in_xcd = (nblk >> 3) + (xcd < (nblk & 7u) ? 1u : 0u);
-  const uint32_t tq = (uint32_t)total_tiles >> 3, tr = (uint32_t)total_tiles & 7u;
+  // work units: slice-major ([slice][tile in walk order]), so that the blocks of an XCD work on ONE K range of neighbouring tiles
+  const uint32_t total_units = (uint32_t)total_tiles * (uint32_t)a.split;
+  const uint32_t tq = total_units >> 3, tr = total_units & 7u;
   const uint32_t xcd_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
   const uint32_t xcd_count = tq + (xcd < tr ? 1u : 0u);
   const int my_tiles = j_in_xcd < xcd_count ? (int)((xcd_count - j_in_xcd + blocks_in_xcd - 1) / blocks_in_xcd) : 0;
   if (my_tiles == 0) return;
+  const int ksuper = a.K / WL_BK;  // >= 2 * split (checked by the launcher)
   [[maybe_unused]] uint16_t* const silu_table = reinterpret_cast<uint16_t*>(lds + 2 * WL_SLOT);  // MLP: behind the two slots
   if constexpr (MLP) silu_table_fill(silu_table, (uint32_t)tid, 512u);  // published by the first tile's barriers
-  auto tile_origin = [&](int it, int& tm0, int& tn0) {
-    it = it < my_tiles ? it : my_tiles - 1;  // streams running past the block's last tile re-read it (never used)
-    const uint32_t tile_id = xcd_first + j_in_xcd + (uint32_t)it * blocks_in_xcd;
+  // unit `it` of this block: tile origin, super-steps [k0, k1) of the contraction, tile number (ticket / slab index) and slice
+  auto tile_origin = [&](int it, int& tm0, int& tn0, int& k0, int& k1, int& tile_no, int& slice) {
+    it = it < my_tiles ? it : my_tiles - 1;  // streams running past the block's last unit re-read it (never used)
+    const uint32_t unit_id = xcd_first + j_in_xcd + (uint32_t)it * blocks_in_xcd;
+    uint32_t tile_id = unit_id, sl = 0;
+    if (a.split > 1) { sl = unit_id / (uint32_t)total_tiles; tile_id = unit_id - sl * (uint32_t)total_tiles; }
+    tile_no = (int)tile_id; slice = (int)sl;
+    k0 = (int)(sl * (uint32_t)ksuper / (uint32_t)a.split);
+    k1 = (int)((sl + 1u) * (uint32_t)ksuper / (uint32_t)a.split);
     const uint32_t gm = (uint32_t)a.group_m;
     // the operand that a group re-reads in full should be the SMALLER one: it is what has to stay in the 256 MiB Infinity
     // Cache between groups while the other streams through once (launcher's choice, `group_cols`)
@@ -233,10 +254,10 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
         const uint32_t vo = c_voff[j] + byte0;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw[j]) : "v"(vo), "s"(c_base) : "memory");
       }
-      // the stream visits the super-steps of a tile in order (0, 1, 2, ...): group bookkeeping by counting, no division
+      // the stream visits the super-steps of a unit in order (k0, k0 + 1, ...): group bookkeeping by counting, one division per unit
       bool new_params = new_tile;
       if constexpr (GROUPED) {
-        if (new_tile) { grp = 0; grp_phase = 0; }
+        if (new_tile) { grp = ks / a.steps_per_group; grp_phase = ks - grp * a.steps_per_group; }  // a unit may start inside the K range (split-K)
         else if (++grp_phase == a.steps_per_group) { grp_phase = 0; ++grp; new_params = true; }
       }
       if (new_params) {  // wave-uniform
@@ -329,9 +350,12 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
     }
   };
   // An MFMA cluster: 16 MFMAs under s_setprio 1. `vmem` (the register loads of the code stream) is issued behind the first four;
-  // `work` (the conversion of one row's codes: 32 VALU + 2 ds_write_b128) is interleaved with all sixteen, two VALU
-  // instructions behind each MFMA (a wave hides about 2.5 issue slots under a 16-cycle MFMA; in one lump the conversion
-  // would run with the matrix pipe idle — the partner wave only reads LDS meanwhile).
+  // `work` (the conversion of one row's codes: ~40 VALU + 2 ds_write_b128) is interleaved with all sixteen — a wave hides about
+  // 2.5 issue slots under a 16-cycle MFMA; in one lump the conversion runs with the matrix pipe idle (the partner wave only reads
+  // LDS meanwhile). The pattern below must name ONLY instruction kinds the cluster contains: a group the scheduler cannot fill
+  // voids every group behind it — round 3 moved the LDS-DMA pieces out of the clusters and left their group in, and the
+  // compiler emitted the conversion as one 30-instruction lump (found in round 4 by reading the ISA; tools/asm_cluster_check.py
+  // now fails the build's CPU test when a cluster carries more than WL_MAX_VALU_RUN VALU instructions in a row).
   auto cluster = [&](int mh, auto vmem, auto work, auto has_work) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -343,18 +367,24 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
       mfma_row(mh, 3);
       vmem();
       work();
+#if FFQ_WL_CLUSTER_MODE == 1
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < 15; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two VALU
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // three VALU
       }
-      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);    // the two LDS-DMA pieces
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);    // whatever VALU is left (address arithmetic of the stores)
+      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);    // the two LDS stores last
+#elif FFQ_WL_CLUSTER_MODE == 2
 #pragma unroll
-      for (int g = 0; g < 12; ++g) {
+      for (int g = 0; g < 16; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);    // the two LDS stores last
+      __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+#endif
     } else {
       mfma_row(mh, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -370,20 +400,19 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
   constexpr std::integral_constant<bool, CODES> kConverts{};
   constexpr std::false_type kNoWork{};
 
-  const int ksuper = a.K / WL_BK;  // >= 2 (checked by the launcher)
-  int m0 = 0, n0 = 0;
-  tile_origin(0, m0, n0);
+  int m0 = 0, n0 = 0, k0 = 0, k1 = 0, tile_no = 0, slice = 0;
+  tile_origin(0, m0, n0, k0, k1, tile_no, slice);
   set_image_sources(m0, n0);
   // ---- prologue: element 0 staged entirely, the codes of element 1 requested
   if constexpr (CODES) {
     set_code_sources(n0);
-    load_codes(0, true);
+    load_codes(k0, true);
     wait_all_vmem();
     convert_row(0, 0);
     convert_row(1, 0);
-    load_codes(1, false);
+    load_codes(k0 + 1, false);
   }
-  issue_a(0, 0, 0); issue_a(0, 0, 2); issue_b(0, 0, 0); issue_b(0, 0, 2);
+  issue_a(k0, 0, 0); issue_a(k0, 0, 2); issue_b(k0, 0, 0); issue_b(k0, 0, 2);
   wait_all_vmem();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -396,20 +425,20 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
       for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[mi][nj][e] = 0.0f;
-    int nm0, nn0;
-    tile_origin(it + 1, nm0, nn0);
+    int nm0, nn0, nk0, nk1, ntile_no, nslice;
+    tile_origin(it + 1, nm0, nn0, nk0, nk1, ntile_no, nslice);
     if (wm == 1) __builtin_amdgcn_s_barrier();  // the upper group runs one interval behind
-    for (int ks = 0; ks < ksuper; ++ks) {
+    for (int ks = k0; ks < k1; ++ks) {
       const uint8_t* st = lds + slot * WL_SLOT;
       // images / conversion: element e + 1; code loads: element e + 2
-      const bool last = ks == ksuper - 1;
-      const int fetch = last ? 0 : ks + 1;
+      const bool last = ks == k1 - 1;
+      const int fetch = last ? nk0 : ks + 1;
       if (last) set_image_sources(nm0, nn0);
       int code_ks = ks + 2;
       bool code_new_tile = false;
-      if (code_ks >= ksuper) {
-        code_ks -= ksuper;
-        if (ks == ksuper - 2) { set_code_sources(nn0); code_new_tile = true; }
+      if (code_ks >= k1) {
+        code_ks = nk0 + (code_ks - k1);
+        if (ks == k1 - 2) { set_code_sources(nn0); code_new_tile = true; }
       }
       // The LDS-DMA pieces are issued by the group that is NOT computing: behind its fragment reads (lgkmcnt(0): the LDS is no
       // longer serving them) and ahead of the barrier, in the first two LOAD segments of the super-step. An LDS-DMA instruction
@@ -452,6 +481,66 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
     // for tile (mi, nj), register t: row m = 16 mi + l % 16, column n = 16 nj + 4 (l / 16) + t — four consecutive output
     // columns of one row.
     __syncthreads();
+    // ---- split-K: the `split` units of a tile run CONCURRENTLY (the launcher admits a split only when all units fit the chip in
+    // one round: one block per CU, every block exactly one unit) and exchange partial sums all-to-all. A wave's accumulators
+    // are four PIECES (row-tile pairs i = 0..3: the rounds of the epilogue below); piece (wave, i) is finished by the unit
+    // `(4 wave + i) % split`: every other unit stores its partial piece to its own slab — register layout, [piece][8][lane] x 16 B,
+    // one dense KiB per wave instruction, WRITE-THROUGH (sc1: a release fence would write back the whole L2, CDNA guide
+    // "publish-large"); the block counts itself in (`arrived`), waits until every unit of the tile is in, and every wave adds the
+    // peers' partials of ITS pieces in slice order to the partial it kept: each piece has one fixed finisher and one fixed
+    // summation order — results do not depend on timing. Units count themselves out (`left`) after reading; the last one
+    // zeroes both counters for the next launch. Pieces beyond M are skipped by everybody. The only wait is for blocks that
+    // are resident by construction; it is bounded and traps instead of hanging.
+    uint32_t own = 0xFu;  // bit i: this wave finishes piece i (wave-uniform)
+    if (a.split > 1) {
+      const int S = a.split;
+      const int rows_left = a.M - (m0 + wm * 128);
+      const int mi_cnt = rows_left <= 0 ? 0 : rows_left >= 128 ? 8 : (rows_left + 15) >> 4;  // wave-uniform
+      own = 0;
+      uint8_t* const tile_slabs = reinterpret_cast<uint8_t*>(a.slabs) + (size_t)tile_no * (size_t)S * WL_UNIT_SLAB;
+      const auto mine = __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)slice * WL_UNIT_SLAB, 0, (int)WL_UNIT_SLAB, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (2 * i >= mi_cnt) continue;
+        if ((wave * 4 + i) % S == slice) { own |= 1u << i; continue; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wl_v4u, acc[2 * i + (q >> 2)][q & 3]), mine, (((wave * 4 + i) * 8 + q) * 64 + lane) * 16, 0, /*sc1*/ 16);
+      }
+      // every storing wave drains its write-through stores, the block meets, ONE lane counts the unit in and waits until all
+      // `split` units of the tile are in (one poller per block: many pollers on one word cost chip bandwidth, CDNA guide
+      // "polling-cost"). The partials are then read with sc1 loads, which bypass this CU's L1 (the L2 cannot hold these lines:
+      // it is invalidated at kernel start and every slab line is written once and read once per launch) — no fence needed.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        int* const arrived = a.tickets + 2 * tile_no;
+        __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t spins = 0; __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S; ++spins) {
+          __builtin_amdgcn_s_sleep(4);
+          if (spins > (1u << 27)) __builtin_trap();  // ~10 s: a peer that never became resident
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // one piece (2 row tiles x 4 column tiles) of one peer in flight: 8 loads; peers added in slice order
+        if (!((own >> i) & 1u)) continue;
+        const uint32_t piece_off = (uint32_t)(((wave * 4 + i) * 8) * 64 + lane) * 16u;
+        for (int sp = 0; sp < S; ++sp) {
+          if (sp == slice) continue;
+          const auto peer = __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)sp * WL_UNIT_SLAB, 0, (int)WL_UNIT_SLAB, 0x00020000);
+          wl_v4u got[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) got[q] = __builtin_amdgcn_raw_buffer_load_b128(peer, piece_off + q * 1024, 0, /*sc1*/ 16);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const wl_v4f g = __builtin_bit_cast(wl_v4f, got[q]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[2 * i + (q >> 2)][q & 3][e] = acc[2 * i + (q >> 2)][q & 3][e] + g[e];
+          }
+        }
+      }
+    }
     {
       TOut* out = static_cast<TOut*>(a.out);
       constexpr int COLS = MLP ? 32 : 64;                     // output columns per wave
@@ -476,6 +565,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
         // against ATen), the reads of a row tile issued back to back, one wave-uniform branch for values outside its window.
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
+          if (!((own >> (mi >> 1)) & 1u)) continue;  // split-K: another unit finishes this piece
           uint32_t wg[2][2], ws[2][2], bad = 0;
 #pragma unroll
           for (int nj = 0; nj < 2; ++nj)
@@ -504,6 +594,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
       }
 #pragma unroll
       for (int i = 0; i < 128 / SLAB; ++i) {
+        if (!((own >> (i * SLAB / 32)) & 1u)) continue;  // split-K: another unit finishes this piece (wave-uniform)
 #pragma unroll
         for (int hh = 0; hh < SLAB / 16; ++hh) {
           const int mi = (SLAB / 16) * i + hh;
@@ -551,7 +642,14 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
       }
     }
     __syncthreads();  // the scratch slot is the next tile's staging target
-    m0 = nm0; n0 = nn0;
+    if (a.split > 1 && tid == 0) {  // every wave of this block has read its peers' pieces (the barrier above): count the unit out
+      int* const arrived = a.tickets + 2 * tile_no;
+      if (__hip_atomic_fetch_add(arrived + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.split - 1) {
+        __hip_atomic_store(arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(arrived + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    m0 = nm0; n0 = nn0; k0 = nk0; k1 = nk1; tile_no = ntile_no; slice = nslice;
   }
   wait_all_vmem();  // the trailing requests of the streams must not outlive the block's LDS / registers
 }
@@ -574,17 +672,102 @@ extern "C" int ffq_linear_wq_supported(int x_dt, int w_dt, int out_dt, int64_t M
   return 0;
 }
 
-// workspace of the two-pass form (A2 of the whole weight into a bf16 image, then the GEMM on that image): N * K * 2 bytes.
-// The caller may pass less (or NULL): the one-pass kernel then runs for every M.
+// ---- the launch plan: K slices per tile ("split-K") when a launch has fewer tiles than the chip has CUs ----------------------------
+// The kernel is one persistent block per CU on 256 x 256 output tiles; 2048 tokens x a 4096-wide projection are 128 tiles, a k/v
+// projection 32 (round 3 sent everything below 4096 tokens to the vendor's GEMM for that reason). A tile's K range is cut
+// into `split` slices, each (tile, slice) is a work unit on its own CU, and the units of a tile exchange their fp32 partial sums
+// (kernel epilogue). All units must be resident at once (they wait for each other), so a split is admitted only while
+// tiles * split <= CUs of the device — one round, one unit per block. The choice is a pure function of (M, N, K, mode, CU count):
+// the fp32 summation order, hence the result's last bit, depends on it. Cost model in units of one 64-deep super-step
+// (tools/wq_split_sweep.py): steps(S) + exchange, the exchange ~ a fixed synchronisation cost + the slab traffic of a unit,
+// which scales with the rows of the tile that exist.
+static int wq_cus() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);
+  }
+  return n;
+}
+
+static int64_t wq_tiles(int64_t M, int64_t N, bool mlp) {
+  return ((M + WL_BM - 1) / WL_BM) * (mlp ? N / 128 : (N + WL_BN - 1) / WL_BN);
+}
+
+static int wq_max_split(int64_t M, int64_t N, int64_t K, bool mlp) {
+  const int64_t tiles = wq_tiles(M, N, mlp), by_cus = tiles > 0 ? wq_cus() / tiles : 1, by_k = (K / WL_BK) / 2;
+  const int64_t most = by_cus < by_k ? by_cus : by_k;
+  return most < 1 ? 1 : most > 32 ? 32 : (int)most;
+}
+
+static int wq_split(int64_t M, int64_t N, int64_t K, bool mlp) {
+  const int64_t ksuper = K / WL_BK;
+  const int most = wq_max_split(M, N, K, mlp);
+  const double rows = (double)(M < WL_BM ? M : WL_BM) / WL_BM;
+  double best_cost = 0.0;
+  int best = 1;
+  for (int S = 1; S <= most; ++S) {
+    if (S > 1 && ksuper / S < 4) break;  // the code stream looks two super-steps ahead: keep slices comfortably longer
+    const double steps = (double)((ksuper + S - 1) / S);
+    const double cost = steps + (S > 1 ? 6.0 + 6.0 * rows * (double)(S - 1) / S + 0.25 * S : 0.0);
+    if (S == 1 || cost < best_cost * 0.97) { best_cost = cost; best = S; }  // a larger split has to pay for itself
+  }
+  return best;
+}
+
+extern "C" int64_t ffq_linear_wq_split(int64_t M, int64_t N, int64_t K, int mlp) {
+  if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 1;
+  return wq_split(M, N, K, mlp != 0);
+}
+
+// int32 counters the split-K exchange needs (two per tile; 0 = none): zero before the first launch that uses them, left zero
+// by every launch — a caller keeps ONE zeroed buffer per stream and never touches it
+extern "C" int64_t ffq_linear_wq_tickets(int64_t M, int64_t N, int64_t K, int mlp) {
+  if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 0;
+  return 2 * wq_tiles(M, N, mlp != 0);
+}
+
+static size_t wq_slab_bytes(int64_t M, int64_t N, int split, bool mlp) {
+  return split > 1 ? (size_t)wq_tiles(M, N, mlp) * (size_t)split * WL_UNIT_SLAB : 0;
+}
+
+// workspace: [split-K slabs of the library's plan | bf16 image(s) of the two-pass form (A2 of the whole weight, then the GEMM on
+// that image): N * K * 2 bytes from 4096 tokens on]. The caller may pass less (or NULL): the launch then runs without the part
+// that does not fit (no split / conversion inside the GEMM) — never fails for lack of scratch.
 extern "C" size_t ffq_linear_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  if (M < WL_TWO_PASS_MIN_TOKENS || N <= 0 || K <= 0) return 0;
-  return (size_t)N * (size_t)K * 2u;
+  if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 0;
+  return wq_slab_bytes(M, N, wq_split(M, N, K, false), false) + (M >= WL_TWO_PASS_MIN_TOKENS ? (size_t)N * (size_t)K * 2u : 0);
+}
+
+// resolves (requested split, scratch on offer) into what the launch uses; returns the bytes the slabs take at the front of `workspace`
+static size_t wq_resolve_split(WLinearArgs& a, int64_t split_request, bool mlp, void* workspace, size_t workspace_bytes, int32_t* tickets, int* rc) {
+  *rc = FFQ_OK;
+  const int most = wq_max_split(a.M, a.N, a.K, mlp);
+  if (split_request > most) {
+    *rc = fail(FFQ_ERR_ARG, "weight-only linear: split %lld exceeds %d (all units of a tile must be resident at once: tiles * split <= CUs, K / 64 >= 2 * split)", (long long)split_request, most);
+    return 0;
+  }
+  int split = split_request > 0 ? (int)split_request : wq_split(a.M, a.N, a.K, mlp);
+  size_t slab = wq_slab_bytes(a.M, a.N, split, mlp);
+  if (split > 1 && (!tickets || !workspace || workspace_bytes < slab || !aligned16(workspace))) {
+    if (split_request > 1) { *rc = fail(FFQ_ERR_ARG, "weight-only linear: split %d needs %zu bytes of workspace and a ticket buffer", split, slab); return 0; }
+    split = 1; slab = 0;  // the plan is a preference: without scratch every tile is one unit
+  }
+  a.split = split;
+  a.slabs = split > 1 ? static_cast<float*>(workspace) : nullptr;
+  a.tickets = split > 1 ? tickets : nullptr;
+  return slab;
 }
 
 template <int BKIND, bool GROUPED, bool OFFSET, typename TOut, bool MLP = false>
 static void wq_launch(const WLinearArgs& a, hipStream_t s) {
   const int total = a.tiles_m * a.tiles_n;
-  const unsigned grid = (unsigned)(total < 256 ? total : 256);
+  const int64_t units = (int64_t)total * a.split;  // split > 1: units <= CUs (wq_max_split): every block exactly one unit, all resident
+  const int cus = wq_cus();
+  const unsigned grid = (unsigned)(units < cus ? units : cus);
   const size_t lds_bytes = (size_t)2 * WL_SLOT + (MLP ? kSiluBytes : 0);
   static uint64_t attr_set = 0;
   ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_gemm256_kernel<BKIND, GROUPED, OFFSET, TOut, MLP>), (int)lds_bytes);
@@ -606,9 +789,10 @@ static void wq_dispatch(const WLinearArgs& a, bool grouped, bool offset, hipStre
 
 extern "C" int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, int64_t pack_block, const float* w_scale,
                              const float* w_offset, int64_t scale_numel, int64_t group, const void* bias, int bias_dt, void* out,
-                             int out_dt, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+                             int out_dt, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, int32_t* tickets,
+                             int64_t split, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (M < 0 || N < 0 || K < 0 || split < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
   if (!x || !w_codes || !w_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
   if (!ffq_linear_wq_supported(x_dt, w_dt, out_dt, M, N, K, group, pack_block))
@@ -642,9 +826,14 @@ extern "C" int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w
   if (const char* gc = getenv("FFQ_WQ_GROUP_COLS")) a.group_cols = atoi(gc);
 #endif
   const bool grouped = groups > 1, offset = w_offset != nullptr;
+  int rc_split;
+  const size_t slab_bytes = wq_resolve_split(a, split, false, workspace, workspace_bytes, tickets, &rc_split);
+  if (rc_split != FFQ_OK) return rc_split;
+  workspace = workspace ? static_cast<uint8_t*>(workspace) + slab_bytes : nullptr;  // the image (if any) lies behind the slabs
+  workspace_bytes = workspace_bytes > slab_bytes ? workspace_bytes - slab_bytes : 0;
 
   const size_t image_bytes = (size_t)N * (size_t)K * 2u;
-  if (M >= WL_TWO_PASS_MIN_TOKENS && workspace && workspace_bytes >= image_bytes && aligned16(workspace)) {
+  if (workspace && workspace_bytes >= image_bytes && aligned16(workspace)) {  // the caller offered the image's scratch (ffq_linear_wq_workspace_bytes: from 4096 tokens on)
     // two-pass form: A2 of the whole weight once (3 or 2.5 B/elem, ~2 % of the GEMM at 16 k tokens), then the GEMM with both
     // operands by LDS-DMA — no conversion work per row tile
     ffq_tiling t;
@@ -669,18 +858,18 @@ extern "C" int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w
 }
 
 // ---- gate_proj + up_proj + SiLU * up of a weight-only quantized MLP in one launch ---------------------------------------------------
-// workspace of the two-pass form: the bf16 images of BOTH matrices
+// workspace: [split-K slabs of the library's plan | the bf16 images of BOTH matrices (two-pass form, from 4096 tokens on)]
 extern "C" size_t ffq_mlp_gate_up_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  if (M < WL_TWO_PASS_MIN_TOKENS || N <= 0 || K <= 0) return 0;
-  return (size_t)2 * (size_t)N * (size_t)K * 2u;
+  if (M <= 0 || N <= 0 || N % 128 != 0 || K < 2 * WL_BK) return 0;
+  return wq_slab_bytes(M, N, wq_split(M, N, K, true), true) + (M >= WL_TWO_PASS_MIN_TOKENS ? (size_t)2 * (size_t)N * (size_t)K * 2u : 0);
 }
 
 extern "C" int ffq_mlp_gate_up_wq(const void* x, int x_dt, const void* gate_codes, const void* up_codes, int w_dt, int64_t pack_block,
                                   const float* gate_scale, const float* gate_offset, const float* up_scale, const float* up_offset,
                                   int64_t scale_numel, int64_t group, void* out, int64_t M, int64_t N, int64_t K, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+                                  size_t workspace_bytes, int32_t* tickets, int64_t split, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (M < 0 || N < 0 || K < 0 || split < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
   if (!x || !gate_codes || !up_codes || !gate_scale || !up_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
   if ((gate_offset == nullptr) != (up_offset == nullptr)) return fail(FFQ_ERR_ARG, "gate and up need offsets both or neither");
@@ -715,9 +904,14 @@ extern "C" int ffq_mlp_gate_up_wq(const void* x, int x_dt, const void* gate_code
   if (const char* gc = getenv("FFQ_WQ_GROUP_COLS")) a.group_cols = atoi(gc);
 #endif
   const bool grouped = groups > 1, offset = gate_offset != nullptr;
+  int rc_split;
+  const size_t slab_bytes = wq_resolve_split(a, split, true, workspace, workspace_bytes, tickets, &rc_split);
+  if (rc_split != FFQ_OK) return rc_split;
+  workspace = workspace ? static_cast<uint8_t*>(workspace) + slab_bytes : nullptr;
+  workspace_bytes = workspace_bytes > slab_bytes ? workspace_bytes - slab_bytes : 0;
 
   const size_t image_bytes = (size_t)N * (size_t)K * 2u;
-  if (M >= WL_TWO_PASS_MIN_TOKENS && workspace && workspace_bytes >= 2 * image_bytes && aligned16(workspace)) {
+  if (workspace && workspace_bytes >= 2 * image_bytes && aligned16(workspace)) {
     ffq_tiling t;
     t.ndim = 2;
     t.shape[0] = N; t.shape[1] = K;

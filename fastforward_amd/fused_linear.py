@@ -98,6 +98,16 @@ def weight_only_kernel(enabled: bool = True, min_tokens: int | None = None):
 
 _FLOATS = (torch.bfloat16, torch.float16, torch.float32)
 
+
+def _module_hooked(module: Any) -> bool:
+    """A forward / backward hook on `module`, or a global module hook, would run if the module were called."""
+    from torch.nn.modules import module as nn_module
+
+    if any(getattr(nn_module, name, None) for name in ("_global_forward_hooks", "_global_forward_pre_hooks", "_global_backward_hooks", "_global_backward_pre_hooks")):
+        return True
+    return bool(getattr(module, "_forward_hooks", None) or getattr(module, "_forward_pre_hooks", None) or getattr(module, "_backward_hooks", None)
+                or getattr(module, "_backward_pre_hooks", None))
+
 # A symmetric quantizer carries an offset BUFFER that is all zeros unless its data is one-sided (reference
 # nn/linear_quantizer.py:164-170). The int8 GEMM recognises that on the device (a one-block check ahead of the launch and a
 # slightly heavier epilogue: no host read, which is what a range estimator that rewrites the parameters on every step needs);
@@ -222,6 +232,8 @@ class DispatcherKernels:
         s = self.surface
         q = output_quantizer
         if q is None or type(q) is not s.linear_quantizer or s.export_mode():
+            return None
+        if _module_hooked(q):  # the fused launch never calls q: a forward hook on it (code recorders, observers) would not fire
             return None
         if q.has_uninitialized_params or next(iter(q.overrides), None) is not None or not q.per_tensor:
             return None

@@ -30,6 +30,7 @@ import torch.nn.functional as F
 import fastforward_amd as ff
 
 from fastforward_amd.nn import QuantizedModule, QuantizerStub
+from fastforward_amd.quantization.affine._memo import sibling_quantizers
 
 
 @dataclasses.dataclass(frozen=True)
@@ -204,6 +205,25 @@ def _untouched(*quantizers: torch.nn.Module | None) -> bool:
     return all(q is None or (q.is_stub() and next(iter(q.overrides), None) is None) for q in quantizers)
 
 
+def _hooked(*modules: torch.nn.Module | None) -> bool:
+    """True if calling one of `modules` through ``nn.Module.__call__`` would run a user hook (its own or a global one). The
+    one-pass paths below compute what a group of module calls would have computed without making those calls; hooks on the
+    bypassed modules would silently stop firing — the reference's strict_quantization_for_module (strict_quantization.py:67-68),
+    its ModuleIORecorder (export/_io_capture.py:78) and the usual GPTQ input capture hang exactly such hooks on linears and
+    quantizers — so any hook sends the caller back to the module-by-module route."""
+    from torch.nn.modules import module as nn_module
+
+    for table in ("_global_forward_hooks", "_global_forward_pre_hooks", "_global_backward_hooks", "_global_backward_pre_hooks"):
+        if getattr(nn_module, table, None):
+            return True
+    for m in modules:
+        if m is None:
+            continue
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, "_backward_pre_hooks", None):
+            return True
+    return False
+
+
 def _one_pass(*tensors: torch.Tensor) -> bool:
     from fastforward_amd import _native
 
@@ -217,21 +237,20 @@ def _weight_only_gate_up(x: torch.Tensor, gate_proj: torch.nn.Module, up_proj: t
     and 4) as one launch of the weight-code GEMM with the SiLU * up epilogue (ops.mlp_gate_up_wq) — the value
     ``silu_mul_quantize(gate_proj(x), up_proj(x))`` has when both projections go through the dispatcher's weight-only kernel,
     bit for bit. None whenever that is not the situation (any set activation quantizer, a bias, parameters the kernel does not
-    cover, fewer tokens than the dispatcher's weight-only threshold): the caller then runs the two module forwards.
+    cover, a hook on a bypassed module): the caller then runs the two module forwards.
     `stored`: (codes, packing block) of the two weights when the caller keeps them; else each weight quantizer runs here, as
     QuantizedLinear.forward would run it (reference nn/linear.py:34)."""
     from fastforward_amd import fused_linear
     from fastforward_amd.nn import QuantizedLinear
 
     kernels = fused_linear.KERNELS
-    if not _one_pass(x) or not x.is_contiguous():
+    if not _one_pass(x) or not x.is_contiguous() or _hooked(gate_proj, up_proj):
         return None
     for lin in (gate_proj, up_proj):
         if (not isinstance(lin, QuantizedLinear) or lin.bias is not None or lin.weight_quantizer.is_stub()
-                or not _untouched(lin.input_quantizer, lin.output_quantizer)):
+                or not _untouched(lin.input_quantizer, lin.output_quantizer) or _hooked(lin.input_quantizer, lin.output_quantizer)):
             return None
-    tokens = x.numel() // x.shape[-1]
-    if not fused_linear._WEIGHT_ONLY_KERNEL or tokens < fused_linear._WEIGHT_ONLY_MIN_TOKENS:
+    if not fused_linear._WEIGHT_ONLY_KERNEL:
         return None
     if stored is not None:
         gq, uq = gate_proj.weight_quantizer, up_proj.weight_quantizer
@@ -267,7 +286,7 @@ def _w8a8_gate_up_down_input(x: torch.Tensor, gate_proj: torch.nn.Module, up_pro
     from fastforward_amd.nn import QuantizedLinear
 
     kernels = fused_linear.KERNELS
-    if not _one_pass(x) or not x.is_contiguous():
+    if not _one_pass(x) or not x.is_contiguous() or _hooked(gate_proj, up_proj, down_proj, gate_proj.output_quantizer, up_proj.output_quantizer):
         return None, None
     for lin in (gate_proj, up_proj, down_proj):
         if not isinstance(lin, QuantizedLinear) or lin.bias is not None or lin.weight_quantizer.is_stub() or lin.input_quantizer.is_stub():
@@ -277,7 +296,8 @@ def _w8a8_gate_up_down_input(x: torch.Tensor, gate_proj: torch.nn.Module, up_pro
     fused = kernels._requant(down_proj.input_quantizer, x.dtype)
     if fused is None or fused["out_dtype"] != torch.int8:
         return None, None
-    xg, xu = gate_proj.input_quantizer(x), up_proj.input_quantizer(x)
+    with sibling_quantizers():
+        xg, xu = gate_proj.input_quantizer(x), up_proj.input_quantizer(x)
     gw, uw = gate_proj.weight_quantizer(gate_proj.weight), up_proj.weight_quantizer(up_proj.weight)
     codes = None
     if (kernels.supported_linear(xg, gw) and kernels.supported_linear(xu, uw) and kernels.row_mode(xg) == "tensor"
@@ -326,7 +346,8 @@ class QuantizedLlamaAttention(QuantizedModule, LlamaAttention):
         hidden_states = self.input_quantizer(hidden_states)
         cfg = self.config
         if hidden_states.dim() == 3 and _one_pass(hidden_states) and attention_kernel_covers(cfg, hidden_states.shape[1], hidden_states.dtype):
-            q, k, v = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
+            with sibling_quantizers():  # equal input quantizers on the same hidden state share one A1 launch
+                q, k, v = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
             if _one_pass(q, k, v, cos, sin) and cos.dim() == 2 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous():
                 # rotary embedding in place on the projections, then softmax(q k^T) v as one flash-style launch
                 ff.ops.rope_(q, k, cos, sin, cfg.head_dim)
@@ -355,6 +376,8 @@ class QuantizedLlamaAttention(QuantizedModule, LlamaAttention):
 
         o_proj = self.o_proj
         if not isinstance(o_proj, QuantizedLinear) or o_proj.bias is not None or o_proj.weight_quantizer.is_stub() or o_proj.input_quantizer.is_stub():
+            return None
+        if _hooked(o_proj):  # the fused route calls neither o_proj nor its input quantizer (the latter: _requant's own check)
             return None
         fused = fused_linear.KERNELS._requant(o_proj.input_quantizer, dtype)
         return fused if fused is not None and fused["out_dtype"] == torch.int8 else None
@@ -394,7 +417,10 @@ class QuantizedLlamaMLP(QuantizedModule, LlamaMLP):
             if quantized is not None:  # down_proj's GEMM on the codes its input quantizer would have produced
                 down = self.down_proj
                 return ff.nn.functional.linear(quantized, down.weight_quantizer(down.weight), None, output_quantizer=down.output_quantizer)
-            gate, up = parts if parts is not None else (self.gate_proj(x), self.up_proj(x))
+            if parts is None:
+                with sibling_quantizers():
+                    parts = (self.gate_proj(x), self.up_proj(x))
+            gate, up = parts
             if _one_pass(gate, up) and gate.shape == up.shape:
                 return self.down_proj(ff.ops.silu_mul_quantize(gate, up, (), want_product=True)[0])  # silu(gate) * up, one pass
             return self.down_proj(F.silu(gate) * up)
@@ -418,7 +444,8 @@ class QuantizedLlamaDecoderLayer(QuantizedModule, LlamaDecoderLayer):
         """True when this layer can take (residual stream, a term not yet added to it): its entry slot is an untouched stub
         and its first RMSNorm runs as the one-pass kernel, which then performs the add."""
         norm = self.input_layernorm
-        return _untouched(self.input_quantizer) and isinstance(norm, QuantizedLlamaRMSNorm) and hidden_states.is_contiguous() and norm._fusable(hidden_states)
+        return (_untouched(self.input_quantizer) and isinstance(norm, QuantizedLlamaRMSNorm) and hidden_states.is_contiguous() and norm._fusable(hidden_states)
+                and not _hooked(self, norm, self.input_quantizer))
 
     def forward_deferred(self, hidden_states: torch.Tensor, pending: torch.Tensor | None, cos: torch.Tensor, sin: torch.Tensor,
                          defer: bool) -> tuple[torch.Tensor, torch.Tensor | None]:
@@ -436,14 +463,18 @@ class QuantizedLlamaDecoderLayer(QuantizedModule, LlamaDecoderLayer):
         attn_out = self.self_attn(normed, cos, sin)
         norm = self.post_attention_layernorm
         if (_untouched(self.attn_res_act_quantizer) and isinstance(norm, QuantizedLlamaRMSNorm) and hidden_states.shape == attn_out.shape
-                and hidden_states.is_contiguous() and attn_out.is_contiguous() and norm._fusable(hidden_states) and _one_pass(attn_out)):
+                and hidden_states.is_contiguous() and attn_out.is_contiguous() and norm._fusable(hidden_states) and _one_pass(attn_out)
+                and not _hooked(norm, self.attn_res_act_quantizer)):
             # the residual add and the RMSNorm behind it as one pass (both values are needed: the sum is the next residual)
             hidden_states, normed, _ = ff.ops.add_rmsnorm_quantize(hidden_states, attn_out, norm.weight, norm.variance_epsilon, (), want_sum=True, want_norm=True)
         else:
             hidden_states = self.attn_res_act_quantizer(hidden_states + attn_out)
             normed = norm(hidden_states)
         mlp_out = self.mlp(normed)
-        if defer and _untouched(self.mlp_res_act_quantizer) and _one_pass(mlp_out) and mlp_out.shape == hidden_states.shape and mlp_out.is_contiguous():
+        # the stream handed on must itself be what the consumer's one-pass launch takes (a set attn_res_act_quantizer makes it a
+        # QuantizedTensor; `consumer` was decided on this layer's INPUT stream)
+        if (defer and _untouched(self.mlp_res_act_quantizer) and not _hooked(self.mlp_res_act_quantizer) and _one_pass(mlp_out, hidden_states)
+                and mlp_out.shape == hidden_states.shape and mlp_out.is_contiguous() and hidden_states.is_contiguous()):
             return hidden_states, mlp_out
         return self.mlp_res_act_quantizer(hidden_states + mlp_out), None
 
@@ -457,12 +488,14 @@ class QuantizedLlamaModel(QuantizedModule, LlamaModel):
         layers = list(self.layers)
         pending: torch.Tensor | None = None
         for i, layer in enumerate(layers):
-            if isinstance(layer, QuantizedLlamaDecoderLayer):
+            # a layer with a user hook is CALLED (hooks fire, pending added first); forward_deferred is the hook-free shortcut
+            if isinstance(layer, QuantizedLlamaDecoderLayer) and (pending is None or layer.accepts_pending(hidden_states)) and not _hooked(layer):
                 nxt = layers[i + 1] if i + 1 < len(layers) else None
                 if nxt is None:
-                    consumer = isinstance(self.norm, QuantizedLlamaRMSNorm) and hidden_states.is_contiguous() and self.norm._fusable(hidden_states)
+                    consumer = (isinstance(self.norm, QuantizedLlamaRMSNorm) and type(hidden_states) is torch.Tensor and hidden_states.is_contiguous()
+                                and self.norm._fusable(hidden_states) and not _hooked(self.norm))
                 else:
-                    consumer = isinstance(nxt, QuantizedLlamaDecoderLayer) and nxt.accepts_pending(hidden_states)
+                    consumer = isinstance(nxt, QuantizedLlamaDecoderLayer) and type(hidden_states) is torch.Tensor and nxt.accepts_pending(hidden_states)
                 hidden_states, pending = layer.forward_deferred(hidden_states, pending, cos, sin, defer=consumer)
             else:
                 hidden_states = layer(hidden_states if pending is None else hidden_states + pending, cos, sin)
@@ -688,6 +721,10 @@ class FusedForward:
         for name, linear in decoder_linears(model):
             if linear.bias is not None:
                 problems.append(f"{name}: bias")
+            wq = linear.weight_quantizer
+            if isinstance(wq, LinearQuantizer) and _weight_row_mode(linear) is None:
+                # the int8 GEMM reads N scales as one per OUTPUT row: PerChannel(1) on a square weight has N parameters too
+                problems.append(f"{name}: weight granularity must be per tensor or per output channel (tile {tuple(wq.granularity.tile_size(linear.weight.shape))})")
         return problems
 
     def _symmetric_weights(self, linear: torch.nn.Module) -> bool:
@@ -720,7 +757,7 @@ class FusedForward:
         ready = self._layer_codes.pop(id(linear), None)  # quantized with the rest of its layer in one launch (_quantize_layer)
         if ready is not None:
             return ready, None
-        if self.fuse_rowsums and wq.scale.numel() == rows and rows > 1 and (wq.offset is None or wq.offset.numel() == rows) and wq.num_bits <= 8:
+        if self.fuse_rowsums and _weight_row_mode(linear) == "row" and rows > 1 and (wq.offset is None or wq.offset.numel() == rows) and wq.num_bits <= 8:
             offset = None if self._symmetric_weights(linear) else wq.offset  # an all-zero offset buffer: same codes
             fused = ff.ops.quantize_rows_rowsum(linear.weight, wq.scale, offset, wq.num_bits, rowsum_out=self._rowsum_slice(rows, linear.weight.device))
             if fused is not None:
@@ -744,7 +781,8 @@ class FusedForward:
                 if hit is not None and hit[0] == key:
                     continue
             rows = linear.weight.shape[0]
-            if wq.scale.numel() == rows and rows > 1 and (wq.offset is None or wq.offset.numel() == rows) and wq.num_bits == attn.q_proj.weight_quantizer.num_bits:
+            # per OUTPUT channel by its tiling, not by its parameter count (PerChannel(1) on a square weight also has `rows` scales)
+            if _weight_row_mode(linear) == "row" and rows > 1 and (wq.offset is None or wq.offset.numel() == rows) and wq.num_bits == attn.q_proj.weight_quantizer.num_bits:
                 todo.append(linear)
         if len(todo) < 2:
             return
@@ -956,7 +994,8 @@ class FusedProducersForward:
                 product = _weight_only_gate_up(normed, gate_proj, up_proj, stored)
                 if product is not None:
                     return product
-        gate, up = self._linear(normed, gate_proj), self._linear(normed, up_proj)
+        with sibling_quantizers():
+            gate, up = self._linear(normed, gate_proj), self._linear(normed, up_proj)
         return ff.ops.silu_mul_quantize(gate, up, (), want_product=True)[0]
 
     @torch.no_grad()
@@ -972,7 +1011,8 @@ class FusedProducersForward:
                 attn, mlp = layer.self_attn, layer.mlp
                 ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
                 hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, ln1.weight, ln1.variance_epsilon, (), want_norm=True, sum_inplace=pending is not None)
-                q, k, v = self._linear(normed, attn.q_proj), self._linear(normed, attn.k_proj), self._linear(normed, attn.v_proj)
+                with sibling_quantizers():
+                    q, k, v = self._linear(normed, attn.q_proj), self._linear(normed, attn.k_proj), self._linear(normed, attn.v_proj)
                 ff.ops.rope_(q, k, cos, sin, d)
                 if attention_kernel_covers(cfg, s, q.dtype):
                     ctx, _ = ff.ops.attention(q, k, v, d, causal=s > 1)
@@ -989,12 +1029,22 @@ class FusedProducersForward:
 FusedCalibrationForward = FusedProducersForward  # the name the calibration path was introduced under
 
 
+def _weight_row_mode(linear: torch.nn.Module) -> str | None:
+    """'tensor' / 'row' (one parameter pair per output channel) / None for the tiling of the linear's weight quantizer
+    (DispatcherKernels.row_mode on the weight's shape and the quantizer's granularity)."""
+    return ff.fused_linear.KERNELS.row_mode(_Shaped(linear.weight, linear.weight_quantizer))
+
+
 class _Shaped:
     """Just enough of a quantized weight for ``DispatcherKernels.weight_group``: a shape and its quantizer's granularity."""
 
     def __init__(self, weight: torch.Tensor, quantizer: torch.nn.Module) -> None:
         self.shape = weight.shape
+        self._dim = weight.dim()
         self.quantization_context = types.SimpleNamespace(quantization_params=types.SimpleNamespace(granularity=quantizer.granularity))
+
+    def dim(self) -> int:
+        return self._dim
 
 
 def count_quantizers(model: LlamaModel) -> int:

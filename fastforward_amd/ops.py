@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import ctypes
 
-from typing import Sequence
+from typing import Any, Sequence
 
 import torch
 
@@ -196,6 +196,25 @@ def _workspace(nbytes: int, device: torch.device) -> torch.Tensor | None:
     if nbytes <= 0:
         return None
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+# Arrival counters of the split-K launches (ffq_linear_wq / ffq_mlp_gate_up_wq, include/ffq.h): zero before the first launch,
+# left zero by every launch, so ONE buffer per (device, stream) serves every call enqueued on that stream — launches of one
+# stream run in order, and a hipGraph captured on it replays against the same (still zero) buffer.
+_TICKETS: dict[tuple[int, int], torch.Tensor] = {}
+
+
+def _tickets(count: int, device: torch.device, stream: int) -> torch.Tensor | None:
+    if count <= 0:
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(stream or 0))
+    have = _TICKETS.get(key)
+    if have is None or have.numel() < count:
+        if have is not None and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the split-K ticket buffer would have to grow inside a hipGraph capture: run the shape once before capturing")
+        have = torch.zeros(max(count, 4096), dtype=torch.int32, device=device)
+        _TICKETS[key] = have
+    return have
 
 
 def quantize_dynamic_by_tile(
@@ -644,6 +663,7 @@ def linear_wq(
     out_dtype: torch.dtype | None = None,
     pack_block: int = 0,
     two_pass: bool | None = None,
+    split: int = 0,
 ) -> torch.Tensor | None:
     """A6, weight-only — ``F.linear(x, dequantize(w_codes))`` with the dequantization inside the GEMM's operand path
     (reference _gen/fallback.py:86-112: quantized weight, plain input).
@@ -654,7 +674,9 @@ def linear_wq(
     or N * K / group entries ([N, K / group] row-major: groups of `group` input channels, PerBlock(1, group, 0)).
     The weight the matrix cores see is bit for bit A2's bf16 result. ``two_pass``: None = the library's rule (from 4096
     tokens on A2 runs once per call into a scratch tensor and the GEMM streams that image), False = always convert inside
-    the GEMM, True = offer the scratch tensor regardless of M (the library still decides).
+    the GEMM, True = offer the scratch tensor regardless of M (the library still decides). ``split``: 0 = the library's plan
+    for cutting the K range of every output tile into slices when the launch has fewer tiles than the chip has CUs
+    (``ffq_linear_wq_split``), >= 1 forces that many slices (tests, tuning).
     Returns None when the kernel does not cover the problem (dtypes, K % 64, group % 64): the caller dequantizes and runs a
     float GEMM as the reference does."""
     packed = pack_block > 0
@@ -685,15 +707,37 @@ def linear_wq(
     bias_c = None if bias is None else bias.detach().contiguous()
     lib, stream = _prepare(xc, wc, sc, of, bias_c)
     out = torch.empty((*xc.shape[:-1], N), dtype=out_dtype, device=xc.device)
-    nbytes = 0 if two_pass is False else (N * K * 2 if two_pass else lib.ffq_linear_wq_workspace_bytes(M, N, K))
+    nbytes, tickets = _wq_scratch(lib, M, N, K, False, two_pass, split, xc.device, stream)
     ws = _workspace(nbytes, xc.device)
     lib.check(
         lib.ffq_linear_wq(
             _ptr(xc), _tag(xc.dtype), _ptr(wc), _tag(wc.dtype), int(pack_block), _ptr(sc), _ptr(of), sc.numel(), group,
-            _ptr(bias_c), _tag(bias_c.dtype) if bias_c is not None else 0, _ptr(out), _tag(out_dtype), M, N, K, _ptr(ws), nbytes, stream,
+            _ptr(bias_c), _tag(bias_c.dtype) if bias_c is not None else 0, _ptr(out), _tag(out_dtype), M, N, K, _ptr(ws), nbytes,
+            _ptr(tickets), int(split), stream,
         )
     )
     return out
+
+
+_WQ_SLAB_BYTES = 32 * 8 * 64 * 16  # one (tile, K slice) unit's partial accumulators (csrc/ffq_wlinear.hip: WL_UNIT_SLAB)
+
+
+def _wq_scratch(lib: Any, M: int, N: int, K: int, mlp: bool, two_pass: bool | None, split: int, device: torch.device, stream: int) -> tuple[int, torch.Tensor | None]:
+    """(workspace bytes, ticket buffer) of a weight-only GEMM launch: the split-K slabs of the plan (or of a forced `split`) at the
+    front, the bf16 image(s) of the two-pass form behind them."""
+    tickets = int(lib.ffq_linear_wq_tickets(M, N, K, int(mlp)))  # two per tile
+    tiles = tickets // 2
+    plan = int(lib.ffq_linear_wq_split(M, N, K, int(mlp)))
+    use = max(1, int(split) if split > 0 else plan)
+    slabs = tiles * use * _WQ_SLAB_BYTES if use > 1 else 0
+    if two_pass is False:
+        image = 0
+    elif two_pass:
+        image = (2 if mlp else 1) * N * K * 2
+    else:  # the library's rule: its figure minus the slabs of its own plan
+        full = int(lib.ffq_mlp_gate_up_wq_workspace_bytes(M, N, K) if mlp else lib.ffq_linear_wq_workspace_bytes(M, N, K))
+        image = full - (tiles * plan * _WQ_SLAB_BYTES if plan > 1 else 0)
+    return slabs + image, (_tickets(tickets, device, stream) if use > 1 else None)
 
 
 def mlp_gate_up_wq(
@@ -707,6 +751,7 @@ def mlp_gate_up_wq(
     group: int | None = None,
     pack_block: int = 0,
     two_pass: bool | None = None,
+    split: int = 0,
 ) -> torch.Tensor | None:
     """``silu(gate_proj(x)) * up_proj(x)`` of a weight-only quantized MLP (reference quantized_llama/mlp.py:30-40 over
     _gen/fallback.py:86-112) in one launch: bit for bit ``silu_mul_quantize(linear_wq(x, gate), linear_wq(x, up), want_product=True)``
@@ -737,12 +782,12 @@ def mlp_gate_up_wq(
         raise RuntimeError("gate and up parameters differ in count")
     lib, stream = _prepare(xc, gc, uc, gs, go, us, uo)
     out = torch.empty((*xc.shape[:-1], N), dtype=torch.bfloat16, device=xc.device)
-    nbytes = 0 if two_pass is False else (2 * N * K * 2 if two_pass else lib.ffq_mlp_gate_up_wq_workspace_bytes(M, N, K))
+    nbytes, tickets = _wq_scratch(lib, M, N, K, True, two_pass, split, xc.device, stream)
     ws = _workspace(nbytes, xc.device)
     lib.check(
         lib.ffq_mlp_gate_up_wq(
             _ptr(xc), _tag(xc.dtype), _ptr(gc), _ptr(uc), _tag(gc.dtype), int(pack_block), _ptr(gs), _ptr(go), _ptr(us), _ptr(uo),
-            gs.numel(), group, _ptr(out), M, N, K, _ptr(ws), nbytes, stream,
+            gs.numel(), group, _ptr(out), M, N, K, _ptr(ws), nbytes, _ptr(tickets), int(split), stream,
         )
     )
     return out
@@ -843,8 +888,8 @@ def quantize_rows_batch(
         return None
     sc, of = [], []
     for w, s, o in zip(weights, scales, offsets):
-        if w.dim() != 2 or w.dtype != torch.bfloat16 or not w.is_contiguous() or w.shape[1] % 16 or (w.numel() // 16) % 256:
-            return None
+        if w.dim() != 2 or w.dtype != torch.bfloat16 or not w.is_contiguous() or w.shape[1] % 16 or (w.numel() // 16) % 256 or w.data_ptr() % 16:
+            return None  # (a 16-byte-misaligned view: the member-by-member kernels take it)
         s32 = s.detach().reshape(-1).to(torch.float32).contiguous()
         o32 = None if o is None else o.detach().reshape(-1).to(torch.float32).contiguous()
         if s32.numel() != w.shape[0] or (o32 is not None and o32.numel() != w.shape[0]):

@@ -12,26 +12,47 @@ synchronisation:
     bump the version counters of what they write: ops.rope_, ops.add_rmsnorm_quantize(sum_inplace=True));
   * "equal parameters" means the same tensors at the same versions, or a verdict of ``torch.equal`` read ONCE on the host for
     a pair of parameter versions that had both been seen before — parameters a range estimator rewrites on every step never
-    reach that point — and never while a hipGraph is being captured (then: no reuse, same result, one launch more).
+    reach that point — and never while a hipGraph is being captured (then: no reuse, same result, one launch more);
+  * the slot exists only INSIDE a ``sibling_quantizers()`` block — opened by this package's own module forwards around the
+    sibling calls (q / k / v in QuantizedLlamaAttention, gate / up in QuantizedLlamaMLP, the same pairs in the fused forwards)
+    and emptied when the outermost block ends. A version counter cannot see a write through ``tensor.data`` (or through a raw
+    pointer of somebody else's kernel); between two sibling calls there is only this package's own code, so no such write can
+    fall between a ``remember`` and its ``lookup``; everywhere else every quantizer call launches A1, as the reference does
+    (nn/linear.py:32-39). Codes produced before a hipGraph capture began are never handed out during it (the graph would
+    lack the A1 launch and replay stale codes) and the other way round; the slot is per thread.
 """
 
 from __future__ import annotations
 
+import contextlib
+import threading
 import weakref
 
-from typing import Any
+from typing import Any, Iterator
 
 import torch
 
 
-class RecentActivationCodes:
+class RecentActivationCodes(threading.local):
     def __init__(self) -> None:
         self._data: weakref.ref | None = None
         self._key: tuple[Any, ...] = ()
         self._entries: list[tuple[Any, ...]] = []
         self._seen: dict[int, tuple[weakref.ref, int]] = {}  # parameter tensor -> version at its last sighting
         self._verdicts: dict[tuple[int, int, int, int], tuple[weakref.ref, weakref.ref, bool]] = {}
+        self._depth = 0
         self.hits = 0
+
+    @contextlib.contextmanager
+    def scope(self) -> Iterator[None]:
+        """Sibling quantizer calls on one activation: reuse is allowed inside, the slot is emptied on the way out."""
+        self._depth += 1
+        try:
+            yield
+        finally:
+            self._depth -= 1
+            if self._depth == 0:
+                self.clear()
 
     @staticmethod
     def _eligible(data: torch.Tensor, params: Any) -> bool:
@@ -76,10 +97,10 @@ class RecentActivationCodes:
 
     @staticmethod
     def _data_key(data: torch.Tensor) -> tuple[Any, ...]:
-        return (data._version, data.data_ptr(), tuple(data.shape), data.dtype)
+        return (data._version, data.data_ptr(), tuple(data.shape), data.dtype, torch.cuda.is_current_stream_capturing())
 
     def lookup(self, data: torch.Tensor, params: Any, tile: Any, container: torch.dtype) -> torch.Tensor | None:
-        if not self._eligible(data, params):
+        if self._depth == 0 or not self._eligible(data, params):
             return None
         stable_scale, stable_offset = self._stable(params.scale), self._stable(params.offset)  # both sightings recorded
         if self._data is None or self._data() is not data or self._key != self._data_key(data):
@@ -95,7 +116,7 @@ class RecentActivationCodes:
         return None
 
     def remember(self, data: torch.Tensor, params: Any, tile: Any, container: torch.dtype, raw: torch.Tensor) -> None:
-        if not self._eligible(data, params):
+        if self._depth == 0 or not self._eligible(data, params):
             return
         key = self._data_key(data)
         if self._data is None or self._data() is not data or self._key != key:
@@ -108,3 +129,4 @@ class RecentActivationCodes:
 
 
 RECENT = RecentActivationCodes()
+sibling_quantizers = RECENT.scope

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define FFQ_MAX_DIMS 8
-#define FFQ_ABI_VERSION 6
+#define FFQ_ABI_VERSION 7
 
 typedef enum ffq_status {
   FFQ_OK = 0,
@@ -209,18 +209,30 @@ int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum,
  * block_sizes=group, per_channel_dims=0) (quantization/granularity.py:159-216; config 4: group 128).
  * The codes are dequantized with A2's arithmetic, (float(q) + round_half_even(o)) * s in fp32 rounded once to bf16 — the B
  * operand of the bf16 MFMA is bit for bit the reference's dequantized weight, accumulation is fp32; only the summation order
- * differs from F.linear. One launch converts the codes once per 256-row tile on their way into LDS; with `workspace` of at
- * least ffq_linear_wq_workspace_bytes() (non-zero from 4096 tokens on: N * K * 2 bytes) the weight is dequantized once per
- * CALL by A2 into that workspace and the GEMM streams the bf16 image — same operands, same results up to summation order
- * (identical tile walk: bit-identical in fact), faster at large M. workspace may be NULL.
+ * differs from F.linear. One launch converts the codes once per 256-row tile on their way into LDS; with enough `workspace`
+ * behind the slabs (below) and from 4096 tokens on the weight is dequantized once per CALL by A2 into it and the GEMM streams
+ * the bf16 image — same operands, same tile walk: bit-identical, faster at large M.
+ * Split-K (ABI 7): the kernel is one persistent block per CU on 256 x 256 output tiles; a launch with fewer tiles than CUs
+ * (2048 tokens x a 4096-wide projection: 128) cuts every tile's K range into ffq_linear_wq_split() slices whose fp32 partial
+ * sums meet in `workspace` and are added in slice order by the last slice to arrive — no token count is left to a vendor GEMM.
+ * The split is a pure function of (M, N, K): it fixes the summation order, i.e. results are reproducible call to call.
+ *   workspace  [ffq_linear_wq_workspace_bytes()]: split-K slabs first, the two-pass image behind them. May be smaller or NULL:
+ *              the launch then runs without the part that does not fit (never fails for lack of scratch).
+ *   tickets    ffq_linear_wq_tickets() int32 counters, ZERO before the first launch that uses the buffer; every launch
+ *              leaves them zero (keep one buffer per stream). NULL: no split.
+ *   split      0 = the library's plan; >= 1 forces that many slices (tests, tuning); FFQ_ERR_ARG if the scratch for a forced
+ *              split is missing.
  * ffq_linear_wq_supported() == 0 (K % 64 != 0, K < 128, other dtypes, group % 64 != 0): the caller dequantizes (A2) and
  * runs a float GEMM, as the reference does.
  */
 int ffq_linear_wq_supported(int x_dt, int w_dt, int out_dt, int64_t M, int64_t N, int64_t K, int64_t group, int64_t pack_block);
+int64_t ffq_linear_wq_split(int64_t M, int64_t N, int64_t K, int mlp);   /* mlp != 0: the plan of ffq_mlp_gate_up_wq */
+int64_t ffq_linear_wq_tickets(int64_t M, int64_t N, int64_t K, int mlp);
 size_t ffq_linear_wq_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, int64_t pack_block, const float* w_scale,
                   const float* w_offset, int64_t scale_numel, int64_t group, const void* bias, int bias_dt, void* out,
-                  int out_dt, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+                  int out_dt, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, int32_t* tickets,
+                  int64_t split, void* stream);
 
 /*
  * The MLP front half of a WEIGHT-ONLY quantized Llama (docs/examples/doc_helpers/quantized_llama/mlp.py:30-40 with plain bf16
@@ -228,14 +240,16 @@ int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, int64_
  * summation order), then bf16(silu(bf16(gate))) * bf16(up) rounded to bf16 —
  *   out == product of ffq_silu_mul_quantize(ffq_linear_wq(x, gate), ffq_linear_wq(x, up))    bit for bit,
  * without the two [M, N] bf16 projections ever visiting HBM. Both weights share dtype, packing, granularity (`scale_numel`,
- * `group`); offsets both or neither; N % 128 == 0; otherwise as ffq_linear_wq. `out` is [M, N] bf16. With a workspace of
- * ffq_mlp_gate_up_wq_workspace_bytes() (both bf16 images) the two-pass form runs from 4096 tokens on.
+ * `group`); offsets both or neither; N % 128 == 0; otherwise as ffq_linear_wq. `out` is [M, N] bf16. `workspace`
+ * (ffq_mlp_gate_up_wq_workspace_bytes(): split-K slabs, then both bf16 images of the two-pass form from 4096 tokens on),
+ * `tickets` (ffq_linear_wq_tickets(..., 1)) and `split` as in ffq_linear_wq; the equality above holds bit for bit when both
+ * sides run the same split (ffq_linear_wq_split(M, N, K, 1) vs (..., 0)), else to one rounding of the fp32 sums.
  */
 size_t ffq_mlp_gate_up_wq_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int ffq_mlp_gate_up_wq(const void* x, int x_dt, const void* gate_codes, const void* up_codes, int w_dt, int64_t pack_block,
                        const float* gate_scale, const float* gate_offset, const float* up_scale, const float* up_offset,
                        int64_t scale_numel, int64_t group, void* out, int64_t M, int64_t N, int64_t K, void* workspace,
-                       size_t workspace_bytes, void* stream);
+                       size_t workspace_bytes, int32_t* tickets, int64_t split, void* stream);
 
 /*
  * Producer-fused A1 (ABI version 2). In the reference's quantized Llama helpers

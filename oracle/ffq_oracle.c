@@ -703,6 +703,9 @@ int ffq_linear_wq_supported(int x_dt, int w_dt, int out_dt, int64_t M, int64_t N
 }
 
 size_t ffq_linear_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) { (void)M; (void)N; (void)K; return 0; }
+/* the restatement sums every output in double: no tiles, no K slices */
+int64_t ffq_linear_wq_split(int64_t M, int64_t N, int64_t K, int mlp) { (void)M; (void)N; (void)K; (void)mlp; return 1; }
+int64_t ffq_linear_wq_tickets(int64_t M, int64_t N, int64_t K, int mlp) { (void)M; (void)N; (void)K; (void)mlp; return 0; }
 
 /* code (n, k) of a weight stored one code per byte, or packed two per byte as ffq_pack_int4 writes a row of K codes with
  * block `pack_block` (_packing.py:44-53: byte j of a block = code j | code (j + block / 2) << 4, both + 8) */
@@ -715,8 +718,9 @@ static double wq_code(const void* w_codes, int64_t pack_block, int64_t n, int64_
 
 int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, int64_t pack_block, const float* w_scale,
                   const float* w_offset, int64_t scale_numel, int64_t group, const void* bias, int bias_dt, void* out,
-                  int out_dt, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
-  (void)stream; (void)workspace; (void)workspace_bytes;
+                  int out_dt, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, int32_t* tickets,
+                  int64_t split, void* stream) {
+  (void)stream; (void)workspace; (void)workspace_bytes; (void)tickets; (void)split;
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
   if (!x || !w_codes || !w_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
@@ -1240,8 +1244,8 @@ size_t ffq_mlp_gate_up_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) { (vo
 int ffq_mlp_gate_up_wq(const void* x, int x_dt, const void* gate_codes, const void* up_codes, int w_dt, int64_t pack_block,
                        const float* gate_scale, const float* gate_offset, const float* up_scale, const float* up_offset,
                        int64_t scale_numel, int64_t group, void* out, int64_t M, int64_t N, int64_t K, void* workspace,
-                       size_t workspace_bytes, void* stream) {
-  (void)workspace; (void)workspace_bytes;
+                       size_t workspace_bytes, int32_t* tickets, int64_t split, void* stream) {
+  (void)workspace; (void)workspace_bytes; (void)tickets; (void)split;
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
   if (!x || !gate_codes || !up_codes || !gate_scale || !up_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
@@ -1251,8 +1255,8 @@ int ffq_mlp_gate_up_wq(const void* x, int x_dt, const void* gate_codes, const vo
   void* g = malloc(bytes);
   void* u = malloc(bytes);
   if (!g || !u) { free(g); free(u); return fail(FFQ_ERR_ARG, "out of memory"); }
-  int rc = ffq_linear_wq(x, x_dt, gate_codes, w_dt, pack_block, gate_scale, gate_offset, scale_numel, group, NULL, 0, g, FFQ_BF16, M, N, K, NULL, 0, stream);
-  if (rc == FFQ_OK) rc = ffq_linear_wq(x, x_dt, up_codes, w_dt, pack_block, up_scale, up_offset, scale_numel, group, NULL, 0, u, FFQ_BF16, M, N, K, NULL, 0, stream);
+  int rc = ffq_linear_wq(x, x_dt, gate_codes, w_dt, pack_block, gate_scale, gate_offset, scale_numel, group, NULL, 0, g, FFQ_BF16, M, N, K, NULL, 0, NULL, 0, stream);
+  if (rc == FFQ_OK) rc = ffq_linear_wq(x, x_dt, up_codes, w_dt, pack_block, up_scale, up_offset, scale_numel, group, NULL, 0, u, FFQ_BF16, M, N, K, NULL, 0, NULL, 0, stream);
   if (rc == FFQ_OK) rc = ffq_silu_mul_quantize(g, u, FFQ_BF16, M * N, out, NULL, stream);
   free(g); free(u);
   return rc;

@@ -312,6 +312,102 @@ def test_module_graph_one_launch_mlp_and_attention_epilogue_are_exact(hip_backen
     assert taken["mlp"] == 0
 
 
+def check_hooks_fire(device):
+    """User hooks on modules the one-pass routes would bypass (decoder layer, down_proj, o_proj, the norms, every input
+    quantizer): each fires once per forward, as on the reference's module graph (strict_quantization.py:67-68 and
+    export/_io_capture.py:78 hang such hooks), and the logits are those of the hook-free forward."""
+    cfg = llama.LlamaConfig(hidden_size=256, intermediate_size=512, num_layers=2, num_heads=2, num_kv_heads=1, vocab_size=512)
+    dtype = torch.bfloat16 if device == "cuda" else torch.float32
+    model = llama.build_model(cfg, device, dtype, seed=5, std=0.05)
+    llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
+    gen = torch.Generator(device=device).manual_seed(3)
+    ids = torch.randint(0, cfg.vocab_size, (2, 64), device=device, generator=gen)
+    llama.calibrate(model, [ids])
+    with torch.no_grad(), ff.strict_quantization(False):
+        for _ in range(3):
+            plain = model(ids, logits=True)
+        fired: dict[str, int] = {}
+        seen: dict[str, torch.Tensor] = {}
+        handles = []
+
+        def count(name):
+            return lambda module, args, output: fired.__setitem__(name, fired.get(name, 0) + 1)
+
+        layer0, layer1 = model.layers[0], model.layers[1]
+        watched = {"layer0": layer0, "layer1.down_proj": layer1.mlp.down_proj, "layer0.o_proj": layer0.self_attn.o_proj, "layer1.input_layernorm": layer1.input_layernorm,
+                   "layer0.post_attention_layernorm": layer0.post_attention_layernorm, "norm": model.norm, "layer0.gate_proj": layer0.mlp.gate_proj}
+        for name, module in watched.items():
+            handles.append(module.register_forward_hook(count(name)))
+        def record(name):
+            def hook(module, args, output):
+                fired[name] = fired.get(name, 0) + 1
+                seen[name] = output.raw_data
+            return hook
+
+        for name, q in ff.nn.named_quantizers(model):
+            if name.endswith("input_quantizer"):
+                handles.append(q.register_forward_hook(record(name)))
+        pre = []
+        handles.append(layer1.register_forward_pre_hook(lambda module, args: pre.append(args[0].shape)))
+        for _ in range(4):
+            hooked = model(ids, logits=True)
+        for h in handles:
+            h.remove()
+        for name in watched:
+            assert fired.get(name, 0) == 4, (name, fired)
+        quantizer_names = [n for n, _ in ff.nn.named_quantizers(model) if n.endswith("input_quantizer")]
+        assert len(quantizer_names) == 14 and all(fired.get(n, 0) == 4 for n in quantizer_names), fired
+        assert all(seen[n].dtype == torch.int8 for n in quantizer_names) and len(pre) == 4
+        again = model(ids, logits=True)  # hooks gone: the one-pass routes are back
+    assert torch.equal(again, plain)
+    torch.testing.assert_close(hooked.float(), plain.float(), rtol=0, atol=0.02 * float(plain.float().std()) + 1e-3)
+
+
+def test_user_hooks_fire_on_the_module_graph(oracle_backend):
+    check_hooks_fire("cpu")
+
+
+@pytest.mark.gpu
+def test_user_hooks_fire_on_the_module_graph_on_gpu(hip_backend):
+    check_hooks_fire("cuda")
+
+
+@pytest.mark.gpu
+def test_a_set_residual_quantizer_is_never_handed_on_as_a_pending_stream(hip_backend):
+    """attn_res_act_quantizer set on a layer whose output slot and successor are stubs: the layer's residual stream is a
+    QuantizedTensor, so the un-added MLP term must NOT be deferred to the next RMSNorm launch (it would normalise raw codes or
+    raise on the dtype); the module graph computes what the eager chains compute."""
+    cfg = llama.LlamaConfig(hidden_size=256, intermediate_size=512, num_layers=3, num_heads=2, num_kv_heads=1, vocab_size=512)
+    model = llama.build_model(cfg, "cuda", torch.bfloat16, seed=9, std=0.05)
+    llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
+    for container in (torch.int8, None):
+        model.layers[1].attn_res_act_quantizer = ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=container, device="cuda")
+        ids = torch.randint(0, cfg.vocab_size, (2, 64), device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+        llama.calibrate(model, [ids])
+        with torch.no_grad(), ff.strict_quantization(False):
+            got = model(ids, logits=True)
+            with llama.eager_modules():
+                want = model(ids, logits=True)
+        assert got.dtype == want.dtype and bool(torch.isfinite(got.float()).all())
+        torch.testing.assert_close(got.float(), want.float(), rtol=0, atol=0.05 * float(want.float().std()) + 1e-3)
+
+
+def test_fused_forward_refuses_weight_granularities_the_gemm_would_misread(oracle_backend):
+    """PerChannel(1) on the square q_proj weight has as many parameters as per-output-channel would: FusedForward must name it
+    a problem instead of quantizing per row (reference granularity.py:130-134: the channel dim decides, not the count)."""
+    cfg = llama.LlamaConfig.tiny()
+    model = llama.build_model(cfg, "cpu", torch.bfloat16, seed=2)
+    llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
+    q_proj = model.layers[0].self_attn.q_proj
+    q_proj.weight_quantizer = ff.nn.LinearQuantizer(8, granularity=ff.PerChannel(1), quantized_dtype=torch.int8)
+    llama.calibrate(model, [torch.randint(0, cfg.vocab_size, (1, 16))])
+    assert q_proj.weight_quantizer.scale.numel() == q_proj.weight.shape[0]  # the count alone cannot tell
+    problems = llama.FusedForward.unsupported(model)
+    assert any("q_proj" in p and "granularity" in p for p in problems), problems
+    with pytest.raises(ff.exceptions.QuantizationError):
+        llama.FusedForward(model)
+
+
 def check_fused_calibration(fixture, device):
     """Calibrating through FusedCalibrationForward (every quantizer's own forward with its estimator override, fused
     producers in between) gives the module graph's ranges: weight quantizers exactly, activation ranges within the

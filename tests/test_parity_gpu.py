@@ -19,7 +19,7 @@ import fastforward_amd as ff
 import parity_cases
 
 from conftest import load_oracle, use_backend
-from fastforward_amd import llama, ops
+from fastforward_amd import _cabi, _native, llama, ops
 from helpers import mismatch_report, same_with_nan
 
 pytestmark = pytest.mark.gpu
@@ -796,8 +796,10 @@ def test_weight_only_gate_up_launch_is_the_two_linears_and_silu_mul(m, n, k, gro
     gen = torch.Generator().manual_seed(m + k)
     x = (torch.randn(m, k, generator=gen) * 1.5).to(torch.bfloat16).to(DEV)
     x[0, :] *= 40.0  # gate values outside the table's window on one row: the patch path
-    gate = ops.linear_wq(x, gc, gs, go, group=group, two_pass=False)
-    up = ops.linear_wq(x, uc, us, uo, group=group, two_pass=False)
+    # both sides on the K slices the one-launch form plans for itself: the split fixes the fp32 summation order (include/ffq.h)
+    split = int(_native.library().ffq_linear_wq_split(m, n, k, 1))
+    gate = ops.linear_wq(x, gc, gs, go, group=group, two_pass=False, split=split)
+    up = ops.linear_wq(x, uc, us, uo, group=group, two_pass=False, split=split)
     want, _ = ops.silu_mul_quantize(gate, up, (), want_product=True)
     assert float(want.float().abs().max()) > 0
     for (label, kwargs, gw), (_, _, uw) in zip(_wq_forms(gc, group, bits, m), _wq_forms(uc, group, bits, m)):
@@ -810,6 +812,53 @@ def test_weight_only_gate_up_launch_is_the_two_linears_and_silu_mul(m, n, k, gro
     assert ops.mlp_gate_up_wq(x, gc[:64], uc[:64], gs[: 64 * (k // group)], None if go is None else go[: 64 * (k // group)], us[: 64 * (k // group)],
                               None if uo is None else uo[: 64 * (k // group)], group=group) is None
     assert ops.mlp_gate_up_wq(x.float(), gc, uc, gs, go, us, uo, group=group) is None
+
+
+@pytest.mark.parametrize("m,n,k,group,bits", [(1, 256, 2048, 2048, 8), (40, 520, 1024, 128, 4), (300, 256, 1536, 1536, 8), (515, 770, 2048, 128, 4), (2048, 1024, 4096, 4096, 8)])
+def test_weight_only_linear_split_k_slices_sum_in_a_fixed_order(m, n, k, group, bits):
+    """Split-K (fewer tiles than CUs: every tile's K range cut into slices, fp32 partial sums added in slice order by the last
+    slice to arrive): every forced split — incl. uneven slices and more units than CUs — stays within one output rounding of the
+    float64 product, repeats bit for bit launch after launch (no arrival-order dependence), leaves the ticket buffer zero, and
+    where the sums are order-independent (small integers, power-of-two scales) ALL splits give the same bits."""
+    gen = torch.Generator().manual_seed(m + n + k)
+    codes, scale, off = _wq_case(n, k, group, bits, True, seed=m + k)
+    x = torch.randn(m, k, generator=gen).to(torch.bfloat16).to(DEV)
+    w_hat = ops.dequantize_by_tile(codes, scale, (1, group), off, torch.bfloat16)
+    ref = x.double() @ w_hat.double().t()
+    lib = _native.library()
+    plan = int(lib.ffq_linear_wq_split(m, n, k, 0))
+    # all units of a tile wait for each other: a split is admitted while tiles * split <= CUs (and slices keep >= 2 super-steps)
+    most = min(torch.cuda.get_device_properties(0).multi_processor_count // (int(lib.ffq_linear_wq_tickets(m, n, k, 0)) // 2), (k // 64) // 2, 32)
+    assert 1 <= plan <= most
+    packed = ops.pack_int4(codes, block=128) if bits == 4 else None
+    for split in sorted({1, 2, 3, 5, 8, 16, plan}):
+        if split > most:
+            continue
+        y = ops.linear_wq(x, codes, scale, off, group=group, split=split)
+        torch.testing.assert_close(y.double(), ref, rtol=2.0**-8, atol=1e-5 * float(ref.abs().max()) + 1e-6 * k, msg=lambda msg: f"split {split}: {msg}")
+        for _ in range(3):
+            assert torch.equal(ops.linear_wq(x, codes, scale, off, group=group, split=split), y), f"split {split}: two launches differ"
+        if packed is not None:
+            assert torch.equal(ops.linear_wq(x, packed, scale, off, group=group, pack_block=128, split=split), y), f"split {split}: packed nibbles differ"
+        y32 = ops.linear_wq(x, codes, scale, off, group=group, split=split, out_dtype=torch.float32)
+        assert torch.equal(y32.to(torch.bfloat16), y), f"split {split}: fp32 output rounds to something else"
+    assert all(int(t.abs().sum()) == 0 for t in ops._TICKETS.values()), "a launch left tickets behind"
+    # order-independent sums: integer activations in [-4, 4], scales 2^-3, integer offsets -> every partial sum is exact in fp32
+    xi = torch.randint(-4, 5, (m, k), generator=gen).to(torch.bfloat16).to(DEV)
+    s2 = torch.full_like(scale, 0.125)
+    o2 = None if off is None else torch.round(off)
+    exact = (xi.double() @ ops.dequantize_by_tile(codes, s2, (1, group), o2, torch.float32).double().t()).to(torch.float32)
+    for split in (1, 2, 3, 5, 8, 16):
+        if split <= most:
+            assert torch.equal(ops.linear_wq(xi, codes, s2, o2, group=group, split=split, out_dtype=torch.float32), exact), f"split {split}"
+    # a forced split without scratch, or one whose units could not all be resident, is refused, never silently changed
+    with pytest.raises(Exception):
+        ops.linear_wq(x, codes, scale, off, group=group, split=most + 1)
+    out = torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    if most >= 2:
+        rc = lib.ffq_linear_wq(x.data_ptr(), int(_cabi.DType.BF16), codes.data_ptr(), int(_cabi.DType.I8), 0, scale.data_ptr(), None, scale.numel(), group, None, 0,
+                               out.data_ptr(), int(_cabi.DType.BF16), m, n, k, None, 0, None, 2, None)
+        assert rc != 0
 
 
 def test_weight_only_gate_up_against_the_oracle_composition(oracle_lib):
@@ -827,7 +876,7 @@ def test_weight_only_gate_up_against_the_oracle_composition(oracle_lib):
     out = torch.empty(m, n, dtype=torch.bfloat16)
     host = [t.cpu().contiguous() for t in (gc, uc, gs, go, us, uo)]
     rc = lib.ffq_mlp_gate_up_wq(x.data_ptr(), int(_cabi.DType.BF16), host[0].data_ptr(), host[1].data_ptr(), int(_cabi.DType.I8), 0, host[2].data_ptr(), host[3].data_ptr(),
-                                host[4].data_ptr(), host[5].data_ptr(), host[2].numel(), group, out.data_ptr(), m, n, k, None, 0, None)
+                                host[4].data_ptr(), host[5].data_ptr(), host[2].numel(), group, out.data_ptr(), m, n, k, None, 0, None, 0, None)
     assert rc == 0
     # the GEMM accumulates in fp32 in its own order: a projection may land on the neighbouring bf16 -> compare loosely, and
     # exactly where the HIP projections equal the oracle's
@@ -913,38 +962,85 @@ def test_grid_error_by_tile_kernel_covers_every_tiling(shape, tile, dtype):
 def test_equal_quantizers_share_one_launch_on_the_same_activation():
     """q_proj / k_proj / v_proj quantize the same hidden state with their own input quantizers (reference nn/linear.py:33);
     once their parameters have stopped changing and are known to be equal, the later ones reuse the first one's codes
-    (quantization/affine/_memo.py) — same bits, fewer launches; any write to the tensor or to a parameter ends the reuse."""
-    from fastforward_amd.quantization.affine._memo import RECENT
+    (quantization/affine/_memo.py) — same bits, fewer launches; any write to the tensor or to a parameter ends the reuse.
+    Reuse exists only inside ``sibling_quantizers()`` (this package's module forwards open it around the sibling calls)."""
+    from fastforward_amd.quantization.affine._memo import RECENT, sibling_quantizers
 
     torch.manual_seed(5)
     x = torch.randn(4, 64, 256, device=DEV, dtype=torch.bfloat16)
     qs = [ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=torch.int8, device=DEV) for _ in range(3)]
     with torch.no_grad():
-        with ff.estimate_ranges(torch.nn.ModuleList(qs), ff.range_setting.running_minmax):
+        with ff.estimate_ranges(torch.nn.ModuleList(qs), ff.range_setting.running_minmax), sibling_quantizers():
             for q in qs:
                 q(x)  # calibration: parameters rewritten on every call, never "stable" -> no host reads, no reuse
         want = ops.quantize_by_tile(x, qs[0].scale, x.shape, 8, torch.int8, qs[0].offset)
-        RECENT.clear()
         hits = RECENT.hits
-        first = [q(x).raw_data for q in qs]       # the final versions were sighted by the last calibration call: verdicts may be read here
-        second = [q(x).raw_data for q in qs]
-        third = [q(x).raw_data for q in qs]
+        rounds = []
+        for _ in range(3):  # the final versions were sighted by the last calibration call: verdicts may be read in the first round
+            with sibling_quantizers():
+                rounds.append([q(x).raw_data for q in qs])
+        third = rounds[2]
         assert RECENT.hits >= hits + 4 and third[1].data_ptr() == third[0].data_ptr() == third[2].data_ptr()
-        for codes in first + second + third:
+        for codes in rounds[0] + rounds[1] + rounds[2]:
             assert torch.equal(codes, want)
+        assert RECENT._data is None and not RECENT._entries, "the slot outlived its block"
+        # outside a block every call launches A1 (the reference's behaviour)
+        before = RECENT.hits
+        loose = [q(x).raw_data for q in qs]
+        assert RECENT.hits == before and len({c.data_ptr() for c in loose}) == 3 and all(torch.equal(c, want) for c in loose)
         # a new tensor, a write autograd can see, a raw-pointer write of this package: all miss
         y = x.clone()
-        before = RECENT.hits
-        a = qs[0](y).raw_data
-        y.mul_(0.5)
-        b = qs[1](y).raw_data
+        with sibling_quantizers():
+            a = qs[0](y).raw_data
+            y.mul_(0.5)
+            b = qs[1](y).raw_data
         assert RECENT.hits == before and torch.equal(b, ops.quantize_by_tile(y, qs[1].scale, y.shape, 8, torch.int8, qs[1].offset)) and not torch.equal(a, b)
         # a parameter that moves: the other quantizers no longer share with it, and its own codes follow the new range
         lo, hi = qs[2].quantization_range
         qs[2].quantization_range = (lo * 0.5, hi * 0.5)
-        c = [q(x).raw_data for q in qs]
+        with sibling_quantizers():
+            c = [q(x).raw_data for q in qs]
         assert torch.equal(c[0], want) and torch.equal(c[1], want) and not torch.equal(c[2], want)
         assert torch.equal(c[2], ops.quantize_by_tile(x, qs[2].scale, x.shape, 8, torch.int8, qs[2].offset))
+
+
+def test_a_write_through_dot_data_between_two_quantizer_calls_gets_fresh_codes():
+    """``h.data.mul_(2)`` moves neither ``h._version`` nor ``h.data_ptr()``: a cache keyed on them would hand the second of two
+    equal quantizers the first one's codes where the reference re-quantizes (nn/linear.py:32-39). The memo only lives inside the
+    package's own sibling blocks, so user code between two module calls always sees A1 of the CURRENT bytes — on bare
+    quantizers and on the module graph (two forwards of a quantized Llama around a ``.data`` write of the embedding output)."""
+    from fastforward_amd.quantization.affine._memo import RECENT
+
+    torch.manual_seed(6)
+    h = torch.randn(2, 64, 256, device=DEV, dtype=torch.bfloat16)
+    qs = [ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=torch.int8, device=DEV) for _ in range(2)]
+    with torch.no_grad():
+        for q in qs:
+            q.quantization_range = (torch.tensor([-4.0], device=DEV), torch.tensor([4.0], device=DEV))
+        for _ in range(3):  # parameters sighted, verdicts readable: everything a version-keyed cache would need to hit
+            first, second = qs[0](h).raw_data, qs[1](h).raw_data
+        assert torch.equal(first, second)
+        version, pointer = h._version, h.data_ptr()
+        first = qs[0](h).raw_data.clone()
+        h.data.mul_(2)
+        assert h._version == version and h.data_ptr() == pointer  # invisible to the counters
+        second = qs[1](h).raw_data
+        assert torch.equal(second, ops.quantize_by_tile(h, qs[1].scale, h.shape, 8, torch.int8, qs[1].offset)) and not torch.equal(second, first)
+        # module graph: the same model, the same ids, the embedding table scaled through .data between the two forwards
+        cfg = llama.LlamaConfig.tiny()
+        model = llama.quantize_llama(llama.build_model(cfg, DEV, seed=3))
+        ids = torch.randint(0, cfg.vocab_size, (2, 64), device=DEV)
+        llama.calibrate(model, [ids])
+        with ff.strict_quantization(False):
+            for _ in range(2):
+                before = model(ids)
+            model.embed_tokens.weight.data.mul_(3.0)
+            after = model(ids)
+            with llama.eager_modules():
+                want = model(ids)
+        assert not torch.equal(before, after)
+        torch.testing.assert_close(after.float(), want.float(), rtol=0.05, atol=0.05 * float(want.float().abs().max()))
+        assert RECENT._data is None
 
 
 def test_batched_weight_quantization_equals_member_by_member():
