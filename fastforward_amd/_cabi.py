@@ -184,8 +184,10 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_quantize_rows_rowsum": (_i, [_vp, _i, _vp, _vp, _i64, _i64, _d, _vp, _vp, _vp]),
     "ffq_linear_wq_supported": (_i, [_i, _i, _i, _i64, _i64, _i64, _i64, _i64]),
     "ffq_linear_wq_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "ffq_linear_wq_multi": (_i, [_vp, _i, _i, _vp, _i, _i64, _vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _vp, _sz, _vp, _i64, _vp]),
     "ffq_linear_wq_split": (_i64, [_i64, _i64, _i64, _i]),
     "ffq_linear_wq_tickets": (_i64, [_i64, _i64, _i64, _i]),
+    "ffq_linear_wq_slab_bytes": (_sz, [_i64, _i64, _i64, _i, _i64]),
     "ffq_linear_wq": (_i, [_vp, _i, _vp, _i, _i64, _vp, _vp, _i64, _i64, _vp, _i, _vp, _i, _i64, _i64, _i64, _vp, _sz, _vp, _i64, _vp]),
     "ffq_force_generic_kernels": (_i, [_i]),
     "ffq_quantize_rows_batch": (_i, [ctypes.POINTER(RowsBatch), _i, _vp]),

@@ -266,9 +266,13 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
     ooff = a.out_offset ? rne(a.out_offset[0]) : 0.0f;
   }
   constexpr int ROW_BYTES = 144;
-  constexpr int WAVE_BYTES = 32 * ROW_BYTES + 4 * 64 * 4;
+  constexpr int WAVE_BYTES = 32 * ROW_BYTES + 4 * 64 * 4 + 3 * 128 * 4;
+  static_assert(8 * WAVE_BYTES <= (BM2 + 256) * 128, "the epilogue scratch must fit the consumed operand slot");
   uint8_t* region = scratch + wave * WAVE_BYTES;
   float* colp = reinterpret_cast<float*>(region + 32 * ROW_BYTES);  // [4][64]: weight scale, weight row sum, bias, weight offset
+  // [3][128]: activation scale, rounded activation offset, activation row sum of the wave's 128 rows. Through LDS, not registers:
+  // 24 preloaded registers beside the 128 accumulators made every WOFF / REQUANT instantiation spill (round 3: 35-87 VGPRs)
+  float* rowp = colp + 4 * 64;
   const int r16 = lane & 15, g4 = lane >> 4;
   const int wave_n0 = n0 + wn * 64;
   const int wave_m0 = m0 + wm * 128;
@@ -287,21 +291,16 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private: only this wave's own writes
   // every global load of the epilogue BEFORE its first store: a load inside the slab loop makes the compiler wait with
   // vmcnt(0), i.e. for the previous slab's global stores too (vmcnt counts stores on gfx9)
-  float sx8[8], ox8[8];
-  [[maybe_unused]] float rsx8[8];
 #pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    int m = wave_m0 + mi * 16 + r16;
+  for (int h = 0; h < 2; ++h) {
+    const int r = lane + 64 * h;
+    int m = wave_m0 + r;
     m = m < a.M ? m : a.M - 1;
-    sx8[mi] = a.x_scale[a.x_per_row ? m : 0];
-    ox8[mi] = a.x_offset ? rne(a.x_offset[a.x_per_row ? m : 0]) : 0.0f;
-    if constexpr (WOFF) rsx8[mi] = woff_live ? (float)a.rowsum_x[m] : 0.0f;
+    rowp[r] = a.x_scale[a.x_per_row ? m : 0];
+    rowp[128 + r] = a.x_offset ? rne(a.x_offset[a.x_per_row ? m : 0]) : 0.0f;
+    if constexpr (WOFF) rowp[256 + r] = woff_live ? (float)a.rowsum_x[m] : 0.0f;
   }
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    asm volatile("" : "+v"(sx8[mi]), "+v"(ox8[mi]));
-    if constexpr (WOFF) asm volatile("" : "+v"(rsx8[mi]));
-  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const float kf = (float)a.K;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -310,7 +309,9 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
       const int mi = 2 * i + hh;
       const int m = wave_m0 + mi * 16 + r16;
       const bool m_ok = m < a.M;
-      const float sx = sx8[mi], ox = ox8[mi];
+      const float sx = rowp[mi * 16 + r16], ox = rowp[128 + mi * 16 + r16];
+      [[maybe_unused]] float rsx = 0.0f;
+      if constexpr (WOFF) rsx = rowp[256 + mi * 16 + r16];
 #pragma unroll
       for (int nj = 0; nj < 4; ++nj) {
         const int nb = nj * 16 + 4 * g4;
@@ -319,13 +320,19 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
         const f32x4 rs4 = *reinterpret_cast<const f32x4*>(colp + 64 + nb);
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(colp + 128 + nb);
         [[maybe_unused]] f32x4 ow4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        if constexpr (WOFF) ow4 = *reinterpret_cast<const f32x4*>(colp + 192 + nb);
+        if constexpr (WOFF) {
+          // re-read per row tile through a pointer the compiler cannot see through: hoisted out of the (unrolled) row-tile loop the
+          // four column-parameter arrays are 64 registers next to the 128 accumulators — the last two spilling instantiations
+          const float* owp = colp + 192 + nb;
+          asm volatile("" : "+v"(owp));
+          ow4 = *reinterpret_cast<const f32x4*>(owp);
+        }
         float y[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           float v = (float)acc[mi][nj][t] + ox * rs4[t];
           if constexpr (WOFF) {  // the order of the tail kernel's terms
-            v = v + ow4[t] * rsx8[mi];
+            v = v + ow4[t] * rsx;
             v = v + kf * ox * ow4[t];
           }
           float r = (sx * sw4[t]) * v;
@@ -565,20 +572,19 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
     }
   };
 
-  // fragment byte offsets inside a slot: [row tile][k-chunk]
+  // fragment byte offsets inside a slot. The swizzle term of a row depends on the row only through lane % 16 (row tiles are
+  // 16 rows apart and the term is (row / 2) mod 8), so ONE register per k-chunk and operand serves every row tile: the row tile
+  // goes into the instruction's offset field (mi * 2048 bytes). Round 3 kept 24 such registers; with 4 the WOFF / REQUANT
+  // instantiations no longer spill (tools/kernel_resources.py).
   const uint32_t r16 = lane & 15, g4 = lane >> 4;
-  uint32_t a_off[8][2], b_off[4][2];
+  uint32_t a_off[2], b_off[2];
+  {
+    const uint32_t arow = wm * 128 + r16, brow = wn * 64 + r16;
 #pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    const uint32_t row = wm * 128 + mi * 16 + r16;
-#pragma unroll
-    for (int kq = 0; kq < 2; ++kq) a_off[mi][kq] = row * 128 + (((kq * 4 + g4) ^ ((row >> 1) & 7u)) << 4);
-  }
-#pragma unroll
-  for (int nj = 0; nj < 4; ++nj) {
-    const uint32_t row = wn * 64 + nj * 16 + r16;
-#pragma unroll
-    for (int kq = 0; kq < 2; ++kq) b_off[nj][kq] = B_IMAGE + row * 128 + (((kq * 4 + g4) ^ ((row >> 1) & 7u)) << 4);
+    for (int kq = 0; kq < 2; ++kq) {
+      a_off[kq] = arow * 128 + (((kq * 4 + g4) ^ ((arow >> 1) & 7u)) << 4);
+      b_off[kq] = B_IMAGE + brow * 128 + (((kq * 4 + g4) ^ ((brow >> 1) & 7u)) << 4);
+    }
   }
 
   v4i32 acc[8][4];
@@ -587,10 +593,10 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
     const int kq = phase >> 1, mh = phase & 1;
     if (mh == 0) {
 #pragma unroll
-      for (int nj = 0; nj < 4; ++nj) fb[nj] = *reinterpret_cast<const v4i*>(st + b_off[nj][kq]);
+      for (int nj = 0; nj < 4; ++nj) fb[nj] = *reinterpret_cast<const v4i*>(st + b_off[kq] + nj * 2048);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) fa[q] = *reinterpret_cast<const v4i*>(st + a_off[4 * mh + q][kq]);
+    for (int q = 0; q < 4; ++q) fa[q] = *reinterpret_cast<const v4i*>(st + a_off[kq] + (4 * mh + q) * 2048);
   };
   auto cluster = [&](int mh) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -41,7 +41,7 @@
 #include <type_traits>
 
 #ifndef FFQ_WL_CLUSTER_MODE
-#define FFQ_WL_CLUSTER_MODE 1  // how a conversion cluster mixes its VALU work with its MFMAs: 0 = the compiler's choice, 1 = three / 2 = two VALU behind each MFMA
+#define FFQ_WL_CLUSTER_MODE 0  // how a conversion cluster mixes its VALU work with its MFMAs: 0 = the compiler's choice, 1 = three / 2 = two VALU behind each MFMA
 #endif
 
 namespace ffq {
@@ -83,7 +83,16 @@ struct WLinearArgs {
   // split-K (fewer tiles than CUs): a work unit is (tile, slice of the K range), `split` slices per tile, all units of the launch
   // resident at once; the units of a tile exchange partial accumulators through `slabs` and each finishes a share of the tile
   // (kernel epilogue). `tickets`: two counters per tile (arrived, left), zero on entry and on exit
+  // several weight matrices side by side along N in ONE launch (q / k / v of an attention block: the same activations, three
+  // weight tensors, three outputs): column tiles [0, seg_tile[0]) belong to matrix 0, [seg_tile[0], seg_tile[1]) to matrix 1, the
+  // rest to matrix 2; every matrix but the last has a multiple of 256 rows. `w` / `w_scale` / `w_offset` / `out` / `N` describe
+  // matrix 0 (N = ALL columns for the tile walk); 1 and 2 below. Plain mode only.
+  int seg_tile[2];
+  const uint8_t* seg_w[2]; const float* seg_scale[2]; const float* seg_offset[2]; void* seg_out[2];
+  int seg_n[3];  // rows (output columns) of each matrix
   int split;
+  int full_tiles;  // tiles [0, full_tiles) of the walk order are whole units (a multiple of the grid: every block gets the same count);
+                   // the TAIL tiles [full_tiles, total) are cut into `split` slices each, at most one such unit per block, every block's last
   float* slabs;
   int* tickets;
 };
@@ -116,25 +125,40 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
   const uint32_t nblk = gridDim.x;
   const uint32_t xcd = blockIdx.x & 7u, j_in_xcd = blockIdx.x >> 3;
   const uint32_t blocks_in_xcd = (nblk >> 3) + (xcd < (nblk & 7u) ? 1u : 0u);
-  // work units: slice-major ([slice][tile in walk order]), so that the blocks of an XCD work on ONE K range of neighbouring tiles
-  const uint32_t total_units = (uint32_t)total_tiles * (uint32_t)a.split;
-  const uint32_t tq = total_units >> 3, tr = total_units & 7u;
-  const uint32_t xcd_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
-  const uint32_t xcd_count = tq + (xcd < tr ? 1u : 0u);
-  const int my_tiles = j_in_xcd < xcd_count ? (int)((xcd_count - j_in_xcd + blocks_in_xcd - 1) / blocks_in_xcd) : 0;
+  // work units: the whole tiles, then the units of the tail tiles slice-major ([slice][tail tile in walk order], so that the
+  // blocks of an XCD work on ONE K range of neighbouring tiles); both lists are dealt to the XCDs as contiguous ranges
+  const uint32_t full_tiles = (uint32_t)a.full_tiles, tail_tiles = (uint32_t)total_tiles - full_tiles;
+  auto xcd_range = [&](uint32_t n, uint32_t& first, uint32_t& count) {
+    const uint32_t tq = n >> 3, tr = n & 7u;
+    first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    count = tq + (xcd < tr ? 1u : 0u);
+  };
+  uint32_t full_first, full_count, tail_first, tail_count;
+  xcd_range(full_tiles, full_first, full_count);
+  xcd_range(tail_tiles * (uint32_t)a.split, tail_first, tail_count);
+  const int n_full = j_in_xcd < full_count ? (int)((full_count - j_in_xcd + blocks_in_xcd - 1) / blocks_in_xcd) : 0;
+  const int n_tail = j_in_xcd < tail_count ? (int)((tail_count - j_in_xcd + blocks_in_xcd - 1) / blocks_in_xcd) : 0;  // <= 1 when split > 1
+  const int my_tiles = n_full + n_tail;
   if (my_tiles == 0) return;
   const int ksuper = a.K / WL_BK;  // >= 2 * split (checked by the launcher)
   [[maybe_unused]] uint16_t* const silu_table = reinterpret_cast<uint16_t*>(lds + 2 * WL_SLOT);  // MLP: behind the two slots
   if constexpr (MLP) silu_table_fill(silu_table, (uint32_t)tid, 512u);  // published by the first tile's barriers
-  // unit `it` of this block: tile origin, super-steps [k0, k1) of the contraction, tile number (ticket / slab index) and slice
-  auto tile_origin = [&](int it, int& tm0, int& tn0, int& k0, int& k1, int& tile_no, int& slice) {
+  // unit `it` of this block: tile origin, super-steps [k0, k1) of the contraction, tail-tile number (ticket / slab index; -1 for a
+  // whole tile) and slice
+  auto tile_origin = [&](int it, int& tm0, int& tn0, int& k0, int& k1, int& tile_no, int& slice, int& seg) {
     it = it < my_tiles ? it : my_tiles - 1;  // streams running past the block's last unit re-read it (never used)
-    const uint32_t unit_id = xcd_first + j_in_xcd + (uint32_t)it * blocks_in_xcd;
-    uint32_t tile_id = unit_id, sl = 0;
-    if (a.split > 1) { sl = unit_id / (uint32_t)total_tiles; tile_id = unit_id - sl * (uint32_t)total_tiles; }
-    tile_no = (int)tile_id; slice = (int)sl;
-    k0 = (int)(sl * (uint32_t)ksuper / (uint32_t)a.split);
-    k1 = (int)((sl + 1u) * (uint32_t)ksuper / (uint32_t)a.split);
+    uint32_t tile_id;
+    if (it < n_full) {
+      tile_id = full_first + j_in_xcd + (uint32_t)it * blocks_in_xcd;
+      tile_no = -1; slice = 0; k0 = 0; k1 = ksuper;
+    } else {
+      const uint32_t unit_id = tail_first + j_in_xcd + (uint32_t)(it - n_full) * blocks_in_xcd;
+      const uint32_t sl = unit_id / tail_tiles, tail_no = unit_id - sl * tail_tiles;
+      tile_id = full_tiles + tail_no;
+      tile_no = a.split > 1 ? (int)tail_no : -1; slice = (int)sl;
+      k0 = (int)(sl * (uint32_t)ksuper / (uint32_t)a.split);
+      k1 = (int)((sl + 1u) * (uint32_t)ksuper / (uint32_t)a.split);
+    }
     const uint32_t gm = (uint32_t)a.group_m;
     // the operand that a group re-reads in full should be the SMALLER one: it is what has to stay in the 256 MiB Infinity
     // Cache between groups while the other streams through once (launcher's choice, `group_cols`)
@@ -145,8 +169,19 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
     const uint32_t group_size = min(gm, along - group * gm);
     const uint32_t inner = group * gm + in_group % group_size, outer = in_group / group_size;
     tm0 = (int)(a.group_cols ? outer : inner) * WL_BM;
-    tn0 = (int)(a.group_cols ? inner : outer) * BN_OUT;
+    int tn = (int)(a.group_cols ? inner : outer);
+    seg = 0;
+    if constexpr (!MLP) {  // which weight matrix the column tile belongs to, and the tile's origin inside it
+      if (tn >= a.seg_tile[1]) { seg = 2; tn -= a.seg_tile[1]; }
+      else if (tn >= a.seg_tile[0]) { seg = 1; tn -= a.seg_tile[0]; }
+    }
+    tn0 = tn * BN_OUT;
   };
+  // the matrix a tile works on (wave-uniform selects: no dynamic indexing of the kernel arguments)
+  auto seg_codes = [&](int seg) { return seg == 0 ? a.w : seg == 1 ? a.seg_w[0] : a.seg_w[1]; };
+  auto seg_scales = [&](int seg) { return seg == 0 ? a.w_scale : seg == 1 ? a.seg_scale[0] : a.seg_scale[1]; };
+  auto seg_offsets = [&](int seg) { return seg == 0 ? a.w_offset : seg == 1 ? a.seg_offset[0] : a.seg_offset[1]; };
+  auto seg_rows = [&](int seg) { return seg == 0 ? a.seg_n[0] : seg == 1 ? a.seg_n[1] : a.seg_n[2]; };
   // first byte of row `row0` of a matrix with `row_bytes` per row, kept in SGPRs (see ffq_linear.hip::row_base)
   auto row_base = [&](const uint8_t* base, int row0, uint32_t row_bytes) {
     const uint64_t off = (uint64_t)(uint32_t)row0 * (uint64_t)row_bytes;
@@ -163,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
   const uint8_t* a_base = a.x;
   [[maybe_unused]] uint32_t b_voff[4];          // WL_B_BF16: the B image by LDS-DMA, as A
   [[maybe_unused]] const uint8_t* b_base[4] = {a.w, a.w, a.w, a.w};  // per piece (MLP: gate or up matrix)
-  auto set_image_sources = [&](int tm0, int tn0) {
+  auto set_image_sources = [&](int tm0, int tn0, int seg) {
     a_base = row_base(a.x, tm0, x_row_bytes);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -179,8 +214,9 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
           b_base[c] = row_base((((wave * 4 + c) * 8) & 32) ? a.w2 : a.w, tn0, w_row_bytes);
           b_voff[c] = (uint32_t)rb * w_row_bytes + d_slot * 16;
         } else {
-          const int rb = tn0 + row < a.N ? row : a.N - 1 - tn0;
-          b_base[c] = row_base(a.w, tn0, w_row_bytes);
+          const int rows = seg_rows(seg);
+          const int rb = tn0 + row < rows ? row : rows - 1 - tn0;
+          b_base[c] = row_base(seg_codes(seg), tn0, w_row_bytes);
           b_voff[c] = (uint32_t)rb * w_row_bytes + d_slot * 16;
         }
       }
@@ -217,19 +253,20 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
   [[maybe_unused]] float sc[2] = {1.0f, 1.0f}, ro[2] = {0.0f, 0.0f};
   [[maybe_unused]] uint32_t nib_shift = 0;        // WL_B_I4: 0 = the low nibbles of the bytes, 4 = the high ones (stream state)
   [[maybe_unused]] int grp = 0, grp_phase = 0;    // GROUPED: parameter group of the code stream's super-step, and the step inside it
-  auto set_code_sources = [&](int tn0) {
+  auto set_code_sources = [&](int tn0, int seg) {
     if constexpr (CODES) {
       // MLP: a wave's 32 tile rows are all gate rows (even waves) or all up rows (odd waves) of the tile's 128 output columns
       const bool second = MLP && (wave & 1);
-      c_base = row_base(second ? a.w2 : a.w, tn0, w_row_bytes);
+      c_base = row_base(second ? a.w2 : seg_codes(seg), tn0, w_row_bytes);
       const uint32_t param_row = a.per_row ? (uint32_t)a.groups : 0u;
-      ps_base = reinterpret_cast<const float*>(row_base(reinterpret_cast<const uint8_t*>(second ? a.w_scale2 : a.w_scale), tn0, param_row * 4u));
-      if constexpr (OFFSET) po_base = reinterpret_cast<const float*>(row_base(reinterpret_cast<const uint8_t*>(second ? a.w_offset2 : a.w_offset), tn0, param_row * 4u));
+      ps_base = reinterpret_cast<const float*>(row_base(reinterpret_cast<const uint8_t*>(second ? a.w_scale2 : seg_scales(seg)), tn0, param_row * 4u));
+      if constexpr (OFFSET) po_base = reinterpret_cast<const float*>(row_base(reinterpret_cast<const uint8_t*>(second ? a.w_offset2 : seg_offsets(seg)), tn0, param_row * 4u));
+      const int rows = MLP ? a.N : seg_rows(seg);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int trow = wave * 32 + j * 16 + (lane >> 2);
         const int row = MLP ? (trow >> 6) * 32 + (trow & 31) : trow;
-        const int rb = tn0 + row < a.N ? row : a.N - 1 - tn0;
+        const int rb = tn0 + row < rows ? row : rows - 1 - tn0;
         c_voff[j] = (uint32_t)rb * w_row_bytes;
         p_voff[j] = (uint32_t)rb * param_row * 4u;
       }
@@ -400,12 +437,12 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
   constexpr std::integral_constant<bool, CODES> kConverts{};
   constexpr std::false_type kNoWork{};
 
-  int m0 = 0, n0 = 0, k0 = 0, k1 = 0, tile_no = 0, slice = 0;
-  tile_origin(0, m0, n0, k0, k1, tile_no, slice);
-  set_image_sources(m0, n0);
+  int m0 = 0, n0 = 0, k0 = 0, k1 = 0, tile_no = 0, slice = 0, seg = 0;
+  tile_origin(0, m0, n0, k0, k1, tile_no, slice, seg);
+  set_image_sources(m0, n0, seg);
   // ---- prologue: element 0 staged entirely, the codes of element 1 requested
   if constexpr (CODES) {
-    set_code_sources(n0);
+    set_code_sources(n0, seg);
     load_codes(k0, true);
     wait_all_vmem();
     convert_row(0, 0);
@@ -425,20 +462,20 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
       for (int nj = 0; nj < 4; ++nj)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[mi][nj][e] = 0.0f;
-    int nm0, nn0, nk0, nk1, ntile_no, nslice;
-    tile_origin(it + 1, nm0, nn0, nk0, nk1, ntile_no, nslice);
+    int nm0, nn0, nk0, nk1, ntile_no, nslice, nseg;
+    tile_origin(it + 1, nm0, nn0, nk0, nk1, ntile_no, nslice, nseg);
     if (wm == 1) __builtin_amdgcn_s_barrier();  // the upper group runs one interval behind
     for (int ks = k0; ks < k1; ++ks) {
       const uint8_t* st = lds + slot * WL_SLOT;
       // images / conversion: element e + 1; code loads: element e + 2
       const bool last = ks == k1 - 1;
       const int fetch = last ? nk0 : ks + 1;
-      if (last) set_image_sources(nm0, nn0);
+      if (last) set_image_sources(nm0, nn0, nseg);
       int code_ks = ks + 2;
       bool code_new_tile = false;
       if (code_ks >= k1) {
         code_ks = nk0 + (code_ks - k1);
-        if (ks == k1 - 2) { set_code_sources(nn0); code_new_tile = true; }
+        if (ks == k1 - 2) { set_code_sources(nn0, nseg); code_new_tile = true; }
       }
       // The LDS-DMA pieces are issued by the group that is NOT computing: behind its fragment reads (lgkmcnt(0): the LDS is no
       // longer serving them) and ahead of the barrier, in the first two LOAD segments of the super-step. An LDS-DMA instruction
@@ -492,7 +529,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
     // zeroes both counters for the next launch. Pieces beyond M are skipped by everybody. The only wait is for blocks that
     // are resident by construction; it is bounded and traps instead of hanging.
     uint32_t own = 0xFu;  // bit i: this wave finishes piece i (wave-uniform)
-    if (a.split > 1) {
+    if (tile_no >= 0) {
       const int S = a.split;
       const int rows_left = a.M - (m0 + wm * 128);
       const int mi_cnt = rows_left <= 0 ? 0 : rows_left >= 128 ? 8 : (rows_left + 15) >> 4;  // wave-uniform
@@ -542,7 +579,8 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
       }
     }
     {
-      TOut* out = static_cast<TOut*>(a.out);
+      TOut* out = static_cast<TOut*>(MLP || seg == 0 ? a.out : seg == 1 ? a.seg_out[0] : a.seg_out[1]);
+      const int out_n = MLP ? a.N : seg_rows(seg);           // columns of this tile's output tensor
       constexpr int COLS = MLP ? 32 : 64;                     // output columns per wave
       constexpr int NJ = COLS / 16;                           // column tiles that leave the wave
       constexpr int PITCH = COLS * (int)sizeof(TOut) + 16;
@@ -552,11 +590,11 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
       uint8_t* region = lds + (slot ^ 1) * WL_SLOT + wave * WAVE_BYTES;
       float* bias_lds = reinterpret_cast<float*>(region + SLAB * PITCH);
       const int wave_n0 = n0 + wn * COLS, wave_m0 = m0 + wm * 128;
-      const bool full = wave_n0 + COLS <= a.N && (a.N * (int)sizeof(TOut)) % 16 == 0;
+      const bool full = wave_n0 + COLS <= out_n && (out_n * (int)sizeof(TOut)) % 16 == 0;
       const bool has_bias = !MLP && a.bias != nullptr;
       if (lane < COLS) {
         const int n = wave_n0 + lane;
-        bias_lds[lane] = has_bias ? (float)load_any(a.bias, a.bias_dt, n < a.N ? n : a.N - 1) : 0.0f;
+        bias_lds[lane] = has_bias ? (float)load_any(a.bias, a.bias_dt, n < out_n ? n : out_n - 1) : 0.0f;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private: only this wave's own writes
       if constexpr (MLP) {
@@ -624,32 +662,32 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
 #pragma unroll
           for (int t = 0; t < SLAB * SEGS / 64; ++t) {
             const int c = lane + 64 * t;
-            const int row = c / SEGS, seg = c % SEGS;
+            const int row = c / SEGS, sg = c % SEGS;
             const int mm = wave_m0 + i * SLAB + row;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * PITCH + seg * 16);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * PITCH + sg * 16);
             // non-temporal, as in ffq_linear.hip: the output must not push the operand panels out of L2
-            if (mm < a.M) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * a.N + wave_n0) * sizeof(TOut) + seg * 16));
+            if (mm < a.M) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * out_n + wave_n0) * sizeof(TOut) + sg * 16));
           }
         } else {  // ragged right edge / unaligned rows: element stores (correctness path)
           for (int c = lane; c < SLAB * COLS; c += 64) {
             const int row = c / COLS, col = c % COLS;
             const int mm = wave_m0 + i * SLAB + row;
-            if (mm < a.M && wave_n0 + col < a.N)
-              out[(size_t)mm * a.N + wave_n0 + col] = *reinterpret_cast<const TOut*>(region + row * PITCH + col * sizeof(TOut));
+            if (mm < a.M && wave_n0 + col < out_n)
+              out[(size_t)mm * out_n + wave_n0 + col] = *reinterpret_cast<const TOut*>(region + row * PITCH + col * sizeof(TOut));
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is re-written by the next i
       }
     }
     __syncthreads();  // the scratch slot is the next tile's staging target
-    if (a.split > 1 && tid == 0) {  // every wave of this block has read its peers' pieces (the barrier above): count the unit out
+    if (tile_no >= 0 && tid == 0) {  // every wave of this block has read its peers' pieces (the barrier above): count the unit out
       int* const arrived = a.tickets + 2 * tile_no;
       if (__hip_atomic_fetch_add(arrived + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.split - 1) {
         __hip_atomic_store(arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(arrived + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    m0 = nm0; n0 = nn0; k0 = nk0; k1 = nk1; tile_no = ntile_no; slice = nslice;
+    m0 = nm0; n0 = nn0; k0 = nk0; k1 = nk1; tile_no = ntile_no; slice = nslice; seg = nseg;
   }
   wait_all_vmem();  // the trailing requests of the streams must not outlive the block's LDS / registers
 }
@@ -697,8 +735,17 @@ static int64_t wq_tiles(int64_t M, int64_t N, bool mlp) {
   return ((M + WL_BM - 1) / WL_BM) * (mlp ? N / 128 : (N + WL_BN - 1) / WL_BN);
 }
 
+// the tiles of the last, partly filled round of the persistent walk (all tiles when there are fewer than CUs): the ones a split
+// applies to. Whole rounds before it keep every CU busy without any exchange.
+static int64_t wq_tail_tiles(int64_t M, int64_t N, bool mlp) {
+  const int64_t tiles = wq_tiles(M, N, mlp);
+  return tiles > 0 ? tiles % wq_cus() : 0;
+}
+
 static int wq_max_split(int64_t M, int64_t N, int64_t K, bool mlp) {
-  const int64_t tiles = wq_tiles(M, N, mlp), by_cus = tiles > 0 ? wq_cus() / tiles : 1, by_k = (K / WL_BK) / 2;
+  const int64_t tail = wq_tail_tiles(M, N, mlp);
+  if (tail <= 0) return 1;
+  const int64_t by_cus = wq_cus() / tail, by_k = (K / WL_BK) / 2;
   const int64_t most = by_cus < by_k ? by_cus : by_k;
   return most < 1 ? 1 : most > 32 ? 32 : (int)most;
 }
@@ -723,15 +770,21 @@ extern "C" int64_t ffq_linear_wq_split(int64_t M, int64_t N, int64_t K, int mlp)
   return wq_split(M, N, K, mlp != 0);
 }
 
-// int32 counters the split-K exchange needs (two per tile; 0 = none): zero before the first launch that uses them, left zero
-// by every launch — a caller keeps ONE zeroed buffer per stream and never touches it
+// int32 counters the split-K exchange needs (two per tail tile; 0 = none): zero before the first launch that uses them, left
+// zero by every launch — a caller keeps ONE zeroed buffer per stream and never touches it
 extern "C" int64_t ffq_linear_wq_tickets(int64_t M, int64_t N, int64_t K, int mlp) {
   if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 0;
-  return 2 * wq_tiles(M, N, mlp != 0);
+  return 2 * wq_tail_tiles(M, N, mlp != 0);
+}
+
+// bytes of partial-sum slabs a launch with `split` K slices per tail tile needs at the front of its workspace (0: none)
+extern "C" size_t ffq_linear_wq_slab_bytes(int64_t M, int64_t N, int64_t K, int mlp, int64_t split) {
+  if (M <= 0 || N <= 0 || K < 2 * WL_BK || split <= 1) return 0;
+  return (size_t)wq_tail_tiles(M, N, mlp != 0) * (size_t)split * WL_UNIT_SLAB;
 }
 
 static size_t wq_slab_bytes(int64_t M, int64_t N, int split, bool mlp) {
-  return split > 1 ? (size_t)wq_tiles(M, N, mlp) * (size_t)split * WL_UNIT_SLAB : 0;
+  return split > 1 ? (size_t)wq_tail_tiles(M, N, mlp) * (size_t)split * WL_UNIT_SLAB : 0;
 }
 
 // workspace: [split-K slabs of the library's plan | bf16 image(s) of the two-pass form (A2 of the whole weight, then the GEMM on
@@ -747,7 +800,7 @@ static size_t wq_resolve_split(WLinearArgs& a, int64_t split_request, bool mlp, 
   *rc = FFQ_OK;
   const int most = wq_max_split(a.M, a.N, a.K, mlp);
   if (split_request > most) {
-    *rc = fail(FFQ_ERR_ARG, "weight-only linear: split %lld exceeds %d (all units of a tile must be resident at once: tiles * split <= CUs, K / 64 >= 2 * split)", (long long)split_request, most);
+    *rc = fail(FFQ_ERR_ARG, "weight-only linear: split %lld exceeds %d (the units of the last round must be resident at once: tail tiles * split <= CUs, K / 64 >= 2 * split)", (long long)split_request, most);
     return 0;
   }
   int split = split_request > 0 ? (int)split_request : wq_split(a.M, a.N, a.K, mlp);
@@ -756,7 +809,9 @@ static size_t wq_resolve_split(WLinearArgs& a, int64_t split_request, bool mlp, 
     if (split_request > 1) { *rc = fail(FFQ_ERR_ARG, "weight-only linear: split %d needs %zu bytes of workspace and a ticket buffer", split, slab); return 0; }
     split = 1; slab = 0;  // the plan is a preference: without scratch every tile is one unit
   }
+  const int64_t tiles = wq_tiles(a.M, a.N, mlp);
   a.split = split;
+  a.full_tiles = (int)(split > 1 ? tiles - wq_tail_tiles(a.M, a.N, mlp) : tiles);
   a.slabs = split > 1 ? static_cast<float*>(workspace) : nullptr;
   a.tickets = split > 1 ? tickets : nullptr;
   return slab;
@@ -765,7 +820,7 @@ static size_t wq_resolve_split(WLinearArgs& a, int64_t split_request, bool mlp, 
 template <int BKIND, bool GROUPED, bool OFFSET, typename TOut, bool MLP = false>
 static void wq_launch(const WLinearArgs& a, hipStream_t s) {
   const int total = a.tiles_m * a.tiles_n;
-  const int64_t units = (int64_t)total * a.split;  // split > 1: units <= CUs (wq_max_split): every block exactly one unit, all resident
+  const int64_t units = (int64_t)a.full_tiles + (int64_t)(total - a.full_tiles) * a.split;  // the split tail: <= CUs units (wq_max_split)
   const int cus = wq_cus();
   const unsigned grid = (unsigned)(units < cus ? units : cus);
   const size_t lds_bytes = (size_t)2 * WL_SLOT + (MLP ? kSiluBytes : 0);
@@ -787,11 +842,93 @@ static void wq_dispatch(const WLinearArgs& a, bool grouped, bool offset, hipStre
   }
 }
 
+// `count` weight matrices side by side along N on the same activations (count == 1: ffq_linear_wq)
+static int wq_linear_impl(const void* x, int x_dt, int count, const void* const* w_codes, int w_dt, int64_t pack_block, const float* const* w_scale,
+                          const float* const* w_offset, int per_row, int64_t group, const void* bias, int bias_dt, void* const* outs,
+                          int out_dt, int64_t M, const int64_t* Ns, int64_t K, void* workspace, size_t workspace_bytes, int32_t* tickets,
+                          int64_t split, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int64_t N = 0;
+  for (int i = 0; i < count; ++i) N += Ns[i];
+  const int64_t groups = K / group;
+
+  WLinearArgs a;
+  a.x = static_cast<const uint8_t*>(x);
+  a.w = static_cast<const uint8_t*>(w_codes[0]);
+  a.w_scale = w_scale[0]; a.w_offset = w_offset[0];
+  a.w2 = nullptr; a.w_scale2 = nullptr; a.w_offset2 = nullptr;
+  a.bias = bias; a.bias_dt = bias_dt;
+  a.out = outs[0]; a.out_dt = out_dt;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.seg_n[0] = (int)Ns[0]; a.seg_n[1] = a.seg_n[2] = 0;
+  a.seg_tile[0] = a.seg_tile[1] = INT32_MAX;
+  for (int i = 0; i < 2; ++i) { a.seg_w[i] = nullptr; a.seg_scale[i] = nullptr; a.seg_offset[i] = nullptr; a.seg_out[i] = nullptr; }
+  int64_t tile_edge = 0;
+  for (int i = 1; i < count; ++i) {
+    tile_edge += Ns[i - 1] / WL_BN;
+    a.seg_tile[i - 1] = (int)tile_edge;
+    a.seg_w[i - 1] = static_cast<const uint8_t*>(w_codes[i]);
+    a.seg_scale[i - 1] = w_scale[i]; a.seg_offset[i - 1] = w_offset[i];
+    a.seg_out[i - 1] = outs[i];
+    a.seg_n[i] = (int)Ns[i];
+  }
+  a.groups = (int)groups;
+  a.steps_per_group = (int)(group / WL_BK);
+  a.per_row = per_row;
+  a.pack_shift = 0;
+  for (int64_t b = pack_block; b > 1; b >>= 1) ++a.pack_shift;
+  a.tiles_m = (int)((M + WL_BM - 1) / WL_BM);
+  a.tiles_n = (int)((N + WL_BN - 1) / WL_BN);
+  a.group_m = K >= 4096 ? 4 : WL_GROUP_M;  // row tiles whose A panels (256 x 2 K bytes each) a group's column tiles share in their XCD's L2
+  a.group_cols = 0;
+#ifdef FFQ_EXPERIMENTS  // tuning builds only (tools/): the shipped library reads no environment
+  if (const char* gm = getenv("FFQ_WQ_GROUP_M")) a.group_m = atoi(gm);
+  if (const char* gc = getenv("FFQ_WQ_GROUP_COLS")) a.group_cols = atoi(gc);
+#endif
+  const bool grouped = groups > 1, offset = w_offset[0] != nullptr;
+  int rc_split;
+  const size_t slab_bytes = wq_resolve_split(a, split, false, workspace, workspace_bytes, tickets, &rc_split);
+  if (rc_split != FFQ_OK) return rc_split;
+  workspace = workspace ? static_cast<uint8_t*>(workspace) + slab_bytes : nullptr;  // the image(s) (if any) lie behind the slabs
+  workspace_bytes = workspace_bytes > slab_bytes ? workspace_bytes - slab_bytes : 0;
+
+  const size_t image_bytes = (size_t)N * (size_t)K * 2u;
+  if (workspace && workspace_bytes >= image_bytes && aligned16(workspace)) {  // the caller offered the image's scratch (ffq_linear_wq_workspace_bytes: from 4096 tokens on)
+    // two-pass form: A2 of the whole weight once (3 or 2.5 B/elem, ~2 % of the GEMM at 16 k tokens), then the GEMM with both
+    // operands by LDS-DMA — no conversion work per row tile
+    uint8_t* image = static_cast<uint8_t*>(workspace);
+    int rc = FFQ_OK;
+    const uint8_t* images[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < count && rc == FFQ_OK; ++i) {
+      ffq_tiling t;
+      t.ndim = 2;
+      t.shape[0] = Ns[i]; t.shape[1] = K;
+      t.tile[0] = per_row ? 1 : Ns[i]; t.tile[1] = per_row ? group : K;
+      const int64_t numel = per_row ? Ns[i] * groups : 1;
+      if (w_dt == FFQ_U8)
+        rc = ffq_unpack_dequantize_int4(static_cast<const uint8_t*>(w_codes[i]), w_scale[i], numel, w_offset[i], w_offset[i] ? numel : 0, &t, pack_block, image, FFQ_BF16, stream);
+      else
+        rc = ffq_dequantize_by_tile(w_codes[i], FFQ_I8, w_scale[i], FFQ_F32, numel, w_offset[i], FFQ_F32, w_offset[i] ? numel : 0, &t, image, FFQ_BF16, stream);
+      images[i] = image;
+      image += (size_t)Ns[i] * (size_t)K * 2u;
+    }
+    if (rc == FFQ_OK) {
+      a.w = images[0];
+      for (int i = 1; i < count; ++i) a.seg_w[i - 1] = images[i];
+      wq_dispatch<WL_B_BF16>(a, false, false, s);
+      return check_launch("wq_gemm256_kernel (bf16 image)");
+    }
+    if (rc != FFQ_ERR_DTYPE) return rc;  // a tiling the stand-alone dequantize kernels decline: the one-pass kernel below covers it
+  }
+  if (w_dt == FFQ_U8) wq_dispatch<WL_B_I4>(a, grouped, offset, s);
+  else wq_dispatch<WL_B_I8>(a, grouped, offset, s);
+  return check_launch("wq_gemm256_kernel");
+}
+
 extern "C" int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, int64_t pack_block, const float* w_scale,
                              const float* w_offset, int64_t scale_numel, int64_t group, const void* bias, int bias_dt, void* out,
                              int out_dt, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, int32_t* tickets,
                              int64_t split, void* stream) {
-  hipStream_t s = static_cast<hipStream_t>(stream);
   if (M < 0 || N < 0 || K < 0 || split < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
   if (!x || !w_codes || !w_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
@@ -803,58 +940,38 @@ extern "C" int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w
   if (!(scale_numel == 1 || scale_numel == N * groups))
     return fail(FFQ_ERR_PARAM_NUMEL, "weight-only linear: %lld parameters for %lld x %lld tiles", (long long)scale_numel, (long long)N, (long long)groups);
   if (scale_numel == 1 && groups != 1) return fail(FFQ_ERR_PARAM_NUMEL, "one parameter pair needs group == K");
+  return wq_linear_impl(x, x_dt, 1, &w_codes, w_dt, pack_block, &w_scale, &w_offset, scale_numel != 1, group, bias, bias_dt, &out, out_dt, M, &N, K,
+                        workspace, workspace_bytes, tickets, split, stream);
+}
 
-  WLinearArgs a;
-  a.x = static_cast<const uint8_t*>(x);
-  a.w = static_cast<const uint8_t*>(w_codes);
-  a.w_scale = w_scale; a.w_offset = w_offset;
-  a.w2 = nullptr; a.w_scale2 = nullptr; a.w_offset2 = nullptr;
-  a.bias = bias; a.bias_dt = bias_dt;
-  a.out = out; a.out_dt = out_dt;
-  a.M = (int)M; a.N = (int)N; a.K = (int)K;
-  a.groups = (int)groups;
-  a.steps_per_group = (int)(group / WL_BK);
-  a.per_row = scale_numel != 1;
-  a.pack_shift = 0;
-  for (int64_t b = pack_block; b > 1; b >>= 1) ++a.pack_shift;
-  a.tiles_m = (int)((M + WL_BM - 1) / WL_BM);
-  a.tiles_n = (int)((N + WL_BN - 1) / WL_BN);
-  a.group_m = K >= 4096 ? 4 : WL_GROUP_M;  // row tiles whose A panels (256 x 2 K bytes each) a group's column tiles share in their XCD's L2
-  a.group_cols = 0;
-#ifdef FFQ_EXPERIMENTS  // tuning builds only (tools/): the shipped library reads no environment
-  if (const char* gm = getenv("FFQ_WQ_GROUP_M")) a.group_m = atoi(gm);
-  if (const char* gc = getenv("FFQ_WQ_GROUP_COLS")) a.group_cols = atoi(gc);
-#endif
-  const bool grouped = groups > 1, offset = w_offset != nullptr;
-  int rc_split;
-  const size_t slab_bytes = wq_resolve_split(a, split, false, workspace, workspace_bytes, tickets, &rc_split);
-  if (rc_split != FFQ_OK) return rc_split;
-  workspace = workspace ? static_cast<uint8_t*>(workspace) + slab_bytes : nullptr;  // the image (if any) lies behind the slabs
-  workspace_bytes = workspace_bytes > slab_bytes ? workspace_bytes - slab_bytes : 0;
-
-  const size_t image_bytes = (size_t)N * (size_t)K * 2u;
-  if (workspace && workspace_bytes >= image_bytes && aligned16(workspace)) {  // the caller offered the image's scratch (ffq_linear_wq_workspace_bytes: from 4096 tokens on)
-    // two-pass form: A2 of the whole weight once (3 or 2.5 B/elem, ~2 % of the GEMM at 16 k tokens), then the GEMM with both
-    // operands by LDS-DMA — no conversion work per row tile
-    ffq_tiling t;
-    t.ndim = 2;
-    t.shape[0] = N; t.shape[1] = K;
-    t.tile[0] = scale_numel == 1 ? N : 1; t.tile[1] = scale_numel == 1 ? K : group;
-    int rc;
-    if (w_dt == FFQ_U8)
-      rc = ffq_unpack_dequantize_int4(static_cast<const uint8_t*>(w_codes), w_scale, scale_numel, w_offset, w_offset ? scale_numel : 0, &t, pack_block, workspace, FFQ_BF16, stream);
-    else
-      rc = ffq_dequantize_by_tile(w_codes, FFQ_I8, w_scale, FFQ_F32, scale_numel, w_offset, FFQ_F32, w_offset ? scale_numel : 0, &t, workspace, FFQ_BF16, stream);
-    if (rc == FFQ_OK) {
-      a.w = static_cast<const uint8_t*>(workspace);
-      wq_dispatch<WL_B_BF16>(a, false, false, s);
-      return check_launch("wq_gemm256_kernel (bf16 image)");
-    }
-    if (rc != FFQ_ERR_DTYPE) return rc;  // a tiling the stand-alone dequantize kernels decline: the one-pass kernel below covers it
+// Two or three weight matrices on the SAME activations in one launch (q_proj / k_proj / v_proj of an attention block: three
+// QuantizedLinear modules reading one hidden state, nn/linear.py:32-39 three times): outs[i] = F.linear(x, dequantize(w_i)) exactly as
+// ffq_linear_wq computes it for the concatenated weight — one tile walk over all the column tiles, so a k/v projection (1024
+// columns = 4 tiles per row tile) no longer runs alone on a corner of the chip. All matrices share dtype, packing, group size,
+// granularity kind (`per_row`: one pair per (row, group), else one pair per matrix) and the presence of offsets; every matrix but
+// the last has a multiple of 256 rows. Workspace / tickets / split as ffq_linear_wq with N = the sum of the rows.
+extern "C" int ffq_linear_wq_multi(const void* x, int x_dt, int count, const void* const* w_codes, int w_dt, int64_t pack_block,
+                                   const float* const* w_scale, const float* const* w_offset, int per_row, int64_t group, void* const* outs,
+                                   int out_dt, int64_t M, const int64_t* Ns, int64_t K, void* workspace, size_t workspace_bytes, int32_t* tickets,
+                                   int64_t split, void* stream) {
+  if (count < 1 || count > 3 || !w_codes || !w_scale || !w_offset || !outs || !Ns) return fail(FFQ_ERR_ARG, "1 to 3 weight matrices");
+  if (M < 0 || K < 0 || split < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  int64_t N = 0;
+  for (int i = 0; i < count; ++i) {
+    if (Ns[i] <= 0) return fail(FFQ_ERR_ARG, "empty weight matrix");
+    if (i + 1 < count && Ns[i] % WL_BN != 0) return fail(FFQ_ERR_DTYPE, "every weight matrix but the last needs a multiple of 256 rows");
+    if (!w_codes[i] || !w_scale[i] || !outs[i]) return fail(FFQ_ERR_ARG, "NULL buffer");
+    if ((w_offset[i] == nullptr) != (w_offset[0] == nullptr)) return fail(FFQ_ERR_ARG, "offsets for all weight matrices or for none");
+    if (!aligned16(w_codes[i]) || !aligned16(outs[i])) return fail(FFQ_ERR_DTYPE, "weight-only linear needs 16-byte aligned buffers");
+    N += Ns[i];
   }
-  if (w_dt == FFQ_U8) wq_dispatch<WL_B_I4>(a, grouped, offset, s);
-  else wq_dispatch<WL_B_I8>(a, grouped, offset, s);
-  return check_launch("wq_gemm256_kernel");
+  if (M == 0) return FFQ_OK;
+  if (!x || !aligned16(x)) return fail(FFQ_ERR_ARG, "NULL or misaligned activations");
+  if (!ffq_linear_wq_supported(x_dt, w_dt, out_dt, M, N, K, group, pack_block))
+    return fail(FFQ_ERR_DTYPE, "weight-only linear: needs bf16 activations, int8-container or packed 4-bit codes, bf16 / f32 output, K %% 64 == 0, K >= 128 and groups of a multiple of 64 input channels");
+  if (!per_row && group != K) return fail(FFQ_ERR_PARAM_NUMEL, "one parameter pair per matrix needs group == K");
+  return wq_linear_impl(x, x_dt, count, w_codes, w_dt, pack_block, w_scale, w_offset, per_row, group, nullptr, 0, outs, out_dt, M, Ns, K, workspace,
+                        workspace_bytes, tickets, split, stream);
 }
 
 // ---- gate_proj + up_proj + SiLU * up of a weight-only quantized MLP in one launch ---------------------------------------------------
@@ -889,6 +1006,9 @@ extern "C" int ffq_mlp_gate_up_wq(const void* x, int x_dt, const void* gate_code
   a.bias = nullptr; a.bias_dt = 0;
   a.out = out; a.out_dt = FFQ_BF16;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.seg_n[0] = (int)N; a.seg_n[1] = a.seg_n[2] = 0;
+  a.seg_tile[0] = a.seg_tile[1] = INT32_MAX;
+  for (int i = 0; i < 2; ++i) { a.seg_w[i] = nullptr; a.seg_scale[i] = nullptr; a.seg_offset[i] = nullptr; a.seg_out[i] = nullptr; }
   a.groups = (int)groups;
   a.steps_per_group = (int)(group / WL_BK);
   a.per_row = scale_numel != 1;

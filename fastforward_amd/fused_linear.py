@@ -71,29 +71,25 @@ def _on_backend(*tensors: Any) -> bool:
     return all(t.is_cuda for t in tensors) and _native.is_available()
 
 
-# Which GEMM a weight-only linear takes: the hand-written bf16 x weight-code kernel (default since round 3) from
-# `_WEIGHT_ONLY_MIN_TOKENS` tokens on, the reference's own path below that and inside ``with weight_only_kernel(False)``
-# (fallback.py:86-112: A2 into a bf16 tensor + F.linear, i.e. the vendor's GEMM — also the A/B arm of tools/bench_configs.py).
-# Both see the same operands bit for bit. Why a token threshold: the kernel is built around 256 x 256 output tiles, one
-# persistent block per CU; at 2048 tokens a 4096-wide projection is 128 tiles for 256 CUs and it runs at half the vendor
-# library's rate (601 vs 1151 TFLOP/s; at 16384 tokens 1.28-1.38 vs 1.45-1.53 PFLOP/s: profiles/r03_wq_time.txt).
+# Which GEMM a weight-only linear takes: the hand-written bf16 x weight-code kernel at EVERY token count (round 4: a launch with
+# fewer output tiles than the chip has CUs cuts the K range of its last round's tiles into slices — csrc/ffq_wlinear.hip — so the
+# round-3 token threshold, below which the reference's A2 + vendor GEMM ran, is gone), or, inside ``with weight_only_kernel(False)``,
+# the reference's own path (fallback.py:86-112: A2 into a bf16 tensor + F.linear — the A/B arm of tools/bench_configs.py).
+# Both see the same operands bit for bit.
 _WEIGHT_ONLY_KERNEL = True
-_WEIGHT_ONLY_MIN_TOKENS = 4096
 
 
 @contextlib.contextmanager
-def weight_only_kernel(enabled: bool = True, min_tokens: int | None = None):
-    """Route weight-only quantized linears (plain bf16 input, quantized weight) to the hand-written GEMM (default, from
-    `min_tokens` tokens on) or, with ``enabled=False``, leave them to the float fallback (A2 + ``F.linear``) inside the block."""
-    global _WEIGHT_ONLY_KERNEL, _WEIGHT_ONLY_MIN_TOKENS
-    previous = (_WEIGHT_ONLY_KERNEL, _WEIGHT_ONLY_MIN_TOKENS)
+def weight_only_kernel(enabled: bool = True):
+    """Route weight-only quantized linears (plain bf16 input, quantized weight) to the hand-written GEMM (default) or, with
+    ``enabled=False``, leave them to the float fallback (A2 + ``F.linear``) inside the block."""
+    global _WEIGHT_ONLY_KERNEL
+    previous = _WEIGHT_ONLY_KERNEL
     _WEIGHT_ONLY_KERNEL = bool(enabled)
-    if min_tokens is not None:
-        _WEIGHT_ONLY_MIN_TOKENS = int(min_tokens)
     try:
         yield
     finally:
-        _WEIGHT_ONLY_KERNEL, _WEIGHT_ONLY_MIN_TOKENS = previous
+        _WEIGHT_ONLY_KERNEL = previous
 
 
 _FLOATS = (torch.bfloat16, torch.float16, torch.float32)
@@ -260,10 +256,10 @@ class DispatcherKernels:
 
     # ---- linear ---------------------------------------------------------------------------------------------------------
     def _wq_covers(self, x_dtype: torch.dtype, weight: Any, tokens: int) -> int | None:
-        """The group size when the bf16 x weight-code GEMM takes (activation dtype, weight tiling, K, tokens): coverage is the
-        library's own rule (``ffq_linear_wq_supported``, asked for int8 codes), the token threshold this module's policy."""
+        """The group size when the bf16 x weight-code GEMM takes (activation dtype, weight tiling, K): coverage is the library's
+        own rule (``ffq_linear_wq_supported``, asked for int8 codes); every token count >= 1 is covered."""
         group = self.weight_group(weight)
-        if group is None or x_dtype not in ops._TAGS or tokens < _WEIGHT_ONLY_MIN_TOKENS:
+        if group is None or x_dtype not in ops._TAGS:
             return None
         n, k = weight.shape
         lib = _native.library()

@@ -272,6 +272,43 @@ def _weight_only_gate_up(x: torch.Tensor, gate_proj: torch.nn.Module, up_proj: t
     return product
 
 
+def _weight_only_qkv(x: torch.Tensor, projections: tuple[torch.nn.Module, ...],
+                     stored: tuple[tuple[torch.Tensor, int], ...] | None = None) -> list[torch.Tensor] | None:
+    """``[q_proj(x), k_proj(x), v_proj(x)]`` of a WEIGHT-ONLY quantized attention block (plain bf16 `x`, quantized weights: BASELINE
+    configs 2 and 4) as ONE launch of the weight-code GEMM over the concatenated output columns (ops.linear_wq_multi): each output
+    is what the dispatcher's weight-only kernel gives for that projection (same operands; the K order of one tile walk). None
+    whenever that is not the situation (a set activation quantizer, a bias, a hook on a bypassed module, parameters the kernel does
+    not cover, differing granularities): the caller then runs the module forwards. `stored`: (codes, packing block) per weight
+    when the caller keeps them; else each weight quantizer runs here, as QuantizedLinear.forward would run it (nn/linear.py:34)."""
+    from fastforward_amd import fused_linear
+    from fastforward_amd.nn import QuantizedLinear
+
+    kernels = fused_linear.KERNELS
+    if not fused_linear._WEIGHT_ONLY_KERNEL or not _one_pass(x) or not x.is_contiguous() or _hooked(*projections):
+        return None
+    for lin in projections:
+        if (not isinstance(lin, QuantizedLinear) or lin.bias is not None or lin.weight_quantizer.is_stub()
+                or not _untouched(lin.input_quantizer, lin.output_quantizer) or _hooked(lin.input_quantizer, lin.output_quantizer)):
+            return None
+    if stored is not None:
+        groups = {kernels.weight_group(_Shaped(lin.weight, lin.weight_quantizer)) for lin in projections}
+        if len(groups) != 1 or None in groups or len({block for _, block in stored}) != 1:
+            return None
+        quantizers = [lin.weight_quantizer for lin in projections]
+        return ff.ops.linear_wq_multi(x, [codes for codes, _ in stored], [q.scale for q in quantizers], [q.offset for q in quantizers],
+                                      group=groups.pop(), pack_block=stored[0][1], out_dtype=x.dtype)
+    weights = [lin.weight_quantizer(lin.weight) for lin in projections]
+    outs = None
+    if all(kernels.supported_weight_only(x, w) for w in weights) and len({kernels.weight_group(w) for w in weights}) == 1:
+        params = [kernels._scale_offset(w) for w in weights]
+        if len({o is None for _, o in params}) == 1:
+            outs = ff.ops.linear_wq_multi(x, [kernels._int8_codes(w) for w in weights], [s for s, _ in params], [o for _, o in params],
+                                          group=kernels.weight_group(weights[0]), out_dtype=x.dtype)
+    if outs is None:  # the weights are quantized already: finish the linears as QuantizedLinear.forward would
+        outs = [ff.nn.functional.linear(x, w, None, output_quantizer=lin.output_quantizer) for lin, w in zip(projections, weights)]
+    return outs
+
+
 def _w8a8_gate_up_down_input(x: torch.Tensor, gate_proj: torch.nn.Module, up_proj: torch.nn.Module, down_proj: torch.nn.Module):
     """The input of ``down_proj``'s GEMM on a W8A8 model — ``down_proj.input_quantizer(silu(gate_proj(x)) * up_proj(x))`` — from ONE
     launch of the int8 GEMM's gate/up mode (ops.mlp_gate_up_w8a8: both projections, SiLU * up and A1 in its epilogue; equal to the
@@ -346,8 +383,12 @@ class QuantizedLlamaAttention(QuantizedModule, LlamaAttention):
         hidden_states = self.input_quantizer(hidden_states)
         cfg = self.config
         if hidden_states.dim() == 3 and _one_pass(hidden_states) and attention_kernel_covers(cfg, hidden_states.shape[1], hidden_states.dtype):
-            with sibling_quantizers():  # equal input quantizers on the same hidden state share one A1 launch
-                q, k, v = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
+            fused_qkv = _weight_only_qkv(hidden_states, (self.q_proj, self.k_proj, self.v_proj)) if type(hidden_states) is torch.Tensor else None
+            if fused_qkv is not None:
+                q, k, v = fused_qkv
+            else:
+                with sibling_quantizers():  # equal input quantizers on the same hidden state share one A1 launch
+                    q, k, v = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
             if _one_pass(q, k, v, cos, sin) and cos.dim() == 2 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous():
                 # rotary embedding in place on the projections, then softmax(q k^T) v as one flash-style launch
                 ff.ops.rope_(q, k, cos, sin, cfg.head_dim)
@@ -957,12 +998,12 @@ class FusedProducersForward:
             if stored is not None:
                 wq = linear.weight_quantizer
                 group = ff.fused_linear.KERNELS.weight_group(_Shaped(linear.weight, wq))
-                if x.numel() // x.shape[-1] >= ff.fused_linear._WEIGHT_ONLY_MIN_TOKENS:
+                if ff.fused_linear._WEIGHT_ONLY_KERNEL:
                     out = ff.ops.linear_wq(x, stored[0], wq.scale, wq.offset, group=group, pack_block=stored[1], out_dtype=x.dtype)
                     if out is not None:
                         return out
-                # below the dispatcher's weight-only threshold (fused_linear.weight_only_kernel: 256 x 256 tiles leave most of
-                # the chip idle there): the reference's own route from the stored codes — A2 (or unpack + A2), float GEMM
+                # outside the kernel's coverage (or inside ``weight_only_kernel(False)``, the A/B arm): the reference's own route
+                # from the stored codes — A2 (or unpack + A2), float GEMM
                 tile = (1, group)
                 if stored[1]:
                     weight = ff.ops.unpack_dequantize_int4(stored[0], wq.scale, linear.weight.shape, tile, wq.offset, block=stored[1], output_dtype=x.dtype)
@@ -981,6 +1022,21 @@ class FusedProducersForward:
         # recognised by the GEMM on the device (no host read while a range estimator rewrites the parameters on every step)
         w_offset = None if wp.offset is None or ff.fused_linear.known_zero_offset(wp.offset) else wp.offset
         return ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, None, out_dtype=torch.bfloat16)
+
+    def _qkv(self, normed: torch.Tensor, attn: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """The three projections of the attention block: one launch for weight-only linears the GEMM covers, else one by one."""
+        projections = (attn.q_proj, attn.k_proj, attn.v_proj)
+        if all(p.input_quantizer.is_stub() for p in projections):
+            stored = None
+            if self.weight_storage != "requantize":
+                kept = tuple(self._stored_weight(p) for p in projections)
+                stored = kept if all(k is not None for k in kept) else None
+            if stored is not None or self.weight_storage == "requantize":
+                outs = _weight_only_qkv(normed, projections, stored)
+                if outs is not None:
+                    return outs[0], outs[1], outs[2]
+        with sibling_quantizers():
+            return self._linear(normed, attn.q_proj), self._linear(normed, attn.k_proj), self._linear(normed, attn.v_proj)
 
     def _gate_up(self, normed: torch.Tensor, mlp: torch.nn.Module) -> torch.Tensor:
         """silu(gate_proj(x)) * up_proj(x): one launch for a weight-only MLP the GEMM covers, else the two linears + SiLU * up."""
@@ -1011,8 +1067,7 @@ class FusedProducersForward:
                 attn, mlp = layer.self_attn, layer.mlp
                 ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
                 hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, ln1.weight, ln1.variance_epsilon, (), want_norm=True, sum_inplace=pending is not None)
-                with sibling_quantizers():
-                    q, k, v = self._linear(normed, attn.q_proj), self._linear(normed, attn.k_proj), self._linear(normed, attn.v_proj)
+                q, k, v = self._qkv(normed, attn)
                 ff.ops.rope_(q, k, cos, sin, d)
                 if attention_kernel_covers(cfg, s, q.dtype):
                     ctx, _ = ff.ops.attention(q, k, v, d, causal=s > 1)

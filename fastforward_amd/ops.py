@@ -38,6 +38,7 @@ __all__ = [
     "grid_sqerror_by_tile",
     "linear_w8a8",
     "linear_wq",
+    "linear_wq_multi",
     "mlp_gate_up_w8a8",
     "add_rmsnorm_quantize",
     "silu_mul_quantize",
@@ -719,24 +720,89 @@ def linear_wq(
     return out
 
 
-_WQ_SLAB_BYTES = 32 * 8 * 64 * 16  # one (tile, K slice) unit's partial accumulators (csrc/ffq_wlinear.hip: WL_UNIT_SLAB)
+def linear_wq_multi(
+    x: torch.Tensor,
+    w_codes: Sequence[torch.Tensor],
+    w_scales: Sequence[torch.Tensor],
+    w_offsets: Sequence[torch.Tensor | None],
+    group: int | None = None,
+    out_dtype: torch.dtype | None = None,
+    pack_block: int = 0,
+    two_pass: bool | None = None,
+    split: int = 0,
+) -> list[torch.Tensor] | None:
+    """Two or three weight-only linears on the SAME input in one launch (q_proj / k_proj / v_proj: three ``QuantizedLinear``
+    modules reading one hidden state, reference nn/linear.py:32-39): ``[linear_wq(x, w_i, ...) for i]`` as separate tensors, from
+    one tile walk over all the column tiles. Operands as :func:`linear_wq`; all weights share dtype, packing, `group`, the
+    granularity kind and the presence of offsets, every weight but the last has a multiple of 256 rows. None when that does
+    not hold (the caller runs the linears one by one)."""
+    count = len(w_codes)
+    if not (2 <= count <= 3) or len(w_scales) != count or len(w_offsets) != count:
+        return None
+    K = x.shape[-1]
+    packed = pack_block > 0
+    rows = []
+    for c in w_codes:
+        if packed:
+            if c.dtype != torch.uint8 or K == 0 or (c.numel() * 2) % K:
+                return None
+            rows.append(c.numel() * 2 // K)
+        else:
+            if c.dim() != 2 or c.shape[1] != K:
+                return None
+            rows.append(c.shape[0])
+    group = K if group is None else int(group)
+    out_dtype = out_dtype or x.dtype
+    if x.dtype not in _TAGS or any(c.dtype != w_codes[0].dtype for c in w_codes) or w_codes[0].dtype not in _TAGS or out_dtype not in _TAGS:
+        return None
+    if any(n % 256 for n in rows[:-1]) or any((o is None) != (w_offsets[0] is None) for o in w_offsets):
+        return None
+    M = x.numel() // K if K else 0
+    N = sum(rows)
+    lib = _native.library()
+    if not lib.ffq_linear_wq_supported(_tag(x.dtype), _tag(w_codes[0].dtype), _tag(out_dtype), M, N, K, group, int(pack_block)):
+        return None
+    flat = lambda t: None if t is None else t.detach().reshape(-1).to(torch.float32).contiguous()  # noqa: E731
+    scales, offsets = [flat(t) for t in w_scales], [flat(t) for t in w_offsets]
+    kinds = {int(s_.numel() != 1) for s_ in scales}
+    if len(kinds) != 1:
+        return None
+    per_row = kinds.pop()
+    for n, s_, o_ in zip(rows, scales, offsets):
+        if s_.numel() != (n * (K // group) if per_row else 1) or (o_ is not None and o_.numel() != s_.numel()):
+            return None
+    if not per_row and group != K:
+        return None
+    xc = x.detach().contiguous()
+    codes = [c.detach().contiguous() for c in w_codes]
+    lib, stream = _prepare(xc, *codes, *scales, *[o for o in offsets if o is not None])
+    outs = [torch.empty((*xc.shape[:-1], n), dtype=out_dtype, device=xc.device) for n in rows]
+    nbytes, tickets = _wq_scratch(lib, M, N, K, False, two_pass, split, xc.device, stream)
+    ws = _workspace(nbytes, xc.device)
+    ptrs = lambda tensors: (ctypes.c_void_p * count)(*[_ptr(t) for t in tensors])  # noqa: E731
+    lib.check(
+        lib.ffq_linear_wq_multi(
+            _ptr(xc), _tag(xc.dtype), count, ptrs(codes), _tag(codes[0].dtype), int(pack_block), ptrs(scales), ptrs(offsets), per_row, group,
+            ptrs(outs), _tag(out_dtype), M, (ctypes.c_int64 * count)(*rows), K, _ptr(ws), nbytes, _ptr(tickets), int(split), stream,
+        )
+    )
+    return outs
 
 
 def _wq_scratch(lib: Any, M: int, N: int, K: int, mlp: bool, two_pass: bool | None, split: int, device: torch.device, stream: int) -> tuple[int, torch.Tensor | None]:
     """(workspace bytes, ticket buffer) of a weight-only GEMM launch: the split-K slabs of the plan (or of a forced `split`) at the
     front, the bf16 image(s) of the two-pass form behind them."""
-    tickets = int(lib.ffq_linear_wq_tickets(M, N, K, int(mlp)))  # two per tile
-    tiles = tickets // 2
+    tickets = int(lib.ffq_linear_wq_tickets(M, N, K, int(mlp)))  # two per tile of the last round
     plan = int(lib.ffq_linear_wq_split(M, N, K, int(mlp)))
     use = max(1, int(split) if split > 0 else plan)
-    slabs = tiles * use * _WQ_SLAB_BYTES if use > 1 else 0
+    slabs = int(lib.ffq_linear_wq_slab_bytes(M, N, K, int(mlp), use))
     if two_pass is False:
         image = 0
     elif two_pass:
         image = (2 if mlp else 1) * N * K * 2
     else:  # the library's rule: its figure minus the slabs of its own plan
         full = int(lib.ffq_mlp_gate_up_wq_workspace_bytes(M, N, K) if mlp else lib.ffq_linear_wq_workspace_bytes(M, N, K))
-        image = full - (tiles * plan * _WQ_SLAB_BYTES if plan > 1 else 0)
+        image = full - int(lib.ffq_linear_wq_slab_bytes(M, N, K, int(mlp), plan))
     return slabs + image, (_tickets(tickets, device, stream) if use > 1 else None)
 
 

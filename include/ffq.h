@@ -212,27 +212,45 @@ int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum,
  * differs from F.linear. One launch converts the codes once per 256-row tile on their way into LDS; with enough `workspace`
  * behind the slabs (below) and from 4096 tokens on the weight is dequantized once per CALL by A2 into it and the GEMM streams
  * the bf16 image — same operands, same tile walk: bit-identical, faster at large M.
- * Split-K (ABI 7): the kernel is one persistent block per CU on 256 x 256 output tiles; a launch with fewer tiles than CUs
- * (2048 tokens x a 4096-wide projection: 128) cuts every tile's K range into ffq_linear_wq_split() slices whose fp32 partial
- * sums meet in `workspace` and are added in slice order by the last slice to arrive — no token count is left to a vendor GEMM.
- * The split is a pure function of (M, N, K): it fixes the summation order, i.e. results are reproducible call to call.
+ * Split-K (ABI 7): the kernel is one persistent block per CU on 256 x 256 output tiles; the tiles of the LAST, partly filled
+ * round of that walk (all tiles when there are fewer than CUs: 2048 tokens x a 4096-wide projection are 128) have their K range
+ * cut into ffq_linear_wq_split() slices, one work unit each on its own CU; the units of a tile exchange fp32 partial sums
+ * through `workspace` and each finishes a fixed share of the tile in a fixed summation order — no token count is left to a
+ * vendor GEMM. The split is a pure function of (M, N, K, CU count): results are reproducible call to call.
  *   workspace  [ffq_linear_wq_workspace_bytes()]: split-K slabs first, the two-pass image behind them. May be smaller or NULL:
  *              the launch then runs without the part that does not fit (never fails for lack of scratch).
  *   tickets    ffq_linear_wq_tickets() int32 counters, ZERO before the first launch that uses the buffer; every launch
  *              leaves them zero (keep one buffer per stream). NULL: no split.
- *   split      0 = the library's plan; >= 1 forces that many slices (tests, tuning); FFQ_ERR_ARG if the scratch for a forced
- *              split is missing.
+ *   split      0 = the library's plan; >= 1 forces that many slices (tests, tuning): ffq_linear_wq_slab_bytes(..., split) bytes
+ *              of workspace; FFQ_ERR_ARG if that scratch is missing or the units of the last round would not all fit the chip
+ *              at once (they wait for each other: tail tiles * split <= CUs).
  * ffq_linear_wq_supported() == 0 (K % 64 != 0, K < 128, other dtypes, group % 64 != 0): the caller dequantizes (A2) and
  * runs a float GEMM, as the reference does.
  */
 int ffq_linear_wq_supported(int x_dt, int w_dt, int out_dt, int64_t M, int64_t N, int64_t K, int64_t group, int64_t pack_block);
 int64_t ffq_linear_wq_split(int64_t M, int64_t N, int64_t K, int mlp);   /* mlp != 0: the plan of ffq_mlp_gate_up_wq */
 int64_t ffq_linear_wq_tickets(int64_t M, int64_t N, int64_t K, int mlp);
+size_t ffq_linear_wq_slab_bytes(int64_t M, int64_t N, int64_t K, int mlp, int64_t split);
 size_t ffq_linear_wq_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int ffq_linear_wq(const void* x, int x_dt, const void* w_codes, int w_dt, int64_t pack_block, const float* w_scale,
                   const float* w_offset, int64_t scale_numel, int64_t group, const void* bias, int bias_dt, void* out,
                   int out_dt, int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, int32_t* tickets,
                   int64_t split, void* stream);
+
+/*
+ * Two or three weight matrices on the SAME activations in one launch — q_proj / k_proj / v_proj of an attention block are three
+ * QuantizedLinear modules reading one hidden state (nn/linear.py:32-39 three times; docs/examples/doc_helpers/quantized_llama/
+ * attention.py:45-60): outs[i] = F.linear(x, dequantize(w_i)), the value ffq_linear_wq gives for each matrix (same operands; the
+ * summation order is that of ONE launch over the concatenated columns), written to `count` separate [M, Ns[i]] tensors. One tile
+ * walk covers all column tiles, so a 1024-column k/v projection no longer runs alone on a corner of the chip. All matrices share
+ * dtype, packing, `group`, the granularity kind (`per_row` != 0: Ns[i] * K / group parameter pairs each; 0: one pair each,
+ * group == K) and the presence of offsets; every matrix but the last has a multiple of 256 rows. workspace / tickets / split as
+ * ffq_linear_wq with N = sum(Ns) (ffq_linear_wq_workspace_bytes(M, N, K), ...).
+ */
+int ffq_linear_wq_multi(const void* x, int x_dt, int count, const void* const* w_codes, int w_dt, int64_t pack_block,
+                        const float* const* w_scale, const float* const* w_offset, int per_row, int64_t group, void* const* outs,
+                        int out_dt, int64_t M, const int64_t* Ns, int64_t K, void* workspace, size_t workspace_bytes, int32_t* tickets,
+                        int64_t split, void* stream);
 
 /*
  * The MLP front half of a WEIGHT-ONLY quantized Llama (docs/examples/doc_helpers/quantized_llama/mlp.py:30-40 with plain bf16

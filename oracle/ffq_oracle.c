@@ -706,6 +706,7 @@ size_t ffq_linear_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) { (void)M;
 /* the restatement sums every output in double: no tiles, no K slices */
 int64_t ffq_linear_wq_split(int64_t M, int64_t N, int64_t K, int mlp) { (void)M; (void)N; (void)K; (void)mlp; return 1; }
 int64_t ffq_linear_wq_tickets(int64_t M, int64_t N, int64_t K, int mlp) { (void)M; (void)N; (void)K; (void)mlp; return 0; }
+size_t ffq_linear_wq_slab_bytes(int64_t M, int64_t N, int64_t K, int mlp, int64_t split) { (void)M; (void)N; (void)K; (void)mlp; (void)split; return 0; }
 
 /* code (n, k) of a weight stored one code per byte, or packed two per byte as ffq_pack_int4 writes a row of K codes with
  * block `pack_block` (_packing.py:44-53: byte j of a block = code j | code (j + block / 2) << 4, both + 8) */
@@ -1239,6 +1240,24 @@ int ffq_quantize_rows_batch(const ffq_rows_batch* batch, int data_dt, void* stre
  * projections being fallback.linear with a quantized weight (_gen/fallback.py:86-112) in bf16 — restated as exactly that
  * composition of the functions above.
  */
+/* several weight matrices on the same activations (q / k / v projections; reference nn/linear.py:32-39 once per module): the
+ * composition of ffq_linear_wq calls above — the restatement has no tile walk to share */
+int ffq_linear_wq_multi(const void* x, int x_dt, int count, const void* const* w_codes, int w_dt, int64_t pack_block,
+                        const float* const* w_scale, const float* const* w_offset, int per_row, int64_t group, void* const* outs,
+                        int out_dt, int64_t M, const int64_t* Ns, int64_t K, void* workspace, size_t workspace_bytes, int32_t* tickets,
+                        int64_t split, void* stream) {
+  (void)workspace; (void)workspace_bytes; (void)tickets; (void)split;
+  if (count < 1 || count > 3 || !w_codes || !w_scale || !w_offset || !outs || !Ns) return fail(FFQ_ERR_ARG, "1 to 3 weight matrices");
+  for (int i = 0; i < count; ++i) {
+    if (i + 1 < count && Ns[i] % 256 != 0) return fail(FFQ_ERR_DTYPE, "every weight matrix but the last needs a multiple of 256 rows");
+    if ((w_offset[i] == NULL) != (w_offset[0] == NULL)) return fail(FFQ_ERR_ARG, "offsets for all weight matrices or for none");
+    int64_t numel = per_row ? Ns[i] * (K / group) : 1;
+    int rc = ffq_linear_wq(x, x_dt, w_codes[i], w_dt, pack_block, w_scale[i], w_offset[i], numel, group, NULL, 0, outs[i], out_dt, M, Ns[i], K, NULL, 0, NULL, 0, stream);
+    if (rc != FFQ_OK) return rc;
+  }
+  return FFQ_OK;
+}
+
 size_t ffq_mlp_gate_up_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) { (void)M; (void)N; (void)K; return 0; }
 
 int ffq_mlp_gate_up_wq(const void* x, int x_dt, const void* gate_codes, const void* up_codes, int w_dt, int64_t pack_block,

@@ -197,11 +197,9 @@ def check_weight_only_linear(device):
             with ff.fused_linear.weight_only_kernel(False):  # the A/B arm: nobody claims it, the reference's path runs (A2 + F.linear)
                 assert ff.dispatcher.dispatch("linear", input=x, weight=wq, bias=lin.bias) is None
                 y_reference_path = model(x)
-            # the hand-written bf16 x weight-code GEMM (the default from 4096 tokens on; the fixture is smaller)
-            assert ff.dispatcher.dispatch("linear", input=x, weight=wq, bias=lin.bias) is None
-            with ff.fused_linear.weight_only_kernel(True, min_tokens=0):
-                assert ff.dispatcher.dispatch("linear", input=x, weight=wq, bias=lin.bias) is ff.fused_linear.fused_linear_weight_only, c["name"]
-                y = model(x)
+            # the hand-written bf16 x weight-code GEMM: the default at every token count since round 4
+            assert ff.dispatcher.dispatch("linear", input=x, weight=wq, bias=lin.bias) is ff.fused_linear.fused_linear_weight_only, c["name"]
+            y = model(x)
         torch.testing.assert_close(y_reference_path.detach().cpu().float(), c["y"].float(), rtol=2.0**-7, atol=2e-4)
         assert same_with_nan(lin.weight_quantizer.scale.detach().cpu(), c["w_scale"]), c["name"]
         if c["w_offset"] is not None:

@@ -84,9 +84,9 @@ def test_dispatcher_hooks_serve_the_reference_operators(oracle_backend, tmp_path
             attached = adapter.install(device_types=("cpu",), register_linear=True)
             assert {"dispatcher:linear", "dispatcher:linear(weight-only)", "dispatcher:mm", "dispatcher:matmul", "dispatcher:bmm"} <= set(attached)
             assert ff_ref.dispatcher.dispatch("linear", input=qx, weight=qw) == adapter.REFERENCE_KERNELS.linear
-            assert ff_ref.dispatcher.dispatch("linear", input=x16, weight=qw16) is None  # 5 tokens: below the weight-only kernel's token threshold
-            policy = fused_linear.weight_only_kernel(True, min_tokens=0)
-            policy.__enter__()
+            with fused_linear.weight_only_kernel(False):  # the A/B arm: nobody claims a weight-only linear, the reference's path runs
+                assert ff_ref.dispatcher.dispatch("linear", input=x16, weight=qw16) is None
+            # 5 tokens: the weight-code GEMM takes every token count since round 4 (no threshold)
             assert ff_ref.dispatcher.dispatch("linear", input=x16, weight=qw16) == adapter.REFERENCE_KERNELS.weight_only_linear
             assert ff_ref.dispatcher.dispatch("mm", input=qx, mat2=qwt) == adapter.REFERENCE_KERNELS.mm
             assert ff_ref.dispatcher.dispatch("matmul", input=qx, other=qwt) == adapter.REFERENCE_KERNELS.mm

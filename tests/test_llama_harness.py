@@ -230,37 +230,43 @@ def test_producers_forward_weight_only_on_gpu(hip_backend):
 @pytest.mark.parametrize("w_bits,block", [(8, None), (4, 128)])
 def test_weight_only_storage_forms_agree_bit_for_bit(hip_backend, w_bits, block):
     """BASELINE configs 2 / 4 on a small Llama: the weight quantizer on every call ("requantize"), kept int8 codes, kept
-    packed nibbles — below the dispatcher's token threshold (A2 + float GEMM on every route) and above it (the weight-code
-    GEMM with its one-launch gate/up/SiLU mode on every route) — produce the SAME logits: one set of codes, one dequantized
-    weight, one summation order per route. The module graph agrees as well (its MLP takes the same one-launch mode)."""
-    cfg = llama.LlamaConfig.tiny()
+    packed nibbles — inside ``weight_only_kernel(False)`` (the A/B arm: A2 + float GEMM on every route) and with the hand-written
+    weight-code GEMM (its one-launch q/k/v and gate/up/SiLU modes on every route; 192 tokens: no token count is left to the
+    vendor's GEMM since round 4) — produce the SAME logits: one set of codes, one dequantized weight, one summation order per
+    route. The module graph agrees as well (its attention and MLP take the same one-launch modes)."""
+    cfg = llama.LlamaConfig(hidden_size=512, intermediate_size=1024, num_layers=2, num_heads=4, num_kv_heads=2, vocab_size=512)  # q 512, k / v 256 rows
     model = llama.build_model(cfg, "cuda", torch.bfloat16, seed=5, std=0.05)
     llama.quantize_llama(model, w_bits=w_bits, a_bits=None, quantized_dtype=torch.int8,
                          weight_granularity=None if block is None else ff.PerBlock(1, block, 0))
     ids = torch.randint(0, cfg.vocab_size, (2, 96), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
     llama.calibrate(model, [ids])
-    launches = []
-    real = ff.ops.mlp_gate_up_wq
+    launches = {"mlp": [], "qkv": []}
+    real_mlp, real_qkv = ff.ops.mlp_gate_up_wq, ff.ops.linear_wq_multi
 
-    def counted(*a, **k):
-        out = real(*a, **k)
-        launches.append(out is not None)
-        return out
+    def counted(kind, real):
+        def call(*a, **k):
+            out = real(*a, **k)
+            launches[kind].append(out is not None)
+            return out
+        return call
 
-    for min_tokens in (1 << 30, 0):
-        with ff.fused_linear.weight_only_kernel(True, min_tokens=min_tokens), torch.no_grad(), ff.strict_quantization(False):
-            ff.ops.mlp_gate_up_wq = counted
+    for kernel in (False, True):
+        with ff.fused_linear.weight_only_kernel(kernel), torch.no_grad(), ff.strict_quantization(False):
+            ff.ops.mlp_gate_up_wq, ff.ops.linear_wq_multi = counted("mlp", real_mlp), counted("qkv", real_qkv)
             try:
-                launches.clear()
+                launches["mlp"].clear(), launches["qkv"].clear()
                 want = llama.FusedProducersForward(model)(ids, logits=True)
-                assert (len(launches) == cfg.num_layers and all(launches)) if min_tokens == 0 else not launches
+                for kind in ("mlp", "qkv"):
+                    assert (len(launches[kind]) == cfg.num_layers and all(launches[kind])) if kernel else not launches[kind], (kind, launches)
                 forms = ["codes"] + (["packed"] if w_bits == 4 else [])
                 for form in forms:
                     got = llama.FusedProducersForward(model, weight_storage=form)(ids, logits=True)
-                    assert torch.equal(got, want), (form, min_tokens, float((got.float() - want.float()).abs().max()))
+                    assert torch.equal(got, want), (form, kernel, float((got.float() - want.float()).abs().max()))
+                launches["qkv"].clear()
                 module = model(ids, logits=True)
+                assert (len(launches["qkv"]) == cfg.num_layers) if kernel else not launches["qkv"]
             finally:
-                ff.ops.mlp_gate_up_wq = real
+                ff.ops.mlp_gate_up_wq, ff.ops.linear_wq_multi = real_mlp, real_qkv
         # the module graph adds the residual before the next RMSNorm in its own order: same linears, close logits
         torch.testing.assert_close(module.float(), want.float(), rtol=0, atol=0.02 * float(want.float().std()) + 1e-3)
 

@@ -814,12 +814,15 @@ def test_weight_only_gate_up_launch_is_the_two_linears_and_silu_mul(m, n, k, gro
     assert ops.mlp_gate_up_wq(x.float(), gc, uc, gs, go, us, uo, group=group) is None
 
 
-@pytest.mark.parametrize("m,n,k,group,bits", [(1, 256, 2048, 2048, 8), (40, 520, 1024, 128, 4), (300, 256, 1536, 1536, 8), (515, 770, 2048, 128, 4), (2048, 1024, 4096, 4096, 8)])
+@pytest.mark.parametrize("m,n,k,group,bits", [(1, 256, 2048, 2048, 8), (40, 520, 1024, 128, 4), (300, 256, 1536, 1536, 8), (515, 770, 2048, 128, 4), (2048, 1024, 4096, 4096, 8),
+                                              (4352, 4096, 1024, 1024, 8), (4200, 4224, 768, 128, 4)])
 def test_weight_only_linear_split_k_slices_sum_in_a_fixed_order(m, n, k, group, bits):
-    """Split-K (fewer tiles than CUs: every tile's K range cut into slices, fp32 partial sums added in slice order by the last
-    slice to arrive): every forced split — incl. uneven slices and more units than CUs — stays within one output rounding of the
-    float64 product, repeats bit for bit launch after launch (no arrival-order dependence), leaves the ticket buffer zero, and
-    where the sums are order-independent (small integers, power-of-two scales) ALL splits give the same bits."""
+    """Split-K (the tiles of the last, partly filled round of the persistent walk — all tiles when there are fewer than CUs — have
+    their K range cut into slices; the units of a tile exchange fp32 partial sums and each finishes a fixed share in a fixed
+    order): every forced split — incl. uneven slices, ragged M / N, whole rounds ahead of the split tail (272 tiles: 16 of them
+    split) — stays within one output rounding of the float64 product, repeats bit for bit launch after launch (no dependence on
+    arrival order), leaves the ticket buffer zero, and where the sums are order-independent (small integers, power-of-two
+    scales) ALL splits give the same bits."""
     gen = torch.Generator().manual_seed(m + n + k)
     codes, scale, off = _wq_case(n, k, group, bits, True, seed=m + k)
     x = torch.randn(m, k, generator=gen).to(torch.bfloat16).to(DEV)
@@ -828,7 +831,9 @@ def test_weight_only_linear_split_k_slices_sum_in_a_fixed_order(m, n, k, group, 
     lib = _native.library()
     plan = int(lib.ffq_linear_wq_split(m, n, k, 0))
     # all units of a tile wait for each other: a split is admitted while tiles * split <= CUs (and slices keep >= 2 super-steps)
-    most = min(torch.cuda.get_device_properties(0).multi_processor_count // (int(lib.ffq_linear_wq_tickets(m, n, k, 0)) // 2), (k // 64) // 2, 32)
+    tail = int(lib.ffq_linear_wq_tickets(m, n, k, 0)) // 2  # tiles of the last round
+    assert tail > 0
+    most = min(torch.cuda.get_device_properties(0).multi_processor_count // tail, (k // 64) // 2, 32)
     assert 1 <= plan <= most
     packed = ops.pack_int4(codes, block=128) if bits == 4 else None
     for split in sorted({1, 2, 3, 5, 8, 16, plan}):
@@ -859,6 +864,44 @@ def test_weight_only_linear_split_k_slices_sum_in_a_fixed_order(m, n, k, group, 
         rc = lib.ffq_linear_wq(x.data_ptr(), int(_cabi.DType.BF16), codes.data_ptr(), int(_cabi.DType.I8), 0, scale.data_ptr(), None, scale.numel(), group, None, 0,
                                out.data_ptr(), int(_cabi.DType.BF16), m, n, k, None, 0, None, 2, None)
         assert rc != 0
+
+
+@pytest.mark.parametrize("m,rows,k,group,bits,offset", [(300, (512, 256, 256), 512, 512, 8, False), (2048, (1024, 256, 256), 1024, 128, 4, True), (77, (256, 130), 256, 64, 4, True),
+                                                        (4200, (768, 256, 320), 640, 640, 8, True)])
+def test_weight_only_linears_on_one_input_as_one_launch(m, rows, k, group, bits, offset, oracle_lib):
+    """ops.linear_wq_multi (q_proj / k_proj / v_proj: three QuantizedLinear modules on one hidden state, reference nn/linear.py:32-39
+    three times) == the separate ops.linear_wq calls BIT FOR BIT under the same split (one tile walk over the concatenated column
+    tiles, the same K order inside every tile), every storage form, ragged M and a ragged last matrix; the default plan within one
+    output rounding of float64; the oracle's composition agrees on a small case."""
+    gen = torch.Generator().manual_seed(m + k)
+    x = torch.randn(m, k, generator=gen).to(torch.bfloat16).to(DEV)
+    cases = [_wq_case(n, k, group, bits, offset, seed=m + n + i) for i, n in enumerate(rows)]
+    codes, scales, offs = [c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases]
+    want = [ops.linear_wq(x, c, s_, o, group=group, two_pass=False, split=1) for c, s_, o in cases]
+    forms = [("int8", dict(two_pass=False), codes)]
+    if m >= 4096:
+        forms.append(("int8, two passes", dict(two_pass=True), codes))
+    if bits == 4:
+        forms.append(("packed", dict(pack_block=64, two_pass=False), [ops.pack_int4(c, block=64) for c in codes]))
+    for label, kwargs, weights in forms:
+        got = ops.linear_wq_multi(x, weights, scales, offs, group=group, split=1, **kwargs)
+        assert got is not None and len(got) == len(rows), label
+        for g, w_, n in zip(got, want, rows):
+            assert g.shape == (m, n) and torch.equal(g, w_), f"{label}: " + mismatch_report(g.cpu(), w_.cpu())
+    planned = ops.linear_wq_multi(x, codes, scales, offs, group=group)
+    for g, (c, s_, o) in zip(planned, cases):
+        ref = x.double() @ ops.dequantize_by_tile(c, s_, (1, group), o, torch.bfloat16).double().t()
+        torch.testing.assert_close(g.double(), ref, rtol=2.0**-8, atol=1e-5 * float(ref.abs().max()) + 1e-6 * k)
+    assert torch.equal(ops.linear_wq_multi(x, codes, scales, offs, group=group, out_dtype=torch.float32)[1].to(torch.bfloat16), planned[1])
+    # not this kernel's: a middle matrix that is no multiple of 256 rows, mixed offsets
+    assert ops.linear_wq_multi(x, [codes[-1], codes[0]], [scales[-1], scales[0]], [offs[-1], offs[0]], group=group) is None or rows[-1] % 256 == 0
+    assert ops.linear_wq_multi(x, codes[:2], scales[:2], [offs[0], None if offs[1] is not None else scales[1]], group=group) is None
+    if m <= 300:
+        host = ops.linear_wq_multi  # the oracle through the same Python surface
+        with use_backend(oracle_lib):
+            cpu = host(x.cpu(), [c.cpu() for c in codes], [s_.cpu() for s_ in scales], [None if o is None else o.cpu() for o in offs], group=group)
+        for g, c_ in zip(planned, cpu):
+            torch.testing.assert_close(g.cpu().float(), c_.float(), rtol=2.0**-6, atol=2.0**-6 * float(c_.float().abs().max()))
 
 
 def test_weight_only_gate_up_against_the_oracle_composition(oracle_lib):

@@ -89,7 +89,7 @@ def cfg2() -> dict:
         producers = llama.FusedProducersForward(model)
         s = timed_forward(lambda: producers(batch, logits=True))
         out[f"forward_B{b}_S2048"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(b * 2048 / s, 1),
-                                      "forward": "FusedProducersForward (RMSNorm / rotary / SiLU*up / attention as one-pass kernels); decoder linears: weight quantizer every call (A1), then the hand-written bf16 x weight-code GEMM (ops.linear_wq: A2 once per call + bf16-image GEMM from 4096 tokens on, conversion inside the GEMM below) — no vendor GEMM on the quantized path; lm_head stays float"}
+                                      "forward": "FusedProducersForward (RMSNorm / rotary / SiLU*up / attention as one-pass kernels); decoder linears: weight quantizer every call (A1), then the hand-written bf16 x weight-code GEMM at every token count (q/k/v as one launch: ops.linear_wq_multi; gate+up+SiLU*up as one launch: ops.mlp_gate_up_wq; o_proj / down_proj: ops.linear_wq; below 4096 tokens the codes are converted inside the GEMM and the tiles of a partly filled round are split along K, from 4096 tokens on A2 runs once per call into a bf16 image) — no vendor GEMM on the quantized path; lm_head stays float"}
         with ff.fused_linear.weight_only_kernel(False):  # A/B arm: the reference's own path for such linears (A2 + F.linear = the vendor's bf16 GEMM)
             s = timed_forward(lambda: producers(batch, logits=True))
         out[f"forward_B{b}_S2048_vendor_gemm_arm"] = {"ms": round(s * 1e3, 2), "tokens_per_s": round(b * 2048 / s, 1),
