@@ -128,10 +128,10 @@ def pmc_traffic(*needles: str, stems: tuple[str, ...] = ("_pmc_", "_pmc_hbm_")) 
     return None, None
 
 
-def pmc_traffic_mix(needle: "str | tuple[str, ...]") -> tuple[float | None, dict, str | None]:
-    """Launch-count-weighted mean of the fabric bytes per launch over EVERY kernel variant whose name contains `needle`
-    (the PMC pass profiles the same forward, so its launch counts are the forward's launch mix), the per-variant
-    figures, and the profile the numbers come from."""
+def pmc_traffic_mix(needle: "str | tuple[str, ...]", keep=None) -> tuple[float | None, dict, str | None]:
+    """Launch-count-weighted mean of the fabric bytes per launch over the kernel variants whose name contains `needle` (and that
+    `keep(name)` accepts: the PMC pass profiles the whole bench command, calibration included, so the caller picks the variants
+    of the TIMED forward), the per-variant figures, and the profile the numbers come from."""
     tables = _pmc_tables("_pmc_")
     if tables is None:
         return None, {}, None
@@ -139,7 +139,7 @@ def pmc_traffic_mix(needle: "str | tuple[str, ...]") -> tuple[float | None, dict
     total, launches, variants = 0.0, 0, {}
     needles = needle if isinstance(needle, tuple) else (needle,)
     for name, row in r.items():
-        if any(n in name for n in needles) and name in w:
+        if any(n in name for n in needles) and name in w and (keep is None or keep(name)):
             b = float(row["hbm_read_bytes"] + w[name]["hbm_write_bytes"])
             variants[name] = {"launches": row["launches"], "bytes_per_launch": b}
             total += b * row["launches"]
@@ -208,7 +208,11 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
             launches += count
         per_shape = per_shape_random
     achieved = total_ops / total_ms / 1e9
-    traffic, traffic_variants, prof = pmc_traffic_mix(("w8a8_gemm256fq_kernel", "w8a8_gemm256fp_kernel"))  # the persistent kernel: 16x16x64 form, or the 32x32x32 form under FFQ_GEMM_FQ=0
+    # the timed forward launches two instantiations: <bf16, REQUANT=false, MLP=false, WOFF=false> and the gate+up launch
+    # <int8, true, true, false>; WOFF=true (weight offsets decided on the device) runs during CALIBRATION only — reported apart
+    woff = lambda name: name.rstrip().rstrip(")").rstrip().endswith("true>") or ", true>" in name.split("(")[0][-8:]  # noqa: E731
+    traffic, traffic_variants, prof = pmc_traffic_mix("w8a8_gemm256fq_kernel", keep=lambda name: not woff(name))
+    traffic_calibration, calibration_variants, _ = pmc_traffic_mix("w8a8_gemm256fq_kernel", keep=woff)
     # algorithmic bytes of the same launch mix: int8 activation codes + int8 weight codes read once, output written once
     # (bf16 for the plain launches; int8 codes for the gate+up launch, which reads two weight matrices)
     # (shape, launches per layer) as a LIST: with kv == h (an MHA config such as --model tiny) dict keys would collide
@@ -235,9 +239,11 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
         "traffic": traffic,
         "traffic_lookup": {"kernel_source_sha16_now": kernel_source_sha16(), "profiles": dict(PMC_STAMPS),
                            "note": "traffic figures are lookups of committed rocprofv3 --pmc passes (a process cannot profile itself); a profile whose stamp differs from kernel_source_sha16_now was measured on older kernel sources"},
-        "traffic_note": None if traffic is None else f"fabric (L2-miss) read+write bytes per launch from FETCH_SIZE x2 + WRITE_SIZE, launch-count-weighted mean over BOTH kernel variants of the forward "
-                        f"(plain bf16-out and the gate+up / SiLU / quantize launch); separate --pmc passes of profiles/{prof}_pmc_*.json. Infinity-Cache hits are counted, so this is L2->fabric traffic, an upper bound of HBM bytes",
+        "traffic_note": None if traffic is None else f"fabric (L2-miss) read+write bytes per launch from FETCH_SIZE x2 + WRITE_SIZE, launch-count-weighted mean over the two kernel variants the TIMED forward launches "
+                        f"(plain bf16-out and the gate+up / SiLU / quantize launch; the calibration-only WOFF variant is listed apart); separate --pmc passes of profiles/{prof}_pmc_*.json. Infinity-Cache hits are counted, so this is L2->fabric traffic, an upper bound of HBM bytes",
         "traffic_per_variant": traffic_variants,
+        "traffic_calibration_variant": {"bytes_per_launch": traffic_calibration, "variants": calibration_variants,
+                                        "note": "WOFF=true instantiation (weight offsets decided on the device): calibration steps only, NOT part of `traffic`"},
         "algorithmic_bytes_per_launch": alg_bytes / alg_launches,
         "algorithmic_bytes_note": "codes of x and W read once + output written once, mean over the same launch mix (5 plain launches + 1 gate+up launch per layer)",
         "avg_launch_ms": round(total_ms / launches, 4),
@@ -248,6 +254,32 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
         "vendor_int8_gemm_same_shapes_uniform_random": vendor,
         "vendor_note": "torch._int_mm (hipBLASLt's tuned assembly, int32 output, no epilogue) on the same shapes and fill: a reference point for what the chip sustains, never on the product path",
     }
+
+
+def host_us_per_op(device: torch.device, calls: int = 1000) -> dict:
+    """Host cost of the op route (torch.library registration in Python -> ctypes -> C ABI; SURVEY 8(b)(i) words a C++ extension):
+    `calls` eager A1 launches on a 256-element tensor through torch.ops.fastforward_amd.quantize_by_tile and through the plain
+    ops.quantize_by_tile wrapper, wall time per call with the device drained before and after (the kernel itself is ~2 us)."""
+    x = torch.randn(256, device=device, dtype=torch.bfloat16)
+    scale = torch.tensor([0.05], device=device)
+    out = {}
+    routes = {"ops.quantize_by_tile (python wrapper -> ctypes)": lambda: ops.quantize_by_tile(x, scale, (256,), 8, torch.int8),
+              "torch.ops.fastforward_amd.quantize_by_tile (dispatcher -> python impl -> ctypes)":
+                  lambda: torch.ops.fastforward_amd.quantize_by_tile(x, scale, [256], 8.0, torch.int8, None)}
+    for name, fn in routes.items():
+        try:
+            for _ in range(50):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                fn()
+            torch.cuda.synchronize()
+            out[name] = round((time.perf_counter() - t0) / calls * 1e6, 2)
+        except Exception as e:  # noqa: BLE001  (a schema detail must not cost the bench line)
+            out[name] = f"unavailable: {type(e).__name__}: {str(e)[:80]}"
+    out["calls"] = calls
+    return out
 
 
 def hbm_kernels(device: torch.device) -> list[dict]:
@@ -411,6 +443,8 @@ def main() -> None:
                     "eager RMSNorm / rotary / SiLU) instead of llama.FusedForward (A1 fused into those producers)")
     ap.add_argument("--cache-weight-codes", action="store_true", help="keep int8 weight codes across steps (NOT the headline: the reference re-quantizes)")
     ap.add_argument("--no-side-measurements", action="store_true", help="skip roofline / cpu_baseline legs")
+    ap.add_argument("--force-dist", action="store_true", help="create the process group even for one rank: the range all-reduce and the cross-rank "
+                    "check then run through the collective backend (RCCL with one rank executes the same all_reduce(MIN) an 8-GPU run issues)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -419,7 +453,7 @@ def main() -> None:
     if args.calib_seqs is None:
         args.calib_seqs = max(args.batch, 512 // args.gpus)
 
-    rank, local_rank, world = ffd.init_process_group_from_env()
+    rank, local_rank, world = ffd.init_process_group_from_env(force=args.force_dist)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)")
     assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
@@ -579,11 +613,11 @@ def main() -> None:
             "forward": "module graph (reference-shaped)" if fused is None else "llama.FusedForward (A1 fused into RMSNorm / SiLU*up / attention, rotary in place)",
         },
         "world_size": torch.distributed.get_world_size() if world > 1 else 1,
-        "collective_backend": (torch.distributed.get_backend() + (" (RCCL over xGMI)" if torch.distributed.get_backend() == "nccl" else "")) if world > 1 else None,
+        "collective_backend": (torch.distributed.get_backend() + (" (RCCL over xGMI)" if torch.distributed.get_backend() == "nccl" else "")) if torch.distributed.is_initialized() else None,
         "module_graph_drop_in": module_graph,
         "calibration": {"sequences_per_gpu": calib_steps * args.batch, "sequences_total": calib_steps * args.batch * world, "seconds": round(calib_s, 3),
                         "sequences_per_s_all_gpus": round(calib_steps * args.batch * world / calib_s, 2),
-                        "allreduce_floats": payload, "collective": "1 x all_reduce(MIN) over RCCL" if world > 1 else "none (1 GPU)",
+                        "allreduce_floats": payload, "collective": "1 x all_reduce(MIN) over RCCL" if world > 1 else ("1 x all_reduce(MIN) through a one-rank group (--force-dist)" if torch.distributed.is_initialized() else "none (1 GPU)"),
                         # self-validation of the sharded path (N > 1): ranks that took part, wall time of the one collective, and
                         # whether every rank ended with bit-identical quantizer parameters (two extra all-reduces on the fingerprint)
                         "ranks_seen": ranks_seen, "ranges_identical_across_ranks": ranges_identical,
@@ -597,11 +631,12 @@ def main() -> None:
         result["hbm_kernels"] = hbm_kernels(device)
         if fused is not None:
             result["attention_kernel"] = attention_kernel(config, args.batch, args.seq_len, device)
+        result["host_us_per_op"] = host_us_per_op(device)
         if world == 1:
             result["cpu_baseline"] = cpu_baseline(config)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -199,15 +199,17 @@ template <typename TIn, typename TOut, int E>
 static int dq_launch_stream(const TIn* in, TOut* out, const float* scale, int64_t scale_numel,
                             const float* offset, int64_t offset_numel, const TileInfo& info,
                             hipStream_t stream) {
+#ifdef FFQ_EXPERIMENTS  // 2 / 4 chunks per lane: tuning builds only (the product instantiates the one form it launches)
   int u = 1;
-#ifdef FFQ_EXPERIMENTS
   if (const char* e = getenv("FFQ_STREAM_U")) u = atoi(e) ? atoi(e) : 1;
-#endif
   switch (u) {
     case 1: return dq_launch_stream_u<TIn, TOut, E, 1>(in, out, scale, scale_numel, offset, offset_numel, info, stream);
     case 4: return dq_launch_stream_u<TIn, TOut, E, 4>(in, out, scale, scale_numel, offset, offset_numel, info, stream);
     default: return dq_launch_stream_u<TIn, TOut, E, 2>(in, out, scale, scale_numel, offset, offset_numel, info, stream);
   }
+#else
+  return dq_launch_stream_u<TIn, TOut, E, 1>(in, out, scale, scale_numel, offset, offset_numel, info, stream);
+#endif
 }
 
 template <typename TIn, typename TOut, int E>
@@ -262,13 +264,11 @@ static int dq_dispatch_fast(const void* data, const void* scale, int64_t scale_n
   // load, two half-dense 16 B stores): 30.1 vs 32.1 us on [14336, 4096] int8 -> bf16 (FFQ_DQ_E16=1 to compare)
 #ifdef FFQ_EXPERIMENTS
   const char* e16 = getenv("FFQ_DQ_E16");
-#else
-  const char* e16 = nullptr;
-#endif
   if (sizeof(TIn) == 1 && e16 && e16[0] == '1') {
     rc = dq_dispatch_fast_e<TIn, TOut, 16>(data, scale, scale_numel, offset, offset_numel, info, out, stream, done);
     if (rc || *done) return rc;
   }
+#endif
   rc = dq_dispatch_fast_e<TIn, TOut, 8>(data, scale, scale_numel, offset, offset_numel, info, out, stream, done);
   if (rc || *done) return rc;
   if (info.layout == LAYOUT_CHANNEL && info.inner == 1 && info.channels % 8 == 0) {

@@ -249,10 +249,14 @@ static int launch_stream_u(const TIn* in, TOut* out, const float* scale, int64_t
     else                                                                                             \
       quantize_stream_kernel<TIn, TOut, LAYOUT, E, U, false, D><<<grid, block, 0, stream>>>(in, out, scale, offset, a); \
   } while (0)
+#ifdef FFQ_EXPERIMENTS  // the IEEE-division form of the streaming kernels exists in tuning builds only (round 4: 1,637 -> ~500 device kernels)
 #define FFQ_LAUNCH(LAYOUT)                                                                           \
   do {                                                                                               \
     if (div_mode() == 1) FFQ_LAUNCH_D(LAYOUT, 1); else FFQ_LAUNCH_D(LAYOUT, 0);                      \
   } while (0)
+#else
+#define FFQ_LAUNCH(LAYOUT) FFQ_LAUNCH_D(LAYOUT, 1)
+#endif
   switch (info.layout) {
     case LAYOUT_SCALAR: FFQ_LAUNCH(LAYOUT_SCALAR); break;
     case LAYOUT_ROWS:
@@ -274,6 +278,7 @@ template <typename TIn, typename TOut, int E>
 static int launch_stream(const TIn* in, TOut* out, const float* scale, int64_t scale_numel,
                          const float* offset, int64_t offset_numel, const TileInfo& info, float lo,
                          float hi, hipStream_t stream) {
+#ifdef FFQ_EXPERIMENTS  // chunks per lane: one in the product (measured fastest, see above); 2 / 4 in tuning builds only
   int u = stream_u_override();
   if (u == 0) u = 1;
   switch (u) {
@@ -281,6 +286,9 @@ static int launch_stream(const TIn* in, TOut* out, const float* scale, int64_t s
     case 4: return launch_stream_u<TIn, TOut, E, 4>(in, out, scale, scale_numel, offset, offset_numel, info, lo, hi, stream);
     default: return launch_stream_u<TIn, TOut, E, 2>(in, out, scale, scale_numel, offset, offset_numel, info, lo, hi, stream);
   }
+#else
+  return launch_stream_u<TIn, TOut, E, 1>(in, out, scale, scale_numel, offset, offset_numel, info, lo, hi, stream);
+#endif
 }
 
 template <typename TIn, typename TOut, int E>

@@ -40,6 +40,9 @@
 
 #include <type_traits>
 
+#ifndef FFQ_WL_LOOP_MODE
+#define FFQ_WL_LOOP_MODE 0  // K-loop of the bf16-image form: 0 = ping-pong wave groups (8 raw barriers per super-step), 1 = free-running waves
+#endif                      //   with fragments fetched one phase ahead and ONE barrier per super-step (experiment, tools/build_variant.sh)
 #ifndef FFQ_WL_CLUSTER_MODE
 #define FFQ_WL_CLUSTER_MODE 0  // how a conversion cluster mixes its VALU work with its MFMAs: 0 = the compiler's choice, 1 = three / 2 = two VALU behind each MFMA
 #endif
@@ -434,6 +437,53 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(0);
   };
+  // ---- free-running form (FFQ_WL_LOOP_MODE 1, bf16 image only): fragments double-buffered in registers, fetched one phase ahead
+  constexpr bool FREE = !CODES && FFQ_WL_LOOP_MODE == 1;
+  // ---- whole-k-chunk phases (FFQ_WL_LOOP_MODE 2, bf16 image only): a phase = one 32-deep k-chunk x ALL eight row tiles of the
+  // wave: 12 fragment reads + 4 LDS-DMA pieces in the LOAD segment, 32 MFMAs in the cluster, 4 barriers per super-step instead of 8
+  constexpr bool WIDE = !CODES && FFQ_WL_LOOP_MODE == 2;
+  [[maybe_unused]] wl_v4i fa8[8];
+  auto read_frags_q = [&](const uint8_t* st, int kq) {
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) fb[nj] = *reinterpret_cast<const wl_v4i*>(st + b_off[kq] + nj * 2048);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) fa8[q] = *reinterpret_cast<const wl_v4i*>(st + a_off[kq] + q * 2048);
+  };
+  auto cluster_q = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int n_ = 0; n_ < 4; ++n_) {
+        const int nj = (q & 1) ? 3 - n_ : n_;
+        acc[q][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wl_v8bf, fb[nj]), __builtin_bit_cast(wl_v8bf, fa8[q]), acc[q][nj], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  [[maybe_unused]] wl_v4i fa2[2][4], fb2[2][4];
+  auto read_frags2 = [&](const uint8_t* st, int phase) {  // into the buffers phase `phase` computes from: fa2[phase & 1], fb2[(phase >> 1) & 1]
+    const int kq = phase >> 1, mh = phase & 1;
+    if (mh == 0) {
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) fb2[kq & 1][nj] = *reinterpret_cast<const wl_v4i*>(st + b_off[kq] + nj * 2048);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fa2[phase & 1][q] = *reinterpret_cast<const wl_v4i*>(st + a_off[kq] + (4 * mh + q) * 2048);
+  };
+  auto cluster2 = [&](int phase) {
+    const int kq = phase >> 1, mh = phase & 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int n_ = 0; n_ < 4; ++n_) {
+        const int nj = (q & 1) ? 3 - n_ : n_;
+        acc[4 * mh + q][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wl_v8bf, fb2[kq & 1][nj]), __builtin_bit_cast(wl_v8bf, fa2[phase & 1][q]),
+                                                                  acc[4 * mh + q][nj], 0, 0, 0);
+      }
+  };
   constexpr std::integral_constant<bool, CODES> kConverts{};
   constexpr std::false_type kNoWork{};
 
@@ -453,6 +503,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
   wait_all_vmem();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if constexpr (FREE) read_frags2(lds, 0);
 
   int slot = 0;  // slot of the super-step about to be computed
   for (int it = 0; it < my_tiles; ++it) {
@@ -464,13 +515,55 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
         for (int e = 0; e < 4; ++e) acc[mi][nj][e] = 0.0f;
     int nm0, nn0, nk0, nk1, ntile_no, nslice, nseg;
     tile_origin(it + 1, nm0, nn0, nk0, nk1, ntile_no, nslice, nseg);
-    if (wm == 1) __builtin_amdgcn_s_barrier();  // the upper group runs one interval behind
+    if (!FREE && wm == 1) __builtin_amdgcn_s_barrier();  // the upper group runs one interval behind
     for (int ks = k0; ks < k1; ++ks) {
       const uint8_t* st = lds + slot * WL_SLOT;
       // images / conversion: element e + 1; code loads: element e + 2
       const bool last = ks == k1 - 1;
       const int fetch = last ? nk0 : ks + 1;
       if (last) set_image_sources(nm0, nn0, nseg);
+      if constexpr (FREE) {
+        // every wave on its own: the fragments of phase p + 1 are requested ahead of the MFMAs of phase p (registers for both), the
+        // pieces of the next super-step go out at the head of phases 0 and 1, and ONE barrier per super-step — ahead of phase 3:
+        // this wave's pieces have landed (vmcnt) and its reads of this slot are done (lgkmcnt) — publishes the other slot for
+        // reading and this one for refilling
+        issue_a(fetch, slot ^ 1, 0); issue_b(fetch, slot ^ 1, 0);
+        read_frags2(st, 1);
+        cluster2(0);
+        issue_a(fetch, slot ^ 1, 2); issue_b(fetch, slot ^ 1, 2);
+        read_frags2(st, 2);
+        cluster2(1);
+        read_frags2(st, 3);
+        cluster2(2);
+        wait_all_vmem();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        read_frags2(lds + (slot ^ 1) * WL_SLOT, 0);
+        cluster2(3);
+        slot ^= 1;
+        continue;
+      }
+      if constexpr (WIDE) {
+        // all eight pieces go out in the first LOAD segment and are waited for in the second one, ahead of its barrier: the other
+        // group's first read of the new slot lies behind a barrier this wave passes only after its wait (RAW: wait -> barrier -> read)
+        read_frags_q(st, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_a(fetch, slot ^ 1, 0); issue_b(fetch, slot ^ 1, 0); issue_a(fetch, slot ^ 1, 2); issue_b(fetch, slot ^ 1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        cluster_q();
+        __builtin_amdgcn_s_barrier();
+        read_frags_q(st, 1);
+        wait_all_vmem();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        cluster_q();
+        __builtin_amdgcn_s_barrier();
+        slot ^= 1;
+        continue;
+      }
       int code_ks = ks + 2;
       bool code_new_tile = false;
       if (code_ks >= k1) {
@@ -513,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
       __builtin_amdgcn_s_barrier();
       slot ^= 1;
     }
-    if (wm == 0) __builtin_amdgcn_s_barrier();  // same number of barriers for both groups
+    if (!FREE && wm == 0) __builtin_amdgcn_s_barrier();  // same number of barriers for both groups
     // ---- epilogue in the A image of the slot just consumed. The weight fragment is the MFMA's first operand: lane l holds,
     // for tile (mi, nj), register t: row m = 16 mi + l % 16, column n = 16 nj + 4 (l / 16) + t — four consecutive output
     // columns of one row.

@@ -43,13 +43,15 @@ from fastforward_amd.nn.quantizer import Quantizer
 from fastforward_amd.range_setting.minmax import RunningMinMaxEstimator
 
 
-def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, int]:
+def init_process_group_from_env(backend: str | None = None, force: bool = False) -> tuple[int, int, int]:
     """(rank, local_rank, world_size) from RANK / LOCAL_RANK / WORLD_SIZE; initialises the default
-    group with "nccl" (= RCCL) when a HIP device is present, else "gloo"."""
+    group with "nccl" (= RCCL) when a HIP device is present, else "gloo". A single process needs no group; ``force`` creates
+    the one-rank group anyway, so that the collectives of this module run through the backend (RCCL executes the very
+    all_reduce(MIN) kernel an 8-GPU run issues — what a one-GPU box can prove about the multi-GPU path)."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:  # FFQ_DIST_BACKEND=gloo: several ranks on one GPU (a control-flow check; RCCL wants one device per rank)
@@ -121,7 +123,7 @@ def all_reduce_ranges(model: torch.nn.Module, group: dist.ProcessGroup | None = 
     statuses = torch.stack([e.status.to(device) if e.status is not None else torch.zeros(1, dtype=torch.int32, device=device) for _, e in pairs])
     any_inf = (statuses & ops.FLAG_INF).max().to(torch.float32).reshape(1)  # 1.0 if any quantizer saw +-Inf
     packed = torch.cat(mins + [-m for m in maxs] + [-any_inf])
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():  # a one-rank group (init_process_group_from_env(force=True)) runs the collective too
         timed = packed.is_cuda
         if timed:  # the caller reads a flag off the result right below anyway: one more drain costs nothing and gives the time
             torch.cuda.synchronize(packed.device)
@@ -212,7 +214,7 @@ def ranges_agree_across_ranks(model: torch.nn.Module, group: dist.ProcessGroup |
     the fingerprint vector (element-wise MIN and MAX over ranks agree exactly where all ranks agree) and a SUM of ones;
     a self-check for multi-GPU runs, not part of the calibration path."""
     fingerprint = ranges_fingerprint(model)
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not dist.is_initialized():
         return True, 1
     bits = fingerprint.view(torch.int32).clone()  # compare bit patterns: NaNs and signed zeros included
     lo, hi = bits.clone(), bits.clone()
