@@ -155,7 +155,8 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_dequantize_by_tile": (_i, [_vp, _i, _vp, _i, _i64, _vp, _i, _i64, _tp, _vp, _i, _vp]),
     "ffq_dequantize_result_dtype": (_i, [_i, _i, _i, _i]),
     "ffq_minmax_workspace_bytes": (_sz, [_tp, _i]),
-    "ffq_minmax_by_tile": (_i, [_vp, _i, _tp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "ffq_minmax_by_tile": (_i, [_vp, _i, _tp, _vp, _vp, _i, _vp, _vp, _sz, _vp, _vp]),
+    "ffq_running_minmax_step": (_i, [_vp, _i, _tp, _vp, _vp, _vp, _d, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp]),
     "ffq_parameters_for_range": (_i, [_vp, _vp, _i, _i64, _d, _i, _i, _vp, _i, _vp, _i, _vp]),
     "ffq_quantize_dynamic_workspace_bytes": (_sz, [_tp, _i]),
     "ffq_quantize_dynamic_by_tile": (_i, [_vp, _i, _tp, _d, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),

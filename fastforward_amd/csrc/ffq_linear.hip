@@ -700,9 +700,19 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   }
 }
 
-// one wavefront per row: sum of K int8 codes. `gate` (nullable): a device word; 0 = the sums are not needed (nothing is read)
+// one wavefront per row: sum of K int8 codes. `gate` (nullable): a device word; 0 = the sums are not needed (nothing is read).
+// `offsets` (nullable): block 0 also decides whether any rounded entry of the `n_offsets` weight offsets is non-zero and writes
+// `flag` — the job of offsets_nonzero_kernel folded into a launch that runs anyway (one launch fewer per linear and calibration step)
 __global__ __launch_bounds__(256) void rowsum_i8_kernel(const int8_t* __restrict__ q, int rows, int K,
-                                                        int32_t* __restrict__ sums, const int32_t* __restrict__ gate) {
+                                                        int32_t* __restrict__ sums, const int32_t* __restrict__ gate,
+                                                        const float* __restrict__ offsets = nullptr, int n_offsets = 0,
+                                                        int32_t* __restrict__ flag = nullptr) {
+  if (offsets && blockIdx.x == 0) {
+    int any = 0;
+    for (int i = threadIdx.x; i < n_offsets; i += 256) any |= rne(offsets[i]) != 0.0f;
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) flag[0] = any ? 1 : 0;
+  }
   if (gate && *gate == 0) return;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -786,20 +796,24 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t
   a.group_m = GROUP_M2;
 
   int32_t* ws = static_cast<int32_t*>(workspace);
+  const int64_t tiles256 = ((M + BM2 - 1) / BM2) * ((N + 255) / 256);
+  const bool persistent = K % 128 == 0 && K >= 256 && M >= 128 && N >= 128 && tiles256 >= 64;
+  bool flag_written = false;
   if (x_offset) {  // sum_k wq[n, k] for the zero-point term: one pass over the weight codes, unless the caller has them
     if (w_rowsum) {
       a.rowsum_w = w_rowsum;
     } else {
-      rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(wq, (int)N, (int)K, ws + M, nullptr);
+      const bool with_flag = w_offset && persistent;  // the weight-offset decision rides in this launch
+      rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(wq, (int)N, (int)K, ws + M, nullptr, with_flag ? w_offset : nullptr,
+                                                               w_per_row ? (int)N : 1, with_flag ? ws + M + N : nullptr);
       a.rowsum_w = ws + M;
+      flag_written = with_flag;
     }
   }
-  const int64_t tiles256 = ((M + BM2 - 1) / BM2) * ((N + 255) / 256);
-  const bool persistent = K % 128 == 0 && K >= 256 && M >= 128 && N >= 128 && tiles256 >= 64;
   if (w_offset) {  // sum_k xq[m, k] for the ow term
     if (persistent) {  // ... only where an offset is really non-zero: decided and consumed on the device
       int32_t* flag = ws + M + N;
-      offsets_nonzero_kernel<<<1, 1024, 0, s>>>(w_offset, w_per_row ? (int)N : 1, flag);
+      if (!flag_written) offsets_nonzero_kernel<<<1, 1024, 0, s>>>(w_offset, w_per_row ? (int)N : 1, flag);
       rowsum_i8_kernel<<<(unsigned)((M + 3) / 4), 256, 0, s>>>(xq, (int)M, (int)K, ws, flag);
       a.woff_live = flag;
     } else {

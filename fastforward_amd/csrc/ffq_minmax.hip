@@ -143,11 +143,70 @@ __device__ __forceinline__ void block_reduce(MinMax& m, float* lds /* 3 * 4 floa
 // Partial record in the workspace: {min, max, nan-flag, pad}
 struct Partial { float mn, mx, nan, pad; };
 
+template <typename T>
+__device__ __forceinline__ void write_result(T* mn_out, T* mx_out, uint32_t t, MinMax m, int accumulate,
+                                             int32_t* flags) {
+  float mn = m.nan ? NAN : m.mn;
+  float mx = m.nan ? NAN : m.mx;
+  int f = 0;
+  // flags describe THIS batch (minmax.py:233 tests data_min / data_max, not the running values)
+  if (__builtin_isinf(mn) || __builtin_isinf(mx)) f |= FFQ_FLAG_INF;
+  if (m.nan) f |= FFQ_FLAG_NAN;
+  if (accumulate) {
+    const float pmn = to_f32(mn_out[t]), pmx = to_f32(mx_out[t]);
+    // torch.min(self.min, data_min) / torch.max(self.max, data_max): NaN propagates    (:236-237)
+    mn = (pmn != pmn || mn != mn) ? NAN : __builtin_fminf(pmn, mn);
+    mx = (pmx != pmx || mx != mx) ? NAN : __builtin_fmaxf(pmx, mx);
+  }
+  mn_out[t] = from_f32<T>(mn);
+  mx_out[t] = from_f32<T>(mx);
+  if (f && flags) atomicOr(flags, f);
+}
+
+// ---- A5 (range -> scale / offset) of ONE tile, shared by parameters_for_range_kernel and the one-launch estimator step ------------
+struct RangeArgs {
+  int range_dt, scale_dt, offset_dt;
+  int64_t ntiles;
+  int symmetric, allow_one_sided, round_offset;
+  float abs_int_min, abs_int_max, num_steps, int_min;
+};
+
+__device__ __forceinline__ void range_to_parameters(float lo, float hi, int one_sided, const RangeArgs& a, float& scale, float& offset) {
+  if (a.symmetric && one_sided) lo = 0.0f;                               // (range.py:104-105)
+  if (a.symmetric && !one_sided) {
+    const float neg = __builtin_fabsf(lo) / a.abs_int_min;               // (:108)
+    const float pos = __builtin_fabsf(hi) / a.abs_int_max;               // (:109)
+    scale = (neg != neg || pos != pos) ? NAN : __builtin_fmaxf(neg, pos);  // torch.max  (:110)
+    offset = 0.0f;  // reference returns None; the setter fills the buffer with 0
+  } else {
+    const float interval = hi - lo;                                      // (:118)
+    scale = interval / a.num_steps;                                      // (:119)
+    scale = scale != scale ? scale : __builtin_fmaxf(scale, 1.1920928955078125e-07f);  // clamp(eps) (:120)
+    const float q = lo / scale;
+    offset = q - a.int_min;                                              // (:121)
+    if (a.round_offset) offset = rne(offset);                            // dynamic path, _quantizer_impl.py:275
+  }
+}
+
 // ---- stage 1, one tile: grid-stride over chunks, one Partial per block -------------------------
-template <typename T, int E, int U>
+// what the LAST block of the one-launch form does with the tile's result
+struct ScalarFinish {
+  void* mn_out; void* mx_out;   // T*
+  int accumulate;
+  int32_t* flags;
+  int32_t* ticket;              // zero on entry, zero on exit
+  void* scale_out; void* offset_out;  // nullable: A5 of the (merged) range straight into the quantizer's parameters
+  RangeArgs range;
+};
+
+// LAST = false: one Partial per block, minmax_finalize_kernel follows. LAST = true (round 4): ONE launch — every block publishes
+// its Partial with write-through stores, takes a ticket, and the last block to arrive reduces the Partials, merges into the
+// running extrema, sets the status flags and (estimator step) writes scale / offset: the finalize and parameters_for_range
+// launches of a per-tensor quantizer are gone (3 launches -> 1; [8, 2048, 4096] bf16: 31.5 -> ~22 us).
+template <typename T, int E, int U, bool LAST>
 __global__ __launch_bounds__(kBlock) void minmax_scalar_partial_kernel(const T* __restrict__ in,
                                                                        uint32_t nchunks, int64_t numel,
-                                                                       Partial* __restrict__ partial) {
+                                                                       Partial* __restrict__ partial, ScalarFinish fin) {
   __shared__ float lds[12];
   typename Accum<T>::type acc;
   acc.init();
@@ -170,7 +229,48 @@ __global__ __launch_bounds__(kBlock) void minmax_scalar_partial_kernel(const T* 
     for (int64_t i = (int64_t)nchunks * E; i < numel; ++i) m.add(to_f32(in[i]));
   }
   block_reduce(m, lds);
-  if (threadIdx.x == 0) partial[blockIdx.x] = Partial{m.mn, m.mx, m.nan ? 1.0f : 0.0f, 0.0f};
+  if constexpr (!LAST) {
+    if (threadIdx.x == 0) partial[blockIdx.x] = Partial{m.mn, m.mx, m.nan ? 1.0f : 0.0f, 0.0f};
+  } else {
+    __shared__ int last_s;
+    unsigned long long* cells = reinterpret_cast<unsigned long long*>(partial);
+    if (threadIdx.x == 0) {
+      // two 8-byte agent-scope stores (write-through: visible to the last block without a release fence), drained, then the ticket
+      const unsigned long long lohi = (unsigned long long)__builtin_bit_cast(uint32_t, m.mn) | ((unsigned long long)__builtin_bit_cast(uint32_t, m.mx) << 32);
+      __hip_atomic_store(cells + 2 * blockIdx.x, lohi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cells + 2 * blockIdx.x + 1, (unsigned long long)(m.nan ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int t = __hip_atomic_fetch_add(fin.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_s = t == (int)gridDim.x - 1;
+      if (last_s) __hip_atomic_store(fin.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
+    }
+    __syncthreads();
+    if (!last_s) return;
+    MinMax r;
+    r.init();
+    for (uint32_t k = threadIdx.x; k < gridDim.x; k += kBlock) {  // agent-scope loads bypass this CU's L1
+      const unsigned long long lohi = __hip_atomic_load(cells + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long nan = __hip_atomic_load(cells + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      r.mn = __builtin_fminf(r.mn, __builtin_bit_cast(float, (uint32_t)lohi));
+      r.mx = __builtin_fmaxf(r.mx, __builtin_bit_cast(float, (uint32_t)(lohi >> 32)));
+      r.nan |= nan != 0;
+    }
+    __syncthreads();  // lds is reused by the second reduction
+    block_reduce(r, lds);
+    if (threadIdx.x == 0) {
+      T* mn_out = static_cast<T*>(fin.mn_out);
+      T* mx_out = static_cast<T*>(fin.mx_out);
+      write_result<T>(mn_out, mx_out, 0, r, fin.accumulate, fin.flags);
+      if (fin.scale_out) {  // A5 on what the estimator now holds, read back in the data dtype as the eager chain does (.to(float32), range.py:90)
+        const float lo = to_f32(mn_out[0]), hi = to_f32(mx_out[0]);
+        const int one_sided = fin.range.symmetric && fin.range.allow_one_sided && lo == lo && lo >= 0.0f;
+        float scale, offset;
+        range_to_parameters(lo, hi, one_sided, fin.range, scale, offset);
+        store_any(fin.scale_out, fin.range.scale_dt, 0, (double)scale);
+        if (fin.offset_out) store_any(fin.offset_out, fin.range.offset_dt, 0, (double)offset);
+      }
+    }
+  }
 }
 
 // ---- contiguous runs: a group of P lanes (P <= 64, power of two) owns one tile ------------------
@@ -179,26 +279,6 @@ struct RowsArgs {
   uint32_t chunks_per_run;
   int accumulate;
 };
-
-template <typename T>
-__device__ __forceinline__ void write_result(T* mn_out, T* mx_out, uint32_t t, MinMax m, int accumulate,
-                                             int32_t* flags) {
-  float mn = m.nan ? NAN : m.mn;
-  float mx = m.nan ? NAN : m.mx;
-  int f = 0;
-  // flags describe THIS batch (minmax.py:233 tests data_min / data_max, not the running values)
-  if (__builtin_isinf(mn) || __builtin_isinf(mx)) f |= FFQ_FLAG_INF;
-  if (m.nan) f |= FFQ_FLAG_NAN;
-  if (accumulate) {
-    const float pmn = to_f32(mn_out[t]), pmx = to_f32(mx_out[t]);
-    // torch.min(self.min, data_min) / torch.max(self.max, data_max): NaN propagates    (:236-237)
-    mn = (pmn != pmn || mn != mn) ? NAN : __builtin_fminf(pmn, mn);
-    mx = (pmx != pmx || mx != mx) ? NAN : __builtin_fmaxf(pmx, mx);
-  }
-  mn_out[t] = from_f32<T>(mn);
-  mx_out[t] = from_f32<T>(mx);
-  if (f && flags) atomicOr(flags, f);
-}
 
 // UF x 16 B non-temporal loads in flight per lane. Measured on [14336, 4096] bf16 (interleaved A/B):
 // temporal UF=4 23.3 us, non-temporal UF=4 21.6 us, non-temporal UF=8 21.4 us (5.49 TB/s).
@@ -422,9 +502,18 @@ static MinMaxPlan plan_for(const TileInfo& info, int data_dt) {
   return p;
 }
 
+// what a caller may add to a min/max call: a ticket word (zero on entry, zero on exit) turns the per-tensor plan into ONE launch,
+// and (estimator step) the quantizer's parameters are written from the merged range in that same launch
+struct StepExtras {
+  int32_t* ticket = nullptr;
+  void* scale_out = nullptr; void* offset_out = nullptr;
+  RangeArgs range = {};
+  bool params_done = false;  // set when the launch wrote scale / offset itself
+};
+
 template <typename T>
 static int run_fast(const MinMaxPlan& p, const TileInfo& info, const void* data, void* mn, void* mx,
-                    int accumulate, int32_t* flags, void* workspace, hipStream_t stream) {
+                    int accumulate, int32_t* flags, void* workspace, hipStream_t stream, StepExtras* ex) {
   const T* in = static_cast<const T*>(data);
   T* mn_out = static_cast<T*>(mn);
   T* mx_out = static_cast<T*>(mx);
@@ -432,7 +521,15 @@ static int run_fast(const MinMaxPlan& p, const TileInfo& info, const void* data,
   switch (p.plan) {
     case PLAN_SCALAR: {
       const uint32_t nchunks = (uint32_t)(info.numel / kE);
-      minmax_scalar_partial_kernel<T, kE, 4><<<p.partials, kBlock, 0, stream>>>(in, nchunks, info.numel, partial);
+      ScalarFinish fin = {};
+      if (ex && ex->ticket) {  // one launch: the last block to arrive finishes the tile
+        fin.mn_out = mn_out; fin.mx_out = mx_out; fin.accumulate = accumulate; fin.flags = flags; fin.ticket = ex->ticket;
+        fin.scale_out = ex->scale_out; fin.offset_out = ex->offset_out; fin.range = ex->range;
+        minmax_scalar_partial_kernel<T, kE, 4, true><<<p.partials, kBlock, 0, stream>>>(in, nchunks, info.numel, partial, fin);
+        ex->params_done = ex->scale_out != nullptr;
+        break;
+      }
+      minmax_scalar_partial_kernel<T, kE, 4, false><<<p.partials, kBlock, 0, stream>>>(in, nchunks, info.numel, partial, fin);
       minmax_finalize_kernel<T><<<1, kBlock, 0, stream>>>(partial, 1, p.partials, mn_out, mx_out, accumulate, flags);
       break;
     }
@@ -478,7 +575,7 @@ static int run_fast(const MinMaxPlan& p, const TileInfo& info, const void* data,
 
 static int minmax_impl(const void* data, int data_dt, const ffq_tiling* tiling, void* mn, void* mx,
                        int accumulate, int32_t* flags, void* workspace, size_t workspace_bytes,
-                       hipStream_t stream) {
+                       hipStream_t stream, StepExtras* ex = nullptr) {
   TileInfo info;
   int rc = analyse(tiling, &info);
   if (rc) return rc;
@@ -492,9 +589,9 @@ static int minmax_impl(const void* data, int data_dt, const ffq_tiling* tiling, 
     // misaligned view: fall through to the element-wise kernels
   } else if (p.plan != PLAN_GENERIC) {
     switch (data_dt) {
-      case FFQ_F32: return run_fast<float>(p, info, data, mn, mx, accumulate, flags, workspace, stream);
-      case FFQ_BF16: return run_fast<bf16_t>(p, info, data, mn, mx, accumulate, flags, workspace, stream);
-      default: return run_fast<f16_t>(p, info, data, mn, mx, accumulate, flags, workspace, stream);
+      case FFQ_F32: return run_fast<float>(p, info, data, mn, mx, accumulate, flags, workspace, stream, ex);
+      case FFQ_BF16: return run_fast<bf16_t>(p, info, data, mn, mx, accumulate, flags, workspace, stream, ex);
+      default: return run_fast<f16_t>(p, info, data, mn, mx, accumulate, flags, workspace, stream, ex);
     }
   }
   const size_t need = sizeof(GenericCell) * (size_t)info.ntiles;
@@ -521,13 +618,6 @@ static size_t minmax_workspace(const ffq_tiling* tiling, int data_dt) {
 }
 
 // ---- A5 -------------------------------------------------------------------------------------
-struct RangeArgs {
-  int range_dt, scale_dt, offset_dt;
-  int64_t ntiles;
-  int symmetric, allow_one_sided, round_offset;
-  float abs_int_min, abs_int_max, num_steps, int_min;
-};
-
 constexpr int kRangeBlock = 1024;
 
 __global__ __launch_bounds__(kRangeBlock) void parameters_for_range_kernel(const void* __restrict__ min_range,
@@ -563,34 +653,17 @@ __global__ __launch_bounds__(kRangeBlock) void parameters_for_range_kernel(const
     one_sided = one_sided_s;
   }
   for (int64_t t = threadIdx.x; t < a.ntiles; t += kRangeBlock) {
-    float lo = (float)load_any(min_range, a.range_dt, t);
+    const float lo = (float)load_any(min_range, a.range_dt, t);
     const float hi = (float)load_any(max_range, a.range_dt, t);
-    if (a.symmetric && one_sided) lo = 0.0f;                               // (:104-105)
     float scale, offset;
-    if (a.symmetric && !one_sided) {
-      const float neg = __builtin_fabsf(lo) / a.abs_int_min;               // (:108)
-      const float pos = __builtin_fabsf(hi) / a.abs_int_max;               // (:109)
-      scale = (neg != neg || pos != pos) ? NAN : __builtin_fmaxf(neg, pos);  // torch.max  (:110)
-      offset = 0.0f;  // reference returns None; the setter fills the buffer with 0
-    } else {
-      const float interval = hi - lo;                                      // (:118)
-      scale = interval / a.num_steps;                                      // (:119)
-      scale = scale != scale ? scale : __builtin_fmaxf(scale, 1.1920928955078125e-07f);  // clamp(eps) (:120)
-      const float q = lo / scale;
-      offset = q - a.int_min;                                              // (:121)
-      if (a.round_offset) offset = rne(offset);                            // dynamic path, _quantizer_impl.py:275
-    }
+    range_to_parameters(lo, hi, one_sided, a, scale, offset);
     store_any(scale_out, a.scale_dt, t, (double)scale);
     if (offset_out) store_any(offset_out, a.offset_dt, t, (double)offset);
   }
 }
 
-static int parameters_impl(const void* min_range, const void* max_range, int range_dt, int64_t ntiles,
-                           double num_bits, int symmetric, int allow_one_sided, void* scale_out, int scale_dt,
-                           void* offset_out, int offset_dt, int round_offset, hipStream_t stream) {
-  if (!min_range || !max_range || !scale_out || ntiles <= 0) return fail(FFQ_ERR_ARG, "bad argument");
-  if (!dt_valid(range_dt) || !dt_valid(scale_dt) || (offset_out && !dt_valid(offset_dt)))
-    return fail(FFQ_ERR_ARG, "bad dtype tag");
+static RangeArgs make_range_args(int range_dt, int64_t ntiles, double num_bits, int symmetric, int allow_one_sided, int scale_dt, int offset_dt,
+                                 int round_offset) {
   RangeArgs a;
   a.range_dt = range_dt; a.scale_dt = scale_dt; a.offset_dt = offset_dt;
   a.ntiles = ntiles;
@@ -600,6 +673,16 @@ static int parameters_impl(const void* min_range, const void* max_range, int ran
   a.abs_int_max = (float)fabs(int_max);
   a.num_steps = (float)(pow(2.0, num_bits) - 1.0);
   a.int_min = (float)int_min;
+  return a;
+}
+
+static int parameters_impl(const void* min_range, const void* max_range, int range_dt, int64_t ntiles,
+                           double num_bits, int symmetric, int allow_one_sided, void* scale_out, int scale_dt,
+                           void* offset_out, int offset_dt, int round_offset, hipStream_t stream) {
+  if (!min_range || !max_range || !scale_out || ntiles <= 0) return fail(FFQ_ERR_ARG, "bad argument");
+  if (!dt_valid(range_dt) || !dt_valid(scale_dt) || (offset_out && !dt_valid(offset_dt)))
+    return fail(FFQ_ERR_ARG, "bad dtype tag");
+  const RangeArgs a = make_range_args(range_dt, ntiles, num_bits, symmetric, allow_one_sided, scale_dt, offset_dt, round_offset);
   parameters_for_range_kernel<<<1, kRangeBlock, 0, stream>>>(min_range, max_range, scale_out, offset_out, a);
   return check_launch("parameters_for_range_kernel");
 }
@@ -614,9 +697,33 @@ size_t ffq_minmax_workspace_bytes(const ffq_tiling* tiling, int data_dt) { retur
 
 int ffq_minmax_by_tile(const void* data, int data_dt, const ffq_tiling* tiling, void* min_inout,
                        void* max_inout, int accumulate, int32_t* status_flags, void* workspace,
-                       size_t workspace_bytes, void* stream) {
+                       size_t workspace_bytes, int32_t* ticket, void* stream) {
+  StepExtras ex;
+  ex.ticket = ticket;
   return minmax_impl(data, data_dt, tiling, min_inout, max_inout, accumulate, status_flags, workspace,
-                     workspace_bytes, static_cast<hipStream_t>(stream));
+                     workspace_bytes, static_cast<hipStream_t>(stream), &ex);
+}
+
+// One RunningMinMax estimator step (range_setting/minmax.py:215-239 + the range setter nn/linear_quantizer.py:350-357 +
+// affine/range.py:54-122): running min / max merged in place (A4), then scale / offset of the merged range (A5) written into the
+// quantizer's own parameter tensors. A per-tensor quantizer with a ticket word takes ONE launch for all of it.
+int ffq_running_minmax_step(const void* data, int data_dt, const ffq_tiling* tiling, void* min_inout, void* max_inout,
+                            int32_t* status_flags, double num_bits, int symmetric, int allow_one_sided, void* scale_out,
+                            int scale_dt, void* offset_out, int offset_dt, void* workspace, size_t workspace_bytes,
+                            int32_t* ticket, void* stream) {
+  if (!scale_out || !dt_valid(scale_dt) || (offset_out && !dt_valid(offset_dt))) return fail(FFQ_ERR_ARG, "bad parameter output");
+  TileInfo info;
+  int rc = analyse(tiling, &info);
+  if (rc) return rc;
+  StepExtras ex;
+  ex.ticket = ticket;
+  ex.scale_out = scale_out; ex.offset_out = offset_out;
+  ex.range = make_range_args(data_dt, info.ntiles, num_bits, symmetric, allow_one_sided, scale_dt, offset_dt, 0);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if ((rc = minmax_impl(data, data_dt, tiling, min_inout, max_inout, 1, status_flags, workspace, workspace_bytes, s, &ex))) return rc;
+  if (ex.params_done) return FFQ_OK;
+  return parameters_impl(min_inout, max_inout, data_dt, info.ntiles, num_bits, symmetric, allow_one_sided, scale_out, scale_dt, offset_out,
+                         offset_dt, 0, s);
 }
 
 int ffq_parameters_for_range(const void* min_range, const void* max_range, int range_dt, int64_t ntiles,

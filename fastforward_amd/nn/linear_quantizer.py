@@ -205,6 +205,30 @@ class LinearQuantizer(AbstractAffineQuantizer):
             self._initialize_parameters(lo.numel())
         self._write_parameters_for_range(lo, hi)
 
+    def update_range_from_data(self, data: torch.Tensor, tile: Any, running_min: torch.Tensor, running_max: torch.Tensor,
+                               status: torch.Tensor | None) -> bool:
+        """A RunningMinMax estimator step on `data` in ONE backend call: merge its per-tile extrema into `running_min` /
+        `running_max` (in place) and set this quantizer's range from the merged values — exactly
+        ``quantization_range = (running_min, running_max)`` after the merge (reference minmax.py:236-239). False when the
+        parameters cannot be written in place (other device, layout or count): the caller then takes the two steps."""
+        with torch.no_grad():
+            if not data.is_cuda:  # the fused entry exists for the device path; host tensors (oracle tests) take the two steps
+                return False
+            if self.has_uninitialized_params:
+                self._initialize_parameters(running_min.numel())
+            direct = (
+                self.scale.device == data.device and self.scale.numel() == running_min.numel() and self.scale.is_contiguous()
+                and (self.offset is None or (self.offset.device == data.device and self.offset.is_contiguous() and self.offset.numel() == running_min.numel()))
+            )
+            if not direct:
+                return False
+            ops.running_minmax_step(data, tile, running_min, running_max, status, self.num_bits, self.symmetric, self.allow_one_sided,
+                                    self.scale.data, None if self.offset is None else self.offset.data)
+            torch.autograd.graph.increment_version(self.scale)  # written through raw pointers: tell the version counters
+            if self.offset is not None:
+                torch.autograd.graph.increment_version(self.offset)
+            return True
+
     def _write_parameters_for_range(self, lo: torch.Tensor, hi: torch.Tensor) -> None:
         """A5 straight into ``scale`` / ``offset`` — no host round trip (reference :350-357 + range.py)."""
         with torch.no_grad():

@@ -27,6 +27,7 @@ __all__ = [
     "quantize_dynamic_by_tile",
     "quantize_by_tile_backward",
     "minmax_by_tile",
+    "running_minmax_step",
     "parameters_for_range",
     "pack_int4",
     "unpack_int4",
@@ -202,13 +203,13 @@ def _workspace(nbytes: int, device: torch.device) -> torch.Tensor | None:
 # Arrival counters of the split-K launches (ffq_linear_wq / ffq_mlp_gate_up_wq, include/ffq.h): zero before the first launch,
 # left zero by every launch, so ONE buffer per (device, stream) serves every call enqueued on that stream — launches of one
 # stream run in order, and a hipGraph captured on it replays against the same (still zero) buffer.
-_TICKETS: dict[tuple[int, int], torch.Tensor] = {}
+_TICKETS: dict[tuple[str, int, int], torch.Tensor] = {}
 
 
-def _tickets(count: int, device: torch.device, stream: int) -> torch.Tensor | None:
+def _tickets(count: int, device: torch.device, stream: int, kind: str = "wq") -> torch.Tensor | None:
     if count <= 0:
         return None
-    key = (device.index if device.index is not None else torch.cuda.current_device(), int(stream or 0))
+    key = (kind, device.index if device.index is not None else torch.cuda.current_device(), int(stream or 0))
     have = _TICKETS.get(key)
     if have is None or have.numel() < count:
         if have is not None and torch.cuda.is_current_stream_capturing():
@@ -368,13 +369,53 @@ def minmax_by_tile(
         mx = torch.empty(ntiles, dtype=data_c.dtype, device=data_c.device)
     nbytes = lib.ffq_minmax_workspace_bytes(ctypes.byref(tiling), _tag(data_c.dtype))
     ws = _workspace(nbytes, data_c.device)
+    ticket = _tickets(1, data_c.device, stream, kind="minmax") if data_c.is_cuda and ntiles == 1 else None  # per-tensor: one launch
     lib.check(
         lib.ffq_minmax_by_tile(
             _ptr(data_c), _tag(data_c.dtype), ctypes.byref(tiling), _ptr(mn), _ptr(mx), int(accumulate),
-            _ptr(status_flags), _ptr(ws), nbytes, stream,
+            _ptr(status_flags), _ptr(ws), nbytes, _ptr(ticket), stream,
         )
     )
     return mn, mx
+
+
+def running_minmax_step(
+    data: torch.Tensor,
+    tile_size: Sequence[int],
+    running_min: torch.Tensor,
+    running_max: torch.Tensor,
+    status_flags: torch.Tensor | None,
+    num_bits: float,
+    symmetric: bool,
+    allow_one_sided: bool,
+    scale_out: torch.Tensor,
+    offset_out: torch.Tensor | None,
+) -> None:
+    """One ``RunningMinMaxEstimator.estimate_step`` (reference range_setting/minmax.py:215-239) without leaving the device:
+    A4 merged into `running_min` / `running_max` in place, then A5 of the merged range (the quantization_range setter,
+    nn/linear_quantizer.py:350-357) written into `scale_out` / `offset_out` — what :func:`minmax_by_tile` with running
+    buffers followed by :func:`parameters_for_range` gives, bit for bit; a per-tensor quantizer takes ONE launch."""
+    data_c = data.detach().contiguous()
+    lib, stream = _prepare(data_c, running_min, running_max, status_flags, scale_out, offset_out)
+    tiling = _tile_of(data_c, tile_size)
+    ntiles = lib.ffq_num_tiles(ctypes.byref(tiling))
+    if ntiles < 0:
+        lib.check(-ntiles)
+    for t in (running_min, running_max):
+        if t.numel() != ntiles or t.dtype != data_c.dtype or not t.is_contiguous():
+            raise RuntimeError(f"running min/max must hold {ntiles} contiguous values of dtype {data_c.dtype}")
+    if scale_out.numel() != ntiles or not scale_out.is_contiguous() or (offset_out is not None and (offset_out.numel() != ntiles or not offset_out.is_contiguous())):
+        raise RuntimeError(f"scale / offset must hold {ntiles} contiguous values")
+    nbytes = lib.ffq_minmax_workspace_bytes(ctypes.byref(tiling), _tag(data_c.dtype))
+    ws = _workspace(nbytes, data_c.device)
+    ticket = _tickets(1, data_c.device, stream, kind="minmax") if data_c.is_cuda and ntiles == 1 else None
+    lib.check(
+        lib.ffq_running_minmax_step(
+            _ptr(data_c), _tag(data_c.dtype), ctypes.byref(tiling), _ptr(running_min), _ptr(running_max), _ptr(status_flags),
+            float(num_bits), int(symmetric), int(allow_one_sided), _ptr(scale_out), _tag(scale_out.dtype),
+            _ptr(offset_out), _tag(offset_out.dtype) if offset_out is not None else 0, _ptr(ws), nbytes, _ptr(ticket), stream,
+        )
+    )
 
 
 def parameters_for_range(

@@ -77,6 +77,11 @@ class RunningMinMaxEstimator(_MinMaxState):
                 self.status = torch.zeros(1, dtype=torch.int32, device=raw.device)
             same_kind = self.min.dtype == raw.dtype and self.max.dtype == raw.dtype and self.min.device == raw.device
             if self.sync_free and same_kind:
+                # reduction, running merge, status flags AND the range setter in one entry point (one launch per tensor for a
+                # per-tensor quantizer) where the quantizer's parameters can be written in place; else the two steps below
+                update = getattr(quantizer, "update_range_from_data", None)
+                if update is not None and update(raw, tile, self.min, self.max, self.status):
+                    return
                 ops.minmax_by_tile(raw, tile, running_min=self.min, running_max=self.max, status_flags=self.status)
             elif same_kind:
                 lo, hi = self.min.clone(), self.max.clone()

@@ -130,11 +130,26 @@ int ffq_dequantize_result_dtype(int data_dt, int scale_dt, int offset_dt, int ha
  * result is merged into the existing contents (running min / running max, :236-237).
  * `status_flags` (nullable, one int32) is OR-ed with FFQ_FLAG_* for THIS batch's per-tile
  * values, so the caller can raise NotImplementedError("Infinite") without a sync per step.
+ * `ticket` (nullable, ABI 7): one int32 that is ZERO before the first call and that every call leaves zero (one word per
+ * stream). With it a per-tensor reduction is ONE launch — every block publishes its partial result, the last block to
+ * arrive finishes — instead of a reduction launch plus a one-block finalize launch.
  */
 size_t ffq_minmax_workspace_bytes(const ffq_tiling* tiling, int data_dt);
 int ffq_minmax_by_tile(const void* data, int data_dt, const ffq_tiling* tiling, void* min_inout,
                        void* max_inout, int accumulate, int32_t* status_flags, void* workspace,
-                       size_t workspace_bytes, void* stream);
+                       size_t workspace_bytes, int32_t* ticket, void* stream);
+
+/*
+ * One RunningMinMaxEstimator.estimate_step on the device (range_setting/minmax.py:215-239): A4 merged into the running
+ * extrema in place, then the range setter (nn/linear_quantizer.py:350-357) = A5 (affine/range.py:54-122) of the merged range
+ * written straight into the quantizer's scale / offset tensors — the same values ffq_minmax_by_tile(accumulate = 1) followed
+ * by ffq_parameters_for_range produce, bit for bit. With `ticket` a per-tensor quantizer takes ONE launch for the reduction,
+ * the merge, the status flags and both parameters (three launches before round 4; 448 quantizers x 64 steps per calibration).
+ */
+int ffq_running_minmax_step(const void* data, int data_dt, const ffq_tiling* tiling, void* min_inout, void* max_inout,
+                            int32_t* status_flags, double num_bits, int symmetric, int allow_one_sided, void* scale_out,
+                            int scale_dt, void* offset_out, int offset_dt, void* workspace, size_t workspace_bytes,
+                            int32_t* ticket, void* stream);
 
 /*
  * A5 — parameters_for_range, quantization/affine/range.py:54-122, fused with the copy performed

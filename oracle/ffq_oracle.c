@@ -450,8 +450,8 @@ static int minmax_core(const void* data, int data_dt, const ffq_tiling* tiling, 
 
 int ffq_minmax_by_tile(const void* data, int data_dt, const ffq_tiling* tiling, void* min_inout,
                        void* max_inout, int accumulate, int32_t* status_flags, void* workspace,
-                       size_t workspace_bytes, void* stream) {
-  (void)workspace; (void)workspace_bytes; (void)stream;
+                       size_t workspace_bytes, int32_t* ticket, void* stream) {
+  (void)workspace; (void)workspace_bytes; (void)ticket; (void)stream;
   int rc = check_tiling(tiling);
   if (rc) return rc;
   if (!dt_valid(data_dt)) return fail(FFQ_ERR_ARG, "bad dtype tag");
@@ -525,6 +525,19 @@ int ffq_parameters_for_range(const void* min_range, const void* max_range, int r
   return FFQ_OK;
 }
 
+/* One RunningMinMaxEstimator.estimate_step (range_setting/minmax.py:215-239): running min / max merged (:236-237), then the range
+ * setter nn/linear_quantizer.py:350-357 = parameters_for_range (affine/range.py:54-122) on the merged range — the composition of
+ * the two restatements above, as the reference composes the two steps. */
+int ffq_running_minmax_step(const void* data, int data_dt, const ffq_tiling* tiling, void* min_inout, void* max_inout,
+                            int32_t* status_flags, double num_bits, int symmetric, int allow_one_sided, void* scale_out,
+                            int scale_dt, void* offset_out, int offset_dt, void* workspace, size_t workspace_bytes,
+                            int32_t* ticket, void* stream) {
+  int rc = ffq_minmax_by_tile(data, data_dt, tiling, min_inout, max_inout, 1, status_flags, workspace, workspace_bytes, ticket, stream);
+  if (rc) return rc;
+  return ffq_parameters_for_range(min_inout, max_inout, data_dt, ffq_num_tiles(tiling), num_bits, symmetric, allow_one_sided, scale_out,
+                                  scale_dt, offset_out, offset_dt, stream);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* A3: quantize_dynamic_by_tile_impl, quantization/_quantizer_impl.py:243-285                  */
 /* ------------------------------------------------------------------------------------------ */
@@ -552,7 +565,7 @@ int ffq_quantize_dynamic_by_tile(const void* data, int data_dt, const ffq_tiling
   void* mn = malloc(dt_size(data_dt) * (size_t)ntiles * 2);
   if (!mn) return fail(FFQ_ERR_ARG, "out of memory");
   void* mx = (char*)mn + dt_size(data_dt) * (size_t)ntiles;
-  rc = ffq_minmax_by_tile(data, data_dt, tiling, mn, mx, 0, NULL, NULL, 0, stream);
+  rc = ffq_minmax_by_tile(data, data_dt, tiling, mn, mx, 0, NULL, NULL, 0, NULL, stream);
   /* parameters_for_range(...); offset None -> zeros_like(scale); offset = round(offset) (:266-275) */
   if (!rc)
     rc = ffq_parameters_for_range(mn, mx, data_dt, ntiles, num_bits, symmetric, allow_one_sided,

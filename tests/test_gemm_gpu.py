@@ -282,8 +282,12 @@ def test_grouped_weights_with_quantized_inputs_take_the_weight_code_gemm():
     with torch.no_grad(), ff.estimate_ranges(torch.nn.ModuleList([wq_, xq_]), ff.range_setting.running_minmax):
         qw, qx = wq_(w), xq_(x)
     assert ff.dispatcher.dispatch("linear", input=qx, weight=qw) is ff.fused_linear.fused_linear
-    with torch.no_grad():
-        assert ff.dispatcher.dispatch("linear", input=xq_(x[:64]), weight=qw) is None  # below the token threshold: the float fallback
+    with torch.no_grad():  # 64 tokens: the same kernel (no token threshold since round 4: a launch with few tiles splits along K)
+        assert ff.dispatcher.dispatch("linear", input=xq_(x[:64]), weight=qw) is ff.fused_linear.fused_linear
+        with ff.strict_quantization(False):
+            few = ff.nn.functional.linear(xq_(x[:64]), qw)
+        want_few = xq_(x[:64]).dequantize().double() @ qw.dequantize().double().t()
+        torch.testing.assert_close(few.double(), want_few, rtol=2.0**-8, atol=1e-5 * float(want_few.abs().max()))
     with torch.no_grad(), ff.strict_quantization(False):
         got = ff.nn.functional.linear(qx, qw)
         with ff.fused_linear.weight_only_kernel(False):

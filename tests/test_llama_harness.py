@@ -238,7 +238,7 @@ def test_weight_only_storage_forms_agree_bit_for_bit(hip_backend, w_bits, block)
     model = llama.build_model(cfg, "cuda", torch.bfloat16, seed=5, std=0.05)
     llama.quantize_llama(model, w_bits=w_bits, a_bits=None, quantized_dtype=torch.int8,
                          weight_granularity=None if block is None else ff.PerBlock(1, block, 0))
-    ids = torch.randint(0, cfg.vocab_size, (2, 96), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    ids = torch.randint(0, cfg.vocab_size, (2, 128), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))  # 128: the attention launch covers it
     llama.calibrate(model, [ids])
     launches = {"mlp": [], "qkv": []}
     real_mlp, real_qkv = ff.ops.mlp_gate_up_wq, ff.ops.linear_wq_multi
