@@ -132,6 +132,7 @@ class RowsBatch(ctypes.Structure):
         ("codes", ctypes.c_void_p * FFQ_MAX_BATCH),
         ("rows", ctypes.c_int64 * FFQ_MAX_BATCH),
         ("cols", ctypes.c_int64 * FFQ_MAX_BATCH),
+        ("rowsum", ctypes.c_void_p * FFQ_MAX_BATCH),
     ]
 
 

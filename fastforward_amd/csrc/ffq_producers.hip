@@ -12,7 +12,10 @@
 // and pushed through the A1 arithmetic of ffq_affine.h for up to three static per-tensor quantizers.
 // HBM-bound like A1: algorithmic bytes per element are stated at each kernel.
 #ifndef FFQ_NT_STREAMS
-#define FFQ_NT_STREAMS 1  // nt loads (ffq_vec.h)
+#define FFQ_NT_STREAMS 3  // nt loads AND nt stores of the code tensors (ffq_vec.h). Round 4, A/B of two builds on one box, two rounds:
+#endif                    // SiLU*up + quantize 54.5 / 55.2 -> 51.4 / 50.2 us (0.67 -> 0.71-0.73 of 8 TB/s); RMSNorm unchanged (0.70)
+#ifndef FFQ_SILU_GRID
+#define FFQ_SILU_GRID 512  // blocks of the table-driven SiLU*up kernel: two 512-thread blocks per CU
 #endif
 #include "ffq_affine.h"
 #include "ffq_common.h"
@@ -381,7 +384,7 @@ extern "C" int ffq_silu_mul_quantize(const void* gate, const void* up, int dt, i
     return fail(FFQ_ERR_ARG, "buffers must be 16-byte aligned");
   const uint32_t nchunks = (uint32_t)(numel / 16);
   if (nchunks >= 8u * kSiluBlock * 256u) {  // >= 4 chunks per thread of the two-blocks-per-CU grid: the table pays
-    silu_mul_quantize_table_kernel<<<512, kSiluBlock, 0, s>>>(
+    silu_mul_quantize_table_kernel<<<FFQ_SILU_GRID, kSiluBlock, 0, s>>>(
         static_cast<const bf16_t*>(gate), static_cast<const bf16_t*>(up), static_cast<bf16_t*>(product_out), f, nchunks);
     return check_launch("silu_mul_quantize_table_kernel");
   }

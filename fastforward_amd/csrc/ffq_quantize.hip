@@ -497,6 +497,7 @@ struct BatchMember {
   int8_t* out;
   const float* scale;
   const float* offset;
+  int32_t* rowsum;          // ROWSUM: += sum of the member's codes per row (zero on entry; cols % 1024 == 0: a wave lies inside one row)
   uint32_t first_block;     // blocks [first_block, next member's first_block) belong to this member
   FastDiv chunks_per_row;   // cols / 16
 };
@@ -506,6 +507,10 @@ struct BatchArgs {
   float lo, hi;
 };
 
+// ROWSUM (round 4): the int8 GEMM's zero-point term needs sum_k wq[n, k] of every weight (ffq_linear.hip); taken here from the
+// codes while they are in registers (one v_dot4 per 4 codes, a DPP wave sum, at most two atomics per block) it replaces one
+// rowsum_i8_kernel launch per linear and forward (224 launches, 2.1 ms of the Llama-3-8B step).
+template <bool ROWSUM>
 __global__ __launch_bounds__(kBlock) void quantize_rows_batch_kernel(BatchArgs a) {
   int k = 0;
 #pragma unroll
@@ -526,6 +531,39 @@ __global__ __launch_bounds__(kBlock) void quantize_rows_batch_kernel(BatchArgs a
   Chunk<int8_t, 16> y;
   finalize_chunk<int8_t, 16>(r, a.lo, a.hi, y);
   y.store(mem.out + (size_t)c * 16);
+  if constexpr (ROWSUM) {
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sum = __builtin_amdgcn_sdot4((int)y.w[i], 0x01010101, sum, false);
+    // wave sum on the VALU (DPP inclusive scan, as quantize_rows_rowsum_kernel): lane 63 ends up with the total
+    sum += __builtin_amdgcn_update_dpp(0, sum, 0x111, 0xf, 0xf, false);
+    sum += __builtin_amdgcn_update_dpp(0, sum, 0x112, 0xf, 0xf, false);
+    sum += __builtin_amdgcn_update_dpp(0, sum, 0x114, 0xf, 0xf, false);
+    sum += __builtin_amdgcn_update_dpp(0, sum, 0x118, 0xf, 0xf, false);
+    sum += __builtin_amdgcn_update_dpp(0, sum, 0x142, 0xa, 0xf, false);
+    sum += __builtin_amdgcn_update_dpp(0, sum, 0x143, 0xc, 0xf, false);
+    __shared__ int wave_sum[4];
+    __shared__ uint32_t wave_row[4];
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) {
+      wave_sum[wave] = sum;
+      wave_row[wave] = row;
+    }
+    __syncthreads();
+    if (threadIdx.x == 63) {  // one atomic per row the block touches (its four waves usually share one)
+      int acc = wave_sum[0];
+      uint32_t cur = wave_row[0];
+      for (uint32_t w = 1; w < 4; ++w) {
+        if (wave_row[w] != cur) {
+          atomicAdd(mem.rowsum + cur, acc);
+          acc = 0;
+          cur = wave_row[w];
+        }
+        acc += wave_sum[w];
+      }
+      atomicAdd(mem.rowsum + cur, acc);
+    }
+  }
 }
 
 }  // namespace ffq
@@ -578,8 +616,11 @@ extern "C" int ffq_quantize_rows_batch(const ffq_rows_batch* batch, int data_dt,
   const double lo = -pow(2.0, batch->num_bits - 1.0);
   a.lo = (float)lo; a.hi = (float)(-lo - 1.0);
   uint64_t blocks = 0;
+  const bool rowsums = batch->rowsum[0] != nullptr;
   for (int i = 0; i < batch->count; ++i) {
     const int64_t rows = batch->rows[i], cols = batch->cols[i];
+    if ((batch->rowsum[i] != nullptr) != rowsums) return fail(FFQ_ERR_ARG, "row sums for every member of the batch or for none");
+    if (rowsums && cols % 1024 != 0) return fail(FFQ_ERR_DTYPE, "batched weight quantization with row sums needs cols %% 1024 == 0");
     if (rows <= 0 || cols <= 0 || cols % 16 != 0 || (rows * cols / 16) % kBlock != 0)
       return fail(FFQ_ERR_DTYPE, "batched weight quantization needs rows * cols %% %d == 0 and cols %% 16 == 0", 16 * kBlock);
     if (!batch->data[i] || !batch->scale[i] || !batch->codes[i]) return fail(FFQ_ERR_ARG, "NULL buffer in batch member %d", i);
@@ -588,12 +629,14 @@ extern "C" int ffq_quantize_rows_batch(const ffq_rows_batch* batch, int data_dt,
     a.m[i].out = batch->codes[i];
     a.m[i].scale = batch->scale[i];
     a.m[i].offset = batch->offset[i];
+    a.m[i].rowsum = batch->rowsum[i];
     a.m[i].first_block = (uint32_t)blocks;
     a.m[i].chunks_per_row = make_fastdiv((uint32_t)(cols / 16));
     blocks += (uint64_t)(rows * cols / 16) / kBlock;
     if (blocks >= ((uint64_t)1 << 31)) return fail(FFQ_ERR_ARG, "too many elements for one launch");
   }
   for (int i = batch->count; i < FFQ_MAX_BATCH; ++i) a.m[i] = a.m[0];
-  quantize_rows_batch_kernel<<<(unsigned)blocks, kBlock, 0, s>>>(a);
+  if (rowsums) quantize_rows_batch_kernel<true><<<(unsigned)blocks, kBlock, 0, s>>>(a);
+  else quantize_rows_batch_kernel<false><<<(unsigned)blocks, kBlock, 0, s>>>(a);
   return check_launch("quantize_rows_batch_kernel");
 }

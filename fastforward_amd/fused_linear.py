@@ -110,12 +110,21 @@ def _module_hooked(module: Any) -> bool:
 # for parameters that have STOPPED changing the answer is read once on the host and such offsets are not passed at all.
 # Keyed on (tensor object, version): the range setter bumps the version; never read while a hipGraph is being captured, and
 # not at the first sighting of a version (calibration: every step is a first sighting).
+# Only BUFFERS are remembered — the derived offset of a symmetric quantizer, which nothing but the range setter writes
+# (nn/linear_quantizer.py:_write_parameters_for_range: version bumped). A learnable offset (an ``nn.Parameter``: asymmetric
+# quantizers) is never remembered: user code and optimizers write parameters, also through ``.data``, which no version counter
+# sees — those always take the device-side decision. ``forget_zero_offsets()`` drops everything remembered (for code that
+# writes a quantizer's buffers behind its back).
 _ZERO_OFFSETS: dict[int, tuple[Any, int, bool | None]] = {}
+
+
+def forget_zero_offsets() -> None:
+    _ZERO_OFFSETS.clear()
 
 
 def known_zero_offset(offset: Any) -> bool:
     """True when `offset` is known (from an earlier call with the same version) to round to all zeros."""
-    if not isinstance(offset, torch.Tensor):
+    if not isinstance(offset, torch.Tensor) or isinstance(offset, torch.nn.Parameter):
         return False
     hit = _ZERO_OFFSETS.get(id(offset))
     seen = hit is not None and hit[0]() is offset and hit[1] == offset._version

@@ -651,7 +651,7 @@ class FusedForward:
     """
 
     def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True, fuse_attention: bool = True, fuse_rowsums: bool = False,
-                 batch_weight_quantization: bool = True) -> None:
+                 batch_weight_quantization: bool = True, batch_rowsums: bool = True) -> None:
         problems = self.unsupported(model)
         if problems:
             raise ff.exceptions.QuantizationError("FusedForward cannot run this model: " + "; ".join(problems[:4]))
@@ -670,6 +670,10 @@ class FusedForward:
         self.fuse_rowsums = fuse_rowsums
         # the seven weights of a layer re-quantized by one launch instead of seven (ops.quantize_rows_batch)
         self.batch_weight_quantization = batch_weight_quantization
+        # ... which also leaves the row sums of the codes (the int8 GEMM's zero-point term) beside them: no rowsum_i8_kernel
+        # launch per linear (224 per forward, 2.1 ms of the Llama-3-8B step in round 3)
+        self.batch_rowsums = batch_rowsums
+        self._layer_rowsums: dict[int, torch.Tensor] = {}
         self._layer_codes: dict[int, torch.Tensor] = {}
         self._zero_offset: dict[int, tuple[int, bool]] = {}
         self._weight_cache: dict[int, tuple[tuple[int, int, int], tuple[torch.Tensor, torch.Tensor | None]]] = {}
@@ -797,7 +801,7 @@ class FusedForward:
         rows = linear.weight.shape[0]
         ready = self._layer_codes.pop(id(linear), None)  # quantized with the rest of its layer in one launch (_quantize_layer)
         if ready is not None:
-            return ready, None
+            return ready, self._layer_rowsums.pop(id(linear), None)
         if self.fuse_rowsums and _weight_row_mode(linear) == "row" and rows > 1 and (wq.offset is None or wq.offset.numel() == rows) and wq.num_bits <= 8:
             offset = None if self._symmetric_weights(linear) else wq.offset  # an all-zero offset buffer: same codes
             fused = ff.ops.quantize_rows_rowsum(linear.weight, wq.scale, offset, wq.num_bits, rowsum_out=self._rowsum_slice(rows, linear.weight.device))
@@ -809,7 +813,7 @@ class FusedForward:
         """A1 of all the layer's weights that are re-quantized this forward, as ONE launch (ops.quantize_rows_batch): seven
         launches otherwise, two of them (k_proj / v_proj) too short to stream at rate. Fills `_layer_codes`; weights the batched
         kernel does not cover (not per-channel bf16, odd sizes) are left to `_quantize_weight`."""
-        self._layer_codes = {}
+        self._layer_codes, self._layer_rowsums = {}, {}
         if not self.batch_weight_quantization or self.fuse_rowsums:
             return
         attn, mlp = layer.self_attn, layer.mlp
@@ -828,9 +832,19 @@ class FusedForward:
         if len(todo) < 2:
             return
         offsets = [None if self._symmetric_weights(l) else l.weight_quantizer.offset for l in todo]  # an all-zero offset buffer: same codes
-        codes = ff.ops.quantize_rows_batch([l.weight for l in todo], [l.weight_quantizer.scale for l in todo], offsets, todo[0].weight_quantizer.num_bits)
+        sums = None
+        if self.batch_rowsums and all(l.weight.shape[1] % 1024 == 0 for l in todo):
+            sums = [self._rowsum_slice(l.weight.shape[0], l.weight.device) for l in todo]
+            sums = sums if all(t is not None for t in sums) else None
+        codes = ff.ops.quantize_rows_batch([l.weight for l in todo], [l.weight_quantizer.scale for l in todo], offsets, todo[0].weight_quantizer.num_bits,
+                                           rowsums=sums)
+        if codes is None and sums is not None:
+            codes, sums = ff.ops.quantize_rows_batch([l.weight for l in todo], [l.weight_quantizer.scale for l in todo], offsets,
+                                                     todo[0].weight_quantizer.num_bits), None
         if codes is not None:
             self._layer_codes = {id(l): c for l, c in zip(todo, codes)}
+            if sums is not None:
+                self._layer_rowsums = {id(l): t for l, t in zip(todo, sums)}
 
     def _weight(self, linear: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor | None, torch.Tensor, torch.Tensor | None]:
         """(int8 codes, row sums or None, scale, offset) of the linear's weight."""
@@ -873,7 +887,8 @@ class FusedForward:
         hidden = model.embed_tokens(input_ids)
         cos, sin = rotary_tables(s, d, cfg.rope_theta, hidden.device, hidden.dtype)
         pending: torch.Tensor | None = None  # down_proj's output: the next RMSNorm launch adds it to the residual stream
-        if self.fuse_rowsums:  # the weight row sums of this forward: one zero fill, slices handed out as the weights are quantized
+        if self.fuse_rowsums or (self.batch_rowsums and self.batch_weight_quantization):
+            # the weight row sums of this forward: one zero fill, slices handed out as the weights are quantized
             self._rowsum_pool = torch.zeros(self._rowsum_rows, dtype=torch.int32, device=hidden.device)
             self._rowsum_used = 0
         for layer, fan in zip(model.layers, self._fan):

@@ -985,13 +985,19 @@ def quantize_rows_rowsum(
 
 
 def quantize_rows_batch(
-    weights: Sequence[torch.Tensor], scales: Sequence[torch.Tensor], offsets: Sequence[torch.Tensor | None], num_bits: float = 8.0
+    weights: Sequence[torch.Tensor], scales: Sequence[torch.Tensor], offsets: Sequence[torch.Tensor | None], num_bits: float = 8.0,
+    rowsums: Sequence[torch.Tensor] | None = None,
 ) -> list[torch.Tensor] | None:
     """A1 of up to 8 ``[rows, cols]`` bf16 weights with one (scale, offset) per row into int8 codes, ONE launch; each result
     equals ``quantize_by_tile(weight, scale, (1, cols), num_bits, torch.int8, offset)``. The seven linears of a decoder layer
     are re-quantized on every forward (reference nn/linear.py:34); as seven launches the short ones (k_proj / v_proj) run far
-    below the streaming rate. Returns None where the one-launch kernel does not apply (then quantize member by member)."""
+    below the streaming rate. `rowsums` (one ZEROED contiguous int32 [rows] tensor per weight, cols % 1024 == 0): the launch also
+    adds each row's code sum into it — what :func:`linear_w8a8` takes as ``w_rowsum``. Returns None where the one-launch
+    kernel does not apply (then quantize member by member)."""
     if not weights or len(weights) > FFQ_MAX_BATCH or not (len(weights) == len(scales) == len(offsets)):
+        return None
+    if rowsums is not None and (len(rowsums) != len(weights) or any(
+            r.dtype != torch.int32 or r.numel() != w.shape[0] or not r.is_contiguous() or w.shape[1] % 1024 for r, w in zip(rowsums, weights))):
         return None
     sc, of = [], []
     for w, s, o in zip(weights, scales, offsets):
@@ -1010,6 +1016,7 @@ def quantize_rows_batch(
     for i, (w, s, o, c) in enumerate(zip(weights, sc, of, codes)):
         batch.data[i], batch.scale[i], batch.offset[i], batch.codes[i] = _ptr(w.detach()), _ptr(s), _ptr(o), _ptr(c)
         batch.rows[i], batch.cols[i] = w.shape
+        batch.rowsum[i] = None if rowsums is None else _ptr(rowsums[i])
     status = lib.ffq_quantize_rows_batch(ctypes.byref(batch), _tag(torch.bfloat16), stream)
     if status == 6:
         return None

@@ -440,6 +440,8 @@ int ffq_quantize_rows_rowsum(const void* data, int data_dt, const float* scale, 
  * The reference re-quantizes every linear's weight on every forward (nn/linear.py:34): a decoder layer's seven weights are one
  * call here instead of seven launches, two of which (k_proj / v_proj) are too short to reach the streaming rate on their own.
  * rows[i] * cols[i] must be a multiple of 4096 and cols[i] of 16, else FFQ_ERR_DTYPE (the caller quantizes member by member).
+ * `rowsum[i]` (ABI 7; for every member or for none; cols[i] % 1024 == 0): += sum_k codes[row, k] into int32 entries that are ZERO
+ * on entry — what ffq_linear_w8a8 / ffq_mlp_gate_up_w8a8 take as `w_rowsum` instead of launching their own reduction per linear.
  */
 #define FFQ_MAX_BATCH 8
 typedef struct {
@@ -451,6 +453,7 @@ typedef struct {
   int8_t* codes[FFQ_MAX_BATCH];
   int64_t rows[FFQ_MAX_BATCH];
   int64_t cols[FFQ_MAX_BATCH];
+  int32_t* rowsum[FFQ_MAX_BATCH];
 } ffq_rows_batch;
 int ffq_quantize_rows_batch(const ffq_rows_batch* batch, int data_dt, void* stream);
 

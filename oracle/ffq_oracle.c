@@ -1244,6 +1244,13 @@ int ffq_quantize_rows_batch(const ffq_rows_batch* batch, int data_dt, void* stre
     int rc = ffq_quantize_by_tile(batch->data[i], data_dt, batch->scale[i], FFQ_F32, batch->rows[i], batch->offset[i], FFQ_F32,
                                   batch->offset[i] ? batch->rows[i] : 0, &t, batch->num_bits, batch->codes[i], FFQ_I8, stream);
     if (rc) return rc;
+    if (batch->rowsum[i]) {  /* += the sum of each row's codes (the int8 GEMM's zero-point term, fallback.py:94-100 expanded) */
+      for (int64_t r = 0; r < batch->rows[i]; ++r) {
+        int32_t sum = 0;
+        for (int64_t c = 0; c < batch->cols[i]; ++c) sum += batch->codes[i][r * batch->cols[i] + c];
+        batch->rowsum[i][r] += sum;
+      }
+    }
   }
   return FFQ_OK;
 }

@@ -297,3 +297,30 @@ def test_grouped_weights_with_quantized_inputs_take_the_weight_code_gemm():
     exact = qx.dequantize().double() @ qw.dequantize().double().t()
     torch.testing.assert_close(got.double(), exact, rtol=2.0**-8, atol=1e-5 * float(exact.abs().max()))
     torch.testing.assert_close(got.float(), reference_path.float(), rtol=2.0**-7, atol=2e-4 * float(exact.abs().max()))
+
+
+def test_a_learnable_weight_offset_written_through_dot_data_is_seen_by_the_next_linear():
+    """The zero-offset shortcut of the dispatcher remembers only the derived offset BUFFER of a symmetric quantizer; a learnable
+    offset (nn.Parameter) written through ``.data`` — invisible to version counters — takes the device-side decision on every call,
+    so the next linear uses the new offsets (reference fallback.py:94-100 dequantizes with the current parameters every call)."""
+    torch.manual_seed(3)
+    tokens, n, k = 2048, 2048, 512
+    x = torch.randn(tokens, k, device=DEV, dtype=torch.bfloat16)
+    w = (torch.randn(n, k, device=DEV) * 0.05).to(torch.bfloat16)
+    wq_ = ff.nn.LinearQuantizer(8, symmetric=False, granularity=ff.PerChannel(0), quantized_dtype=torch.int8, device=DEV)
+    xq_ = ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=torch.int8, device=DEV)
+    with torch.no_grad(), ff.estimate_ranges(torch.nn.ModuleList([wq_, xq_]), ff.range_setting.running_minmax):
+        wq_(w), xq_(x)
+    assert isinstance(wq_.offset, torch.nn.Parameter)
+    with torch.no_grad(), ff.strict_quantization(False):
+        wq_.offset.data.zero_()  # all zero: a version-keyed cache would now learn "zero" ...
+        for _ in range(3):
+            zero = ff.nn.functional.linear(xq_(x), wq_(w))
+        version = wq_.offset._version
+        wq_.offset.data.fill_(5.0)  # ... and keep it across this write
+        assert wq_.offset._version == version
+        qx, qw = xq_(x), wq_(w)
+        got = ff.nn.functional.linear(qx, qw)
+        want = qx.dequantize().double() @ qw.dequantize().double().t()
+    assert not torch.equal(got, zero)
+    torch.testing.assert_close(got.double(), want, rtol=2.0**-7, atol=2e-3 * float(want.abs().max()))

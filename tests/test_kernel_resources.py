@@ -1,0 +1,55 @@
+"""What hipcc actually emitted for the persistent GEMM kernels (CPU tests: no device needed).
+
+* `tools/kernel_resources.py` reads the AMDGPU metadata of the code objects inside the SHIPPED library: no instantiation of the
+  int8 GEMM may spill a vector register (round 3 shipped 35-87 spilled VGPRs in every WOFF / REQUANT form), nor may the bf16-image
+  form of the weight-only GEMM.
+* `tools/asm_cluster_check.py` compiles the two GEMM sources to assembly and checks the K-loops themselves: no scratch access
+  between the first and the last MFMA of any persistent kernel (the code-converting forms of the weight-only GEMM keep a few
+  spills in their cold prologue / split-K epilogue, never in the loop).
+"""
+
+import pathlib
+import sys
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tools"))
+
+import asm_cluster_check  # noqa: E402
+import kernel_resources  # noqa: E402
+
+
+def _kernels(needle: str):
+    if kernel_resources.readelf() is None or not kernel_resources.DEFAULT_LIBRARY.exists():
+        pytest.skip("llvm-readelf or the built library is missing")
+    rows = [k for k in kernel_resources.kernel_resources() if needle in str(k["name"])]
+    assert rows, f"no {needle} kernel in {kernel_resources.DEFAULT_LIBRARY}"
+    return rows
+
+
+def test_the_int8_gemm_spills_nothing():
+    rows = _kernels("w8a8_gemm256fq_kernel")
+    assert len(rows) >= 13  # 4 containers x REQUANT x WOFF (- the float / WOFF pair) + the MLP mode
+    spilled = {str(k["name"]): k["vgpr_spill_count"] for k in rows if k["vgpr_spill_count"] or k["private_segment_fixed_size"]}
+    assert not spilled, spilled
+    assert all(k["vgpr_count"] <= 256 and k["agpr_count"] == 0 for k in rows)  # two waves per SIMD: 256 registers each
+
+
+def test_the_bf16_image_form_of_the_weight_only_gemm_spills_nothing():
+    rows = [k for k in _kernels("wq_gemm256_kernel") if "wq_gemm256_kernelILi0E" in str(k["name"])]
+    assert len(rows) == 3  # bf16 / fp32 output, MLP mode
+    assert all(k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0 for k in rows), rows
+
+
+@pytest.mark.parametrize("source,needle", [("csrc/ffq_linear.hip", "w8a8_gemm256fq_kernel"), ("csrc/ffq_wlinear.hip", "wq_gemm256_kernel")])
+def test_no_scratch_access_inside_a_k_loop(source, needle):
+    if not pathlib.Path("/opt/rocm/bin/hipcc").exists():
+        pytest.skip("hipcc is missing")
+    text = asm_cluster_check.build_assembly(ROOT / "fastforward_amd" / source)
+    seen = 0
+    for name, clusters, scratch in asm_cluster_check.clusters_of(text, needle):
+        seen += 1
+        assert scratch == 0, f"{name}: {scratch} scratch instructions between the first and the last MFMA"
+        assert clusters, name
+    assert seen >= 10

@@ -1098,6 +1098,21 @@ def test_batched_weight_quantization_equals_member_by_member():
     assert got is not None
     for w, s, c in zip(ws, scales, got):
         assert torch.equal(c, ops.quantize_by_tile(w, s, (1, w.shape[1]), 8, torch.int8))
+    # the same launch with the row sums of the codes (the int8 GEMM's zero-point term): += into zeroed int32 slices of one pool
+    pool = torch.zeros(sum(s[0] for s in shapes), dtype=torch.int32, device=DEV)
+    sums, at = [], 0
+    for s in shapes:
+        sums.append(pool[at:at + s[0]])
+        at += s[0]
+    again = ops.quantize_rows_batch(ws, scales, offsets, 8, rowsums=sums)
+    assert again is not None
+    for c, c2, r in zip(got, again, sums):
+        assert torch.equal(c, c2) and torch.equal(r, c.to(torch.int32).sum(1, dtype=torch.int32))
+    x8 = torch.randint(-128, 128, (512, 4096), device=DEV, dtype=torch.int8)
+    sx, ox = torch.tensor([0.02], device=DEV), torch.tensor([3.0], device=DEV)
+    assert torch.equal(ops.linear_w8a8(x8, got[0], sx, ox, scales[0], None, out_dtype=torch.bfloat16, w_rowsum=sums[0]),
+                       ops.linear_w8a8(x8, got[0], sx, ox, scales[0], None, out_dtype=torch.bfloat16))
+    assert ops.quantize_rows_batch([ws[0][:, :2560].contiguous()], [scales[0]], [None], 8, rowsums=[sums[0]]) is None  # 2560 columns: a wave would straddle rows
     small = [(torch.randn(256, 1024, device=DEV)).to(torch.bfloat16), (torch.randn(512, 48, device=DEV) * 3).to(torch.bfloat16), (torch.randn(16, 4096, device=DEV)).to(torch.bfloat16)]
     sc = [torch.rand(w.shape[0], device=DEV) * 0.05 + 0.01 for w in small]
     of = [torch.round(torch.randn(256, device=DEV) * 5) + 0.5, None, torch.zeros(16, device=DEV)]
