@@ -443,7 +443,7 @@ def main() -> None:
                     "eager RMSNorm / rotary / SiLU) instead of llama.FusedForward (A1 fused into those producers)")
     ap.add_argument("--cache-weight-codes", action="store_true", help="keep int8 weight codes across steps (NOT the headline: the reference re-quantizes)")
     ap.add_argument("--no-side-measurements", action="store_true", help="skip roofline / cpu_baseline legs")
-    ap.add_argument("--no-batch-rowsums", action="store_true", help="A/B: weight row sums from one rowsum_i8 launch per linear (round 3) instead of the batched weight quantization launch")
+    ap.add_argument("--batch-rowsums", action="store_true", help="A/B: weight row sums from the batched weight-quantization launch instead of one rowsum_i8 launch per linear (measured slower: llama.FusedForward)")
     ap.add_argument("--force-dist", action="store_true", help="create the process group even for one rank: the range all-reduce and the cross-rank "
                     "check then run through the collective backend (RCCL with one rank executes the same all_reduce(MIN) an 8-GPU run issues)")
     args = ap.parse_args()
@@ -493,7 +493,7 @@ def main() -> None:
     ranges_identical, ranks_seen = ffd.ranges_agree_across_ranks(model)
     exchange = dict(ffd.last_exchange)
 
-    fused = None if args.module_graph else llama.FusedForward(model, cache_weight_codes=args.cache_weight_codes, batch_rowsums=not args.no_batch_rowsums)
+    fused = None if args.module_graph else llama.FusedForward(model, cache_weight_codes=args.cache_weight_codes, batch_rowsums=args.batch_rowsums)
 
     def forward():
         if fused is not None:

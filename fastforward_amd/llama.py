@@ -651,7 +651,7 @@ class FusedForward:
     """
 
     def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True, fuse_attention: bool = True, fuse_rowsums: bool = False,
-                 batch_weight_quantization: bool = True, batch_rowsums: bool = True) -> None:
+                 batch_weight_quantization: bool = True, batch_rowsums: bool = False) -> None:
         problems = self.unsupported(model)
         if problems:
             raise ff.exceptions.QuantizationError("FusedForward cannot run this model: " + "; ".join(problems[:4]))
@@ -670,8 +670,11 @@ class FusedForward:
         self.fuse_rowsums = fuse_rowsums
         # the seven weights of a layer re-quantized by one launch instead of seven (ops.quantize_rows_batch)
         self.batch_weight_quantization = batch_weight_quantization
-        # ... which also leaves the row sums of the codes (the int8 GEMM's zero-point term) beside them: no rowsum_i8_kernel
-        # launch per linear (224 per forward, 2.1 ms of the Llama-3-8B step in round 3)
+        # ... which can also leave the row sums of the codes (the int8 GEMM's zero-point term) beside them: no rowsum_i8_kernel
+        # launch per linear (224 per forward, 2.1 ms of kernel time). OFF by default: the Llama-3-8B forward measures 2.9 % SLOWER
+        # with it (125.3 vs 121.9 ms, two alternating runs of bench.py on one box in round 4) — the same direction as round 2's
+        # one-pass codes + row sums per weight (`fuse_rowsums`): the int8 GEMMs behind a heavier quantization launch run slower by
+        # more than the 224 small launches cost (the chip is power-limited in the GEMMs; tools/gemm_cache_probe.py)
         self.batch_rowsums = batch_rowsums
         self._layer_rowsums: dict[int, torch.Tensor] = {}
         self._layer_codes: dict[int, torch.Tensor] = {}
