@@ -164,6 +164,8 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_pack_int4": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
     "ffq_unpack_int4": (_i, [_vp, _i64, _i64, _vp, _i, _vp]),
     "ffq_linear_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "ffq_bmm_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "ffq_bmm_w8a8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _d, _i, _i64, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ffq_linear_w8a8": (
         _i,
         [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _d, _i, _i64, _i64, _i64, _vp, _sz, _vp],

@@ -58,6 +58,8 @@ struct LinearArgs {
   int group_m;  // row tiles per group of the persistent kernel's tile walk (A panels shared by a group's column tiles)
   // MLP mode (gate and up projections in one launch): the second weight matrix
   const int8_t* wq2; const float* w_scale2; const int32_t* rowsum_w2;
+  // batched matmul (ffq_bmm_w8a8, tail kernel only): blockIdx.y selects the matrix pair; element strides between consecutive matrices
+  int64_t batch_x, batch_w, batch_out;
 };
 
 // The value the linear would have returned in dtype `y_dt` (one rounding), as fp32
@@ -94,6 +96,14 @@ template <> __device__ __forceinline__ void store_out<int8_t>(int8_t* p, float v
 template <typename TOut, bool REQUANT>
 __global__ __launch_bounds__(256) void w8a8_gemm_kernel(LinearArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[2][2][kTileBytes];
+  if (gridDim.y > 1) {  // one matrix pair of a batch per blockIdx.y (block-uniform): shift every per-matrix pointer
+    const int64_t b = blockIdx.y;
+    a.xq += b * a.batch_x;
+    a.wq += b * a.batch_w;
+    a.out = static_cast<uint8_t*>(a.out) + b * a.batch_out * (int64_t)sizeof(TOut);
+    if (a.rowsum_x) a.rowsum_x += b * a.M;
+    if (a.rowsum_w) a.rowsum_w += b * a.N;
+  }
 
   // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (observed dispatch: XCD = b % 8),
   // give each XCD a contiguous range of tiles so a weight panel is fetched into one L2 only.
@@ -785,6 +795,7 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t
   a.w_scale = w_scale; a.w_offset = w_offset;
   a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.woff_live = nullptr;
   a.wq2 = nullptr; a.w_scale2 = nullptr; a.rowsum_w2 = nullptr;
+  a.batch_x = a.batch_w = a.batch_out = 0;
   a.bias = bias; a.bias_dt = bias_dt;
   a.out = out; a.out_dt = out_dt;
   a.out_scale = out_scale; a.out_offset = out_offset;
@@ -879,6 +890,84 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t
   return check_launch("w8a8_gemm_kernel");
 }
 
+// ---- bmm: `batch` independent [M, K] x [N, K]^T products with ONE parameter pair per operand, as ONE launch -----------------------
+// fallback.bmm (_gen/fallback.py:699-798 pattern: dequantize both operands, torch.bmm, output quantizer) on int8 codes: the
+// 128 x 128-tile kernel with the matrix pair chosen by blockIdx.y (round 3 looped over the batch in Python: up to 256 launches
+// and a torch.stack). Row sums of both operands over the flattened [batch * rows, K] matrices: two launches for the whole batch.
+extern "C" size_t ffq_bmm_w8a8_workspace_bytes(int64_t batch, int64_t M, int64_t N, int64_t K) {
+  (void)K;
+  if (batch < 0 || M < 0 || N < 0) return 0;
+  return (size_t)((batch * (M + N) * 4 + 255) & ~(int64_t)255);
+}
+
+extern "C" int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, const float* x_offset, const float* w_scale,
+                            const float* w_offset, void* out, int out_dt, const float* out_scale, const float* out_offset,
+                            double out_num_bits, int y_dt, int64_t batch, int64_t M, int64_t N, int64_t K, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (batch < 0 || M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (batch == 0 || M == 0 || N == 0) return FFQ_OK;
+  if (!xq || !wq || !x_scale || !w_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (batch > 65535 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX || batch * M > INT32_MAX || batch * N > INT32_MAX)
+    return fail(FFQ_ERR_ARG, "extent out of range");
+  if (K % 16 != 0 || !aligned16(xq) || !aligned16(wq) || (M * K) % 16 != 0 || (N * K) % 16 != 0)
+    return fail(FFQ_ERR_DTYPE, "batched w8a8 matmul needs K %% 16 == 0 and 16-byte aligned matrices");
+  const bool requant = out_scale != nullptr;
+  if (requant) {
+    if (!ffq_can_support_bitwidth(out_dt, out_num_bits))
+      return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.", out_dt, out_num_bits);
+    if (!(y_dt == FFQ_F32 || y_dt == FFQ_BF16 || y_dt == FFQ_F16)) return fail(FFQ_ERR_DTYPE, "the re-quantized product's real-valued dtype must be f32, bf16 or f16");
+  } else if (!(out_dt == FFQ_F32 || out_dt == FFQ_BF16 || out_dt == FFQ_F16)) {
+    return fail(FFQ_ERR_DTYPE, "real-valued output must be f32, bf16 or f16");
+  }
+  const size_t need = ffq_bmm_w8a8_workspace_bytes(batch, M, N, K);
+  if ((x_offset || w_offset) && (need > workspace_bytes || !workspace)) return fail(FFQ_ERR_WORKSPACE, "batched w8a8 matmul needs %zu workspace bytes, got %zu", need, workspace_bytes);
+  LinearArgs a;
+  a.xq = xq; a.wq = wq;
+  a.x_scale = x_scale; a.x_offset = x_offset;
+  a.w_scale = w_scale; a.w_offset = w_offset;
+  a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.woff_live = nullptr;
+  a.wq2 = nullptr; a.w_scale2 = nullptr; a.rowsum_w2 = nullptr;
+  a.batch_x = M * K; a.batch_w = N * K; a.batch_out = M * N;
+  a.bias = nullptr; a.bias_dt = 0;
+  a.out = out; a.out_dt = out_dt;
+  a.out_scale = out_scale; a.out_offset = out_offset;
+  const double lo = -pow(2.0, out_num_bits - 1.0);
+  a.out_lo = (float)lo; a.out_hi = (float)(-lo - 1.0);
+  a.y_dt = y_dt;
+  a.x_per_row = 0; a.w_per_row = 0;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.group_m = GROUP_M2;
+  int32_t* ws = static_cast<int32_t*>(workspace);
+  if (x_offset) {
+    rowsum_i8_kernel<<<(unsigned)((batch * N + 3) / 4), 256, 0, s>>>(wq, (int)(batch * N), (int)K, ws + batch * M, nullptr);
+    a.rowsum_w = ws + batch * M;
+  }
+  if (w_offset) {
+    rowsum_i8_kernel<<<(unsigned)((batch * M + 3) / 4), 256, 0, s>>>(xq, (int)(batch * M), (int)K, ws, nullptr);
+    a.rowsum_x = ws;
+  }
+  a.tiles_m = (int)((M + BM - 1) / BM);
+  a.tiles_n = (int)((N + BN - 1) / BN);
+  const dim3 grid((unsigned)(a.tiles_m * a.tiles_n), (unsigned)batch);
+  if (requant) {
+    switch (out_dt) {
+      case FFQ_I8: w8a8_gemm_kernel<int8_t, true><<<grid, 256, 0, s>>>(a); break;
+      case FFQ_BF16: w8a8_gemm_kernel<bf16_t, true><<<grid, 256, 0, s>>>(a); break;
+      case FFQ_F16: w8a8_gemm_kernel<f16_t, true><<<grid, 256, 0, s>>>(a); break;
+      case FFQ_F32: w8a8_gemm_kernel<float, true><<<grid, 256, 0, s>>>(a); break;
+      default: return fail(FFQ_ERR_DTYPE, "re-quantized output container must be i8, bf16, f16 or f32");
+    }
+  } else {
+    switch (out_dt) {
+      case FFQ_BF16: w8a8_gemm_kernel<bf16_t, false><<<grid, 256, 0, s>>>(a); break;
+      case FFQ_F16: w8a8_gemm_kernel<f16_t, false><<<grid, 256, 0, s>>>(a); break;
+      default: w8a8_gemm_kernel<float, false><<<grid, 256, 0, s>>>(a); break;
+    }
+  }
+  return check_launch("w8a8_gemm_kernel (batched)");
+}
+
 // ---- gate_proj + up_proj + SiLU * up + the down_proj input quantizer in one launch -----------------------------
 extern "C" size_t ffq_mlp_gate_up_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   (void)M; (void)K;
@@ -909,6 +998,7 @@ extern "C" int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, con
   a.x_scale = x_scale; a.x_offset = x_offset;
   a.w_scale = gate_w_scale; a.w_scale2 = up_w_scale; a.w_offset = nullptr;
   a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.rowsum_w2 = nullptr; a.woff_live = nullptr;
+  a.batch_x = a.batch_w = a.batch_out = 0;
   a.bias = nullptr; a.bias_dt = 0;
   a.out = codes_out; a.out_dt = FFQ_I8;
   a.out_scale = out_scale; a.out_offset = out_offset;

@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import contextlib
 import dataclasses
+import math
 import weakref
 
 from typing import Any, Callable
@@ -352,6 +353,10 @@ class DispatcherKernels:
         right = other if other is not None else mat2
         if not self._pair_ok(input, right):
             return False
+        if right.dim() > 2:  # matmul with an N-d right operand: the batched launch when the leading dims agree (no broadcasting)
+            return (input.dim() == right.dim() and tuple(input.shape[:-2]) == tuple(right.shape[:-2]) and input.shape[-1] == right.shape[-2]
+                    and right.shape[-2] % 16 == 0 and input.numel() > 0 and right.numel() > 0 and math.prod(input.shape[:-2]) <= 65535
+                    and self.row_mode(input) == "tensor" and self.row_mode(right) == "tensor")
         if right.dim() != 2 or input.dim() < 1 or input.shape[-1] != right.shape[0] or right.shape[0] % 16 or input.numel() == 0 or right.numel() == 0:
             return False
         return self.row_mode(input) is not None and self.col_mode(right) is not None
@@ -362,6 +367,13 @@ class DispatcherKernels:
             raise self.surface.error("'output_quantizer' must be provided if strict_quantization=True")
         deq = self._deq_dtype(input)
         (xs, xo), (ws, wo) = self._scale_offset(input), self._scale_offset(right)
+        if right.dim() > 2:  # [..., M, K] x [..., K, N]: flatten the leading dims into one batch
+            lead = tuple(input.shape[:-2])
+            x_codes = self._int8_codes(input).reshape(-1, input.shape[-2], input.shape[-1])
+            w_codes = self._int8_codes(right).reshape(-1, right.shape[-2], right.shape[-1]).transpose(1, 2).contiguous()
+            fused = self._requant(output_quantizer, deq)
+            out = ops.bmm_w8a8(x_codes, w_codes, xs, xo, ws, wo, **(fused or dict(out_dtype=deq)))
+            return self._finish(out.reshape(*lead, input.shape[-2], right.shape[-1]), fused, input, output_quantizer, deq)
         w_codes = self._int8_codes(right).t().contiguous()  # [N, K]
         fused = self._requant(output_quantizer, deq)
         out = ops.linear_w8a8(self._int8_codes(input), w_codes, xs, xo, ws, wo, bias=None, **(fused or dict(out_dtype=deq)))
@@ -372,7 +384,7 @@ class DispatcherKernels:
             return False
         if input.dim() != 3 or mat2.dim() != 3 or input.shape[0] != mat2.shape[0] or input.shape[2] != mat2.shape[1]:
             return False
-        if input.shape[2] % 16 or input.numel() == 0 or mat2.numel() == 0 or input.shape[0] > 256:
+        if input.shape[2] % 16 or input.numel() == 0 or mat2.numel() == 0 or input.shape[0] > 65535:
             return False
         # one parameter pair for each operand: the batch shares it, every matrix of the batch is one GEMM
         return self.row_mode(input) == "tensor" and self.row_mode(mat2) == "tensor"
@@ -384,8 +396,7 @@ class DispatcherKernels:
         (xs, xo), (ws, wo) = self._scale_offset(input), self._scale_offset(mat2)
         x_codes, w_codes = self._int8_codes(input), self._int8_codes(mat2).transpose(1, 2).contiguous()  # [B, N, K]
         fused = self._requant(output_quantizer, deq)
-        out = torch.stack([ops.linear_w8a8(x_codes[b], w_codes[b], xs, xo, ws, wo, bias=None, **(fused or dict(out_dtype=deq)))
-                           for b in range(x_codes.shape[0])])
+        out = ops.bmm_w8a8(x_codes, w_codes, xs, xo, ws, wo, **(fused or dict(out_dtype=deq)))  # ONE launch for the whole batch
         return self._finish(out, fused, input, output_quantizer, deq)
 
     def register_all(self, register_fn: Callable[[str, Any, Any], Any], predicate_type: type) -> dict[str, Any]:

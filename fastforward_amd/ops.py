@@ -38,6 +38,7 @@ __all__ = [
     "gptq_block",
     "grid_sqerror_by_tile",
     "linear_w8a8",
+    "bmm_w8a8",
     "linear_wq",
     "linear_wq_multi",
     "mlp_gate_up_w8a8",
@@ -690,6 +691,47 @@ def linear_w8a8(
             _ptr(xc), _ptr(wc), _ptr(w_rowsum), _ptr(xs), _ptr(xo), x_per_row, _ptr(ws_), _ptr(wo), w_per_row,
             _ptr(bias_c), _tag(bias_c.dtype) if bias_c is not None else 0, _ptr(out), _tag(out_dtype),
             _ptr(os_), _ptr(oo), float(out_num_bits), y_dt, M, N, K, _ptr(ws), nbytes, stream,
+        )
+    )
+    return out
+
+
+def bmm_w8a8(
+    x_codes: torch.Tensor,
+    w_codes: torch.Tensor,
+    x_scale: torch.Tensor,
+    x_offset: torch.Tensor | None,
+    w_scale: torch.Tensor,
+    w_offset: torch.Tensor | None,
+    out_dtype: torch.dtype = torch.bfloat16,
+    out_scale: torch.Tensor | None = None,
+    out_offset: torch.Tensor | None = None,
+    out_num_bits: float = 8.0,
+    requant_from: torch.dtype | None = None,
+) -> torch.Tensor:
+    """``torch.bmm`` on int8 codes in ONE launch: `x_codes` [B, M, K], `w_codes` [B, N, K] (the right operand K-contiguous),
+    one parameter pair per operand (per-tensor quantizers) -> [B, M, N]; per matrix pair exactly :func:`linear_w8a8`, the output
+    quantizer optionally in the epilogue (reference _gen/fallback.py:699-798: dequantize, bmm, output quantizer)."""
+    if x_codes.dtype != torch.int8 or w_codes.dtype != torch.int8 or x_codes.dim() != 3 or w_codes.dim() != 3:
+        raise TypeError("bmm_w8a8 expects int8 codes of shape [B, M, K] and [B, N, K]")
+    xc, wc = x_codes.detach().contiguous(), w_codes.detach().contiguous()
+    B, M, K = xc.shape
+    if wc.shape[0] != B or wc.shape[2] != K:
+        raise RuntimeError(f"batch1 and batch2 shapes cannot be multiplied ({tuple(xc.shape)} and {tuple(wc.shape)}^T)")
+    N = wc.shape[1]
+    f32 = lambda t: None if t is None else t.detach().reshape(-1).to(torch.float32).contiguous()  # noqa: E731
+    xs, xo, ws_, wo, os_, oo = f32(x_scale), f32(x_offset), f32(w_scale), f32(w_offset), f32(out_scale), f32(out_offset)
+    if xs.numel() != 1 or ws_.numel() != 1:
+        raise RuntimeError("bmm_w8a8 takes per-tensor parameters (one scale per operand)")
+    lib, stream = _prepare(xc, wc, xs, xo, ws_, wo, os_, oo)
+    out = torch.empty((B, M, N), dtype=out_dtype, device=xc.device)
+    nbytes = lib.ffq_bmm_w8a8_workspace_bytes(B, M, N, K)
+    ws = _workspace(nbytes, xc.device)
+    y_dt = _tag(requant_from or torch.bfloat16) if os_ is not None else 0
+    lib.check(
+        lib.ffq_bmm_w8a8(
+            _ptr(xc), _ptr(wc), _ptr(xs), _ptr(xo), _ptr(ws_), _ptr(wo), _ptr(out), _tag(out_dtype), _ptr(os_), _ptr(oo),
+            float(out_num_bits), y_dt, B, M, N, K, _ptr(ws), nbytes, stream,
         )
     )
     return out

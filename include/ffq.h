@@ -213,6 +213,18 @@ int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * bmm on int8 codes — the quantized-operand pattern of _gen/fallback.py:699-798 (dequantize both operands, the float op, the output
+ * quantizer) for `batch` independent products out[b] = xq[b] [M, K] x wq[b]^T [N, K] with ONE parameter pair per operand (per-tensor
+ * quantizers: the batch shares them), as ONE launch; arithmetic, epilogue and the optional fused output quantizer exactly as
+ * ffq_linear_w8a8 (per matrix pair: bit-identical to `batch` calls of it). K % 16 == 0.
+ */
+size_t ffq_bmm_w8a8_workspace_bytes(int64_t batch, int64_t M, int64_t N, int64_t K);
+int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, const float* x_offset, const float* w_scale,
+                 const float* w_offset, void* out, int out_dt, const float* out_scale, const float* out_offset,
+                 double out_num_bits, int y_dt, int64_t batch, int64_t M, int64_t N, int64_t K, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/*
  * A6 (weight-only) — the branch of `fallback.linear` taken by a quantized WEIGHT and a plain, non-quantized INPUT
  * (_gen/fallback.py:77-112 with strict_quantization off, :86-100): y = F.linear(x, weight.dequantize(), bias).
  * `x` is [M, K] bf16. `w_codes` holds the weight's integer codes (any num_bits <= 8) either one per byte

@@ -1031,6 +1031,23 @@ int ffq_grid_sqerror_by_tile(const void* data, int dt, const float* scales, cons
   return FFQ_OK;
 }
 
+/* bmm on codes (_gen/fallback.py:699-798 pattern): `batch` independent products with shared per-tensor parameters — the composition
+ * of ffq_linear_w8a8 calls, one per matrix pair */
+size_t ffq_bmm_w8a8_workspace_bytes(int64_t batch, int64_t M, int64_t N, int64_t K) { (void)batch; return ffq_linear_w8a8_workspace_bytes(M, N, K); }
+int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, const float* x_offset, const float* w_scale,
+                 const float* w_offset, void* out, int out_dt, const float* out_scale, const float* out_offset,
+                 double out_num_bits, int y_dt, int64_t batch, int64_t M, int64_t N, int64_t K, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+  if (batch < 0 || M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  for (int64_t b = 0; b < batch; ++b) {
+    int rc = ffq_linear_w8a8(xq + b * M * K, wq + b * N * K, NULL, x_scale, x_offset, 0, w_scale, w_offset, 0, NULL, 0,
+                             (char*)out + (size_t)(b * M * N) * (size_t)dt_size(out_dt), out_dt, out_scale, out_offset, out_num_bits, y_dt, M, N, K,
+                             workspace, workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return FFQ_OK;
+}
+
 /* mlp.py:30-40 composed from the restatements above: two A6 linears (bf16 outputs), SiLU * up, A1 */
 size_t ffq_mlp_gate_up_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K) { (void)K; return ffq_linear_w8a8_workspace_bytes(M, N, 0); }
 

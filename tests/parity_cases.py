@@ -363,6 +363,26 @@ def check_matmul_family(device):
         a, b = quantized(torch.randn(3, 10, 32).to(torch.bfloat16), symmetric=False), quantized(torch.randn(3, 32, 20).to(torch.bfloat16))
         assert ff.dispatcher.dispatch("bmm", input=a, mat2=b) is not None
         close(F_.bmm(a, b), a, b, torch.bmm)
+        # ... as ONE launch for the whole batch (round 4; a Python loop of launches before): every pair equals its own mm call bit for bit,
+        # asymmetric on both sides, ragged sizes, and the output quantizer rides in the batched launch's epilogue
+        a, b = quantized(torch.randn(7, 150, 96).to(torch.bfloat16), symmetric=False), quantized((torch.randn(7, 96, 70) * 0.3).to(torch.bfloat16), symmetric=False)
+        whole = F_.bmm(a, b)
+        close(whole, a, b, torch.bmm)
+        pa, pb = a.quantization_context.quantization_params, b.quantization_context.quantization_params
+        for i in (0, 3, 6):
+            one = ff.ops.linear_w8a8(a.raw_data[i], b.raw_data[i].t().contiguous(), pa.scale, pa.offset, pb.scale, pb.offset, out_dtype=torch.bfloat16)
+            assert torch.equal(whole[i], one)
+        bq = ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=torch.int8, device=device)
+        with ff.estimate_ranges(bq, ff.range_setting.running_minmax):
+            bq(whole)
+        fused_codes = F_.bmm(a, b, output_quantizer=bq)
+        assert isinstance(fused_codes, ff.QuantizedTensor) and torch.equal(fused_codes.raw_data, bq(whole).raw_data)
+        # matmul with an N-d RIGHT operand (attention-shaped [B, H, S, D] x [B, H, D, S]): the batched launch, no broadcasting
+        a4, b4 = quantized(torch.randn(2, 3, 20, 32).to(torch.bfloat16), symmetric=False), quantized(torch.randn(2, 3, 32, 24).to(torch.bfloat16))
+        assert ff.dispatcher.dispatch("matmul", input=a4, other=b4) is not None
+        close(F_.matmul(a4, b4), a4, b4, torch.matmul)
+        close(torch.matmul(a4, b4), a4, b4, torch.matmul)
+        assert ff.dispatcher.dispatch("matmul", input=a4, other=quantized(torch.randn(3, 32, 24).to(torch.bfloat16))) is None  # broadcasting: the float fallback
         # an output quantizer is applied to the result
         out_q = ff.nn.LinearQuantizer(8, symmetric=False, quantized_dtype=torch.int8, device=device)
         a, b = quantized(x2, symmetric=False), quantized(w)
