@@ -1279,3 +1279,27 @@ _LIBRARY.impl("quantize_by_tile", _meta_quantize_by_tile, "Meta")
 _LIBRARY.impl("dequantize_by_tile", _meta_dequantize_by_tile, "Meta")
 _LIBRARY.impl("quantize_dynamic_by_tile", _meta_quantize_dynamic_by_tile, "Meta")
 _LIBRARY.impl("quantize_by_tile_backward", _meta_quantize_by_tile_backward, "Meta")
+
+
+# The two static operators also have C++ device kernels (csrc/ffq_torch.cpp -> csrc/libffq_torch.so, registered for the HIP
+# dispatch key): torch.ops.fastforward_amd.quantize_by_tile / dequantize_by_tile on a HIP tensor then run dispatcher -> C++ ->
+# the C ABI without entering the interpreter. Same library, same kernels, same results as the Python implementations above,
+# which stay registered (and serve when the extension is absent or FFQ_NO_TORCH_EXT=1 — they are the HIP path too).
+TORCH_EXTENSION_PATH = _native.LIBRARY_PATH.with_name("libffq_torch.so")
+
+
+def _load_torch_extension() -> bool:
+    import os
+    import warnings
+
+    if os.environ.get("FFQ_NO_TORCH_EXT") == "1" or not TORCH_EXTENSION_PATH.exists() or not _native.is_available():
+        return False
+    try:
+        torch.ops.load_library(str(TORCH_EXTENSION_PATH))
+    except OSError as e:  # built against another PyTorch
+        warnings.warn(f"fastforward_amd: cannot load {TORCH_EXTENSION_PATH} ({e}); the operators run through the Python implementations")
+        return False
+    return True
+
+
+NATIVE_DISPATCH: bool = _load_torch_extension()
