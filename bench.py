@@ -257,14 +257,16 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
 
 
 def host_us_per_op(device: torch.device, calls: int = 1000) -> dict:
-    """Host cost of the op route (torch.library registration in Python -> ctypes -> C ABI; SURVEY 8(b)(i) words a C++ extension):
-    `calls` eager A1 launches on a 256-element tensor through torch.ops.fastforward_amd.quantize_by_tile and through the plain
-    ops.quantize_by_tile wrapper, wall time per call with the device drained before and after (the kernel itself is ~2 us)."""
+    """Host cost of the op routes: `calls` eager A1 launches on a 256-element tensor, wall time per call with the device
+    drained before and after (the kernel itself is ~2 us). Through the operator registry the device kernel is C++
+    (csrc/ffq_torch.cpp: dispatcher -> C++ -> C ABI) when libffq_torch.so is loaded, else the Python implementation; the plain
+    ops.quantize_by_tile wrapper is Python -> ctypes -> C ABI either way."""
     x = torch.randn(256, device=device, dtype=torch.bfloat16)
     scale = torch.tensor([0.05], device=device)
-    out = {}
+    out = {"native_dispatch": bool(ops.NATIVE_DISPATCH)}
+    registry = "dispatcher -> C++ (libffq_torch.so) -> C ABI" if ops.NATIVE_DISPATCH else "dispatcher -> python impl -> ctypes"
     routes = {"ops.quantize_by_tile (python wrapper -> ctypes)": lambda: ops.quantize_by_tile(x, scale, (256,), 8, torch.int8),
-              "torch.ops.fastforward_amd.quantize_by_tile (dispatcher -> python impl -> ctypes)":
+              f"torch.ops.fastforward_amd.quantize_by_tile ({registry})":
                   lambda: torch.ops.fastforward_amd.quantize_by_tile(x, scale, [256], 8.0, torch.int8, None)}
     for name, fn in routes.items():
         try:

@@ -107,9 +107,10 @@ def merge(trace_csv: str, plan_path: str, cpu_path: str, out_md: str) -> None:
     key = {"A1": ("ffq::quantize_",), "A2": ("ffq::dequantize_",), "A4": ("ffq::minmax_",)}  # NB "dequantize_" contains "quantize_"
     # the measured launches of each plan row: the LAST N groups of its kernels before the next row's kernels begin
     pos = 0
-    out = [f"# r03 — A1 / A2 / A4 per shape: rocprofv3 kernel trace (GPU) beside the CPU eager chain", "",
+    tag = pathlib.Path(out_md).name.split("_")[0]  # profiles/rNN_micro.md
+    out = [f"# {tag} — A1 / A2 / A4 per shape: rocprofv3 kernel trace (GPU) beside the CPU eager chain", "",
            f"`rocprofv3 --kernel-trace -- python3 tools/micro_table.py --probe` on one MI355X: per row {N} launches after {WARM} warm-up launches, inputs rotated over 3 tensors; "
-           "avg = mean kernel duration from the trace (A4 per tensor = partial + finalize kernels summed). Algorithmic bytes per element: A1 3, A2 3, A4 2 (SURVEY 8(d)); "
+           "avg = mean kernel duration from the trace (A4 = every kernel of the call summed: one launch where the last block to arrive finishes, else partial + finalize). Algorithmic bytes per element: A1 3, A2 3, A4 2 (SURVEY 8(d)); "
            f"peak 8000 GB/s. CPU column: `oracle/eager_chain.py` (the reference's unfused ATen chain) with {cpu_ms.get('threads')} torch threads on {cpu_ms.get('host_cpus')} host CPUs, median of 3.", "",
            "| tensor | op | kernels per launch | GPU avg us | GB/s | frac of 8 TB/s | CPU eager ms | GPU / CPU |", "|---|---|---:|---:|---:|---:|---:|---:|"]
     for row in plan:
