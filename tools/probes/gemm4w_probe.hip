@@ -1,0 +1,261 @@
+// gemm4w_probe — structural experiment for the bf16 GEMM skeleton: ONE wavefront per SIMD, 4 waves x 128x128
+// accumulators (256 registers per lane, the vendor kernel's shape) instead of the shipped 8-wave ping-pong with 128x64 per wave.
+// Both operands are bf16 images in HBM ([M, K] and [N, K] row-major, the "two-pass" form of ffq_linear_wq), staged by LDS-DMA
+// into two 64 KiB slots; fragments are read one k-half ahead into a second register set and sit in the shadow of the wave's OWN
+// MFMAs; ONE barrier per 64-deep super-step.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gemm4w_probe gemm4w_probe.hip
+// Run:   ./gemm4w_probe M N K            (M, N multiples of 256, K of 128; checks sampled outputs on the host, then times)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_t;
+typedef __attribute__((address_space(1))) const void gbl_t;
+
+constexpr int IMAGE = 256 * 128;  // one operand image of a super-step: 256 rows x 64 bf16
+constexpr int SLOT = 2 * IMAGE;
+
+#ifndef P4_DS_PER
+#define P4_DS_PER 4  // MFMAs per fragment read in a phase
+#endif
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  // round to nearest even (inputs are finite)
+  uint32_t a = __builtin_bit_cast(uint32_t, lo), b = __builtin_bit_cast(uint32_t, hi);
+  a += 0x7FFFu + ((a >> 16) & 1u);
+  b += 0x7FFFu + ((b >> 16) & 1u);
+  return (a >> 16) | (b & 0xFFFF0000u);
+}
+
+__global__ __launch_bounds__(256, 1) void gemm4w_kernel(const uint8_t* __restrict__ x, const uint8_t* __restrict__ w, uint16_t* __restrict__ out, int M,
+                                                         int N, int K, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  // XCD-aware grouped tile order: XCD x (= blockIdx % 8) owns a contiguous range of the order, groups of 8 row tiles x all column tiles
+  const uint32_t nblk = gridDim.x;
+  const uint32_t xcd = blockIdx.x & 7u, slot_in_xcd = blockIdx.x >> 3;
+  const uint32_t q8 = nblk >> 3, r8 = nblk & 7u;
+  const uint32_t tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot_in_xcd;
+  const uint32_t per_group = 8u * (uint32_t)tiles_n;
+  const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
+  const uint32_t group_rows = min(8u, (uint32_t)tiles_m - group * 8u);
+  const int m0 = (int)(group * 8u + in_group % group_rows) * 256;
+  const int n0 = (int)(in_group / group_rows) * 256;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // LDS-DMA: piece c (0..7) of wave w covers image rows (8 w + c) * 8 + lane / 8, the lane's 16-byte slot is swizzled on the
+  // SOURCE address (slot ^ (row / 2) % 8) so that the linear LDS write lands in the swizzled image
+  const uint32_t row_bytes = (uint32_t)K * 2u;
+  const uint8_t* a_base = x + (size_t)m0 * row_bytes;
+  const uint8_t* b_base = w + (size_t)n0 * row_bytes;
+  uint32_t d_voff[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int row = (wave * 8 + c) * 8 + (lane >> 3);
+    const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
+    d_voff[c] = (uint32_t)row * row_bytes + d_slot * 16;
+  }
+  auto issue = [&](int ks, uint8_t* slot, int c0, int n) {
+#pragma unroll
+    for (int c = c0; c < c0 + n; ++c) {
+      asm volatile("" : "+v"(d_voff[c]));
+      __builtin_amdgcn_global_load_lds((gbl_t*)((a_base + ks * 128) + d_voff[c]), (lds_t*)(slot + (wave * 8 + c) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_t*)((b_base + ks * 128) + d_voff[c]), (lds_t*)(slot + IMAGE + (wave * 8 + c) * 1024), 16, 0, 0);
+    }
+  };
+
+  // fragment addresses: lane (r16, g4) reads 8 bf16 (16 B) of row r16 of a 16-row tile: logical slot kq * 4 + g4. One register
+  // per (slot, k-half, operand); the row tile goes into the instruction's offset field (t * 2048 bytes)
+  const uint32_t r16 = lane & 15, g4 = lane >> 4;
+  uint32_t a_off[2][2], b_off[2][2];
+  {
+    const uint32_t arow = wm * 128 + r16, brow = wn * 128 + r16;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int kq = 0; kq < 2; ++kq) {
+        a_off[sl][kq] = sl * SLOT + arow * 128 + (((kq * 4 + g4) ^ ((arow >> 1) & 7u)) << 4);
+        b_off[sl][kq] = sl * SLOT + IMAGE + brow * 128 + (((kq * 4 + g4) ^ ((brow >> 1) & 7u)) << 4);
+      }
+  }
+  // Everything of the K-loop is `asm volatile` in source order: the accumulators are pinned to AGPRs ("+a": hipcc otherwise rotates
+  // them through VGPRs — 590 v_accvgpr moves per two super-steps in the builtin form of this loop), and the fragment reads sit
+  // where they are written, between the MFMAs, with hand-counted waits (the compiler does not see them).
+  v4i fa0[8], fb0[8], fa1[8], fb1[8];
+  v4f acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+#define P4_MFMA(ACC, B, A) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(B), "v"(A))
+#define P4_READ(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+  // fragment read number r (0..15) of a k-half, in the order the next phase's MFMAs need them: fb0, fa0, fb1..fb7, fa1..fa7
+  auto read_one = [&](int r, uint32_t ao, uint32_t bo, v4i (&fa)[8], v4i (&fb)[8]) {
+    switch (r) {
+      case 0: P4_READ(fb[0], bo, 0 * 2048); break;
+      case 1: P4_READ(fa[0], ao, 0 * 2048); break;
+      case 2: P4_READ(fb[1], bo, 1 * 2048); break;
+      case 3: P4_READ(fb[2], bo, 2 * 2048); break;
+      case 4: P4_READ(fb[3], bo, 3 * 2048); break;
+      case 5: P4_READ(fb[4], bo, 4 * 2048); break;
+      case 6: P4_READ(fb[5], bo, 5 * 2048); break;
+      case 7: P4_READ(fb[6], bo, 6 * 2048); break;
+      case 8: P4_READ(fb[7], bo, 7 * 2048); break;
+      case 9: P4_READ(fa[1], ao, 1 * 2048); break;
+      case 10: P4_READ(fa[2], ao, 2 * 2048); break;
+      case 11: P4_READ(fa[3], ao, 3 * 2048); break;
+      case 12: P4_READ(fa[4], ao, 4 * 2048); break;
+      case 13: P4_READ(fa[5], ao, 5 * 2048); break;
+      case 14: P4_READ(fa[6], ao, 6 * 2048); break;
+      default: P4_READ(fa[7], ao, 7 * 2048); break;
+    }
+  };
+  // one k-half: 64 MFMAs on (fa, fb); fragment read r of the NEXT k-half behind MFMA P4_DS_PER * r + 1; with DMA: one pair of
+  // LDS-DMA pieces (A and B) behind every 8th MFMA
+  auto phase = [&](const v4i (&fa)[8], const v4i (&fb)[8], v4i (&na)[8], v4i (&nb)[8], uint32_t ao, uint32_t bo, auto dma, auto with_dma) {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const int mi = i >> 3, n_ = i & 7;
+      const int nj = (mi & 1) ? 7 - n_ : n_;  // snake: every MFMA shares an operand with its predecessor
+      P4_MFMA(acc[mi][nj], fb[nj], fa[mi]);
+      if (i % P4_DS_PER == 1 && i / P4_DS_PER < 16) read_one(i / P4_DS_PER, ao, bo, na, nb);
+      if constexpr (decltype(with_dma)::value) {
+        if ((i & 7) == 3) dma(i >> 3);
+      }
+    }
+  };
+
+  const int ksuper = K / 64;  // even
+  uint8_t* const s0 = lds;
+  uint8_t* const s1 = lds + SLOT;
+  issue(0, s0, 0, 8);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  issue(1, s1, 0, 8);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) read_one(r, a_off[0][0], b_off[0][0], fa0, fb0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  auto super_step = [&](int ks, int cur) {  // cur = slot of super-step ks (compile-time after inlining)
+    const int nxt = cur ^ 1;
+    // ---- phase 0: MFMAs on set 0 | read k-half 1 of `cur` into set 1
+    phase(fa0, fb0, fa1, fb1, a_off[cur][1], b_off[cur][1], [](int) {}, std::false_type{});
+    // the images of ks + 1 have landed (this wave's pieces; the barrier makes it everybody's) and `cur` has been read in full
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: MFMAs on set 1 | LDS-DMA of ks + 2 into `cur`, read k-half 0 of `nxt` into set 0
+    const int kn = ks + 2 < ksuper ? ks + 2 : ksuper - 1;
+    uint8_t* const dst = cur ? s1 : s0;
+    phase(fa1, fb1, fa0, fb0, a_off[nxt][0], b_off[nxt][0], [&](int c) { issue(kn, dst, c, 1); }, std::true_type{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+#pragma unroll 1
+  for (int ks = 0; ks < ksuper; ks += 2) {
+    super_step(ks, 0);
+    super_step(ks + 1, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+  // ---- epilogue (probe quality): lane holds D[n = nj*16 + 4 g4 + t][m = mi*16 + r16] -> 8-byte stores
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const size_t m = (size_t)(m0 + wm * 128 + mi * 16 + (int)r16);
+#pragma unroll
+    for (int nj = 0; nj < 8; ++nj) {
+      const int n = n0 + wn * 128 + nj * 16 + 4 * (int)g4;
+      u32x2 pk;
+      pk.x = pack_bf16(acc[mi][nj][0], acc[mi][nj][1]);
+      pk.y = pack_bf16(acc[mi][nj][2], acc[mi][nj][3]);
+      __builtin_nontemporal_store(pk, reinterpret_cast<u32x2*>(out + m * N + n));
+    }
+  }
+}
+
+static uint16_t to_bf16(float f) {
+  uint32_t a;
+  memcpy(&a, &f, 4);
+  a += 0x7FFFu + ((a >> 16) & 1u);
+  return (uint16_t)(a >> 16);
+}
+static float from_bf16(uint16_t h) {
+  uint32_t a = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &a, 4);
+  return f;
+}
+
+#define CHECK(e)                                                                      \
+  do {                                                                                \
+    hipError_t err_ = (e);                                                            \
+    if (err_ != hipSuccess) {                                                         \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(err_));     \
+      exit(1);                                                                        \
+    }                                                                                 \
+  } while (0)
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 16384, N = argc > 2 ? atoi(argv[2]) : 14336, K = argc > 3 ? atoi(argv[3]) : 4096;
+  if (M % 256 || N % 256 || K % 128) { fprintf(stderr, "M, N multiples of 256, K of 128\n"); return 2; }
+  std::vector<uint16_t> hx((size_t)M * K), hw((size_t)N * K);
+  uint32_t s = 12345;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((int)(s >> 9) % 2001 - 1000) * 1e-3f; };
+  for (auto& v : hx) v = to_bf16(rnd());
+  for (auto& v : hw) v = to_bf16(rnd() * 0.05f);
+  uint16_t *dx, *dw, *dout;
+  CHECK(hipMalloc(&dx, hx.size() * 2)); CHECK(hipMalloc(&dw, hw.size() * 2)); CHECK(hipMalloc(&dout, (size_t)M * N * 2));
+  CHECK(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+  CHECK(hipMemset(dout, 0xFF, (size_t)M * N * 2));
+  const int tiles_m = M / 256, tiles_n = N / 256;
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLOT));
+  auto launch = [&]() { gemm4w_kernel<<<tiles_m * tiles_n, 256, 2 * SLOT>>>((const uint8_t*)dx, (const uint8_t*)dw, dout, M, N, K, tiles_m, tiles_n); };
+  launch();
+  CHECK(hipDeviceSynchronize());
+  std::vector<uint16_t> ho((size_t)M * N);
+  CHECK(hipMemcpy(ho.data(), dout, ho.size() * 2, hipMemcpyDeviceToHost));
+  double worst = 0;
+  int bad = 0;
+  for (int t = 0; t < 4000; ++t) {
+    s = s * 1664525u + 1013904223u;
+    const int m = (int)((s >> 8) % (uint32_t)M);
+    s = s * 1664525u + 1013904223u;
+    const int n = (int)((s >> 8) % (uint32_t)N);
+    double ref = 0;
+    for (int k = 0; k < K; ++k) ref += (double)from_bf16(hx[(size_t)m * K + k]) * (double)from_bf16(hw[(size_t)n * K + k]);
+    const double got = from_bf16(ho[(size_t)m * N + n]);
+    const double err = fabs(got - ref), tol = 0.01 * fabs(ref) + 0.02;
+    if (err > tol) { if (bad < 5) fprintf(stderr, "mismatch at (%d, %d): got %g want %g\n", m, n, got, ref); ++bad; }
+    if (err > worst) worst = err;
+  }
+  printf("check: %d of 4000 sampled outputs off (worst abs err %.4g)\n", bad, worst);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) launch();
+  float best = 1e30f, sum = 0;
+  const int reps = 10;
+  for (int r = 0; r < reps; ++r) {
+    hipEventRecord(e0);
+    launch();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    best = ms < best ? ms : best;
+    sum += ms;
+  }
+  const double flops = 2.0 * M * N * K;
+  printf("gemm4w %d x %d x %d: mean %.4f ms = %.0f TFLOP/s, best %.4f ms = %.0f TFLOP/s\n", M, N, K, sum / reps, flops / (sum / reps) / 1e9, best, flops / best / 1e9);
+  return bad ? 1 : 0;
+}
