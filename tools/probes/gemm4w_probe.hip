@@ -22,6 +22,8 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_t;
 typedef __attribute__((address_space(1))) const void gbl_t;
 
+__device__ unsigned long long g_clk[4];
+__device__ unsigned long long g_tile[3][64][3];  // blocks 0 / 100 / 255: per tile K-loop cycles, epilogue cycles, reference ticks of the K-loop  // block 0: shader-clock cycles and 100 MHz reference ticks over its lifetime
 constexpr int IMAGE = 256 * 128;  // one operand image of a super-step: 256 rows x 64 bf16
 constexpr int SLOT = 2 * IMAGE;
 
@@ -37,19 +39,38 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   return (a >> 16) | (b & 0xFFFF0000u);
 }
 
+// tile order. xc == 0: XCD x (= blockIdx % 8) owns a contiguous range of the global order (groups of 8 row tiles x all column
+// tiles) — the shipped kernels' walk: different XCDs work on different row groups. xc > 0: the XCDs form an (8 / xc) x xc grid,
+// each owns a sub-matrix of tiles and walks it in the same grouped order, so the XCDs of one grid row stream the SAME activation
+// panels at the same time (one HBM read, the others hit the Infinity Cache) and keep their own weight panels resident.
+__device__ __forceinline__ void tile_of(uint32_t vid, uint32_t nblk, int tiles_m, int tiles_n, int xc, int& m0, int& n0) {
+  const uint32_t xcd = vid & 7u, slot_in_xcd = vid >> 3;
+  if (xc == 0) {
+    const uint32_t q8 = nblk >> 3, r8 = nblk & 7u;
+    const uint32_t tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot_in_xcd;
+    const uint32_t per_group = 8u * (uint32_t)tiles_n;
+    const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
+    const uint32_t group_rows = min(8u, (uint32_t)tiles_m - group * 8u);
+    m0 = (int)(group * 8u + in_group % group_rows) * 256;
+    n0 = (int)(in_group / group_rows) * 256;
+  } else {
+    const uint32_t xr = 8u / (uint32_t)xc;
+    const uint32_t R = (uint32_t)tiles_m / xr, C = (uint32_t)tiles_n / (uint32_t)xc;  // divisible (checked by the host)
+    const uint32_t rb = xcd / (uint32_t)xc, cb = xcd % (uint32_t)xc;
+    const uint32_t per_group = 8u * C;
+    const uint32_t group = slot_in_xcd / per_group, in_group = slot_in_xcd - group * per_group;
+    const uint32_t group_rows = min(8u, R - group * 8u);
+    m0 = (int)(rb * R + group * 8u + in_group % group_rows) * 256;
+    n0 = (int)(cb * C + in_group / group_rows) * 256;
+  }
+}
+
 __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const uint8_t* __restrict__ x, const uint8_t* __restrict__ w, uint16_t* __restrict__ out, int M,
-                                                         int N, int K, int tiles_m, int tiles_n) {
+                                                         int N, int K, int tiles_m, int tiles_n, int xc) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  // XCD-aware grouped tile order: XCD x (= blockIdx % 8) owns a contiguous range of the order, groups of 8 row tiles x all column tiles
-  const uint32_t nblk = gridDim.x;
-  const uint32_t xcd = blockIdx.x & 7u, slot_in_xcd = blockIdx.x >> 3;
-  const uint32_t q8 = nblk >> 3, r8 = nblk & 7u;
-  const uint32_t tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot_in_xcd;
-  const uint32_t per_group = 8u * (uint32_t)tiles_n;
-  const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
-  const uint32_t group_rows = min(8u, (uint32_t)tiles_m - group * 8u);
-  const int m0 = (int)(group * 8u + in_group % group_rows) * 256;
-  const int n0 = (int)(in_group / group_rows) * 256;
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
+  int m0, n0;
+  tile_of(blockIdx.x, gridDim.x, tiles_m, tiles_n, xc, m0, n0);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,8 +92,15 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const uint8_t* __restric
 #pragma unroll
     for (int c = c0; c < c0 + n; ++c) {
       asm volatile("" : "+v"(d_voff[c]));
-      __builtin_amdgcn_global_load_lds((gbl_t*)((a_base + ks * 128) + d_voff[c]), (lds_t*)(slot + (wave * 8 + c) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_t*)((b_base + ks * 128) + d_voff[c]), (lds_t*)(slot + IMAGE + (wave * 8 + c) * 1024), 16, 0, 0);
+#ifdef P4_SAMEK  // timing only: every super-step re-reads K range 0 (all hits): prices the memory latency the loop exposes
+      const int kk = 0 * ks;
+#elif defined(P4_KWINDOW)  // timing only: the K range wraps after P4_KWINDOW super-steps: misses the L1, hits the L2
+      const int kk = ks % P4_KWINDOW;
+#else
+      const int kk = ks;
+#endif
+      __builtin_amdgcn_global_load_lds((gbl_t*)((a_base + kk * 128) + d_voff[c]), (lds_t*)(slot + (wave * 8 + c) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_t*)((b_base + kk * 128) + d_voff[c]), (lds_t*)(slot + IMAGE + (wave * 8 + c) * 1024), 16, 0, 0);
     }
   };
 
@@ -154,7 +182,9 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const uint8_t* __restric
     phase(fa0, fb0, fa1, fb1, a_off[cur][1], b_off[cur][1], [](int) {}, std::false_type{});
     // the images of ks + 1 have landed (this wave's pieces; the barrier makes it everybody's) and `cur` has been read in full
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifndef P4_NOBAR  // timing only without it: prices the barrier
     __builtin_amdgcn_s_barrier();
+#endif
     // ---- phase 1: MFMAs on set 1 | LDS-DMA of ks + 2 into `cur`, read k-half 0 of `nxt` into set 0
     const int kn = ks + 2 < ksuper ? ks + 2 : ksuper - 1;
     uint8_t* const dst = cur ? s1 : s0;
@@ -167,6 +197,10 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const uint8_t* __restric
     super_step(ks + 1, 1);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // the K-loop of block 0 (prologue included, epilogue not)
+    g_clk[0] = __builtin_amdgcn_s_memtime() - clk0;
+    g_clk[1] = __builtin_amdgcn_s_memrealtime() - ref0;
+  }
 
   // ---- epilogue (probe quality): lane holds D[n = nj*16 + 4 g4 + t][m = mi*16 + r16] -> 8-byte stores
 #pragma unroll
@@ -181,6 +215,320 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const uint8_t* __restric
       __builtin_nontemporal_store(pk, reinterpret_cast<u32x2*>(out + m * N + n));
     }
   }
+}
+
+// ---- ring form: stages of 32 k (a 16 KiB image per operand: 256 rows x 64 bytes), P4_NBUF buffers. Stage s lives in buffer
+// s % NBUF; while stage s is computed from registers, the fragments of s + 1 are read, and the LDS-DMA of stage s + NBUF is issued
+// into the buffer stage s just left (everybody finished reading it before the barrier that ended phase s - 1). A stage's pieces are
+// in flight for NBUF - 2 whole phases (2 slots of 64 k: at most one): counted vmcnt, the younger stages stay in flight.
+#ifndef P4_NBUF
+#define P4_NBUF 5
+#endif
+constexpr int R_IMAGE = 256 * 64;
+constexpr int R_STAGE = 2 * R_IMAGE;  // 32 KiB
+
+__global__ __launch_bounds__(256, 1) void gemm4w_ring_kernel(const uint8_t* __restrict__ x, const uint8_t* __restrict__ w, uint16_t* __restrict__ out,
+                                                              int M, int N, int K, int tiles_m, int tiles_n, int xc) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
+  constexpr int NBUF = P4_NBUF;
+  int m0, n0;
+  tile_of(blockIdx.x, gridDim.x, tiles_m, tiles_n, xc, m0, n0);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // LDS-DMA: piece c (0..3) of wave w covers image rows (4 w + c) * 16 + lane / 4; a row is 4 slots of 16 bytes, the lane's slot is
+  // swizzled on the SOURCE address: position p of the row holds logical slot p ^ (row / 4) % 4 (conflict-free fragment reads:
+  // 16 lanes = 16 rows of one logical slot hit 16 different 16-byte bank groups)
+  const uint32_t row_bytes = (uint32_t)K * 2u;
+  const uint8_t* a_base = x + (size_t)m0 * row_bytes;
+  const uint8_t* b_base = w + (size_t)n0 * row_bytes;
+  uint32_t d_voff[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int row = (wave * 4 + c) * 16 + (lane >> 2);
+    const int d_slot = (lane & 3) ^ ((row >> 2) & 3);
+    d_voff[c] = (uint32_t)row * row_bytes + d_slot * 16;
+  }
+  auto issue = [&](int st, int buf, int c) {  // one A piece and one B piece of stage `st` into buffer `buf`
+#ifdef P4_SAMEK
+    const int kk = 0 * st;
+#else
+    const int kk = st;
+#endif
+    uint8_t* slot = lds + buf * R_STAGE;
+    asm volatile("" : "+v"(d_voff[c]));
+    __builtin_amdgcn_global_load_lds((gbl_t*)((a_base + kk * 64) + d_voff[c]), (lds_t*)(slot + (wave * 4 + c) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_t*)((b_base + kk * 64) + d_voff[c]), (lds_t*)(slot + R_IMAGE + (wave * 4 + c) * 1024), 16, 0, 0);
+  };
+
+  const uint32_t r16 = lane & 15, g4 = lane >> 4;
+  const uint32_t arow = wm * 128 + r16, brow = wn * 128 + r16;
+  // byte offset inside a stage buffer; the row tile goes into the offset field (t * 16 rows * 64 B = t * 1024)
+  const uint32_t a_off0 = arow * 64 + ((g4 ^ ((arow >> 2) & 3u)) << 4);
+  const uint32_t b_off0 = R_IMAGE + brow * 64 + ((g4 ^ ((brow >> 2) & 3u)) << 4);
+
+  v4i fa0[8], fb0[8], fa1[8], fb1[8];
+  v4f acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+  auto read_one = [&](int r, uint32_t ao, uint32_t bo, v4i (&fa)[8], v4i (&fb)[8]) {
+    switch (r) {
+      case 0: P4_READ(fb[0], bo, 0 * 1024); break;
+      case 1: P4_READ(fa[0], ao, 0 * 1024); break;
+      case 2: P4_READ(fb[1], bo, 1 * 1024); break;
+      case 3: P4_READ(fb[2], bo, 2 * 1024); break;
+      case 4: P4_READ(fb[3], bo, 3 * 1024); break;
+      case 5: P4_READ(fb[4], bo, 4 * 1024); break;
+      case 6: P4_READ(fb[5], bo, 5 * 1024); break;
+      case 7: P4_READ(fb[6], bo, 6 * 1024); break;
+      case 8: P4_READ(fb[7], bo, 7 * 1024); break;
+      case 9: P4_READ(fa[1], ao, 1 * 1024); break;
+      case 10: P4_READ(fa[2], ao, 2 * 1024); break;
+      case 11: P4_READ(fa[3], ao, 3 * 1024); break;
+      case 12: P4_READ(fa[4], ao, 4 * 1024); break;
+      case 13: P4_READ(fa[5], ao, 5 * 1024); break;
+      case 14: P4_READ(fa[6], ao, 6 * 1024); break;
+      default: P4_READ(fa[7], ao, 7 * 1024); break;
+    }
+  };
+  // one stage: 64 MFMAs on (fa, fb); fragment read r of the next stage behind MFMA P4_DS_PER * r + 1; the four LDS-DMA piece pairs
+  // of stage `st_dma` behind MFMAs 3, 19, 35, 51
+  auto phase = [&](const v4i (&fa)[8], const v4i (&fb)[8], v4i (&na)[8], v4i (&nb)[8], int next_buf, int st_dma, int dma_buf) {
+    const uint32_t ao = a_off0 + next_buf * R_STAGE, bo = b_off0 + next_buf * R_STAGE;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const int mi = i >> 3, n_ = i & 7;
+      const int nj = (mi & 1) ? 7 - n_ : n_;
+      P4_MFMA(acc[mi][nj], fb[nj], fa[mi]);
+      if (i % P4_DS_PER == 1 && i / P4_DS_PER < 16) read_one(i / P4_DS_PER, ao, bo, na, nb);
+      if ((i & 15) == 3) issue(st_dma, dma_buf, i >> 4);
+    }
+    // stage s + 2 has landed (this wave's pieces; NBUF - 2 younger stages of 8 instructions stay in flight), the next stage's
+    // fragments are in registers: the buffer they came from is free once everybody is here
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 * (NBUF - 2)) : "memory");
+#ifndef P4_NOBAR
+    __builtin_amdgcn_s_barrier();
+#endif
+  };
+
+  const int nstage = K / 32;  // a multiple of 2 * NBUF is not required: stages past the end re-read the last one and are never used
+  auto clamp = [&](int st) { return st < nstage ? st : nstage - 1; };
+#pragma unroll
+  for (int b = 0; b < NBUF; ++b)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) issue(clamp(b), b, c);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NBUF - 1)) : "memory");
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) read_one(r, a_off0, b_off0, fa0, fb0);
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 * (NBUF - 2)) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // 2 * NBUF stages per trip: buffer numbers and register sets are compile-time
+#pragma unroll 1
+  for (int s0 = 0; s0 < nstage; s0 += 2 * NBUF) {
+#pragma unroll
+    for (int u = 0; u < 2 * NBUF; ++u) {
+      const int s = s0 + u;
+      if (s < nstage) {  // wave-uniform
+        if ((u & 1) == 0) phase(fa0, fb0, fa1, fb1, (u + 1) % NBUF, clamp(s + NBUF), u % NBUF);
+        else phase(fa1, fb1, fa0, fb0, (u + 1) % NBUF, clamp(s + NBUF), u % NBUF);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // the K-loop of block 0 (prologue included, epilogue not)
+    g_clk[0] = __builtin_amdgcn_s_memtime() - clk0;
+    g_clk[1] = __builtin_amdgcn_s_memrealtime() - ref0;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const size_t m = (size_t)(m0 + wm * 128 + mi * 16 + (int)r16);
+#pragma unroll
+    for (int nj = 0; nj < 8; ++nj) {
+      const int n = n0 + wn * 128 + nj * 16 + 4 * (int)g4;
+      u32x2 pk;
+      pk.x = pack_bf16(acc[mi][nj][0], acc[mi][nj][1]);
+      pk.y = pack_bf16(acc[mi][nj][2], acc[mi][nj][3]);
+      __builtin_nontemporal_store(pk, reinterpret_cast<u32x2*>(out + m * N + n));
+    }
+  }
+}
+
+// ---- persistent form of the pair kernel: one block per CU walks its tiles in the order a non-persistent launch would dispatch
+// them; the K-loop runs ACROSS tile boundaries (the last two super-steps of a tile fetch the first two of the next, the last
+// k-half reads the next tile's first fragments), so a tile costs its K-loop plus an epilogue that goes through 32 KiB of LDS
+// behind the two slots (16-byte row-contiguous stores) while the next tile's images are landing.
+constexpr int EP_PITCH = 128 * 2 + 16;       // one staged row of a wave: 128 bf16 + pad
+constexpr int EP_WAVE = 16 * EP_PITCH;       // 16 rows
+
+__global__ __launch_bounds__(256, 1) void gemm4w_persist_kernel(const uint8_t* __restrict__ x, const uint8_t* __restrict__ w, uint16_t* __restrict__ out,
+                                                                 int M, int N, int K, int tiles_m, int tiles_n, int xc) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
+  const uint32_t total = (uint32_t)tiles_m * (uint32_t)tiles_n;
+  const int my_tiles = (int)((total - blockIdx.x + gridDim.x - 1) / gridDim.x);  // grid = a multiple of 8, <= total
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint32_t row_bytes = (uint32_t)K * 2u;
+  auto origin = [&](int it, int& m0, int& n0) {
+    it = it < my_tiles ? it : my_tiles - 1;
+    tile_of(blockIdx.x + (uint32_t)it * gridDim.x, total, tiles_m, tiles_n, xc, m0, n0);
+  };
+  auto base_of = [&](const uint8_t* p, int row0) {
+    const uint64_t off = (uint64_t)(uint32_t)row0 * (uint64_t)row_bytes;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)off), hi = __builtin_amdgcn_readfirstlane((uint32_t)(off >> 32));
+    return p + (((uint64_t)hi << 32) | lo);
+  };
+  uint32_t d_voff[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int row = (wave * 8 + c) * 8 + (lane >> 3);
+    const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
+    d_voff[c] = (uint32_t)row * row_bytes + d_slot * 16;
+  }
+  auto issue = [&](const uint8_t* ab, const uint8_t* bb, int ks, uint8_t* slot, int c) {
+    asm volatile("" : "+v"(d_voff[c]));
+    __builtin_amdgcn_global_load_lds((gbl_t*)((ab + ks * 128) + d_voff[c]), (lds_t*)(slot + (wave * 8 + c) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_t*)((bb + ks * 128) + d_voff[c]), (lds_t*)(slot + IMAGE + (wave * 8 + c) * 1024), 16, 0, 0);
+  };
+  const uint32_t r16 = lane & 15, g4 = lane >> 4;
+  uint32_t a_off[2][2], b_off[2][2];
+  {
+    const uint32_t arow = wm * 128 + r16, brow = wn * 128 + r16;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int kq = 0; kq < 2; ++kq) {
+        a_off[sl][kq] = sl * SLOT + arow * 128 + (((kq * 4 + g4) ^ ((arow >> 1) & 7u)) << 4);
+        b_off[sl][kq] = sl * SLOT + IMAGE + brow * 128 + (((kq * 4 + g4) ^ ((brow >> 1) & 7u)) << 4);
+      }
+  }
+  v4i fa0[8], fb0[8], fa1[8], fb1[8];
+  v4f acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+  auto read_one = [&](int r, uint32_t ao, uint32_t bo, v4i (&fa)[8], v4i (&fb)[8]) {
+    switch (r) {
+      case 0: P4_READ(fb[0], bo, 0 * 2048); break;
+      case 1: P4_READ(fa[0], ao, 0 * 2048); break;
+      case 2: P4_READ(fb[1], bo, 1 * 2048); break;
+      case 3: P4_READ(fb[2], bo, 2 * 2048); break;
+      case 4: P4_READ(fb[3], bo, 3 * 2048); break;
+      case 5: P4_READ(fb[4], bo, 4 * 2048); break;
+      case 6: P4_READ(fb[5], bo, 5 * 2048); break;
+      case 7: P4_READ(fb[6], bo, 6 * 2048); break;
+      case 8: P4_READ(fb[7], bo, 7 * 2048); break;
+      case 9: P4_READ(fa[1], ao, 1 * 2048); break;
+      case 10: P4_READ(fa[2], ao, 2 * 2048); break;
+      case 11: P4_READ(fa[3], ao, 3 * 2048); break;
+      case 12: P4_READ(fa[4], ao, 4 * 2048); break;
+      case 13: P4_READ(fa[5], ao, 5 * 2048); break;
+      case 14: P4_READ(fa[6], ao, 6 * 2048); break;
+      default: P4_READ(fa[7], ao, 7 * 2048); break;
+    }
+  };
+  auto phase = [&](const v4i (&fa)[8], const v4i (&fb)[8], v4i (&na)[8], v4i (&nb)[8], uint32_t ao, uint32_t bo, auto dma, auto with_dma) {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const int mi = i >> 3, n_ = i & 7;
+      const int nj = (mi & 1) ? 7 - n_ : n_;
+      P4_MFMA(acc[mi][nj], fb[nj], fa[mi]);
+      if (i % P4_DS_PER == 1 && i / P4_DS_PER < 16) read_one(i / P4_DS_PER, ao, bo, na, nb);
+      if constexpr (decltype(with_dma)::value) {
+        if ((i & 7) == 3) dma(i >> 3);
+      }
+    }
+  };
+
+  const int ksuper = K / 64;  // even
+  uint8_t* const s0 = lds;
+  uint8_t* const s1 = lds + SLOT;
+  uint8_t* const stage = lds + 2 * SLOT + wave * EP_WAVE;
+  int m0, n0, m1, n1;
+  origin(0, m0, n0);
+  const uint8_t* ab = base_of(x, m0);
+  const uint8_t* bb = base_of(w, n0);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) issue(ab, bb, 0, s0, c);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) issue(ab, bb, 1, s1, c);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) read_one(r, a_off[0][0], b_off[0][0], fa0, fb0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  const int rec = blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : blockIdx.x == 255 ? 2 : -1;
+#pragma unroll 1
+  for (int it = 0; it < my_tiles; ++it) {
+    const unsigned long long t_k0 = __builtin_amdgcn_s_memtime(), r_k0 = __builtin_amdgcn_s_memrealtime();
+    origin(it + 1, m1, n1);
+    const uint8_t* ab1 = base_of(x, m1);
+    const uint8_t* bb1 = base_of(w, n1);
+    auto super_step = [&](int ks, int cur) {
+      const int nxt = cur ^ 1;
+      phase(fa0, fb0, fa1, fb1, a_off[cur][1], b_off[cur][1], [](int) {}, std::false_type{});
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // super-step ks + 2 of this tile, or — on the tile's last two super-steps — super-step 0 / 1 of the next tile
+      const bool over = ks + 2 >= ksuper;
+      const uint8_t* pa = over ? ab1 : ab;
+      const uint8_t* pb = over ? bb1 : bb;
+      const int kn = over ? ks + 2 - ksuper : ks + 2;
+      uint8_t* const dst = cur ? s1 : s0;
+      phase(fa1, fb1, fa0, fb0, a_off[nxt][0], b_off[nxt][0], [&](int c) { issue(pa, pb, kn, dst, c); }, std::true_type{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+#pragma unroll 1
+    for (int ks = 0; ks < ksuper; ks += 2) {
+      super_step(ks, 0);
+      super_step(ks + 1, 1);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (it == 0 && blockIdx.x == 0 && threadIdx.x == 0) {  // first tile's K-loop (prologue included)
+      g_clk[0] = __builtin_amdgcn_s_memtime() - clk0;
+      g_clk[1] = __builtin_amdgcn_s_memrealtime() - ref0;
+    }
+    const unsigned long long t_k1 = __builtin_amdgcn_s_memtime(), r_k1 = __builtin_amdgcn_s_memrealtime();
+    // ---- epilogue: 16 rows x 128 columns of the wave at a time through its staging rows; lane holds D[n = nj*16 + 4 g4 + t][m = r16]
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+      for (int nj = 0; nj < 8; ++nj) {
+        u32x2 pk;
+        pk.x = pack_bf16(acc[mi][nj][0], acc[mi][nj][1]);
+        pk.y = pack_bf16(acc[mi][nj][2], acc[mi][nj][3]);
+        *reinterpret_cast<u32x2*>(stage + r16 * EP_PITCH + (nj * 16 + 4 * g4) * 2) = pk;
+        acc[mi][nj] = v4f{0.f, 0.f, 0.f, 0.f};
+      }
+      // the wave's own rows only: no block barrier, just the wave's LDS traffic in order
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = (lane >> 4) + 4 * t, seg = lane & 15;
+        const v4i v = *reinterpret_cast<const v4i*>(stage + row * EP_PITCH + seg * 16);
+        const size_t m = (size_t)(m0 + wm * 128 + mi * 16 + row);
+        __builtin_nontemporal_store(v, reinterpret_cast<v4i*>(reinterpret_cast<uint8_t*>(out) + (m * N + n0 + wn * 128) * 2 + seg * 16));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (rec >= 0 && threadIdx.x == 0 && it < 64) {
+      g_tile[rec][it][0] = t_k1 - t_k0;
+      g_tile[rec][it][1] = __builtin_amdgcn_s_memtime() - t_k1;
+      g_tile[rec][it][2] = r_k1 - r_k0;
+    }
+    m0 = m1; n0 = n1; ab = ab1; bb = bb1;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
 static uint16_t to_bf16(float f) {
@@ -219,8 +567,21 @@ int main(int argc, char** argv) {
   CHECK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
   CHECK(hipMemset(dout, 0xFF, (size_t)M * N * 2));
   const int tiles_m = M / 256, tiles_n = N / 256;
+  const bool ring = argc > 4 && !strcmp(argv[4], "ring");
+  const bool persist = argc > 4 && !strcmp(argv[4], "persist");
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4w_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLOT + 4 * EP_WAVE));
+  int cus = 0;
+  CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLOT));
-  auto launch = [&]() { gemm4w_kernel<<<tiles_m * tiles_n, 256, 2 * SLOT>>>((const uint8_t*)dx, (const uint8_t*)dw, dout, M, N, K, tiles_m, tiles_n); };
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4w_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P4_NBUF * R_STAGE));
+  int xc = argc > 5 ? atoi(argv[5]) : 0;
+  if (xc && (8 % xc || tiles_m % (8 / xc) || tiles_n % xc)) { fprintf(stderr, "XCD grid %d x %d does not divide %d x %d tiles\n", 8 / xc, xc, tiles_m, tiles_n); return 2; }
+  printf("%s, XCD grid %s: ", ring ? "ring" : persist ? "persist" : "pair", xc ? argv[5] : "none");
+  auto launch = [&]() {
+    if (persist) gemm4w_persist_kernel<<<(tiles_m * tiles_n < cus ? tiles_m * tiles_n : cus), 256, 2 * SLOT + 4 * EP_WAVE>>>((const uint8_t*)dx, (const uint8_t*)dw, dout, M, N, K, tiles_m, tiles_n, xc);
+    else if (ring) gemm4w_ring_kernel<<<tiles_m * tiles_n, 256, P4_NBUF * R_STAGE>>>((const uint8_t*)dx, (const uint8_t*)dw, dout, M, N, K, tiles_m, tiles_n, xc);
+    else gemm4w_kernel<<<tiles_m * tiles_n, 256, 2 * SLOT>>>((const uint8_t*)dx, (const uint8_t*)dw, dout, M, N, K, tiles_m, tiles_n, xc);
+  };
   launch();
   CHECK(hipDeviceSynchronize());
   std::vector<uint16_t> ho((size_t)M * N);
@@ -254,6 +615,21 @@ int main(int argc, char** argv) {
     hipEventElapsedTime(&ms, e0, e1);
     best = ms < best ? ms : best;
     sum += ms;
+  }
+  unsigned long long clk[4];
+  CHECK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk)));
+  const double mfma_cycles = (double)(K / 32) * 64 * 16;  // one wave's MFMAs of one tile, 16 cycles each
+  printf("block 0 K-loop: %llu shader cycles in %.2f us -> %.0f MHz; matrix pipe busy %.1f %% of them\n", clk[0], clk[1] / 100.0, clk[0] / (clk[1] / 100.0),
+         100.0 * mfma_cycles / (double)clk[0]);
+  if (persist) {
+    static unsigned long long tl[3][64][3];
+    CHECK(hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_tile), sizeof(tl)));
+    const int nt = (tiles_m * tiles_n + cus - 1) / cus < 64 ? (tiles_m * tiles_n + cus - 1) / cus : 64;
+    for (int b = 0; b < 3; ++b) {
+      printf("block %d per tile: K-loop busy %% @ MHz | epilogue cycles:", b == 0 ? 0 : b == 1 ? 100 : 255);
+      for (int t = 0; t < nt; ++t) printf(" %.0f@%.0f|%llu", 100.0 * mfma_cycles / (double)tl[b][t][0], tl[b][t][0] / (tl[b][t][2] / 100.0), tl[b][t][1]);
+      printf("\n");
+    }
   }
   const double flops = 2.0 * M * N * K;
   printf("gemm4w %d x %d x %d: mean %.4f ms = %.0f TFLOP/s, best %.4f ms = %.0f TFLOP/s\n", M, N, K, sum / reps, flops / (sum / reps) / 1e9, best, flops / best / 1e9);
