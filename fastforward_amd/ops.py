@@ -341,12 +341,14 @@ def minmax_by_tile(
     running_min: torch.Tensor | None = None,
     running_max: torch.Tensor | None = None,
     status_flags: torch.Tensor | None = None,
+    into: tuple[torch.Tensor, torch.Tensor] | None = None,
 ) -> tuple[torch.Tensor, torch.Tensor]:
     """A4 — per-tile (min, max) of `data` in the data dtype (reference minmax.py:227-237).
 
     With `running_min` / `running_max` given they are updated IN PLACE (running min / running max)
     and returned. `status_flags` (int32[1] on the data's device) is OR-ed with FLAG_INF / FLAG_NAN
     for this batch so the caller can decide when to look at it; nothing here waits for the device.
+    `into` = (min, max) buffers for THIS batch's extrema (overwritten, not merged).
     """
     data_c = data.detach().contiguous()
     lib, stream = _prepare(data_c, running_min, running_max, status_flags)
@@ -365,6 +367,10 @@ def minmax_by_tile(
             )
         if not (mn.is_contiguous() and mx.is_contiguous()):
             raise RuntimeError("running min/max must be contiguous")
+    elif into is not None:
+        mn, mx = into
+        if not (mn.numel() == mx.numel() == ntiles and mn.dtype == mx.dtype == data_c.dtype and mn.is_contiguous() and mx.is_contiguous()):
+            raise RuntimeError(f"`into` must be two contiguous buffers of {ntiles} values of dtype {data_c.dtype}")
     else:
         mn = torch.empty(ntiles, dtype=data_c.dtype, device=data_c.device)
         mx = torch.empty(ntiles, dtype=data_c.dtype, device=data_c.device)

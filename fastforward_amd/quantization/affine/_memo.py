@@ -42,6 +42,8 @@ class RecentActivationCodes(threading.local):
         self._verdicts: dict[tuple[int, int, int, int], tuple[weakref.ref, weakref.ref, bool]] = {}
         self._depth = 0
         self.hits = 0
+        self._extrema: tuple[weakref.ref, tuple[Any, ...], torch.Tensor] | None = None  # (data, key, [min, max] of it)
+        self.extrema_hits = 0
 
     @contextlib.contextmanager
     def scope(self) -> Iterator[None]:
@@ -124,8 +126,30 @@ class RecentActivationCodes(threading.local):
         offset = params.offset
         self._entries.append((params.scale, params.scale._version, offset, -1 if offset is None else offset._version, params.num_bits, tile, container, raw))
 
+    # Range ESTIMATION of siblings (RunningMinMax on q / k / v or gate / up inputs): every estimator needs the extrema of the
+    # same activation; the reduction over the tensor is done once and each estimator merges the two numbers into its own
+    # running state — exact whatever the states are (min / max are exact), unlike code reuse it needs no equal parameters.
+    def extrema(self, data: torch.Tensor) -> torch.Tensor | None:
+        """[min, max] of `data` (data dtype, on its device) left by an earlier sibling's estimator step, or None."""
+        if self._depth == 0 or self._extrema is None or type(data) is not torch.Tensor:
+            return None
+        ref, key, pair = self._extrema
+        if ref() is not data or key != self._data_key(data):
+            return None
+        self.extrema_hits += 1
+        return pair
+
+    def remember_extrema(self, data: torch.Tensor, pair: torch.Tensor) -> None:
+        if self._depth > 0 and type(data) is torch.Tensor and data.is_cuda:
+            self._extrema = (weakref.ref(data), self._data_key(data), pair)
+
+    @property
+    def inside_scope(self) -> bool:
+        return self._depth > 0
+
     def clear(self) -> None:
         self._data, self._key, self._entries = None, (), []
+        self._extrema = None
 
 
 RECENT = RecentActivationCodes()

@@ -80,7 +80,8 @@ class RunningMinMaxEstimator(_MinMaxState):
                 # reduction, running merge, status flags AND the range setter in one entry point (one launch per tensor for a
                 # per-tensor quantizer) where the quantizer's parameters can be written in place; else the two steps below
                 update = getattr(quantizer, "update_range_from_data", None)
-                if update is not None and update(raw, tile, self.min, self.max, self.status):
+                # (the caller's own tensor object where autograd is not involved: sibling estimators recognise a shared input by it)
+                if update is not None and update(raw if data.requires_grad else data, tile, self.min, self.max, self.status):
                     return
                 ops.minmax_by_tile(raw, tile, running_min=self.min, running_max=self.max, status_flags=self.status)
             elif same_kind:

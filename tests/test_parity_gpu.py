@@ -1047,6 +1047,48 @@ def test_equal_quantizers_share_one_launch_on_the_same_activation():
         assert torch.equal(c[2], ops.quantize_by_tile(x, qs[2].scale, x.shape, 8, torch.int8, qs[2].offset))
 
 
+def test_sibling_estimators_share_one_reduction_and_merge_exactly():
+    """RunningMinMax on q / k / v inputs: inside ``sibling_quantizers()`` the tensor is reduced ONCE and every estimator merges the
+    two numbers into ITS OWN running state (reference minmax.py:227-239 per quantizer). Exact whatever the states are — here the
+    three quantizers start from different earlier batches — and for Inf / NaN batches (the status word included)."""
+    from fastforward_amd.quantization.affine._memo import RECENT, sibling_quantizers
+
+    torch.manual_seed(11)
+    earlier = [torch.randn(4, 64, 256, device=DEV, dtype=torch.bfloat16) * s for s in (0.5, 2.0, 5.0)]
+    batches = [torch.randn(4, 64, 256, device=DEV, dtype=torch.bfloat16) * s for s in (1.0, 3.0, 0.1)]
+    spiked = batches[1].clone()
+    spiked[0, 0, 0] = float("inf")
+
+    def run(shared: bool, feed):
+        qs = [ff.nn.LinearQuantizer(8, symmetric=sym, quantized_dtype=torch.int8, device=DEV) for sym in (False, False, True)]
+        with torch.no_grad(), ff.estimate_ranges(torch.nn.ModuleList(qs), ff.range_setting.running_minmax, sync_free=True) as handles:
+            for q, x in zip(qs, earlier):  # three different running states
+                q(x)
+            for x in feed:
+                if shared:
+                    with sibling_quantizers():
+                        codes = [q(x).raw_data for q in qs]
+                else:
+                    codes = [q(x).raw_data for q in qs]
+            estimators = [next(iter(q.overrides)) for q in qs]
+            state = [(e.min.clone(), e.max.clone(), e.status.clone()) for e in estimators]
+            del handles
+            return [(q.scale.clone(), q.offset.clone() if q.offset is not None else None) for q in qs], codes, state
+
+    hits = RECENT.extrema_hits
+    got = run(True, batches)
+    assert RECENT.extrema_hits == hits + 2 * len(batches)  # the second and third sibling of every batch
+    want = run(False, batches)
+    for (gs, go), (ws, wo) in zip(got[0], want[0]):
+        assert torch.equal(gs, ws) and (go is None) == (wo is None) and (go is None or torch.equal(go, wo))
+    assert all(torch.equal(a, b) for a, b in zip(got[1], want[1]))
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) for a, b in zip(got[2], want[2]))
+    # an infinite batch: the same running extrema and the same status flags on every sibling, then the reference's error
+    for shared in (True, False):
+        with pytest.raises(NotImplementedError, match="[Ii]nfinite"):
+            run(shared, [spiked])
+
+
 def test_a_write_through_dot_data_between_two_quantizer_calls_gets_fresh_codes():
     """``h.data.mul_(2)`` moves neither ``h._version`` nor ``h.data_ptr()``: a cache keyed on them would hand the second of two
     equal quantizers the first one's codes where the reference re-quantizes (nn/linear.py:32-39). The memo only lives inside the
