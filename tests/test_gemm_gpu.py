@@ -175,6 +175,48 @@ def test_repeated_launches_are_bit_identical():
             assert all(torch.equal(fn(), first) for _ in range(40)), (m, n, k, i)
 
 
+def test_repeated_split_k_launches_are_bit_identical():
+    """Race hunt on the split-K exchange (write-through slabs, arrival counters, `sc1` reads of the peers' pieces): 2048-token
+    launches of every split the chip allows, the q / k / v launch and the MLP mode, 60 repeats each, back to back on one stream
+    (every launch must leave the counters zero for the next), on a second stream with its own counters, and replayed from a
+    hipGraph — all bit-equal to the first result."""
+    from fastforward_amd import _native
+
+    lib = _native.library()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    t, k = 2048, 4096
+    x = torch.randn(t, k, device=DEV, generator=g).to(torch.bfloat16)
+    ws = {n: torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g) for n in (4096, 1024)}
+    ss = {n: torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4 for n in ws}
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    forms = []
+    for n in ws:
+        tiles = (t // 256) * (n // 256)
+        for split in (2, 4, 8):
+            if tiles * split <= cus:
+                forms.append((f"N={n} S={split}", lambda n=n, split=split: ops.linear_wq(x, ws[n], ss[n], None, two_pass=False, split=split)))
+        assert int(lib.ffq_linear_wq_split(t, n, k, 0)) > 1  # and the plan the library takes by itself
+        forms.append((f"N={n} plan", lambda n=n: ops.linear_wq(x, ws[n], ss[n], None)))
+    forms.append(("q/k/v", lambda: torch.cat(ops.linear_wq_multi(x, [ws[4096], ws[1024], ws[1024]], [ss[4096], ss[1024], ss[1024]], [None] * 3), dim=1)))
+    forms.append(("mlp", lambda: ops.mlp_gate_up_wq(x, ws[4096], ws[4096], ss[4096], None, ss[4096], None)))
+    side = torch.cuda.Stream()
+    for name, fn in forms:
+        first = fn()
+        assert all(torch.equal(fn(), first) for _ in range(60)), name
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            assert all(torch.equal(fn(), first) for _ in range(10)), name
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                captured = fn()
+        torch.cuda.synchronize()
+        for _ in range(10):
+            captured.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(captured, first), name
+
+
 def test_all_zero_weight_offsets_cost_no_row_sums_and_change_nothing():
     """The offset BUFFER of a symmetric quantizer (reference nn/linear_quantizer.py:164-170) at a persistent-kernel shape:
     same bits as no offset at all; one non-zero entry switches the exact ow terms on (for every column)."""
