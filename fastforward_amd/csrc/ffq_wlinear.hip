@@ -785,6 +785,248 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
   wait_all_vmem();  // the trailing requests of the streams must not outlive the block's LDS / registers
 }
 
+// =====================================================================================================================================
+// The bf16-image form with ONE wavefront per SIMD (round 4; tools/probes/gemm4w_probe.hip is the experiment this came out of):
+// 4 waves x 128 x 128 accumulators — 256 registers per lane, pinned to AGPRs as "+a" operands of inline-assembly MFMAs (with the
+// builtin hipcc rotates them through VGPRs: ~590 v_accvgpr moves per two super-steps) — so a k-half of 64 MFMAs needs 16 fragment
+// reads (0.25 per MFMA against 0.375 with 128 x 64 per wave), hand-placed one per three MFMAs a k-half AHEAD of their use into a
+// second register set; both operand images by LDS-DMA into the two 64 KiB slots, the sixteen pieces of a wave spread over the
+// second k-half; ONE barrier per super-step (behind the first k-half: the next images have landed, this slot has been read in
+// full). The K-loop is `asm volatile` in source order: 256 MFMAs + 64 ds_read_b128 + 32 LDS-DMA pieces + scalar bookkeeping per
+// two super-steps and nothing else. It runs ACROSS tile boundaries: the last two super-steps of a tile fetch the first two of
+// the next, its last k-half reads the next tile's first fragments, and the epilogue in between goes through wave-private rows
+// of LDS behind the slots while those images land. Same MFMA instruction, same k order as wq_gemm256_kernel: bit-identical results.
+// Taken for plain launches without a split tail, without a bias and with an even number of super-steps (wq_dispatch); bf16 output.
+// (A gate+up+SiLU*up mode of this kernel was built and is bit-equal too, but measured 3-5 % SLOWER than the 8-wave kernel's —
+// 2.83 against 2.75 ms at 16 k tokens — and was removed; the plain form is +2 % on q/o and gate/up, +4 % on down_proj.)
+constexpr int W4_PITCH_PLAIN = 128 * 2 + 16;  // a staged row of a wave: 128 bf16 + pad
+constexpr int W4_WAVE_PLAIN = 16 * W4_PITCH_PLAIN;
+
+__global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // the tile walk of wq_gemm256_kernel without a split tail: XCD x owns a contiguous range of the grouped order
+  const uint32_t nblk = gridDim.x;
+  const uint32_t xcd = blockIdx.x & 7u, j_in_xcd = blockIdx.x >> 3;
+  const uint32_t blocks_in_xcd = (nblk >> 3) + (xcd < (nblk & 7u) ? 1u : 0u);
+  uint32_t first, count;
+  {
+    const uint32_t tq = (uint32_t)total_tiles >> 3, tr = (uint32_t)total_tiles & 7u;
+    first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    count = tq + (xcd < tr ? 1u : 0u);
+  }
+  const int my_tiles = j_in_xcd < count ? (int)((count - j_in_xcd + blocks_in_xcd - 1) / blocks_in_xcd) : 0;
+  if (my_tiles == 0) return;
+  const int ksuper = a.K / WL_BK;  // even (wq_dispatch)
+  uint8_t* const stage = lds + 2 * WL_SLOT + wave * W4_WAVE_PLAIN;
+
+  auto tile_origin = [&](int it, int& tm0, int& tn0, int& seg) {
+    it = it < my_tiles ? it : my_tiles - 1;  // the stream running past the block's last tile re-reads it (never used)
+    const uint32_t tile_id = first + j_in_xcd + (uint32_t)it * blocks_in_xcd;
+    const uint32_t gm = (uint32_t)a.group_m;
+    const uint32_t across = a.group_cols ? (uint32_t)a.tiles_m : (uint32_t)a.tiles_n;
+    const uint32_t along = a.group_cols ? (uint32_t)a.tiles_n : (uint32_t)a.tiles_m;
+    const uint32_t per_group = gm * across;
+    const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
+    const uint32_t group_size = min(gm, along - group * gm);
+    const uint32_t inner = group * gm + in_group % group_size, outer = in_group / group_size;
+    tm0 = (int)(a.group_cols ? outer : inner) * WL_BM;
+    int tn = (int)(a.group_cols ? inner : outer);
+    seg = 0;  // which weight matrix the column tile belongs to, and the tile's origin inside it
+    if (tn >= a.seg_tile[1]) { seg = 2; tn -= a.seg_tile[1]; }
+    else if (tn >= a.seg_tile[0]) { seg = 1; tn -= a.seg_tile[0]; }
+    tn0 = tn * WL_BN;
+  };
+  auto seg_codes = [&](int seg) { return seg == 0 ? a.w : seg == 1 ? a.seg_w[0] : a.seg_w[1]; };
+  auto seg_rows = [&](int seg) { return seg == 0 ? a.seg_n[0] : seg == 1 ? a.seg_n[1] : a.seg_n[2]; };
+  auto row_base = [&](const uint8_t* base, int row0, uint32_t row_bytes) {
+    const uint64_t off = (uint64_t)(uint32_t)row0 * (uint64_t)row_bytes;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)off), hi = __builtin_amdgcn_readfirstlane((uint32_t)(off >> 32));
+    return base + (((uint64_t)hi << 32) | lo);
+  };
+
+  // ---- LDS-DMA sources: piece c (0..7) of wave w covers image rows (8 w + c) * 8 + lane / 8; the lane's 16-byte slot is
+  // swizzled on the SOURCE address (slot ^ (row / 2) % 8): the linear LDS write lands in the swizzled image
+  const uint32_t row_bytes = (uint32_t)a.K * 2u;
+  const int d_row = lane >> 3;
+  uint32_t a_voff[8], b_voff[8];
+  const uint8_t* a_base = a.x;
+  const uint8_t* b_base = a.w;
+  auto set_image_sources = [&](int tm0, int tn0, int seg) {
+    a_base = row_base(a.x, tm0, row_bytes);
+    b_base = row_base(seg_codes(seg), tn0, row_bytes);
+    const int rows = seg_rows(seg);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int row = (wave * 8 + c) * 8 + d_row;
+      const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
+      const int ra = tm0 + row < a.M ? row : a.M - 1 - tm0;  // rows past the edge re-read the last row and are never stored
+      a_voff[c] = (uint32_t)ra * row_bytes + d_slot * 16;
+      const int rb = tn0 + row < rows ? row : rows - 1 - tn0;
+      b_voff[c] = (uint32_t)rb * row_bytes + d_slot * 16;
+    }
+  };
+  auto issue = [&](int ks, int slot, int c) {  // piece c of both images of super-step ks (of the tile the sources point at)
+    uint8_t* base = lds + slot * WL_SLOT;
+    asm volatile("" : "+v"(a_voff[c]), "+v"(b_voff[c]));  // keeps the saddr form in every unrolled body (ffq_linear.hip)
+    __builtin_amdgcn_global_load_lds((wl_gbl_t*)((a_base + ks * 128) + a_voff[c]), (wl_lds_t*)(base + (wave * 8 + c) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((wl_gbl_t*)((b_base + ks * 128) + b_voff[c]), (wl_lds_t*)(base + WL_IMAGE + (wave * 8 + c) * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment addresses: lane (r16, g4) reads 8 bf16 of row r16 of a 16-row tile, logical slot kq * 4 + g4; one register per
+  // (slot, k-half, operand), the row tile in the instruction's offset field (t * 2048)
+  const uint32_t r16 = lane & 15, g4 = lane >> 4;
+  uint32_t a_off[2][2], b_off[2][2];
+  {
+    const uint32_t arow = wm * 128 + r16, brow = wn * 128 + r16;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int kq = 0; kq < 2; ++kq) {
+        a_off[sl][kq] = sl * WL_SLOT + arow * 128 + (((kq * 4 + g4) ^ ((arow >> 1) & 7u)) << 4);
+        b_off[sl][kq] = sl * WL_SLOT + WL_IMAGE + brow * 128 + (((kq * 4 + g4) ^ ((brow >> 1) & 7u)) << 4);
+      }
+  }
+  wl_v4i fa0[8], fb0[8], fa1[8], fb1[8];
+  wl_v4f acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = wl_v4f{0.f, 0.f, 0.f, 0.f};
+#define FFQ_W4_MFMA(ACC, B, A) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(B), "v"(A))
+#define FFQ_W4_READ(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+  // fragment read r (0..15) of a k-half in the order the next k-half's MFMAs need them: fb0, fa0, fb1..fb7, fa1..fa7
+  auto read_one = [&](int r, uint32_t ao, uint32_t bo, wl_v4i (&fa)[8], wl_v4i (&fb)[8]) {
+    switch (r) {
+      case 0: FFQ_W4_READ(fb[0], bo, 0 * 2048); break;
+      case 1: FFQ_W4_READ(fa[0], ao, 0 * 2048); break;
+      case 2: FFQ_W4_READ(fb[1], bo, 1 * 2048); break;
+      case 3: FFQ_W4_READ(fb[2], bo, 2 * 2048); break;
+      case 4: FFQ_W4_READ(fb[3], bo, 3 * 2048); break;
+      case 5: FFQ_W4_READ(fb[4], bo, 4 * 2048); break;
+      case 6: FFQ_W4_READ(fb[5], bo, 5 * 2048); break;
+      case 7: FFQ_W4_READ(fb[6], bo, 6 * 2048); break;
+      case 8: FFQ_W4_READ(fb[7], bo, 7 * 2048); break;
+      case 9: FFQ_W4_READ(fa[1], ao, 1 * 2048); break;
+      case 10: FFQ_W4_READ(fa[2], ao, 2 * 2048); break;
+      case 11: FFQ_W4_READ(fa[3], ao, 3 * 2048); break;
+      case 12: FFQ_W4_READ(fa[4], ao, 4 * 2048); break;
+      case 13: FFQ_W4_READ(fa[5], ao, 5 * 2048); break;
+      case 14: FFQ_W4_READ(fa[6], ao, 6 * 2048); break;
+      default: FFQ_W4_READ(fa[7], ao, 7 * 2048); break;
+    }
+  };
+  // one k-half: 64 MFMAs on (fa, fb) in snake order (every MFMA shares an operand with its predecessor); fragment read r of the NEXT
+  // k-half behind MFMA 3 r + 1 (all sixteen issued by MFMA 46: the last has 17 MFMAs to return in); with DMA: piece c behind MFMA 8 c + 3
+  auto phase = [&](const wl_v4i (&fa)[8], const wl_v4i (&fb)[8], wl_v4i (&na)[8], wl_v4i (&nb)[8], uint32_t ao, uint32_t bo, auto dma, auto with_dma) {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const int mi = i >> 3, n_ = i & 7;
+      const int nj = (mi & 1) ? 7 - n_ : n_;
+      FFQ_W4_MFMA(acc[mi][nj], fb[nj], fa[mi]);
+      if (i % 3 == 1 && i / 3 < 16) read_one(i / 3, ao, bo, na, nb);
+      if constexpr (decltype(with_dma)::value) {
+        if ((i & 7) == 3) dma(i >> 3);
+      }
+    }
+  };
+
+  int m0 = 0, n0 = 0, seg = 0;
+  tile_origin(0, m0, n0, seg);
+  set_image_sources(m0, n0, seg);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) issue(0, 0, c);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) issue(1, 1, c);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // super-step 0 has landed (this wave's pieces), super-step 1 may still fly
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) read_one(r, a_off[0][0], b_off[0][0], fa0, fb0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+#pragma unroll 1
+  for (int it = 0; it < my_tiles; ++it) {
+    int nm0, nn0, nseg;
+    tile_origin(it + 1, nm0, nn0, nseg);
+    // super-step ks from slot `cur` (compile-time after inlining); its second k-half fetches super-step `kn` of the tile the image
+    // sources point at into `cur`
+    auto super_step = [&](int kn, int cur) {
+      const int nxt = cur ^ 1;
+      // ---- first k-half: MFMAs on set 0 | read the second k-half of `cur` into set 1
+      phase(fa0, fb0, fa1, fb1, a_off[cur][1], b_off[cur][1], [](int) {}, std::false_type{});
+      // the images of the next super-step have landed (this wave's pieces; the barrier makes it everybody's), `cur` has been read in full
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // ---- second k-half: MFMAs on set 1 | LDS-DMA of super-step `kn` into `cur` | read the first k-half of `nxt` into set 0
+      phase(fa1, fb1, fa0, fb0, a_off[nxt][0], b_off[nxt][0], [&](int c) { issue(kn, cur, c); }, std::true_type{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+#pragma unroll 1
+    for (int ks = 0; ks < ksuper - 2; ks += 2) {
+      super_step(ks + 2, 0);
+      super_step(ks + 3, 1);
+    }
+    // the tile's last two super-steps fetch super-steps 0 and 1 of the NEXT tile; the last k-half reads its first fragments
+    set_image_sources(nm0, nn0, nseg);
+    super_step(0, 0);
+    super_step(1, 1);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before the accumulators are read
+
+    // ---- epilogue: 16 rows of the wave at a time through its own staging rows (no block barrier: the slots belong to the next
+    // tile's images already). Lane l holds, for tile (mi, nj), register t: row m = 16 mi + l % 16, column n = 16 nj + 4 (l / 16) + t.
+    {
+      bf16_t* out = static_cast<bf16_t*>(seg == 0 ? a.out : seg == 1 ? a.seg_out[0] : a.seg_out[1]);
+      const int out_n = seg_rows(seg);
+      constexpr int COLS = 128;  // output columns per wave
+      constexpr int PITCH = W4_PITCH_PLAIN;
+      const int wave_n0 = n0 + wn * COLS, wave_m0 = m0 + wm * 128;
+      const bool full = wave_n0 + COLS <= out_n && (out_n * 2) % 16 == 0;
+      const int rows_left = a.M - wave_m0;
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        if (mi * 16 < rows_left) {  // wave-uniform: row tiles past the edge are not stored
+#pragma unroll
+          for (int nj = 0; nj < 8; ++nj) {
+            const int nb = nj * 16 + 4 * g4;
+            u32x2 pk;
+            pk.x = pack2<bf16_t>(acc[mi][nj][0], acc[mi][nj][1]);
+            pk.y = pack2<bf16_t>(acc[mi][nj][2], acc[mi][nj][3]);
+            *reinterpret_cast<u32x2*>(stage + r16 * PITCH + nb * 2) = pk;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (full) {
+            constexpr int SEGS = COLS * 2 / 16;  // 16-byte segments per row
+#pragma unroll
+            for (int t = 0; t < 16 * SEGS / 64; ++t) {
+              const int c = lane + 64 * t;
+              const int row = c / SEGS, sg = c % SEGS;
+              const int mm = wave_m0 + mi * 16 + row;
+              const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * PITCH + sg * 16);
+              if (mm < a.M) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * out_n + wave_n0) * 2 + sg * 16));
+            }
+          } else {  // ragged right edge / unaligned rows: element stores (correctness path)
+            for (int c = lane; c < 16 * COLS; c += 64) {
+              const int row = c / COLS, col = c % COLS;
+              const int mm = wave_m0 + mi * 16 + row;
+              if (mm < a.M && wave_n0 + col < out_n) out[(size_t)mm * out_n + wave_n0 + col] = *reinterpret_cast<const bf16_t*>(stage + row * PITCH + col * 2);
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are re-written by the next mi
+        }
+#pragma unroll
+        for (int nj = 0; nj < 8; ++nj) acc[mi][nj] = wl_v4f{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    m0 = nm0; n0 = nn0; seg = nseg;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing requests of the stream must not outlive the block's LDS
+#undef FFQ_W4_MFMA
+#undef FFQ_W4_READ
+}
+
 }  // namespace ffq
 
 using namespace ffq;
@@ -922,10 +1164,31 @@ static void wq_launch(const WLinearArgs& a, hipStream_t s) {
   wq_gemm256_kernel<BKIND, GROUPED, OFFSET, TOut, MLP><<<grid, 512, lds_bytes, s>>>(a, total);
 }
 
+// the one-wave-per-SIMD kernel: plain launches, whole tiles only (no split tail), an even number of super-steps, bf16 output
+static void wq_launch4w(const WLinearArgs& a, hipStream_t s) {
+  const int total = a.tiles_m * a.tiles_n;
+  const int cus = wq_cus();
+  const unsigned grid = (unsigned)(total < cus ? total : cus);
+  const size_t lds_bytes = (size_t)2 * WL_SLOT + (size_t)4 * W4_WAVE_PLAIN;
+  static uint64_t attr_set = 0;
+  ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_gemm4w_kernel), (int)lds_bytes);
+  wq_gemm4w_kernel<<<grid, 256, lds_bytes, s>>>(a, total);
+}
+
+static bool wq_takes_4w(const WLinearArgs& a) {
+#ifdef FFQ_WL_NO_4W  // A/B builds (tools/build_variant.sh)
+  return false;
+#else
+  if (generic_kernels_forced()) return false;  // tests: the 8-wave kernel on the same operands (ffq_force_generic_kernels)
+  return a.split == 1 && a.out_dt == FFQ_BF16 && a.bias == nullptr && (a.K / WL_BK) % 2 == 0 && a.K >= 4 * WL_BK;
+#endif
+}
+
 template <int BKIND, bool MLP = false>
 static void wq_dispatch(const WLinearArgs& a, bool grouped, bool offset, hipStream_t s) {
   if constexpr (BKIND == WL_B_BF16) {
-    if (MLP || a.out_dt == FFQ_BF16) wq_launch<BKIND, false, false, bf16_t, MLP>(a, s);
+    if (!MLP && wq_takes_4w(a)) wq_launch4w(a, s);
+    else if (MLP || a.out_dt == FFQ_BF16) wq_launch<BKIND, false, false, bf16_t, MLP>(a, s);
     else if constexpr (!MLP) wq_launch<BKIND, false, false, float, false>(a, s);
   } else {
 #define FFQ_WL_T(G, O) do { if (MLP || a.out_dt == FFQ_BF16) wq_launch<BKIND, G, O, bf16_t, MLP>(a, s); else if constexpr (!MLP) wq_launch<BKIND, G, O, float, false>(a, s); } while (0)
@@ -984,7 +1247,6 @@ static int wq_linear_impl(const void* x, int x_dt, int count, const void* const*
   if (rc_split != FFQ_OK) return rc_split;
   workspace = workspace ? static_cast<uint8_t*>(workspace) + slab_bytes : nullptr;  // the image(s) (if any) lie behind the slabs
   workspace_bytes = workspace_bytes > slab_bytes ? workspace_bytes - slab_bytes : 0;
-
   const size_t image_bytes = (size_t)N * (size_t)K * 2u;
   if (workspace && workspace_bytes >= image_bytes && aligned16(workspace)) {  // the caller offered the image's scratch (ffq_linear_wq_workspace_bytes: from 4096 tokens on)
     // two-pass form: A2 of the whole weight once (3 or 2.5 B/elem, ~2 % of the GEMM at 16 k tokens), then the GEMM with both
@@ -1008,6 +1270,11 @@ static int wq_linear_impl(const void* x, int x_dt, int count, const void* const*
     if (rc == FFQ_OK) {
       a.w = images[0];
       for (int i = 1; i < count; ++i) a.seg_w[i - 1] = images[i];
+      // Activations that do not fit the 256 MiB Infinity Cache (down_proj at 16 k tokens: 470 MB) must come from HBM ONCE: groups of 8
+      // COLUMN tiles x all row tiles make the XCDs stream the same row panels at the same time (one HBM read, the other XCDs hit the
+      // Infinity Cache) and keep their column panels resident, where row groups give every XCD its own rows and read them once per
+      // batch of column tiles (round-4 A/B on one box, one-wave-per-SIMD kernel: down_proj 1.36 -> 1.42 PFLOP/s; q/o ±0, gate/up -1.3 %)
+      if (count == 1 && (size_t)M * (size_t)K * 2u > ((size_t)200 << 20) && wq_takes_4w(a)) { a.group_cols = 1; a.group_m = 8; }
       wq_dispatch<WL_B_BF16>(a, false, false, s);
       return check_launch("wq_gemm256_kernel (bf16 image)");
     }
