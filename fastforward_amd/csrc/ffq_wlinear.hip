@@ -996,7 +996,11 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
             pk.y = pack2<bf16_t>(acc[mi][nj][2], acc[mi][nj][3]);
             *reinterpret_cast<u32x2*>(stage + r16 * PITCH + nb * 2) = pk;
           }
+#ifdef FFQ_W4_EPILOGUE_WAITS
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+          // (no wait between the writes and the reads below, nor before the next row tile's writes: a wave's LDS instructions
+          // execute in order, and the rows are this wave's own)
           if (full) {
             constexpr int SEGS = COLS * 2 / 16;  // 16-byte segments per row
 #pragma unroll
@@ -1014,7 +1018,9 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
               if (mm < a.M && wave_n0 + col < out_n) out[(size_t)mm * out_n + wave_n0 + col] = *reinterpret_cast<const bf16_t*>(stage + row * PITCH + col * 2);
             }
           }
+#ifdef FFQ_W4_EPILOGUE_WAITS
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are re-written by the next mi
+#endif
         }
 #pragma unroll
         for (int nj = 0; nj < 8; ++nj) acc[mi][nj] = wl_v4f{0.f, 0.f, 0.f, 0.f};

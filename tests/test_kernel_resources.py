@@ -53,3 +53,27 @@ def test_no_scratch_access_inside_a_k_loop(source, needle):
         assert scratch == 0, f"{name}: {scratch} scratch instructions between the first and the last MFMA"
         assert clusters, name
     assert seen >= 10
+
+
+def test_the_one_wave_per_simd_k_loop_is_what_was_written():
+    """wq_gemm4w_kernel's K-loop is inline assembly in source order; what hipcc may add is scalar bookkeeping and address moves.
+    Its inner loop (two super-steps) must hold exactly 256 MFMAs, 64 fragment reads and 32 LDS-DMA pieces, no scratch access, no
+    accumulator traffic between AGPRs and VGPRs, and the kernel must own all 256 AGPRs (the accumulators pinned there)."""
+    import re
+
+    if not pathlib.Path("/opt/rocm/bin/hipcc").exists():
+        pytest.skip("hipcc is missing")
+    text = asm_cluster_check.build_assembly(ROOT / "fastforward_amd" / "csrc/ffq_wlinear.hip")
+    lines = text.split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN3ffq16wq_gemm4w_kernel\w*:", l))
+    end = next(i for i in range(start, len(lines)) if ".end_amdhsa_kernel" in lines[i])
+    header = next(i for i in range(start, end) if "Inner Loop Header" in lines[i])
+    label = next(lines[j].split(":")[0] for j in range(header, start, -1) if re.match(r"^\.LBB\d+_\d+:", lines[j]))
+    back = next(i for i in range(header, end) if re.search(r"s_cbranch_\w+ " + re.escape(label) + r"\b", lines[i]))
+    ops = [l.split()[0] for l in (x.strip() for x in lines[header:back]) if l and not l.startswith((";", ".", "//"))]
+    count = lambda prefix: sum(1 for o in ops if o.startswith(prefix))  # noqa: E731
+    assert count("v_mfma_f32_16x16x32_bf16") == 256 and count("ds_read_b128") == 64 and count("global_load_lds_dwordx4") == 32
+    assert count("scratch_") == 0 and count("v_accvgpr") == 0 and count("s_barrier") == 2
+    assert count("v_") - count("v_mfma") <= 64  # address moves of the DMA pieces at most
+    rows = [k for k in _kernels("wq_gemm4w_kernel")]
+    assert len(rows) == 1 and rows[0]["agpr_count"] == 256
