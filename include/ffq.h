@@ -238,7 +238,8 @@ int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, const
  * operand of the bf16 MFMA is bit for bit the reference's dequantized weight, accumulation is fp32; only the summation order
  * differs from F.linear. One launch converts the codes once per 256-row tile on their way into LDS; with enough `workspace`
  * behind the slabs (below) and from 4096 tokens on the weight is dequantized once per CALL by A2 into it and the GEMM streams
- * the bf16 image — same operands, same tile walk: bit-identical, faster at large M.
+ * the bf16 image — same operands, same k order: bit-identical, faster at large M (whole-tile launches of that form with a bf16
+ * output, no bias and K % 128 == 0 run a one-wave-per-SIMD kernel, 4 waves x 128 x 128 accumulators; also bit-identical).
  * Split-K (ABI 7): the kernel is one persistent block per CU on 256 x 256 output tiles; the tiles of the LAST, partly filled
  * round of that walk (all tiles when there are fewer than CUs: 2048 tokens x a 4096-wide projection are 128) have their K range
  * cut into ffq_linear_wq_split() slices, one work unit each on its own CU; the units of a tile exchange fp32 partial sums
