@@ -23,6 +23,7 @@ typedef __attribute__((address_space(3))) void lds_t;
 typedef __attribute__((address_space(1))) const void gbl_t;
 
 __device__ unsigned long long g_clk[4];
+__device__ unsigned long long g_xcd[8][4];  // persistent form, blocks 0..7 (one per XCD): start / end reference ticks, shader cycles
 __device__ unsigned long long g_tile[3][64][3];  // blocks 0 / 100 / 255: per tile K-loop cycles, epilogue cycles, reference ticks of the K-loop  // block 0: shader-clock cycles and 100 MHz reference ticks over its lifetime
 constexpr int IMAGE = 256 * 128;  // one operand image of a super-step: 256 rows x 64 bf16
 constexpr int SLOT = 2 * IMAGE;
@@ -528,6 +529,11 @@ __global__ __launch_bounds__(256, 1) void gemm4w_persist_kernel(const uint8_t* _
     m0 = m1; n0 = n1; ab = ab1; bb = bb1;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (blockIdx.x < 8 && threadIdx.x == 0) {
+    g_xcd[blockIdx.x][0] = ref0;
+    g_xcd[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+    g_xcd[blockIdx.x][2] = __builtin_amdgcn_s_memtime() - clk0;
+  }
 }
 
 static uint16_t to_bf16(float f) {
@@ -622,6 +628,13 @@ int main(int argc, char** argv) {
   printf("block 0 K-loop: %llu shader cycles in %.2f us -> %.0f MHz; matrix pipe busy %.1f %% of them\n", clk[0], clk[1] / 100.0, clk[0] / (clk[1] / 100.0),
          100.0 * mfma_cycles / (double)clk[0]);
   if (persist) {
+    unsigned long long xc_[8][4];
+    CHECK(hipMemcpyFromSymbol(xc_, HIP_SYMBOL(g_xcd), sizeof(xc_)));
+    unsigned long long t0 = ~0ull;
+    for (int i = 0; i < 8; ++i) t0 = xc_[i][0] < t0 ? xc_[i][0] : t0;
+    printf("per XCD (block i on XCD i): start us, end us, MHz:");
+    for (int i = 0; i < 8; ++i) printf("  %d: %.1f %.1f %.0f", i, (xc_[i][0] - t0) / 100.0, (xc_[i][1] - t0) / 100.0, xc_[i][2] / ((xc_[i][1] - xc_[i][0]) / 100.0));
+    printf("\n");
     static unsigned long long tl[3][64][3];
     CHECK(hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_tile), sizeof(tl)));
     const int nt = (tiles_m * tiles_n + cus - 1) / cus < 64 ? (tiles_m * tiles_n + cus - 1) / cus : 64;

@@ -37,7 +37,7 @@ if [ $WHAT = all ] || [ $WHAT = traces ]; then
       rm -rf $OUT/trace_$cfg
       timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_$cfg -o t -- python3 tools/cfg_trace.py $cfg $b > $OUT/trace_${cfg}_B$b.log 2>&1
       echo "$cfg B=$b trace rc=$?"
-      python3 tools/rocprof_summary.py $OUT/trace_$cfg/t_results.db $OUT/r04_${cfg}_B${b}_forward_kernel_trace.md "r04 — rocprofv3 --kernel-trace --stats -- python3 tools/cfg_trace.py $cfg $b (3 forwards of B=$b, S=2048 through llama.FusedProducersForward; the weight quantizers / the one-off packing and a 256-token calibration forward included). Vendor GEMMs (Cijk_*) in this trace: lm_head only (float in the recipe, quick-start :145) — one launch per forward, 3 in all; every decoder linear is wq_gemm256_kernel"
+      python3 tools/rocprof_summary.py $OUT/trace_$cfg/t_results.db $OUT/r04_${cfg}_B${b}_forward_kernel_trace.md "r04 — rocprofv3 --kernel-trace --stats -- python3 tools/cfg_trace.py $cfg $b (3 forwards of B=$b, S=2048 through llama.FusedProducersForward; the weight quantizers / the one-off packing and a 256-token calibration forward included). Vendor GEMMs (Cijk_*) in this trace: lm_head only (float in the recipe, quick-start :145) — one launch per forward, 3 in all; every decoder linear is wq_gemm256_kernel or wq_gemm4w_kernel (the one-wave-per-SIMD form of its bf16-image launches)"
       rm -rf $OUT/trace_$cfg
     done
   done
