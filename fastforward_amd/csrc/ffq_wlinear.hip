@@ -849,31 +849,35 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
   };
 
   // ---- LDS-DMA sources: piece c (0..7) of wave w covers image rows (8 w + c) * 8 + lane / 8; the lane's 16-byte slot is
-  // swizzled on the SOURCE address (slot ^ (row / 2) % 8): the linear LDS write lands in the swizzled image
+  // swizzled on the SOURCE address (slot ^ (row / 2) % 8): the linear LDS write lands in the swizzled image. Buffer addressing
+  // (`buffer_load_dwordx4 ... offen lds`): one descriptor per operand and tile (base = the tile's first row, extent = what is
+  // left of the matrix, so rows past the edge read as zeros and are never stored), ONE per-lane offset for the even and one
+  // for the odd pieces (the swizzle term (row / 2) % 8 contains bit 0 of the piece number), the piece and the super-step in the
+  // scalar offset — no vector arithmetic in the K-loop, no per-piece registers (the vendor kernel's addressing).
   const uint32_t row_bytes = (uint32_t)a.K * 2u;
   const int d_row = lane >> 3;
-  uint32_t a_voff[8], b_voff[8];
-  const uint8_t* a_base = a.x;
-  const uint8_t* b_base = a.w;
-  auto set_image_sources = [&](int tm0, int tn0, int seg) {
-    a_base = row_base(a.x, tm0, row_bytes);
-    b_base = row_base(seg_codes(seg), tn0, row_bytes);
-    const int rows = seg_rows(seg);
+  uint32_t d_voff[2];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int row = (wave * 8 + c) * 8 + d_row;
-      const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
-      const int ra = tm0 + row < a.M ? row : a.M - 1 - tm0;  // rows past the edge re-read the last row and are never stored
-      a_voff[c] = (uint32_t)ra * row_bytes + d_slot * 16;
-      const int rb = tn0 + row < rows ? row : rows - 1 - tn0;
-      b_voff[c] = (uint32_t)rb * row_bytes + d_slot * 16;
-    }
+  for (int odd = 0; odd < 2; ++odd) {
+    const int row = (wave * 8 + odd) * 8 + d_row;  // piece `odd` of this wave; pieces c and c + 2 differ by 16 rows: same swizzle
+    const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
+    d_voff[odd] = (uint32_t)(wave * 64 + d_row) * row_bytes + d_slot * 16;
+  }
+  __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t b_rsrc = a_rsrc;
+  auto extent = [&](int rows_left) {  // bytes from the tile's first row to the end of the matrix, as a descriptor extent
+    const uint64_t bytes = (uint64_t)(uint32_t)(rows_left > 0 ? rows_left : 0) * (uint64_t)row_bytes;
+    return (int)(bytes < 0xFFFFFFFFull ? (uint32_t)bytes : 0xFFFFFFFFu);
   };
-  auto issue = [&](int ks, int slot, int c) {  // piece c of both images of super-step ks (of the tile the sources point at)
+  auto set_image_sources = [&](int tm0, int tn0, int seg) {
+    a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row_base(a.x, tm0, row_bytes), 0, extent(a.M - tm0), 0x00020000);
+    b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row_base(seg_codes(seg), tn0, row_bytes), 0, extent(seg_rows(seg) - tn0), 0x00020000);
+  };
+  auto issue = [&](int ks, int slot, int c) {  // piece c of both images of super-step ks (of the tile the descriptors point at)
     uint8_t* base = lds + slot * WL_SLOT;
-    asm volatile("" : "+v"(a_voff[c]), "+v"(b_voff[c]));  // keeps the saddr form in every unrolled body (ffq_linear.hip)
-    __builtin_amdgcn_global_load_lds((wl_gbl_t*)((a_base + ks * 128) + a_voff[c]), (wl_lds_t*)(base + (wave * 8 + c) * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((wl_gbl_t*)((b_base + ks * 128) + b_voff[c]), (wl_lds_t*)(base + WL_IMAGE + (wave * 8 + c) * 1024), 16, 0, 0);
+    const uint32_t soff = (uint32_t)c * 8u * row_bytes + (uint32_t)ks * 128u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (wl_lds_t*)(base + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (wl_lds_t*)(base + WL_IMAGE + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);
   };
 
   // ---- fragment addresses: lane (r16, g4) reads 8 bf16 of row r16 of a 16-row tile, logical slot kq * 4 + g4; one register per
