@@ -796,7 +796,8 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
 // two super-steps and nothing else. It runs ACROSS tile boundaries: the last two super-steps of a tile fetch the first two of
 // the next, its last k-half reads the next tile's first fragments, and the epilogue in between goes through wave-private rows
 // of LDS behind the slots while those images land. Same MFMA instruction, same k order as wq_gemm256_kernel: bit-identical results.
-// Taken for plain launches without a split tail, without a bias and with an even number of super-steps (wq_dispatch); bf16 output.
+// Taken for plain launches of whole tiles (M and every weight matrix a multiple of 256 rows) without a split tail, without a bias
+// and with an even number of super-steps (wq_dispatch); bf16 output.
 // (A gate+up+SiLU*up mode of this kernel was built and is bit-equal too, but measured 3-5 % SLOWER than the 8-wave kernel's —
 // 2.83 against 2.75 ms at 16 k tokens — and was removed; the plain form is +2 % on q/o and gate/up, +4 % on down_proj.)
 constexpr int W4_PITCH_PLAIN = 128 * 2 + 16;  // a staged row of a wave: 128 bf16 + pad
@@ -851,9 +852,10 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
   // ---- LDS-DMA sources: piece c (0..7) of wave w covers image rows (8 w + c) * 8 + lane / 8; the lane's 16-byte slot is
   // swizzled on the SOURCE address (slot ^ (row / 2) % 8): the linear LDS write lands in the swizzled image. Buffer addressing
   // (`buffer_load_dwordx4 ... offen lds`): one descriptor per operand and tile (base = the tile's first row, extent = what is
-  // left of the matrix, so rows past the edge read as zeros and are never stored), ONE per-lane offset for the even and one
-  // for the odd pieces (the swizzle term (row / 2) % 8 contains bit 0 of the piece number), the piece and the super-step in the
-  // scalar offset — no vector arithmetic in the K-loop, no per-piece registers (the vendor kernel's addressing).
+  // left of the matrix), ONE per-lane offset for the even and one for the odd pieces (the swizzle term (row / 2) % 8 contains
+  // bit 0 of the piece number), the piece and the super-step in the scalar offset — no vector arithmetic in the K-loop, no
+  // per-piece registers (the vendor kernel's addressing). The scalar offset is outside the hardware's range check, so the
+  // launcher admits whole tiles only (wq_takes_4w): every row a piece names exists.
   const uint32_t row_bytes = (uint32_t)a.K * 2u;
   const int d_row = lane >> 3;
   uint32_t d_voff[2];
@@ -981,53 +983,34 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
 
     // ---- epilogue: 16 rows of the wave at a time through its own staging rows (no block barrier: the slots belong to the next
     // tile's images already). Lane l holds, for tile (mi, nj), register t: row m = 16 mi + l % 16, column n = 16 nj + 4 (l / 16) + t.
+    // Whole tiles (wq_takes_4w): every row and column exists, rows are 16-byte aligned.
     {
       bf16_t* out = static_cast<bf16_t*>(seg == 0 ? a.out : seg == 1 ? a.seg_out[0] : a.seg_out[1]);
       const int out_n = seg_rows(seg);
-      constexpr int COLS = 128;  // output columns per wave
       constexpr int PITCH = W4_PITCH_PLAIN;
-      const int wave_n0 = n0 + wn * COLS, wave_m0 = m0 + wm * 128;
-      const bool full = wave_n0 + COLS <= out_n && (out_n * 2) % 16 == 0;
-      const int rows_left = a.M - wave_m0;
+      const int wave_n0 = n0 + wn * 128, wave_m0 = m0 + wm * 128;
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) {
-        if (mi * 16 < rows_left) {  // wave-uniform: row tiles past the edge are not stored
 #pragma unroll
-          for (int nj = 0; nj < 8; ++nj) {
-            const int nb = nj * 16 + 4 * g4;
-            u32x2 pk;
-            pk.x = pack2<bf16_t>(acc[mi][nj][0], acc[mi][nj][1]);
-            pk.y = pack2<bf16_t>(acc[mi][nj][2], acc[mi][nj][3]);
-            *reinterpret_cast<u32x2*>(stage + r16 * PITCH + nb * 2) = pk;
-          }
-#ifdef FFQ_W4_EPILOGUE_WAITS
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-          // (no wait between the writes and the reads below, nor before the next row tile's writes: a wave's LDS instructions
-          // execute in order, and the rows are this wave's own)
-          if (full) {
-            constexpr int SEGS = COLS * 2 / 16;  // 16-byte segments per row
-#pragma unroll
-            for (int t = 0; t < 16 * SEGS / 64; ++t) {
-              const int c = lane + 64 * t;
-              const int row = c / SEGS, sg = c % SEGS;
-              const int mm = wave_m0 + mi * 16 + row;
-              const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * PITCH + sg * 16);
-              if (mm < a.M) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * out_n + wave_n0) * 2 + sg * 16));
-            }
-          } else {  // ragged right edge / unaligned rows: element stores (correctness path)
-            for (int c = lane; c < 16 * COLS; c += 64) {
-              const int row = c / COLS, col = c % COLS;
-              const int mm = wave_m0 + mi * 16 + row;
-              if (mm < a.M && wave_n0 + col < out_n) out[(size_t)mm * out_n + wave_n0 + col] = *reinterpret_cast<const bf16_t*>(stage + row * PITCH + col * 2);
-            }
-          }
-#ifdef FFQ_W4_EPILOGUE_WAITS
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are re-written by the next mi
-#endif
+        for (int nj = 0; nj < 8; ++nj) {
+          const int nb = nj * 16 + 4 * g4;
+          u32x2 pk;
+          pk.x = pack2<bf16_t>(acc[mi][nj][0], acc[mi][nj][1]);
+          pk.y = pack2<bf16_t>(acc[mi][nj][2], acc[mi][nj][3]);
+          *reinterpret_cast<u32x2*>(stage + r16 * PITCH + nb * 2) = pk;
+          acc[mi][nj] = wl_v4f{0.f, 0.f, 0.f, 0.f};
         }
+        // (no wait between the writes and the reads below, nor before the next row tile's writes: a wave's LDS instructions
+        // execute in order, and the rows are this wave's own)
 #pragma unroll
-        for (int nj = 0; nj < 8; ++nj) acc[mi][nj] = wl_v4f{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 4; ++t) {
+          const int c = lane + 64 * t;
+          const int row = c >> 4, sg = c & 15;  // 16 segments of 16 bytes per 128-column row
+          const int mm = wave_m0 + mi * 16 + row;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * PITCH + sg * 16);
+          // non-temporal, as in ffq_linear.hip: the output must not push the operand panels out of L2
+          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * out_n + wave_n0) * 2 + sg * 16));
+        }
       }
     }
     m0 = nm0; n0 = nn0; seg = nseg;
@@ -1190,6 +1173,12 @@ static bool wq_takes_4w(const WLinearArgs& a) {
   return false;
 #else
   if (generic_kernels_forced()) return false;  // tests: the 8-wave kernel on the same operands (ffq_force_generic_kernels)
+  // whole tiles only: the piece's row offset travels in the buffer instruction's SCALAR offset, which the hardware's range check
+  // does not see (only the per-lane offset is compared with the descriptor's extent) — rows past a ragged edge would be read
+  // from beyond the tensor. Ragged shapes take the 8-wave kernel, which clamps its source rows.
+  if (a.M % WL_BM != 0) return false;
+  for (int i = 0; i < 3; ++i)
+    if (a.seg_n[i] % WL_BN != 0) return false;
   return a.split == 1 && a.out_dt == FFQ_BF16 && a.bias == nullptr && (a.K / WL_BK) % 2 == 0 && a.K >= 4 * WL_BK;
 #endif
 }

@@ -177,11 +177,11 @@ def test_repeated_launches_are_bit_identical():
 
 def test_one_wave_per_simd_form_equals_the_eight_wave_kernel():
     """The bf16-image form of the weight-only GEMM has two kernels: wq_gemm4w_kernel (one wave per SIMD, 128 x 128 accumulators per
-    wave in AGPRs; taken by plain launches without a split tail, with an even number of 64-deep super-steps, bf16 output) and the
-    8-wave wq_gemm256_kernel. Same MFMA instruction, same k order: bit-equal — full tiles, ragged rows, ragged / odd column counts
-    (element-store path), three weight matrices in one launch, an odd super-step count and the gate+up+SiLU*up mode (both arms
-    take the 8-wave kernel), many tiles per block (the K-loop running across tile boundaries), and down_proj at 16 k tokens,
-    whose 470 MB of activations switch the walk to column groups."""
+    wave in AGPRs; taken by plain launches of whole 256 x 256 tiles without a split tail, with an even number of 64-deep super-steps,
+    bf16 output) and the 8-wave wq_gemm256_kernel. Same MFMA instruction, same k order: bit-equal — one to many tiles per block
+    (the K-loop running across tile boundaries), three weight matrices in one launch, down_proj at 16 k tokens (470 MB of
+    activations switch the walk to column groups); ragged shapes, an odd super-step count and the gate+up+SiLU*up mode keep both
+    arms on the 8-wave kernel (the dispatch must not send them to a kernel that assumes whole tiles)."""
     from fastforward_amd import _native
 
     lib = _native.library()
@@ -202,7 +202,7 @@ def test_one_wave_per_simd_form_equals_the_eight_wave_kernel():
             lib.ffq_force_generic_kernels(previous)
         return got, want
 
-    for m, n, k in ((4096, 4096, 4096), (512, 768, 256), (300, 520, 384), (1000, 1001, 640), (256, 256, 320), (8192, 2048, 512), (16384, 1024, 256), (16384, 4096, 14336)):
+    for m, n, k in ((4096, 4096, 4096), (512, 768, 256), (256, 256, 384), (2048, 1024, 640), (300, 520, 384), (1000, 1001, 640), (256, 256, 320), (8192, 2048, 512), (16384, 1024, 256), (16384, 4096, 14336)):
         x, w, s = operands(m, n, k)
         got, want = both(lambda: ops.linear_wq(x, w, s, None, two_pass=True, split=1))
         assert torch.equal(got, want), (m, n, k)
@@ -210,12 +210,13 @@ def test_one_wave_per_simd_form_equals_the_eight_wave_kernel():
         exact = x[rows].double() @ (w.double() * s.double()[:, None]).to(torch.bfloat16).double().t()
         torch.testing.assert_close(got[rows].double(), exact, rtol=2.0**-7, atol=1e-5 * float(exact.abs().max()) * k**0.5)
         del x, w, s, got, want, exact
-    x, w, s = operands(700, 512, 512)
-    ws = [w, torch.randint(-128, 128, (256, 512), device=DEV, dtype=torch.int8, generator=g), torch.randint(-128, 128, (200, 512), device=DEV, dtype=torch.int8, generator=g)]
-    ss = [s, torch.rand(256, device=DEV, generator=g) * 1e-3 + 1e-4, torch.rand(200, device=DEV, generator=g) * 1e-3 + 1e-4]
-    got, want = both(lambda: ops.linear_wq_multi(x, ws, ss, [None] * 3, two_pass=True, split=1))
-    assert all(torch.equal(a, b) for a, b in zip(got, want))
-    assert all(torch.equal(a, ops.linear_wq(x, wi, si, None, two_pass=True, split=1)) for a, wi, si in zip(got, ws, ss))
+    for m, last in ((768, 512), (700, 200)):  # whole tiles: the 4-wave kernel; ragged rows and a ragged last matrix: the 8-wave one
+        x, w, s = operands(m, 512, 512)
+        ws = [w, torch.randint(-128, 128, (256, 512), device=DEV, dtype=torch.int8, generator=g), torch.randint(-128, 128, (last, 512), device=DEV, dtype=torch.int8, generator=g)]
+        ss = [s, torch.rand(256, device=DEV, generator=g) * 1e-3 + 1e-4, torch.rand(last, device=DEV, generator=g) * 1e-3 + 1e-4]
+        got, want = both(lambda: ops.linear_wq_multi(x, ws, ss, [None] * 3, two_pass=True, split=1))
+        assert all(torch.equal(a, b) for a, b in zip(got, want))
+        assert all(torch.equal(a, ops.linear_wq(x, wi, si, None, two_pass=True, split=1)) for a, wi, si in zip(got, ws, ss))
     for m, n, k in ((700, 384, 512), (4096, 1024, 1024)):
         x, w, s = operands(m, n, k)
         u = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
