@@ -637,11 +637,15 @@ def main() -> None:
         result["host_us_per_op"] = host_us_per_op(device)
         if world == 1:
             result["cpu_baseline"] = cpu_baseline(config)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes out last: RCCL prints a version banner through C stdio, which would otherwise be flushed behind it
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
