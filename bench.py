@@ -294,7 +294,7 @@ def hbm_kernels(device: torch.device) -> list[dict]:
     qs = [ops.quantize_by_tile(w, scale, tile, 8, torch.int8) for w in ws]
     rows = []
 
-    def add(name, kernel, needles, bytes_per_elem, fn):
+    def add(name, kernel, needles, bytes_per_elem, fn, n=n):
         ms = event_time_ms(fn, iters=10, reps=12)
         gbs = n * bytes_per_elem / ms / 1e6
         traffic, _ = pmc_traffic(*needles, stems=("_pmc_hbm_",))  # the launches of tools/hbm_probe.py: this shape
@@ -309,6 +309,11 @@ def hbm_kernels(device: torch.device) -> list[dict]:
     add("dequantize per-channel int8->bf16", "dequantize_stream_kernel<i8,bf16,ROWS>", ("dequantize_stream_kernel<signed char, ffq::bf16_t, 1,", "false"), 3,
         lambda r: ops.dequantize_by_tile(qs[r % 6], scale, tile, None, torch.bfloat16))
     add("running min/max per-channel bf16", "minmax_rows_kernel<bf16>", ("minmax_rows_kernel<ffq::bf16_t",), 2, lambda r: ops.minmax_by_tile(ws[r % 6], tile))
+    # A3, per-token dynamic quantization of an activation [8, 2048, 4096] (asymmetric: min, max, A5, A1 in ONE launch, 2 R + 1 W)
+    acts = [torch.randn(8, 2048, 4096, device=device, dtype=torch.bfloat16) for _ in range(5)]  # 5 x 134 MB > Infinity Cache
+    add("dynamic quantize per-token bf16->int8 [8,2048,4096] (A4 + A5 + A1, one launch)", "quantize_dynamic_rows_kernel<bf16,i8,16,256,1>", ("quantize_dynamic_rows_kernel<ffq::bf16_t, signed char",), 3,
+        lambda r: ops.quantize_dynamic_by_tile(acts[r % 5], (1, 1, 4096), 8, False, True, torch.int8), n=8 * 2048 * 4096)
+    del acts
     # producer-fused A1 on the same number of elements ([14336, 4096] read as 14336 rows of 4096)
     s1, o1 = torch.tensor([0.03], device=device), torch.tensor([3.0], device=device)
     gamma = torch.ones(shape[1], device=device, dtype=torch.bfloat16)

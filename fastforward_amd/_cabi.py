@@ -19,7 +19,7 @@ from fastforward_amd.exceptions import QuantizationError
 
 FFQ_MAX_DIMS = 8
 FFQ_MAX_FANOUT = 3
-FFQ_ABI_VERSION = 7
+FFQ_ABI_VERSION = 8
 
 
 class Status(enum.IntEnum):
@@ -158,9 +158,10 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_minmax_workspace_bytes": (_sz, [_tp, _i]),
     "ffq_minmax_by_tile": (_i, [_vp, _i, _tp, _vp, _vp, _i, _vp, _vp, _sz, _vp, _vp]),
     "ffq_running_minmax_step": (_i, [_vp, _i, _tp, _vp, _vp, _vp, _d, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp]),
-    "ffq_parameters_for_range": (_i, [_vp, _vp, _i, _i64, _d, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "ffq_parameters_for_range_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "ffq_parameters_for_range": (_i, [_vp, _vp, _i, _i64, _d, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "ffq_quantize_dynamic_workspace_bytes": (_sz, [_tp, _i]),
-    "ffq_quantize_dynamic_by_tile": (_i, [_vp, _i, _tp, _d, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ffq_quantize_dynamic_by_tile": (_i, [_vp, _i, _tp, _d, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ffq_pack_int4": (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
     "ffq_unpack_int4": (_i, [_vp, _i64, _i64, _vp, _i, _vp]),
     "ffq_linear_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64]),

@@ -60,6 +60,62 @@ __device__ __forceinline__ void quantize_chunk(const float (&x)[E], float s, flo
   quantize_chunk_with<DIVMODE, E>(d, x, o, r);
 }
 
+// A1 for a chunk whose quotients are known to be ordinary numbers — the form the VALU-bound kernels take on their common path.
+// quantize_chunk + finalize_chunk cost ~17 VALU ops per element into a byte container (unpack, 5 for the division, 3-4 for the
+// window test, subtract, round, convert, clamp, pack): 58.7 M elements x 17 ops / (1024 SIMDs x 16 lanes) is 27 us of issue at
+// 2.2 GHz — these kernels are as much VALU-bound as HBM-bound. Here the same values take ~6:
+//   * the Markstein iteration (see Divider) on PAIRS of elements: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 are full-rate on
+//     two fp32 lanes, and each lane's result is the same IEEE operation as the scalar instruction;
+//   * no window test per element: the CALLER guarantees 2^-40 < |s| < 2^40 and |x r| < 2^39 for every element of the chunk
+//     (no Inf, no NaN, no overflow: the iteration's residuals are exact or — below 2^-40 — irrelevant to an INTEGER container:
+//     whatever the last bits of a quotient of that size, it rounds to 0 after the integer offset is subtracted; the sign of a
+//     zero, which the float containers keep, is why those stay on quantize_chunk);
+//   * clamp first (v_med3_f32; clamp and round-half-even commute for integer bounds), then round AND convert in one packed add of
+//     1.5 * 2^23: the sum's mantissa holds the two's-complement integer in its low bits, rounded half-even by the adder itself
+//     (|v| <= 2^15 after the clamp, far inside the trick's 2^22 range);
+//   * the low bytes of four such words are one int8 quadruple: three v_perm_b32.
+// Bit-identical to quantize_chunk + finalize_chunk on every chunk that meets the precondition
+// (tests/test_parity_gpu.py::test_fast_chunk_arithmetic_equals_the_reference_chain).
+typedef float fq_f32x2 __attribute__((ext_vector_type(2)));
+// CHECK: `*check` receives the sum of the E values x / s - o; it is NaN whenever the precondition on x failed (an Inf or NaN
+// element, or x r overflowing: each of these turns the iteration's residual into Inf - Inf), so a caller that knows nothing
+// about its elements tests `check == check` once per chunk instead of three VALU ops per element.
+template <int E, bool CHECK>
+__device__ __forceinline__ void quantize_chunk_bytes_fast(const float (&x)[E], float s, float r, float o, float lo, float hi,
+                                                          uint32_t (&words)[E / 4], float* check = nullptr) {
+  static_assert(E % 4 == 0, "whole dwords of codes");
+  const fq_f32x2 S = {s, s}, R = {r, r}, O = {o, o}, M = {12582912.0f, 12582912.0f};
+  fq_f32x2 acc = {0.0f, 0.0f};
+  uint32_t b[E];
+#pragma unroll
+  for (int i = 0; i < E; i += 2) {
+    const fq_f32x2 X = {x[i], x[i + 1]};
+    const fq_f32x2 q0 = X * R;
+    const fq_f32x2 q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, S, X), R, q0);
+    const fq_f32x2 q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(-q1, S, X), R, q1);
+    const fq_f32x2 d = q2 - O;
+    if constexpr (CHECK) acc = acc + d;
+    const fq_f32x2 c = {__builtin_amdgcn_fmed3f(d.x, lo, hi), __builtin_amdgcn_fmed3f(d.y, lo, hi)};
+    const fq_f32x2 e = c + M;
+    // (through scalar temporaries: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this hipcc)
+    const float e0 = e.x, e1 = e.y;
+    b[i] = __builtin_bit_cast(uint32_t, e0);
+    b[i + 1] = __builtin_bit_cast(uint32_t, e1);
+  }
+#pragma unroll
+  for (int i = 0; i < E; i += 4) {
+    const uint32_t t01 = __builtin_amdgcn_perm(b[i + 1], b[i], 0x0c0c0400u);      // [b0.0, b1.0, 0, 0]
+    const uint32_t t23 = __builtin_amdgcn_perm(b[i + 3], b[i + 2], 0x0c0c0400u);  // [b2.0, b3.0, 0, 0]
+    words[i >> 2] = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+  }
+  if constexpr (CHECK) *check = acc.x + acc.y;
+}
+// the caller's precondition for one scale and a bound on |x| over the elements it covers (an Inf / NaN bound fails it)
+__device__ __forceinline__ bool fast_chunk_ok(float s, float r, float abs_x_max) {
+  const float as = __builtin_fabsf(s);
+  return as > 0x1p-40f && as < 0x1p40f && abs_x_max * __builtin_fabsf(r) < 0x1p39f;
+}
+
 // clamp + cast of E rounded values. Float containers: v_med3_f32 with NaN passed through
 // (torch.clamp propagates NaN). Integer containers: convert first (v_cvt_i32_f32 saturates and
 // maps NaN to 0, the value the reference's CPU cast yields for int8/int16), then v_med3_i32.
@@ -83,6 +139,22 @@ __device__ __forceinline__ void finalize_chunk(const float (&r)[E], float lo, fl
     for (int i = 0; i < E; ++i) c[i] = r[i] != r[i] ? r[i] : __builtin_amdgcn_fmed3f(r[i], lo, hi);
     y.pack(c);
   }
+}
+
+// A1 of one chunk into a BYTE container, parameters (s, o) with o already rounded: the packed form when its self-check passes
+// (always, on ordinary data), the reference chain otherwise — same codes either way.
+template <int E>
+__device__ __forceinline__ void quantize_chunk_to_bytes(const float (&x)[E], float s, float o, float lo, float hi,
+                                                        Chunk<int8_t, E>& y) {
+  const Divider<1> d(s);
+  if (d.safe) {
+    float check;
+    quantize_chunk_bytes_fast<E, true>(x, s, d.r, o, lo, hi, y.w, &check);
+    if (check == check) return;
+  }
+  float r[E];
+  quantize_chunk_with<1, E>(d, x, o, r);
+  finalize_chunk<int8_t, E>(r, lo, hi, y);
 }
 
 }  // namespace ffq

@@ -277,12 +277,11 @@ __global__ __launch_bounds__(kWaves * 64) void attention_fwd_kernel(AttnArgs a) 
     const size_t at = (((size_t)b * a.S + (size_t)(qw0 + (int32_t)row)) * a.H + head) * kD + seg * 16;
     if (a.ctx) z.store(reinterpret_cast<bf16_t*>(a.ctx) + at);
     if (a.codes) {
-      float x[16], r[16];
+      float x[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) x[i] = z.get(i);
-      quantize_chunk<1, 16>(x, sc, of, r);
       Chunk<int8_t, 16> y;
-      finalize_chunk<int8_t, 16>(r, a.lo, a.hi, y);
+      quantize_chunk_to_bytes<16>(x, sc, of, a.lo, a.hi, y);
       y.store(a.codes + at);
     }
   }

@@ -14,6 +14,7 @@
 //
 // Reduction shape: 16 B per lane loads, min/max in VGPRs, NaN tracked as a wave-level predicate,
 // wavefront (64-lane) xor-shuffle butterflies, one LDS hop across the 4 waves of a block.
+#include "ffq_affine.h"
 #include "ffq_common.h"
 #include "ffq_vec.h"
 
@@ -118,6 +119,51 @@ __device__ __forceinline__ void wave_reduce(MinMax& m) {
     m.mx = __builtin_fmaxf(m.mx, omx);
     m.nan |= onan != 0;
   }
+}
+
+// The same butterfly on the VALU where the data-parallel primitives reach (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror:
+// every lane of a 16-lane row ends up with the row's result in 4 steps of ~2 cycles each) and lane reads for the rest: a
+// __shfl_xor is a ds_bpermute_b32, i.e. an LDS-pipe round trip per step and value (18 of them for a wave's min, max and NaN
+// flag) — the latency chain of a block that lives for one row. Every lane of the group holds the result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ void dpp_step(float& mn, float& mx, int& nan) {
+  mn = __builtin_fminf(mn, dpp_f<CTRL>(mn));
+  mx = __builtin_fmaxf(mx, dpp_f<CTRL>(mx));
+  nan |= dpp_i<CTRL>(nan);
+}
+template <int WIDTH>
+__device__ __forceinline__ void wave_allreduce(MinMax& m) {
+  float mn = m.mn, mx = m.mx;
+  int nan = m.nan ? 1 : 0;
+  if constexpr (WIDTH >= 2) dpp_step<0xB1>(mn, mx, nan);    // quad_perm [1,0,3,2]: lane ^ 1
+  if constexpr (WIDTH >= 4) dpp_step<0x4E>(mn, mx, nan);    // quad_perm [2,3,0,1]: lane ^ 2
+  if constexpr (WIDTH >= 8) dpp_step<0x141>(mn, mx, nan);   // row_half_mirror: lane -> 7 - lane within 8
+  if constexpr (WIDTH >= 16) dpp_step<0x140>(mn, mx, nan);  // row_mirror: lane -> 15 - lane within 16
+  if constexpr (WIDTH == 32) {
+    mn = __builtin_fminf(mn, __shfl_xor(mn, 16, 64));
+    mx = __builtin_fmaxf(mx, __shfl_xor(mx, 16, 64));
+    nan |= __shfl_xor(nan, 16, 64);
+  }
+  if constexpr (WIDTH == 64) {  // the four rows' results through scalar registers
+    const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mn), 0));
+    const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mn), 16));
+    const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mn), 32));
+    const float a3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mn), 48));
+    const float b0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 0));
+    const float b1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 16));
+    const float b2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 32));
+    const float b3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 48));
+    mn = __builtin_fminf(__builtin_fminf(a0, a1), __builtin_fminf(a2, a3));
+    mx = __builtin_fmaxf(__builtin_fmaxf(b0, b1), __builtin_fmaxf(b2, b3));
+    nan = __builtin_amdgcn_readlane(nan, 0) | __builtin_amdgcn_readlane(nan, 16) | __builtin_amdgcn_readlane(nan, 32) | __builtin_amdgcn_readlane(nan, 48);
+  }
+  m.mn = mn; m.mx = mx; m.nan = nan != 0;
 }
 
 // all 256 lanes of the block -> result valid in thread 0
@@ -672,6 +718,62 @@ __global__ __launch_bounds__(kRangeBlock) void parameters_for_range_kernel(const
   }
 }
 
+// ---- A5 as a grid (round 5) ---------------------------------------------------------------------------------------------------
+// One 1024-lane block walking 458,752 tiles (gate_proj at group 128) through the runtime-typed `double` accessors took 368 us;
+// above kRangeGridTiles tiles the work is spread over the chip with typed loads. The only thing that ties the tiles together is
+// the GLOBAL one-sided test (range.py:100), needed when symmetric and allow_one_sided: a first launch leaves one minimum per
+// block in `partial` (NaN when the block saw one: NaN >= 0 is False), every block of the second launch reduces those <= 1024
+// numbers itself (4 KiB from L2) and then writes its tiles — two short launches, no atomics, no tickets, nothing to zero.
+// Without the global test it is one launch.
+constexpr int64_t kRangeGridTiles = 8192;
+constexpr uint32_t kRangePartials = 1024;
+
+template <typename R>
+__global__ __launch_bounds__(kBlock) void range_min_partial_kernel(const R* __restrict__ min_range, int64_t ntiles,
+                                                                   float* __restrict__ partial) {
+  __shared__ float lds[12];
+  MinMax m;
+  m.init();
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < ntiles; t += stride) m.add(to_f32(min_range[t]));
+  block_reduce(m, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = m.nan ? NAN : m.mn;
+}
+
+template <typename R, bool F32OUT>
+__global__ __launch_bounds__(kBlock) void parameters_for_range_grid_kernel(const R* __restrict__ min_range,
+                                                                           const R* __restrict__ max_range,
+                                                                           void* __restrict__ scale_out,
+                                                                           void* __restrict__ offset_out,
+                                                                           const float* __restrict__ partial,
+                                                                           uint32_t npartial, RangeArgs a) {
+  __shared__ float lds[12];
+  __shared__ int one_sided_s;
+  int one_sided = 0;
+  if (partial) {  // min_range.min() >= 0 over ALL tiles                                   (:100)
+    MinMax m;
+    m.init();
+    for (uint32_t k = threadIdx.x; k < npartial; k += kBlock) m.add(partial[k]);
+    block_reduce(m, lds);
+    if (threadIdx.x == 0) one_sided_s = (!m.nan && m.mn >= 0.0f) ? 1 : 0;
+    __syncthreads();
+    one_sided = one_sided_s;
+  }
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < a.ntiles; t += stride) {
+    const float lo = to_f32(min_range[t]), hi = to_f32(max_range[t]);  // .to(torch.float32)   (:90)
+    float scale, offset;
+    range_to_parameters(lo, hi, one_sided, a, scale, offset);
+    if constexpr (F32OUT) {
+      static_cast<float*>(scale_out)[t] = scale;
+      if (offset_out) static_cast<float*>(offset_out)[t] = offset;
+    } else {
+      store_any(scale_out, a.scale_dt, t, (double)scale);
+      if (offset_out) store_any(offset_out, a.offset_dt, t, (double)offset);
+    }
+  }
+}
+
 static RangeArgs make_range_args(int range_dt, int64_t ntiles, double num_bits, int symmetric, int allow_one_sided, int scale_dt, int offset_dt,
                                  int round_offset) {
   RangeArgs a;
@@ -686,15 +788,227 @@ static RangeArgs make_range_args(int range_dt, int64_t ntiles, double num_bits, 
   return a;
 }
 
+template <typename R>
+static int parameters_grid(const void* min_range, const void* max_range, void* scale_out, void* offset_out, const RangeArgs& a,
+                           float* partial, hipStream_t stream) {
+  const R* mn = static_cast<const R*>(min_range);
+  const R* mx = static_cast<const R*>(max_range);
+  uint32_t npartial = 0;
+  if (partial) {
+    const int64_t want = (a.ntiles + kBlock * 4 - 1) / (kBlock * 4);
+    npartial = (uint32_t)(want > (int64_t)kRangePartials ? kRangePartials : want);
+    range_min_partial_kernel<R><<<npartial, kBlock, 0, stream>>>(mn, a.ntiles, partial);
+  }
+  int64_t blocks = (a.ntiles + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;
+  const bool f32out = a.scale_dt == FFQ_F32 && (!offset_out || a.offset_dt == FFQ_F32);
+  if (f32out) parameters_for_range_grid_kernel<R, true><<<(unsigned)blocks, kBlock, 0, stream>>>(mn, mx, scale_out, offset_out, partial, npartial, a);
+  else parameters_for_range_grid_kernel<R, false><<<(unsigned)blocks, kBlock, 0, stream>>>(mn, mx, scale_out, offset_out, partial, npartial, a);
+  return check_launch("parameters_for_range_grid_kernel");
+}
+
+// bytes of scratch the grid form wants (0: none — few tiles, or nothing global to decide)
+static size_t parameters_workspace(int64_t ntiles, int symmetric, int allow_one_sided) {
+  if (ntiles <= kRangeGridTiles || !(symmetric && allow_one_sided)) return 0;
+  return sizeof(float) * kRangePartials;
+}
+
 static int parameters_impl(const void* min_range, const void* max_range, int range_dt, int64_t ntiles,
                            double num_bits, int symmetric, int allow_one_sided, void* scale_out, int scale_dt,
-                           void* offset_out, int offset_dt, int round_offset, hipStream_t stream) {
+                           void* offset_out, int offset_dt, int round_offset, void* workspace, size_t workspace_bytes,
+                           hipStream_t stream) {
   if (!min_range || !max_range || !scale_out || ntiles <= 0) return fail(FFQ_ERR_ARG, "bad argument");
   if (!dt_valid(range_dt) || !dt_valid(scale_dt) || (offset_out && !dt_valid(offset_dt)))
     return fail(FFQ_ERR_ARG, "bad dtype tag");
   const RangeArgs a = make_range_args(range_dt, ntiles, num_bits, symmetric, allow_one_sided, scale_dt, offset_dt, round_offset);
+  const bool typed = range_dt == FFQ_F32 || range_dt == FFQ_BF16 || range_dt == FFQ_F16;
+  if (typed && ntiles > kRangeGridTiles && !generic_kernels_forced()) {
+    const size_t need = parameters_workspace(ntiles, symmetric, allow_one_sided);
+    float* partial = need ? static_cast<float*>(workspace) : nullptr;
+    if (!need || (workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 3u) == 0)) {
+      switch (range_dt) {
+        case FFQ_F32: return parameters_grid<float>(min_range, max_range, scale_out, offset_out, a, partial, stream);
+        case FFQ_BF16: return parameters_grid<bf16_t>(min_range, max_range, scale_out, offset_out, a, partial, stream);
+        default: return parameters_grid<f16_t>(min_range, max_range, scale_out, offset_out, a, partial, stream);
+      }
+    }
+    // no scratch for the global decision: the one-block kernel below decides it in LDS (never fails for lack of scratch)
+  }
   parameters_for_range_kernel<<<1, kRangeBlock, 0, stream>>>(min_range, max_range, scale_out, offset_out, a);
   return check_launch("parameters_for_range_kernel");
+}
+
+// ---- A3 in ONE launch (round 5): per-token / per-row / per-group dynamic quantization ---------------------------------------------
+// quantize_dynamic_by_tile_impl (_quantizer_impl.py:243-285) is min, max, parameters_for_range, round(offset), quantize: five
+// passes in the reference, three launches (A4, A5, A1: 2 + 3 = 5 B/elem for bf16 -> int8) in rounds 1-4. When every tile is a
+// contiguous run that fits the registers of the lanes that own it and nothing global has to be decided — asymmetric, or
+// symmetric without the one-sided fallback (range.py:100 is the only cross-tile dependency of the whole op) — one pass does it:
+// a group of P lanes loads its run (U chunks of E elements per lane), reduces min / max (raw 16-bit patterns for bf16 / fp16,
+// wave butterflies, one LDS hop when the group is the whole block), every lane evaluates A5 on the two numbers, and the chunks
+// still sitting in registers are quantized with A1's arithmetic (ffq_affine.h) and stored: 2 R + 1 W = 3 B/elem.
+// Codes, scales and offsets are bit-identical to the composed form (same min / max, same A5 expression, same division).
+#ifndef FFQ_DYN_WAVE_ROWS
+#define FFQ_DYN_WAVE_ROWS 0
+#endif
+struct DynRowsArgs {
+  uint32_t ntiles, chunks_per_run;
+  float lo, hi;  // clamp bounds
+  RangeArgs range;
+};
+
+template <typename TIn, typename TOut, int E, int P, int U>
+__global__ __launch_bounds__(kBlock) void quantize_dynamic_rows_kernel(const TIn* __restrict__ in, TOut* __restrict__ out,
+                                                                       float* __restrict__ scale_out, float* __restrict__ offset_out,
+                                                                       DynRowsArgs a) {
+  static_assert(P <= 64 || P == kBlock, "a group is part of a wave or the whole block");
+  constexpr int TILES_PER_BLOCK = kBlock / P;
+  const uint32_t t = blockIdx.x * TILES_PER_BLOCK + threadIdx.x / P;
+  const uint32_t lane = threadIdx.x % P;
+  const bool live = t < a.ntiles;
+  const size_t row = (size_t)t * a.chunks_per_run;
+  Chunk<TIn, E> x[U];
+  typename Accum<TIn>::type acc;
+  acc.init();
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t c = lane + u * P;
+    if (live && c < a.chunks_per_run) x[u].load_nt(in + (row + c) * E);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t c = lane + u * P;
+    if (live && c < a.chunks_per_run) add_chunk<TIn, E>(acc, x[u]);
+  }
+  MinMax m = finish_accum<TIn>(acc);
+  if constexpr (P <= 64) {
+    wave_allreduce<P>(m);
+  } else {
+    __shared__ float lds[12];
+    wave_allreduce<64>(m);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+      lds[wave] = m.mn;
+      lds[4 + wave] = m.mx;
+      lds[8 + wave] = m.nan ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      m.mn = __builtin_fminf(m.mn, lds[w]);
+      m.mx = __builtin_fmaxf(m.mx, lds[4 + w]);
+      m.nan |= lds[8 + w] != 0.0f;
+    }
+  }
+  if (!live) return;
+  // torch.min / torch.max propagate NaN; the extrema are elements of the data, so .to(float32) is exact   (:257-258, range.py:90)
+  const float mn = m.nan ? NAN : m.mn, mx = m.nan ? NAN : m.mx;
+  float scale, offset;
+  range_to_parameters(mn, mx, 0, a.range, scale, offset);  // offset None -> zeros; offset = round(offset)   (:266-275)
+  if (lane == 0) {
+    scale_out[t] = scale;
+    offset_out[t] = offset;
+  }
+  const Divider<1> d(scale);
+  if constexpr (sizeof(TOut) == 1) {
+    // the run's own extrema bound every |x|: one test per tile decides for the packed arithmetic of ffq_affine.h
+    if (fast_chunk_ok(scale, d.r, __builtin_fmaxf(__builtin_fabsf(mn), __builtin_fabsf(mx)))) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t c = lane + u * P;
+        if (c >= a.chunks_per_run) continue;
+        float xf[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) xf[i] = x[u].get(i);
+        Chunk<TOut, E> y;
+        quantize_chunk_bytes_fast<E, false>(xf, scale, d.r, offset, a.lo, a.hi, y.w);
+        y.store(out + (row + c) * E);
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t c = lane + u * P;
+    if (c >= a.chunks_per_run) continue;
+    float xf[E], r[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) xf[i] = x[u].get(i);
+    quantize_chunk_with<1, E>(d, xf, offset, r);  // round(row / scale - offset), clamp, cast               (:277-284)
+    Chunk<TOut, E> y;
+    finalize_chunk<TOut, E>(r, a.lo, a.hi, y);
+    y.store(out + (row + c) * E);
+  }
+}
+
+template <typename TIn, typename TOut>
+static bool launch_dynamic_rows(const void* data, void* out, float* scale_out, float* offset_out, const TileInfo& info,
+                                const DynRowsArgs& base, hipStream_t stream) {
+  constexpr int E = sizeof(TOut) == 1 ? 16 : 8;
+  if (info.run % E != 0) return false;
+  const int64_t chunks = info.run / E;
+  if (chunks > 4 * kBlock) return false;  // the run no longer fits the block's registers
+  DynRowsArgs a = base;
+  a.chunks_per_run = (uint32_t)chunks;
+  const TIn* in = static_cast<const TIn*>(data);
+  TOut* o = static_cast<TOut*>(out);
+#define FFQ_DYN(P, U)                                                                                             \
+  do {                                                                                                            \
+    const unsigned grid = (unsigned)((info.ntiles + (kBlock / P) - 1) / (kBlock / P));                            \
+    quantize_dynamic_rows_kernel<TIn, TOut, E, P, U><<<grid, kBlock, 0, stream>>>(in, o, scale_out, offset_out, a); \
+  } while (0)
+  if (chunks <= 1) FFQ_DYN(1, 1);
+  else if (chunks <= 2) FFQ_DYN(2, 1);
+  else if (chunks <= 4) FFQ_DYN(4, 1);
+  else if (chunks <= 8) FFQ_DYN(8, 1);
+  else if (chunks <= 16) FFQ_DYN(16, 1);
+  else if (chunks <= 32) FFQ_DYN(32, 1);
+  else if (chunks <= 64) FFQ_DYN(64, 1);
+  else if (chunks <= 128) FFQ_DYN(64, 2);
+#if FFQ_DYN_WAVE_ROWS  // A/B: one wave per run up to 256 chunks (no block barrier, four loads in flight per lane)
+  else if (chunks <= 256) FFQ_DYN(64, 4);
+#else
+  else if (chunks <= 256) FFQ_DYN(256, 1);
+#endif
+  else if (chunks <= 512) FFQ_DYN(256, 2);
+  else FFQ_DYN(256, 4);
+#undef FFQ_DYN
+  return true;
+}
+
+template <typename TIn>
+static bool launch_dynamic_rows_out(int out_dt, const void* data, void* out, float* scale_out, float* offset_out,
+                                    const TileInfo& info, const DynRowsArgs& a, hipStream_t stream) {
+  switch (out_dt) {
+    case FFQ_I8: return launch_dynamic_rows<TIn, int8_t>(data, out, scale_out, offset_out, info, a, stream);
+    case FFQ_F32: return launch_dynamic_rows<TIn, float>(data, out, scale_out, offset_out, info, a, stream);
+    case FFQ_BF16: return launch_dynamic_rows<TIn, bf16_t>(data, out, scale_out, offset_out, info, a, stream);
+    default: return false;
+  }
+}
+
+// true: the one-launch kernel was enqueued (*rc holds the launch status); false: the caller composes A4 -> A5 -> A1
+static bool dynamic_one_launch(const void* data, int data_dt, const TileInfo& info, double num_bits, int symmetric,
+                               int allow_one_sided, void* out, int out_dt, float* scale_out, float* offset_out,
+                               hipStream_t stream, int* rc) {
+  if (info.layout != LAYOUT_ROWS || info.ntiles >= ((int64_t)1 << 31) || info.numel >= ((int64_t)1 << 36)) return false;
+  if (symmetric && allow_one_sided) return false;  // the one decision that is global over the tiles (range.py:100)
+  if (num_bits != floor(num_bits) || num_bits < 1 || num_bits > 32 || generic_kernels_forced()) return false;
+  if (!aligned16(data) || !aligned16(out)) return false;
+  DynRowsArgs a;
+  a.ntiles = (uint32_t)info.ntiles;
+  a.chunks_per_run = 0;
+  const double lo = -pow(2.0, num_bits - 1.0);
+  a.lo = (float)lo; a.hi = (float)(-lo - 1.0);
+  a.range = make_range_args(data_dt, info.ntiles, num_bits, symmetric, allow_one_sided, FFQ_F32, FFQ_F32, 1);
+  bool done = false;
+  switch (data_dt) {
+    case FFQ_BF16: done = launch_dynamic_rows_out<bf16_t>(out_dt, data, out, scale_out, offset_out, info, a, stream); break;
+    case FFQ_F16: done = launch_dynamic_rows_out<f16_t>(out_dt, data, out, scale_out, offset_out, info, a, stream); break;
+    case FFQ_F32: done = launch_dynamic_rows_out<float>(out_dt, data, out, scale_out, offset_out, info, a, stream); break;
+    default: break;
+  }
+  if (done) *rc = check_launch("quantize_dynamic_rows_kernel");
+  return done;
 }
 
 }  // namespace ffq
@@ -732,22 +1046,31 @@ int ffq_running_minmax_step(const void* data, int data_dt, const ffq_tiling* til
   hipStream_t s = static_cast<hipStream_t>(stream);
   if ((rc = minmax_impl(data, data_dt, tiling, min_inout, max_inout, 1, status_flags, workspace, workspace_bytes, s, &ex))) return rc;
   if (ex.params_done) return FFQ_OK;
+  // the reduction's scratch is free again (stream order): the grid form of A5 keeps its per-block minima there
   return parameters_impl(min_inout, max_inout, data_dt, info.ntiles, num_bits, symmetric, allow_one_sided, scale_out, scale_dt, offset_out,
-                         offset_dt, 0, s);
+                         offset_dt, 0, workspace, workspace_bytes, s);
+}
+
+size_t ffq_parameters_for_range_workspace_bytes(int64_t ntiles, int symmetric, int allow_one_sided) {
+  return parameters_workspace(ntiles, symmetric, allow_one_sided);
 }
 
 int ffq_parameters_for_range(const void* min_range, const void* max_range, int range_dt, int64_t ntiles,
                              double num_bits, int symmetric, int allow_one_sided, void* scale_out,
-                             int scale_dt, void* offset_out, int offset_dt, void* stream) {
+                             int scale_dt, void* offset_out, int offset_dt, void* workspace, size_t workspace_bytes,
+                             void* stream) {
   return parameters_impl(min_range, max_range, range_dt, ntiles, num_bits, symmetric, allow_one_sided,
-                         scale_out, scale_dt, offset_out, offset_dt, 0, static_cast<hipStream_t>(stream));
+                         scale_out, scale_dt, offset_out, offset_dt, 0, workspace, workspace_bytes,
+                         static_cast<hipStream_t>(stream));
 }
 
 // workspace layout: [ minmax scratch | min (ntiles, data dtype) | max (ntiles, data dtype) ]
 size_t ffq_quantize_dynamic_workspace_bytes(const ffq_tiling* tiling, int data_dt) {
   TileInfo info;
   if (analyse(tiling, &info) || info.numel == 0) return 0;
-  const size_t mm = minmax_workspace(tiling, data_dt);
+  size_t mm = minmax_workspace(tiling, data_dt);
+  const size_t a5 = (parameters_workspace(info.ntiles, 1, 1) + 255) & ~(size_t)255;
+  if (mm < a5) mm = a5;
   const size_t ranges = (((size_t)info.ntiles * dt_size(data_dt)) + 255) & ~(size_t)255;
   return mm + 2 * ranges;
 }
@@ -755,29 +1078,38 @@ size_t ffq_quantize_dynamic_workspace_bytes(const ffq_tiling* tiling, int data_d
 int ffq_quantize_dynamic_by_tile(const void* data, int data_dt, const ffq_tiling* tiling, double num_bits,
                                  int symmetric, int allow_one_sided, void* out, int out_dt,
                                  float* scale_out, float* offset_out, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+                                 size_t workspace_bytes, int32_t* ticket, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   TileInfo info;
   int rc = analyse(tiling, &info);
   if (rc) return rc;
   // torch.min over an empty row raises IndexError -> QuantizationError                 (:259-264)
   if (info.numel == 0) return fail(FFQ_ERR_EMPTY, "Cannot dynamically quantize an empty tensor");
-  if (!scale_out || !offset_out) return fail(FFQ_ERR_ARG, "NULL parameter output");
+  if (!data || !out || !scale_out || !offset_out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (!dt_valid(data_dt) || !dt_valid(out_dt)) return fail(FFQ_ERR_ARG, "bad dtype tag");
   if (!ffq_can_support_bitwidth(out_dt, num_bits))
     return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.",
                 out_dt, num_bits);
+  // contiguous-run tiles that fit a block's registers and no global one-sided decision: ONE launch, 3 B/elem
+  if (dynamic_one_launch(data, data_dt, info, num_bits, symmetric, allow_one_sided, out, out_dt, scale_out, offset_out, s, &rc)) return rc;
   const size_t need = ffq_quantize_dynamic_workspace_bytes(tiling, data_dt);
   if (need > workspace_bytes || !workspace)
     return fail(FFQ_ERR_WORKSPACE, "dynamic quantize needs %zu workspace bytes, got %zu", need, workspace_bytes);
-  const size_t mm = minmax_workspace(tiling, data_dt);
   const size_t ranges = (((size_t)info.ntiles * dt_size(data_dt)) + 255) & ~(size_t)255;
+  const size_t mm = need - 2 * ranges;
   char* base = static_cast<char*>(workspace);
   void* mn = base + mm;
   void* mx = base + mm + ranges;
-  if ((rc = minmax_impl(data, data_dt, tiling, mn, mx, 0, nullptr, base, mm, s))) return rc;
+  // one tile and a ticket word: the reduction's last block also evaluates A5 (round(offset) included)   (:266-275)
+  StepExtras ex;
+  ex.ticket = ticket;
+  ex.scale_out = scale_out; ex.offset_out = offset_out;
+  ex.range = make_range_args(data_dt, info.ntiles, num_bits, symmetric, allow_one_sided, FFQ_F32, FFQ_F32, 1);
+  if ((rc = minmax_impl(data, data_dt, tiling, mn, mx, 0, nullptr, base, mm, s, &ex))) return rc;
   // parameters_for_range; offset None -> zeros; offset = round(offset)                  (:266-275)
-  if ((rc = parameters_impl(mn, mx, data_dt, info.ntiles, num_bits, symmetric, allow_one_sided, scale_out,
-                            FFQ_F32, offset_out, FFQ_F32, 1, s)))
+  if (!ex.params_done &&
+      (rc = parameters_impl(mn, mx, data_dt, info.ntiles, num_bits, symmetric, allow_one_sided, scale_out,
+                            FFQ_F32, offset_out, FFQ_F32, 1, base, mm, s)))
     return rc;
   // round(row / scale - offset), clamp, cast                                            (:277-284)
   return quantize_impl(data, data_dt, scale_out, FFQ_F32, info.ntiles, offset_out, FFQ_F32, info.ntiles,

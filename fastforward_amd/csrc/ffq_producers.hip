@@ -75,11 +75,7 @@ __device__ __forceinline__ void fan_store(const FanOut& f, const FanParams& p, c
         reuse = true;
       }
     }
-    if (!reuse) {
-      float r[16];
-      quantize_chunk<1, 16>(z, p.s[j], p.o[j], r);
-      finalize_chunk<int8_t, 16>(r, f.lo, f.hi, y[j]);
-    }
+    if (!reuse) quantize_chunk_to_bytes<16>(z, p.s[j], p.o[j], f.lo, f.hi, y[j]);
     y[j].FFQ_SSTORE(f.codes[j] + at);
   }
 }

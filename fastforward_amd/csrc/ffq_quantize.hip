@@ -77,12 +77,17 @@ __global__ __launch_bounds__(kBlock) void quantize_stream_kernel(const TIn* __re
   for (int u = 0; u < U; ++u) {
     const uint32_t c = first + u * kBlock;
     if (c >= a.nchunks) continue;
-    float xf[E], r[E];
+    float xf[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) xf[i] = x[u].get(i);
-    quantize_chunk<DIVMODE, E>(xf, s[u], HAS_OFFSET ? rne(o[u]) : 0.0f, r);
     Chunk<TOut, E> y;
-    finalize_chunk<TOut, E>(r, a.lo, a.hi, y);
+    if constexpr (TypeTag<TOut>::value == FFQ_I8 && DIVMODE == 1 && E % 4 == 0) {
+      quantize_chunk_to_bytes<E>(xf, s[u], HAS_OFFSET ? rne(o[u]) : 0.0f, a.lo, a.hi, y);  // packed arithmetic, self-checked
+    } else {
+      float r[E];
+      quantize_chunk<DIVMODE, E>(xf, s[u], HAS_OFFSET ? rne(o[u]) : 0.0f, r);
+      finalize_chunk<TOut, E>(r, a.lo, a.hi, y);
+    }
     if constexpr (NT & 2) y.store_nt(out + (size_t)c * E); else y.store(out + (size_t)c * E);
   }
 }
@@ -439,12 +444,11 @@ __global__ __launch_bounds__(kBlock) void quantize_rows_rowsum_kernel(const bf16
   const uint32_t row = fdiv(live ? c : a.nchunks - 1, a.chunks_per_run);
   const float s = scale[row];
   const float o = HAS_OFFSET ? rne(offset[row]) : 0.0f;
-  float xf[16], r[16];
+  float xf[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) xf[i] = x.get(i);
-  quantize_chunk<1, 16>(xf, s, o, r);
   Chunk<int8_t, 16> y;
-  finalize_chunk<int8_t, 16>(r, a.lo, a.hi, y);
+  quantize_chunk_to_bytes<16>(xf, s, o, a.lo, a.hi, y);
   if (live) y.store(out + (size_t)c * 16);
   int sum = 0;
 #pragma unroll
@@ -524,12 +528,11 @@ __global__ __launch_bounds__(kBlock) void quantize_rows_batch_kernel(BatchArgs a
   const uint32_t row = fdiv(c, mem.chunks_per_row);
   const float s = mem.scale[row];
   const float o = mem.offset ? rne(mem.offset[row]) : 0.0f;
-  float xf[16], r[16];
+  float xf[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) xf[i] = x.get(i);
-  quantize_chunk<1, 16>(xf, s, o, r);
   Chunk<int8_t, 16> y;
-  finalize_chunk<int8_t, 16>(r, a.lo, a.hi, y);
+  quantize_chunk_to_bytes<16>(xf, s, o, a.lo, a.hi, y);
   y.store(mem.out + (size_t)c * 16);
   if constexpr (ROWSUM) {
     int sum = 0;

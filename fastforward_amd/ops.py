@@ -242,10 +242,11 @@ def quantize_dynamic_by_tile(
     offset = torch.empty(ntiles, dtype=torch.float32, device=data_c.device)
     nbytes = lib.ffq_quantize_dynamic_workspace_bytes(ctypes.byref(tiling), _tag(data_c.dtype))
     ws = _workspace(nbytes, data_c.device)
+    ticket = _tickets(1, data_c.device, stream, kind="minmax") if data_c.is_cuda and ntiles == 1 else None  # per-tensor: A5 in the reduction
     lib.check(
         lib.ffq_quantize_dynamic_by_tile(
             _ptr(data_c), _tag(data_c.dtype), ctypes.byref(tiling), float(num_bits), int(symmetric),
-            int(allow_one_sided), _ptr(out), _tag(output_dtype), _ptr(scale), _ptr(offset), _ptr(ws), nbytes, stream,
+            int(allow_one_sided), _ptr(out), _tag(output_dtype), _ptr(scale), _ptr(offset), _ptr(ws), nbytes, _ptr(ticket), stream,
         )
     )
     return out, scale, offset
@@ -456,11 +457,13 @@ def parameters_for_range(
     for name, t in (("scale", scale_out), ("offset", offset_out)):
         if t is not None and (t.numel() != n or not t.is_contiguous()):
             raise RuntimeError(f"{name} output must be contiguous with {n} elements, got {tuple(t.shape)}")
+    nbytes = lib.ffq_parameters_for_range_workspace_bytes(n, int(symmetric), int(allow_one_sided))
+    ws = _workspace(nbytes, mn.device)
     lib.check(
         lib.ffq_parameters_for_range(
             _ptr(mn), _ptr(mx), _tag(mn.dtype), n, float(num_bits), int(symmetric), int(allow_one_sided),
             _ptr(scale_out), _tag(scale_out.dtype), _ptr(offset_out),
-            _tag(offset_out.dtype) if offset_out is not None else 0, stream,
+            _tag(offset_out.dtype) if offset_out is not None else 0, _ptr(ws), nbytes, stream,
         )
     )
     return scale_out, offset_out

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define FFQ_MAX_DIMS 8
-#define FFQ_ABI_VERSION 7
+#define FFQ_ABI_VERSION 8
 
 typedef enum ffq_status {
   FFQ_OK = 0,
@@ -158,22 +158,33 @@ int ffq_running_minmax_step(const void* data, int data_dt, const ffq_tiling* til
  * GLOBAL over all tiles (:100) and is decided on the device. scale_out / offset_out are written
  * in their own dtypes. When the symmetric two-sided branch is taken (reference returns
  * offset=None) and offset_out != NULL it is filled with 0 (linear_quantizer.py:353-357).
+ * `workspace` (ABI 8, nullable): ffq_parameters_for_range_workspace_bytes() bytes of scratch, contents irrelevant. Above 8192
+ * tiles (group-128 weights: 458,752 for a 14336 x 4096 projection) the tiles are spread over the chip; the global one-sided
+ * test then costs a first short launch that leaves one minimum per block in the scratch. Without scratch one block does
+ * everything, as below 8192 tiles (same values either way).
  */
+size_t ffq_parameters_for_range_workspace_bytes(int64_t ntiles, int symmetric, int allow_one_sided);
 int ffq_parameters_for_range(const void* min_range, const void* max_range, int range_dt,
                              int64_t ntiles, double num_bits, int symmetric, int allow_one_sided,
                              void* scale_out, int scale_dt, void* offset_out, int offset_dt,
-                             void* stream);
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * A3 — fastforward::quantize_dynamic_by_tile, _quantizer_impl.py:243-285 (affine/_autograd.py:121).
  * = A4 (fresh min/max) + A5 + round(offset) + A1, returning (q, scale, offset) with fp32 params.
  * Empty input -> FFQ_ERR_EMPTY.
+ * ONE launch (ABI 8; 2 B read + 1 B written per bf16 element into an int8 container) when every tile is a contiguous run of at
+ * most 16384 (1-byte containers) / 8192 elements — per-token and per-channel(0) activations, group-128 weights — and the
+ * parameters of a tile depend on that tile alone: asymmetric, or symmetric with allow_one_sided == 0 (the one-sided test of
+ * range.py:100 is the only cross-tile dependency of the op). Everything else is A4 -> A5 -> A1 enqueued back to back through
+ * `workspace`; with `ticket` (nullable; one int32, ZERO before the first call, left zero by every call: one word per stream)
+ * a per-tensor call folds A5 into the reduction's last block (two launches instead of three). Same values on every route.
  */
 size_t ffq_quantize_dynamic_workspace_bytes(const ffq_tiling* tiling, int data_dt);
 int ffq_quantize_dynamic_by_tile(const void* data, int data_dt, const ffq_tiling* tiling,
                                  double num_bits, int symmetric, int allow_one_sided, void* out,
                                  int out_dt, float* scale_out, float* offset_out, void* workspace,
-                                 size_t workspace_bytes, void* stream);
+                                 size_t workspace_bytes, int32_t* ticket, void* stream);
 
 /*
  * A7 — sub-byte storage. The reference keeps 4-bit codes unpacked; its only packing convention is

@@ -484,11 +484,16 @@ int ffq_minmax_by_tile(const void* data, int data_dt, const ffq_tiling* tiling, 
 /* ------------------------------------------------------------------------------------------ */
 /* A5: parameters_for_range, quantization/affine/range.py:54-122                               */
 /* ------------------------------------------------------------------------------------------ */
+size_t ffq_parameters_for_range_workspace_bytes(int64_t ntiles, int symmetric, int allow_one_sided) {
+  (void)ntiles; (void)symmetric; (void)allow_one_sided;
+  return 0;
+}
+
 int ffq_parameters_for_range(const void* min_range, const void* max_range, int range_dt,
                              int64_t ntiles, double num_bits, int symmetric, int allow_one_sided,
                              void* scale_out, int scale_dt, void* offset_out, int offset_dt,
-                             void* stream) {
-  (void)stream;
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  (void)stream; (void)workspace; (void)workspace_bytes;
   if (!min_range || !max_range || !scale_out || ntiles <= 0) return fail(FFQ_ERR_ARG, "bad argument");
   if (!dt_valid(range_dt) || !dt_valid(scale_dt) || (offset_out && !dt_valid(offset_dt)))
     return fail(FFQ_ERR_ARG, "bad dtype tag");
@@ -535,7 +540,7 @@ int ffq_running_minmax_step(const void* data, int data_dt, const ffq_tiling* til
   int rc = ffq_minmax_by_tile(data, data_dt, tiling, min_inout, max_inout, 1, status_flags, workspace, workspace_bytes, ticket, stream);
   if (rc) return rc;
   return ffq_parameters_for_range(min_inout, max_inout, data_dt, ffq_num_tiles(tiling), num_bits, symmetric, allow_one_sided, scale_out,
-                                  scale_dt, offset_out, offset_dt, stream);
+                                  scale_dt, offset_out, offset_dt, NULL, 0, stream);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -549,8 +554,8 @@ size_t ffq_quantize_dynamic_workspace_bytes(const ffq_tiling* tiling, int data_d
 int ffq_quantize_dynamic_by_tile(const void* data, int data_dt, const ffq_tiling* tiling,
                                  double num_bits, int symmetric, int allow_one_sided, void* out,
                                  int out_dt, float* scale_out, float* offset_out, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
-  (void)workspace; (void)workspace_bytes;
+                                 size_t workspace_bytes, int32_t* ticket, void* stream) {
+  (void)workspace; (void)workspace_bytes; (void)ticket;
   int rc = check_tiling(tiling);
   if (rc) return rc;
   int64_t n = numel_of(tiling);
@@ -569,7 +574,7 @@ int ffq_quantize_dynamic_by_tile(const void* data, int data_dt, const ffq_tiling
   /* parameters_for_range(...); offset None -> zeros_like(scale); offset = round(offset) (:266-275) */
   if (!rc)
     rc = ffq_parameters_for_range(mn, mx, data_dt, ntiles, num_bits, symmetric, allow_one_sided,
-                                  scale_out, FFQ_F32, offset_out, FFQ_F32, stream);
+                                  scale_out, FFQ_F32, offset_out, FFQ_F32, NULL, 0, stream);
   free(mn);
   if (rc) return rc;
   for (int64_t t = 0; t < ntiles; ++t) offset_out[t] = nearbyintf(offset_out[t]);

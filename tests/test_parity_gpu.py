@@ -203,6 +203,43 @@ def test_fast_division_is_bit_identical_to_ieee_division(generic_kernels):
             assert same_with_nan(fast_f.cpu(), slow_f.cpu()), mismatch_report(fast_f.cpu(), slow_f.cpu())
 
 
+def test_fast_chunk_arithmetic_equals_the_reference_chain(generic_kernels):
+    """Byte containers take packed arithmetic on ordinary chunks (csrc/ffq_affine.h: pairs of elements through v_pk_fma_f32, no
+    window test per element, clamp before a round-and-convert magic add, a NaN self-check per chunk) — against the generic kernel's
+    IEEE division + round + clamp + cast on quotients placed ON and next to the ties k + 0.5 (one ulp either side), at the clamp
+    bounds, with every scale regime of the Markstein window, integer offsets up to 2^20, raw bit patterns for x (Inf, NaN,
+    denormals, -0.0: the self-check sends those chunks to the reference chain) and for the scale."""
+    g = torch.Generator(device=DEV).manual_seed(77)
+    n = 1 << 20
+    cases = []
+    for lo_exp, hi_exp in ((-3, 3), (-30, 30), (-39.9, -30), (30, 39.9)):
+        s = torch.exp2(torch.empty(n, device=DEV).uniform_(lo_exp, hi_exp, generator=g)) * torch.empty(n, device=DEV).uniform_(1, 2, generator=g)
+        k = torch.randint(-140, 141, (n, 16), device=DEV, generator=g).float() + 0.5
+        ulps = torch.randint(-2, 3, (n, 16), device=DEV, generator=g, dtype=torch.int32)
+        q = (k.view(torch.int32) + ulps).view(torch.float32)          # k + 0.5 and its neighbours
+        q[:, 15] = torch.empty(n, device=DEV).uniform_(-300, 300, generator=g)
+        cases.append((q * s[:, None], s))
+    x = torch.randint(-(2**31), 2**31 - 1, (n, 16), device=DEV, generator=g, dtype=torch.int64).to(torch.int32).view(torch.float32)
+    cases.append((x, torch.rand(n, device=DEV, generator=g) + 0.01))
+    sparse = torch.randn(n, 16, device=DEV, generator=g) * 40
+    sparse[::7, 3] = float("inf")
+    sparse[::11, 5] = float("nan")
+    sparse[::13, 0] = -0.0
+    sparse[::17, 9] = 3.0e38
+    cases.append((sparse, torch.rand(n, device=DEV, generator=g) * 1e-3 + 0.3))
+    sb = torch.randint(-(2**31), 2**31 - 1, (n,), device=DEV, generator=g, dtype=torch.int64).to(torch.int32).view(torch.float32)
+    cases.append((torch.randn(n, 16, device=DEV, generator=g), sb))
+    for x, s in cases:
+        for offset in (None, torch.full_like(s, 3.0), torch.randint(-(1 << 20), 1 << 20, s.shape, device=DEV, generator=g).float()):
+            for bits in (8, 4):
+                for data in (x, x.to(torch.bfloat16)):
+                    generic_kernels(False)
+                    fast = ops.quantize_by_tile(data, s, (1, 16), bits, torch.int8, offset)
+                    generic_kernels(True)
+                    slow = ops.quantize_by_tile(data, s, (1, 16), bits, torch.int8, offset)
+                    assert torch.equal(fast, slow), mismatch_report(fast.cpu(), slow.cpu())
+
+
 # ---- 2. HIP vs oracle on seeded inputs ------------------------------------------------------------
 def _both(fn):
     """Run fn(device) with the HIP backend on cuda and with the oracle on cpu."""
@@ -284,6 +321,99 @@ def test_minmax_and_dynamic_quantize_match_oracle(shape, gran, dtype):
     got, want = _both(run)
     for a, b in zip(got, want):
         assert same_with_nan(a, b), mismatch_report(a, b)
+
+
+DYNAMIC_ONE_LAUNCH_CASES = [
+    # shape, granularity                      what it exercises
+    ((4, 128, 4096), ff.PerChannel((0, 1))),  # per-token activations: one 256-lane block per row
+    ((96, 14336), ff.PerChannel(0)),          # 896 chunks of 16: four chunks per lane, idle lanes in the last round
+    ((40, 16384), ff.PerChannel(0)),          # the longest run the one-launch form takes
+    ((24, 32768), ff.PerChannel(0)),          # beyond it: composed A4 -> A5 -> A1
+    ((64, 1024), ff.PerBlock(1, 128, 0)),     # group 128: 8 lanes per tile, 32 tiles per block
+    ((64, 1024), ff.PerBlock(1, 32, 0)),      # 2 lanes per tile
+    ((33, 16), ff.PerChannel(0)),             # one chunk per tile, a partly filled last block
+    ((5, 2000), ff.PerChannel(0)),            # 125 chunks: 64 lanes x 2
+    ((6, 40), ff.PerChannel(0)),              # 40 % 16 != 0 for byte containers (composed), % 8 == 0 for wide ones (one launch)
+]
+
+
+@pytest.mark.parametrize("shape,gran", DYNAMIC_ONE_LAUNCH_CASES, ids=lambda v: str(v))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+def test_one_launch_dynamic_quantize_matches_oracle_and_the_composed_form(shape, gran, dtype):
+    """A3 in one launch (contiguous-run tiles, no global one-sided decision) == the oracle's restatement of
+    quantize_dynamic_by_tile_impl (_quantizer_impl.py:243-285) == the composed A4 -> A5 -> A1 form, bit for bit: codes, scales, offsets.
+    Rows holding NaN, +-Inf, a constant (eps-clamped scale) and only zeros (0 / 0 in the symmetric branch) included."""
+    g = torch.Generator().manual_seed(sum(shape) * 7 + len(shape))
+    x = (torch.randn(*shape, generator=g) * 3).to(dtype)
+    rows = x.view(-1, shape[-1]) if isinstance(gran, ff.PerChannel) else x.view(-1, gran.tile_size(x.shape)[-1])
+    if rows.shape[0] > 4:
+        rows[1, 0] = float("nan")
+        rows[2, -1] = float("inf")
+        rows[3, :] = 1.5
+        rows[4, :] = 0.0
+    rows[0, :] = rows[0, :].abs()  # a non-negative tile: one-sided only if EVERY tile were
+
+    def run(device):
+        xd = x.to(device)
+        outs = []
+        for symmetric, one_sided in ((False, True), (True, False), (True, True)):
+            for qdt in (torch.int8, None, torch.bfloat16 if dtype == torch.bfloat16 else torch.float32):
+                q = ff.quantization.affine.dynamic.quantize_per_granularity(xd, gran, 8, symmetric=symmetric, allow_one_sided=one_sided, output_dtype=qdt)
+                p = q.quantization_context.quantization_params
+                outs += [q.raw_data.cpu(), p.scale.cpu(), p.offset.cpu()]
+        q4 = ff.quantization.affine.dynamic.quantize_per_granularity(xd, gran, 4, symmetric=False, output_dtype=torch.int8)
+        outs += [q4.raw_data.cpu(), q4.quantization_context.quantization_params.scale.cpu()]
+        return outs
+
+    got, want = _both(run)
+    lib = _native.library()
+    previous = lib.ffq_force_generic_kernels(1)  # the composed form on the element-wise kernel family
+    try:
+        composed = run(DEV)
+    finally:
+        lib.ffq_force_generic_kernels(previous)
+    for a, b, c in zip(got, want, composed):
+        assert a.dtype == b.dtype
+        assert same_with_nan(a, b), mismatch_report(a, b)
+        assert same_with_nan(a, c), mismatch_report(a, c)
+
+
+@pytest.mark.parametrize("ntiles", [8193, 20000, 458752])
+@pytest.mark.parametrize("range_dtype", [torch.float32, torch.bfloat16])
+def test_parameters_for_range_grid_form_matches_oracle(ntiles, range_dtype):
+    """A5 above 8192 tiles runs as a grid (two launches when the one-sided test of range.py:100 is global): same values as the
+    oracle and as the one-block kernel, for two-sided, one-sided, NaN-holding and asymmetric ranges."""
+    g = torch.Generator().manual_seed(ntiles)
+    lo = (torch.randn(ntiles, generator=g) * 2 - 1).to(range_dtype)
+    hi = (lo.float() + torch.rand(ntiles, generator=g) * 4).to(range_dtype)
+    hi[5] = lo[5]  # empty interval: eps clamp
+    cases = {"two_sided": (lo, hi), "one_sided": (lo.abs(), lo.abs() + (hi - lo).abs())}
+    with_nan = lo.abs().clone()
+    with_nan[ntiles - 3] = float("nan")
+    cases["nan"] = (with_nan, cases["one_sided"][1])
+    late_negative = lo.abs().clone()
+    late_negative[ntiles - 1] = -0.25  # the only negative minimum sits in the last block's share
+    cases["late_negative"] = (late_negative, cases["one_sided"][1])
+
+    def run(device):
+        outs = []
+        for mn, mx in cases.values():
+            for symmetric, one_sided in ((True, True), (True, False), (False, True)):
+                for bits in (8, 4):
+                    s, o = ops.parameters_for_range(mn.to(device), mx.to(device), bits, symmetric, one_sided)
+                    outs += [s.cpu(), o.cpu()]
+        return outs
+
+    got, want = _both(run)
+    lib = _native.library()
+    previous = lib.ffq_force_generic_kernels(1)  # the one-block kernel
+    try:
+        one_block = run(DEV)
+    finally:
+        lib.ffq_force_generic_kernels(previous)
+    for a, b, c in zip(got, want, one_block):
+        assert same_with_nan(a, b), mismatch_report(a, b)
+        assert same_with_nan(a, c), mismatch_report(a, c)
 
 
 def test_minmax_flags_inf_and_nan():
