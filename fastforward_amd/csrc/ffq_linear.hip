@@ -338,20 +338,29 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
           ow4 = *reinterpret_cast<const f32x4*>(owp);
         }
         float y[4];
+        // two columns per VALU instruction (v_pk_mul_f32 / v_pk_add_f32: each half is the scalar instruction's IEEE result; the
+        // epilogue's arithmetic is paid in full, nothing overlaps it)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float v = (float)acc[mi][nj][t] + ox * rs4[t];
+        for (int t = 0; t < 4; t += 2) {
+          const fq_f32x2 A = {(float)acc[mi][nj][t], (float)acc[mi][nj][t + 1]};
+          const fq_f32x2 OX = {ox, ox}, SX = {sx, sx};
+          fq_f32x2 V = A + OX * fq_f32x2{rs4[t], rs4[t + 1]};
           if constexpr (WOFF) {  // the order of the tail kernel's terms
-            v = v + ow4[t] * rsx;
-            v = v + kf * ox * ow4[t];
+            const fq_f32x2 OW = {ow4[t], ow4[t + 1]}, RSX = {rsx, rsx}, KFOX = {kf * ox, kf * ox};
+            V = V + OW * RSX;
+            V = V + KFOX * OW;
           }
-          float r = (sx * sw4[t]) * v;
-          if (a.bias) r = r + b4[t];
+          fq_f32x2 R = (SX * fq_f32x2{sw4[t], sw4[t + 1]}) * V;
+          if (a.bias) R = R + fq_f32x2{b4[t], b4[t + 1]};
+          float r0 = R.x, r1 = R.y;
           if constexpr (REQUANT) {
-            r = round_to_dt(r, a.y_dt);
-            r = clamp_nan(rne(r / oscale - ooff), a.out_lo, a.out_hi);
+            r0 = round_to_dt(r0, a.y_dt);
+            r1 = round_to_dt(r1, a.y_dt);
+            r0 = clamp_nan(rne(r0 / oscale - ooff), a.out_lo, a.out_hi);
+            r1 = clamp_nan(rne(r1 / oscale - ooff), a.out_lo, a.out_hi);
           }
-          y[t] = r;
+          y[t] = r0;
+          y[t + 1] = r1;
         }
         if constexpr (sizeof(TOut) == 2) {
           if (lds_path) {
@@ -391,7 +400,6 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
 // is formed in registers with exactly the roundings of the three-launch path (GEMM epilogue -> bf16 tensors ->
 // silu_mul_quantize_kernel), goes through ONE block-wide LDS tile [256][128 B] and leaves as full 128-byte lines of int8
 // codes: a quarter of the bytes of one bf16 projection, instead of two.
-template <bool SAFE>
 __device__ __forceinline__ void mlp_epilogue16_body(const LinearArgs& a, v4i32 (&acc)[8][4], int (&rsw)[2], uint8_t* lds2, int wave,
                                                     int lane, int wm, int wn, int m0, int n0, const uint16_t* silu_table) {
   constexpr int PITCH = 144;  // 128 B of codes + 16 B pad
@@ -408,35 +416,27 @@ __device__ __forceinline__ void mlp_epilogue16_body(const LinearArgs& a, v4i32 (
   }
   const int r16 = lane & 15, g4 = lane >> 4;
   const int col0 = n0 + wn * 32;  // this wave's 32 output columns
-  const int lo = (int)a.out_lo, hi = (int)a.out_hi;
-  // Every VALU instruction of this epilogue is paid in full — it does not hide under another wave's MFMAs (an ablation
-  // without the division and the window test, 10 instructions per element, made the launch 2.9 % faster) — so:
-  //  * the quotient is Divider::fast with its window test as ONE v_cmp_class: q2 for every normal q0, q0 itself for
-  //    zero / denormal / Inf / NaN (normal quotients outside 2^-40 .. 2^40 round to -o or leave through the clamp whichever
-  //    candidate is taken; zero keeps its sign, an overflowed quotient stays Inf instead of the NaN of its residual);
-  //  * the clamp is one v_med3_i32 (lo <= hi).
-  auto quotient = [&](float x) {
-    const float q0 = x * div.r;
-    const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, div.s, x), div.r, q0);
-    const float q2 = __builtin_fmaf(__builtin_fmaf(-q1, div.s, x), div.r, q1);
-    return __builtin_amdgcn_class(q0, 0x108) ? q2 : q0;
-  };
-  auto clamp_code = [&](int v) {
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
-    return r;
-  };
+  // Every VALU instruction of this epilogue is paid in full — it does not hide under another wave's MFMAs (round 2: an ablation
+  // without the division and the window test, 10 instructions per element, made the launch 2.9 % faster) — so the arithmetic
+  // runs on PAIRS of columns (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: each half is the scalar instruction's IEEE result):
+  //  * y = (sx sw[n]) (acc + ox rowsum[n]) with both column constants formed once per column pair;
+  //  * the output quantizer is ffq_affine.h's packed form (Markstein quotient without a window test per element, clamp, then
+  //    round + convert as one magic add, bytes gathered with v_perm_b32) and its NaN self-check per 16 codes; a lane whose
+  //    check fails (an Inf / NaN product, a scale outside the Markstein window) redoes those 16 codes with the reference chain
+  //    (IEEE division, round, convert, clamp) — same codes either way, as tests/test_gemm_gpu.py / test_fullsize_gpu.py assert.
+  const fq_f32x2 SO = {so, so}, RO = {div.r, div.r}, OO = {oo, oo}, MAGIC = {12582912.0f, 12582912.0f};
+  const float lo = a.out_lo, hi = a.out_hi;
 #pragma unroll
   for (int nj = 0; nj < 2; ++nj) {
     const int cb = 16 * nj + 4 * g4;  // this lane's 4 columns: col0 + cb + (0..3)
-    float swg[4], swu[4], rsg[4], rsu[4];
+    fq_f32x2 CG[2], OG[2], CU[2], OU[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 4; t += 2) {
       const int n = col0 + cb + t;  // N % 128 == 0: always inside
-      swg[t] = a.w_scale[n];
-      swu[t] = a.w_scale2[n];
-      rsg[t] = rs_lds[cb + t];
-      rsu[t] = rs_lds[32 + cb + t];
+      CG[t >> 1] = fq_f32x2{sx * a.w_scale[n], sx * a.w_scale[n + 1]};
+      CU[t >> 1] = fq_f32x2{sx * a.w_scale2[n], sx * a.w_scale2[n + 1]};
+      OG[t >> 1] = fq_f32x2{ox * rs_lds[cb + t], ox * rs_lds[cb + t + 1]};
+      OU[t >> 1] = fq_f32x2{ox * rs_lds[32 + cb + t], ox * rs_lds[32 + cb + t + 1]};
     }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -448,9 +448,9 @@ __device__ __forceinline__ void mlp_epilogue16_body(const LinearArgs& a, v4i32 (
         const int mi = 4 * half + q;
 #pragma unroll
         for (int t = 0; t < 4; t += 2) {
-          const float g0 = (sx * swg[t]) * ((float)acc[mi][nj][t] + ox * rsg[t]);
-          const float g1 = (sx * swg[t + 1]) * ((float)acc[mi][nj][t + 1] + ox * rsg[t + 1]);
-          wg[q][t >> 1] = pack2<bf16_t>(g0, g1);
+          const fq_f32x2 A = {(float)acc[mi][nj][t], (float)acc[mi][nj][t + 1]};
+          const fq_f32x2 G = CG[t >> 1] * (A + OG[t >> 1]);
+          wg[q][t >> 1] = pack2<bf16_t>(G.x, G.y);
           ws[q][t >> 1] = silu_pair_lookup(wg[q][t >> 1], silu_table, bad);
         }
       }
@@ -460,28 +460,58 @@ __device__ __forceinline__ void mlp_epilogue16_body(const LinearArgs& a, v4i32 (
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) ws[q][h2] = silu_pair_patch(wg[q][h2], ws[q][h2]);
       }
+      // z = bf16(silu) * bf16(up) as bf16 pairs (kept for the fallback), codes by the packed chain
+      uint32_t zw[4][2], cw[4];
+      fq_f32x2 chk = {0.0f, 0.0f};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int mi = 4 * half + q;
-        int c[4];
+        uint32_t b[4];
 #pragma unroll
         for (int t = 0; t < 4; t += 2) {
-          uint32_t w = pack2<bf16_t>((sx * swu[t]) * ((float)acc[mi][nj + 2][t] + ox * rsu[t]),
-                                     (sx * swu[t + 1]) * ((float)acc[mi][nj + 2][t + 1] + ox * rsu[t + 1]));
-          const float u0 = __builtin_bit_cast(float, w << 16), u1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
+          const fq_f32x2 A = {(float)acc[mi][nj + 2][t], (float)acc[mi][nj + 2][t + 1]};
+          const fq_f32x2 U = CU[t >> 1] * (A + OU[t >> 1]);
+          uint32_t w = pack2<bf16_t>(U.x, U.y);
+          const fq_f32x2 UB = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
           w = ws[q][t >> 1];
-          const float a0 = __builtin_bit_cast(float, w << 16), a1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
-          float z0 = a0 * u0, z1 = a1 * u1;
-          w = pack2<bf16_t>(z0, z1);
-          z0 = __builtin_bit_cast(float, w << 16); z1 = __builtin_bit_cast(float, w & 0xFFFF0000u);
-          const float r0 = SAFE ? rne(quotient(z0) - oo) : rne(z0 / so - oo);
-          const float r1 = SAFE ? rne(quotient(z1) - oo) : rne(z1 / so - oo);
-          const int c0 = (int)r0, c1 = (int)r1;  // v_cvt_i32_f32: NaN -> 0, the int8 container's value
-          c[t] = clamp_code(c0);
-          c[t + 1] = clamp_code(c1);
+          const fq_f32x2 SB = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
+          const fq_f32x2 Z = SB * UB;
+          w = pack2<bf16_t>(Z.x, Z.y);
+          zw[q][t >> 1] = w;
+          const fq_f32x2 X = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
+          const fq_f32x2 q0 = X * RO;
+          const fq_f32x2 q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, SO, X), RO, q0);
+          const fq_f32x2 q2 = __builtin_elementwise_fma(__builtin_elementwise_fma(-q1, SO, X), RO, q1);
+          const fq_f32x2 d = q2 - OO;
+          chk = chk + d;
+          const fq_f32x2 c = {__builtin_amdgcn_fmed3f(d.x, lo, hi), __builtin_amdgcn_fmed3f(d.y, lo, hi)};
+          const fq_f32x2 e = c + MAGIC;
+          const float e0 = e.x, e1 = e.y;  // (bit_cast of a vector ELEMENT reads element 0 with this hipcc: scalar temporaries)
+          b[t] = __builtin_bit_cast(uint32_t, e0);
+          b[t + 1] = __builtin_bit_cast(uint32_t, e1);
         }
-        const int row = wm * 128 + mi * 16 + r16;
-        *reinterpret_cast<uint32_t*>(lds2 + row * PITCH + wn * 32 + cb) = pack_bytes(c[0], c[1], c[2], c[3]);
+        cw[q] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(b[3], b[2], 0x0c0c0400u), __builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u), 0x05040100u);
+      }
+      const float chk1 = chk.x + chk.y;
+      if (__builtin_expect(!div.safe || chk1 != chk1, 0)) {  // the reference chain for these 16 codes
+        const int ilo = (int)lo, ihi = (int)hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int c[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const uint32_t w = zw[q][t >> 1];
+            const float z = __builtin_bit_cast(float, (t & 1) ? (w & 0xFFFF0000u) : (w << 16));
+            const int v = (int)rne(z / so - oo);  // v_cvt_i32_f32: NaN -> 0, the int8 container's value
+            c[t] = v < ilo ? ilo : (v > ihi ? ihi : v);
+          }
+          cw[q] = pack_bytes(c[0], c[1], c[2], c[3]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = wm * 128 + (4 * half + q) * 16 + r16;
+        *reinterpret_cast<uint32_t*>(lds2 + row * PITCH + wn * 32 + cb) = cw[q];
       }
     }
   }
@@ -699,9 +729,7 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
         rsw[0] = a.rowsum_w[n0 + wn * 32 + (lane & 31)];
         rsw[1] = a.rowsum_w2[n0 + wn * 32 + (lane & 31)];
       }
-      const float as = __builtin_fabsf(a.out_scale[0]);
-      if (as > 0x1p-40f && as < 0x1p40f) mlp_epilogue16_body<true>(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table);
-      else mlp_epilogue16_body<false>(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table);
+      mlp_epilogue16_body(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table);
     } else {
       gemm256_epilogue_slabs16<TOut, REQUANT, WOFF>(a, acc, scratch, wave, lane, wm, wn, m0, n0);
     }
