@@ -47,67 +47,9 @@
 #define FFQ_WL_CLUSTER_MODE 0  // how a conversion cluster mixes its VALU work with its MFMAs: 0 = the compiler's choice, 1 = three / 2 = two VALU behind each MFMA
 #endif
 
+#include "ffq_wq.h"
+
 namespace ffq {
-
-typedef int wl_v4i __attribute__((ext_vector_type(4)));
-typedef unsigned int wl_v4u __attribute__((ext_vector_type(4)));
-typedef float wl_v4f __attribute__((ext_vector_type(4)));
-typedef __bf16 wl_v8bf __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) void wl_lds_t;
-typedef __attribute__((address_space(1))) const void wl_gbl_t;
-
-constexpr int WL_BM = 256, WL_BN = 256, WL_BK = 64;
-constexpr int WL_IMAGE = 256 * 128;            // one operand image: 256 rows x 128 bytes
-constexpr int WL_SLOT = 2 * WL_IMAGE;          // A image then B image: 64 KiB
-constexpr int WL_GROUP_M = 8;
-constexpr size_t WL_UNIT_SLAB = (size_t)32 * 8 * 64 * 16;  // split-K: one unit's partial accumulators, [32 pieces][8][64 lanes] x 16 B = 256 KiB
-constexpr int64_t WL_TWO_PASS_MIN_TOKENS = 4096;  // from this many tokens on, A2 as its own pass + the bf16-image GEMM
-
-enum { WL_B_BF16 = 0, WL_B_I8 = 1, WL_B_I4 = 2 };
-
-struct WLinearArgs {
-  const uint8_t* x;       // [M, K] bf16
-  const uint8_t* w;       // WL_B_BF16: [N, K] bf16; WL_B_I8: [N, K] int8 codes; WL_B_I4: [N, K / 2] packed nibbles
-  const float* w_scale;   // [N * groups] (or [1])
-  const float* w_offset;  // same shape, or NULL
-  const void* bias; int bias_dt;
-  void* out; int out_dt;  // bf16 or f32
-  int M, N, K;
-  int groups;             // parameters per output channel along K (1 = per channel / per tensor)
-  int steps_per_group;    // super-steps of 64 that share one group
-  int per_row;            // 0: one parameter pair for the whole tensor
-  int pack_shift;         // WL_B_I4: log2(packing block)
-  int tiles_m, tiles_n, group_m;
-  int group_cols;  // 0: groups of `group_m` row tiles x all column tiles (the weight is re-streamed per group); 1: groups of `group_m` column tiles x all row tiles (the activations are)
-  // MLP mode (ffq_mlp_gate_up_wq): `w` / `w_scale` / `w_offset` describe gate_proj, these up_proj; N = rows of each = output columns
-  const uint8_t* w2;
-  const float* w_scale2;
-  const float* w_offset2;
-  // split-K (fewer tiles than CUs): a work unit is (tile, slice of the K range), `split` slices per tile, all units of the launch
-  // resident at once; the units of a tile exchange partial accumulators through `slabs` and each finishes a share of the tile
-  // (kernel epilogue). `tickets`: two counters per tile (arrived, left), zero on entry and on exit
-  // several weight matrices side by side along N in ONE launch (q / k / v of an attention block: the same activations, three
-  // weight tensors, three outputs): column tiles [0, seg_tile[0]) belong to matrix 0, [seg_tile[0], seg_tile[1]) to matrix 1, the
-  // rest to matrix 2; every matrix but the last has a multiple of 256 rows. `w` / `w_scale` / `w_offset` / `out` / `N` describe
-  // matrix 0 (N = ALL columns for the tile walk); 1 and 2 below. Plain mode only.
-  int seg_tile[2];
-  const uint8_t* seg_w[2]; const float* seg_scale[2]; const float* seg_offset[2]; void* seg_out[2];
-  int seg_n[3];  // rows (output columns) of each matrix
-  int split;
-  int full_tiles;  // tiles [0, full_tiles) of the walk order are whole units (a multiple of the grid: every block gets the same count);
-                   // the TAIL tiles [full_tiles, total) are cut into `split` slices each, at most one such unit per block, every block's last
-  float* slabs;
-  int* tickets;
-};
-
-// 4 codes in the bytes of `w` (signed bytes; for nibbles: 16 * code, see the header) -> 4 bf16 of (float(b) + c) * s
-template <bool OFFSET>
-__device__ __forceinline__ void dequantize4(uint32_t w, float s, float c, uint32_t& lo, uint32_t& hi) {
-  float f0 = (float)(int)(int8_t)(w), f1 = (float)(int)(int8_t)(w >> 8), f2 = (float)(int)(int8_t)(w >> 16), f3 = (float)(int)(int8_t)(w >> 24);
-  if constexpr (OFFSET) { f0 = f0 + c; f1 = f1 + c; f2 = f2 + c; f3 = f3 + c; }
-  lo = pack2<bf16_t>(f0 * s, f1 * s);
-  hi = pack2<bf16_t>(f2 * s, f3 * s);
-}
 
 // MLP: the B tile holds 128 gate_proj rows and the same 128 up_proj rows, interleaved in runs of 32 so that a wave's column tiles
 // nj = 0, 1 are gate and nj + 2 up of the SAME 32 output columns; the epilogue writes bf16(silu(bf16(gate))) * bf16(up) — exactly
@@ -1047,7 +989,7 @@ extern "C" int ffq_linear_wq_supported(int x_dt, int w_dt, int out_dt, int64_t M
 // the fp32 summation order, hence the result's last bit, depends on it. Cost model in units of one 64-deep super-step
 // (tools/wq_split_sweep.py): steps(S) + exchange, the exchange ~ a fixed synchronisation cost + the slab traffic of a unit,
 // which scales with the rows of the tile that exist.
-static int wq_cus() {
+int ffq::wq_cus() {
   static int cached[64] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
@@ -1093,8 +1035,14 @@ static int wq_split(int64_t M, int64_t N, int64_t K, bool mlp) {
   return best;
 }
 
+// M <= 128 rows, plain launches: the skinny form's plan (ffq_wskinny.hip) — unless the test hook selects the 256-row-tile kernel
+static bool wq_plan_is_skinny(int64_t M, int64_t K, int mlp) {
+  return !mlp && !generic_kernels_forced() && wq_skinny_tickets(M, 128, K) > 0;
+}
+
 extern "C" int64_t ffq_linear_wq_split(int64_t M, int64_t N, int64_t K, int mlp) {
   if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 1;
+  if (wq_plan_is_skinny(M, K, mlp)) return wq_skinny_split(M, N, K);
   return wq_split(M, N, K, mlp != 0);
 }
 
@@ -1102,12 +1050,14 @@ extern "C" int64_t ffq_linear_wq_split(int64_t M, int64_t N, int64_t K, int mlp)
 // zero by every launch — a caller keeps ONE zeroed buffer per stream and never touches it
 extern "C" int64_t ffq_linear_wq_tickets(int64_t M, int64_t N, int64_t K, int mlp) {
   if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 0;
+  if (wq_plan_is_skinny(M, K, mlp)) return wq_skinny_tickets(M, N, K);
   return 2 * wq_tail_tiles(M, N, mlp != 0);
 }
 
 // bytes of partial-sum slabs a launch with `split` K slices per tail tile needs at the front of its workspace (0: none)
 extern "C" size_t ffq_linear_wq_slab_bytes(int64_t M, int64_t N, int64_t K, int mlp, int64_t split) {
   if (M <= 0 || N <= 0 || K < 2 * WL_BK || split <= 1) return 0;
+  if (wq_plan_is_skinny(M, K, mlp)) return wq_skinny_slab_bytes(M, N, K, split);
   return (size_t)wq_tail_tiles(M, N, mlp != 0) * (size_t)split * WL_UNIT_SLAB;
 }
 
@@ -1120,6 +1070,7 @@ static size_t wq_slab_bytes(int64_t M, int64_t N, int split, bool mlp) {
 // that does not fit (no split / conversion inside the GEMM) — never fails for lack of scratch.
 extern "C" size_t ffq_linear_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 0;
+  if (wq_plan_is_skinny(M, K, 0)) return wq_skinny_slab_bytes(M, N, K, wq_skinny_split(M, N, K));
   return wq_slab_bytes(M, N, wq_split(M, N, K, false), false) + (M >= WL_TWO_PASS_MIN_TOKENS ? (size_t)N * (size_t)K * 2u : 0);
 }
 
@@ -1241,6 +1192,8 @@ static int wq_linear_impl(const void* x, int x_dt, int count, const void* const*
   if (const char* gc = getenv("FFQ_WQ_GROUP_COLS")) a.group_cols = atoi(gc);
 #endif
   const bool grouped = groups > 1, offset = w_offset[0] != nullptr;
+  // few rows: the contraction is a stream over the codes, bounded by HBM — 16-row MFMA tiles, no padding to 256 rows (ffq_wskinny.hip)
+  if (wq_skinny_applies(a, pack_block)) return wq_skinny_launch(a, w_dt, pack_block, group, split, workspace, workspace_bytes, tickets, s);
   int rc_split;
   const size_t slab_bytes = wq_resolve_split(a, split, false, workspace, workspace_bytes, tickets, &rc_split);
   if (rc_split != FFQ_OK) return rc_split;

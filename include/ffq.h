@@ -263,6 +263,15 @@ int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, const
  *   split      0 = the library's plan; >= 1 forces that many slices (tests, tuning): ffq_linear_wq_slab_bytes(..., split) bytes
  *              of workspace; FFQ_ERR_ARG if that scratch is missing or the units of the last round would not all fit the chip
  *              at once (they wait for each other: tail tiles * split <= CUs).
+ * Few rows (ABI 8, M <= 128 with K % 256 == 0, or K % 128 == 0 for M <= 16 and M > 64; int8 containers and nibbles packed with block
+ * 128): the contraction is a STREAM over the codes and takes its own kernel (csrc/ffq_wskinny.hip) — 16-row MFMA tiles, the codes
+ * straight from HBM into the MFMA's register layout, no padding to 256 rows. Up to 16 rows a block owns 16 output columns for the
+ * whole contraction (its eight waves share K); above that a block owns 128 columns of one K slice and the slices meet through
+ * `workspace` / `tickets`: every wave takes a ticket for its strip and the LAST one to arrive adds the partial sums in slice order —
+ * nobody waits for anybody. The plan queries below describe whichever kernel the launch takes (same arguments, same meaning).
+ * Summation order: the fp32 order of a contraction — hence the last bit of an output — is a function of (M, N, K, CU count, split,
+ * kernel): bit-reproducible launch to launch, equal across the storage forms that share a kernel, NOT equal across batch sizes or
+ * across the kernels (every route stays within one output rounding of the float64 product of the same operands).
  * ffq_linear_wq_supported() == 0 (K % 64 != 0, K < 128, other dtypes, group % 64 != 0): the caller dequantizes (A2) and
  * runs a float GEMM, as the reference does.
  */
