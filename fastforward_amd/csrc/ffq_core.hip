@@ -200,9 +200,12 @@ int ffq_dequantize_result_dtype(int data_dt, int scale_dt, int offset_dt, int ha
 // ---- test hook: kernel-family selection (no environment variables in the product) ------------------------------------------
 namespace ffq {
 static int g_force_generic = 0;
-bool generic_kernels_forced() { return __atomic_load_n(&g_force_generic, __ATOMIC_RELAXED) != 0; }
+bool generic_kernels_forced() { return (__atomic_load_n(&g_force_generic, __ATOMIC_RELAXED) & 1) != 0; }
+bool splitk_abandon_forced() { return (__atomic_load_n(&g_force_generic, __ATOMIC_RELAXED) & 2) != 0; }
 }  // namespace ffq
 
+// bit 0: the generic kernel families; bit 1: every odd K slice of a split-K tile gives up waiting for its peers at once (the
+// path a unit takes when its peers cannot become resident: include/ffq.h, ffq_linear_wq)
 extern "C" int ffq_force_generic_kernels(int on) {
-  return __atomic_exchange_n(&ffq::g_force_generic, on ? 1 : 0, __ATOMIC_RELAXED);
+  return __atomic_exchange_n(&ffq::g_force_generic, on & 3, __ATOMIC_RELAXED);
 }

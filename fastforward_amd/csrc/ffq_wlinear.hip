@@ -553,16 +553,20 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
     // for tile (mi, nj), register t: row m = 16 mi + l % 16, column n = 16 nj + 4 (l / 16) + t — four consecutive output
     // columns of one row.
     __syncthreads();
-    // ---- split-K: the `split` units of a tile run CONCURRENTLY (the launcher admits a split only when all units fit the chip in
-    // one round: one block per CU, every block exactly one unit) and exchange partial sums all-to-all. A wave's accumulators
-    // are four PIECES (row-tile pairs i = 0..3: the rounds of the epilogue below); piece (wave, i) is finished by the unit
-    // `(4 wave + i) % split`: every other unit stores its partial piece to its own slab — register layout, [piece][8][lane] x 16 B,
-    // one dense KiB per wave instruction, WRITE-THROUGH (sc1: a release fence would write back the whole L2, CDNA guide
-    // "publish-large"); the block counts itself in (`arrived`), waits until every unit of the tile is in, and every wave adds the
-    // peers' partials of ITS pieces in slice order to the partial it kept: each piece has one fixed finisher and one fixed
-    // summation order — results do not depend on timing. Units count themselves out (`left`) after reading; the last one
-    // zeroes both counters for the next launch. Pieces beyond M are skipped by everybody. The only wait is for blocks that
-    // are resident by construction; it is bounded and traps instead of hanging.
+    // ---- split-K: the `split` units of a tile normally run CONCURRENTLY (the launcher admits a split only while all units fit the
+    // chip in one round) and exchange partial sums all-to-all. A wave's accumulators are four PIECES (row-tile pairs i = 0..3: the
+    // rounds of the epilogue below); piece (wave, i) is FINISHED by the unit `(4 wave + i) % split`: every other unit stores its
+    // partial piece to its own slab — register layout, [piece][8][lane] x 16 B, one dense KiB per wave instruction, WRITE-THROUGH
+    // (sc1: a release fence would write back the whole L2, CDNA guide "publish-large") — counts itself in, waits until every unit of
+    // the tile is in, and every wave adds the peers' partials of ITS pieces to the partial it kept, the owner's own first, then the
+    // others in slice order: each piece has one fixed summation order — results do not depend on timing.
+    // Nobody depends on that wait (round 5; ADVICE r4: a peer that cannot become resident — another kernel, another process, a CU
+    // mask holding its CU — made the old form spin for minutes and trap). The tile's state is ONE 64-bit word
+    // [abandoned-slice mask : 32 | arrived : 8 | left : 8]: a unit whose wait runs out publishes the pieces it OWNS as well, sets
+    // its mask bit and exits, which frees its CU; if the atomic OR still finds fewer than `split` arrivals, the unit that arrives
+    // LAST is guaranteed to see the bit (its own arrival RMW comes later in the word's modification order) and finishes the
+    // abandoned unit's pieces from the slabs in that piece's canonical order — the same bits as the symmetric exchange; if the
+    // OR finds everybody arrived, the unit simply carries on. The last unit to leave zeroes the word for the next launch.
     uint32_t own = 0xFu;  // bit i: this wave finishes piece i (wave-uniform)
     if (tile_no >= 0) {
       const int S = a.split;
@@ -571,35 +575,17 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
       own = 0;
       uint8_t* const tile_slabs = reinterpret_cast<uint8_t*>(a.slabs) + (size_t)tile_no * (size_t)S * WL_UNIT_SLAB;
       const auto mine = __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)slice * WL_UNIT_SLAB, 0, (int)WL_UNIT_SLAB, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (2 * i >= mi_cnt) continue;
-        if ((wave * 4 + i) % S == slice) { own |= 1u << i; continue; }
+      auto publish_piece = [&](int i) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wl_v4u, acc[2 * i + (q >> 2)][q & 3]), mine, (((wave * 4 + i) * 8 + q) * 64 + lane) * 16, 0, /*sc1*/ 16);
-      }
-      // every storing wave drains its write-through stores, the block meets, ONE lane counts the unit in and waits until all
-      // `split` units of the tile are in (one poller per block: many pollers on one word cost chip bandwidth, CDNA guide
-      // "polling-cost"). The partials are then read with sc1 loads, which bypass this CU's L1 (the L2 cannot hold these lines:
-      // it is invalidated at kernel start and every slab line is written once and read once per launch) — no fence needed.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        int* const arrived = a.tickets + 2 * tile_no;
-        __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (uint32_t spins = 0; __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S; ++spins) {
-          __builtin_amdgcn_s_sleep(4);
-          if (spins > (1u << 27)) __builtin_trap();  // ~10 s: a peer that never became resident
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {  // one piece (2 row tiles x 4 column tiles) of one peer in flight: 8 loads; peers added in slice order
-        if (!((own >> i) & 1u)) continue;
+      };
+      // piece i of this wave <- the S partials in the slabs: `first` (its owner), then the others in slice order; `keep` = the
+      // owner's partial is already in the registers (the owner itself is summing)
+      auto gather_piece = [&](int i, int first, bool keep) {
         const uint32_t piece_off = (uint32_t)(((wave * 4 + i) * 8) * 64 + lane) * 16u;
-        for (int sp = 0; sp < S; ++sp) {
-          if (sp == slice) continue;
+        for (int step = keep ? 1 : 0; step < S; ++step) {
+          const int sp = step == 0 ? first : (step - 1 < first ? step - 1 : step);  // first, 0, 1, .., first - 1, first + 1, ..
           const auto peer = __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)sp * WL_UNIT_SLAB, 0, (int)WL_UNIT_SLAB, 0x00020000);
           wl_v4u got[8];
 #pragma unroll
@@ -608,7 +594,75 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
           for (int q = 0; q < 8; ++q) {
             const wl_v4f g = __builtin_bit_cast(wl_v4f, got[q]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[2 * i + (q >> 2)][q & 3][e] = acc[2 * i + (q >> 2)][q & 3][e] + g[e];
+            for (int e = 0; e < 4; ++e) acc[2 * i + (q >> 2)][q & 3][e] = step == 0 ? g[e] : acc[2 * i + (q >> 2)][q & 3][e] + g[e];
+          }
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (2 * i >= mi_cnt) continue;
+        if ((wave * 4 + i) % S == slice) { own |= 1u << i; continue; }
+        publish_piece(i);
+      }
+      // every storing wave drains its write-through stores, the block meets, ONE lane counts the unit in and polls (one poller
+      // per block: many pollers on one word cost chip bandwidth, CDNA guide "polling-cost"). The partials are read with sc1 loads,
+      // which bypass this CU's L1 (the L2 cannot hold these lines: it is invalidated at kernel start and every slab line is
+      // written once and read once per launch).
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      unsigned long long* const state = reinterpret_cast<unsigned long long*>(a.tickets + 2 * tile_no);
+      constexpr unsigned long long kArrive = 1ull << 32;  // (the `left` field: 1ull << 40, below)
+      // two words at the end of the slot just consumed (the epilogue's regions end below 40 KiB of it; the other slot may still receive
+      // the trailing pieces of the DMA stream): [0]: 1 = everybody is in, 3 = the wait ran out; [1]: abandoned slices seen by the last arriver
+      int* const verdict = reinterpret_cast<int*>(lds + (slot ^ 1) * WL_SLOT + WL_SLOT - 16);
+      if (tid == 0) {
+        const unsigned long long old = __hip_atomic_fetch_add(state, kArrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int v = 1;
+        uint32_t seen = 0;
+        if ((int)((old >> 32) & 0xFFu) + 1 == S) {
+          seen = (uint32_t)old;  // the last to arrive: whoever gave up is known now, nobody can give up later
+        } else {
+          // ~0.25 ms of polling (an L2 round trip + s_sleep per poll): two orders of magnitude beyond a healthy exchange
+          const uint32_t budget = a.abandon_test ? ((slice & 1) ? 0u : (1u << 20)) : 256u;
+          uint32_t spins = 0;
+          while ((int)((__hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) & 0xFFu) < S) {
+            if (spins++ >= budget) { v = 3; break; }
+            __builtin_amdgcn_s_sleep(8);
+          }
+        }
+        verdict[0] = v;
+        verdict[1] = (int)seen;
+      }
+      __syncthreads();
+      int v = verdict[0];
+      const uint32_t seen = (uint32_t)verdict[1];
+      __syncthreads();  // verdict is re-written below
+      if (v == 3) {  // give up: the owned pieces go to the slab as well, then the mask bit
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if ((own >> i) & 1u) publish_piece(i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          const unsigned long long old = __hip_atomic_fetch_or(state, 1ull << slice, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          verdict[0] = (int)((old >> 32) & 0xFFu) == S ? 1 : 2;  // everybody came in meanwhile: nobody will cover for this unit, carry on
+        }
+        __syncthreads();
+        v = verdict[0];
+        if (v == 2) own = 0;  // abandoned: the last arriver finishes this unit's pieces; nothing left to do but to leave
+      }
+      if (v == 1) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if ((own >> i) & 1u) gather_piece(i, slice, true);
+        if (seen) {  // the last arriver covers for the units that gave up
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int owner = (wave * 4 + i) % S;
+            if (2 * i >= mi_cnt || owner == slice || !((seen >> owner) & 1u)) continue;
+            gather_piece(i, owner, false);
+            own |= 1u << i;
           }
         }
       }
@@ -715,12 +769,10 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
       }
     }
     __syncthreads();  // the scratch slot is the next tile's staging target
-    if (tile_no >= 0 && tid == 0) {  // every wave of this block has read its peers' pieces (the barrier above): count the unit out
-      int* const arrived = a.tickets + 2 * tile_no;
-      if (__hip_atomic_fetch_add(arrived + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.split - 1) {
-        __hip_atomic_store(arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(arrived + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+    if (tile_no >= 0 && tid == 0) {  // every wave of this block is done with the slabs (the barrier above): count the unit out
+      unsigned long long* const state = reinterpret_cast<unsigned long long*>(a.tickets + 2 * tile_no);
+      const unsigned long long old = __hip_atomic_fetch_add(state, 1ull << 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)((old >> 40) & 0xFFu) == a.split - 1) __hip_atomic_store(state, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next launch
     }
     m0 = nm0; n0 = nn0; k0 = nk0; k1 = nk1; tile_no = ntile_no; slice = nslice; seg = nseg;
   }
@@ -1093,6 +1145,7 @@ static size_t wq_resolve_split(WLinearArgs& a, int64_t split_request, bool mlp, 
   a.full_tiles = (int)(split > 1 ? tiles - wq_tail_tiles(a.M, a.N, mlp) : tiles);
   a.slabs = split > 1 ? static_cast<float*>(workspace) : nullptr;
   a.tickets = split > 1 ? tickets : nullptr;
+  a.abandon_test = splitk_abandon_forced() ? 1 : 0;
   return slab;
 }
 

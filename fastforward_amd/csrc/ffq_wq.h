@@ -55,6 +55,7 @@ struct WLinearArgs {
                    // the TAIL tiles [full_tiles, total) are cut into `split` slices each, at most one such unit per block, every block's last
   float* slabs;
   int* tickets;
+  int abandon_test;  // test hook: odd slices give up their wait immediately (splitk_abandon_forced)
 };
 
 // 4 codes in the bytes of `w` (signed bytes; for nibbles: 16 * code, see the header) -> 4 bf16 of (float(b) + c) * s

@@ -983,6 +983,15 @@ def test_weight_only_linear_split_k_slices_sum_in_a_fixed_order(m, n, k, group, 
             assert torch.equal(ops.linear_wq(x, packed, scale, off, group=group, pack_block=128, split=split), y), f"split {split}: packed nibbles differ"
         y32 = ops.linear_wq(x, codes, scale, off, group=group, split=split, out_dtype=torch.float32)
         assert torch.equal(y32.to(torch.bfloat16), y), f"split {split}: fp32 output rounds to something else"
+        if split > 1:
+            # units that give up their wait (a peer that cannot become resident; here: every odd slice, at once, through the library's
+            # test hook) publish all their pieces and leave; the last arriver finishes them in the same order: the same bits
+            previous = lib.ffq_force_generic_kernels(2 | int(m <= 128))
+            try:
+                for _ in range(3):
+                    assert torch.equal(ops.linear_wq(x, codes, scale, off, group=group, split=split), y), f"split {split}: abandoned units change the result"
+            finally:
+                lib.ffq_force_generic_kernels(previous)
     assert all(int(t.abs().sum()) == 0 for t in ops._TICKETS.values()), "a launch left tickets behind"
     # order-independent sums: integer activations in [-4, 4], scales 2^-3, integer offsets -> every partial sum is exact in fp32
     xi = torch.randint(-4, 5, (m, k), generator=gen).to(torch.bfloat16).to(DEV)
