@@ -57,10 +57,18 @@ def install(device_types: Sequence[str] = ("cuda",), register_linear: bool = Tru
         "quantize_dynamic_by_tile_impl": ops.quantize_dynamic_by_tile,
         "quant_dequant_by_tile_grad_impl": ops.quantize_by_tile_backward,
     }
+    native = False
+    if ops.NATIVE_DISPATCH and tuple(device_types) == ("cuda",):
+        # the C++ dispatch-key kernels of libffq_torch.so under the reference's operator names: fastforward::* on a HIP tensor
+        # then runs dispatcher -> C++ -> C ABI (csrc/ffq_torch.cpp::ffq_torch_install_reference_kernels), no Python in between
+        import ctypes
+
+        native = ctypes.CDLL(str(ops.TORCH_EXTENSION_PATH)).ffq_torch_install_reference_kernels() >= 0
     for attr, fn in table.items():
         op_def = getattr(impl, attr)
-        for device_type in device_types:
-            op_def.register_kernel(device_type)(fn)
+        if not native:  # Python functions (ctypes -> C ABI) as the ops' device kernels
+            for device_type in device_types:
+                op_def.register_kernel(device_type)(fn)
         attached.append(f"fastforward::{op_def._opname if hasattr(op_def, '_opname') else attr}")
     if register_linear:
         hooks = REFERENCE_KERNELS.register_all(lambda name, predicate, kernel: ff.dispatcher.register(name, predicate, kernel), ff.dispatcher.Predicate)

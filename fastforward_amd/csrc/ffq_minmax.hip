@@ -292,6 +292,7 @@ __global__ __launch_bounds__(kBlock) void minmax_scalar_partial_kernel(const T* 
     }
     __syncthreads();
     if (!last_s) return;
+    asm volatile("" ::: "memory");  // the partial cells are read after the ticket said every block has published (reader side of the hand-over)
     MinMax r;
     r.init();
     for (uint32_t k = threadIdx.x; k < gridDim.x; k += kBlock) {  // agent-scope loads bypass this CU's L1

@@ -215,6 +215,11 @@ class LinearQuantizer(AbstractAffineQuantizer):
         with torch.no_grad():
             if not data.is_cuda:  # the fused entry exists for the device path; host tensors (oracle tests) take the two steps
                 return False
+            # a subclass that overrides the range setter or the parameter write (to clamp, log or keep derived state) must see
+            # every range: the fused entry writes scale / offset through raw pointers, so it is taken only when both are this class's own
+            cls = type(self)
+            if cls.quantization_range is not LinearQuantizer.quantization_range or cls._write_parameters_for_range is not LinearQuantizer._write_parameters_for_range:
+                return False
             if self.has_uninitialized_params:
                 self._initialize_parameters(running_min.numel())
             direct = (

@@ -119,6 +119,13 @@ def _prepare(*tensors: torch.Tensor | None):
     return lib, stream
 
 
+def _native_route(t: torch.Tensor) -> bool:
+    """True when the C++ dispatch-key kernels of libffq_torch.so serve this tensor: a HIP tensor, the extension loaded, and
+    the library in use the shipped one the extension is linked against (tools/ and tests may select another build or the oracle
+    through ``_native._LIB``: those go through ctypes, i.e. through whatever library that is)."""
+    return NATIVE_DISPATCH and t.is_cuda and (_native._LIB is None or _native._LIB.path == str(_native.LIBRARY_PATH))
+
+
 def _ptr(t: torch.Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 
@@ -202,14 +209,18 @@ def _workspace(nbytes: int, device: torch.device) -> torch.Tensor | None:
 
 
 # Arrival counters of the split-K launches (ffq_linear_wq / ffq_mlp_gate_up_wq, include/ffq.h): zero before the first launch,
-# left zero by every launch, so ONE buffer per (device, stream) serves every call enqueued on that stream — launches of one
-# stream run in order, and a hipGraph captured on it replays against the same (still zero) buffer.
+# left zero by every launch, so ONE buffer per (device, stream) serves every EAGER call enqueued on that stream — valid only for
+# launches serialised on that stream. Launches captured into a hipGraph get a buffer owned by that graph (below).
 _TICKETS: dict[tuple[str, int, int], torch.Tensor] = {}
 
 
 def _tickets(count: int, device: torch.device, stream: int, kind: str = "wq") -> torch.Tensor | None:
     if count <= 0:
         return None
+    if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        # a buffer of the graph's own (allocated from its pool, zeroed by a memset node of the capture): a graph replayed on another
+        # stream, or two graphs captured on one stream and replayed concurrently, must not share counters with eager launches
+        return torch.zeros(count, dtype=torch.int32, device=device)
     key = (kind, device.index if device.index is not None else torch.cuda.current_device(), int(stream or 0))
     have = _TICKETS.get(key)
     if have is None or have.numel() < count:
@@ -403,6 +414,15 @@ def running_minmax_step(
     A4 merged into `running_min` / `running_max` in place, then A5 of the merged range (the quantization_range setter,
     nn/linear_quantizer.py:350-357) written into `scale_out` / `offset_out` — what :func:`minmax_by_tile` with running
     buffers followed by :func:`parameters_for_range` gives, bit for bit; a per-tensor quantizer takes ONE launch."""
+    if _native_route(data):  # dispatcher -> C++ (csrc/ffq_torch.cpp) -> C ABI: 448 calls per calibration step of Llama-3-8B
+        torch.ops.fastforward_amd.running_minmax_step(data, list(tile_size), running_min, running_max, status_flags, float(num_bits), bool(symmetric),
+                                                      bool(allow_one_sided), scale_out, offset_out)
+        return
+    _running_minmax_step(data, tile_size, running_min, running_max, status_flags, num_bits, symmetric, allow_one_sided, scale_out, offset_out)
+
+
+def _running_minmax_step(data, tile_size, running_min, running_max, status_flags, num_bits, symmetric, allow_one_sided, scale_out, offset_out) -> None:  # type: ignore[no-untyped-def]
+    """Python implementation of the ``running_minmax_step`` operator (Python -> ctypes -> C ABI)."""
     data_c = data.detach().contiguous()
     lib, stream = _prepare(data_c, running_min, running_max, status_flags, scale_out, offset_out)
     tiling = _tile_of(data_c, tile_size)
@@ -667,6 +687,14 @@ def linear_w8a8(
     `out_dtype` — exactly ``quantize_by_tile(linear_w8a8(..., out_dtype=requant_from), out_scale, shape, bits, out_dtype,
     out_offset)`` without the real-valued tensor's round trip through HBM.
     """
+    if _native_route(x_codes):  # dispatcher -> C++ (csrc/ffq_torch.cpp) -> C ABI
+        return torch.ops.fastforward_amd.linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, bias, out_dtype, out_scale, out_offset,
+                                                     float(out_num_bits), w_rowsum, requant_from)
+    return _linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, bias, out_dtype, out_scale, out_offset, out_num_bits, w_rowsum, requant_from)
+
+
+def _linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, bias, out_dtype, out_scale, out_offset, out_num_bits, w_rowsum, requant_from):  # type: ignore[no-untyped-def]
+    """Python implementation of the ``linear_w8a8`` operator (Python -> ctypes -> C ABI); arguments in schema order."""
     if x_codes.dtype != torch.int8 or w_codes.dtype != torch.int8:
         raise TypeError("linear_w8a8 expects int8 codes")
     xc = x_codes.detach().contiguous()
@@ -721,6 +749,13 @@ def bmm_w8a8(
     """``torch.bmm`` on int8 codes in ONE launch: `x_codes` [B, M, K], `w_codes` [B, N, K] (the right operand K-contiguous),
     one parameter pair per operand (per-tensor quantizers) -> [B, M, N]; per matrix pair exactly :func:`linear_w8a8`, the output
     quantizer optionally in the epilogue (reference _gen/fallback.py:699-798: dequantize, bmm, output quantizer)."""
+    if _native_route(x_codes):
+        return torch.ops.fastforward_amd.bmm_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, out_dtype, out_scale, out_offset, float(out_num_bits), requant_from)
+    return _bmm_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, out_dtype, out_scale, out_offset, out_num_bits, requant_from)
+
+
+def _bmm_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, out_dtype, out_scale, out_offset, out_num_bits, requant_from):  # type: ignore[no-untyped-def]
+    """Python implementation of the ``bmm_w8a8`` operator; arguments in schema order."""
     if x_codes.dtype != torch.int8 or w_codes.dtype != torch.int8 or x_codes.dim() != 3 or w_codes.dim() != 3:
         raise TypeError("bmm_w8a8 expects int8 codes of shape [B, M, K] and [B, N, K]")
     xc, wc = x_codes.detach().contiguous(), w_codes.detach().contiguous()
@@ -792,6 +827,18 @@ def linear_wq(
     lib = _native.library()
     if not lib.ffq_linear_wq_supported(_tag(x.dtype), _tag(w_codes.dtype), _tag(out_dtype), M, N, K, group, int(pack_block)):
         return None
+    if _native_route(x):  # dispatcher -> C++ (csrc/ffq_torch.cpp) -> C ABI
+        return torch.ops.fastforward_amd.linear_wq(x, w_codes, w_scale, w_offset, group, bias, out_dtype, int(pack_block), -1 if two_pass is None else int(bool(two_pass)), int(split))
+    return _linear_wq(x, w_codes, w_scale, w_offset, group, bias, out_dtype, int(pack_block), -1 if two_pass is None else int(bool(two_pass)), int(split))
+
+
+def _linear_wq(x, w_codes, w_scale, w_offset, group, bias, out_dtype, pack_block, two_pass, split):  # type: ignore[no-untyped-def]
+    """Python implementation of the ``linear_wq`` operator for a problem the kernel covers; arguments in schema order
+    (`two_pass`: -1 = the library's rule, 0 = never, 1 = offer the image's scratch whatever M)."""
+    K = x.shape[-1]
+    N = w_codes.numel() * 2 // K if pack_block > 0 else w_codes.shape[0]
+    M = x.numel() // K
+    two_pass = None if two_pass < 0 else bool(two_pass)
     xc, wc = x.detach().contiguous(), w_codes.detach().contiguous()
     sc = w_scale.detach().reshape(-1).to(torch.float32).contiguous()
     of = None if w_offset is None else w_offset.detach().reshape(-1).to(torch.float32).contiguous()
@@ -1241,6 +1288,28 @@ _LIBRARY.define(
     "quantize_by_tile_backward(Tensor data, Tensor output_grad, Tensor scale, SymInt[] tile_size, "
     "float num_bits, Tensor? offset=None) -> Tensor[]"
 )
+# ... and the hot entry points behind the dispatcher and the range estimator as operators of the same library (round 5), so that
+# they too have C++ device kernels (csrc/ffq_torch.cpp); the Python bodies stay registered and serve whenever the extension is absent
+_LIBRARY.define(
+    "running_minmax_step(Tensor data, SymInt[] tile_size, Tensor(a!) running_min, Tensor(b!) running_max, Tensor(c!)? status_flags, "
+    "float num_bits, bool symmetric, bool allow_one_sided, Tensor(d!) scale_out, Tensor(e!)? offset_out) -> ()"
+)
+_LIBRARY.define(
+    "linear_w8a8(Tensor x_codes, Tensor w_codes, Tensor x_scale, Tensor? x_offset, Tensor w_scale, Tensor? w_offset, Tensor? bias, "
+    "ScalarType out_dtype, Tensor? out_scale, Tensor? out_offset, float out_num_bits, Tensor? w_rowsum, ScalarType? requant_from) -> Tensor"
+)
+_LIBRARY.define(
+    "bmm_w8a8(Tensor x_codes, Tensor w_codes, Tensor x_scale, Tensor? x_offset, Tensor w_scale, Tensor? w_offset, ScalarType out_dtype, "
+    "Tensor? out_scale, Tensor? out_offset, float out_num_bits, ScalarType? requant_from) -> Tensor"
+)
+_LIBRARY.define(
+    "linear_wq(Tensor x, Tensor w_codes, Tensor w_scale, Tensor? w_offset, int group, Tensor? bias, ScalarType out_dtype, int pack_block, "
+    "int two_pass, int split) -> Tensor"
+)
+_LIBRARY.impl("running_minmax_step", _running_minmax_step, "CompositeExplicitAutograd")
+_LIBRARY.impl("linear_w8a8", _linear_w8a8, "CompositeExplicitAutograd")
+_LIBRARY.impl("bmm_w8a8", _bmm_w8a8, "CompositeExplicitAutograd")
+_LIBRARY.impl("linear_wq", _linear_wq, "CompositeExplicitAutograd")
 _LIBRARY.impl("quantize_by_tile", quantize_by_tile, "CompositeExplicitAutograd")
 _LIBRARY.impl("dequantize_by_tile", dequantize_by_tile, "CompositeExplicitAutograd")
 _LIBRARY.impl("quantize_dynamic_by_tile", quantize_dynamic_by_tile, "CompositeExplicitAutograd")
@@ -1284,16 +1353,33 @@ def _meta_quantize_by_tile_backward(data, output_grad, scale, tile_size, num_bit
     return [torch.empty(data.shape, dtype=data.dtype, device=data.device), torch.empty_like(scale), doffset]
 
 
+def _meta_linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, bias, out_dtype, out_scale, out_offset, out_num_bits, w_rowsum, requant_from):  # type: ignore[no-untyped-def]
+    return torch.empty((*x_codes.shape[:-1], w_codes.shape[0]), dtype=out_dtype, device=x_codes.device)
+
+
+def _meta_bmm_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, out_dtype, out_scale, out_offset, out_num_bits, requant_from):  # type: ignore[no-untyped-def]
+    return torch.empty((x_codes.shape[0], x_codes.shape[1], w_codes.shape[1]), dtype=out_dtype, device=x_codes.device)
+
+
+def _meta_linear_wq(x, w_codes, w_scale, w_offset, group, bias, out_dtype, pack_block, two_pass, split):  # type: ignore[no-untyped-def]
+    n = w_codes.numel() * 2 // x.shape[-1] if pack_block > 0 else w_codes.shape[0]
+    return torch.empty((*x.shape[:-1], n), dtype=out_dtype, device=x.device)
+
+
+_LIBRARY.impl("running_minmax_step", lambda *args: None, "Meta")
+_LIBRARY.impl("linear_w8a8", _meta_linear_w8a8, "Meta")
+_LIBRARY.impl("bmm_w8a8", _meta_bmm_w8a8, "Meta")
+_LIBRARY.impl("linear_wq", _meta_linear_wq, "Meta")
 _LIBRARY.impl("quantize_by_tile", _meta_quantize_by_tile, "Meta")
 _LIBRARY.impl("dequantize_by_tile", _meta_dequantize_by_tile, "Meta")
 _LIBRARY.impl("quantize_dynamic_by_tile", _meta_quantize_dynamic_by_tile, "Meta")
 _LIBRARY.impl("quantize_by_tile_backward", _meta_quantize_by_tile_backward, "Meta")
 
 
-# The two static operators also have C++ device kernels (csrc/ffq_torch.cpp -> csrc/libffq_torch.so, registered for the HIP
-# dispatch key): torch.ops.fastforward_amd.quantize_by_tile / dequantize_by_tile on a HIP tensor then run dispatcher -> C++ ->
-# the C ABI without entering the interpreter. Same library, same kernels, same results as the Python implementations above,
-# which stay registered (and serve when the extension is absent or FFQ_NO_TORCH_EXT=1 — they are the HIP path too).
+# Every operator above also has a C++ device kernel (csrc/ffq_torch.cpp -> csrc/libffq_torch.so, registered for the HIP
+# dispatch key): torch.ops.fastforward_amd.* on a HIP tensor then runs dispatcher -> C++ -> the C ABI without entering the
+# interpreter. Same library, same kernels, same results as the Python implementations above, which stay registered (and serve
+# when the extension is absent or FFQ_NO_TORCH_EXT=1 — they are the HIP path too).
 TORCH_EXTENSION_PATH = _native.LIBRARY_PATH.with_name("libffq_torch.so")
 
 

@@ -110,3 +110,31 @@ def test_dispatcher_hooks_serve_the_reference_operators(oracle_backend, tmp_path
             policy.__exit__(None, None, None)
         sys.path.remove(REFERENCE)
         sys.path.remove(str(tmp_path))
+
+
+def test_install_attaches_the_cpp_kernels_under_the_reference_operator_names(oracle_backend, tmp_path):
+    """adapter.install() for the device key: fastforward::* get the C++ dispatch-key kernels of libffq_torch.so (dispatcher -> C++ ->
+    C ABI), not Python functions — checked on the dispatch table (no GPU here); the host route of the reference's ops is untouched."""
+    shim = tmp_path / "optree"
+    shim.mkdir()
+    (shim / "__init__.py").write_text("from torch.utils._pytree import tree_map, tree_flatten, tree_unflatten, tree_leaves\n")
+    sys.path[:0] = [REFERENCE, str(tmp_path)]
+    try:
+        import fastforward as ff_ref
+
+        from fastforward_amd import adapter, ops
+
+        assert ops.NATIVE_DISPATCH
+        x = torch.randn(8, 16)
+        before = ff_ref.quantization.affine.quantize_per_tensor(x, 0.05, 1.0, 8)
+        attached = adapter.install(register_linear=False)
+        assert len(attached) == 4
+        for name in ("quantize_by_tile", "dequantize_by_tile", "quantize_dynamic_by_tile", "quantize_by_tile_backward"):
+            assert "CUDA: registered at ffq_torch.cpp" in torch._C._dispatch_dump(f"fastforward::{name}"), name
+        # host tensors never reach the device kernels (the reference's eager chain — or, after the tests above, the oracle-backed host hook)
+        after = ff_ref.quantization.affine.quantize_per_tensor(x, 0.05, 1.0, 8)
+        assert torch.equal(after.raw_data, before.raw_data)
+        adapter.install(register_linear=False)  # idempotent
+    finally:
+        sys.path.remove(REFERENCE)
+        sys.path.remove(str(tmp_path))
