@@ -257,30 +257,50 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
 
 
 def host_us_per_op(device: torch.device, calls: int = 1000) -> dict:
-    """Host cost of the op routes: `calls` eager A1 launches on a 256-element tensor, wall time per call with the device
-    drained before and after (the kernel itself is ~2 us). Through the operator registry the device kernel is C++
-    (csrc/ffq_torch.cpp: dispatcher -> C++ -> C ABI) when libffq_torch.so is loaded, else the Python implementation; the plain
-    ops.quantize_by_tile wrapper is Python -> ctypes -> C ABI either way."""
+    """Host cost of every operator of the seam on both routes: `calls` eager launches on tiny tensors (the kernels themselves are
+    ~2 us), wall time per call with the device drained before and after. "cpp" = torch.ops.fastforward_amd.* with the C++ dispatch-key
+    kernels of libffq_torch.so (dispatcher -> C++ -> C ABI; what ops.* and the quantizer modules take), "python" = the Python body
+    of the same operator (Python -> ctypes -> C ABI; what runs when the extension is absent)."""
+    o = torch.ops.fastforward_amd
     x = torch.randn(256, device=device, dtype=torch.bfloat16)
-    scale = torch.tensor([0.05], device=device)
-    out = {"native_dispatch": bool(ops.NATIVE_DISPATCH)}
-    registry = "dispatcher -> C++ (libffq_torch.so) -> C ABI" if ops.NATIVE_DISPATCH else "dispatcher -> python impl -> ctypes"
-    routes = {"ops.quantize_by_tile (python wrapper -> ctypes)": lambda: ops.quantize_by_tile(x, scale, (256,), 8, torch.int8),
-              f"torch.ops.fastforward_amd.quantize_by_tile ({registry})":
-                  lambda: torch.ops.fastforward_amd.quantize_by_tile(x, scale, [256], 8.0, torch.int8, None)}
-    for name, fn in routes.items():
-        try:
-            for _ in range(50):
-                fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(calls):
-                fn()
-            torch.cuda.synchronize()
-            out[name] = round((time.perf_counter() - t0) / calls * 1e6, 2)
-        except Exception as e:  # noqa: BLE001  (a schema detail must not cost the bench line)
-            out[name] = f"unavailable: {type(e).__name__}: {str(e)[:80]}"
-    out["calls"] = calls
+    x2 = torch.randn(16, 256, device=device, dtype=torch.bfloat16)
+    scale, scale16 = torch.tensor([0.05], device=device), torch.rand(16, device=device) * 0.05 + 0.01
+    lo, hi = torch.full((1,), float("inf"), dtype=torch.bfloat16, device=device), torch.full((1,), float("-inf"), dtype=torch.bfloat16, device=device)
+    s_out, o_out, flags = torch.empty(1, device=device), torch.empty(1, device=device), torch.zeros(1, dtype=torch.int32, device=device)
+    xq = torch.randint(-128, 128, (16, 256), device=device, dtype=torch.int8)
+    wq = torch.randint(-128, 128, (128, 256), device=device, dtype=torch.int8)
+    sw = torch.rand(128, device=device) * 1e-2 + 1e-3
+    ox = torch.tensor([3.0], device=device)
+    bf, i8 = torch.bfloat16, torch.int8
+    routes = {
+        "quantize_by_tile": (lambda: o.quantize_by_tile(x, scale, [256], 8.0, i8, None), lambda: ops.quantize_by_tile(x, scale, (256,), 8, i8)),
+        "dequantize_by_tile": (lambda: o.dequantize_by_tile(xq, scale16, [1, 256], None, bf), lambda: ops.dequantize_by_tile(xq, scale16, (1, 256), None, bf)),
+        "quantize_dynamic_by_tile": (lambda: o.quantize_dynamic_by_tile(x2, [1, 256], 8.0, False, True, i8), lambda: ops.quantize_dynamic_by_tile(x2, (1, 256), 8, False, True, i8)),
+        "quantize_by_tile_backward": (lambda: o.quantize_by_tile_backward(x2, x2, scale16, [1, 256], 8.0, None), lambda: ops.quantize_by_tile_backward(x2, x2, scale16, (1, 256), 8.0, None)),
+        "running_minmax_step": (lambda: o.running_minmax_step(x, [256], lo, hi, flags, 8.0, False, True, s_out, o_out),
+                                lambda: ops._running_minmax_step(x, (256,), lo, hi, flags, 8.0, False, True, s_out, o_out)),
+        "linear_w8a8": (lambda: o.linear_w8a8(xq, wq, scale, ox, sw, None, None, bf, None, None, 8.0, None, None),
+                        lambda: ops._linear_w8a8(xq, wq, scale, ox, sw, None, None, bf, None, None, 8.0, None, None)),
+        "bmm_w8a8": (lambda: o.bmm_w8a8(xq.view(1, 16, 256), wq.view(1, 128, 256), scale, ox, scale, None, bf, None, None, 8.0, None),
+                     lambda: ops._bmm_w8a8(xq.view(1, 16, 256), wq.view(1, 128, 256), scale, ox, scale, None, bf, None, None, 8.0, None)),
+        "linear_wq": (lambda: o.linear_wq(x2, wq, sw, None, 256, None, bf, 0, -1, 0), lambda: ops._linear_wq(x2, wq, sw, None, 256, None, bf, 0, -1, 0)),
+    }
+    out: dict = {"native_dispatch": bool(ops.NATIVE_DISPATCH), "calls": calls, "unit": "us per call, host side"}
+    for name, pair in routes.items():
+        row = {}
+        for label, fn in zip(("cpp" if ops.NATIVE_DISPATCH else "python via the registry", "python"), pair):
+            try:
+                for _ in range(50):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(calls):
+                    fn()
+                torch.cuda.synchronize()
+                row[label] = round((time.perf_counter() - t0) / calls * 1e6, 2)
+            except Exception as e:  # noqa: BLE001  (a schema detail must not cost the bench line)
+                row[label] = f"unavailable: {type(e).__name__}: {str(e)[:80]}"
+        out[name] = row
     return out
 
 

@@ -17,7 +17,7 @@ from typing import Any, Sequence
 
 import torch
 
-from fastforward_amd import _native
+from fastforward_amd import _host, _native
 from fastforward_amd._cabi import FFQ_MAX_BATCH, FLAG_INF, FLAG_NAN, DType, FanOut, RowsBatch, Tiling
 from fastforward_amd.exceptions import BackendError
 
@@ -110,13 +110,23 @@ def _prepare(*tensors: torch.Tensor | None):
     assert device is not None
     if device.type != "cuda":
         raise BackendError(
-            f"fastforward_amd runs on the HIP device only (tensor on '{device}'); there is no CPU "
-            "implementation. Move the tensors to 'cuda'."
+            f"fastforward_amd's kernels run on the HIP device only (tensor on '{device}'); there is no CPU "
+            "implementation of this entry point. Move the tensors to 'cuda'."
         )
     stream = torch.cuda.current_stream(device).cuda_stream
     if device.index is not None and device.index != torch.cuda.current_device():
         lib = _OnDevice(lib, device.index)
     return lib, stream
+
+
+_PRODUCT_PREPARE = _prepare  # (tests substitute `_prepare` to drive this module with the oracle on host memory: oracle/inject.py)
+
+
+def _host_route(t: torch.Tensor) -> bool:
+    """True for a tensor in HOST memory when the product's own library is in use: the operator then runs the reference's
+    device-agnostic ATen chain (``fastforward_amd/_host.py`` — BASELINE configs[0], the reference's default ``device="cpu"``).
+    Decided by the tensor's device alone: a HIP tensor never takes it, and a HIP tensor without the library still raises."""
+    return t.device.type == "cpu" and _prepare is _PRODUCT_PREPARE
 
 
 def _native_route(t: torch.Tensor) -> bool:
@@ -149,6 +159,8 @@ def quantize_by_tile(
     offset: torch.Tensor | None = None,
 ) -> torch.Tensor:
     """A1 — ``fastforward::quantize_by_tile`` (reference _quantizer_impl.py:144-169)."""
+    if _host_route(data):
+        return _host.quantize_by_tile(data.detach(), scale.detach(), tile_size, num_bits, output_dtype, None if offset is None else offset.detach())
     data_c = data.detach().contiguous()
     scale_c, offset_c = _flat(scale), _flat(offset)
     lib, stream = _prepare(data_c, scale_c, offset_c)
@@ -180,6 +192,8 @@ def dequantize_by_tile(
     output_dtype: torch.dtype | None = None,
 ) -> torch.Tensor:
     """A2 — ``fastforward::dequantize_by_tile`` (reference _quantizer_impl.py:172-190)."""
+    if _host_route(data):
+        return _host.dequantize_by_tile(data.detach(), scale.detach(), tile_size, None if offset is None else offset.detach(), output_dtype)
     data_c = data.detach().contiguous()
     scale_c, offset_c = _flat(scale), _flat(offset)
     lib, stream = _prepare(data_c, scale_c, offset_c)
@@ -240,6 +254,8 @@ def quantize_dynamic_by_tile(
     output_dtype: torch.dtype | None,
 ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """A3 — ``fastforward::quantize_dynamic_by_tile`` (reference _quantizer_impl.py:243-285)."""
+    if _host_route(data):
+        return _host.quantize_dynamic_by_tile(data.detach(), tile_size, num_bits, symmetric, allow_one_sided, output_dtype)
     data_c = data.detach().contiguous()
     lib, stream = _prepare(data_c)
     tiling = _tile_of(data_c, tile_size)
@@ -280,7 +296,8 @@ def quantize_by_tile_backward(
     :func:`_quantize_by_tile_backward_composite` (device tensor ops, same formulas).
     """
     fast = (
-        data.dtype == output_grad.dtype
+        not _host_route(data)  # host tensors: the composite below IS the reference's chain
+        and data.dtype == output_grad.dtype
         and data.dtype in (torch.float32, torch.bfloat16, torch.float16)
         and scale.dtype == torch.float32
         and (offset is None or offset.dtype == torch.float32)
@@ -362,6 +379,21 @@ def minmax_by_tile(
     for this batch so the caller can decide when to look at it; nothing here waits for the device.
     `into` = (min, max) buffers for THIS batch's extrema (overwritten, not merged).
     """
+    if _host_route(data):
+        lo, hi = _host.minmax_by_tile(data.detach(), tile_size)
+        if status_flags is not None:
+            flag = (FLAG_INF if bool(lo.isinf().any() or hi.isinf().any()) else 0) | (FLAG_NAN if bool(lo.isnan().any() or hi.isnan().any()) else 0)
+            status_flags.bitwise_or_(torch.tensor([flag], dtype=status_flags.dtype))
+        if running_min is not None:
+            assert running_max is not None
+            running_min.copy_(torch.min(running_min, lo.to(running_min.dtype)))  # torch.min / torch.max propagate NaN (minmax.py:236-237)
+            running_max.copy_(torch.max(running_max, hi.to(running_max.dtype)))
+            return running_min, running_max
+        if into is not None:
+            into[0].copy_(lo)
+            into[1].copy_(hi)
+            return into
+        return lo, hi
     data_c = data.detach().contiguous()
     lib, stream = _prepare(data_c, running_min, running_max, status_flags)
     tiling = _tile_of(data_c, tile_size)
@@ -414,6 +446,10 @@ def running_minmax_step(
     A4 merged into `running_min` / `running_max` in place, then A5 of the merged range (the quantization_range setter,
     nn/linear_quantizer.py:350-357) written into `scale_out` / `offset_out` — what :func:`minmax_by_tile` with running
     buffers followed by :func:`parameters_for_range` gives, bit for bit; a per-tensor quantizer takes ONE launch."""
+    if _host_route(data):
+        minmax_by_tile(data, tile_size, running_min=running_min, running_max=running_max, status_flags=status_flags)
+        parameters_for_range(running_min, running_max, num_bits, symmetric, allow_one_sided, scale_out, offset_out, want_offset=offset_out is not None)
+        return
     if _native_route(data):  # dispatcher -> C++ (csrc/ffq_torch.cpp) -> C ABI: 448 calls per calibration step of Llama-3-8B
         torch.ops.fastforward_amd.running_minmax_step(data, list(tile_size), running_min, running_max, status_flags, float(num_bits), bool(symmetric),
                                                       bool(allow_one_sided), scale_out, offset_out)
@@ -463,6 +499,16 @@ def parameters_for_range(
     (the reference returns None there and its range setter fills the buffer with 0).
     """
     mn, mx = _flat(min_range), _flat(max_range)
+    if _host_route(mn):
+        scale, offset = _host.parameters_for_range(mn, mx.to(mn.device), num_bits, symmetric, allow_one_sided)
+        if scale_out is None:
+            scale_out = torch.empty(mn.numel(), dtype=torch.float32)
+        scale_out.reshape(-1).copy_(scale)
+        if offset_out is None and want_offset:
+            offset_out = torch.empty(mn.numel(), dtype=torch.float32)
+        if offset_out is not None:  # the reference returns None for the symmetric two-sided branch; its range setter fills the buffer with 0
+            offset_out.reshape(-1).copy_(offset if offset is not None else torch.zeros_like(scale))
+        return scale_out, offset_out
     if mn.dtype != mx.dtype:
         common = torch.promote_types(mn.dtype, mx.dtype)
         mn, mx = mn.to(common), mx.to(common)

@@ -446,14 +446,18 @@ def test_flags_setters_return_restoring_contexts():
 
 
 def test_no_cpu_fallback_in_the_product(hip_lib):
-    """With the real library active, host tensors are refused loudly."""
+    """With the real library active the KERNEL entry points refuse host memory loudly: nothing of the device path ever computes on
+    the CPU. (Host tensors handed to the four operators / the estimator take the reference's own device-agnostic ATen chain,
+    fastforward_amd/_host.py — BASELINE configs[0]; tests/test_host_route.py.) A HIP tensor without the library raises BackendError."""
     from conftest import use_backend
 
     with use_backend(hip_lib):
         with pytest.raises(BackendError, match="no CPU"):
-            ff.quantization.affine.quantize_per_tensor(torch.randn(4), 0.1, None, 8)
+            ff.ops.linear_w8a8(torch.zeros(4, 64, dtype=torch.int8), torch.zeros(8, 64, dtype=torch.int8), torch.ones(1), None, torch.ones(8), None)
         with pytest.raises(BackendError):
-            ff.ops.minmax_by_tile(torch.randn(4), (4,))
+            ff.ops.pack_int4(torch.zeros(64, dtype=torch.int8), block=32)
+        with pytest.raises(BackendError):
+            ff.ops.add_rmsnorm_quantize(torch.zeros(2, 64, dtype=torch.bfloat16), None, torch.ones(64, dtype=torch.bfloat16), 1e-5, [])
 
 
 def test_fuse_qdq_weights_snaps_weights_and_is_idempotent(oracle_backend):
