@@ -471,6 +471,8 @@ def main() -> None:
     ap.add_argument("--cache-weight-codes", action="store_true", help="keep int8 weight codes across steps (NOT the headline: the reference re-quantizes)")
     ap.add_argument("--no-side-measurements", action="store_true", help="skip roofline / cpu_baseline legs")
     ap.add_argument("--batch-rowsums", action="store_true", help="A/B: weight row sums from the batched weight-quantization launch instead of one rowsum_i8 launch per linear (measured slower: llama.FusedForward)")
+    ap.add_argument("--layer-batched-weights", action="store_true", help="A/B: all seven weights of a layer re-quantized by one launch at the top of the layer (round 4's schedule) instead of group by group right before their GEMMs")
+    ap.add_argument("--fuse-rowsums", action="store_true", help="A/B: every weight re-quantized right before its GEMM by the one-pass codes + row sums kernel (no batched launch, no rowsum_i8 launches)")
     ap.add_argument("--force-dist", action="store_true", help="create the process group even for one rank: the range all-reduce and the cross-rank "
                     "check then run through the collective backend (RCCL with one rank executes the same all_reduce(MIN) an 8-GPU run issues)")
     args = ap.parse_args()
@@ -520,7 +522,7 @@ def main() -> None:
     ranges_identical, ranks_seen = ffd.ranges_agree_across_ranks(model)
     exchange = dict(ffd.last_exchange)
 
-    fused = None if args.module_graph else llama.FusedForward(model, cache_weight_codes=args.cache_weight_codes, batch_rowsums=args.batch_rowsums)
+    fused = None if args.module_graph else llama.FusedForward(model, cache_weight_codes=args.cache_weight_codes, batch_rowsums=args.batch_rowsums, fuse_rowsums=args.fuse_rowsums, just_in_time_weights=not args.layer_batched_weights)
 
     def forward():
         if fused is not None:

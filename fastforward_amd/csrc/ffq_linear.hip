@@ -56,6 +56,7 @@ struct LinearArgs {
   int M, N, K;
   int tiles_m, tiles_n;
   int group_m;  // row tiles per group of the persistent kernel's tile walk (A panels shared by a group's column tiles)
+  int group_cols;  // 1: the groups are `group_m` COLUMN tiles x all row tiles
   // MLP mode (gate and up projections in one launch): the second weight matrix
   const int8_t* wq2; const float* w_scale2; const int32_t* rowsum_w2;
   // batched matmul (ffq_bmm_w8a8, tail kernel only): blockIdx.y selects the matrix pair; element strides between consecutive matrices
@@ -559,11 +560,16 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   auto tile_origin = [&](int it, int& tm0, int& tn0) {
     const uint32_t tile_id = xcd_first + j_in_xcd + (uint32_t)it * blocks_in_xcd;
     const uint32_t gm = (uint32_t)a.group_m;
-    const uint32_t per_group = gm * (uint32_t)a.tiles_n;
+    // groups of `gm` row tiles x all column tiles (the weight is re-streamed per group), or — group_cols — `gm` column tiles x all
+    // row tiles (the activations are): the operand a group re-reads in full should be the one that fits the Infinity Cache
+    const uint32_t across = a.group_cols ? (uint32_t)a.tiles_m : (uint32_t)a.tiles_n;
+    const uint32_t along = a.group_cols ? (uint32_t)a.tiles_n : (uint32_t)a.tiles_m;
+    const uint32_t per_group = gm * across;
     const uint32_t group = tile_id / per_group, in_group = tile_id - group * per_group;
-    const uint32_t group_rows = min(gm, (uint32_t)a.tiles_m - group * gm);
-    tm0 = (int)(group * gm + in_group % group_rows) * BM2;
-    tn0 = (int)(in_group / group_rows) * BN_OUT;
+    const uint32_t group_size = min(gm, along - group * gm);
+    const uint32_t inner = group * gm + in_group % group_size, outer = in_group / group_size;
+    tm0 = (int)(a.group_cols ? outer : inner) * BM2;
+    tn0 = (int)(a.group_cols ? inner : outer) * BN_OUT;
   };
   // first byte of row `row0` of a K-contiguous matrix, as a value the compiler keeps in SGPRs: there is no scalar 64-bit
   // multiply, so the product is formed in vector registers once per tile and read back — everything the loop derives from it
@@ -833,6 +839,7 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t
   a.x_per_row = x_per_row; a.w_per_row = w_per_row;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.group_m = GROUP_M2;
+  a.group_cols = 0;
 
   int32_t* ws = static_cast<int32_t*>(workspace);
   const int64_t tiles256 = ((M + BM2 - 1) / BM2) * ((N + 255) / 256);
@@ -867,6 +874,9 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t
     // 8 row tiles per group; 4 for long contractions (down_proj, K = 14336: +3 %; A/B of 2 / 3 / 4 / 6 / 8 / 16 / 32 on one
     // box) — the group's A panels are 256 x K bytes each
     a.group_m = K >= 8192 ? 4 : GROUP_M2;
+#ifdef FFQ_I8_GROUP_COLS  // A/B builds (tools/build_variant.sh): column groups where the activation codes exceed ~200 MB
+    if ((size_t)M * (size_t)K > ((size_t)200 << 20)) { a.group_cols = 1; a.group_m = FFQ_I8_GROUP_COLS; }
+#endif
     const unsigned total = (unsigned)(a.tiles_m * a.tiles_n);
     const unsigned grid = total < 256u ? total : 256u;  // persistent: one block per CU
     const size_t lds = (size_t)2 * (BM2 + 256) * 128;
@@ -966,6 +976,7 @@ extern "C" int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_s
   a.x_per_row = 0; a.w_per_row = 0;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.group_m = GROUP_M2;
+  a.group_cols = 0;
   int32_t* ws = static_cast<int32_t*>(workspace);
   if (x_offset) {
     rowsum_i8_kernel<<<(unsigned)((batch * N + 3) / 4), 256, 0, s>>>(wq, (int)(batch * N), (int)K, ws + batch * M, nullptr);
@@ -1038,6 +1049,7 @@ extern "C" int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, con
   a.tiles_m = (int)((M + BM2 - 1) / BM2);
   a.tiles_n = (int)(N / 128);
   a.group_m = K >= 8192 ? 4 : GROUP_M2;
+  a.group_cols = 0;
   if (x_offset && have_sums) {
     a.rowsum_w = gate_rowsum; a.rowsum_w2 = up_rowsum;
   } else if (x_offset) {

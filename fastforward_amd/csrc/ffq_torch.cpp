@@ -129,7 +129,7 @@ void same_device(const at::Tensor& data, const at::Tensor& other) {
               data.device(), " and ", other.device(), "!");
 }
 
-at::Tensor flat(const at::Tensor& t) { return t.reshape({-1}).contiguous(); }
+at::Tensor flat(const at::Tensor& t) { return t.is_contiguous() ? t : t.reshape({-1}).contiguous(); }  // (pointer + numel() are what is read)
 
 void* stream_on(const at::Tensor& data) { return c10::hip::getCurrentHIPStream(data.device().index()).stream(); }
 
@@ -188,7 +188,12 @@ at::Tensor workspace(size_t nbytes, const at::Tensor& like) {
 }
 void* ptr(const at::Tensor& t) { return t.defined() ? t.data_ptr() : nullptr; }
 at::Tensor opt(const std::optional<at::Tensor>& t) { return t.has_value() && t->defined() ? *t : at::Tensor(); }
-at::Tensor f32_flat(const at::Tensor& t) { return t.defined() ? t.detach().reshape({-1}).to(at::kFloat).contiguous() : t; }
+// fp32 parameters as the C ABI reads them: a dense run of floats (only the pointer and numel() are used, so a contiguous fp32
+// tensor of any shape passes as it is: the common case costs no operator call)
+at::Tensor f32_flat(const at::Tensor& t) {
+  if (!t.defined() || (t.scalar_type() == at::kFloat && t.is_contiguous())) return t;
+  return t.reshape({-1}).to(at::kFloat).contiguous();
+}
 
 // The ticket words of the one-launch reductions and the split-K exchanges (include/ffq.h: zero before the first launch, left zero
 // by every launch): one buffer per (kind, device, stream) for eager launches, which are serialised on that stream; a launch
@@ -216,7 +221,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> quantize_dynamic_by_tile(const at
                                                                         bool symmetric, bool allow_one_sided,
                                                                         std::optional<at::ScalarType> output_dtype) {
   c10::DeviceGuard guard(data.device());
-  at::Tensor data_c = data.detach().contiguous();
+  at::Tensor data_c = data.contiguous();
   ffq_tiling tiling = tiling_of(data_c, tile_size);
   const int64_t ntiles = num_tiles(tiling);
   const at::ScalarType out_type = output_dtype.has_value() ? *output_dtype
@@ -271,8 +276,8 @@ std::vector<at::Tensor> quantize_by_tile_backward(const at::Tensor& data, const 
   const bool fast = dt == output_grad.scalar_type() && (dt == at::kFloat || dt == at::kBFloat16 || dt == at::kHalf) && scale.scalar_type() == at::kFloat &&
                     (!has_offset || offset->scalar_type() == at::kFloat) && data.sizes() == output_grad.sizes();
   if (fast) {
-    at::Tensor data_c = data.detach().contiguous(), grad_c = output_grad.detach().contiguous();
-    at::Tensor scale_c = flat(scale.detach()), offset_c = has_offset ? flat(offset->detach()) : at::Tensor();
+    at::Tensor data_c = data.contiguous(), grad_c = output_grad.contiguous();
+    at::Tensor scale_c = flat(scale), offset_c = has_offset ? flat(*offset) : at::Tensor();
     ffq_tiling tiling = tiling_of(data_c, tile_size);
     const int64_t ntiles = num_tiles(tiling);
     at::Tensor dinput = at::empty_like(data_c), dscale = at::empty({ntiles}, scale_c.options());
@@ -310,7 +315,7 @@ void running_minmax_step(const at::Tensor& data, at::IntArrayRef tile_size, at::
                          const std::optional<at::Tensor>& status_flags, double num_bits, bool symmetric, bool allow_one_sided, at::Tensor scale_out,
                          const std::optional<at::Tensor>& offset_out) {
   c10::DeviceGuard guard(data.device());
-  at::Tensor data_c = data.detach().contiguous(), flags = opt(status_flags), offset = opt(offset_out);
+  at::Tensor data_c = data.contiguous(), flags = opt(status_flags), offset = opt(offset_out);
   for (const at::Tensor* t : {&running_min, &running_max, &scale_out}) same_device(data_c, *t);
   if (flags.defined()) same_device(data_c, flags);
   if (offset.defined()) same_device(data_c, offset);
@@ -338,12 +343,12 @@ at::Tensor linear_w8a8(const at::Tensor& x_codes, const at::Tensor& w_codes, con
                        double out_num_bits, const std::optional<at::Tensor>& w_rowsum, std::optional<at::ScalarType> requant_from) {
   TORCH_CHECK_TYPE(x_codes.scalar_type() == at::kChar && w_codes.scalar_type() == at::kChar, "linear_w8a8 expects int8 codes");
   c10::DeviceGuard guard(x_codes.device());
-  at::Tensor xc = x_codes.detach().contiguous(), wc = w_codes.detach().contiguous();
+  at::Tensor xc = x_codes.contiguous(), wc = w_codes.contiguous();
   const int64_t K = xc.dim() ? xc.size(-1) : 0, N = wc.dim() ? wc.size(0) : 0, M = K ? xc.numel() / K : 0;
   TORCH_CHECK(wc.dim() == 2 && wc.size(1) == K, "mat1 and mat2 shapes cannot be multiplied (", M, "x", K, " and ", wc.sizes(), "^T)");
   at::Tensor xs = f32_flat(x_scale), xo = f32_flat(opt(x_offset)), ws_ = f32_flat(w_scale), wo = f32_flat(opt(w_offset));
   at::Tensor os_ = f32_flat(opt(out_scale)), oo = f32_flat(opt(out_offset)), bias_c = opt(bias), rowsum = opt(w_rowsum);
-  if (bias_c.defined()) bias_c = bias_c.detach().contiguous();
+  if (bias_c.defined()) bias_c = bias_c.contiguous();
   for (const at::Tensor* t : {&wc, &xs, &xo, &ws_, &wo, &os_, &oo, &bias_c, &rowsum})
     if (t->defined()) same_device(xc, *t);
   const int x_per_row = xs.numel() != 1, w_per_row = ws_.numel() != 1;
@@ -373,7 +378,7 @@ at::Tensor bmm_w8a8(const at::Tensor& x_codes, const at::Tensor& w_codes, const 
   TORCH_CHECK_TYPE(x_codes.scalar_type() == at::kChar && w_codes.scalar_type() == at::kChar && x_codes.dim() == 3 && w_codes.dim() == 3,
                    "bmm_w8a8 expects int8 codes of shape [B, M, K] and [B, N, K]");
   c10::DeviceGuard guard(x_codes.device());
-  at::Tensor xc = x_codes.detach().contiguous(), wc = w_codes.detach().contiguous();
+  at::Tensor xc = x_codes.contiguous(), wc = w_codes.contiguous();
   const int64_t B = xc.size(0), M = xc.size(1), K = xc.size(2), N = wc.size(1);
   TORCH_CHECK(wc.size(0) == B && wc.size(2) == K, "batch1 and batch2 shapes cannot be multiplied (", xc.sizes(), " and ", wc.sizes(), "^T)");
   at::Tensor xs = f32_flat(x_scale), xo = f32_flat(opt(x_offset)), ws_ = f32_flat(w_scale), wo = f32_flat(opt(w_offset));
@@ -397,7 +402,7 @@ at::Tensor bmm_w8a8(const at::Tensor& x_codes, const at::Tensor& w_codes, const 
 at::Tensor linear_wq(const at::Tensor& x, const at::Tensor& w_codes, const at::Tensor& w_scale, const std::optional<at::Tensor>& w_offset, int64_t group,
                      const std::optional<at::Tensor>& bias, at::ScalarType out_dtype, int64_t pack_block, int64_t two_pass, int64_t split) {
   c10::DeviceGuard guard(x.device());
-  at::Tensor xc = x.detach().contiguous(), wc = w_codes.detach().contiguous();
+  at::Tensor xc = x.contiguous(), wc = w_codes.contiguous();
   const int64_t K = xc.dim() ? xc.size(-1) : 0;
   TORCH_CHECK(K > 0, "linear_wq: empty contraction");
   const int64_t N = pack_block > 0 ? wc.numel() * 2 / K : wc.size(0), M = xc.numel() / K;
@@ -405,7 +410,7 @@ at::Tensor linear_wq(const at::Tensor& x, const at::Tensor& w_codes, const at::T
               "linear_wq: the weight-code GEMM does not cover this problem (ask ffq_linear_wq_supported first)");
   at::Tensor sc = f32_flat(w_scale), of = f32_flat(opt(w_offset)), bias_c = opt(bias);
   TORCH_CHECK(!of.defined() || of.numel() == sc.numel(), "scale has ", sc.numel(), " entries, offset ", of.numel());
-  if (bias_c.defined()) bias_c = bias_c.detach().contiguous();
+  if (bias_c.defined()) bias_c = bias_c.contiguous();
   for (const at::Tensor* t : {&wc, &sc, &of, &bias_c})
     if (t->defined()) same_device(xc, *t);
   std::vector<int64_t> shape(xc.sizes().begin(), xc.sizes().end());

@@ -651,7 +651,7 @@ class FusedForward:
     """
 
     def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True, fuse_attention: bool = True, fuse_rowsums: bool = False,
-                 batch_weight_quantization: bool = True, batch_rowsums: bool = False) -> None:
+                 batch_weight_quantization: bool = True, batch_rowsums: bool = False, just_in_time_weights: bool = True) -> None:
         problems = self.unsupported(model)
         if problems:
             raise ff.exceptions.QuantizationError("FusedForward cannot run this model: " + "; ".join(problems[:4]))
@@ -676,7 +676,18 @@ class FusedForward:
         # one-pass codes + row sums per weight (`fuse_rowsums`): the int8 GEMMs behind a heavier quantization launch run slower by
         # more than the 224 small launches cost (the chip is power-limited in the GEMMs; tools/gemm_cache_probe.py)
         self.batch_rowsums = batch_rowsums
+        # Round 5, what the two measurements above really show (rocprofv3 per kernel, profiles/r05_rowsum_ab.md): the quantization
+        # launches are NOT heavier with the row sums (100.0 against 100.5 us) — the int8 GEMMs behind them are slower, the gate+up
+        # launch by 11.6 % (1584 against 1420 us), because a rowsum_i8 launch right before a GEMM reads the weight codes and thereby
+        # brings them into the 256 MiB Infinity Cache: the GEMM's L2 misses on the weight panels are then served from there instead
+        # of HBM (the codes written by one launch for the whole layer are long evicted by the time down_proj runs). So the weights
+        # are re-quantized JUST IN TIME, group by group, right before the GEMMs that read them — q/k/v as one launch that leaves
+        # their row sums, o_proj and down_proj each by the one-pass codes + row sums kernel (codes hot, no reduction launch: 5 of
+        # the 7 rowsum_i8 launches per layer gone) — while gate/up (117 MB of codes behind 235 MB of bf16 reads: more than the cache
+        # keeps) stay one launch followed by their two rowsum_i8 launches, which double as the prefetch.
+        self.just_in_time_weights = just_in_time_weights and batch_weight_quantization and not fuse_rowsums and not batch_rowsums
         self._layer_rowsums: dict[int, torch.Tensor] = {}
+        self._jit_single: set[int] = set()  # o_proj / down_proj of the layer in flight: one-pass codes + row sums right before their GEMM
         self._layer_codes: dict[int, torch.Tensor] = {}
         self._zero_offset: dict[int, tuple[int, bool]] = {}
         self._weight_cache: dict[int, tuple[tuple[int, int, int], tuple[torch.Tensor, torch.Tensor | None]]] = {}
@@ -805,23 +816,28 @@ class FusedForward:
         ready = self._layer_codes.pop(id(linear), None)  # quantized with the rest of its layer in one launch (_quantize_layer)
         if ready is not None:
             return ready, self._layer_rowsums.pop(id(linear), None)
-        if self.fuse_rowsums and _weight_row_mode(linear) == "row" and rows > 1 and (wq.offset is None or wq.offset.numel() == rows) and wq.num_bits <= 8:
+        if (self.fuse_rowsums or (self.just_in_time_weights and id(linear) in self._jit_single)) and _weight_row_mode(linear) == "row" and rows > 1 and (wq.offset is None or wq.offset.numel() == rows) and wq.num_bits <= 8:
             offset = None if self._symmetric_weights(linear) else wq.offset  # an all-zero offset buffer: same codes
             fused = ff.ops.quantize_rows_rowsum(linear.weight, wq.scale, offset, wq.num_bits, rowsum_out=self._rowsum_slice(rows, linear.weight.device))
             if fused is not None:
                 return fused
         return wq(linear.weight).raw_data, None
 
-    def _quantize_layer(self, layer: torch.nn.Module) -> None:
-        """A1 of all the layer's weights that are re-quantized this forward, as ONE launch (ops.quantize_rows_batch): seven
-        launches otherwise, two of them (k_proj / v_proj) too short to stream at rate. Fills `_layer_codes`; weights the batched
-        kernel does not cover (not per-channel bf16, odd sizes) are left to `_quantize_weight`."""
-        self._layer_codes, self._layer_rowsums = {}, {}
+    def _quantize_layer(self, layer: torch.nn.Module, group: tuple[torch.nn.Module, ...] | None = None, with_rowsums: bool | None = None) -> None:
+        """A1 of the layer's weights that are re-quantized this forward (`group`: some of them, right before the GEMMs that read
+        them — `just_in_time_weights`), as ONE launch (ops.quantize_rows_batch): seven launches otherwise, two of them (k_proj /
+        v_proj) too short to reach the streaming rate on their own. Fills `_layer_codes`; weights the batched kernel does not cover
+        (not per-channel bf16, odd sizes) and one-member groups are left to `_quantize_weight`."""
+        if group is None:
+            self._layer_codes, self._layer_rowsums = {}, {}
         if not self.batch_weight_quantization or self.fuse_rowsums:
             return
         attn, mlp = layer.self_attn, layer.mlp
+        if group is None and self.just_in_time_weights:
+            return  # group by group from __call__
+        want_rowsums = self.batch_rowsums if with_rowsums is None else with_rowsums
         todo = []
-        for linear in (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj):
+        for linear in (group if group is not None else (attn.q_proj, attn.k_proj, attn.v_proj, attn.o_proj, mlp.gate_proj, mlp.up_proj, mlp.down_proj)):
             wq = linear.weight_quantizer
             if self.cache_weight_codes:
                 key = (linear.weight._version, wq.scale._version, -1 if wq.offset is None else wq.offset._version)
@@ -836,7 +852,7 @@ class FusedForward:
             return
         offsets = [None if self._symmetric_weights(l) else l.weight_quantizer.offset for l in todo]  # an all-zero offset buffer: same codes
         sums = None
-        if self.batch_rowsums and all(l.weight.shape[1] % 1024 == 0 for l in todo):
+        if want_rowsums and all(l.weight.shape[1] % 1024 == 0 for l in todo):
             sums = [self._rowsum_slice(l.weight.shape[0], l.weight.device) for l in todo]
             sums = sums if all(t is not None for t in sums) else None
         codes = ff.ops.quantize_rows_batch([l.weight for l in todo], [l.weight_quantizer.scale for l in todo], offsets, todo[0].weight_quantizer.num_bits,
@@ -845,9 +861,9 @@ class FusedForward:
             codes, sums = ff.ops.quantize_rows_batch([l.weight for l in todo], [l.weight_quantizer.scale for l in todo], offsets,
                                                      todo[0].weight_quantizer.num_bits), None
         if codes is not None:
-            self._layer_codes = {id(l): c for l, c in zip(todo, codes)}
+            self._layer_codes.update({id(l): c for l, c in zip(todo, codes)})
             if sums is not None:
-                self._layer_rowsums = {id(l): t for l, t in zip(todo, sums)}
+                self._layer_rowsums.update({id(l): t for l, t in zip(todo, sums)})
 
     def _weight(self, linear: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor | None, torch.Tensor, torch.Tensor | None]:
         """(int8 codes, row sums or None, scale, offset) of the linear's weight."""
@@ -890,7 +906,7 @@ class FusedForward:
         hidden = model.embed_tokens(input_ids)
         cos, sin = rotary_tables(s, d, cfg.rope_theta, hidden.device, hidden.dtype)
         pending: torch.Tensor | None = None  # down_proj's output: the next RMSNorm launch adds it to the residual stream
-        if self.fuse_rowsums or (self.batch_rowsums and self.batch_weight_quantization):
+        if self.fuse_rowsums or self.just_in_time_weights or (self.batch_rowsums and self.batch_weight_quantization):
             # the weight row sums of this forward: one zero fill, slices handed out as the weights are quantized
             self._rowsum_pool = torch.zeros(self._rowsum_rows, dtype=torch.int32, device=hidden.device)
             self._rowsum_used = 0
@@ -902,6 +918,9 @@ class FusedForward:
             hidden, _, codes = ff.ops.add_rmsnorm_quantize(
                 hidden, pending, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon, pairs, bits, sum_inplace=pending is not None
             )
+            if self.just_in_time_weights:
+                self._jit_single = {id(attn.o_proj), id(mlp.down_proj)}
+                self._quantize_layer(layer, (attn.q_proj, attn.k_proj, attn.v_proj), with_rowsums=True)
             q = self._linear(codes[index[0]], attn.q_proj)
             k = self._linear(codes[index[1]], attn.k_proj)
             v = self._linear(codes[index[2]], attn.v_proj)
@@ -921,6 +940,8 @@ class FusedForward:
             )
             d_in = mlp.down_proj.input_quantizer
             d_codes = None
+            if self.just_in_time_weights:
+                self._quantize_layer(layer, (mlp.gate_proj, mlp.up_proj), with_rowsums=False)
             if self.fuse_mlp and index[0] == index[1] and self._symmetric_weights(mlp.gate_proj) and self._symmetric_weights(mlp.up_proj):
                 g_codes, g_rowsum, g_scale, _ = self._weight(mlp.gate_proj)
                 u_codes, u_rowsum, u_scale, _ = self._weight(mlp.up_proj)
