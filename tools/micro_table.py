@@ -1,4 +1,4 @@
-"""BASELINE.md §3's microbenchmark table: A1 / A2 / A4 on each of the 7 Llama-3-8B weight shapes (per output channel) and the two
+"""BASELINE.md §3's microbenchmark table: A1 / A2 / A4 (and, round 5, A3 per row) on each of the 7 Llama-3-8B weight shapes (per output channel) and the two
 activation shapes (per tensor), GPU kernel time from a rocprofv3 kernel trace beside the CPU eager chain's time for the same op.
 
     rocprofv3 --kernel-trace --output-format csv -d DIR -o micro -- python3 tools/micro_table.py --probe PLAN.json
@@ -55,9 +55,11 @@ def probe(plan_path: str) -> None:
         offset = offset if per_tensor else None
         codes = [ops.quantize_by_tile(x, scale, tile, 8, torch.int8, offset) for x in xs]
         torch.cuda.synchronize()
+        row_tile = tuple([1] * (len(shape) - 1) + [shape[-1]])  # A3: one parameter pair per row (per output channel / per token)
         for op, fn in (("A1 quantize bf16->int8", lambda r: ops.quantize_by_tile(xs[r % 3], scale, tile, 8, torch.int8, offset)),
                        ("A2 dequantize int8->bf16", lambda r: ops.dequantize_by_tile(codes[r % 3], scale, tile, offset, torch.bfloat16)),
-                       ("A4 min/max", lambda r: ops.minmax_by_tile(xs[r % 3], tile))):
+                       ("A4 min/max", lambda r: ops.minmax_by_tile(xs[r % 3], tile)),
+                       ("A3 dynamic quantize per row bf16->int8", lambda r: ops.quantize_dynamic_by_tile(xs[r % 3], row_tile, 8, False, True, torch.int8))):
             marker.flip(0)  # a kernel nothing else here launches: marks the start of a measured row in the trace
             for r in range(WARM + N):
                 fn(r)
@@ -83,9 +85,17 @@ def cpu(out_path: str) -> None:
         lo, hi = eager_chain.minmax(x, tile)
         scale, offset = eager_chain.parameters_for_range(lo, hi, 8, not per_tensor, True)
         codes = eager_chain.quantize(x, scale, tile, 8, torch.int8, offset)
+        row_tile = tuple([1] * (len(shape) - 1) + [shape[-1]])
+
+        def dynamic():  # quantize_dynamic_by_tile_impl (_quantizer_impl.py:243-285): min, max, parameters_for_range, round(offset), quantize
+            lo_r, hi_r = eager_chain.minmax(x, row_tile)
+            s_r, o_r = eager_chain.parameters_for_range(lo_r, hi_r, 8, False, True)
+            return eager_chain.quantize(x, s_r, row_tile, 8, torch.int8, torch.round(o_r))
+
         for op, fn in (("A1 quantize bf16->int8", lambda: eager_chain.quantize(x, scale, tile, 8, torch.int8, offset)),
                        ("A2 dequantize int8->bf16", lambda: eager_chain.dequantize(codes, scale, tile, offset, torch.bfloat16)),
-                       ("A4 min/max", lambda: eager_chain.minmax(x, tile))):
+                       ("A4 min/max", lambda: eager_chain.minmax(x, tile)),
+                       ("A3 dynamic quantize per row bf16->int8", dynamic)):
             fn()
             times = []
             for _ in range(3):
@@ -104,13 +114,13 @@ def merge(trace_csv: str, plan_path: str, cpu_path: str, out_md: str) -> None:
     with open(trace_csv) as f:
         rows = list(csv.DictReader(f))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    key = {"A1": ("ffq::quantize_",), "A2": ("ffq::dequantize_",), "A4": ("ffq::minmax_",)}  # NB "dequantize_" contains "quantize_"
+    key = {"A1": ("ffq::quantize_",), "A2": ("ffq::dequantize_",), "A4": ("ffq::minmax_",), "A3": ("ffq::quantize_dynamic",)}  # NB "dequantize_" contains "quantize_"
     # the measured launches of each plan row: the LAST N groups of its kernels before the next row's kernels begin
     pos = 0
     tag = pathlib.Path(out_md).name.split("_")[0]  # profiles/rNN_micro.md
     out = [f"# {tag} — A1 / A2 / A4 per shape: rocprofv3 kernel trace (GPU) beside the CPU eager chain", "",
            f"`rocprofv3 --kernel-trace -- python3 tools/micro_table.py --probe` on one MI355X: per row {N} launches after {WARM} warm-up launches, inputs rotated over 3 tensors; "
-           "avg = mean kernel duration from the trace (A4 = every kernel of the call summed: one launch where the last block to arrive finishes, else partial + finalize). Algorithmic bytes per element: A1 3, A2 3, A4 2 (SURVEY 8(d)); "
+           "avg = mean kernel duration from the trace (A4 = every kernel of the call summed: one launch where the last block to arrive finishes, else partial + finalize; A3 = quantize_dynamic_by_tile with one parameter pair per ROW of the tensor, asymmetric: one launch). Algorithmic bytes per element: A1 3, A2 3, A4 2, A3 3 (SURVEY 8(d)); "
            f"peak 8000 GB/s. CPU column: `oracle/eager_chain.py` (the reference's unfused ATen chain) with {cpu_ms.get('threads')} torch threads on {cpu_ms.get('host_cpus')} host CPUs, median of 3.", "",
            "| tensor | op | kernels per launch | GPU avg us | GB/s | frac of 8 TB/s | CPU eager ms | GPU / CPU |", "|---|---|---:|---:|---:|---:|---:|---:|"]
     for row in plan:
