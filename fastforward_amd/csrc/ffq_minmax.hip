@@ -851,93 +851,108 @@ static int parameters_impl(const void* min_range, const void* max_range, int ran
 #ifndef FFQ_DYN_WAVE_ROWS
 #define FFQ_DYN_WAVE_ROWS 0
 #endif
+#ifndef FFQ_DYN_ROWS_IN_FLIGHT
+#define FFQ_DYN_ROWS_IN_FLIGHT 2  // tiles a block of the 129..256-chunk plan works on at once (A/B: 1, 2, 4)
+#endif
 struct DynRowsArgs {
   uint32_t ntiles, chunks_per_run;
   float lo, hi;  // clamp bounds
   RangeArgs range;
 };
 
-template <typename TIn, typename TOut, int E, int P, int U>
+// R = tiles a group of lanes works on at once (R > 1: whole-block groups only): all their loads are issued up front, the R reductions
+// meet in ONE barrier, and tile r + 1's memory latency hides behind tile r's arithmetic — a block that lives for one 8 KiB row spends
+// most of its life waiting ([8, 2048, 4096] bf16 per token: 39.7 us with R = 1).
+template <typename TIn, typename TOut, int E, int P, int U, int R = 1>
 __global__ __launch_bounds__(kBlock) void quantize_dynamic_rows_kernel(const TIn* __restrict__ in, TOut* __restrict__ out,
                                                                        float* __restrict__ scale_out, float* __restrict__ offset_out,
                                                                        DynRowsArgs a) {
   static_assert(P <= 64 || P == kBlock, "a group is part of a wave or the whole block");
+  static_assert(R == 1 || P == kBlock, "several tiles in flight: whole-block groups");
   constexpr int TILES_PER_BLOCK = kBlock / P;
-  const uint32_t t = blockIdx.x * TILES_PER_BLOCK + threadIdx.x / P;
+  const uint32_t t0 = (blockIdx.x * TILES_PER_BLOCK + threadIdx.x / P) * R;
   const uint32_t lane = threadIdx.x % P;
-  const bool live = t < a.ntiles;
-  const size_t row = (size_t)t * a.chunks_per_run;
-  Chunk<TIn, E> x[U];
-  typename Accum<TIn>::type acc;
-  acc.init();
+  Chunk<TIn, E> x[R][U];
+  MinMax m[R];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const uint32_t c = lane + u * P;
-    if (live && c < a.chunks_per_run) x[u].load_nt(in + (row + c) * E);
+  for (int r = 0; r < R; ++r) {
+    const size_t row = (size_t)(t0 + r) * a.chunks_per_run;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t c = lane + u * P;
+      if (t0 + r < a.ntiles && c < a.chunks_per_run) x[r][u].load_nt(in + (row + c) * E);
+    }
   }
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const uint32_t c = lane + u * P;
-    if (live && c < a.chunks_per_run) add_chunk<TIn, E>(acc, x[u]);
+  for (int r = 0; r < R; ++r) {
+    typename Accum<TIn>::type acc;
+    acc.init();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t c = lane + u * P;
+      if (t0 + r < a.ntiles && c < a.chunks_per_run) add_chunk<TIn, E>(acc, x[r][u]);
+    }
+    m[r] = finish_accum<TIn>(acc);
+    wave_allreduce<(P <= 64 ? P : 64)>(m[r]);
   }
-  MinMax m = finish_accum<TIn>(acc);
-  if constexpr (P <= 64) {
-    wave_allreduce<P>(m);
-  } else {
-    __shared__ float lds[12];
-    wave_allreduce<64>(m);
+  if constexpr (P > 64) {
+    __shared__ float lds[R][12];
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-      lds[wave] = m.mn;
-      lds[4 + wave] = m.mx;
-      lds[8 + wave] = m.nan ? 1.0f : 0.0f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        lds[r][wave] = m[r].mn;
+        lds[r][4 + wave] = m[r].mx;
+        lds[r][8 + wave] = m[r].nan ? 1.0f : 0.0f;
+      }
     }
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      m.mn = __builtin_fminf(m.mn, lds[w]);
-      m.mx = __builtin_fmaxf(m.mx, lds[4 + w]);
-      m.nan |= lds[8 + w] != 0.0f;
-    }
-  }
-  if (!live) return;
-  // torch.min / torch.max propagate NaN; the extrema are elements of the data, so .to(float32) is exact   (:257-258, range.py:90)
-  const float mn = m.nan ? NAN : m.mn, mx = m.nan ? NAN : m.mx;
-  float scale, offset;
-  range_to_parameters(mn, mx, 0, a.range, scale, offset);  // offset None -> zeros; offset = round(offset)   (:266-275)
-  if (lane == 0) {
-    scale_out[t] = scale;
-    offset_out[t] = offset;
-  }
-  const Divider<1> d(scale);
-  if constexpr (sizeof(TOut) == 1) {
-    // the run's own extrema bound every |x|: one test per tile decides for the packed arithmetic of ffq_affine.h
-    if (fast_chunk_ok(scale, d.r, __builtin_fmaxf(__builtin_fabsf(mn), __builtin_fabsf(mx)))) {
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t c = lane + u * P;
-        if (c >= a.chunks_per_run) continue;
-        float xf[E];
-#pragma unroll
-        for (int i = 0; i < E; ++i) xf[i] = x[u].get(i);
-        Chunk<TOut, E> y;
-        quantize_chunk_bytes_fast<E, false>(xf, scale, d.r, offset, a.lo, a.hi, y.w);
-        y.store(out + (row + c) * E);
+      for (int w = 0; w < 4; ++w) {
+        m[r].mn = __builtin_fminf(m[r].mn, lds[r][w]);
+        m[r].mx = __builtin_fmaxf(m[r].mx, lds[r][4 + w]);
+        m[r].nan |= lds[r][8 + w] != 0.0f;
       }
-      return;
-    }
   }
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const uint32_t c = lane + u * P;
-    if (c >= a.chunks_per_run) continue;
-    float xf[E], r[E];
+  for (int r = 0; r < R; ++r) {
+    const uint32_t t = t0 + r;
+    if (t >= a.ntiles) continue;
+    const size_t row = (size_t)t * a.chunks_per_run;
+    // torch.min / torch.max propagate NaN; the extrema are elements of the data, so .to(float32) is exact   (:257-258, range.py:90)
+    const float mn = m[r].nan ? NAN : m[r].mn, mx = m[r].nan ? NAN : m[r].mx;
+    float scale, offset;
+    range_to_parameters(mn, mx, 0, a.range, scale, offset);  // offset None -> zeros; offset = round(offset)   (:266-275)
+    if (lane == 0) {
+      scale_out[t] = scale;
+      offset_out[t] = offset;
+    }
+    const Divider<1> d(scale);
+    bool fast = false;
+    // the run's own extrema bound every |x|: one test per tile decides for the packed arithmetic of ffq_affine.h
+    if constexpr (sizeof(TOut) == 1) fast = fast_chunk_ok(scale, d.r, __builtin_fmaxf(__builtin_fabsf(mn), __builtin_fabsf(mx)));
 #pragma unroll
-    for (int i = 0; i < E; ++i) xf[i] = x[u].get(i);
-    quantize_chunk_with<1, E>(d, xf, offset, r);  // round(row / scale - offset), clamp, cast               (:277-284)
-    Chunk<TOut, E> y;
-    finalize_chunk<TOut, E>(r, a.lo, a.hi, y);
-    y.store(out + (row + c) * E);
+    for (int u = 0; u < U; ++u) {
+      const uint32_t c = lane + u * P;
+      if (c >= a.chunks_per_run) continue;
+      float xf[E];
+#pragma unroll
+      for (int i = 0; i < E; ++i) xf[i] = x[r][u].get(i);
+      Chunk<TOut, E> y;
+      if constexpr (sizeof(TOut) == 1) {
+        if (fast) {
+          quantize_chunk_bytes_fast<E, false>(xf, scale, d.r, offset, a.lo, a.hi, y.w);
+          y.store(out + (row + c) * E);
+          continue;
+        }
+      }
+      float q[E];
+      quantize_chunk_with<1, E>(d, xf, offset, q);  // round(row / scale - offset), clamp, cast               (:277-284)
+      finalize_chunk<TOut, E>(q, a.lo, a.hi, y);
+      y.store(out + (row + c) * E);
+    }
   }
 }
 
@@ -952,11 +967,13 @@ static bool launch_dynamic_rows(const void* data, void* out, float* scale_out, f
   a.chunks_per_run = (uint32_t)chunks;
   const TIn* in = static_cast<const TIn*>(data);
   TOut* o = static_cast<TOut*>(out);
-#define FFQ_DYN(P, U)                                                                                             \
+#define FFQ_DYN_R(P, U, R)                                                                                        \
   do {                                                                                                            \
-    const unsigned grid = (unsigned)((info.ntiles + (kBlock / P) - 1) / (kBlock / P));                            \
-    quantize_dynamic_rows_kernel<TIn, TOut, E, P, U><<<grid, kBlock, 0, stream>>>(in, o, scale_out, offset_out, a); \
+    const int64_t per_block = (int64_t)(kBlock / P) * R;                                                          \
+    const unsigned grid = (unsigned)((info.ntiles + per_block - 1) / per_block);                                  \
+    quantize_dynamic_rows_kernel<TIn, TOut, E, P, U, R><<<grid, kBlock, 0, stream>>>(in, o, scale_out, offset_out, a); \
   } while (0)
+#define FFQ_DYN(P, U) FFQ_DYN_R(P, U, 1)
   if (chunks <= 1) FFQ_DYN(1, 1);
   else if (chunks <= 2) FFQ_DYN(2, 1);
   else if (chunks <= 4) FFQ_DYN(4, 1);
@@ -968,11 +985,12 @@ static bool launch_dynamic_rows(const void* data, void* out, float* scale_out, f
 #if FFQ_DYN_WAVE_ROWS  // A/B: one wave per run up to 256 chunks (no block barrier, four loads in flight per lane)
   else if (chunks <= 256) FFQ_DYN(64, 4);
 #else
-  else if (chunks <= 256) FFQ_DYN(256, 1);
+  else if (chunks <= 256) FFQ_DYN_R(256, 1, FFQ_DYN_ROWS_IN_FLIGHT);
 #endif
   else if (chunks <= 512) FFQ_DYN(256, 2);
   else FFQ_DYN(256, 4);
 #undef FFQ_DYN
+#undef FFQ_DYN_R
   return true;
 }
 

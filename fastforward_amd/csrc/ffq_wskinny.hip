@@ -30,12 +30,22 @@
 
 #include <math.h>
 
+#include <type_traits>
+
 namespace ffq {
 
 constexpr int SK_BN = 128;     // weight rows (output columns) per block
 constexpr int SK_MAX_M = 128;  // token rows the skinny form covers
+#ifndef FFQ_SK_ROWS_MAX_M
+#define FFQ_SK_ROWS_MAX_M 32    // rows form up to this many token rows ... (A/B hooks: tools/build_variant.sh)
+#endif
+#ifndef FFQ_SK_ROWS_MAX_K
+#define FFQ_SK_ROWS_MAX_K 4096  // ... of contractions up to this deep (16 rows: any depth)
+#endif
+#ifndef FFQ_SK_NT2_MIN_M
+#define FFQ_SK_NT2_MIN_M 5      // rows form: two weight tiles per block from this many token rows
+#endif
 constexpr int SK_WAVES = 8;
-constexpr int SK_ROWS_KC = 128;  // chunk of the <= 16-row form
 
 struct SkinnyArgs {
   const uint8_t* x;
@@ -288,23 +298,28 @@ __global__ __launch_bounds__(512, 2) void wq_skinny_kernel(SkinnyArgs a) {
   }
 }
 
-// ---- up to 16 token rows: one 16-row weight tile per BLOCK, the K range cut across its eight WAVES ---------------------------------
-// With <= 16 rows the activations are tiny (32 KiB per row-tile of a 4096-deep contraction, L2-resident for everybody), so nothing
-// has to be shared through LDS and nothing has to be exchanged between blocks: a block owns 16 output columns for the whole
-// contraction (256 blocks for a 4096-wide projection, 896 for gate / up), wave w contracts chunks [w C / 8, (w + 1) C / 8) with
-// both operands loaded straight into the MFMA's register layout (weights: 16 rows x 64 B per instruction; activations: lane
-// (m, g) reads the 32 bytes of row m it multiplies — rows >= M re-read row M - 1: a column of the MFMA's result that is never
-// stored), the eight partial tiles meet in 8 KiB of LDS and wave 0 adds them in wave order. The dependent chain of a launch is one
-// memory round trip + one barrier, where the 128-column form pays a write-through, a ticket and a read-back on top.
-// Matrices with fewer than CUs / 2 such tiles (k / v: 64) also cut K across `S` blocks and finish through the same tickets.
-template <int BKIND, bool GROUPED, bool OFFSET>
+// ---- the rows form: NT 16-row weight tiles per BLOCK, the K range cut across its eight WAVES -----------------------------------------
+// With few rows the activations are small (32 KiB per 16 rows of a 4096-deep contraction, L2-resident for everybody), so nothing
+// has to be shared through LDS and nothing has to be exchanged between blocks: a block owns 16 NT output columns for the whole
+// contraction (256 blocks for a 4096-wide projection at NT = 1, 448 for gate / up at NT = 2), every wave contracts an eighth of
+// the K range with both operands loaded straight into the MFMA's register layout (weights: 16 rows x 64 B per instruction;
+// activations: lane (m, g) reads the 32 bytes of row 16 mt + m it multiplies — rows >= M re-read row M - 1: a column of the
+// MFMA's result that is never stored — and every activation fragment serves the block's NT weight tiles), the eight waves'
+// partial tiles meet in LDS and wave t adds tile t of the NT x MT in wave order. The dependent chain of a launch is one memory
+// round trip + one barrier, where the 128-column form pays a write-through, a ticket and a read-back on top; the price is
+// activation traffic from L2 — N / (16 NT) x 16 MT x K x 2 bytes — which bounds the form (sk_rows_form below, measured).
+// Matrices with fewer than CUs / 4 blocks also cut K across `S` blocks and finish through the tickets.
+template <int BKIND, bool GROUPED, bool OFFSET, int MT, int NT>
 __global__ __launch_bounds__(512, 2) void wq_skinny_rows_kernel(SkinnyArgs a) {
-  constexpr int KC = SK_ROWS_KC;  // 128: 48 registers of operands per chunk in flight, two blocks per CU
-  constexpr int ROW_BYTES_PER_CHUNK = BKIND == WL_B_I8 ? KC : KC / 2;
-  constexpr int NL = ROW_BYTES_PER_CHUNK / 64;
-  constexpr int HALVES = BKIND == WL_B_I4 ? 2 : 1;
-  constexpr int DEPTH = 2;
-  __shared__ __attribute__((aligned(16))) uint8_t red[SK_WAVES * 1024];
+  // The K range is walked in UNITS of 64 k: one 16-byte piece of int8 codes per lane and weight tile, or one nibble half of a
+  // 16-byte piece of packed codes (two units share a load); the activation fragments of XD units are in flight per wave.
+  // Partitions (slices across blocks, ranges of the eight waves) are taken in PAIRS of units = 128 k, a packing block of nibbles:
+  // both storage forms contract the same k values in the same MFMA steps of the same wave and give the same bits.
+  constexpr int XD = MT == 4 ? 2 : 4;                      // units in flight (8 MT registers of activation fragments each)
+  constexpr int WD = BKIND == WL_B_I8 ? XD : XD / 2;       // weight pieces in flight per weight tile
+  constexpr int TILES = NT * MT;
+  static_assert(TILES <= SK_WAVES, "one wave finishes one tile");
+  __shared__ __attribute__((aligned(16))) uint8_t red[SK_WAVES * TILES * 1024];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -315,137 +330,179 @@ __global__ __launch_bounds__(512, 2) void wq_skinny_rows_kernel(SkinnyArgs a) {
   const float* const s_base = seg == 0 ? a.scale[0] : seg == 1 ? a.scale[1] : a.scale[2];
   const float* const o_base = seg == 0 ? a.offset[0] : seg == 1 ? a.offset[1] : a.offset[2];
   const int rows = seg == 0 ? a.seg_n[0] : seg == 1 ? a.seg_n[1] : a.seg_n[2];
-  const int n0 = (nb - (seg == 0 ? 0 : seg == 1 ? a.seg_block[1] : a.seg_block[2])) * 16;
-  int row = n0 + r16;
-  row = row < rows ? row : rows - 1;
+  const int n0 = (nb - (seg == 0 ? 0 : seg == 1 ? a.seg_block[1] : a.seg_block[2])) * 16 * NT;
   const uint32_t w_row_bytes = BKIND == WL_B_I8 ? (uint32_t)a.K : (uint32_t)a.K / 2u;
-  const uint8_t* const w_row = w_base + (size_t)row * w_row_bytes;
-  const size_t p_row = a.per_row ? (size_t)row * (size_t)a.groups : 0;
-  const uint8_t* const x_row = a.x + (size_t)(r16 < a.M ? r16 : a.M - 1) * (size_t)a.K * 2u;
+  const uint8_t* w_row[NT];
+  size_t p_row[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int row = n0 + 16 * nt + r16;
+    row = row < rows ? row : rows - 1;  // rows past the edge re-read the last row and are never stored
+    w_row[nt] = w_base + (size_t)row * w_row_bytes + 16 * g4;
+    p_row[nt] = a.per_row ? (size_t)row * (size_t)a.groups : 0;
+  }
+  const uint8_t* x_row[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = 16 * mt + r16;
+    x_row[mt] = a.x + ((size_t)(m < a.M ? m : a.M - 1) * (size_t)a.K + 16u * g4) * 2u;
+  }
 
-  // chunks of this block's K slice, then of this wave
+  // pairs of units (128 k) of this block's K slice, then of this wave; units [u_begin, u_end)
   const int b_begin = (int)((int64_t)slice * a.chunks / a.S), b_end = (int)((int64_t)(slice + 1) * a.chunks / a.S);
-  const int c_begin = b_begin + (int)((int64_t)wave * (b_end - b_begin) / SK_WAVES), c_end = b_begin + (int)((int64_t)(wave + 1) * (b_end - b_begin) / SK_WAVES);
+  const int u_begin = 2 * (b_begin + (int)((int64_t)wave * (b_end - b_begin) / SK_WAVES)), u_end = 2 * (b_begin + (int)((int64_t)(wave + 1) * (b_end - b_begin) / SK_WAVES));
 
-  u32x4 raw[DEPTH][NL], xf[DEPTH][NL][HALVES][2];
-  [[maybe_unused]] float sc[DEPTH][NL][2], ro[DEPTH][NL][2];
-  float s_row = 1.0f, o_row = 0.0f;
-  if constexpr (!GROUPED) {
-    s_row = s_base[p_row];
-    if constexpr (OFFSET) o_row = rne(o_base[p_row]);
+  u32x4 raw[WD][NT], xf[XD][2][MT];
+  [[maybe_unused]] float sc[XD][NT], ro[XD][NT];
+  float s_row[NT], o_row[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    s_row[nt] = 1.0f; o_row[nt] = 0.0f;
+    if constexpr (!GROUPED) {
+      s_row[nt] = s_base[p_row[nt]];
+      if constexpr (OFFSET) o_row[nt] = rne(o_base[p_row[nt]]);
+    }
   }
-  auto k_of = [&](int j, int half) -> int {
+  // unit v into slot k (compile-time): this lane's k values are 64 v + 16 g4 + (0..15)
+  auto load_unit = [&](int v, auto kc) {
+    constexpr int k = decltype(kc)::value;
     if constexpr (BKIND == WL_B_I8) {
-      return 64 * j + 16 * g4;
-    } else {
-      const int p = 64 * j + 16 * g4, hb = 1 << (a.pack_shift - 1);
-      return ((p >> (a.pack_shift - 1)) << a.pack_shift) + (p & (hb - 1)) + half * hb;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) raw[k][nt] = *reinterpret_cast<const u32x4*>(w_row[nt] + (size_t)v * 64);
+    } else if constexpr ((k & 1) == 0) {  // the pair's packed bytes: low nibbles = unit v, high nibbles = unit v + 1 (packing block 128)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) raw[k >> 1][nt] = *reinterpret_cast<const u32x4*>(w_row[nt] + (size_t)(v >> 1) * 64);
     }
-  };
-  auto load_chunk = [&](int c, int d) {
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      raw[d][j] = *reinterpret_cast<const u32x4*>(w_row + (size_t)c * ROW_BYTES_PER_CHUNK + 64 * j + 16 * g4);
+    for (int mt = 0; mt < MT; ++mt) {
+      xf[k][0][mt] = *reinterpret_cast<const u32x4*>(x_row[mt] + (size_t)v * 128);
+      xf[k][1][mt] = *reinterpret_cast<const u32x4*>(x_row[mt] + (size_t)v * 128 + 16);
+    }
+    if constexpr (GROUPED) {
+      const uint32_t grp = fdiv((uint32_t)v * 64u, a.group_div);
 #pragma unroll
-      for (int h = 0; h < HALVES; ++h) {
-        const size_t k = (size_t)c * KC + (size_t)k_of(j, h);
-        xf[d][j][h][0] = *reinterpret_cast<const u32x4*>(x_row + k * 2u);
-        xf[d][j][h][1] = *reinterpret_cast<const u32x4*>(x_row + k * 2u + 16u);
-        if constexpr (GROUPED) {
-          const size_t gi = p_row + (size_t)fdiv((uint32_t)k, a.group_div);
-          sc[d][j][h] = s_base[gi];
-          if constexpr (OFFSET) ro[d][j][h] = rne(o_base[gi]);
-        }
+      for (int nt = 0; nt < NT; ++nt) {
+        sc[k][nt] = s_base[p_row[nt] + grp];
+        if constexpr (OFFSET) ro[k][nt] = rne(o_base[p_row[nt] + grp]);
       }
     }
   };
 
-  wl_v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  wl_v4f acc[NT][MT];
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d)
-    if (c_begin + d < c_end) load_chunk(c_begin + d, d);
-  for (int c = c_begin; c < c_end; ++c) {
-    const int d = (c - c_begin) & (DEPTH - 1);
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int dd = 0; dd < DEPTH; ++dd) {
-      if (dd != d) continue;
+    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = wl_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+  auto compute_unit = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
 #pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        const uint32_t wsrc[4] = {raw[dd][j].x, raw[dd][j].y, raw[dd][j].z, raw[dd][j].w};
+    for (int nt = 0; nt < NT; ++nt) {
+      u32x4 piece;
+      if constexpr (BKIND == WL_B_I8) piece = raw[k][nt]; else piece = raw[k >> 1][nt];
+      const uint32_t wsrc[4] = {piece.x, piece.y, piece.z, piece.w};
+      float s = GROUPED ? sc[k][nt] : s_row[nt];
+      float co = OFFSET ? (GROUPED ? ro[k][nt] : o_row[nt]) : 0.0f;
+      uint32_t wv[4];
+      if constexpr (BKIND == WL_B_I4) {
+        // nibble n = code + 8 -> (n ^ 8) << 4 in the byte's high half = 16 * code as a signed byte, and (16 q + 16 o) * (s / 16) is
+        // (q + o) * s with the same single rounding wherever s / 16 is exact; a tiny scale takes the codes themselves (ffq_wlinear.hip)
+        const bool tiny = __builtin_fabsf(s) < 0x1p-120f && s != 0.0f;
 #pragma unroll
-        for (int h = 0; h < HALVES; ++h) {
-          float s = GROUPED ? sc[dd][j][h] : s_row;
-          float co = OFFSET ? (GROUPED ? ro[dd][j][h] : o_row) : 0.0f;
-          uint32_t wv[4];
-          if constexpr (BKIND == WL_B_I4) {
-            const bool tiny = __builtin_fabsf(s) < 0x1p-120f && s != 0.0f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              uint32_t b = (((wsrc[q] >> (4 * h)) << 4) & 0xF0F0F0F0u) ^ 0x80808080u;
-              if (__builtin_expect(tiny, 0)) {
-                const uint32_t b0 = (uint32_t)(((int32_t)(b << 24)) >> 28) & 0xFFu, b1 = (uint32_t)(((int32_t)(b << 16)) >> 28) & 0xFFu;
-                const uint32_t b2 = (uint32_t)(((int32_t)(b << 8)) >> 28) & 0xFFu, b3 = (uint32_t)(((int32_t)b) >> 28) & 0xFFu;
-                b = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-              }
-              wv[q] = b;
-            }
-            if (!tiny) { s = s * 0.0625f; co = co * 16.0f; }
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wv[q] = wsrc[q];
+        for (int q = 0; q < 4; ++q) {
+          uint32_t b = (((wsrc[q] >> (4 * (k & 1))) << 4) & 0xF0F0F0F0u) ^ 0x80808080u;
+          if (__builtin_expect(tiny, 0)) {
+            const uint32_t b0 = (uint32_t)(((int32_t)(b << 24)) >> 28) & 0xFFu, b1 = (uint32_t)(((int32_t)(b << 16)) >> 28) & 0xFFu;
+            const uint32_t b2 = (uint32_t)(((int32_t)(b << 8)) >> 28) & 0xFFu, b3 = (uint32_t)(((int32_t)b) >> 28) & 0xFFu;
+            b = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
           }
-          uint32_t o8[8];
+          wv[q] = b;
+        }
+        if (!tiny) { s = s * 0.0625f; co = co * 16.0f; }
+      } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) dequantize4<OFFSET>(wv[q], s, co, o8[2 * q], o8[2 * q + 1]);
+        for (int q = 0; q < 4; ++q) wv[q] = wsrc[q];
+      }
+      uint32_t o8[8];
 #pragma unroll
-          for (int st = 0; st < 2; ++st) {
-            const wl_v4i wf = {(int)o8[4 * st], (int)o8[4 * st + 1], (int)o8[4 * st + 2], (int)o8[4 * st + 3]};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wl_v8bf, wf), __builtin_bit_cast(wl_v8bf, xf[dd][j][h][st]), acc, 0, 0, 0);
+      for (int q = 0; q < 4; ++q) dequantize4<OFFSET>(wv[q], s, co, o8[2 * q], o8[2 * q + 1]);
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {  // bytes 0-7 and 8-15 of the piece: two MFMA k-slices of this lane
+        const wl_v4i wf = {(int)o8[4 * st], (int)o8[4 * st + 1], (int)o8[4 * st + 2], (int)o8[4 * st + 3]};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wl_v8bf, wf), __builtin_bit_cast(wl_v8bf, xf[k][st][mt]), acc[nt][mt], 0, 0, 0);
+      }
+    }
+  };
+  auto each_slot = [&](auto&& fn) {
+    fn(std::integral_constant<int, 0>{});
+    fn(std::integral_constant<int, 1>{});
+    if constexpr (XD == 4) {
+      fn(std::integral_constant<int, 2>{});
+      fn(std::integral_constant<int, 3>{});
+    }
+  };
+  each_slot([&](auto kc) { if (u_begin + decltype(kc)::value < u_end) load_unit(u_begin + decltype(kc)::value, kc); });
+  for (int u = u_begin; u < u_end; u += XD) {  // (u_begin, u_end and XD are even: a pair of units never straddles two rounds)
+    each_slot([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if (u + k < u_end) {
+        compute_unit(kc);
+        // the slot just consumed takes the unit a round ahead; a packed pair's piece is consumed by its SECOND unit
+        if (u + k + XD < u_end) {
+          if constexpr (BKIND == WL_B_I8 || (k & 1) == 1) {
+            if constexpr (BKIND == WL_B_I4) load_unit(u + k - 1 + XD, std::integral_constant<int, k - 1>{});
+            load_unit(u + k + XD, kc);
           }
         }
       }
-      if (c + DEPTH < c_end) load_chunk(c + DEPTH, dd);
-    }
+    });
   }
-  // ---- the eight waves' partial tiles -> wave 0, in wave order
-  *reinterpret_cast<wl_v4f*>(red + wave * 1024 + lane * 16) = acc;
+  // ---- the eight waves' partial tiles -> wave t finishes tile t = (nt, mt), adding the waves in wave order
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<wl_v4f*>(red + ((wave * TILES + nt * MT + mt) * 64 + lane) * 16) = acc[nt][mt];
   __syncthreads();
-  if (wave != 0) return;
+  if (wave >= TILES) return;
+  const int tile = wave, tnt = tile / MT, tmt = tile - tnt * MT;
+  wl_v4f sum = *reinterpret_cast<const wl_v4f*>(red + ((0 * TILES + tile) * 64 + lane) * 16);
 #pragma unroll
   for (int w = 1; w < SK_WAVES; ++w) {
-    const wl_v4f p = *reinterpret_cast<const wl_v4f*>(red + w * 1024 + lane * 16);
+    const wl_v4f p = *reinterpret_cast<const wl_v4f*>(red + ((w * TILES + tile) * 64 + lane) * 16);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = acc[e] + p[e];
+    for (int e = 0; e < 4; ++e) sum[e] = sum[e] + p[e];
   }
-  if (a.S > 1) {  // K also cut across blocks: the ticketed exchange of wq_skinny_kernel with one strip per n-block
-    uint8_t* const strip = reinterpret_cast<uint8_t*>(a.slabs) + (size_t)nb * a.S * 1024;
+  if (a.S > 1) {  // K also cut across blocks: the ticketed exchange of wq_skinny_kernel with one strip per (n-block, tile)
+    uint8_t* const strip = reinterpret_cast<uint8_t*>(a.slabs) + ((size_t)nb * a.S * TILES + tile) * 1024;
+    const size_t slice_stride = (size_t)TILES * 1024;
     {
-      const auto mine = __builtin_amdgcn_make_buffer_rsrc(strip + (size_t)slice * 1024, 0, 1024, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wl_v4u, acc), mine, lane * 16, 0, /*sc1*/ 16);
+      const auto mine = __builtin_amdgcn_make_buffer_rsrc(strip + (size_t)slice * slice_stride, 0, 1024, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wl_v4u, sum), mine, lane * 16, 0, /*sc1*/ 16);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(a.tickets + nb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) t = __hip_atomic_fetch_add(a.tickets + nb * TILES + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t != a.S - 1) return;
-    if (lane == 0) __hip_atomic_store(a.tickets + nb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(a.tickets + nb * TILES + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" ::: "memory");
-    acc = wl_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    sum = wl_v4f{0.0f, 0.0f, 0.0f, 0.0f};
     for (int sl = 0; sl < a.S; ++sl) {
-      const auto peer = __builtin_amdgcn_make_buffer_rsrc(strip + (size_t)sl * 1024, 0, 1024, 0x00020000);
+      const auto peer = __builtin_amdgcn_make_buffer_rsrc(strip + (size_t)sl * slice_stride, 0, 1024, 0x00020000);
       const wl_v4f g = __builtin_bit_cast(wl_v4f, __builtin_amdgcn_raw_buffer_load_b128(peer, lane * 16, 0, /*sc1*/ 16));
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = acc[e] + g[e];
+      for (int e = 0; e < 4; ++e) sum[e] = sum[e] + g[e];
     }
   }
-  const int ncol = n0 + 4 * g4;
-  if (ncol >= rows || r16 >= a.M) return;
+  const int ncol = n0 + 16 * tnt + 4 * g4, m = 16 * tmt + r16;
+  if (ncol >= rows || m >= a.M) return;
   void* const out = seg == 0 ? a.out[0] : seg == 1 ? a.out[1] : a.out[2];
   float y[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) y[e] = a.bias ? acc[e] + (ncol + e < rows ? (float)load_any(a.bias, a.bias_dt, ncol + e) : 0.0f) : acc[e];
+  for (int e = 0; e < 4; ++e) y[e] = a.bias ? sum[e] + (ncol + e < rows ? (float)load_any(a.bias, a.bias_dt, ncol + e) : 0.0f) : sum[e];
   const bool whole = ncol + 4 <= rows && (rows & 3) == 0;
-  const size_t at = (size_t)r16 * (size_t)rows + (size_t)ncol;
+  const size_t at = (size_t)m * (size_t)rows + (size_t)ncol;
   if (a.out_dt == FFQ_BF16) {
     bf16_t* o = static_cast<bf16_t*>(out) + at;
     if (whole) {
@@ -471,52 +528,81 @@ __global__ __launch_bounds__(512, 2) void wq_skinny_rows_kernel(SkinnyArgs a) {
 }
 
 // ---- the plan ---------------------------------------------------------------------------------------------------------------------
+// Both storage forms of one weight take the same kernel and the same partition of K (pairs of 64-k units = 128 k): that is what makes
+// them agree bit for bit, so nothing below depends on the container.
 static int sk_mt(int64_t M) { return M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 8; }
-static int sk_kc(int64_t M) { return M <= 16 ? SK_ROWS_KC : sk_mt(M) <= 4 ? 256 : 128; }
-static bool sk_rows_form(int64_t M) { return M <= 16; }                       // one 16-row weight tile per block, K across its waves
-static int sk_bn(int64_t M) { return sk_rows_form(M) ? 16 : SK_BN; }
-static int64_t sk_n_blocks(int64_t M, int64_t N) { const int bn = sk_bn(M); return (N + bn - 1) / bn; }  // (every matrix but the last of a multi launch has a multiple of 256 rows)
-static int64_t sk_strips(int64_t M) { return sk_rows_form(M) ? 1 : SK_WAVES; }  // ticket words / partial strips per n-block
+static int sk_cols_kc(int64_t M) { return sk_mt(M) <= 4 ? 256 : 128; }  // K chunk of the 128-column form
+// The rows form (a block owns its columns for the whole contraction) re-reads the activations from L2 once per 16 NT columns —
+// N / (16 NT) x 16 MT x K x 2 bytes: it wins outright up to 16 rows and, for contractions up to 4096 deep, up to 32 (q/o 13.2 vs
+// 17.3 us, k/v 12.9 vs 14.6; down_proj's 14336-deep rows would be 36 vs 27 us) — and covers the shapes the 128-column form's chunk
+// does not divide. The form is a function of (M, K) alone: one launch of several matrices and one launch each agree bit for bit.
+static bool sk_rows_form(int64_t M, int64_t K) {
+  return M <= 16 || (M <= FFQ_SK_ROWS_MAX_M && K <= FFQ_SK_ROWS_MAX_K) || (M <= 64 && K % sk_cols_kc(M) != 0);
+}
+constexpr int SK_KC = 128;  // rows form: a pair of 64-k units
+// weight tiles of 16 rows per block of the rows form: two where every matrix of the launch keeps >= CUs blocks (gate / up) and the
+// rows are distinct enough to be worth sharing (a single token's row is one L2 line for all sixteen lanes of a fragment)
+static int sk_nt(int64_t M, int64_t K, int64_t n_min) {
+  if (!sk_rows_form(M, K) || sk_mt(M) > 2 || M < FFQ_SK_NT2_MIN_M) return 1;
+  return n_min / 32 >= wq_cus() && n_min % 32 == 0 ? 2 : 1;
+}
+static int sk_bn(int64_t M, int64_t K, int64_t n_min) { return sk_rows_form(M, K) ? 16 * sk_nt(M, K, n_min) : SK_BN; }
+static int64_t sk_n_blocks(int64_t M, int64_t K, int64_t N, int64_t n_min) { const int bn = sk_bn(M, K, n_min); return (N + bn - 1) / bn; }
+// ticket words = partial strips per n-block, and the bytes of one strip
+static int64_t sk_strips(int64_t M, int64_t K, int64_t n_min) { return sk_rows_form(M, K) ? sk_nt(M, K, n_min) * sk_mt(M) : SK_WAVES; }
+static int64_t sk_strip_bytes(int64_t M, int64_t K) { return sk_rows_form(M, K) ? 1024 : (int64_t)sk_mt(M) * 1024; }
 
-static bool sk_shape_ok(int64_t M, int64_t K) { return M >= 1 && M <= SK_MAX_M && K % sk_kc(M) == 0; }
+static bool sk_shape_ok(int64_t M, int64_t K) { return M >= 1 && M <= SK_MAX_M && K % SK_KC == 0; }
 
-int wq_skinny_split(int64_t M, int64_t N, int64_t K) {
+static int sk_split_for(int64_t M, int64_t N, int64_t n_min, int64_t K) {
   if (!sk_shape_ok(M, K)) return 1;
-  const int64_t chunks = K / sk_kc(M), blocks = sk_n_blocks(M, N), cus = wq_cus();
+  const int64_t blocks = sk_n_blocks(M, K, N, n_min), cus = wq_cus();
   int64_t S;
-  if (sk_rows_form(M)) {
-    // a block's eight waves already share the K range: cut it across blocks only while the chip is less than half full
-    S = blocks >= cus / 2 ? 1 : (cus / 2 + blocks - 1) / blocks;
-    if (S > chunks / SK_WAVES) S = chunks / SK_WAVES;  // at least one chunk per wave
+  if (sk_rows_form(M, K)) {
+    // a block's eight waves already share the K range: 64 blocks (k / v) are quicker whole than as 128 halves that meet through a
+    // ticket (6.6 vs 8.9 us at one token); cut K across blocks only below a quarter of the chip
+    const int64_t chunks = K / SK_KC;
+    S = blocks >= cus / 4 ? 1 : (cus / 4 + blocks - 1) / blocks;
+    if (S > chunks / SK_WAVES) S = chunks / SK_WAVES;  // at least one pair of units per wave
   } else {
+    const int64_t chunks = K / sk_cols_kc(M);
     S = (cus + blocks - 1) / blocks;  // at least one block per CU ...
-    if (S > chunks / 2) S = chunks / 2;  // ... of at least two chunks (one in flight behind the one being contracted)
+    while (S < chunks / 2 && chunks % S != 0) ++S;  // ... of equally many chunks (three slices of 16 chunks: 29.1 us, four: 25.8) ...
+    if (S > chunks / 2) S = chunks / 2;  // ... and at least two (one in flight behind the one being contracted)
   }
   if (S > 64) S = 64;
   return S < 1 ? 1 : (int)S;
 }
 
-int64_t wq_skinny_tickets(int64_t M, int64_t N, int64_t K) { return sk_shape_ok(M, K) ? sk_n_blocks(M, N) * sk_strips(M) : 0; }
+// (the plan queries of the C ABI see M, N, K only: one matrix)
+int wq_skinny_split(int64_t M, int64_t N, int64_t K) { return sk_split_for(M, N, N, K); }
+
+// ticket words / slab bytes: upper bounds over the forms a launch of this (M, N, K) can take (one or two weight tiles per block, one
+// to three matrices, each rounded up to whole blocks)
+int64_t wq_skinny_tickets(int64_t M, int64_t N, int64_t K) {
+  if (!sk_shape_ok(M, K)) return 0;
+  return ((N + 15) / 16 + 6) * SK_WAVES;
+}
 
 size_t wq_skinny_slab_bytes(int64_t M, int64_t N, int64_t K, int64_t split) {
   if (!sk_shape_ok(M, K) || split <= 1) return 0;
-  return (size_t)sk_n_blocks(M, N) * (size_t)split * (size_t)sk_strips(M) * (size_t)sk_mt(M) * 1024u;
+  return (size_t)((N + 15) / 16 + 24) * (size_t)split * (size_t)sk_mt(M) * 1024u;
 }
 
 bool wq_skinny_applies(const WLinearArgs& a, int64_t pack_block) {
   if (generic_kernels_forced()) return false;  // tests: the 256-row-tile kernel on the same operands (ffq_force_generic_kernels)
-  if (!sk_shape_ok(a.M, a.K)) return false;
-  // packed nibbles: only the packing block whose low / high halves are the 64-code groups of the int8 walk (128: BASELINE config 4's
+  // packed nibbles: only the packing block whose low / high halves are the 64-code units of the int8 walk (128: BASELINE config 4's
   // group size) — then lane (r, g) multiplies the same k values in the same MFMA steps as with an int8 container and every storage
   // form gives the same bits; other blocks (GGUF's 32, 64, 256) keep the 256-row-tile kernel, which converts into a
   // k-ordered LDS image
   if (pack_block != 0 && pack_block != 128) return false;
+  if (!sk_shape_ok(a.M, a.K)) return false;
   if (a.groups > 1 && (a.K / a.groups) % 64 != 0) return false;
   return true;
 }
 
 template <int BKIND, bool GROUPED, bool OFFSET>
-static void sk_launch_mt(const SkinnyArgs& s, int mt, unsigned grid, hipStream_t stream) {
+static void sk_launch_cols(const SkinnyArgs& s, int mt, unsigned grid, hipStream_t stream) {
 #define FFQ_SK(MT)                                                                                                            \
   do {                                                                                                                        \
     static uint64_t attr_set = 0;                                                                                             \
@@ -532,31 +618,46 @@ static void sk_launch_mt(const SkinnyArgs& s, int mt, unsigned grid, hipStream_t
 #undef FFQ_SK
 }
 
+template <int BKIND, bool GROUPED, bool OFFSET>
+static void sk_launch_rows(const SkinnyArgs& s, int mt, int nt, unsigned grid, hipStream_t stream) {
+#define FFQ_SKR(MT, NT) wq_skinny_rows_kernel<BKIND, GROUPED, OFFSET, MT, NT><<<grid, 512, 0, stream>>>(s)
+  switch (mt) {
+    case 1: if (nt == 2) FFQ_SKR(1, 2); else FFQ_SKR(1, 1); break;
+    case 2: if (nt == 2) FFQ_SKR(2, 2); else FFQ_SKR(2, 1); break;
+    default: FFQ_SKR(4, 1); break;
+  }
+#undef FFQ_SKR
+}
+
 int wq_skinny_launch(const WLinearArgs& a, int w_dt, int64_t pack_block, int64_t group, int64_t split, void* workspace, size_t workspace_bytes,
                      int32_t* tickets, hipStream_t stream) {
+  (void)pack_block;
   SkinnyArgs s;
   s.x = a.x;
   s.w[0] = a.w; s.scale[0] = a.w_scale; s.offset[0] = a.w_offset; s.out[0] = a.out;
-  int64_t N = 0, blocks = 0;
+  int64_t N = 0, blocks = 0, n_min = INT64_MAX;
+  for (int i = 0; i < 3; ++i)
+    if (a.seg_n[i] > 0 && a.seg_n[i] < n_min) n_min = a.seg_n[i];
   for (int i = 0; i < 3; ++i) {
     s.seg_n[i] = a.seg_n[i];
     s.seg_block[i] = i == 0 ? 0 : (a.seg_n[i] > 0 ? (int)blocks : INT32_MAX);
     if (i > 0) { s.w[i] = a.seg_w[i - 1]; s.scale[i] = a.seg_scale[i - 1]; s.offset[i] = a.seg_offset[i - 1]; s.out[i] = a.seg_out[i - 1]; }
     N += a.seg_n[i];
-    blocks += sk_n_blocks(a.M, a.seg_n[i]);
+    blocks += sk_n_blocks(a.M, a.K, a.seg_n[i], n_min);
   }
   s.bias = a.bias; s.bias_dt = a.bias_dt; s.out_dt = a.out_dt;
   s.M = a.M; s.K = a.K;
   s.n_blocks = (int)blocks;
   s.groups = a.groups; s.group_div = make_fastdiv((uint32_t)group); s.per_row = a.per_row; s.pack_shift = a.pack_shift;
-  const int mt = sk_mt(a.M), kc = sk_kc(a.M);
-  s.chunks = a.K / kc;
-  int64_t S = split > 0 ? split : wq_skinny_split(a.M, N, a.K);
+  const bool rows_form = sk_rows_form(a.M, a.K);
+  const int mt = sk_mt(a.M), nt = sk_nt(a.M, a.K, n_min), kc = rows_form ? SK_KC : sk_cols_kc(a.M);
+  s.chunks = (int)(a.K / kc);
+  int64_t S = split > 0 ? split : sk_split_for(a.M, N, n_min, a.K);
   if (S > s.chunks) {
     if (split > 0) return fail(FFQ_ERR_ARG, "weight-only linear (skinny form): split %lld exceeds the %d chunks of %d along K", (long long)split, s.chunks, kc);
     S = s.chunks;
   }
-  const size_t slab = wq_skinny_slab_bytes(a.M, N, a.K, S);
+  const size_t slab = S > 1 ? (size_t)blocks * (size_t)S * (size_t)sk_strips(a.M, a.K, n_min) * (size_t)sk_strip_bytes(a.M, a.K) : 0;
   if (S > 1 && (!tickets || !workspace || workspace_bytes < slab || !aligned16(workspace))) {
     if (split > 1) return fail(FFQ_ERR_ARG, "weight-only linear (skinny form): split %lld needs %zu bytes of workspace and a ticket buffer", (long long)S, slab);
     S = 1;  // the plan is a preference: without scratch every block walks the whole K range
@@ -566,19 +667,16 @@ int wq_skinny_launch(const WLinearArgs& a, int w_dt, int64_t pack_block, int64_t
   s.tickets = S > 1 ? tickets : nullptr;
   const unsigned grid = (unsigned)(blocks * S);
   const bool grouped = a.groups > 1, offset = a.w_offset != nullptr;
-  (void)pack_block;
-  if (sk_rows_form(a.M)) {
-#define FFQ_SKR(BK, G, O) wq_skinny_rows_kernel<BK, G, O><<<grid, 512, 0, stream>>>(s)
-#define FFQ_SKR_T(BK) do { if (grouped) { if (offset) FFQ_SKR(BK, true, true); else FFQ_SKR(BK, true, false); } else { if (offset) FFQ_SKR(BK, false, true); else FFQ_SKR(BK, false, false); } } while (0)
+  if (rows_form) {
+#define FFQ_SKR_T(BK) do { if (grouped) { if (offset) sk_launch_rows<BK, true, true>(s, mt, nt, grid, stream); else sk_launch_rows<BK, true, false>(s, mt, nt, grid, stream); } else { if (offset) sk_launch_rows<BK, false, true>(s, mt, nt, grid, stream); else sk_launch_rows<BK, false, false>(s, mt, nt, grid, stream); } } while (0)
     if (w_dt == FFQ_U8) FFQ_SKR_T(WL_B_I4); else FFQ_SKR_T(WL_B_I8);
 #undef FFQ_SKR_T
-#undef FFQ_SKR
     return check_launch("wq_skinny_rows_kernel");
   }
 #define FFQ_SK_T(BK)                                                                              \
   do {                                                                                            \
-    if (grouped) { if (offset) sk_launch_mt<BK, true, true>(s, mt, grid, stream); else sk_launch_mt<BK, true, false>(s, mt, grid, stream); } \
-    else { if (offset) sk_launch_mt<BK, false, true>(s, mt, grid, stream); else sk_launch_mt<BK, false, false>(s, mt, grid, stream); }        \
+    if (grouped) { if (offset) sk_launch_cols<BK, true, true>(s, mt, grid, stream); else sk_launch_cols<BK, true, false>(s, mt, grid, stream); } \
+    else { if (offset) sk_launch_cols<BK, false, true>(s, mt, grid, stream); else sk_launch_cols<BK, false, false>(s, mt, grid, stream); }        \
   } while (0)
   if (w_dt == FFQ_U8) FFQ_SK_T(WL_B_I4); else FFQ_SK_T(WL_B_I8);
 #undef FFQ_SK_T

@@ -36,8 +36,8 @@ def _check(x, w, scale, offset, group, got):
     assert bool((err <= bound).all()), f"max err {float(err.max())} at |y| {float(want.abs().max())}"
 
 
-@pytest.mark.parametrize("tokens", [1, 7, 16, 33, 64, 100, 128, 300, 512])
-@pytest.mark.parametrize("n,k", [(4096, 4096), (1024, 4096), (1000, 1024), (4096, 14336)], ids=str)
+@pytest.mark.parametrize("tokens", [1, 4, 7, 16, 17, 33, 64, 100, 128, 300, 512])
+@pytest.mark.parametrize("n,k", [(4096, 4096), (1024, 4096), (1000, 1024), (4096, 14336), (14336, 1152)], ids=str)
 def test_weight_only_linear_at_few_rows_matches_float64_of_the_same_operands(tokens, n, k):
     g = torch.Generator(device=DEV).manual_seed(tokens * 7 + n)
     x = torch.randn(tokens, k, device=DEV, generator=g).to(torch.bfloat16)

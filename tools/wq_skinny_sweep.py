@@ -38,6 +38,10 @@ for T in [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 16, 64, 128]:
             us = t(lambda r: ops.linear_wq(xs[r % 2], codes[r % copies], s8, None, split=split))
             row.append(f"S={split}{'*' if split == plan else ''} {us:.1f}us")
         us = t(lambda r: ops.linear_wq(xs[r % 2], codes[r % copies], s8, None))
+        if os.environ.get("SWEEP_QUICK"):
+            print(f"{name:7s} N={n:5d} K={k:5d}: default {us:.1f}us", flush=True)
+            del codes
+            continue
         head = f"default {us:.1f}us = {n * k / us / 1e3:.0f} GB/s = {n * k / us / 8e6:.3f} of 8 TB/s"
         prev = lib.ffq_force_generic_kernels(1)
         try:
