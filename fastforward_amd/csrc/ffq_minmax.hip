@@ -863,102 +863,168 @@ struct DynRowsArgs {
 // R = tiles a group of lanes works on at once (R > 1: whole-block groups only): all their loads are issued up front, the R reductions
 // meet in ONE barrier, and tile r + 1's memory latency hides behind tile r's arithmetic — a block that lives for one 8 KiB row spends
 // most of its life waiting ([8, 2048, 4096] bf16 per token: 39.7 us with R = 1).
-template <typename TIn, typename TOut, int E, int P, int U, int R = 1>
+//
+// MODE (symmetric AND allow_one_sided: range.py:100 asks whether the smallest minimum of ALL tiles is >= 0):
+//   DYN_PLAIN  nothing global to decide.
+//   DYN_GUESS  first launch. A tile whose own minimum is negative (or NaN) has answered the global question — "not one-sided" — by
+//              itself and is finished here, two-sided. A tile with a minimum >= 0 cannot know: it leaves its maximum in scale_out, its
+//              minimum with the SIGN BIT SET in offset_out (a finished two-sided tile holds +0.0 there) and is counted in ticket[0].
+//   DYN_SETTLE second launch, a few blocks striding over the first launch's blocks. ticket[0] == 0: nothing was left open, return
+//              (activations with both signs in every row: 60.7 -> ~44 us for [8, 2048, 4096], 3 B/elem + an empty launch).
+//              Otherwise the verdict is known — one-sided iff EVERY tile was left open — and the open tiles are read again and
+//              finished with it (all-non-negative data: 2 + 3 = 5 B/elem, what the composed form moves); the last block to leave
+//              zeroes the two ticket words.
+enum { DYN_PLAIN = 0, DYN_GUESS = 1, DYN_SETTLE = 2 };
+
+template <typename TIn, typename TOut, int E, int P, int U, int R = 1, int MODE = DYN_PLAIN>
 __global__ __launch_bounds__(kBlock) void quantize_dynamic_rows_kernel(const TIn* __restrict__ in, TOut* __restrict__ out,
                                                                        float* __restrict__ scale_out, float* __restrict__ offset_out,
-                                                                       DynRowsArgs a) {
+                                                                       DynRowsArgs a, int32_t* __restrict__ ticket, uint32_t logical_blocks) {
   static_assert(P <= 64 || P == kBlock, "a group is part of a wave or the whole block");
   static_assert(R == 1 || P == kBlock, "several tiles in flight: whole-block groups");
   constexpr int TILES_PER_BLOCK = kBlock / P;
-  const uint32_t t0 = (blockIdx.x * TILES_PER_BLOCK + threadIdx.x / P) * R;
   const uint32_t lane = threadIdx.x % P;
-  Chunk<TIn, E> x[R][U];
-  MinMax m[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const size_t row = (size_t)(t0 + r) * a.chunks_per_run;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t c = lane + u * P;
-      if (t0 + r < a.ntiles && c < a.chunks_per_run) x[r][u].load_nt(in + (row + c) * E);
-    }
+  [[maybe_unused]] int verdict = 0;     // DYN_SETTLE: one-sided?
+  [[maybe_unused]] int open_here = 0;   // DYN_GUESS: tiles this thread left open (counted once per tile, by the group's first lane)
+  if constexpr (MODE == DYN_SETTLE) {
+    const int open = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (open == 0) return;
+    verdict = (uint32_t)open == a.ntiles;
   }
+  for (uint32_t blk = blockIdx.x; blk < logical_blocks; blk += gridDim.x) {  // (one trip unless DYN_SETTLE)
+    const uint32_t t0 = (blk * TILES_PER_BLOCK + threadIdx.x / P) * R;
+    Chunk<TIn, E> x[R][U];
+    MinMax m[R];
+    [[maybe_unused]] bool mine[R];  // DYN_SETTLE: the tile was left open
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    typename Accum<TIn>::type acc;
-    acc.init();
+    for (int r = 0; r < R; ++r) {
+      mine[r] = true;
+      if constexpr (MODE == DYN_SETTLE) {
+        mine[r] = t0 + r < a.ntiles && (__builtin_bit_cast(uint32_t, offset_out[t0 + r]) >> 31) != 0;
+        if (mine[r]) {
+          m[r].mn = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, offset_out[t0 + r]) & 0x7FFFFFFFu);
+          m[r].mx = scale_out[t0 + r];
+          m[r].nan = false;  // (a NaN minimum is "not >= 0": such a tile was finished by the first launch)
+        }
+      }
+      const size_t row = (size_t)(t0 + r) * a.chunks_per_run;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t c = lane + u * P;
-      if (t0 + r < a.ntiles && c < a.chunks_per_run) add_chunk<TIn, E>(acc, x[r][u]);
+      for (int u = 0; u < U; ++u) {
+        const uint32_t c = lane + u * P;
+        if (mine[r] && t0 + r < a.ntiles && c < a.chunks_per_run) x[r][u].load_nt(in + (row + c) * E);
+      }
     }
-    m[r] = finish_accum<TIn>(acc);
-    wave_allreduce<(P <= 64 ? P : 64)>(m[r]);
-  }
-  if constexpr (P > 64) {
-    __shared__ float lds[R][12];
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
+    // (a whole-block group: every wave has read the tile's marker before the first lane replaces it with the parameters)
+    if constexpr (MODE == DYN_SETTLE && P > 64) __syncthreads();
+    if constexpr (MODE != DYN_SETTLE) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        lds[r][wave] = m[r].mn;
-        lds[r][4 + wave] = m[r].mx;
-        lds[r][8 + wave] = m[r].nan ? 1.0f : 0.0f;
+        typename Accum<TIn>::type acc;
+        acc.init();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t c = lane + u * P;
+          if (t0 + r < a.ntiles && c < a.chunks_per_run) add_chunk<TIn, E>(acc, x[r][u]);
+        }
+        m[r] = finish_accum<TIn>(acc);
+        wave_allreduce<(P <= 64 ? P : 64)>(m[r]);
+      }
+      if constexpr (P > 64) {
+        __shared__ float lds[R][12];
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            lds[r][wave] = m[r].mn;
+            lds[r][4 + wave] = m[r].mx;
+            lds[r][8 + wave] = m[r].nan ? 1.0f : 0.0f;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            m[r].mn = __builtin_fminf(m[r].mn, lds[r][w]);
+            m[r].mx = __builtin_fmaxf(m[r].mx, lds[r][4 + w]);
+            m[r].nan |= lds[r][8 + w] != 0.0f;
+          }
       }
     }
-    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        m[r].mn = __builtin_fminf(m[r].mn, lds[r][w]);
-        m[r].mx = __builtin_fmaxf(m[r].mx, lds[r][4 + w]);
-        m[r].nan |= lds[r][8 + w] != 0.0f;
-      }
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const uint32_t t = t0 + r;
-    if (t >= a.ntiles) continue;
-    const size_t row = (size_t)t * a.chunks_per_run;
-    // torch.min / torch.max propagate NaN; the extrema are elements of the data, so .to(float32) is exact   (:257-258, range.py:90)
-    const float mn = m[r].nan ? NAN : m[r].mn, mx = m[r].nan ? NAN : m[r].mx;
-    float scale, offset;
-    range_to_parameters(mn, mx, 0, a.range, scale, offset);  // offset None -> zeros; offset = round(offset)   (:266-275)
-    if (lane == 0) {
-      scale_out[t] = scale;
-      offset_out[t] = offset;
-    }
-    const Divider<1> d(scale);
-    bool fast = false;
-    // the run's own extrema bound every |x|: one test per tile decides for the packed arithmetic of ffq_affine.h
-    if constexpr (sizeof(TOut) == 1) fast = fast_chunk_ok(scale, d.r, __builtin_fmaxf(__builtin_fabsf(mn), __builtin_fabsf(mx)));
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t c = lane + u * P;
-      if (c >= a.chunks_per_run) continue;
-      float xf[E];
-#pragma unroll
-      for (int i = 0; i < E; ++i) xf[i] = x[r][u].get(i);
-      Chunk<TOut, E> y;
-      if constexpr (sizeof(TOut) == 1) {
-        if (fast) {
-          quantize_chunk_bytes_fast<E, false>(xf, scale, d.r, offset, a.lo, a.hi, y.w);
-          y.store(out + (row + c) * E);
+    for (int r = 0; r < R; ++r) {
+      const uint32_t t = t0 + r;
+      if (t >= a.ntiles || !mine[r]) continue;
+      const size_t row = (size_t)t * a.chunks_per_run;
+      // torch.min / torch.max propagate NaN; the extrema are elements of the data, so .to(float32) is exact   (:257-258, range.py:90)
+      const float mn = m[r].nan ? NAN : m[r].mn, mx = m[r].nan ? NAN : m[r].mx;
+      if constexpr (MODE == DYN_GUESS) {
+        if (mn >= 0.0f) {  // the answer depends on the other tiles: leave the range behind and count the tile
+          if (lane == 0) {
+            scale_out[t] = mx;
+            offset_out[t] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, mn) | 0x80000000u);
+            ++open_here;
+          }
           continue;
         }
       }
-      float q[E];
-      quantize_chunk_with<1, E>(d, xf, offset, q);  // round(row / scale - offset), clamp, cast               (:277-284)
-      finalize_chunk<TOut, E>(q, a.lo, a.hi, y);
-      y.store(out + (row + c) * E);
+      float scale, offset;
+      range_to_parameters(mn, mx, MODE == DYN_SETTLE ? verdict : 0, a.range, scale, offset);  // offset None -> zeros; offset = round(offset)   (:266-275)
+      if (lane == 0) {
+        scale_out[t] = scale;
+        offset_out[t] = offset;
+      }
+      const Divider<1> d(scale);
+      bool fast = false;
+      // the run's own extrema bound every |x|: one test per tile decides for the packed arithmetic of ffq_affine.h
+      if constexpr (sizeof(TOut) == 1) fast = fast_chunk_ok(scale, d.r, __builtin_fmaxf(__builtin_fabsf(mn), __builtin_fabsf(mx)));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t c = lane + u * P;
+        if (c >= a.chunks_per_run) continue;
+        float xf[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) xf[i] = x[r][u].get(i);
+        Chunk<TOut, E> y;
+        if constexpr (sizeof(TOut) == 1) {
+          if (fast) {
+            quantize_chunk_bytes_fast<E, false>(xf, scale, d.r, offset, a.lo, a.hi, y.w);
+            y.store(out + (row + c) * E);
+            continue;
+          }
+        }
+        float q[E];
+        quantize_chunk_with<1, E>(d, xf, offset, q);  // round(row / scale - offset), clamp, cast               (:277-284)
+        finalize_chunk<TOut, E>(q, a.lo, a.hi, y);
+        y.store(out + (row + c) * E);
+      }
+    }
+    if constexpr (MODE != DYN_SETTLE) break;
+  }
+  if constexpr (MODE == DYN_GUESS) {  // one global atomic per block that left something open
+    __shared__ int open_s;
+    if (threadIdx.x == 0) open_s = 0;
+    __syncthreads();
+    if (open_here) atomicAdd(&open_s, open_here);
+    __syncthreads();
+    if (threadIdx.x == 0 && open_s) __hip_atomic_fetch_add(ticket, open_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if constexpr (MODE == DYN_SETTLE) {  // (reached only when something was open) the last block to leave zeroes the words
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int left = __hip_atomic_fetch_add(ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (left == (int)gridDim.x - 1) {
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ticket + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
 
 template <typename TIn, typename TOut>
 static bool launch_dynamic_rows(const void* data, void* out, float* scale_out, float* offset_out, const TileInfo& info,
-                                const DynRowsArgs& base, hipStream_t stream) {
+                                const DynRowsArgs& base, int32_t* ticket, hipStream_t stream) {
   constexpr int E = sizeof(TOut) == 1 ? 16 : 8;
   if (info.run % E != 0) return false;
   const int64_t chunks = info.run / E;
@@ -967,11 +1033,18 @@ static bool launch_dynamic_rows(const void* data, void* out, float* scale_out, f
   a.chunks_per_run = (uint32_t)chunks;
   const TIn* in = static_cast<const TIn*>(data);
   TOut* o = static_cast<TOut*>(out);
+  const bool global_question = a.range.symmetric && a.range.allow_one_sided;  // (the caller checked the ticket words)
 #define FFQ_DYN_R(P, U, R)                                                                                        \
   do {                                                                                                            \
     const int64_t per_block = (int64_t)(kBlock / P) * R;                                                          \
     const unsigned grid = (unsigned)((info.ntiles + per_block - 1) / per_block);                                  \
-    quantize_dynamic_rows_kernel<TIn, TOut, E, P, U, R><<<grid, kBlock, 0, stream>>>(in, o, scale_out, offset_out, a); \
+    if (!global_question) {                                                                                       \
+      quantize_dynamic_rows_kernel<TIn, TOut, E, P, U, R, DYN_PLAIN><<<grid, kBlock, 0, stream>>>(in, o, scale_out, offset_out, a, nullptr, grid); \
+    } else {                                                                                                      \
+      quantize_dynamic_rows_kernel<TIn, TOut, E, P, U, R, DYN_GUESS><<<grid, kBlock, 0, stream>>>(in, o, scale_out, offset_out, a, ticket, grid);  \
+      const unsigned settle = grid < 2048u ? grid : 2048u;                                                        \
+      quantize_dynamic_rows_kernel<TIn, TOut, E, P, U, R, DYN_SETTLE><<<settle, kBlock, 0, stream>>>(in, o, scale_out, offset_out, a, ticket, grid); \
+    }                                                                                                             \
   } while (0)
 #define FFQ_DYN(P, U) FFQ_DYN_R(P, U, 1)
   if (chunks <= 1) FFQ_DYN(1, 1);
@@ -996,11 +1069,11 @@ static bool launch_dynamic_rows(const void* data, void* out, float* scale_out, f
 
 template <typename TIn>
 static bool launch_dynamic_rows_out(int out_dt, const void* data, void* out, float* scale_out, float* offset_out,
-                                    const TileInfo& info, const DynRowsArgs& a, hipStream_t stream) {
+                                    const TileInfo& info, const DynRowsArgs& a, int32_t* ticket, hipStream_t stream) {
   switch (out_dt) {
-    case FFQ_I8: return launch_dynamic_rows<TIn, int8_t>(data, out, scale_out, offset_out, info, a, stream);
-    case FFQ_F32: return launch_dynamic_rows<TIn, float>(data, out, scale_out, offset_out, info, a, stream);
-    case FFQ_BF16: return launch_dynamic_rows<TIn, bf16_t>(data, out, scale_out, offset_out, info, a, stream);
+    case FFQ_I8: return launch_dynamic_rows<TIn, int8_t>(data, out, scale_out, offset_out, info, a, ticket, stream);
+    case FFQ_F32: return launch_dynamic_rows<TIn, float>(data, out, scale_out, offset_out, info, a, ticket, stream);
+    case FFQ_BF16: return launch_dynamic_rows<TIn, bf16_t>(data, out, scale_out, offset_out, info, a, ticket, stream);
     default: return false;
   }
 }
@@ -1008,9 +1081,11 @@ static bool launch_dynamic_rows_out(int out_dt, const void* data, void* out, flo
 // true: the one-launch kernel was enqueued (*rc holds the launch status); false: the caller composes A4 -> A5 -> A1
 static bool dynamic_one_launch(const void* data, int data_dt, const TileInfo& info, double num_bits, int symmetric,
                                int allow_one_sided, void* out, int out_dt, float* scale_out, float* offset_out,
-                               hipStream_t stream, int* rc) {
+                               int32_t* ticket, hipStream_t stream, int* rc) {
   if (info.layout != LAYOUT_ROWS || info.ntiles >= ((int64_t)1 << 31) || info.numel >= ((int64_t)1 << 36)) return false;
-  if (symmetric && allow_one_sided) return false;  // the one decision that is global over the tiles (range.py:100)
+  // the one decision that is global over the tiles (range.py:100) takes two ticket words (DYN_GUESS / DYN_SETTLE); a single tile
+  // answers it in the reduction's last block (below)
+  if (symmetric && allow_one_sided && (!ticket || info.ntiles == 1)) return false;
   if (num_bits != floor(num_bits) || num_bits < 1 || num_bits > 32 || generic_kernels_forced()) return false;
   if (!aligned16(data) || !aligned16(out)) return false;
   DynRowsArgs a;
@@ -1021,9 +1096,9 @@ static bool dynamic_one_launch(const void* data, int data_dt, const TileInfo& in
   a.range = make_range_args(data_dt, info.ntiles, num_bits, symmetric, allow_one_sided, FFQ_F32, FFQ_F32, 1);
   bool done = false;
   switch (data_dt) {
-    case FFQ_BF16: done = launch_dynamic_rows_out<bf16_t>(out_dt, data, out, scale_out, offset_out, info, a, stream); break;
-    case FFQ_F16: done = launch_dynamic_rows_out<f16_t>(out_dt, data, out, scale_out, offset_out, info, a, stream); break;
-    case FFQ_F32: done = launch_dynamic_rows_out<float>(out_dt, data, out, scale_out, offset_out, info, a, stream); break;
+    case FFQ_BF16: done = launch_dynamic_rows_out<bf16_t>(out_dt, data, out, scale_out, offset_out, info, a, ticket, stream); break;
+    case FFQ_F16: done = launch_dynamic_rows_out<f16_t>(out_dt, data, out, scale_out, offset_out, info, a, ticket, stream); break;
+    case FFQ_F32: done = launch_dynamic_rows_out<float>(out_dt, data, out, scale_out, offset_out, info, a, ticket, stream); break;
     default: break;
   }
   if (done) *rc = check_launch("quantize_dynamic_rows_kernel");
@@ -1110,7 +1185,7 @@ int ffq_quantize_dynamic_by_tile(const void* data, int data_dt, const ffq_tiling
     return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.",
                 out_dt, num_bits);
   // contiguous-run tiles that fit a block's registers and no global one-sided decision: ONE launch, 3 B/elem
-  if (dynamic_one_launch(data, data_dt, info, num_bits, symmetric, allow_one_sided, out, out_dt, scale_out, offset_out, s, &rc)) return rc;
+  if (dynamic_one_launch(data, data_dt, info, num_bits, symmetric, allow_one_sided, out, out_dt, scale_out, offset_out, ticket, s, &rc)) return rc;
   const size_t need = ffq_quantize_dynamic_workspace_bytes(tiling, data_dt);
   if (need > workspace_bytes || !workspace)
     return fail(FFQ_ERR_WORKSPACE, "dynamic quantize needs %zu workspace bytes, got %zu", need, workspace_bytes);

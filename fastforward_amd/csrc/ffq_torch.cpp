@@ -232,7 +232,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> quantize_dynamic_by_tile(const at
   const size_t nbytes = ffq_quantize_dynamic_workspace_bytes(&tiling, data_dt);
   at::Tensor ws = workspace(nbytes, data_c);
   void* stream = stream_on(data_c);
-  at::Tensor ticket = ntiles == 1 ? tickets(1, data_c, stream, /*minmax*/ 1) : at::Tensor();
+  // per-tensor: A5 in the reduction's last block; symmetric with the one-sided fallback: the two words of the guess / settle pair
+  at::Tensor ticket = (ntiles == 1 || (symmetric && allow_one_sided)) ? tickets(2, data_c, stream, /*minmax*/ 1) : at::Tensor();
   check(ffq_quantize_dynamic_by_tile(data_c.data_ptr(), data_dt, &tiling, num_bits, symmetric ? 1 : 0, allow_one_sided ? 1 : 0, out.data_ptr(), out_dt,
                                      static_cast<float*>(scale.data_ptr()), static_cast<float*>(offset.data_ptr()), ptr(ws), nbytes,
                                      static_cast<int32_t*>(ptr(ticket)), stream));

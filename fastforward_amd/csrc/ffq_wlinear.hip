@@ -794,6 +794,9 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
 // and with an even number of super-steps (wq_dispatch); bf16 output.
 // (A gate+up+SiLU*up mode of this kernel was built and is bit-equal too, but measured 3-5 % SLOWER than the 8-wave kernel's —
 // 2.83 against 2.75 ms at 16 k tokens — and was removed; the plain form is +2 % on q/o and gate/up, +4 % on down_proj.)
+#ifndef FFQ_W4_AHEAD
+#define FFQ_W4_AHEAD 0  // A/B hook (tools/build_variant.sh): L2 warm-up distance in super-steps beyond the LDS-DMA's own
+#endif
 constexpr int W4_PITCH_PLAIN = 128 * 2 + 16;  // a staged row of a wave: 128 bf16 + pad
 constexpr int W4_WAVE_PLAIN = 16 * W4_PITCH_PLAIN;
 
@@ -876,6 +879,20 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (wl_lds_t*)(base + WL_IMAGE + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);
   };
 
+  // ---- L2 warm-up (FFQ_W4_AHEAD super-steps ahead of the LDS-DMA): a super-step of an image is ONE 128-byte line per row, so one
+  // dword per lane touches the 64 lines of this wave's rows of either operand. The dwords go to a scratch corner of LDS (no register
+  // is written: nothing to keep alive while the request flies) and stay outstanding across the mid-step wait (vmcnt counts in order:
+  // the DMA pieces are older), which gives a line from HBM two or three super-steps to arrive instead of one.
+#if FFQ_W4_AHEAD > 0
+  uint8_t* const warm = lds + 2 * WL_SLOT + 4 * W4_WAVE_PLAIN + wave * 512;
+  const uint32_t warm_voff = (uint32_t)(wave * 64 + lane) * row_bytes;
+  auto warm_up = [&](int kn, int which) {
+    int ks = kn + FFQ_W4_AHEAD;
+    ks = ks < ksuper ? ks : ksuper - 1;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? b_rsrc : a_rsrc, (wl_lds_t*)(warm + which * 256), 4, warm_voff, (uint32_t)ks * 128u, 0, 0);
+  };
+#endif
+
   // ---- fragment addresses: lane (r16, g4) reads 8 bf16 of row r16 of a 16-row tile, logical slot kq * 4 + g4; one register per
   // (slot, k-half, operand), the row tile in the instruction's offset field (t * 2048)
   const uint32_t r16 = lane & 15, g4 = lane >> 4;
@@ -956,9 +973,16 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
     auto super_step = [&](int kn, int cur) {
       const int nxt = cur ^ 1;
       // ---- first k-half: MFMAs on set 0 | read the second k-half of `cur` into set 1
+#if FFQ_W4_AHEAD > 0
+      phase(fa0, fb0, fa1, fb1, a_off[cur][1], b_off[cur][1], [&](int c) { if (c < 2) warm_up(kn, c); }, std::true_type{});
+      // the images of the next super-step have landed (this wave's pieces; the barrier makes it everybody's), `cur` has been read in
+      // full; the two warm-up dwords issued in this k-half are younger than the pieces and stay in flight
+      asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+#else
       phase(fa0, fb0, fa1, fb1, a_off[cur][1], b_off[cur][1], [](int) {}, std::false_type{});
       // the images of the next super-step have landed (this wave's pieces; the barrier makes it everybody's), `cur` has been read in full
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
       __builtin_amdgcn_s_barrier();
       // ---- second k-half: MFMAs on set 1 | LDS-DMA of super-step `kn` into `cur` | read the first k-half of `nxt` into set 0
       phase(fa1, fb1, fa0, fb0, a_off[nxt][0], b_off[nxt][0], [&](int c) { issue(kn, cur, c); }, std::true_type{});
@@ -1166,7 +1190,7 @@ static void wq_launch4w(const WLinearArgs& a, hipStream_t s) {
   const int total = a.tiles_m * a.tiles_n;
   const int cus = wq_cus();
   const unsigned grid = (unsigned)(total < cus ? total : cus);
-  const size_t lds_bytes = (size_t)2 * WL_SLOT + (size_t)4 * W4_WAVE_PLAIN;
+  const size_t lds_bytes = (size_t)2 * WL_SLOT + (size_t)4 * W4_WAVE_PLAIN + (FFQ_W4_AHEAD > 0 ? 4 * 512 : 0);
   static uint64_t attr_set = 0;
   ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_gemm4w_kernel), (int)lds_bytes);
   wq_gemm4w_kernel<<<grid, 256, lds_bytes, s>>>(a, total);

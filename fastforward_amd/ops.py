@@ -269,7 +269,8 @@ def quantize_dynamic_by_tile(
     offset = torch.empty(ntiles, dtype=torch.float32, device=data_c.device)
     nbytes = lib.ffq_quantize_dynamic_workspace_bytes(ctypes.byref(tiling), _tag(data_c.dtype))
     ws = _workspace(nbytes, data_c.device)
-    ticket = _tickets(1, data_c.device, stream, kind="minmax") if data_c.is_cuda and ntiles == 1 else None  # per-tensor: A5 in the reduction
+    # per-tensor: A5 in the reduction's last block; symmetric with the one-sided fallback: the two words of the guess / settle launches
+    ticket = _tickets(2, data_c.device, stream, kind="minmax") if data_c.is_cuda and (ntiles == 1 or (symmetric and allow_one_sided)) else None
     lib.check(
         lib.ffq_quantize_dynamic_by_tile(
             _ptr(data_c), _tag(data_c.dtype), ctypes.byref(tiling), float(num_bits), int(symmetric),

@@ -175,10 +175,15 @@ int ffq_parameters_for_range(const void* min_range, const void* max_range, int r
  * Empty input -> FFQ_ERR_EMPTY.
  * ONE launch (ABI 8; 2 B read + 1 B written per bf16 element into an int8 container) when every tile is a contiguous run of at
  * most 16384 (1-byte containers) / 8192 elements — per-token and per-channel(0) activations, group-128 weights — and the
- * parameters of a tile depend on that tile alone: asymmetric, or symmetric with allow_one_sided == 0 (the one-sided test of
- * range.py:100 is the only cross-tile dependency of the op). Everything else is A4 -> A5 -> A1 enqueued back to back through
- * `workspace`; with `ticket` (nullable; one int32, ZERO before the first call, left zero by every call: one word per stream)
- * a per-tensor call folds A5 into the reduction's last block (two launches instead of three). Same values on every route.
+ * parameters of a tile depend on that tile alone: asymmetric, or symmetric with allow_one_sided == 0. The one-sided test of
+ * range.py:100 (symmetric && allow_one_sided: is the smallest minimum of ALL tiles >= 0?) is the only cross-tile dependency of the
+ * op; with `ticket` those calls take the same kernel twice: every tile whose own minimum is negative answers the question by
+ * itself and is finished in the first launch, a tile that cannot know leaves its range behind and is counted, and the second
+ * launch returns at once when nothing was left open (data with both signs in every tile: 3 B/elem) or finishes the open tiles
+ * with the verdict (all of them when the data are non-negative: 5 B/elem, what the composed form moves).
+ * Everything else is A4 -> A5 -> A1 enqueued back to back through `workspace`; a per-tensor call with `ticket` folds A5 into the
+ * reduction's last block (two launches instead of three). Same values on every route.
+ * `ticket` (nullable): TWO int32, ZERO before the first call, left zero by every call: one pair per stream.
  */
 size_t ffq_quantize_dynamic_workspace_bytes(const ffq_tiling* tiling, int data_dt);
 int ffq_quantize_dynamic_by_tile(const void* data, int data_dt, const ffq_tiling* tiling,

@@ -378,6 +378,63 @@ def test_one_launch_dynamic_quantize_matches_oracle_and_the_composed_form(shape,
         assert same_with_nan(a, c), mismatch_report(a, c)
 
 
+@pytest.mark.parametrize("shape,gran", [((4, 96, 4096), ff.PerChannel((0, 1))), ((300, 1024), ff.PerBlock(1, 128, 0)), ((40, 16384), ff.PerChannel(0)), ((3000, 16), ff.PerChannel(0))], ids=str)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_symmetric_one_sided_dynamic_quantize_in_two_launches(shape, gran, dtype):
+    """symmetric AND allow_one_sided (range.py:100: one-sided iff the smallest minimum of ALL tiles is >= 0): the first launch finishes
+    every tile whose own minimum is negative, the second settles the rest with the verdict. Against the oracle and the composed form,
+    bit for bit, for: every tile non-negative (one-sided, every tile settled late), one negative element in the LAST tile, in the
+    first tile, a NaN in one tile of non-negative data (NaN >= 0 is False: two-sided), minima of -0.0 and +0.0, mixed signs everywhere.
+    The two ticket words are zero after every call and the result survives 20 repeats."""
+    g = torch.Generator().manual_seed(sum(shape))
+    base = (torch.randn(*shape, generator=g) * 3).to(dtype)
+    flat_len = base.numel()
+
+    def variant(kind):
+        x = base.abs().clone() if kind != "mixed" else base.clone()
+        f = x.view(-1)
+        if kind == "late_negative":
+            f[flat_len - 1] = -0.125
+        elif kind == "early_negative":
+            f[0] = -7.0
+        elif kind == "nan":
+            f[flat_len // 2] = float("nan")
+        elif kind == "zeros":
+            f[: shape[-1]] = 0.0
+            f[shape[-1]] = -0.0
+        return x
+
+    kinds = ("non_negative", "late_negative", "early_negative", "nan", "zeros", "mixed")
+
+    def run(device):
+        outs = []
+        for kind in kinds:
+            xd = variant(kind).to(device)
+            for qdt in (torch.int8, None):
+                q = ff.quantization.affine.dynamic.quantize_per_granularity(xd, gran, 8, symmetric=True, allow_one_sided=True, output_dtype=qdt)
+                p = q.quantization_context.quantization_params
+                outs += [q.raw_data.cpu(), p.scale.cpu(), p.offset.cpu()]
+        return outs
+
+    got, want = _both(run)
+    lib = _native.library()
+    previous = lib.ffq_force_generic_kernels(1)  # the composed A4 -> A5 -> A1 form
+    try:
+        composed = run(DEV)
+    finally:
+        lib.ffq_force_generic_kernels(previous)
+    for i, (a, b, c) in enumerate(zip(got, want, composed)):
+        assert same_with_nan(a, b), (kinds[i // 6], mismatch_report(a, b))
+        assert same_with_nan(a, c), (kinds[i // 6], mismatch_report(a, c))
+    for buf in ops._TICKETS.values():
+        assert int(buf.abs().sum()) == 0
+    xd = variant("late_negative").to(DEV)
+    first = ops.quantize_dynamic_by_tile(xd, gran.tile_size(xd.shape), 8, True, True, torch.int8)
+    for _ in range(20):
+        again = ops.quantize_dynamic_by_tile(xd, gran.tile_size(xd.shape), 8, True, True, torch.int8)
+        assert all(same_with_nan(u.cpu(), v.cpu()) for u, v in zip(first, again))
+
+
 @pytest.mark.parametrize("ntiles", [8193, 20000, 458752])
 @pytest.mark.parametrize("range_dtype", [torch.float32, torch.bfloat16])
 def test_parameters_for_range_grid_form_matches_oracle(ntiles, range_dtype):
