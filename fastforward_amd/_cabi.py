@@ -171,6 +171,7 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
         _i,
         [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _d, _i, _i64, _i64, _i64, _vp, _sz, _vp],
     ),
+    "ffq_linear_w8a8_gated": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _vp, _vp]),
     "ffq_gptq_block": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _d, _vp]),
     "ffq_pack_gguf_blocks": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "ffq_quantize_pack_int4": (_i, [_vp, _i, _vp, _i64, _vp, _i64, _tp, _i64, _vp, _vp]),

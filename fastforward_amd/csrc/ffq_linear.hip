@@ -24,6 +24,7 @@
 #include "ffq_affine.h"
 #include "ffq_common.h"
 #include "ffq_vec.h"
+#include "ffq_extrema.h"
 #include "ffq_silu.h"
 
 #include <math.h>
@@ -61,6 +62,9 @@ struct LinearArgs {
   const int8_t* wq2; const float* w_scale2; const int32_t* rowsum_w2;
   // batched matmul (ffq_bmm_w8a8, tail kernel only): blockIdx.y selects the matrix pair; element strides between consecutive matrices
   int64_t batch_x, batch_w, batch_out;
+  // gated output (ffq_linear_w8a8_gated): the bf16 [M, N] tensor whose silu multiplies this linear's bf16 result
+  const bf16_t* gate;
+  ExtremaSink extrema;  // words == nullptr: not wanted. [min, max] of the gated product (ffq_extrema.h)
 };
 
 // The value the linear would have returned in dtype `y_dt` (one rounding), as fp32
@@ -267,9 +271,13 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 // Epilogue of the plain mode: 32 rows x 64 columns per wave and round go through LDS (144-byte pitch, conflict-free
 // ds_write_b64) and leave as whole 128-byte lines with the non-temporal hint (the output is not read again by this launch
 // and must not push the operand panels out of L2: gate/up shape +7.7 %, A/B of two builds on one box).
-template <typename TOut, bool REQUANT, bool WOFF>
+// GATED (ffq_linear_w8a8_gated; bf16 out, whole 128-byte lines): what leaves is bf16(silu(gate)) * y with y this linear's bf16
+// value — the MLP's silu(gate_proj(x)) * up_proj(x) (mlp.py:36-38) formed in up_proj's epilogue from gate_proj's stored result,
+// with the roundings of the two-tensor chain (ffq_silu.h's table; ops.silu_mul_quantize's product).
+template <typename TOut, bool REQUANT, bool WOFF, bool GATED = false>
 __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4i32 (&acc)[8][4], uint8_t* scratch, int wave, int lane,
-                                                         int wm, int wn, int m0, int n0) {
+                                                         int wm, int wn, int m0, int n0, [[maybe_unused]] const uint16_t* silu_table = nullptr,
+                                                         [[maybe_unused]] float* zext = nullptr /* GATED: this lane's running {min, max, NaN seen} of the product */) {
   TOut* out = static_cast<TOut*>(a.out);
   float oscale = 1.0f, ooff = 0.0f;
   if constexpr (REQUANT) {
@@ -291,6 +299,22 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
   const bool lds_path = sizeof(TOut) == 2 && (a.N & 7) == 0 && wave_n0 + 64 <= a.N;
   bool woff_live = false;
   if constexpr (WOFF) woff_live = *a.woff_live != 0;
+  // GATED: the gate lines of slab round i + 1 are fetched while round i is computed (round 0's here, ahead of the parameter
+  // loads): a load issued where it is used exposes a trip to HBM per round and line batch (+227 us on the gate / up shape)
+  [[maybe_unused]] u32x4 gate_next[4];
+  [[maybe_unused]] auto fetch_gate = [&](int i) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = lane + 64 * t;
+      const int row = c >> 3, seg = c & 7;
+      int mm = wave_m0 + i * 32 + row;
+      mm = mm < a.M ? mm : a.M - 1;
+      gate_next[t] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(a.gate) + ((size_t)mm * a.N + wave_n0) * 2 + seg * 16);
+    }
+  };
+  if constexpr (GATED) {
+    if (lds_path) fetch_gate(0);
+  }
   {
     int n = wave_n0 + lane;
     n = n < a.N ? n : a.N - 1;
@@ -382,12 +406,47 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
     }
     if (lds_path) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      [[maybe_unused]] u32x4 gate_now[4];
+      if constexpr (GATED) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gate_now[t] = gate_next[t];
+        if (i < 3) fetch_gate(i + 1);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int c = lane + 64 * t;
         const int row = c >> 3, seg = c & 7;
         const int mm = wave_m0 + i * 32 + row;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * ROW_BYTES + seg * 16);
+        u32x4 v = *reinterpret_cast<const u32x4*>(region + row * ROW_BYTES + seg * 16);
+        if constexpr (GATED) {
+          if (mm < a.M) {
+            const u32x4 g = gate_now[t];
+            const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, uw[4] = {v.x, v.y, v.z, v.w};
+            uint32_t sw[4], bad = 0, zw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sw[q] = silu_pair_lookup(gw[q], silu_table, bad);
+            if (silu_any_outside(bad)) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) sw[q] = silu_pair_patch(gw[q], sw[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)  // bf16 x bf16 -> fp32 exactly, one rounding to bf16: the product tensor of the two-tensor chain
+              zw[q] = pack2<bf16_t>(__builtin_bit_cast(float, sw[q] << 16) * __builtin_bit_cast(float, uw[q] << 16),
+                                    __builtin_bit_cast(float, sw[q] & 0xFFFF0000u) * __builtin_bit_cast(float, uw[q] & 0xFFFF0000u));
+            v.x = zw[0]; v.y = zw[1]; v.z = zw[2]; v.w = zw[3];
+            if (a.extrema.words) {
+              float zmn = zext[0], zmx = zext[512], znan = zext[1024];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float z0 = __builtin_bit_cast(float, zw[q] << 16), z1 = __builtin_bit_cast(float, zw[q] & 0xFFFF0000u);
+                zmn = __builtin_fminf(zmn, __builtin_fminf(z0, z1));
+                zmx = __builtin_fmaxf(zmx, __builtin_fmaxf(z0, z1));
+                znan = (z0 != z0 || z1 != z1) ? 1.0f : znan;
+              }
+              zext[0] = zmn; zext[512] = zmx; zext[1024] = znan;
+            }
+          }
+        }
         if (mm < a.M)
           __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * a.N + wave_n0) * 2 + seg * 16));
       }
@@ -527,7 +586,7 @@ __device__ __forceinline__ void mlp_epilogue16_body(const LinearArgs& a, v4i32 (
   }
 }
 
-template <typename TOut, bool REQUANT, bool MLP, bool WOFF = false>
+template <typename TOut, bool REQUANT, bool MLP, bool WOFF = false, bool GATED = false>
 __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, int total_tiles) {
   constexpr int BN2 = 256, WAVES_N = 4;
   constexpr int BN_OUT = MLP ? 128 : 256;
@@ -548,9 +607,20 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   const uint32_t xcd_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
   const uint32_t xcd_count = tq + (xcd < tr ? 1u : 0u);
   const int my_tiles = j_in_xcd < xcd_count ? (int)((xcd_count - j_in_xcd + blocks_in_xcd - 1) / blocks_in_xcd) : 0;
-  if (my_tiles == 0) return;
+  if (my_tiles == 0) {
+    if constexpr (GATED) {
+      if (a.extrema.words && tid == 0) extrema_publish(a.extrema, 0.0f, 0.0f, false, false, gridDim.x);
+    }
+    return;
+  }
   uint16_t* const silu_table = reinterpret_cast<uint16_t*>(lds2 + 2 * SLOT_BYTES);
-  if constexpr (MLP) silu_table_fill(silu_table, (uint32_t)tid, 512u);
+  // GATED: the lane's running {min, max, NaN seen} of the product lives in LDS behind the table (three registers held across the
+  // K-loop spill next to the 128 accumulators), lane-interleaved: word j of thread t at [j * 512 + t]
+  [[maybe_unused]] float* const zext = reinterpret_cast<float*>(lds2 + 2 * SLOT_BYTES + kSiluBytes) + tid;
+  if constexpr (GATED) {
+    zext[0] = INFINITY; zext[512] = -INFINITY; zext[1024] = 0.0f;
+  }
+  if constexpr (MLP || GATED) silu_table_fill(silu_table, (uint32_t)tid, 512u);
 
   const int d_row = lane >> 3;
   uint32_t a_voff[4], b_voff[4];   // lane offsets inside the tile's rows: < 256 K + 128
@@ -737,10 +807,32 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
       }
       mlp_epilogue16_body(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table);
     } else {
-      gemm256_epilogue_slabs16<TOut, REQUANT, WOFF>(a, acc, scratch, wave, lane, wm, wn, m0, n0);
+      gemm256_epilogue_slabs16<TOut, REQUANT, WOFF, GATED>(a, acc, scratch, wave, lane, wm, wn, m0, n0, silu_table, zext);
     }
     __syncthreads();  // the scratch slot is the next tile's DMA target
     m0 = nm0; n0 = nn0;
+  }
+  if constexpr (GATED) {
+    if (a.extrema.words) {  // lanes -> waves -> block -> the launch's three words (the operand ring is free: every tile is done)
+      float mn = zext[0], mx = zext[512], nan = zext[1024];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        mn = __builtin_fminf(mn, __shfl_xor(mn, d, 64));
+        mx = __builtin_fmaxf(mx, __shfl_xor(mx, d, 64));
+        nan = __builtin_fmaxf(nan, __shfl_xor(nan, d, 64));
+      }
+      float* red = reinterpret_cast<float*>(lds2);
+      if (lane == 0) { red[wave] = mn; red[8 + wave] = mx; red[16 + wave] = nan; }
+      __syncthreads();
+      if (tid == 0) {
+        for (int w = 1; w < 8; ++w) {
+          mn = __builtin_fminf(mn, red[w]);
+          mx = __builtin_fmaxf(mx, red[8 + w]);
+          nan = __builtin_fmaxf(nan, red[16 + w]);
+        }
+        extrema_publish(a.extrema, mn, mx, nan != 0.0f, true, gridDim.x);
+      }
+    }
   }
 }
 
@@ -796,11 +888,12 @@ extern "C" size_t ffq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t 
   return (size_t)(((M + N + 1) * 4 + 255) & ~(int64_t)255);
 }
 
-extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
-                               const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset,
-                               int w_per_row, const void* bias, int bias_dt, void* out, int out_dt,
-                               const float* out_scale, const float* out_offset, double out_num_bits, int y_dt, int64_t M,
-                               int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                            const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset,
+                            int w_per_row, const void* bias, int bias_dt, void* out, int out_dt,
+                            const float* out_scale, const float* out_offset, double out_num_bits, int y_dt, int64_t M,
+                            int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream, const void* gate,
+                            uint32_t* extrema_words = nullptr, void* extrema_pair = nullptr) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
@@ -840,10 +933,15 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.group_m = GROUP_M2;
   a.group_cols = 0;
+  a.gate = static_cast<const bf16_t*>(gate);
+  a.extrema.words = extrema_words; a.extrema.pair = extrema_pair; a.extrema.pair_dt = FFQ_BF16;
 
   int32_t* ws = static_cast<int32_t*>(workspace);
   const int64_t tiles256 = ((M + BM2 - 1) / BM2) * ((N + 255) / 256);
   const bool persistent = K % 128 == 0 && K >= 256 && M >= 128 && N >= 128 && tiles256 >= 64;
+  // the gated epilogue lives in the persistent kernel's whole-line store path: everything else is the caller's two launches
+  if (gate && !(persistent && N % 64 == 0 && out_dt == FFQ_BF16 && !requant && !bias && aligned16(gate) && aligned16(out)))
+    return fail(FFQ_ERR_DTYPE, "gated w8a8 linear: outside the persistent kernel's whole-line path (bf16 out, N %% 64 == 0, >= 64 tiles of 256 x 256)");
   bool flag_written = false;
   if (x_offset) {  // sum_k wq[n, k] for the zero-point term: one pass over the weight codes, unless the caller has them
     if (w_rowsum) {
@@ -879,6 +977,18 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t
 #endif
     const unsigned total = (unsigned)(a.tiles_m * a.tiles_n);
     const unsigned grid = total < 256u ? total : 256u;  // persistent: one block per CU
+    if (gate) {  // bf16 out, no re-quantization (checked above); with or without weight offsets
+      const size_t lds_gated = (size_t)2 * (BM2 + 256) * 128 + kSiluBytes + 3 * 512 * 4;
+#define FFQ_FQ_GATED(WO)                                                                                                        \
+  do {                                                                                                                          \
+    static uint64_t attr_set = 0;                                                                                               \
+    ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&w8a8_gemm256fq_kernel<bf16_t, false, false, WO, true>), (int)lds_gated); \
+    w8a8_gemm256fq_kernel<bf16_t, false, false, WO, true><<<grid, 512, lds_gated, s>>>(a, (int)total);                          \
+  } while (0)
+      if (w_offset) FFQ_FQ_GATED(true); else FFQ_FQ_GATED(false);
+#undef FFQ_FQ_GATED
+      return check_launch("w8a8_gemm256fq_kernel (gated)");
+    }
     const size_t lds = (size_t)2 * (BM2 + 256) * 128;
 #define FFQ_FQ_LAUNCH(T, RQ, WO)                                                                            \
   do {                                                                                                      \
@@ -928,6 +1038,26 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t
   return check_launch("w8a8_gemm_kernel");
 }
 
+extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                               const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset,
+                               int w_per_row, const void* bias, int bias_dt, void* out, int out_dt,
+                               const float* out_scale, const float* out_offset, double out_num_bits, int y_dt, int64_t M,
+                               int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  return linear_w8a8_impl(xq, wq, w_rowsum, x_scale, x_offset, x_per_row, w_scale, w_offset, w_per_row, bias, bias_dt, out, out_dt, out_scale,
+                          out_offset, out_num_bits, y_dt, M, N, K, workspace, workspace_bytes, stream, nullptr);
+}
+
+// out = bf16(silu(gate)) * bf16(linear(x, w))  — see include/ffq.h
+extern "C" int ffq_linear_w8a8_gated(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                                     const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset,
+                                     int w_per_row, const void* gate, void* out, int64_t M, int64_t N, int64_t K,
+                                     void* workspace, size_t workspace_bytes, uint32_t* extrema_words, void* extrema_pair, void* stream) {
+  if (!gate) return fail(FFQ_ERR_ARG, "NULL gate");
+  if ((extrema_words == nullptr) != (extrema_pair == nullptr)) return fail(FFQ_ERR_ARG, "extrema_words and extrema_pair come together");
+  return linear_w8a8_impl(xq, wq, w_rowsum, x_scale, x_offset, x_per_row, w_scale, w_offset, w_per_row, nullptr, 0, out, FFQ_BF16, nullptr,
+                          nullptr, 8.0, 0, M, N, K, workspace, workspace_bytes, stream, gate, extrema_words, extrema_pair);
+}
+
 // ---- bmm: `batch` independent [M, K] x [N, K]^T products with ONE parameter pair per operand, as ONE launch -----------------------
 // fallback.bmm (_gen/fallback.py:699-798 pattern: dequantize both operands, torch.bmm, output quantizer) on int8 codes: the
 // 128 x 128-tile kernel with the matrix pair chosen by blockIdx.y (round 3 looped over the batch in Python: up to 256 launches
@@ -967,6 +1097,7 @@ extern "C" int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_s
   a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.woff_live = nullptr;
   a.wq2 = nullptr; a.w_scale2 = nullptr; a.rowsum_w2 = nullptr;
   a.batch_x = M * K; a.batch_w = N * K; a.batch_out = M * N;
+  a.gate = nullptr; a.extrema.words = nullptr; a.extrema.pair = nullptr; a.extrema.pair_dt = 0;
   a.bias = nullptr; a.bias_dt = 0;
   a.out = out; a.out_dt = out_dt;
   a.out_scale = out_scale; a.out_offset = out_offset;
@@ -1038,6 +1169,7 @@ extern "C" int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, con
   a.w_scale = gate_w_scale; a.w_scale2 = up_w_scale; a.w_offset = nullptr;
   a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.rowsum_w2 = nullptr; a.woff_live = nullptr;
   a.batch_x = a.batch_w = a.batch_out = 0;
+  a.gate = nullptr; a.extrema.words = nullptr; a.extrema.pair = nullptr; a.extrema.pair_dt = 0;
   a.bias = nullptr; a.bias_dt = 0;
   a.out = codes_out; a.out_dt = FFQ_I8;
   a.out_scale = out_scale; a.out_offset = out_offset;

@@ -30,7 +30,7 @@ import torch.nn.functional as F
 import fastforward_amd as ff
 
 from fastforward_amd.nn import QuantizedModule, QuantizerStub
-from fastforward_amd.quantization.affine._memo import sibling_quantizers
+from fastforward_amd.quantization.affine._memo import RECENT, sibling_quantizers
 
 
 @dataclasses.dataclass(frozen=True)
@@ -1000,6 +1000,7 @@ class FusedProducersForward:
         # (ops.linear_wq(pack_block=...)); frozen inference weights do not change between forwards.
         self.weight_storage = weight_storage
         self._stored: dict[int, tuple[tuple[int, int, int], torch.Tensor, int]] = {}
+        self._product_extrema: tuple[torch.Tensor, torch.Tensor] | None = None  # (SiLU * up product, its [min, max]) of the layer in flight
 
     def _stored_weight(self, linear: torch.nn.Module) -> tuple[torch.Tensor, int] | None:
         """(codes or packed nibbles, packing block) of a weight-only linear's weight under ``weight_storage``, or None when
@@ -1027,9 +1028,13 @@ class FusedProducersForward:
         self._stored[id(linear)] = (key, stored, block)
         return stored, block
 
-    def _linear(self, x: torch.Tensor, linear: torch.nn.Module) -> torch.Tensor:
+    def _linear(self, x: torch.Tensor, linear: torch.nn.Module, gate: torch.Tensor | None = None) -> torch.Tensor:
         """QuantizedLinear.forward; int8 codes on both sides go to the int8 GEMM directly, stored weight codes of a weight-only
-        linear to the bf16 x weight-code GEMM."""
+        linear to the bf16 x weight-code GEMM. With `gate` (the bf16 result of the MLP's gate projection) the result is
+        silu(gate) * linear(x) — formed in the int8 GEMM's epilogue where that launch covers the shapes."""
+        if gate is not None:
+            product = self._gated(x, linear, gate)
+            return product if product is not None else ff.ops.silu_mul_quantize(gate, self._linear(x, linear), (), want_product=True)[0]
         if linear.bias is not None or linear.weight_quantizer.is_stub() or not linear.output_quantizer.is_stub():
             return linear(x)
         if linear.input_quantizer.is_stub():
@@ -1062,6 +1067,32 @@ class FusedProducersForward:
         w_offset = None if wp.offset is None or ff.fused_linear.known_zero_offset(wp.offset) else wp.offset
         return ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, None, out_dtype=torch.bfloat16)
 
+    def _gated(self, x: torch.Tensor, linear: torch.nn.Module, gate: torch.Tensor) -> torch.Tensor | None:
+        """silu(gate) * linear(x) as ONE launch of the int8 GEMM (ops.linear_w8a8_gated), or None: the quantizers run exactly as
+        in ``_linear`` (range estimation included); only what consumes their codes differs."""
+        if (linear.bias is not None or linear.weight_quantizer.is_stub() or not linear.output_quantizer.is_stub() or linear.input_quantizer.is_stub()
+                or gate.dtype != torch.bfloat16):
+            return None
+        xq = linear.input_quantizer(x)
+        wq = linear.weight_quantizer(linear.weight)
+        usable = (isinstance(xq, ff.QuantizedTensor) and isinstance(wq, ff.QuantizedTensor) and xq.raw_data.dtype == torch.int8 and wq.raw_data.dtype == torch.int8)
+        if usable:
+            xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
+            usable = xp.scale.numel() == 1 and ff.fused_linear.KERNELS.row_mode(wq) is not None
+        product = None
+        if usable:
+            w_offset = None if wp.offset is None or ff.fused_linear.known_zero_offset(wp.offset) else wp.offset
+            both = ff.ops.linear_w8a8_gated(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, gate, want_extrema=True)
+            if both is not None:  # [min, max] of the product rode along: down_proj's estimator step starts from the two numbers
+                product, self._product_extrema = both[0], (both[0], both[1])
+        if product is None:  # the quantizers have run (an estimator step each): finish on the codes / tensors they returned
+            if usable:
+                up = ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, None, out_dtype=torch.bfloat16)
+            else:
+                up = ff.nn.functional.linear(xq, wq, None, output_quantizer=linear.output_quantizer)
+            product = ff.ops.silu_mul_quantize(gate, up, (), want_product=True)[0]
+        return product
+
     def _qkv(self, normed: torch.Tensor, attn: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """The three projections of the attention block: one launch for weight-only linears the GEMM covers, else one by one."""
         projections = (attn.q_proj, attn.k_proj, attn.v_proj)
@@ -1090,8 +1121,8 @@ class FusedProducersForward:
                 if product is not None:
                     return product
         with sibling_quantizers():
-            gate, up = self._linear(normed, gate_proj), self._linear(normed, up_proj)
-        return ff.ops.silu_mul_quantize(gate, up, (), want_product=True)[0]
+            gate = self._linear(normed, gate_proj)
+            return self._linear(normed, up_proj, gate=gate)
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, logits: bool = False) -> torch.Tensor:
@@ -1114,8 +1145,13 @@ class FusedProducersForward:
                     ctx = _sdpa(q, k, v, cfg, b, s)
                 attn_out = self._linear(ctx, attn.o_proj)
                 hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, attn_out, ln2.weight, ln2.variance_epsilon, (), want_norm=True, sum_inplace=True)
+                self._product_extrema = None
                 product = self._gate_up(normed, mlp)
-                pending = self._linear(product, mlp.down_proj)
+                with sibling_quantizers():
+                    if self._product_extrema is not None and self._product_extrema[0] is product:
+                        RECENT.remember_extrema(product, self._product_extrema[1])
+                    pending = self._linear(product, mlp.down_proj)
+                self._product_extrema = None
             _, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, model.norm.weight, model.norm.variance_epsilon, (), want_sum=False, want_norm=True)
             return model.lm_head(normed) if logits else normed
 

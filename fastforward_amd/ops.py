@@ -245,6 +245,24 @@ def _tickets(count: int, device: torch.device, stream: int, kind: str = "wq") ->
     return have
 
 
+# The three accumulator words + the arrival counter of a producer launch that also leaves [min, max] of its output
+# (csrc/ffq_extrema.h): {0xFFFFFFFF, 0, 0, 0} before the first launch, put back by every launch — one buffer per (device, stream)
+# for eager launches, a fresh one inside a hipGraph capture.
+_EXTREMA_WORDS: dict[tuple[int, int], torch.Tensor] = {}
+
+
+def _extrema_words(device: torch.device, stream: int) -> torch.Tensor:
+    capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(stream or 0))
+    have = None if capturing else _EXTREMA_WORDS.get(key)
+    if have is None:
+        have = torch.zeros(4, dtype=torch.int32, device=device)
+        have[0] = -1
+        if not capturing:
+            _EXTREMA_WORDS[key] = have
+    return have
+
+
 def quantize_dynamic_by_tile(
     data: torch.Tensor,
     tile_size: Sequence[int],
@@ -778,6 +796,58 @@ def _linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, bias, o
         )
     )
     return out
+
+
+def linear_w8a8_gated(
+    x_codes: torch.Tensor,
+    w_codes: torch.Tensor,
+    x_scale: torch.Tensor,
+    x_offset: torch.Tensor | None,
+    w_scale: torch.Tensor,
+    w_offset: torch.Tensor | None,
+    gate: torch.Tensor,
+    w_rowsum: torch.Tensor | None = None,
+    want_extrema: bool = False,
+) -> torch.Tensor | tuple[torch.Tensor, torch.Tensor] | None:
+    """``silu(gate) * linear(x, w)`` with the linear on int8 codes and the product formed in its epilogue: the second
+    projection of a gated MLP (reference docs/examples/doc_helpers/quantized_llama/mlp.py:36-38) when the first one's bf16 result
+    `gate` [..., N] is at hand and the product's own quantizer is not yet known (range estimation). Equals
+    ``silu_mul_quantize(gate, linear_w8a8(...), (), want_product=True)[0]`` bit for bit. None where the one-launch form does not
+    apply (then take those two calls). ``want_extrema``: returns ``(product, pair)`` with ``pair = [min, max]`` of the product in
+    bf16 (``minmax_by_tile`` over the whole tensor), left by the same launch: the reduction a RunningMinMax step on the product
+    would start with."""
+    if x_codes.dtype != torch.int8 or w_codes.dtype != torch.int8:
+        raise TypeError("linear_w8a8_gated expects int8 codes")
+    xc, wc, gc = x_codes.detach().contiguous(), w_codes.detach().contiguous(), gate.detach().contiguous()
+    K, N = xc.shape[-1], wc.shape[0]
+    M = xc.numel() // K if K else 0
+    if wc.dim() != 2 or wc.shape[1] != K:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({M}x{K} and {tuple(wc.shape)}^T)")
+    if gc.dtype != torch.bfloat16 or gc.numel() != M * N or gc.shape[-1] != N or M == 0 or N == 0:
+        return None
+
+    def f32(t: torch.Tensor | None) -> torch.Tensor | None:
+        return None if t is None else t.detach().reshape(-1).to(torch.float32).contiguous()
+
+    xs, xo, ws_, wo = f32(x_scale), f32(x_offset), f32(w_scale), f32(w_offset)
+    if xs.numel() not in (1, M) or ws_.numel() not in (1, N):
+        return None
+    if w_rowsum is not None and (w_rowsum.dtype != torch.int32 or w_rowsum.numel() != N or not w_rowsum.is_contiguous() or w_rowsum.device != wc.device):
+        raise RuntimeError(f"w_rowsum must be a contiguous int32 tensor with {N} entries on the codes' device")
+    lib, stream = _prepare(xc, wc, gc, xs, xo, ws_, wo)
+    out = torch.empty((*xc.shape[:-1], N), dtype=torch.bfloat16, device=xc.device)
+    nbytes = lib.ffq_linear_w8a8_workspace_bytes(M, N, K)
+    ws = _workspace(nbytes, xc.device)
+    words = _extrema_words(xc.device, stream) if want_extrema else None
+    pair = torch.empty(2, dtype=torch.bfloat16, device=xc.device) if want_extrema else None
+    status = lib.ffq_linear_w8a8_gated(
+        _ptr(xc), _ptr(wc), _ptr(w_rowsum), _ptr(xs), _ptr(xo), int(xs.numel() != 1), _ptr(ws_), _ptr(wo), int(ws_.numel() != 1),
+        _ptr(gc), _ptr(out), M, N, K, _ptr(ws), nbytes, _ptr(words), _ptr(pair), stream,
+    )
+    if status == 6:  # FFQ_ERR_DTYPE: outside the persistent kernel's whole-line path
+        return None
+    lib.check(status)
+    return (out, pair) if want_extrema else out
 
 
 def bmm_w8a8(

@@ -229,6 +229,24 @@ int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The second linear of a gated MLP on int8 codes: out = bf16(silu(gate)) * bf16(y), y = ffq_linear_w8a8(...) in bf16 —
+ * silu(gate_proj(x)) * up_proj(x) of the reference's Llama MLP (docs/examples/doc_helpers/quantized_llama/mlp.py:36-38) formed in
+ * up_proj's epilogue from gate_proj's stored bf16 result `gate` [M, N]: the up tensor and the SiLU * up pass (two reads, one write
+ * of M x N bf16) never exist. Same values as the three-step chain (silu rounded to bf16, then one rounding of the product).
+ * For launches whose down_proj input quantizer is not yet known (range estimation: ffq_mlp_gate_up_w8a8 needs its parameters).
+ * bf16 output, no bias; other arguments as ffq_linear_w8a8. Covered: N % 64 == 0, K % 128 == 0, >= 64 output tiles of
+ * 256 x 256; anything else returns FFQ_ERR_DTYPE and the caller takes ffq_linear_w8a8 + ffq_silu_mul_quantize.
+ * `extrema_words` / `extrema_pair` (both or neither): the launch also leaves [min, max] of the product (bf16, NaN-propagating:
+ * what ffq_minmax_by_tile over `out` as one tile returns) in `extrema_pair` — the first step of the next quantizer's RunningMinMax
+ * estimator without a pass over the tensor. `extrema_words`: four uint32 holding {0xFFFFFFFF, 0, 0, 0} before the first launch
+ * that uses them; every launch leaves them in that state (one buffer per stream).
+ */
+int ffq_linear_w8a8_gated(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                          const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset,
+                          int w_per_row, const void* gate, void* out, int64_t M, int64_t N, int64_t K,
+                          void* workspace, size_t workspace_bytes, uint32_t* extrema_words, void* extrema_pair, void* stream);
+
+/*
  * bmm on int8 codes — the quantized-operand pattern of _gen/fallback.py:699-798 (dequantize both operands, the float op, the output
  * quantizer) for `batch` independent products out[b] = xq[b] [M, K] x wq[b]^T [N, K] with ONE parameter pair per operand (per-tensor
  * quantizers: the batch shares them), as ONE launch; arithmetic, epilogue and the optional fused output quantizer exactly as

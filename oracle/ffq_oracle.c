@@ -1079,6 +1079,28 @@ int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* 
   return rc;
 }
 
+/* mlp.py:36-38 with gate_proj's result at hand: the second linear (A6, bf16), then SiLU(gate) * up — composed from the restatements above */
+int ffq_linear_w8a8_gated(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
+                          const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset,
+                          int w_per_row, const void* gate, void* out, int64_t M, int64_t N, int64_t K,
+                          void* workspace, size_t workspace_bytes, uint32_t* extrema_words, void* extrema_pair, void* stream) {
+  if (!gate) return fail(FFQ_ERR_ARG, "NULL gate");
+  if ((extrema_words == NULL) != (extrema_pair == NULL)) return fail(FFQ_ERR_ARG, "extrema_words and extrema_pair come together");
+  if (M <= 0 || N <= 0) return FFQ_OK;
+  uint16_t* u = (uint16_t*)malloc((size_t)M * N * 2);
+  int rc = ffq_linear_w8a8(xq, wq, w_rowsum, x_scale, x_offset, x_per_row, w_scale, w_offset, w_per_row, NULL, 0, u, FFQ_BF16, NULL, NULL, 8.0,
+                           FFQ_BF16, M, N, K, workspace, workspace_bytes, stream);
+  if (!rc) rc = ffq_silu_mul_quantize(gate, u, FFQ_BF16, M * N, out, NULL, stream);
+  free(u);
+  if (!rc && extrema_pair) {  /* A4 of the product as ONE tile (minmax.py:215-232 on the finished tensor) */
+    ffq_tiling t;
+    memset(&t, 0, sizeof t);
+    t.ndim = 1; t.shape[0] = M * N; t.tile[0] = M * N;
+    rc = ffq_minmax_by_tile(out, FFQ_BF16, &t, extrema_pair, (uint16_t*)extrema_pair + 1, 0, NULL, NULL, 0, NULL, stream);
+  }
+  return rc;
+}
+
 /* pack_q4_0_blocks / pack_q8_0_blocks, export/stages/gguf/_packing.py:23-72. The module cannot be imported in the
    build container (it pulls in the `gguf` package, which is not installed), so this restatement is pinned by the
    reference's own assertions for it (tests/export/stages/gguf/test_packing.py), re-expressed in tests/. */

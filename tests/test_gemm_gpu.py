@@ -420,3 +420,66 @@ def test_a_learnable_weight_offset_written_through_dot_data_is_seen_by_the_next_
         want = x_hat @ w_hat.t()
     assert not torch.equal(got, zero)
     torch.testing.assert_close(got.double(), want, rtol=2.0**-7, atol=1e-3 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("m,n,k", [(2048, 2048, 512), (2000, 2112, 256), (4096, 4096, 1024)], ids=str)
+@pytest.mark.parametrize("weight_offset", [None, "zero", "real"])
+def test_gated_epilogue_is_silu_of_the_gate_times_the_plain_output(m, n, k, weight_offset):
+    """ops.linear_w8a8_gated (silu(gate) * linear in the int8 GEMM's epilogue: the MLP's second projection during range estimation)
+    == silu_mul_quantize(gate, linear_w8a8(...)) bit for bit — i.e. ATen's F.silu(gate) * up on the two bf16 tensors (mlp.py:36-38;
+    tests/test_parity_gpu.py pins silu_mul_quantize to that chain). The gate tensor holds every bf16 pattern (NaN, Inf, denormals,
+    both zeros) besides ordinary activations; ragged M, N % 256 != 0, with / without (all-zero) weight offsets."""
+    g = torch.Generator(device=DEV).manual_seed(m + n + k)
+    xq = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+    wq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    sx = torch.tensor([0.013], device=DEV)
+    ox = torch.tensor([-7.0], device=DEV)
+    sw = torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+    ow = None if weight_offset is None else (torch.zeros(n, device=DEV) if weight_offset == "zero" else torch.round(torch.randn(n, device=DEV, generator=g) * 3))
+    gate = (torch.randn(m, n, device=DEV, generator=g) * 4).to(torch.bfloat16)
+    patterns = torch.arange(65536, device=DEV, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)
+    gate.view(-1)[: 65536] = patterns
+    gate.view(-1)[-65536:] = patterns.flip(0)
+    up = ops.linear_w8a8(xq, wq, sx, ox, sw, ow, None, out_dtype=torch.bfloat16)
+    want = ops.silu_mul_quantize(gate, up, (), want_product=True)[0]
+    got = ops.linear_w8a8_gated(xq, wq, sx, ox, sw, ow, gate)
+    assert got is not None
+    eager = torch.nn.functional.silu(gate) * up
+    for other in (want, eager):  # the same bits wherever the value is a number, NaN where the chain gives NaN (its payload is not pinned)
+        assert torch.equal(got.isnan(), other.isnan())
+        assert torch.equal(torch.where(got.isnan(), 0, got.view(torch.int16)), torch.where(other.isnan(), 0, other.view(torch.int16)))
+
+
+def test_gated_epilogue_declines_what_the_whole_line_path_does_not_cover():
+    g = torch.Generator(device=DEV).manual_seed(1)
+    for m, n, k in ((2048, 2040, 512), (256, 256, 512), (2048, 2048, 320)):
+        xq = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+        wq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+        gate = torch.randn(m, n, device=DEV, generator=g).to(torch.bfloat16)
+        assert ops.linear_w8a8_gated(xq, wq, torch.tensor([0.01], device=DEV), None, torch.tensor([0.02], device=DEV), None, gate) is None
+
+
+@pytest.mark.parametrize("with_nan", [False, True])
+def test_gated_epilogue_leaves_the_extrema_of_its_product(with_nan):
+    """want_extrema: [min, max] of the product, left by the launch that wrote it == ops.minmax_by_tile over the finished tensor
+    (NaN-propagating), launch after launch from the same four accumulator words; ragged M and columns beyond N % 256 included."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for m, n, k in ((2048, 2048, 256), (2000, 2112, 512)):
+        xq = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+        wq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+        sx, ox = torch.tensor([0.02], device=DEV), torch.tensor([3.0], device=DEV)
+        sw = torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+        ow = torch.round(torch.randn(n, device=DEV, generator=g))
+        for trial in range(3):
+            gate = (torch.randn(m, n, device=DEV, generator=g) * (trial + 1)).to(torch.bfloat16)
+            if with_nan and trial == 1:
+                gate[m - 1, n - 1] = float("nan")
+            if trial == 2:
+                gate[5, 7] = -0.0
+            product, pair = ops.linear_w8a8_gated(xq, wq, sx, ox, sw, ow, gate, want_extrema=True)
+            lo, hi = ops.minmax_by_tile(product, product.shape)
+            assert torch.equal(pair[0:1].isnan(), lo.isnan()) and torch.equal(pair[1:2].isnan(), hi.isnan())
+            if not bool(lo.isnan()):
+                assert torch.equal(pair.view(torch.int16), torch.cat([lo, hi]).view(torch.int16)), (pair, lo, hi)
+    for words in ops._EXTREMA_WORDS.values():
+        assert words.tolist() == [-1, 0, 0, 0]
