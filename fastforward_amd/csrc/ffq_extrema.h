@@ -28,21 +28,12 @@ __device__ __forceinline__ float extrema_value(uint32_t key) {
   return __builtin_bit_cast(float, (key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
 }
 
-// one thread per block, after the block's reduction; `arrivals` = blocks of the launch that call this (all of them)
-__device__ __forceinline__ void extrema_publish(const ExtremaSink& s, float mn, float mx, bool nan, bool any, uint32_t arrivals) {
-  if (any) {  // (returning atomics: complete at L2 before the ticket below is taken)
-    (void)__hip_atomic_fetch_min(s.words + 0, extrema_key(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    (void)__hip_atomic_fetch_max(s.words + 1, extrema_key(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (nan) (void)__hip_atomic_fetch_or(s.words + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const uint32_t t = __hip_atomic_fetch_add(s.words + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (t != arrivals - 1) return;
-  asm volatile("" ::: "memory");
+// the words -> the pair, and the words back to their initial state (one thread, after every block has merged)
+__device__ __forceinline__ void extrema_finish(const ExtremaSink& s) {
   const uint32_t kmin = __hip_atomic_load(s.words + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t kmax = __hip_atomic_load(s.words + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t knan = __hip_atomic_load(s.words + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // (an empty tensor never gets here with values: +inf / -inf, the estimator's own initial state)
+  // (nothing merged: +inf / -inf, the estimator's own initial state)
   const float lo = knan ? NAN : (kmin == 0xFFFFFFFFu ? INFINITY : extrema_value(kmin));
   const float hi = knan ? NAN : (kmax == 0u ? -INFINITY : extrema_value(kmax));
   store_any(s.pair, s.pair_dt, 0, (double)lo);
@@ -51,6 +42,29 @@ __device__ __forceinline__ void extrema_publish(const ExtremaSink& s, float mn, 
   __hip_atomic_store(s.words + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(s.words + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(s.words + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One thread per block, after the block's reduction. A block first LOOKS at the words and merges only what would move them: a
+// stale look costs an atomic that changes nothing, never a wrong result (min / max are idempotent), and after the first few
+// arrivals almost no block of a 16 k-block launch has anything to add — the words are read-shared, not a serialised hot spot.
+// `arrivals` = blocks of the launch that call this (all of them): the last one finishes. 0: no ticket — a one-thread
+// extrema_finish launch follows in stream order (launches of thousands of short-lived blocks).
+__device__ __forceinline__ void extrema_publish(const ExtremaSink& s, float mn, float mx, bool nan, bool any, uint32_t arrivals) {
+  if (any) {  // (returning atomics: complete at L2 before the ticket below is taken)
+    const uint32_t kmn = extrema_key(mn), kmx = extrema_key(mx);
+    if (kmn < __hip_atomic_load(s.words + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      (void)__hip_atomic_fetch_min(s.words + 0, kmn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (kmx > __hip_atomic_load(s.words + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      (void)__hip_atomic_fetch_max(s.words + 1, kmx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nan && __hip_atomic_load(s.words + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+      (void)__hip_atomic_fetch_or(s.words + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (arrivals == 0) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t t = __hip_atomic_fetch_add(s.words + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t != arrivals - 1) return;
+  asm volatile("" ::: "memory");
+  extrema_finish(s);
 }
 
 }  // namespace ffq

@@ -858,6 +858,10 @@ struct DynRowsArgs {
   uint32_t ntiles, chunks_per_run;
   float lo, hi;  // clamp bounds
   RangeArgs range;
+  // RUNNING (ffq_running_minmax_quantize: a RunningMinMax estimator step and the quantizer's own forward in one pass): the
+  // estimator's per-tile running min / max in the data dtype, merged in place, and its status word (flags of THIS batch)
+  void* run_min; void* run_max;
+  int32_t* flags;
 };
 
 // R = tiles a group of lanes works on at once (R > 1: whole-block groups only): all their loads are issued up front, the R reductions
@@ -876,7 +880,12 @@ struct DynRowsArgs {
 //              zeroes the two ticket words.
 enum { DYN_PLAIN = 0, DYN_GUESS = 1, DYN_SETTLE = 2 };
 
-template <typename TIn, typename TOut, int E, int P, int U, int R = 1, int MODE = DYN_PLAIN>
+// RUNNING: the tile's fresh extrema are merged into the estimator's running pair (read before the block's barrier, written by the
+// group's first lane after it), the status flags describe this batch, and A5 runs on the MERGED range read back in the data dtype —
+// range_setting/minmax.py:215-239 followed by the range setter and the quantizer's forward (common.py:218-238) in 2 R + 1 W bytes
+// per element instead of 2 + 2 R + 1 W. With the global one-sided question the open tiles need no stash: their merged range is
+// in the running buffers; offset_out holds -0.0 as the marker.
+template <typename TIn, typename TOut, int E, int P, int U, int R = 1, int MODE = DYN_PLAIN, bool RUNNING = false>
 __global__ __launch_bounds__(kBlock) void quantize_dynamic_rows_kernel(const TIn* __restrict__ in, TOut* __restrict__ out,
                                                                        float* __restrict__ scale_out, float* __restrict__ offset_out,
                                                                        DynRowsArgs a, int32_t* __restrict__ ticket, uint32_t logical_blocks) {
@@ -902,8 +911,13 @@ __global__ __launch_bounds__(kBlock) void quantize_dynamic_rows_kernel(const TIn
       if constexpr (MODE == DYN_SETTLE) {
         mine[r] = t0 + r < a.ntiles && (__builtin_bit_cast(uint32_t, offset_out[t0 + r]) >> 31) != 0;
         if (mine[r]) {
-          m[r].mn = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, offset_out[t0 + r]) & 0x7FFFFFFFu);
-          m[r].mx = scale_out[t0 + r];
+          if constexpr (RUNNING) {
+            m[r].mn = to_f32(static_cast<const TIn*>(a.run_min)[t0 + r]);
+            m[r].mx = to_f32(static_cast<const TIn*>(a.run_max)[t0 + r]);
+          } else {
+            m[r].mn = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, offset_out[t0 + r]) & 0x7FFFFFFFu);
+            m[r].mx = scale_out[t0 + r];
+          }
           m[r].nan = false;  // (a NaN minimum is "not >= 0": such a tile was finished by the first launch)
         }
       }
@@ -916,6 +930,15 @@ __global__ __launch_bounds__(kBlock) void quantize_dynamic_rows_kernel(const TIn
     }
     // (a whole-block group: every wave has read the tile's marker before the first lane replaces it with the parameters)
     if constexpr (MODE == DYN_SETTLE && P > 64) __syncthreads();
+    [[maybe_unused]] float prev_mn[R], prev_mx[R];
+    if constexpr (RUNNING && MODE != DYN_SETTLE) {  // every lane of the group, ahead of the barrier its first lane writes behind
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t t = t0 + r < a.ntiles ? t0 + r : a.ntiles - 1;
+        prev_mn[r] = to_f32(static_cast<const TIn*>(a.run_min)[t]);
+        prev_mx[r] = to_f32(static_cast<const TIn*>(a.run_max)[t]);
+      }
+    }
     if constexpr (MODE != DYN_SETTLE) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -957,12 +980,28 @@ __global__ __launch_bounds__(kBlock) void quantize_dynamic_rows_kernel(const TIn
       if (t >= a.ntiles || !mine[r]) continue;
       const size_t row = (size_t)t * a.chunks_per_run;
       // torch.min / torch.max propagate NaN; the extrema are elements of the data, so .to(float32) is exact   (:257-258, range.py:90)
-      const float mn = m[r].nan ? NAN : m[r].mn, mx = m[r].nan ? NAN : m[r].mx;
+      float mn = m[r].nan ? NAN : m[r].mn, mx = m[r].nan ? NAN : m[r].mx;
+      if constexpr (RUNNING && MODE != DYN_SETTLE) {  // write_result() of the two-step form, on this tile
+        int f = 0;
+        if (__builtin_isinf(mn) || __builtin_isinf(mx)) f |= FFQ_FLAG_INF;
+        if (m[r].nan) f |= FFQ_FLAG_NAN;
+        mn = (prev_mn[r] != prev_mn[r] || mn != mn) ? NAN : __builtin_fminf(prev_mn[r], mn);
+        mx = (prev_mx[r] != prev_mx[r] || mx != mx) ? NAN : __builtin_fmaxf(prev_mx[r], mx);
+        if (lane == 0) {
+          static_cast<TIn*>(a.run_min)[t] = from_f32<TIn>(mn);
+          static_cast<TIn*>(a.run_max)[t] = from_f32<TIn>(mx);
+          if (f && a.flags) atomicOr(a.flags, f);
+        }
+      }
       if constexpr (MODE == DYN_GUESS) {
         if (mn >= 0.0f) {  // the answer depends on the other tiles: leave the range behind and count the tile
           if (lane == 0) {
-            scale_out[t] = mx;
-            offset_out[t] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, mn) | 0x80000000u);
+            if constexpr (RUNNING) {
+              offset_out[t] = -0.0f;  // (the merged range is in the running buffers)
+            } else {
+              scale_out[t] = mx;
+              offset_out[t] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, mn) | 0x80000000u);
+            }
             ++open_here;
           }
           continue;
@@ -974,6 +1013,7 @@ __global__ __launch_bounds__(kBlock) void quantize_dynamic_rows_kernel(const TIn
         scale_out[t] = scale;
         offset_out[t] = offset;
       }
+      if constexpr (RUNNING) offset = rne(offset);  // the parameter keeps its fraction, A1 rounds it (_quantizer_impl.py:140-141); A3's is rounded already
       const Divider<1> d(scale);
       bool fast = false;
       // the run's own extrema bound every |x|: one test per tile decides for the packed arithmetic of ffq_affine.h
@@ -1034,18 +1074,19 @@ static bool launch_dynamic_rows(const void* data, void* out, float* scale_out, f
   const TIn* in = static_cast<const TIn*>(data);
   TOut* o = static_cast<TOut*>(out);
   const bool global_question = a.range.symmetric && a.range.allow_one_sided;  // (the caller checked the ticket words)
-#define FFQ_DYN_R(P, U, R)                                                                                        \
+#define FFQ_DYN_M(P, U, R, RUN)                                                                                   \
   do {                                                                                                            \
     const int64_t per_block = (int64_t)(kBlock / P) * R;                                                          \
     const unsigned grid = (unsigned)((info.ntiles + per_block - 1) / per_block);                                  \
     if (!global_question) {                                                                                       \
-      quantize_dynamic_rows_kernel<TIn, TOut, E, P, U, R, DYN_PLAIN><<<grid, kBlock, 0, stream>>>(in, o, scale_out, offset_out, a, nullptr, grid); \
+      quantize_dynamic_rows_kernel<TIn, TOut, E, P, U, R, DYN_PLAIN, RUN><<<grid, kBlock, 0, stream>>>(in, o, scale_out, offset_out, a, nullptr, grid); \
     } else {                                                                                                      \
-      quantize_dynamic_rows_kernel<TIn, TOut, E, P, U, R, DYN_GUESS><<<grid, kBlock, 0, stream>>>(in, o, scale_out, offset_out, a, ticket, grid);  \
+      quantize_dynamic_rows_kernel<TIn, TOut, E, P, U, R, DYN_GUESS, RUN><<<grid, kBlock, 0, stream>>>(in, o, scale_out, offset_out, a, ticket, grid);  \
       const unsigned settle = grid < 2048u ? grid : 2048u;                                                        \
-      quantize_dynamic_rows_kernel<TIn, TOut, E, P, U, R, DYN_SETTLE><<<settle, kBlock, 0, stream>>>(in, o, scale_out, offset_out, a, ticket, grid); \
+      quantize_dynamic_rows_kernel<TIn, TOut, E, P, U, R, DYN_SETTLE, RUN><<<settle, kBlock, 0, stream>>>(in, o, scale_out, offset_out, a, ticket, grid); \
     }                                                                                                             \
   } while (0)
+#define FFQ_DYN_R(P, U, R) do { if (a.run_min) FFQ_DYN_M(P, U, R, true); else FFQ_DYN_M(P, U, R, false); } while (0)
 #define FFQ_DYN(P, U) FFQ_DYN_R(P, U, 1)
   if (chunks <= 1) FFQ_DYN(1, 1);
   else if (chunks <= 2) FFQ_DYN(2, 1);
@@ -1064,6 +1105,7 @@ static bool launch_dynamic_rows(const void* data, void* out, float* scale_out, f
   else FFQ_DYN(256, 4);
 #undef FFQ_DYN
 #undef FFQ_DYN_R
+#undef FFQ_DYN_M
   return true;
 }
 
@@ -1081,7 +1123,8 @@ static bool launch_dynamic_rows_out(int out_dt, const void* data, void* out, flo
 // true: the one-launch kernel was enqueued (*rc holds the launch status); false: the caller composes A4 -> A5 -> A1
 static bool dynamic_one_launch(const void* data, int data_dt, const TileInfo& info, double num_bits, int symmetric,
                                int allow_one_sided, void* out, int out_dt, float* scale_out, float* offset_out,
-                               int32_t* ticket, hipStream_t stream, int* rc) {
+                               int32_t* ticket, hipStream_t stream, int* rc, void* run_min = nullptr, void* run_max = nullptr,
+                               int32_t* flags = nullptr) {
   if (info.layout != LAYOUT_ROWS || info.ntiles >= ((int64_t)1 << 31) || info.numel >= ((int64_t)1 << 36)) return false;
   // the one decision that is global over the tiles (range.py:100) takes two ticket words (DYN_GUESS / DYN_SETTLE); a single tile
   // answers it in the reduction's last block (below)
@@ -1093,7 +1136,9 @@ static bool dynamic_one_launch(const void* data, int data_dt, const TileInfo& in
   a.chunks_per_run = 0;
   const double lo = -pow(2.0, num_bits - 1.0);
   a.lo = (float)lo; a.hi = (float)(-lo - 1.0);
-  a.range = make_range_args(data_dt, info.ntiles, num_bits, symmetric, allow_one_sided, FFQ_F32, FFQ_F32, 1);
+  // A3 rounds the offset it returns (_quantizer_impl.py:275); a static quantizer's parameter keeps its fraction (range.py:121)
+  a.range = make_range_args(data_dt, info.ntiles, num_bits, symmetric, allow_one_sided, FFQ_F32, FFQ_F32, run_min ? 0 : 1);
+  a.run_min = run_min; a.run_max = run_max; a.flags = flags;
   bool done = false;
   switch (data_dt) {
     case FFQ_BF16: done = launch_dynamic_rows_out<bf16_t>(out_dt, data, out, scale_out, offset_out, info, a, ticket, stream); break;
@@ -1143,6 +1188,25 @@ int ffq_running_minmax_step(const void* data, int data_dt, const ffq_tiling* til
   // the reduction's scratch is free again (stream order): the grid form of A5 keeps its per-block minima there
   return parameters_impl(min_inout, max_inout, data_dt, info.ntiles, num_bits, symmetric, allow_one_sided, scale_out, scale_dt, offset_out,
                          offset_dt, 0, workspace, workspace_bytes, s);
+}
+
+// The estimator step above AND the quantizer's forward on the same data (range_setting/common.py:218-238: estimate_step, then
+// the quantizer's own forward) in one pass over it — see include/ffq.h
+int ffq_running_minmax_quantize(const void* data, int data_dt, const ffq_tiling* tiling, void* min_inout, void* max_inout,
+                                int32_t* status_flags, double num_bits, int symmetric, int allow_one_sided, float* scale_out,
+                                float* offset_out, void* out, int out_dt, int32_t* ticket, void* stream) {
+  if (!data || !min_inout || !max_inout || !scale_out || !offset_out || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (!dt_valid(data_dt) || !dt_valid(out_dt)) return fail(FFQ_ERR_ARG, "bad dtype tag");
+  TileInfo info;
+  int rc = analyse(tiling, &info);
+  if (rc) return rc;
+  if (info.numel == 0) return fail(FFQ_ERR_DTYPE, "running min/max + quantize: empty tensor (take the two steps)");
+  if (!ffq_can_support_bitwidth(out_dt, num_bits))
+    return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.", out_dt, num_bits);
+  if (info.ntiles == 1 || !dynamic_one_launch(data, data_dt, info, num_bits, symmetric, allow_one_sided, out, out_dt, scale_out, offset_out, ticket,
+                                              static_cast<hipStream_t>(stream), &rc, min_inout, max_inout, status_flags))
+    return fail(FFQ_ERR_DTYPE, "running min/max + quantize: tiling outside the one-pass kernel (take ffq_running_minmax_step, then ffq_quantize_by_tile)");
+  return rc;
 }
 
 size_t ffq_parameters_for_range_workspace_bytes(int64_t ntiles, int symmetric, int allow_one_sided) {

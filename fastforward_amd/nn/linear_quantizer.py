@@ -245,6 +245,42 @@ class LinearQuantizer(AbstractAffineQuantizer):
                 torch.autograd.graph.increment_version(self.offset)
             return True
 
+    def update_range_and_quantize(self, data: torch.Tensor, tile: Any, running_min: torch.Tensor, running_max: torch.Tensor,
+                                  status: torch.Tensor | None) -> QuantizedTensor | None:
+        """:meth:`update_range_from_data` AND ``self.quantize(data)`` in one pass over `data` (``ops.running_minmax_quantize``): the
+        two things a RunningMinMax estimator's override does per call (reference range_setting/common.py:218-238). The result is the
+        QuantizedTensor ``quantize`` returns with the parameters the step wrote. None — nothing touched — where the one-pass kernel
+        or its preconditions do not apply; the caller then takes the two steps."""
+        with torch.no_grad():
+            cls = type(self)
+            plain = (
+                cls.quantization_range is LinearQuantizer.quantization_range and cls._write_parameters_for_range is LinearQuantizer._write_parameters_for_range
+                and cls.quantize is LinearQuantizer.quantize and cls.quantization_parameters is LinearQuantizer.quantization_parameters
+                and cls.quantization_function is LinearQuantizer.quantization_function
+            )
+            if not plain or not data.is_cuda or type(data) not in (torch.Tensor, torch.nn.Parameter) or running_min.numel() <= 1:
+                return None
+            from fastforward_amd import flags
+
+            if flags.get_export_mode() or (torch.is_grad_enabled() and data.requires_grad):
+                return None
+            container = self.quantized_dtype or data.dtype
+            if self.has_uninitialized_params:
+                self._initialize_parameters(running_min.numel())
+            if self.scale.device != data.device or self.scale.numel() != running_min.numel() or (self.offset is not None and self.offset.numel() != running_min.numel()):
+                return None
+            offset_out = self.offset.data if self.offset is not None else torch.empty(running_min.numel(), dtype=torch.float32, device=data.device)
+            raw = ops.running_minmax_quantize(data, tile, running_min, running_max, status, self.num_bits, self.symmetric, self.allow_one_sided,
+                                              self.scale.data, offset_out, container)
+            if raw is None:
+                return None
+            torch.autograd.graph.increment_version(self.scale)  # written through raw pointers: tell the version counters
+            if self.offset is not None:
+                torch.autograd.graph.increment_version(self.offset)
+            params = self.quantization_parameters()
+            stamped = params.with_changes(dequantize_dtype=params.dequantize_dtype or data.dtype)  # (function.py: _static_quantize)
+            return QuantizedTensor(raw, QuantizationContext(self.quantization_function, stamped))
+
     def _write_parameters_for_range(self, lo: torch.Tensor, hi: torch.Tensor) -> None:
         """A5 straight into ``scale`` / ``offset`` — no host round trip (reference :350-357 + range.py)."""
         with torch.no_grad():

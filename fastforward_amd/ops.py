@@ -501,6 +501,50 @@ def _running_minmax_step(data, tile_size, running_min, running_max, status_flags
     )
 
 
+def running_minmax_quantize(
+    data: torch.Tensor,
+    tile_size: Sequence[int],
+    running_min: torch.Tensor,
+    running_max: torch.Tensor,
+    status_flags: torch.Tensor | None,
+    num_bits: float,
+    symmetric: bool,
+    allow_one_sided: bool,
+    scale_out: torch.Tensor,
+    offset_out: torch.Tensor,
+    output_dtype: torch.dtype,
+) -> torch.Tensor | None:
+    """:func:`running_minmax_step` AND ``quantize_by_tile(data, scale_out, tile_size, num_bits, output_dtype, offset_out)`` in one
+    pass over `data` (C ABI ``ffq_running_minmax_quantize``): what ``estimate_ranges`` runs per quantizer call with a RunningMinMax
+    estimator (reference range_setting/common.py:218-238). Returns the codes, or None — nothing written — where the one-pass kernel
+    does not apply (host tensors, one tile, tiles that are not short contiguous runs, parameters that are not contiguous fp32):
+    take the two calls."""
+    if _host_route(data) or not data.is_contiguous() or running_min.dtype != data.dtype or running_max.dtype != data.dtype:
+        return None
+    if scale_out.dtype != torch.float32 or offset_out.dtype != torch.float32 or not scale_out.is_contiguous() or not offset_out.is_contiguous():
+        return None
+    if not running_min.is_contiguous() or not running_max.is_contiguous():
+        return None
+    data_c = data.detach()
+    lib, stream = _prepare(data_c, running_min, running_max, scale_out, offset_out, status_flags)
+    tiling = _tile_of(data_c, tile_size)
+    ntiles = lib.ffq_num_tiles(ctypes.byref(tiling))
+    if ntiles < 0:
+        lib.check(-ntiles)
+    if ntiles <= 1 or running_min.numel() != ntiles or running_max.numel() != ntiles or scale_out.numel() != ntiles or offset_out.numel() != ntiles:
+        return None
+    out = torch.empty(data_c.shape, dtype=output_dtype, device=data_c.device)
+    ticket = _tickets(2, data_c.device, stream, kind="minmax") if symmetric and allow_one_sided else None
+    status = lib.ffq_running_minmax_quantize(
+        _ptr(data_c), _tag(data_c.dtype), ctypes.byref(tiling), _ptr(running_min), _ptr(running_max), _ptr(status_flags), float(num_bits),
+        int(symmetric), int(allow_one_sided), _ptr(scale_out), _ptr(offset_out), _ptr(out), _tag(output_dtype), _ptr(ticket), stream,
+    )
+    if status == 6:  # FFQ_ERR_DTYPE: outside the one-pass kernel; no buffer was touched
+        return None
+    lib.check(status)
+    return out
+
+
 def parameters_for_range(
     min_range: torch.Tensor,
     max_range: torch.Tensor,
@@ -1265,12 +1309,15 @@ def add_rmsnorm_quantize(
     want_sum: bool = True,
     want_norm: bool = False,
     sum_inplace: bool = False,
+    norm_extrema: list[torch.Tensor] | None = None,
 ) -> tuple[torch.Tensor | None, torch.Tensor | None, list[torch.Tensor]]:
     """Residual add + RMSNorm + A1 for up to three per-tensor int8 quantizers, one pass
     (reference docs/examples/doc_helpers/quantized_llama/rms_norm.py:17-35 behind decoder.py:60-90).
 
     Returns ``(x + delta, normalised or None, [codes per quantizer])``; with ``delta is None`` the first
     element is `x` itself. ``sum_inplace`` writes the sum over `x` (the residual stream of a decoder).
+    ``norm_extrema``: an empty list that receives ``[min, max]`` of the normalised tensor (bf16 pair, ``minmax_by_tile`` over the
+    whole tensor) where the kernel can leave it on the way (rows of more than 1024 elements); left empty otherwise.
     """
     xc = x.detach().contiguous()
     dc = None if delta is None else delta.detach().contiguous()
@@ -1287,12 +1334,17 @@ def add_rmsnorm_quantize(
     total = xc if dc is None or sum_inplace else (torch.empty_like(xc) if want_sum else None)
     norm = torch.empty_like(xc) if want_norm else None
     fan, codes, keep = _fan(quantizers, num_bits, xc.shape, xc.device)
+    words = pair = None
+    if norm_extrema is not None and cols > 1024 and rows > 0 and xc.is_cuda:
+        words, pair = _extrema_words(xc.device, stream), torch.empty(2, dtype=xc.dtype, device=xc.device)
     lib.check(
         lib.ffq_add_rmsnorm_quantize(
             _ptr(xc), _ptr(dc), None if dc is None else _ptr(total), _ptr(wc), _tag(xc.dtype), rows, cols, float(eps),
-            _ptr(norm), ctypes.byref(fan), stream,
+            _ptr(norm), ctypes.byref(fan), _ptr(words), _ptr(pair), stream,
         )
     )
+    if pair is not None:
+        norm_extrema.append(pair)
     del keep
     if sum_inplace and dc is not None:
         torch.autograd.graph.increment_version(x)  # written through a raw pointer

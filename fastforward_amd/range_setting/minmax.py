@@ -66,6 +66,31 @@ class RunningMinMaxEstimator(_MinMaxState):
         if self.status is not None and int(self.status.item()) & ops.FLAG_INF:
             raise NotImplementedError("Infinite")
 
+    def forward(self, quantizer: Any, callback: Any, args: tuple[Any, ...], kwargs: dict[str, Any]) -> torch.Tensor:
+        """``estimate_step`` then the quantizer's forward (reference common.py:218-238) — as ONE pass over the data where this
+        estimator is the quantizer's only override, works sync-free and the quantizer offers ``update_range_and_quantize`` (per-channel /
+        per-token / per-block tilings of a plain LinearQuantizer on the device): a weight is read once per calibration step
+        instead of twice. Same running state, parameters, status flags and codes as the two steps."""
+        if self.sync_free and not self._disable_quantization and not kwargs and len(args) == 1 and isinstance(args[0], torch.Tensor):
+            fused = getattr(quantizer, "update_range_and_quantize", None)
+            overrides = getattr(quantizer, "_quantizer_overrides", None)
+            data = args[0]
+            if fused is not None and overrides is not None and len(overrides) == 1 and next(iter(overrides.values())) is self:
+                if not self._initialized:
+                    self.setup_estimator(data)
+                    self._initialized = True
+                self.initialize_parameters(quantizer, data)
+                assert self.min is not None and self.max is not None
+                if self.min.dtype == data.dtype and self.max.dtype == data.dtype and self.min.device == data.device and self.min.numel() > 1:
+                    tile = quantizer.granularity.tile_size(data.shape)
+                    tile = data.shape if isinstance(tile, str) else tile
+                    if self.status is None or self.status.device != data.device:
+                        self.status = torch.zeros(1, dtype=torch.int32, device=data.device)
+                    out = fused(data, tile, self.min, self.max, self.status)
+                    if out is not None:
+                        return out
+        return super().forward(quantizer, callback, args, kwargs)
+
     def estimate_step(self, quantizer: RangeSettable, data: torch.Tensor) -> None:
         self.initialize_parameters(quantizer, data)
         assert self.min is not None and self.max is not None

@@ -152,6 +152,21 @@ int ffq_running_minmax_step(const void* data, int data_dt, const ffq_tiling* til
                             int32_t* ticket, void* stream);
 
 /*
+ * The estimator step above AND the quantizer's own forward on the same data in ONE pass (2 B read + 1 B written per bf16 element
+ * into an int8 container, instead of A4's read + A1's read and write): what ``estimate_ranges`` runs per quantizer call —
+ * RunningMinMax.estimate_step, the range setter, then the quantizer's forward (range_setting/common.py:218-238) — for tilings whose
+ * tiles are contiguous runs of at most 16384 / 8192 elements (per-channel(0) weights, per-token activations, group-128 weights;
+ * more than one tile). Running min / max (data dtype) merged in place, status flags of THIS batch OR-ed in, scale / offset
+ * (fp32, one per tile; the offset keeps its fraction as ffq_parameters_for_range leaves it) written, codes = A1 of `data` with
+ * them. symmetric && allow_one_sided needs `ticket` (two int32, ZERO before the first call, left zero: the guess / settle launches
+ * of ffq_quantize_dynamic_by_tile, judged on the MERGED minima). Same values as the two calls, bit for bit.
+ * Anything else returns FFQ_ERR_DTYPE before touching a buffer: take ffq_running_minmax_step, then ffq_quantize_by_tile.
+ */
+int ffq_running_minmax_quantize(const void* data, int data_dt, const ffq_tiling* tiling, void* min_inout, void* max_inout,
+                                int32_t* status_flags, double num_bits, int symmetric, int allow_one_sided, float* scale_out,
+                                float* offset_out, void* out, int out_dt, int32_t* ticket, void* stream);
+
+/*
  * A5 — parameters_for_range, quantization/affine/range.py:54-122, fused with the copy performed
  * by the LinearQuantizer.quantization_range setter, nn/linear_quantizer.py:350-357.
  * min/max (dtype `range_dt`, `ntiles` entries) are cast to fp32 (:90); the one-sided test is
@@ -368,10 +383,13 @@ typedef struct ffq_fanout {
  * norm_out are nullable (sum_out may alias x). The fp32 summation order of mean(h^2) is the
  * kernel's own, so z can differ from the eager chain by one bf16 ulp on rare elements; the codes are
  * exactly A1 of the z this call produces. cols % 16 == 0, cols <= 8192.
+ * `extrema_words` / `extrema_pair` (both or neither; ABI 8, cols > 1024 else FFQ_ERR_DTYPE): [min, max] of z in bf16 — what
+ * ffq_minmax_by_tile over z as one tile returns — left by the same pass (+ a one-thread finishing launch); words as in
+ * ffq_linear_w8a8_gated.
  */
 int ffq_add_rmsnorm_quantize(const void* x, const void* delta, void* sum_out, const void* weight,
                              int dt, int64_t rows, int64_t cols, double eps, void* norm_out,
-                             const ffq_fanout* fan, void* stream);
+                             const ffq_fanout* fan, uint32_t* extrema_words, void* extrema_pair, void* stream);
 
 /*
  * SiLU(gate) * up — mlp.py:30-40:  z = bf16(silu(float(gate))) * up  (bf16), codes = A1(z).

@@ -543,6 +543,20 @@ int ffq_running_minmax_step(const void* data, int data_dt, const ffq_tiling* til
                                   scale_dt, offset_out, offset_dt, NULL, 0, stream);
 }
 
+/* range_setting/common.py:218-238 for a RunningMinMax estimator: estimate_step (above), then the quantizer's own forward = A1 with
+ * the parameters the step just wrote — the composition of the restatements, as the reference composes the calls */
+int ffq_running_minmax_quantize(const void* data, int data_dt, const ffq_tiling* tiling, void* min_inout, void* max_inout,
+                                int32_t* status_flags, double num_bits, int symmetric, int allow_one_sided, float* scale_out,
+                                float* offset_out, void* out, int out_dt, int32_t* ticket, void* stream) {
+  (void)ticket;
+  const int64_t ntiles = ffq_num_tiles(tiling);
+  if (ntiles < 0) return (int)-ntiles;
+  int rc = ffq_running_minmax_step(data, data_dt, tiling, min_inout, max_inout, status_flags, num_bits, symmetric, allow_one_sided, scale_out,
+                                   FFQ_F32, offset_out, FFQ_F32, NULL, 0, NULL, stream);
+  if (rc) return rc;
+  return ffq_quantize_by_tile(data, data_dt, scale_out, FFQ_F32, ntiles, offset_out, FFQ_F32, ntiles, tiling, num_bits, out, out_dt, stream);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* A3: quantize_dynamic_by_tile_impl, quantization/_quantizer_impl.py:243-285                  */
 /* ------------------------------------------------------------------------------------------ */
@@ -809,8 +823,10 @@ static void fan_quantize(const ffq_fanout* fan, double lo, double hi, float z, i
 /* rms_norm.py:17-35 (LlamaRMSNorm.forward) behind the residual add of decoder.py:60-90 */
 int ffq_add_rmsnorm_quantize(const void* x, const void* delta, void* sum_out, const void* weight,
                              int dt, int64_t rows, int64_t cols, double eps, void* norm_out,
-                             const ffq_fanout* fan, void* stream) {
+                             const ffq_fanout* fan, uint32_t* extrema_words, void* extrema_pair, void* stream) {
   (void)stream;
+  /* the ride-along extrema are a device-side saving of one pass (A4 over norm_out gives the same pair): not restated here */
+  if (extrema_words || extrema_pair) return fail(FFQ_ERR_DTYPE, "oracle: take ffq_minmax_by_tile over the normalised tensor");
   if (rows < 0 || cols < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "fused RMSNorm is built for bf16 activations");
   if (cols == 0) return fail(FFQ_ERR_EMPTY, "RMSNorm over an empty row");

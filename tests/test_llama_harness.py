@@ -518,3 +518,63 @@ def test_gptq_invalidates_cached_weight_codes(oracle_backend):
     assert layer.weight._version > w_version
     after = cached(ids).float()
     assert torch.equal(after, llama.FusedForward(model)(ids).float()) and not torch.equal(after, before)
+
+
+@pytest.mark.gpu
+def test_producers_leaving_extrema_change_no_range(hip_backend, monkeypatch):
+    """During range estimation the fused producers leave [min, max] of what they write (RMSNorm's output, the SiLU * up product of the
+    gated int8 GEMM) and the estimators of the consuming linears start from those two numbers; weights take the one-pass
+    estimator-step-and-quantize kernel. With every one of those shortcuts switched off — estimators reduce over the tensors,
+    the SiLU * up pass runs, weights take the two steps — the calibrated parameters are the same bits."""
+    from fastforward_amd import distributed as ffd
+    from fastforward_amd.quantization.affine._memo import RECENT
+
+    cfg = llama.LlamaConfig(hidden_size=2048, intermediate_size=4096, num_layers=2, num_heads=16, num_kv_heads=4, vocab_size=512)
+
+    def calibrated(shortcuts):
+        torch.manual_seed(5)
+        model = llama.build_model(cfg, "cuda", torch.bfloat16, seed=9)
+        llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
+        batches = [torch.randint(0, cfg.vocab_size, (4, 512), device="cuda") for _ in range(3)]
+        hits = RECENT.extrema_hits
+        with monkeypatch.context() as patch:
+            if not shortcuts:
+                patch.setattr(RECENT, "remember_extrema", lambda data, pair: None)
+                patch.setattr(ff.ops, "linear_w8a8_gated", lambda *a, **k: None)
+                patch.setattr(ff.nn.LinearQuantizer, "update_range_and_quantize", lambda self, *a, **k: None)
+            ffd.calibrate_sharded(model, batches, disable_quantization=False, fused=True)
+        return ffd.ranges_fingerprint(model), RECENT.extrema_hits - hits
+
+    want, hits_without = calibrated(False)
+    got, hits_with = calibrated(True)
+    # per layer and step: q/k/v and gate/up share the normalised input's pair (5 estimator steps), down_proj takes the product's
+    assert hits_with >= hits_without + 3 * cfg.num_layers * 4
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+@pytest.mark.gpu
+def test_rmsnorm_leaves_the_extrema_of_its_output(hip_backend):
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for rows, cols in ((64, 2048), (37, 4096), (16, 8192)):
+        x = (torch.randn(rows, cols, device="cuda", generator=g) * 3).to(torch.bfloat16)
+        delta = torch.randn(rows, cols, device="cuda", generator=g).to(torch.bfloat16)
+        weight = (torch.rand(cols, device="cuda", generator=g) + 0.5).to(torch.bfloat16)
+        for trial in range(3):
+            if trial == 1:
+                x[rows - 1, cols - 1] = float("nan")
+            if trial == 2:
+                x[rows - 1, cols - 1] = 1.0
+                x[0, :] = 0.0
+                delta[0, :] = 0.0
+            ext: list[torch.Tensor] = []
+            _, norm, _ = ff.ops.add_rmsnorm_quantize(x, delta, weight, 1e-5, (), want_norm=True, norm_extrema=ext)
+            assert len(ext) == 1
+            lo, hi = ff.ops.minmax_by_tile(norm, norm.shape)
+            assert torch.equal(ext[0][0:1].isnan(), lo.isnan()) and torch.equal(ext[0][1:2].isnan(), hi.isnan())
+            if not bool(lo.isnan()):
+                assert torch.equal(ext[0].view(torch.int16), torch.cat([lo, hi]).view(torch.int16))
+    ext = []
+    ff.ops.add_rmsnorm_quantize(torch.randn(8, 512, device="cuda").to(torch.bfloat16), None, torch.ones(512, device="cuda", dtype=torch.bfloat16), 1e-5, (), want_norm=True, norm_extrema=ext)
+    assert ext == []  # short rows: the estimator reads the tensor
+    for words in ff.ops._EXTREMA_WORDS.values():
+        assert words.tolist() == [-1, 0, 0, 0]

@@ -435,6 +435,63 @@ def test_symmetric_one_sided_dynamic_quantize_in_two_launches(shape, gran, dtype
         assert all(same_with_nan(u.cpu(), v.cpu()) for u, v in zip(first, again))
 
 
+RUNNING_QUANTIZE_CASES = [
+    ((512, 4096), ff.PerChannel(0)),         # a weight: one 256-lane block per two rows
+    ((96, 14336), ff.PerChannel(0)),         # down_proj-shaped rows
+    ((64, 1024), ff.PerBlock(1, 128, 0)),    # group 128
+    ((4, 64, 2048), ff.PerChannel((0, 1))),  # per-token activations
+    ((33, 16), ff.PerChannel(0)),            # one chunk per tile
+    ((64, 1001), ff.PerChannel(0)),          # rows that split chunks: declined, the two steps run
+    ((7, 33), ff.PerTensor()),               # one tile: declined
+]
+
+
+@pytest.mark.parametrize("shape,gran", RUNNING_QUANTIZE_CASES, ids=str)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("symmetric,one_sided", [(True, True), (True, False), (False, True)])
+def test_estimator_step_and_quantize_in_one_pass(shape, gran, dtype, symmetric, one_sided):
+    """``estimate_ranges(model, running_minmax, sync_free=True)`` on a LinearQuantizer: three batches through the quantizer's forward
+    (RunningMinMax step + the quantizer's own forward, reference common.py:218-238). HIP with the one-pass kernel
+    (ops.running_minmax_quantize: per-row tilings) == HIP with a second override in the chain (the two steps) == the oracle: codes
+    of every batch, running min / max, scale, offset, status flags. Batches: mixed signs; non-negative in every tile (the one-sided
+    verdict flips when a later batch brings a negative value); an Inf and a NaN in the last one."""
+    g = torch.Generator().manual_seed(sum(shape) + int(symmetric) * 2 + int(one_sided))
+    batches = [(torch.randn(*shape, generator=g) * 2).abs().to(dtype), (torch.randn(*shape, generator=g) * 3).abs().to(dtype), (torch.randn(*shape, generator=g)).to(dtype)]
+    batches[1].view(-1)[-1] = -0.5
+    batches[2].view(-1)[3] = float("inf")
+    batches[2].view(-1)[-2] = float("nan")
+
+    def run(device, two_steps=False):
+        quantizer = ff.nn.LinearQuantizer(8, symmetric=symmetric, allow_one_sided=one_sided, granularity=gran, quantized_dtype=torch.int8, device=device)
+        outs = []
+        extra = quantizer.register_override(lambda _ctx, fn, args, kwargs: fn(*args, **kwargs)) if two_steps else None
+        estimators = []
+        try:
+            with ff.estimate_ranges(quantizer, ff.range_setting.running_minmax, sync_free=True):
+                estimators = [fn for fn in quantizer.overrides if isinstance(fn, ff.range_setting.minmax.RunningMinMaxEstimator)]
+                for x in batches:
+                    q = quantizer(x.to(device))
+                    p = q.quantization_context.quantization_params
+                    assert p.dequantize_dtype == dtype
+                    outs += [q.raw_data.cpu(), quantizer.scale.detach().cpu().clone(), (quantizer.offset.detach().cpu().clone() if quantizer.offset is not None else torch.zeros(1))]
+                    outs += [estimators[0].min.float().cpu().clone(), estimators[0].max.float().cpu().clone(), estimators[0].status.cpu().clone()]
+        except NotImplementedError:  # the deferred "Infinite" check at the end of the context (minmax.py:233-234): raised on every route alike
+            outs.append(torch.tensor([1.0]))
+        finally:
+            if extra is not None:
+                extra.remove()
+        return outs
+
+    got, want = _both(run)
+    two = run(DEV, two_steps=True)
+    assert len(got) == len(want) == len(two)
+    for a, b, c in zip(got, want, two):
+        assert same_with_nan(a, b), mismatch_report(a, b)
+        assert same_with_nan(a, c), mismatch_report(a, c)
+    for buf in ops._TICKETS.values():
+        assert int(buf.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("ntiles", [8193, 20000, 458752])
 @pytest.mark.parametrize("range_dtype", [torch.float32, torch.bfloat16])
 def test_parameters_for_range_grid_form_matches_oracle(ntiles, range_dtype):
