@@ -19,7 +19,6 @@
 #endif
 #include "ffq_affine.h"
 #include "ffq_common.h"
-#include "ffq_extrema.h"
 #include "ffq_silu.h"
 #include "ffq_vec.h"
 
@@ -89,17 +88,14 @@ __device__ __forceinline__ void fan_store(const FanOut& f, const FanParams& p, c
 //     the one-wave-per-row form of a 4096-wide row needs 117 VGPRs (4 waves/SIMD) and reaches 4.5 TB/s.
 //     Algorithmic bytes / element: 2 (x) [+ 2 (delta) + 2 (sum)] [+ 2 (z)] + 1 per distinct code tensor.
 // ---------------------------------------------------------------------------------------------------
-// EXT (WPR == 4 only: the block is one row): the launch also leaves [min, max] of the normalised tensor (ffq_extrema.h) — the first
-// step of the RunningMinMax estimators of the linears that consume it — through a one-thread finishing launch.
-template <int CPL, int WPR, bool EXT = false>
+template <int CPL, int WPR>
 __global__ __launch_bounds__(kBlock) void add_rmsnorm_quantize_kernel(const bf16_t* __restrict__ x,
                                                                       const bf16_t* __restrict__ delta,
                                                                       bf16_t* __restrict__ sum_out,
                                                                       const bf16_t* __restrict__ weight,
                                                                       bf16_t* __restrict__ norm_out, FanOut f,
                                                                       uint32_t rows, uint32_t chunks_per_row,
-                                                                      float inv_cols, float eps, ExtremaSink sink = ExtremaSink{nullptr, nullptr, 0}) {
-  static_assert(!EXT || WPR == 4, "extrema: one row per block");
+                                                                      float inv_cols, float eps) {
   constexpr uint32_t LPR = 64u * WPR;  // lanes per row
   const uint32_t lane = threadIdx.x % LPR;
   const uint32_t row = blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR;
@@ -153,7 +149,6 @@ __global__ __launch_bounds__(kBlock) void add_rmsnorm_quantize_kernel(const bf16
   }
   const float r = rsqrtf(ss * inv_cols + eps);
   const FanParams p = load_fan(f);
-  [[maybe_unused]] float zmn = INFINITY, zmx = -INFINITY, znan = 0.0f;
 #pragma unroll
   for (int u = 0; u < CPL; ++u) {
     const uint32_t c = lane + LPR * u;
@@ -169,14 +164,6 @@ __global__ __launch_bounds__(kBlock) void add_rmsnorm_quantize_kernel(const bf16
       z[i + 1] = w.get(i + 1) * n1;
       bf16_round2(z[i], z[i + 1]);              // weight * hidden in bf16
     }
-    if constexpr (EXT) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        zmn = __builtin_fminf(zmn, z[i]);
-        zmx = __builtin_fmaxf(zmx, z[i]);
-        znan = z[i] != z[i] ? 1.0f : znan;
-      }
-    }
     if (norm_out) {
       Chunk<bf16_t, 16> zc;
       zc.pack(z);
@@ -184,29 +171,7 @@ __global__ __launch_bounds__(kBlock) void add_rmsnorm_quantize_kernel(const bf16
     }
     fan_store(f, p, z, base + (size_t)c * 16);
   }
-  if constexpr (EXT) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      zmn = __builtin_fminf(zmn, __shfl_xor(zmn, d, 64));
-      zmx = __builtin_fmaxf(zmx, __shfl_xor(zmx, d, 64));
-      znan = __builtin_fmaxf(znan, __shfl_xor(znan, d, 64));
-    }
-    __shared__ float wave_ext[3][kBlock / 64];
-    if ((threadIdx.x & 63u) == 0) { wave_ext[0][threadIdx.x >> 6] = zmn; wave_ext[1][threadIdx.x >> 6] = zmx; wave_ext[2][threadIdx.x >> 6] = znan; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int w = 1; w < kBlock / 64; ++w) {
-        zmn = __builtin_fminf(zmn, wave_ext[0][w]);
-        zmx = __builtin_fmaxf(zmx, wave_ext[1][w]);
-        znan = __builtin_fmaxf(znan, wave_ext[2][w]);
-      }
-      extrema_publish(sink, zmn, zmx, znan != 0.0f, true, 0u);
-    }
-  }
 }
-
-__global__ void extrema_finish_kernel(ExtremaSink sink) { extrema_finish(sink); }
 
 // ---------------------------------------------------------------------------------------------------
 // P2: z = bf16(silu(gate)) * up in bf16 (mlp.py:36-38: F.silu rounds to bf16, the product rounds again);
@@ -372,10 +337,8 @@ using namespace ffq;
 
 extern "C" int ffq_add_rmsnorm_quantize(const void* x, const void* delta, void* sum_out, const void* weight,
                                         int dt, int64_t rows, int64_t cols, double eps, void* norm_out,
-                                        const ffq_fanout* fan, uint32_t* extrema_words, void* extrema_pair, void* stream) {
+                                        const ffq_fanout* fan, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if ((extrema_words == nullptr) != (extrema_pair == nullptr)) return fail(FFQ_ERR_ARG, "extrema_words and extrema_pair come together");
-  if (extrema_words && (cols <= 1024 || rows <= 0)) return fail(FFQ_ERR_DTYPE, "fused RMSNorm: extrema ride along for rows of more than 1024 elements");
   if (rows < 0 || cols < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "fused RMSNorm is built for bf16 activations");
   if (cols == 0) return fail(FFQ_ERR_EMPTY, "RMSNorm over an empty row");
@@ -395,17 +358,6 @@ extern "C" int ffq_add_rmsnorm_quantize(const void* x, const void* delta, void* 
   add_rmsnorm_quantize_kernel<CPL, WPR><<<(unsigned)((rows + 4 / WPR - 1) / (4 / WPR)), kBlock, 0, s>>>(  \
       static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(delta), static_cast<bf16_t*>(sum_out),    \
       static_cast<const bf16_t*>(weight), static_cast<bf16_t*>(norm_out), f, (uint32_t)rows, cpr, inv, (float)eps)
-  if (extrema_words) {
-    const ExtremaSink sink{extrema_words, extrema_pair, FFQ_BF16};
-#define FFQ_P1X(CPL)                                                                                      \
-  add_rmsnorm_quantize_kernel<CPL, 4, true><<<(unsigned)rows, kBlock, 0, s>>>(                            \
-      static_cast<const bf16_t*>(x), static_cast<const bf16_t*>(delta), static_cast<bf16_t*>(sum_out),    \
-      static_cast<const bf16_t*>(weight), static_cast<bf16_t*>(norm_out), f, (uint32_t)rows, cpr, inv, (float)eps, sink)
-    if (cpr <= 256) FFQ_P1X(1); else FFQ_P1X(2);
-#undef FFQ_P1X
-    extrema_finish_kernel<<<1, 1, 0, s>>>(sink);
-    return check_launch("add_rmsnorm_quantize_kernel (extrema)");
-  }
   if (cpr <= 64) FFQ_P1(1, 1);
   else if (cpr <= 256) FFQ_P1(1, 4);
   else FFQ_P1(2, 4);

@@ -1001,7 +1001,6 @@ class FusedProducersForward:
         self.weight_storage = weight_storage
         self._stored: dict[int, tuple[tuple[int, int, int], torch.Tensor, int]] = {}
         self._product_extrema: tuple[torch.Tensor, torch.Tensor] | None = None  # (SiLU * up product, its [min, max]) of the layer in flight
-        self._input_extrema: tuple[torch.Tensor, torch.Tensor] | None = None    # (normalised hidden state, its [min, max])
 
     def _stored_weight(self, linear: torch.nn.Module) -> tuple[torch.Tensor, int] | None:
         """(codes or packed nibbles, packing block) of a weight-only linear's weight under ``weight_storage``, or None when
@@ -1094,12 +1093,6 @@ class FusedProducersForward:
             product = ff.ops.silu_mul_quantize(gate, up, (), want_product=True)[0]
         return product
 
-    def _remember_input_extrema(self, data: torch.Tensor) -> None:
-        """(inside a sibling_quantizers() block) hand the [min, max] the producer of `data` left to the estimators about to run on it"""
-        if self._input_extrema is not None and self._input_extrema[0] is data:
-            RECENT.remember_extrema(data, self._input_extrema[1])
-        self._input_extrema = None
-
     def _qkv(self, normed: torch.Tensor, attn: torch.nn.Module) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """The three projections of the attention block: one launch for weight-only linears the GEMM covers, else one by one."""
         projections = (attn.q_proj, attn.k_proj, attn.v_proj)
@@ -1113,7 +1106,6 @@ class FusedProducersForward:
                 if outs is not None:
                     return outs[0], outs[1], outs[2]
         with sibling_quantizers():
-            self._remember_input_extrema(normed)
             return self._linear(normed, attn.q_proj), self._linear(normed, attn.k_proj), self._linear(normed, attn.v_proj)
 
     def _gate_up(self, normed: torch.Tensor, mlp: torch.nn.Module) -> torch.Tensor:
@@ -1129,7 +1121,6 @@ class FusedProducersForward:
                 if product is not None:
                     return product
         with sibling_quantizers():
-            self._remember_input_extrema(normed)
             gate = self._linear(normed, gate_proj)
             return self._linear(normed, up_proj, gate=gate)
 
@@ -1142,16 +1133,10 @@ class FusedProducersForward:
             hidden = model.embed_tokens(input_ids)
             cos, sin = rotary_tables(s, d, cfg.rope_theta, hidden.device, hidden.dtype)
             pending: torch.Tensor | None = None
-            # range estimation in progress (an override on a decoder linear's input quantizer): the producers leave [min, max] of
-            # what they write, so an estimator step merges two numbers instead of reading the tensor
-            estimating = len(model.layers) > 0 and next(iter(model.layers[0].self_attn.q_proj.input_quantizer.overrides), None) is not None
             for layer in model.layers:
                 attn, mlp = layer.self_attn, layer.mlp
                 ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
-                ext: list[torch.Tensor] = []
-                hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, ln1.weight, ln1.variance_epsilon, (), want_norm=True, sum_inplace=pending is not None,
-                                                                norm_extrema=ext if estimating else None)
-                self._input_extrema = (normed, ext[0]) if ext else None  # the siblings' estimators start from the two numbers
+                hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, ln1.weight, ln1.variance_epsilon, (), want_norm=True, sum_inplace=pending is not None)
                 q, k, v = self._qkv(normed, attn)
                 ff.ops.rope_(q, k, cos, sin, d)
                 if attention_kernel_covers(cfg, s, q.dtype):
@@ -1159,10 +1144,7 @@ class FusedProducersForward:
                 else:
                     ctx = _sdpa(q, k, v, cfg, b, s)
                 attn_out = self._linear(ctx, attn.o_proj)
-                ext = []
-                hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, attn_out, ln2.weight, ln2.variance_epsilon, (), want_norm=True, sum_inplace=True,
-                                                                norm_extrema=ext if estimating else None)
-                self._input_extrema = (normed, ext[0]) if ext else None
+                hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, attn_out, ln2.weight, ln2.variance_epsilon, (), want_norm=True, sum_inplace=True)
                 self._product_extrema = None
                 product = self._gate_up(normed, mlp)
                 with sibling_quantizers():

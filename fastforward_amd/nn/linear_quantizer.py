@@ -245,6 +245,23 @@ class LinearQuantizer(AbstractAffineQuantizer):
                 torch.autograd.graph.increment_version(self.offset)
             return True
 
+    def is_plain(self) -> bool:
+        """No subclass has replaced a piece of the quantize / range-setting path: the fused entries, which do those pieces'
+        work in one kernel, give what the pieces would."""
+        cls = type(self)
+        return (
+            cls.quantization_range is LinearQuantizer.quantization_range and cls._write_parameters_for_range is LinearQuantizer._write_parameters_for_range
+            and cls.quantize is LinearQuantizer.quantize and cls.quantization_parameters is LinearQuantizer.quantization_parameters
+            and cls.quantization_function is LinearQuantizer.quantization_function and cls.forward is Quantizer.forward
+        )
+
+    def wrap_codes(self, raw: torch.Tensor, data_dtype: torch.dtype) -> QuantizedTensor:
+        """The QuantizedTensor ``self.quantize(data)`` returns, around codes `raw` that somebody else produced from `data` with this
+        quantizer's current parameters (function.py: _static_quantize stamps the dequantize dtype at quantize time)."""
+        params = self.quantization_parameters()
+        stamped = params.with_changes(dequantize_dtype=params.dequantize_dtype or data_dtype)
+        return QuantizedTensor(raw, QuantizationContext(self.quantization_function, stamped))
+
     def update_range_and_quantize(self, data: torch.Tensor, tile: Any, running_min: torch.Tensor, running_max: torch.Tensor,
                                   status: torch.Tensor | None) -> QuantizedTensor | None:
         """:meth:`update_range_from_data` AND ``self.quantize(data)`` in one pass over `data` (``ops.running_minmax_quantize``): the
@@ -252,13 +269,7 @@ class LinearQuantizer(AbstractAffineQuantizer):
         QuantizedTensor ``quantize`` returns with the parameters the step wrote. None — nothing touched — where the one-pass kernel
         or its preconditions do not apply; the caller then takes the two steps."""
         with torch.no_grad():
-            cls = type(self)
-            plain = (
-                cls.quantization_range is LinearQuantizer.quantization_range and cls._write_parameters_for_range is LinearQuantizer._write_parameters_for_range
-                and cls.quantize is LinearQuantizer.quantize and cls.quantization_parameters is LinearQuantizer.quantization_parameters
-                and cls.quantization_function is LinearQuantizer.quantization_function
-            )
-            if not plain or not data.is_cuda or type(data) not in (torch.Tensor, torch.nn.Parameter) or running_min.numel() <= 1:
+            if not self.is_plain() or not data.is_cuda or type(data) not in (torch.Tensor, torch.nn.Parameter) or running_min.numel() <= 1:
                 return None
             from fastforward_amd import flags
 
@@ -277,9 +288,7 @@ class LinearQuantizer(AbstractAffineQuantizer):
             torch.autograd.graph.increment_version(self.scale)  # written through raw pointers: tell the version counters
             if self.offset is not None:
                 torch.autograd.graph.increment_version(self.offset)
-            params = self.quantization_parameters()
-            stamped = params.with_changes(dequantize_dtype=params.dequantize_dtype or data.dtype)  # (function.py: _static_quantize)
-            return QuantizedTensor(raw, QuantizationContext(self.quantization_function, stamped))
+            return self.wrap_codes(raw, data.dtype)
 
     def _write_parameters_for_range(self, lo: torch.Tensor, hi: torch.Tensor) -> None:
         """A5 straight into ``scale`` / ``offset`` — no host round trip (reference :350-357 + range.py)."""

@@ -253,7 +253,8 @@ _EXTREMA_WORDS: dict[tuple[int, int], torch.Tensor] = {}
 
 def _extrema_words(device: torch.device, stream: int) -> torch.Tensor:
     capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
-    key = (device.index if device.index is not None else torch.cuda.current_device(), int(stream or 0))
+    index = device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else -1)
+    key = (index, int(stream or 0))
     have = None if capturing else _EXTREMA_WORDS.get(key)
     if have is None:
         have = torch.zeros(4, dtype=torch.int32, device=device)
@@ -1309,15 +1310,12 @@ def add_rmsnorm_quantize(
     want_sum: bool = True,
     want_norm: bool = False,
     sum_inplace: bool = False,
-    norm_extrema: list[torch.Tensor] | None = None,
 ) -> tuple[torch.Tensor | None, torch.Tensor | None, list[torch.Tensor]]:
     """Residual add + RMSNorm + A1 for up to three per-tensor int8 quantizers, one pass
     (reference docs/examples/doc_helpers/quantized_llama/rms_norm.py:17-35 behind decoder.py:60-90).
 
     Returns ``(x + delta, normalised or None, [codes per quantizer])``; with ``delta is None`` the first
     element is `x` itself. ``sum_inplace`` writes the sum over `x` (the residual stream of a decoder).
-    ``norm_extrema``: an empty list that receives ``[min, max]`` of the normalised tensor (bf16 pair, ``minmax_by_tile`` over the
-    whole tensor) where the kernel can leave it on the way (rows of more than 1024 elements); left empty otherwise.
     """
     xc = x.detach().contiguous()
     dc = None if delta is None else delta.detach().contiguous()
@@ -1334,17 +1332,12 @@ def add_rmsnorm_quantize(
     total = xc if dc is None or sum_inplace else (torch.empty_like(xc) if want_sum else None)
     norm = torch.empty_like(xc) if want_norm else None
     fan, codes, keep = _fan(quantizers, num_bits, xc.shape, xc.device)
-    words = pair = None
-    if norm_extrema is not None and cols > 1024 and rows > 0 and xc.is_cuda:
-        words, pair = _extrema_words(xc.device, stream), torch.empty(2, dtype=xc.dtype, device=xc.device)
     lib.check(
         lib.ffq_add_rmsnorm_quantize(
             _ptr(xc), _ptr(dc), None if dc is None else _ptr(total), _ptr(wc), _tag(xc.dtype), rows, cols, float(eps),
-            _ptr(norm), ctypes.byref(fan), _ptr(words), _ptr(pair), stream,
+            _ptr(norm), ctypes.byref(fan), stream,
         )
     )
-    if pair is not None:
-        norm_extrema.append(pair)
     del keep
     if sum_inplace and dc is not None:
         torch.autograd.graph.increment_version(x)  # written through a raw pointer

@@ -383,13 +383,10 @@ typedef struct ffq_fanout {
  * norm_out are nullable (sum_out may alias x). The fp32 summation order of mean(h^2) is the
  * kernel's own, so z can differ from the eager chain by one bf16 ulp on rare elements; the codes are
  * exactly A1 of the z this call produces. cols % 16 == 0, cols <= 8192.
- * `extrema_words` / `extrema_pair` (both or neither; ABI 8, cols > 1024 else FFQ_ERR_DTYPE): [min, max] of z in bf16 — what
- * ffq_minmax_by_tile over z as one tile returns — left by the same pass (+ a one-thread finishing launch); words as in
- * ffq_linear_w8a8_gated.
  */
 int ffq_add_rmsnorm_quantize(const void* x, const void* delta, void* sum_out, const void* weight,
                              int dt, int64_t rows, int64_t cols, double eps, void* norm_out,
-                             const ffq_fanout* fan, uint32_t* extrema_words, void* extrema_pair, void* stream);
+                             const ffq_fanout* fan, void* stream);
 
 /*
  * SiLU(gate) * up — mlp.py:30-40:  z = bf16(silu(float(gate))) * up  (bf16), codes = A1(z).

@@ -823,10 +823,8 @@ static void fan_quantize(const ffq_fanout* fan, double lo, double hi, float z, i
 /* rms_norm.py:17-35 (LlamaRMSNorm.forward) behind the residual add of decoder.py:60-90 */
 int ffq_add_rmsnorm_quantize(const void* x, const void* delta, void* sum_out, const void* weight,
                              int dt, int64_t rows, int64_t cols, double eps, void* norm_out,
-                             const ffq_fanout* fan, uint32_t* extrema_words, void* extrema_pair, void* stream) {
+                             const ffq_fanout* fan, void* stream) {
   (void)stream;
-  /* the ride-along extrema are a device-side saving of one pass (A4 over norm_out gives the same pair): not restated here */
-  if (extrema_words || extrema_pair) return fail(FFQ_ERR_DTYPE, "oracle: take ffq_minmax_by_tile over the normalised tensor");
   if (rows < 0 || cols < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "fused RMSNorm is built for bf16 activations");
   if (cols == 0) return fail(FFQ_ERR_EMPTY, "RMSNorm over an empty row");
