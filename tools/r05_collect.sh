@@ -8,6 +8,7 @@
 #             the skinny form's sweep (1 .. 128 tokens)
 #   a3        A3 / A5 timings (one-launch and grid forms against the composed / one-block forms)
 #   traces    rocprofv3 kernel traces of one cfg2 and one cfg4 forward at B=1 and B=8
+#   calib     the calibration step with each estimation shortcut switched off (tools/calib_ab.py) and a calibration-dominated kernel trace
 #   configs   BASELINE configs 2-5 (tools/bench_configs.py)
 # EVERY profiled command runs under `timeout`: a profiled process that aborts can otherwise sit in rocprofv3's signal handler.
 set -u
@@ -38,7 +39,7 @@ if [ $WHAT = all ] || [ $WHAT = wq ]; then
   : > $OUT/r05_wq_time.txt
   for T in 16384 4096 2048; do timeout 300 python3 tools/wq_time.py $T 2>&1 | grep -v amdgpu.ids >> $OUT/r05_wq_time.txt; done
   timeout 600 python3 tools/wq_split_sweep.py 512 2048 4096 2>&1 | grep -v amdgpu.ids > $OUT/r05_wq_split_sweep.txt
-  timeout 600 python3 tools/wq_skinny_sweep.py 1 4 16 64 128 2>&1 | grep -v amdgpu.ids > $OUT/r05_wq_skinny_sweep.txt
+  timeout 900 python3 tools/wq_skinny_sweep.py 1 4 8 16 32 64 128 2>&1 | grep -v amdgpu.ids > $OUT/r05_wq_skinny_sweep.txt
 fi
 if [ $WHAT = all ] || [ $WHAT = a3 ]; then
   timeout 300 python3 tools/a3_time.py 2>&1 | grep -v amdgpu.ids > $OUT/r05_a3_a5_time.txt
@@ -53,6 +54,13 @@ if [ $WHAT = all ] || [ $WHAT = traces ]; then
       rm -rf $OUT/trace_$cfg
     done
   done
+fi
+if [ $WHAT = all ] || [ $WHAT = calib ]; then
+  timeout 900 python3 tools/calib_ab.py 32 8 2>&1 | grep -v "amdgpu\|Warning\|_warn_once" > $OUT/r05_calib_ab_final.txt
+  rm -rf $OUT/calib_trace
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/calib_trace -o calib -- python3 bench.py --steps 1 --warmup 0 --calib-seqs 64 --no-side-measurements > $OUT/calib_bench.json 2> $OUT/calib_err.log
+  python3 tools/rocprof_summary.py $OUT/calib_trace/calib_results.db $OUT/r05_calibration_kernel_stats.md "r05 — rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 1 --warmup 0 --calib-seqs 64 --no-side-measurements (calibration dominates: 1 + 8 calibration steps of 8 sequences, 3 forwards)"
+  rm -rf $OUT/calib_trace
 fi
 if [ $WHAT = all ] || [ $WHAT = configs ]; then
   timeout 2400 python3 tools/bench_configs.py --out $OUT/r05_configs.json > $OUT/configs.log 2>&1
