@@ -1001,6 +1001,7 @@ class FusedProducersForward:
         self.weight_storage = weight_storage
         self._stored: dict[int, tuple[tuple[int, int, int], torch.Tensor, int]] = {}
         self._product_extrema: tuple[torch.Tensor, torch.Tensor] | None = None  # (SiLU * up product, its [min, max]) of the layer in flight
+        self._want_product_extrema = False
 
     def _stored_weight(self, linear: torch.nn.Module) -> tuple[torch.Tensor, int] | None:
         """(codes or packed nibbles, packing block) of a weight-only linear's weight under ``weight_storage``, or None when
@@ -1082,9 +1083,12 @@ class FusedProducersForward:
         product = None
         if usable:
             w_offset = None if wp.offset is None or ff.fused_linear.known_zero_offset(wp.offset) else wp.offset
-            both = ff.ops.linear_w8a8_gated(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, gate, want_extrema=True)
-            if both is not None:  # [min, max] of the product rode along: down_proj's estimator step starts from the two numbers
-                product, self._product_extrema = both[0], (both[0], both[1])
+            if self._want_product_extrema:  # [min, max] of the product rides along: down_proj's estimator step starts from the two numbers
+                both = ff.ops.linear_w8a8_gated(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, gate, want_extrema=True)
+                if both is not None:
+                    product, self._product_extrema = both[0], (both[0], both[1])
+            else:
+                product = ff.ops.linear_w8a8_gated(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, gate)
         if product is None:  # the quantizers have run (an estimator step each): finish on the codes / tensors they returned
             if usable:
                 up = ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, None, out_dtype=torch.bfloat16)
@@ -1146,6 +1150,8 @@ class FusedProducersForward:
                 attn_out = self._linear(ctx, attn.o_proj)
                 hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, attn_out, ln2.weight, ln2.variance_epsilon, (), want_norm=True, sum_inplace=True)
                 self._product_extrema = None
+                # (only an estimator on down_proj's input quantizer has a use for the product's extrema)
+                self._want_product_extrema = next(iter(getattr(mlp.down_proj.input_quantizer, "overrides", ())), None) is not None
                 product = self._gate_up(normed, mlp)
                 with sibling_quantizers():
                     if self._product_extrema is not None and self._product_extrema[0] is product:

@@ -258,7 +258,7 @@ def _extrema_words(device: torch.device, stream: int) -> torch.Tensor:
     have = None if capturing else _EXTREMA_WORDS.get(key)
     if have is None:
         have = torch.zeros(4, dtype=torch.int32, device=device)
-        have[0] = -1
+        have[:1].fill_(-1)  # (a fill kernel: capturable, unlike an assignment from a host scalar)
         if not capturing:
             _EXTREMA_WORDS[key] = have
     return have

@@ -483,3 +483,27 @@ def test_gated_epilogue_leaves_the_extrema_of_its_product(with_nan):
                 assert torch.equal(pair.view(torch.int16), torch.cat([lo, hi]).view(torch.int16)), (pair, lo, hi)
     for words in ops._EXTREMA_WORDS.values():
         assert words.tolist() == [-1, 0, 0, 0]
+
+
+def test_gated_epilogue_with_extrema_inside_a_hipgraph():
+    """A captured launch gets accumulator words of its own (zeroed and set by fill nodes of the capture); replays reproduce the
+    eager result and leave the words in their initial state."""
+    g = torch.Generator(device=DEV).manual_seed(4)
+    m, n, k = 2048, 2048, 256
+    xq = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+    wq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    sx, sw = torch.tensor([0.02], device=DEV), torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+    gate = torch.randn(m, n, device=DEV, generator=g).to(torch.bfloat16)
+    want, want_pair = ops.linear_w8a8_gated(xq, wq, sx, None, sw, None, gate, want_extrema=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        ops.linear_w8a8_gated(xq, wq, sx, None, sw, None, gate, want_extrema=True)  # code objects, allocator
+        with torch.cuda.graph(graph, stream=side):
+            got, pair = ops.linear_w8a8_gated(xq, wq, sx, None, sw, None, gate, want_extrema=True)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and torch.equal(pair, want_pair)
