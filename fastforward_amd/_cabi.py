@@ -185,6 +185,8 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_mlp_gate_up_wq": (_i, [_vp, _i, _vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _i64, _vp]),
     "ffq_mlp_gate_up_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "ffq_mlp_gate_up_w8a8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "ffq_mlp_gate_up_w8a8_estimating_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "ffq_mlp_gate_up_w8a8_estimating": (_i, [_vp] * 14 + [_i64, _i64, _i64, _vp, _sz, _vp, _vp, _vp]),
     "ffq_add_rmsnorm_quantize": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _d, _vp, _fp, _vp]),
     "ffq_silu_mul_quantize": (_i, [_vp, _vp, _i, _i64, _vp, _fp, _vp]),
     "ffq_rope_inplace": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -65,6 +65,8 @@ struct LinearArgs {
   // gated output (ffq_linear_w8a8_gated): the bf16 [M, N] tensor whose silu multiplies this linear's bf16 result
   const bf16_t* gate;
   ExtremaSink extrema;  // words == nullptr: not wanted. [min, max] of the gated product (ffq_extrema.h)
+  // a launch of a device-side either / or (ffq_mlp_gate_up_w8a8_estimating): it runs iff *run_if == run_when (nullptr: always)
+  const int32_t* run_if; int run_when;
 };
 
 // The value the linear would have returned in dtype `y_dt` (one rounding), as fp32
@@ -586,6 +588,104 @@ __device__ __forceinline__ void mlp_epilogue16_body(const LinearArgs& a, v4i32 (
   }
 }
 
+// The MLP mode WITHOUT the output quantizer (ffq_mlp_gate_up_w8a8_estimating: range estimation, where down_proj's input quantizer is
+// what the forward is calibrating): z as above leaves as bf16 — [256 rows][256 B] per tile, through LDS in two passes of 128 rows
+// (pitch 272 B: the consumed operand slot holds 34 KiB at a time) as whole 128-byte lines — and every thread keeps the running
+// {min, max, NaN seen} of the z it stores (zext, LDS: ffq_extrema.h).
+__device__ __forceinline__ void mlp_epilogue16_product(const LinearArgs& a, v4i32 (&acc)[8][4], int (&rsw)[2], uint8_t* lds2, int wave,
+                                                       int lane, int wm, int wn, int m0, int n0, const uint16_t* silu_table, float* zext) {
+  constexpr int PITCH = 272;  // 256 B of bf16 + 16 B pad
+  const float sx = a.x_scale[0];
+  const float ox = a.x_offset ? rne(a.x_offset[0]) : 0.0f;
+  __syncthreads();  // every wave is done with the operand ring
+  float* rs_lds = reinterpret_cast<float*>(lds2 + 128 * PITCH) + wave * 64;
+  if (lane < 32) {
+    rs_lds[lane] = (float)rsw[0];
+    rs_lds[32 + lane] = (float)rsw[1];
+  }
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int col0 = n0 + wn * 32;  // this wave's 32 output columns
+  bf16_t* out = static_cast<bf16_t*>(a.out);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      const int cb = 16 * nj + 4 * g4;  // this lane's 4 columns: col0 + cb + (0..3)
+      fq_f32x2 CG[2], OG[2], CU[2], OU[2];
+#pragma unroll
+      for (int t = 0; t < 4; t += 2) {
+        const int n = col0 + cb + t;  // N % 128 == 0: always inside
+        CG[t >> 1] = fq_f32x2{sx * a.w_scale[n], sx * a.w_scale[n + 1]};
+        CU[t >> 1] = fq_f32x2{sx * a.w_scale2[n], sx * a.w_scale2[n + 1]};
+        OG[t >> 1] = fq_f32x2{ox * rs_lds[cb + t], ox * rs_lds[cb + t + 1]};
+        OU[t >> 1] = fq_f32x2{ox * rs_lds[32 + cb + t], ox * rs_lds[32 + cb + t + 1]};
+      }
+      uint32_t wg[4][2], ws[4][2];
+      uint32_t bad = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int mi = 4 * half + q;
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+          const fq_f32x2 A = {(float)acc[mi][nj][t], (float)acc[mi][nj][t + 1]};
+          const fq_f32x2 G = CG[t >> 1] * (A + OG[t >> 1]);
+          wg[q][t >> 1] = pack2<bf16_t>(G.x, G.y);
+          ws[q][t >> 1] = silu_pair_lookup(wg[q][t >> 1], silu_table, bad);
+        }
+      }
+      if (__builtin_expect(silu_any_outside(bad), 0)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) ws[q][h2] = silu_pair_patch(wg[q][h2], ws[q][h2]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int mi = 4 * half + q;
+        u32x2 zw;
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+          const fq_f32x2 A = {(float)acc[mi][nj + 2][t], (float)acc[mi][nj + 2][t + 1]};
+          const fq_f32x2 U = CU[t >> 1] * (A + OU[t >> 1]);
+          uint32_t w = pack2<bf16_t>(U.x, U.y);
+          const fq_f32x2 UB = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
+          w = ws[q][t >> 1];
+          const fq_f32x2 SB = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
+          const fq_f32x2 Z = SB * UB;
+          w = pack2<bf16_t>(Z.x, Z.y);
+          if (t == 0) zw.x = w; else zw.y = w;
+        }
+        const int rowl = wm * 64 + q * 16 + r16;  // row of this pass: tile row wm * 128 + half * 64 + q * 16 + r16
+        *reinterpret_cast<u32x2*>(lds2 + rowl * PITCH + wn * 64 + cb * 2) = zw;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {  // 128 rows x 16 segments of 16 B over 512 threads
+      const int idx = wave * 256 + t * 64 + lane;
+      const int rowl = idx >> 4, seg = idx & 15;
+      const int m = m0 + (rowl >> 6) * 128 + half * 64 + (rowl & 63);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(lds2 + rowl * PITCH + seg * 16);
+      if (m < a.M) {  // (rows past the edge of a ragged M hold garbage)
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)m * a.N + n0) * 2 + seg * 16));
+        if (a.extrema.words) {  // on the way out, where the accumulators' registers are not in the way
+          const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+          float zmn = zext[0], zmx = zext[512], znan = zext[1024];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float z0 = __builtin_bit_cast(float, vw[q] << 16), z1 = __builtin_bit_cast(float, vw[q] & 0xFFFF0000u);
+            zmn = __builtin_fminf(zmn, __builtin_fminf(z0, z1));
+            zmx = __builtin_fmaxf(zmx, __builtin_fmaxf(z0, z1));
+            znan = (z0 != z0 || z1 != z1) ? 1.0f : znan;
+          }
+          zext[0] = zmn; zext[512] = zmx; zext[1024] = znan;
+        }
+      }
+    }
+    __syncthreads();  // the tile is re-written by the next pass / the slot is the next tile's DMA target
+  }
+}
+
 template <typename TOut, bool REQUANT, bool MLP, bool WOFF = false, bool GATED = false>
 __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, int total_tiles) {
   constexpr int BN2 = 256, WAVES_N = 4;
@@ -607,8 +707,12 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   const uint32_t xcd_first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
   const uint32_t xcd_count = tq + (xcd < tr ? 1u : 0u);
   const int my_tiles = j_in_xcd < xcd_count ? (int)((xcd_count - j_in_xcd + blocks_in_xcd - 1) / blocks_in_xcd) : 0;
+  constexpr bool PRODUCT = MLP && !REQUANT;  // the gate/up launch that leaves the bf16 product (and its extrema)
+  if constexpr (WOFF || GATED || PRODUCT) {  // (the instantiations a device-side either / or is built from; the forward's are not among them)
+    if (a.run_if && *a.run_if != a.run_when) return;
+  }
   if (my_tiles == 0) {
-    if constexpr (GATED) {
+    if constexpr (GATED || PRODUCT) {
       if (a.extrema.words && tid == 0) extrema_publish(a.extrema, 0.0f, 0.0f, false, false, gridDim.x);
     }
     return;
@@ -617,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   // GATED: the lane's running {min, max, NaN seen} of the product lives in LDS behind the table (three registers held across the
   // K-loop spill next to the 128 accumulators), lane-interleaved: word j of thread t at [j * 512 + t]
   [[maybe_unused]] float* const zext = reinterpret_cast<float*>(lds2 + 2 * SLOT_BYTES + kSiluBytes) + tid;
-  if constexpr (GATED) {
+  if constexpr (GATED || PRODUCT) {
     zext[0] = INFINITY; zext[512] = -INFINITY; zext[1024] = 0.0f;
   }
   if constexpr (MLP || GATED) silu_table_fill(silu_table, (uint32_t)tid, 512u);
@@ -805,14 +909,15 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
         rsw[0] = a.rowsum_w[n0 + wn * 32 + (lane & 31)];
         rsw[1] = a.rowsum_w2[n0 + wn * 32 + (lane & 31)];
       }
-      mlp_epilogue16_body(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table);
+      if constexpr (REQUANT) mlp_epilogue16_body(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table);
+      else mlp_epilogue16_product(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table, zext);
     } else {
       gemm256_epilogue_slabs16<TOut, REQUANT, WOFF, GATED>(a, acc, scratch, wave, lane, wm, wn, m0, n0, silu_table, zext);
     }
     __syncthreads();  // the scratch slot is the next tile's DMA target
     m0 = nm0; n0 = nn0;
   }
-  if constexpr (GATED) {
+  if constexpr (GATED || PRODUCT) {
     if (a.extrema.words) {  // lanes -> waves -> block -> the launch's three words (the operand ring is free: every tile is done)
       float mn = zext[0], mx = zext[512], nan = zext[1024];
 #pragma unroll
@@ -893,7 +998,7 @@ static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w
                             int w_per_row, const void* bias, int bias_dt, void* out, int out_dt,
                             const float* out_scale, const float* out_offset, double out_num_bits, int y_dt, int64_t M,
                             int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream, const void* gate,
-                            uint32_t* extrema_words = nullptr, void* extrema_pair = nullptr) {
+                            uint32_t* extrema_words = nullptr, void* extrema_pair = nullptr, const int32_t* run_if = nullptr, int run_when = 0) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
@@ -934,6 +1039,7 @@ static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w
   a.group_m = GROUP_M2;
   a.group_cols = 0;
   a.gate = static_cast<const bf16_t*>(gate);
+  a.run_if = run_if; a.run_when = run_when;
   a.extrema.words = extrema_words; a.extrema.pair = extrema_pair; a.extrema.pair_dt = FFQ_BF16;
 
   int32_t* ws = static_cast<int32_t*>(workspace);
@@ -996,7 +1102,10 @@ static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w
     ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&w8a8_gemm256fq_kernel<T, RQ, false, WO>), (int)lds); \
     w8a8_gemm256fq_kernel<T, RQ, false, WO><<<grid, 512, lds, s>>>(a, (int)total);                          \
   } while (0)
-#define FFQ_FQ(T, RQ) do { if (w_offset) FFQ_FQ_LAUNCH(T, RQ, true); else FFQ_FQ_LAUNCH(T, RQ, false); } while (0)
+    // a predicated launch without weight offsets takes the WOFF instantiation too (the forward's own instantiations carry no
+    // predicate): its "some offset is live" word is run_if[1], which the either / or's deciding kernel keeps at zero
+    if (run_if && !w_offset) a.woff_live = run_if + 1;
+#define FFQ_FQ(T, RQ) do { if (w_offset || run_if) FFQ_FQ_LAUNCH(T, RQ, true); else FFQ_FQ_LAUNCH(T, RQ, false); } while (0)
     if (requant) {
       switch (out_dt) {
         case FFQ_I8: FFQ_FQ(int8_t, true); break;
@@ -1097,7 +1206,7 @@ extern "C" int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_s
   a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.woff_live = nullptr;
   a.wq2 = nullptr; a.w_scale2 = nullptr; a.rowsum_w2 = nullptr;
   a.batch_x = M * K; a.batch_w = N * K; a.batch_out = M * N;
-  a.gate = nullptr; a.extrema.words = nullptr; a.extrema.pair = nullptr; a.extrema.pair_dt = 0;
+  a.gate = nullptr; a.extrema.words = nullptr; a.extrema.pair = nullptr; a.extrema.pair_dt = 0; a.run_if = nullptr; a.run_when = 0;
   a.bias = nullptr; a.bias_dt = 0;
   a.out = out; a.out_dt = out_dt;
   a.out_scale = out_scale; a.out_offset = out_offset;
@@ -1145,21 +1254,23 @@ extern "C" size_t ffq_mlp_gate_up_w8a8_workspace_bytes(int64_t M, int64_t N, int
   return (size_t)((2 * N * 4 + 255) & ~(int64_t)255);
 }
 
-extern "C" int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const int32_t* gate_rowsum,
-                                    const int32_t* up_rowsum, const float* x_scale, const float* x_offset,
-                                    const float* gate_w_scale, const float* up_w_scale, int8_t* codes_out,
-                                    const float* out_scale, const float* out_offset, double out_num_bits, int64_t M,
-                                    int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+// `product_out` (bf16 [M, N]) instead of `codes_out`: the launch leaves silu(gate) * up itself, unquantized (+ its extrema)
+static int mlp_gate_up_w8a8_impl(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const int32_t* gate_rowsum,
+                                 const int32_t* up_rowsum, const float* x_scale, const float* x_offset,
+                                 const float* gate_w_scale, const float* up_w_scale, int8_t* codes_out,
+                                 const float* out_scale, const float* out_offset, double out_num_bits, int64_t M,
+                                 int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream,
+                                 void* product_out, uint32_t* extrema_words, void* extrema_pair, const int32_t* run_if, int run_when) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool have_sums = gate_rowsum && up_rowsum;
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
-  if (!xq || !gate_wq || !up_wq || !x_scale || !gate_w_scale || !up_w_scale || !codes_out || !out_scale)
+  if (!xq || !gate_wq || !up_wq || !x_scale || !gate_w_scale || !up_w_scale || (!product_out && (!codes_out || !out_scale)))
     return fail(FFQ_ERR_ARG, "NULL buffer");
   if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return fail(FFQ_ERR_ARG, "extent exceeds 2^31");
-  if (N % 128 != 0 || K % 128 != 0 || K < 256 || !aligned16(xq) || !aligned16(gate_wq) || !aligned16(up_wq) || !aligned16(codes_out))
+  if (N % 128 != 0 || K % 128 != 0 || K < 256 || !aligned16(xq) || !aligned16(gate_wq) || !aligned16(up_wq) || !aligned16(product_out ? product_out : (void*)codes_out))
     return fail(FFQ_ERR_DTYPE, "fused gate/up kernel needs N %% 128 == 0, K %% 128 == 0, K >= 256 and 16-byte aligned buffers");
-  if (!(out_num_bits >= 1 && out_num_bits <= 8 && out_num_bits == floor(out_num_bits)))
+  if (!product_out && !(out_num_bits >= 1 && out_num_bits <= 8 && out_num_bits == floor(out_num_bits)))
     return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.", FFQ_I8, out_num_bits);
   const size_t need = ffq_mlp_gate_up_w8a8_workspace_bytes(M, N, K);
   if (x_offset && !have_sums && (need > workspace_bytes || !workspace)) return fail(FFQ_ERR_WORKSPACE, "fused gate/up needs %zu workspace bytes, got %zu", need, workspace_bytes);
@@ -1169,9 +1280,10 @@ extern "C" int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, con
   a.w_scale = gate_w_scale; a.w_scale2 = up_w_scale; a.w_offset = nullptr;
   a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.rowsum_w2 = nullptr; a.woff_live = nullptr;
   a.batch_x = a.batch_w = a.batch_out = 0;
-  a.gate = nullptr; a.extrema.words = nullptr; a.extrema.pair = nullptr; a.extrema.pair_dt = 0;
+  a.gate = nullptr; a.extrema.words = extrema_words; a.extrema.pair = extrema_pair; a.extrema.pair_dt = FFQ_BF16;
+  a.run_if = run_if; a.run_when = run_when;
   a.bias = nullptr; a.bias_dt = 0;
-  a.out = codes_out; a.out_dt = FFQ_I8;
+  a.out = product_out ? product_out : (void*)codes_out; a.out_dt = product_out ? FFQ_BF16 : FFQ_I8;
   a.out_scale = out_scale; a.out_offset = out_offset;
   const double lo = -pow(2.0, out_num_bits - 1.0);
   a.out_lo = (float)lo; a.out_hi = (float)(-lo - 1.0);
@@ -1190,10 +1302,105 @@ extern "C" int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, con
     rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(up_wq, (int)N, (int)K, ws + N, nullptr);
     a.rowsum_w = ws; a.rowsum_w2 = ws + N;
   }
+  const int total = a.tiles_m * a.tiles_n;
+  if (product_out) {
+    const size_t lds = (size_t)2 * (BM2 + 256) * 128 + kSiluBytes + 3 * 512 * 4;  // ... + the threads' running extrema
+    static uint64_t attr_set = 0;
+    ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&w8a8_gemm256fq_kernel<bf16_t, false, true>), (int)lds);
+    w8a8_gemm256fq_kernel<bf16_t, false, true><<<(unsigned)(total < 256 ? total : 256), 512, lds, s>>>(a, total);
+    return check_launch("w8a8_gemm256fq_kernel (mlp mode, product)");
+  }
   const size_t lds = (size_t)2 * (BM2 + 256) * 128 + kSiluBytes;  // two operand slots + the silu table
   static uint64_t attr_set = 0;
   ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&w8a8_gemm256fq_kernel<int8_t, true, true>), (int)lds);
-  const int total = a.tiles_m * a.tiles_n;
   w8a8_gemm256fq_kernel<int8_t, true, true><<<(unsigned)(total < 256 ? total : 256), 512, lds, s>>>(a, total);
   return check_launch("w8a8_gemm256fq_kernel (mlp mode)");
+}
+
+extern "C" int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* up_wq, const int32_t* gate_rowsum,
+                                    const int32_t* up_rowsum, const float* x_scale, const float* x_offset,
+                                    const float* gate_w_scale, const float* up_w_scale, int8_t* codes_out,
+                                    const float* out_scale, const float* out_offset, double out_num_bits, int64_t M,
+                                    int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  return mlp_gate_up_w8a8_impl(xq, gate_wq, up_wq, gate_rowsum, up_rowsum, x_scale, x_offset, gate_w_scale, up_w_scale, codes_out, out_scale,
+                               out_offset, out_num_bits, M, N, K, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr, nullptr, 0);
+}
+
+// ---- the gated MLP up to its product while gate_proj's and up_proj's input quantizers are being calibrated ----------------------------
+// The one-launch mode takes ONE set of activation codes and weights without offsets; during range estimation the two input
+// quantizers are separate estimators whose parameters are rewritten on every step — equal whenever both have seen the same data, which
+// the host cannot know without a read per layer and step — and a symmetric weight quantizer's offset buffer is zero unless its
+// weight is non-negative, also a fact of the device. So the decision is taken on the device: one block compares the two parameter
+// pairs (scale bit for bit, rounded offsets) and tests the two offset buffers, and both routes are enqueued with the flag as
+// their predicate — the route that is not taken costs a launch whose blocks return on their first instruction:
+//   flag == 1  w8a8_gemm256fq_kernel<bf16, no requant, MLP>: gate + up + SiLU * up -> the bf16 product, its [min, max]
+//   flag == 0  gate_proj's linear (weight offsets on the device) into `gate_scratch`, then up_proj's with the gated epilogue
+// Either way `product_out` / `extrema_pair` hold what the two linears + SiLU * up + a reduction would have produced.
+namespace ffq {
+__global__ __launch_bounds__(1024) void mlp_inputs_agree_kernel(const float* __restrict__ xs_g, const float* __restrict__ xo_g,
+                                                               const float* __restrict__ xs_u, const float* __restrict__ xo_u,
+                                                               const float* __restrict__ wo_g, const float* __restrict__ wo_u, int n,
+                                                               int32_t* __restrict__ flag) {
+  int bad = 0;
+  if (wo_g) for (int i = threadIdx.x; i < n; i += 1024) bad |= rne(wo_g[i]) != 0.0f;
+  if (wo_u) for (int i = threadIdx.x; i < n; i += 1024) bad |= rne(wo_u[i]) != 0.0f;
+  if (threadIdx.x == 0) {
+    bad |= __builtin_bit_cast(uint32_t, xs_g[0]) != __builtin_bit_cast(uint32_t, xs_u[0]);
+    const float og = xo_g ? rne(xo_g[0]) : 0.0f, ou = xo_u ? rne(xo_u[0]) : 0.0f;
+    bad |= !(og == ou);  // (a NaN offset: not equal, the two-launch route reproduces whatever the linears make of it)
+  }
+  bad = __syncthreads_or(bad);
+  if (threadIdx.x == 0) {
+    flag[0] = bad ? 0 : 1;
+    flag[1] = 0;  // (the "a weight offset is live" word of a predicated launch without weight offsets: linear_w8a8_impl)
+  }
+}
+}  // namespace ffq
+
+// workspace: [64 int32: the flag] [N gate row sums] [N up row sums] [ffq_linear_w8a8_workspace_bytes(M, N, K) for the two-launch route]
+extern "C" size_t ffq_mlp_gate_up_w8a8_estimating_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M < 0 || N < 0) return 0;
+  return 256 + (size_t)((2 * N * 4 + 255) & ~(int64_t)255) + ffq_linear_w8a8_workspace_bytes(M, N, K);
+}
+
+extern "C" int ffq_mlp_gate_up_w8a8_estimating(const int8_t* xq_gate, const int8_t* xq_up, const int8_t* gate_wq, const int8_t* up_wq,
+                                               const float* x_scale_gate, const float* x_offset_gate, const float* x_scale_up,
+                                               const float* x_offset_up, const float* gate_w_scale, const float* gate_w_offset,
+                                               const float* up_w_scale, const float* up_w_offset, void* gate_scratch, void* product_out,
+                                               int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes,
+                                               uint32_t* extrema_words, void* extrema_pair, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (M == 0 || N == 0) return FFQ_OK;
+  if (!xq_gate || !xq_up || !gate_wq || !up_wq || !x_scale_gate || !x_scale_up || !gate_w_scale || !up_w_scale || !gate_scratch || !product_out)
+    return fail(FFQ_ERR_ARG, "NULL buffer");
+  if ((extrema_words == nullptr) != (extrema_pair == nullptr)) return fail(FFQ_ERR_ARG, "extrema_words and extrema_pair come together");
+  if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return fail(FFQ_ERR_ARG, "extent exceeds 2^31");
+  const int64_t tiles256 = ((M + BM2 - 1) / BM2) * ((N + 255) / 256);
+  // both routes must be able to run: the one-launch mode's shapes and the persistent kernel's whole-line path of the gated epilogue
+  if (N % 128 != 0 || K % 128 != 0 || K < 256 || M < 128 || tiles256 < 64 || !aligned16(xq_gate) || !aligned16(xq_up) || !aligned16(gate_wq) ||
+      !aligned16(up_wq) || !aligned16(gate_scratch) || !aligned16(product_out))
+    return fail(FFQ_ERR_DTYPE, "gate/up while estimating: needs N %% 128 == 0, K %% 128 == 0, K >= 256, >= 64 tiles of 256 x 256 and 16-byte aligned buffers");
+  const size_t need = ffq_mlp_gate_up_w8a8_estimating_workspace_bytes(M, N, K);
+  if (!workspace || workspace_bytes < need) return fail(FFQ_ERR_WORKSPACE, "gate/up while estimating needs %zu workspace bytes, got %zu", need, workspace_bytes);
+  char* base = static_cast<char*>(workspace);
+  int32_t* flag = reinterpret_cast<int32_t*>(base);
+  int32_t* rs_gate = reinterpret_cast<int32_t*>(base + 256);
+  int32_t* rs_up = rs_gate + N;
+  void* lin_ws = base + 256 + ((2 * N * 4 + 255) & ~(int64_t)255);
+  const size_t lin_bytes = ffq_linear_w8a8_workspace_bytes(M, N, K);
+  mlp_inputs_agree_kernel<<<1, 1024, 0, s>>>(x_scale_gate, x_offset_gate, x_scale_up, x_offset_up, gate_w_offset, up_w_offset, (int)N, flag);
+  // the weight row sums serve both routes (the zero-point term of either x offset)
+  rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(gate_wq, (int)N, (int)K, rs_gate, nullptr);
+  rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(up_wq, (int)N, (int)K, rs_up, nullptr);
+  int rc = check_launch("mlp_inputs_agree_kernel / rowsum_i8_kernel");
+  if (rc) return rc;
+  rc = mlp_gate_up_w8a8_impl(xq_gate, gate_wq, up_wq, rs_gate, rs_up, x_scale_gate, x_offset_gate ? x_offset_gate : nullptr, gate_w_scale, up_w_scale,
+                             nullptr, nullptr, nullptr, 8.0, M, N, K, nullptr, 0, stream, product_out, extrema_words, extrema_pair, flag, 1);
+  if (rc) return rc;
+  rc = linear_w8a8_impl(xq_gate, gate_wq, rs_gate, x_scale_gate, x_offset_gate, 0, gate_w_scale, gate_w_offset, 1, nullptr, 0, gate_scratch, FFQ_BF16,
+                        nullptr, nullptr, 8.0, 0, M, N, K, lin_ws, lin_bytes, stream, nullptr, nullptr, nullptr, flag, 0);
+  if (rc) return rc;
+  return linear_w8a8_impl(xq_up, up_wq, rs_up, x_scale_up, x_offset_up, 0, up_w_scale, up_w_offset, 1, nullptr, 0, product_out, FFQ_BF16, nullptr, nullptr,
+                          8.0, 0, M, N, K, lin_ws, lin_bytes, stream, gate_scratch, extrema_words, extrema_pair, flag, 0);
 }

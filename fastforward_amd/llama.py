@@ -1029,13 +1029,14 @@ class FusedProducersForward:
         self._stored[id(linear)] = (key, stored, block)
         return stored, block
 
-    def _linear(self, x: torch.Tensor, linear: torch.nn.Module, gate: torch.Tensor | None = None) -> torch.Tensor:
+    def _linear(self, x: torch.Tensor, linear: torch.nn.Module, gate: torch.Tensor | None = None, pre: tuple | None = None) -> torch.Tensor:
         """QuantizedLinear.forward; int8 codes on both sides go to the int8 GEMM directly, stored weight codes of a weight-only
         linear to the bf16 x weight-code GEMM. With `gate` (the bf16 result of the MLP's gate projection) the result is
-        silu(gate) * linear(x) — formed in the int8 GEMM's epilogue where that launch covers the shapes."""
+        silu(gate) * linear(x) — formed in the int8 GEMM's epilogue where that launch covers the shapes. `pre`: what the linear's
+        input and weight quantizers returned, when the caller has run them already."""
         if gate is not None:
-            product = self._gated(x, linear, gate)
-            return product if product is not None else ff.ops.silu_mul_quantize(gate, self._linear(x, linear), (), want_product=True)[0]
+            product = self._gated(x, linear, gate, pre)
+            return product if product is not None else ff.ops.silu_mul_quantize(gate, self._linear(x, linear, pre=pre), (), want_product=True)[0]
         if linear.bias is not None or linear.weight_quantizer.is_stub() or not linear.output_quantizer.is_stub():
             return linear(x)
         if linear.input_quantizer.is_stub():
@@ -1056,8 +1057,7 @@ class FusedProducersForward:
                     weight = ff.ops.dequantize_by_tile(stored[0], wq.scale, tile, wq.offset, x.dtype)
                 return F.linear(x, weight)
             return linear(x)
-        xq = linear.input_quantizer(x)
-        wq = linear.weight_quantizer(linear.weight)
+        xq, wq = pre if pre is not None else (linear.input_quantizer(x), linear.weight_quantizer(linear.weight))
         if not (isinstance(xq, ff.QuantizedTensor) and isinstance(wq, ff.QuantizedTensor)) or xq.raw_data.dtype != torch.int8 or wq.raw_data.dtype != torch.int8:
             return ff.nn.functional.linear(xq, wq, None, output_quantizer=linear.output_quantizer)  # e.g. disable_quantization=True
         xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
@@ -1068,14 +1068,13 @@ class FusedProducersForward:
         w_offset = None if wp.offset is None or ff.fused_linear.known_zero_offset(wp.offset) else wp.offset
         return ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, None, out_dtype=torch.bfloat16)
 
-    def _gated(self, x: torch.Tensor, linear: torch.nn.Module, gate: torch.Tensor) -> torch.Tensor | None:
+    def _gated(self, x: torch.Tensor, linear: torch.nn.Module, gate: torch.Tensor, pre: tuple | None = None) -> torch.Tensor | None:
         """silu(gate) * linear(x) as ONE launch of the int8 GEMM (ops.linear_w8a8_gated), or None: the quantizers run exactly as
         in ``_linear`` (range estimation included); only what consumes their codes differs."""
         if (linear.bias is not None or linear.weight_quantizer.is_stub() or not linear.output_quantizer.is_stub() or linear.input_quantizer.is_stub()
                 or gate.dtype != torch.bfloat16):
             return None
-        xq = linear.input_quantizer(x)
-        wq = linear.weight_quantizer(linear.weight)
+        xq, wq = pre if pre is not None else (linear.input_quantizer(x), linear.weight_quantizer(linear.weight))
         usable = (isinstance(xq, ff.QuantizedTensor) and isinstance(wq, ff.QuantizedTensor) and xq.raw_data.dtype == torch.int8 and wq.raw_data.dtype == torch.int8)
         if usable:
             xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
@@ -1125,8 +1124,40 @@ class FusedProducersForward:
                 if product is not None:
                     return product
         with sibling_quantizers():
+            if normed.dtype == torch.bfloat16 and all(l.bias is None and not l.weight_quantizer.is_stub() and l.output_quantizer.is_stub()
+                                                      and not l.input_quantizer.is_stub() for l in (gate_proj, up_proj)):
+                # every quantizer first (each is its own estimator step during range estimation), then ONE op for what consumes their
+                # codes: gate + up + SiLU * up as one launch where the two input quantizers turn out — on the device — to hold equal
+                # parameters, else the two linears with the gated epilogue
+                pre_gate = (gate_proj.input_quantizer(normed), gate_proj.weight_quantizer(gate_proj.weight))
+                pre_up = (up_proj.input_quantizer(normed), up_proj.weight_quantizer(up_proj.weight))
+                product = self._gate_up_either_or(pre_gate, pre_up)
+                if product is not None:
+                    return product
+                gate = self._linear(normed, gate_proj, pre=pre_gate)
+                return self._linear(normed, up_proj, gate=gate, pre=pre_up)
             gate = self._linear(normed, gate_proj)
             return self._linear(normed, up_proj, gate=gate)
+
+    def _gate_up_either_or(self, pre_gate: tuple, pre_up: tuple) -> torch.Tensor | None:
+        """ops.mlp_gate_up_w8a8_estimating on what the four quantizers returned, or None where it does not apply."""
+        params = []
+        for xq, wq in (pre_gate, pre_up):
+            if not (isinstance(xq, ff.QuantizedTensor) and isinstance(wq, ff.QuantizedTensor)) or xq.raw_data.dtype != torch.int8 or wq.raw_data.dtype != torch.int8:
+                return None
+            xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
+            if xp.scale.numel() != 1 or ff.fused_linear.KERNELS.row_mode(wq) != "row" or xp.num_bits > 8 or wp.num_bits > 8:
+                return None
+            w_offset = None if wp.offset is None or ff.fused_linear.known_zero_offset(wp.offset) else wp.offset
+            params.append(((xp.scale, xp.offset), (wp.scale, w_offset)))
+        out = ff.ops.mlp_gate_up_w8a8_estimating(pre_gate[0].raw_data, pre_up[0].raw_data, pre_gate[1].raw_data, pre_up[1].raw_data,
+                                                 params[0][0], params[1][0], params[0][1], params[1][1], want_extrema=self._want_product_extrema)
+        if out is None:
+            return None
+        if self._want_product_extrema:
+            self._product_extrema = (out[0], out[1])
+            return out[0]
+        return out
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, logits: bool = False) -> torch.Tensor:

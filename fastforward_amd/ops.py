@@ -1214,6 +1214,63 @@ def mlp_gate_up_w8a8(
     return out
 
 
+def mlp_gate_up_w8a8_estimating(
+    x_codes_gate: torch.Tensor,
+    x_codes_up: torch.Tensor,
+    gate_codes: torch.Tensor,
+    up_codes: torch.Tensor,
+    x_params_gate: tuple[torch.Tensor, torch.Tensor | None],
+    x_params_up: tuple[torch.Tensor, torch.Tensor | None],
+    gate_params: tuple[torch.Tensor, torch.Tensor | None],
+    up_params: tuple[torch.Tensor, torch.Tensor | None],
+    want_extrema: bool = False,
+) -> torch.Tensor | tuple[torch.Tensor, torch.Tensor] | None:
+    """``silu(linear(xg, Wg)) * linear(xu, Wu)`` as a bf16 tensor for int8 operands whose quantizers are still being calibrated
+    (C ABI ``ffq_mlp_gate_up_w8a8_estimating``): `x_codes_gate` / `x_codes_up` are the codes gate_proj's and up_proj's own input
+    quantizers produced from the same activation, each with its (scale, offset). Whether the two hold equal parameters — then the
+    one-launch gate + up + SiLU * up kernel runs on one of the code tensors — is decided on the device; otherwise the two linears
+    run, the second with the gated epilogue. Same values either way: ``silu_mul_quantize(linear_w8a8(xg, ...), linear_w8a8(xu, ...),
+    (), want_product=True)[0]``. ``want_extrema``: also ``[min, max]`` of the product. None outside the kernels' shapes."""
+    xg, xu = x_codes_gate.detach().contiguous(), x_codes_up.detach().contiguous()
+    gc, uc = gate_codes.detach().contiguous(), up_codes.detach().contiguous()
+    if not (xg.dtype == xu.dtype == gc.dtype == uc.dtype == torch.int8) or gc.shape != uc.shape or gc.dim() != 2 or xg.shape != xu.shape:
+        raise TypeError("mlp_gate_up_w8a8_estimating expects int8 codes, equally shaped gate / up weights and equally shaped activations")
+    K, N = xg.shape[-1], gc.shape[0]
+    M = xg.numel() // K if K else 0
+    if gc.shape[1] != K:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({M}x{K} and {tuple(gc.shape)}^T)")
+    if N % 128 or K % 128 or K < 256 or M < 128 or ((M + 255) // 256) * ((N + 255) // 256) < 64:
+        return None
+
+    def f32(t: torch.Tensor | None, n: int) -> torch.Tensor | None:
+        if t is None:
+            return None
+        t = t.detach().reshape(-1).to(torch.float32).contiguous()
+        return t if t.numel() == n else None
+
+    xsg, xsu, gs, us = f32(x_params_gate[0], 1), f32(x_params_up[0], 1), f32(gate_params[0], N), f32(up_params[0], N)
+    if xsg is None or xsu is None or gs is None or us is None:
+        return None
+    xog, xou, go, uo = f32(x_params_gate[1], 1), f32(x_params_up[1], 1), f32(gate_params[1], N), f32(up_params[1], N)
+    if any(p[1] is not None and o is None for p, o in ((x_params_gate, xog), (x_params_up, xou), (gate_params, go), (up_params, uo))):
+        return None  # an offset of another granularity
+    lib, stream = _prepare(xg, xu, gc, uc, xsg, xsu, gs, us, xog, xou, go, uo)
+    product = torch.empty((*xg.shape[:-1], N), dtype=torch.bfloat16, device=xg.device)
+    gate_scratch = torch.empty_like(product)  # touched only where the two-launch route runs
+    nbytes = lib.ffq_mlp_gate_up_w8a8_estimating_workspace_bytes(M, N, K)
+    ws = _workspace(nbytes, xg.device)
+    words = _extrema_words(xg.device, stream) if want_extrema else None
+    pair = torch.empty(2, dtype=torch.bfloat16, device=xg.device) if want_extrema else None
+    status = lib.ffq_mlp_gate_up_w8a8_estimating(
+        _ptr(xg), _ptr(xu), _ptr(gc), _ptr(uc), _ptr(xsg), _ptr(xog), _ptr(xsu), _ptr(xou), _ptr(gs), _ptr(go), _ptr(us), _ptr(uo),
+        _ptr(gate_scratch), _ptr(product), M, N, K, _ptr(ws), nbytes, _ptr(words), _ptr(pair), stream,
+    )
+    if status == 6:
+        return None
+    lib.check(status)
+    return (product, pair) if want_extrema else product
+
+
 def quantize_rows_rowsum(
     weight: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor | None, num_bits: float = 8.0, rowsum_out: torch.Tensor | None = None
 ) -> tuple[torch.Tensor, torch.Tensor] | None:

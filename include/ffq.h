@@ -470,6 +470,26 @@ int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* 
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The gated MLP up to its product while gate_proj's and up_proj's input quantizers are being calibrated (range estimation:
+ * `ff.estimate_ranges` around QuantizedLlamaMLP.forward, mlp.py:30-40): product_out [M, N] bf16 = bf16(silu(bf16 gate)) * bf16(up)
+ * with gate = linear(xq_gate; gate weights), up = linear(xq_up; up weights) — two activation code tensors, one per input
+ * quantizer (nn/linear.py:33), per-tensor parameters; weights per output channel with nullable offset buffers. The one-launch
+ * mode above needs ONE set of activation codes and offset-free weights: whether the two quantizers hold equal parameters (they
+ * do whenever both have seen the same data) and whether the offset buffers are all zero is decided ON THE DEVICE, and both routes
+ * are enqueued with that flag as their predicate — one launch (gate + up + SiLU * up, the product left unquantized), or
+ * gate_proj's linear into `gate_scratch` [M, N] bf16 followed by ffq_linear_w8a8_gated. Same values either way (the product of
+ * the two-tensor chain); no host read. `extrema_words` / `extrema_pair` as in ffq_linear_w8a8_gated.
+ * Shapes: N % 128 == 0, K % 128 == 0, K >= 256, >= 64 output tiles of 256 x 256; else FFQ_ERR_DTYPE.
+ */
+size_t ffq_mlp_gate_up_w8a8_estimating_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int ffq_mlp_gate_up_w8a8_estimating(const int8_t* xq_gate, const int8_t* xq_up, const int8_t* gate_wq, const int8_t* up_wq,
+                                    const float* x_scale_gate, const float* x_offset_gate, const float* x_scale_up,
+                                    const float* x_offset_up, const float* gate_w_scale, const float* gate_w_offset,
+                                    const float* up_w_scale, const float* up_w_offset, void* gate_scratch, void* product_out,
+                                    int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes,
+                                    uint32_t* extrema_words, void* extrema_pair, void* stream);
+
+/*
  * GGUF block-32 records — pack_q4_0_blocks / pack_q8_0_blocks, export/stages/gguf/_packing.py:23-72: `codes` is
  * [nblocks, 32] int8 in FastForward's signed convention, `scales` [nblocks] fp32 (positive). format 4 -> Q4_0:
  * 18 bytes per block = fp16(scale) then byte[j] = (code[j] + 8) | (code[j + 16] + 8) << 4 (nibbles clamped to

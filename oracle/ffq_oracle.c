@@ -1093,6 +1093,26 @@ int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* 
   return rc;
 }
 
+/* mlp.py:30-40 up to the product, each linear on its own input quantizer's codes (nn/linear.py:33): two A6 linears (bf16), SiLU(gate) * up */
+size_t ffq_mlp_gate_up_w8a8_estimating_workspace_bytes(int64_t M, int64_t N, int64_t K) { return ffq_linear_w8a8_workspace_bytes(M, N, K); }
+
+int ffq_mlp_gate_up_w8a8_estimating(const int8_t* xq_gate, const int8_t* xq_up, const int8_t* gate_wq, const int8_t* up_wq,
+                                    const float* x_scale_gate, const float* x_offset_gate, const float* x_scale_up,
+                                    const float* x_offset_up, const float* gate_w_scale, const float* gate_w_offset,
+                                    const float* up_w_scale, const float* up_w_offset, void* gate_scratch, void* product_out,
+                                    int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes,
+                                    uint32_t* extrema_words, void* extrema_pair, void* stream) {
+  if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if ((extrema_words == NULL) != (extrema_pair == NULL)) return fail(FFQ_ERR_ARG, "extrema_words and extrema_pair come together");
+  if (M == 0 || N == 0) return FFQ_OK;
+  if (N % 128 != 0 || K % 128 != 0 || K < 256) return fail(FFQ_ERR_DTYPE, "gate/up while estimating: needs N %% 128 == 0, K %% 128 == 0, K >= 256");
+  int rc = ffq_linear_w8a8(xq_gate, gate_wq, NULL, x_scale_gate, x_offset_gate, 0, gate_w_scale, gate_w_offset, 1, NULL, 0, gate_scratch, FFQ_BF16, NULL,
+                           NULL, 8.0, FFQ_BF16, M, N, K, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  return ffq_linear_w8a8_gated(xq_up, up_wq, NULL, x_scale_up, x_offset_up, 0, up_w_scale, up_w_offset, 1, gate_scratch, product_out, M, N, K, workspace,
+                               workspace_bytes, extrema_words, extrema_pair, stream);
+}
+
 /* mlp.py:36-38 with gate_proj's result at hand: the second linear (A6, bf16), then SiLU(gate) * up — composed from the restatements above */
 int ffq_linear_w8a8_gated(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
                           const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset,

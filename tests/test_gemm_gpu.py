@@ -507,3 +507,45 @@ def test_gated_epilogue_with_extrema_inside_a_hipgraph():
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(got, want) and torch.equal(pair, want_pair)
+
+
+@pytest.mark.parametrize("route", ["equal_parameters", "different_scale", "different_offset", "a_weight_offset", "zero_weight_offsets"])
+def test_gate_up_while_estimating_takes_either_route_to_the_same_product(route):
+    """ops.mlp_gate_up_w8a8_estimating decides ON THE DEVICE between the one-launch gate + up + SiLU * up kernel (the two input
+    quantizers hold equal parameters, no weight offset is live) and the two linears with the gated epilogue. Either way the
+    product and its [min, max] are those of silu_mul_quantize(linear_w8a8(xg, Wg), linear_w8a8(xu, Wu)) — bit for bit wherever the
+    chain gives a number. Ragged M; an ordinary launch on the same stream afterwards sees the accumulator words in their initial state."""
+    g = torch.Generator(device=DEV).manual_seed(len(route))
+    m, n, k = 2000, 2048, 512
+    x = (torch.randn(m, k, device=DEV, generator=g) * 2).to(torch.bfloat16)
+    sg, og = torch.tensor([0.031], device=DEV), torch.tensor([-2.6], device=DEV)
+    su, ou = sg.clone(), og.clone()
+    if route == "different_scale":
+        su = torch.tensor([0.04], device=DEV)
+    if route == "different_offset":
+        ou = torch.tensor([3.2], device=DEV)
+    xg = ops.quantize_by_tile(x, sg, x.shape, 8, torch.int8, og)
+    xu = ops.quantize_by_tile(x, su, x.shape, 8, torch.int8, ou)
+    wg = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    wu = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    swg = torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+    swu = torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+    owg = owu = None
+    if route == "zero_weight_offsets":
+        owg, owu = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV) + 0.25  # rounds to zero
+    if route == "a_weight_offset":
+        owg, owu = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        owu[n - 1] = 2.0
+    gate = ops.linear_w8a8(xg, wg, sg, og, swg, owg, None, out_dtype=torch.bfloat16)
+    up = ops.linear_w8a8(xu, wu, su, ou, swu, owu, None, out_dtype=torch.bfloat16)
+    want = ops.silu_mul_quantize(gate, up, (), want_product=True)[0]
+    lo, hi = ops.minmax_by_tile(want, want.shape)
+    for _ in range(2):
+        got, pair = ops.mlp_gate_up_w8a8_estimating(xg, xu, wg, wu, (sg, og), (su, ou), (swg, owg), (swu, owu), want_extrema=True)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+        assert torch.equal(pair.view(torch.int16), torch.cat([lo, hi]).view(torch.int16)), (pair, lo, hi)
+    plain = ops.mlp_gate_up_w8a8_estimating(xg, xu, wg, wu, (sg, og), (su, ou), (swg, owg), (swu, owu))
+    assert torch.equal(plain.view(torch.int16), want.view(torch.int16))
+    for words in ops._EXTREMA_WORDS.values():
+        assert words.tolist() == [-1, 0, 0, 0]
+    assert ops.mlp_gate_up_w8a8_estimating(xg[:100], xu[:100], wg, wu, (sg, og), (su, ou), (swg, None), (swu, None)) is None  # too few tiles
