@@ -200,7 +200,7 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
     "ffq_linear_wq": (_i, [_vp, _i, _vp, _i, _i64, _vp, _vp, _i64, _i64, _vp, _i, _vp, _i, _i64, _i64, _i64, _vp, _sz, _vp, _i64, _vp]),
     "ffq_force_generic_kernels": (_i, [_i]),
     "ffq_quantize_rows_batch": (_i, [ctypes.POINTER(RowsBatch), _i, _vp]),
-    "ffq_attention": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _d, _i, _vp, _vp, _vp, _vp, _d, _vp]),
+    "ffq_attention": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _d, _i, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
 }
 
 

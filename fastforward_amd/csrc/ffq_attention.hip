@@ -63,6 +63,8 @@ struct AttnArgs {
   int32_t nqb;            // query blocks per sequence
   float c;                // softmax scale * log2(e)
   float lo, hi;           // clamp bounds of the codes
+  const uint16_t* q_cos;  // nullable: rotary tables [S][128] — q arrives UN-rotated and is rotated as it is loaded
+  const uint16_t* q_sin;
 };
 
 // V^T fragment of one MFMA: 8 keys x 1 column per lane = two transposing reads (ds_read_b64_tr_b16: lane i of a 16-lane
@@ -112,6 +114,41 @@ __global__ __launch_bounds__(kWaves * 64) void attention_fwd_kernel(AttnArgs a) 
       u32x4 v = *reinterpret_cast<const u32x4*>(qrow + (2 * t + h) * 8);
       if (!wave_valid) v = u32x4{0, 0, 0, 0};
       qf[t] = __builtin_bit_cast(bf16x8, v);
+    }
+    // Rotary embedding of q on the way in (attention.py:20-41: out = bf16(bf16(q * cos) + bf16(rotate_half(q) * sin)), the
+    // arithmetic of ffq_rope_inplace): a lane's fragments t and t + 4 are columns c .. c + 7 and c + 64 .. c + 71 of ITS row — the
+    // two halves the rotation pairs — so nothing leaves the lane, and a query row is rotated once, by the one wave that owns it.
+    // The q pass of the stand-alone rotary kernel (a read and a write of the whole q projection per layer) is gone.
+    if (a.q_cos && wave_valid) {
+      const size_t trow = (size_t)(qw0 + (int32_t)r32) * kD;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = (2 * t + (int)h) * 8;
+        const u32x4 cl = *reinterpret_cast<const u32x4*>(a.q_cos + trow + c), ch = *reinterpret_cast<const u32x4*>(a.q_cos + trow + 64 + c);
+        const u32x4 sl = *reinterpret_cast<const u32x4*>(a.q_sin + trow + c), sh = *reinterpret_cast<const u32x4*>(a.q_sin + trow + 64 + c);
+        const u32x4 lo = __builtin_bit_cast(u32x4, qf[t]), hi = __builtin_bit_cast(u32x4, qf[t + 4]);
+        const uint32_t lw[4] = {lo.x, lo.y, lo.z, lo.w}, hw[4] = {hi.x, hi.y, hi.z, hi.w};
+        const uint32_t clw[4] = {cl.x, cl.y, cl.z, cl.w}, chw[4] = {ch.x, ch.y, ch.z, ch.w};
+        const uint32_t slw[4] = {sl.x, sl.y, sl.z, sl.w}, shw[4] = {sh.x, sh.y, sh.z, sh.w};
+        uint32_t ol[4], oh[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          float r[2][2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            auto el = [&](uint32_t word) { return __builtin_bit_cast(float, e ? (word & 0xFFFF0000u) : (word << 16)); };
+            const float x1 = el(lw[w]), x2 = el(hw[w]);
+            float p = x1 * el(clw[w]), q2 = (-x2) * el(slw[w]), u = x2 * el(chw[w]), d = x1 * el(shw[w]);
+            const uint32_t pq = pack2<bf16_t>(p, q2), ud = pack2<bf16_t>(u, d);  // every product rounds to bf16
+            r[0][e] = __builtin_bit_cast(float, pq << 16) + __builtin_bit_cast(float, pq & 0xFFFF0000u);
+            r[1][e] = __builtin_bit_cast(float, ud << 16) + __builtin_bit_cast(float, ud & 0xFFFF0000u);
+          }
+          ol[w] = pack2<bf16_t>(r[0][0], r[0][1]);  // ... and so does the sum
+          oh[w] = pack2<bf16_t>(r[1][0], r[1][1]);
+        }
+        qf[t] = __builtin_bit_cast(bf16x8, u32x4{ol[0], ol[1], ol[2], ol[3]});
+        qf[t + 4] = __builtin_bit_cast(bf16x8, u32x4{oh[0], oh[1], oh[2], oh[3]});
+      }
     }
   }
 
@@ -295,7 +332,7 @@ using namespace ffq;
 extern "C" int ffq_attention(const void* q, const void* k, const void* v, int dt, int64_t batch, int64_t seq_len,
                              int64_t q_heads, int64_t kv_heads, int64_t head_dim, double softmax_scale, int causal,
                              void* ctx_out, int8_t* codes_out, const float* out_scale, const float* out_offset,
-                             double out_num_bits, void* stream) {
+                             double out_num_bits, const void* q_cos, const void* q_sin, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (batch < 0 || seq_len < 0 || q_heads <= 0 || kv_heads <= 0) return fail(FFQ_ERR_ARG, "bad extent");
   if (dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "attention is built for bf16 activations");
@@ -310,7 +347,10 @@ extern "C" int ffq_attention(const void* q, const void* k, const void* v, int dt
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (ctx_out && !aligned16(ctx_out)) || (codes_out && !aligned16(codes_out)))
     return fail(FFQ_ERR_ARG, "buffers must be 16-byte aligned");
   if (batch * seq_len * q_heads * head_dim >= ((int64_t)1 << 40)) return fail(FFQ_ERR_ARG, "too many elements for one launch");
+  if ((q_cos == nullptr) != (q_sin == nullptr)) return fail(FFQ_ERR_ARG, "q_cos and q_sin come together");
+  if (q_cos && (!aligned16(q_cos) || !aligned16(q_sin))) return fail(FFQ_ERR_ARG, "buffers must be 16-byte aligned");
   AttnArgs a;
+  a.q_cos = static_cast<const uint16_t*>(q_cos); a.q_sin = static_cast<const uint16_t*>(q_sin);
   a.q = static_cast<const uint16_t*>(q); a.k = static_cast<const uint16_t*>(k); a.v = static_cast<const uint16_t*>(v);
   a.ctx = static_cast<uint16_t*>(ctx_out); a.codes = codes_out; a.scale = out_scale; a.offset = out_offset;
   a.B = (int32_t)batch; a.S = (int32_t)seq_len; a.H = (int32_t)q_heads; a.HKV = (int32_t)kv_heads;

@@ -190,6 +190,11 @@ class LlamaModel(torch.nn.Module):
 _ONE_PASS_MODULES = True
 
 
+# q's rotary embedding inside the attention launch (ops.attention(q_rope=...)) instead of a pass over the q projection; a switch for
+# A/B measurements (tools/rope_ab.py) — both settings give the same bits
+FUSE_Q_ROPE = True
+
+
 @contextlib.contextmanager
 def eager_modules(eager: bool = True):
     """Run the quantized Llama modules' forwards as the reference's eager ATen chains inside the block."""
@@ -391,7 +396,9 @@ class QuantizedLlamaAttention(QuantizedModule, LlamaAttention):
                     q, k, v = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
             if _one_pass(q, k, v, cos, sin) and cos.dim() == 2 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous():
                 # rotary embedding in place on the projections, then softmax(q k^T) v as one flash-style launch
-                ff.ops.rope_(q, k, cos, sin, cfg.head_dim)
+                # (k in place; q as the attention launch loads it: no pass over the q projection)
+                ff.ops.rope_(None if FUSE_Q_ROPE else q, k, cos, sin, cfg.head_dim)
+                q_rope = (cos, sin) if FUSE_Q_ROPE else None
                 causal = hidden_states.shape[1] > 1
                 o_proj = self.o_proj
                 fused = self._o_proj_input_in_epilogue(q.dtype)
@@ -401,10 +408,10 @@ class QuantizedLlamaAttention(QuantizedModule, LlamaAttention):
                     from fastforward_amd import fused_linear
 
                     _, codes = ff.ops.attention(q, k, v, cfg.head_dim, causal=causal, quantizer=(fused["out_scale"], fused["out_offset"]),
-                                                num_bits=fused["out_num_bits"], want_context=False)
+                                                num_bits=fused["out_num_bits"], want_context=False, q_rope=q_rope)
                     quantized = fused_linear.KERNELS._wrap(None, codes, o_proj.input_quantizer, q.dtype)
                     return ff.nn.functional.linear(quantized, o_proj.weight_quantizer(o_proj.weight), None, output_quantizer=o_proj.output_quantizer)
-                ctx, _ = ff.ops.attention(q, k, v, cfg.head_dim, causal=causal)
+                ctx, _ = ff.ops.attention(q, k, v, cfg.head_dim, causal=causal, q_rope=q_rope)
                 return o_proj(ctx)
             return self._attend(q, k, v, cos, sin)
         return LlamaAttention.forward(self, hidden_states, cos, sin)
@@ -924,12 +931,15 @@ class FusedForward:
             q = self._linear(codes[index[0]], attn.q_proj)
             k = self._linear(codes[index[1]], attn.k_proj)
             v = self._linear(codes[index[2]], attn.v_proj)
-            ff.ops.rope_(q, k, cos, sin, d)
             o_in = attn.o_proj.input_quantizer
             if self.fuse_attention and attention_kernel_covers(cfg, s, q.dtype):
-                # softmax(q k^T) v and o_proj's input quantizer in one launch: the bf16 context never visits HBM
-                _, o_codes = ff.ops.attention(q, k, v, d, causal=s > 1, quantizer=(o_in.scale, o_in.offset), num_bits=o_in.num_bits, want_context=False)
+                # rotary embedding: k in place, q as the attention launch loads it (no pass over the q projection); softmax(q k^T) v
+                # and o_proj's input quantizer in that one launch: the bf16 context never visits HBM
+                ff.ops.rope_(None if FUSE_Q_ROPE else q, k, cos, sin, d)
+                _, o_codes = ff.ops.attention(q, k, v, d, causal=s > 1, quantizer=(o_in.scale, o_in.offset), num_bits=o_in.num_bits, want_context=False,
+                                              q_rope=(cos, sin) if FUSE_Q_ROPE else None)
             else:
+                ff.ops.rope_(q, k, cos, sin, d)
                 ctx = _sdpa(q, k, v, cfg, b, s)
                 o_codes = ff.ops.quantize_by_tile(ctx, o_in.scale, ctx.shape, o_in.num_bits, torch.int8, o_in.offset)
             attn_out = self._linear(o_codes, attn.o_proj)
@@ -1173,10 +1183,11 @@ class FusedProducersForward:
                 ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
                 hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, pending, ln1.weight, ln1.variance_epsilon, (), want_norm=True, sum_inplace=pending is not None)
                 q, k, v = self._qkv(normed, attn)
-                ff.ops.rope_(q, k, cos, sin, d)
                 if attention_kernel_covers(cfg, s, q.dtype):
-                    ctx, _ = ff.ops.attention(q, k, v, d, causal=s > 1)
+                    ff.ops.rope_(None if FUSE_Q_ROPE else q, k, cos, sin, d)
+                    ctx, _ = ff.ops.attention(q, k, v, d, causal=s > 1, q_rope=(cos, sin) if FUSE_Q_ROPE else None)
                 else:
+                    ff.ops.rope_(q, k, cos, sin, d)
                     ctx = _sdpa(q, k, v, cfg, b, s)
                 attn_out = self._linear(ctx, attn.o_proj)
                 hidden, normed, _ = ff.ops.add_rmsnorm_quantize(hidden, attn_out, ln2.weight, ln2.variance_epsilon, (), want_norm=True, sum_inplace=True)

@@ -1420,25 +1420,27 @@ def silu_mul_quantize(
     return product, codes
 
 
-def rope_(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, head_dim: int) -> None:
+def rope_(q: torch.Tensor | None, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, head_dim: int) -> None:
     """Rotary embedding IN PLACE on the q/k projections laid out ``[batch, seq, heads * head_dim]``
-    (reference quantized_llama/attention.py:20-41); `cos`/`sin` are ``[seq, head_dim]``."""
-    if not (q.is_contiguous() and k.is_contiguous() and cos.is_contiguous() and sin.is_contiguous()):
+    (reference quantized_llama/attention.py:20-41); `cos`/`sin` are ``[seq, head_dim]``. ``q=None``: k alone (q is rotated
+    inside :func:`attention` when that call gets the tables: ``q_rope=(cos, sin)``)."""
+    if not ((q is None or q.is_contiguous()) and k.is_contiguous() and cos.is_contiguous() and sin.is_contiguous()):
         raise RuntimeError("rope_ works in place on contiguous projections")
-    if q.dim() != 3 or k.dim() != 3 or q.shape[:2] != k.shape[:2] or cos.shape != (q.shape[1], head_dim) or sin.shape != cos.shape:
+    if (q is not None and (q.dim() != 3 or q.shape[:2] != k.shape[:2])) or k.dim() != 3 or cos.shape != (k.shape[1], head_dim) or sin.shape != cos.shape:
         raise RuntimeError("rope_ expects q/k [batch, seq, heads * head_dim] and cos/sin [seq, head_dim]")
-    if not (q.dtype == k.dtype == cos.dtype == sin.dtype):
+    if not ((q is None or q.dtype == k.dtype) and k.dtype == cos.dtype == sin.dtype):
         raise RuntimeError("rope_ expects one dtype")
     lib, stream = _prepare(q, k, cos, sin)
-    tokens = q.shape[0] * q.shape[1]
+    tokens = k.shape[0] * k.shape[1]
     lib.check(
         lib.ffq_rope_inplace(
-            _ptr(q), q.shape[2] // head_dim, _ptr(k), k.shape[2] // head_dim, _tag(q.dtype), tokens, q.shape[1], head_dim,
+            _ptr(q), 0 if q is None else q.shape[2] // head_dim, _ptr(k), k.shape[2] // head_dim, _tag(k.dtype), tokens, k.shape[1], head_dim,
             _ptr(cos), _ptr(sin), stream,
         )
     )
     # written through raw pointers: tell the version counters (whatever is keyed on them, e.g. the activation-code memo, must miss)
-    torch.autograd.graph.increment_version(q)
+    if q is not None:
+        torch.autograd.graph.increment_version(q)
     torch.autograd.graph.increment_version(k)
 
 
@@ -1452,11 +1454,14 @@ def attention(
     num_bits: float = 8.0,
     want_context: bool = True,
     softmax_scale: float | None = None,
+    q_rope: tuple[torch.Tensor, torch.Tensor] | None = None,
 ) -> tuple[torch.Tensor | None, torch.Tensor | None]:
     """Attention on the projections as they leave q/k/v_proj — ``q`` ``[batch, seq, heads * head_dim]``, ``k`` / ``v``
     ``[batch, seq, kv_heads * head_dim]``, rotary embedding already applied — as one flash-style launch (reference
     quantized_llama/attention.py:45-92), optionally with the static per-tensor input quantizer of ``o_proj`` (A1)
-    fused in. Returns ``(context [batch, seq, heads * head_dim] or None, int8 codes or None)``."""
+    fused in. ``q_rope=(cos, sin)`` (``[seq, head_dim]`` each): `q` is given UN-rotated and rotated as the kernel loads it —
+    equal to ``rope_`` on q followed by this call, bit for bit, without the pass over q (k is rotated by the caller:
+    ``rope_(None, k, ...)``). Returns ``(context [batch, seq, heads * head_dim] or None, int8 codes or None)``."""
     if not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
         raise RuntimeError("attention expects contiguous projections")
     if q.dim() != 3 or k.dim() != 3 or k.shape != v.shape or q.shape[:2] != k.shape[:2] or q.shape[2] % head_dim or k.shape[2] % head_dim:
@@ -1471,7 +1476,12 @@ def attention(
         offset = None if quantizer[1] is None else quantizer[1].detach().reshape(-1).to(torch.float32)
         if scale.numel() != 1 or (offset is not None and offset.numel() != 1):
             raise RuntimeError("the fused quantizer is per-tensor (one scale, one offset)")
-    lib, stream = _prepare(q, k, v, scale, offset)
+    cos = sin = None
+    if q_rope is not None:
+        cos, sin = q_rope
+        if cos.shape != (q.shape[1], head_dim) or sin.shape != cos.shape or not (cos.dtype == sin.dtype == q.dtype) or not (cos.is_contiguous() and sin.is_contiguous()):
+            raise RuntimeError("attention: q_rope is (cos, sin), contiguous [seq, head_dim] tables in the activations' dtype")
+    lib, stream = _prepare(q, k, v, scale, offset, cos, sin)
     if quantizer is not None:
         codes = torch.empty(q.shape, dtype=torch.int8, device=q.device)
     ctx = torch.empty_like(q) if want_context else None
@@ -1480,7 +1490,7 @@ def attention(
         lib.ffq_attention(
             _ptr(q), _ptr(k), _ptr(v), _tag(q.dtype), b, s, q.shape[2] // head_dim, k.shape[2] // head_dim, head_dim,
             float(head_dim**-0.5 if softmax_scale is None else softmax_scale), int(bool(causal)),
-            _ptr(ctx), _ptr(codes), _ptr(scale), _ptr(offset), float(num_bits), stream,
+            _ptr(ctx), _ptr(codes), _ptr(scale), _ptr(offset), float(num_bits), _ptr(cos), _ptr(sin), stream,
         )
     )
     return ctx, codes

@@ -560,11 +560,14 @@ int ffq_quantize_rows_batch(const ffq_rows_batch* batch, int data_dt, void* stre
  * nullable. bf16 operands, fp32 accumulation and softmax (one pass, online softmax; no seq x seq matrix in HBM), so
  * ctx agrees with the eager chain to bf16 rounding (tolerance in tests/parity_cases.py::check_attention).
  * head_dim == 128, seq_len % 64 == 0, bf16 only: anything else returns FFQ_ERR_DTYPE.
+ * `q_cos` / `q_sin` (both or neither; ABI 8): the rotary tables [seq_len, head_dim] of ffq_rope_inplace — q then arrives
+ * UN-rotated and is rotated as the kernel loads it (the same arithmetic: equal to ffq_rope_inplace on q followed by this call
+ * without tables, bit for bit); k is rotated by the caller (ffq_rope_inplace with q_heads = 0).
  */
 int ffq_attention(const void* q, const void* k, const void* v, int dt, int64_t batch, int64_t seq_len,
                   int64_t q_heads, int64_t kv_heads, int64_t head_dim, double softmax_scale, int causal,
                   void* ctx_out, int8_t* codes_out, const float* out_scale, const float* out_offset,
-                  double out_num_bits, void* stream);
+                  double out_num_bits, const void* q_cos, const void* q_sin, void* stream);
 
 /*
  * Test hook. The streaming kernels (fp32 parameters, one 16-byte chunk per lane, Markstein division) and the generic kernels

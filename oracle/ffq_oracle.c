@@ -1213,9 +1213,20 @@ int ffq_gptq_block(float* weights, float* quantized, float* errors, int64_t rows
 int ffq_attention(const void* q, const void* k, const void* v, int dt, int64_t batch, int64_t seq_len,
                   int64_t q_heads, int64_t kv_heads, int64_t head_dim, double softmax_scale, int causal,
                   void* ctx_out, int8_t* codes_out, const float* out_scale, const float* out_offset,
-                  double out_num_bits, void* stream) {
-  (void)stream;
+                  double out_num_bits, const void* q_cos, const void* q_sin, void* stream) {
   if (batch < 0 || seq_len < 0 || q_heads <= 0 || kv_heads <= 0) return fail(FFQ_ERR_ARG, "bad extent");
+  if ((q_cos == NULL) != (q_sin == NULL)) return fail(FFQ_ERR_ARG, "q_cos and q_sin come together");
+  if (q_cos && q && batch > 0 && seq_len > 0 && dt == FFQ_BF16 && head_dim == 128) {
+    /* attention.py:20-41 then :45-92: rotate a copy of q with the restatement of the rotary embedding, then the attention on it */
+    const size_t bytes = (size_t)batch * seq_len * q_heads * head_dim * 2;
+    void* rotated = malloc(bytes);
+    memcpy(rotated, q, bytes);
+    int rc = ffq_rope_inplace(rotated, q_heads, NULL, 0, dt, batch * seq_len, seq_len, head_dim, q_cos, q_sin, stream);
+    if (!rc) rc = ffq_attention(rotated, k, v, dt, batch, seq_len, q_heads, kv_heads, head_dim, softmax_scale, causal, ctx_out, codes_out, out_scale,
+                                out_offset, out_num_bits, NULL, NULL, stream);
+    free(rotated);
+    return rc;
+  }
   if (dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "attention is built for bf16 activations");
   if (head_dim != 128) return fail(FFQ_ERR_DTYPE, "attention is built for head_dim 128");
   if (seq_len % 64 != 0) return fail(FFQ_ERR_DTYPE, "attention needs seq_len %% 64 == 0");

@@ -1428,3 +1428,32 @@ def test_batched_weight_quantization_equals_member_by_member():
         assert torch.equal(c, ops.quantize_by_tile(w, s, (1, w.shape[1]), 4, torch.int8, o))
     assert ops.quantize_rows_batch([small[0][:, :40].contiguous()], [sc[0]], [None]) is None  # 40 columns: not a multiple of 16
     assert ops.quantize_rows_batch([small[0].float()], [sc[0]], [None]) is None                # fp32 weights: member by member
+
+
+@pytest.mark.parametrize("causal", [True, False])
+def test_attention_rotates_q_on_the_way_in(causal):
+    """ops.attention(q_rope=(cos, sin)) on an UN-rotated q == ops.rope_ on q followed by ops.attention: context and o_proj codes bit
+    for bit (the rotation is the rotary kernel's arithmetic applied to the fragments a lane already holds); k alone through
+    rope_(None, k, ...) == the k half of the joint call. GQA shape of the 8B model at a short sequence; the oracle restates the
+    same composition on the CPU."""
+    g = torch.Generator().manual_seed(9)
+    b, s, h, hkv, d = 2, 256, 8, 2, 128
+    q = (torch.randn(b, s, h * d, generator=g) * 1.5).to(torch.bfloat16)
+    k = (torch.randn(b, s, hkv * d, generator=g) * 1.5).to(torch.bfloat16)
+    v = torch.randn(b, s, hkv * d, generator=g).to(torch.bfloat16)
+    cos, sin = (t.to(torch.bfloat16) for t in (torch.cos(torch.randn(s, d, generator=g) * 3), torch.sin(torch.randn(s, d, generator=g) * 3)))
+    sc, of = torch.tensor([0.021]), torch.tensor([1.7])
+
+    def run(device):
+        qd, kd, vd, cd, sd = (t.to(device) for t in (q, k, v, cos, sin))
+        q1, k1 = qd.clone(), kd.clone()
+        ops.rope_(q1, k1, cd, sd, d)
+        want_ctx, want_codes = ops.attention(q1, k1, vd, d, causal=causal, quantizer=(sc.to(device), of.to(device)))
+        k2 = kd.clone()
+        ops.rope_(None, k2, cd, sd, d)
+        assert torch.equal(k2, k1)
+        got_ctx, got_codes = ops.attention(qd, k2, vd, d, causal=causal, quantizer=(sc.to(device), of.to(device)), q_rope=(cd, sd))
+        assert torch.equal(got_ctx, want_ctx) and torch.equal(got_codes, want_codes)
+        return [got_ctx.float().cpu(), got_codes.cpu()]
+
+    _both(run)  # the equalities hold on the HIP path and in the oracle's restatement (HIP against oracle: test_attention_and_fused_output_quantizer)
