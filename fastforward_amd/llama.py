@@ -356,6 +356,47 @@ def _w8a8_gate_up_down_input(x: torch.Tensor, gate_proj: torch.nn.Module, up_pro
     return None, (gate, up)
 
 
+def _w8a8_gate_up_product(x: torch.Tensor, gate_proj: torch.nn.Module, up_proj: torch.nn.Module, want_extrema: bool):
+    """``silu(gate_proj(x)) * up_proj(x)`` of a W8A8 MLP whose quantizers may still be moving (range estimation) from ONE op
+    (ops.mlp_gate_up_w8a8_estimating): every quantizer runs as itself first — input and weight quantizer of either linear, each
+    with whatever override it carries (an estimator step) — then the op decides ON THE DEVICE whether the two input quantizers
+    hold equal parameters (one launch: gate + up + SiLU * up) or not (two linears, the second with the gated epilogue). Returns
+    ``(product, pair or None, None)`` — `pair` = [min, max] of the product when asked for — or ``(None, None, pre)`` with
+    ``pre = ((xq_gate, wq_gate), (xq_up, wq_up))`` when the quantizers have run but the op does not apply (the caller finishes
+    from them: nothing runs twice), or ``(None, None, None)`` when nothing was touched."""
+    from fastforward_amd import fused_linear
+    from fastforward_amd.nn import QuantizedLinear
+
+    if not _one_pass(x) or not x.is_contiguous() or _hooked(gate_proj, up_proj, gate_proj.output_quantizer, up_proj.output_quantizer):
+        return None, None, None
+    for lin in (gate_proj, up_proj):
+        if not isinstance(lin, QuantizedLinear) or lin.bias is not None or lin.weight_quantizer.is_stub() or lin.input_quantizer.is_stub():
+            return None, None, None
+    if not _untouched(gate_proj.output_quantizer, up_proj.output_quantizer):
+        return None, None, None
+    pre = tuple((lin.input_quantizer(x), lin.weight_quantizer(lin.weight)) for lin in (gate_proj, up_proj))
+    params = []
+    for xq, wq in pre:
+        if not (isinstance(xq, ff.QuantizedTensor) and isinstance(wq, ff.QuantizedTensor)) or xq.raw_data.dtype != torch.int8 or wq.raw_data.dtype != torch.int8:
+            return None, None, pre
+        xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
+        if (xp.scale.numel() != 1 or fused_linear.KERNELS.row_mode(wq) != "row" or xp.num_bits > 8 or wp.num_bits > 8
+                or fused_linear.KERNELS._deq_dtype(xq) != x.dtype):
+            return None, None, pre
+        w_offset = None if wp.offset is None or fused_linear.known_zero_offset(wp.offset) else wp.offset
+        params.append(((xp.scale, xp.offset), (wp.scale, w_offset)))
+    out = ff.ops.mlp_gate_up_w8a8_estimating(pre[0][0].raw_data, pre[1][0].raw_data, pre[0][1].raw_data, pre[1][1].raw_data,
+                                             params[0][0], params[1][0], params[0][1], params[1][1], want_extrema=want_extrema)
+    if out is None:
+        return None, None, pre
+    return (out[0], out[1], None) if want_extrema else (out, None, None)
+
+
+def _estimating(quantizer: torch.nn.Module | None) -> bool:
+    """The quantizer carries an override (a range estimator): its parameters are about to move with the data it is given."""
+    return quantizer is not None and next(iter(getattr(quantizer, "overrides", ())), None) is not None
+
+
 class QuantizedLlamaRMSNorm(QuantizedModule, LlamaRMSNorm):
     """Float under strict_quantization(False), like reference rms_norm.py:17-35."""
 
@@ -465,6 +506,17 @@ class QuantizedLlamaMLP(QuantizedModule, LlamaMLP):
             if quantized is not None:  # down_proj's GEMM on the codes its input quantizer would have produced
                 down = self.down_proj
                 return ff.nn.functional.linear(quantized, down.weight_quantizer(down.weight), None, output_quantizer=down.output_quantizer)
+            if parts is None and type(x) is torch.Tensor and _estimating(getattr(self.down_proj, "input_quantizer", None)):
+                # range estimation: the product from one op whatever the two input estimators hold (decided on the device), its
+                # [min, max] handed to down_proj's input estimator
+                with sibling_quantizers():
+                    product, pair, pre = _w8a8_gate_up_product(x, self.gate_proj, self.up_proj, want_extrema=True)
+                    if product is not None:
+                        RECENT.remember_extrema(product, pair)
+                        return self.down_proj(product)
+                    if pre is not None:  # the quantizers have run: finish the two linears from what they returned
+                        parts = tuple(ff.nn.functional.linear(xq, wq, None, output_quantizer=lin.output_quantizer)
+                                      for (xq, wq), lin in zip(pre, (self.gate_proj, self.up_proj)))
             if parts is None:
                 with sibling_quantizers():
                     parts = (self.gate_proj(x), self.up_proj(x))
@@ -1134,40 +1186,21 @@ class FusedProducersForward:
                 if product is not None:
                     return product
         with sibling_quantizers():
-            if normed.dtype == torch.bfloat16 and all(l.bias is None and not l.weight_quantizer.is_stub() and l.output_quantizer.is_stub()
-                                                      and not l.input_quantizer.is_stub() for l in (gate_proj, up_proj)):
+            if all(l.bias is None and not l.weight_quantizer.is_stub() and l.output_quantizer.is_stub() and not l.input_quantizer.is_stub()
+                   for l in (gate_proj, up_proj)):
                 # every quantizer first (each is its own estimator step during range estimation), then ONE op for what consumes their
                 # codes: gate + up + SiLU * up as one launch where the two input quantizers turn out — on the device — to hold equal
                 # parameters, else the two linears with the gated epilogue
-                pre_gate = (gate_proj.input_quantizer(normed), gate_proj.weight_quantizer(gate_proj.weight))
-                pre_up = (up_proj.input_quantizer(normed), up_proj.weight_quantizer(up_proj.weight))
-                product = self._gate_up_either_or(pre_gate, pre_up)
+                product, pair, pre = _w8a8_gate_up_product(normed, gate_proj, up_proj, want_extrema=self._want_product_extrema)
                 if product is not None:
+                    if pair is not None:
+                        self._product_extrema = (product, pair)
                     return product
-                gate = self._linear(normed, gate_proj, pre=pre_gate)
-                return self._linear(normed, up_proj, gate=gate, pre=pre_up)
+                if pre is not None:
+                    gate = self._linear(normed, gate_proj, pre=pre[0])
+                    return self._linear(normed, up_proj, gate=gate, pre=pre[1])
             gate = self._linear(normed, gate_proj)
             return self._linear(normed, up_proj, gate=gate)
-
-    def _gate_up_either_or(self, pre_gate: tuple, pre_up: tuple) -> torch.Tensor | None:
-        """ops.mlp_gate_up_w8a8_estimating on what the four quantizers returned, or None where it does not apply."""
-        params = []
-        for xq, wq in (pre_gate, pre_up):
-            if not (isinstance(xq, ff.QuantizedTensor) and isinstance(wq, ff.QuantizedTensor)) or xq.raw_data.dtype != torch.int8 or wq.raw_data.dtype != torch.int8:
-                return None
-            xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
-            if xp.scale.numel() != 1 or ff.fused_linear.KERNELS.row_mode(wq) != "row" or xp.num_bits > 8 or wp.num_bits > 8:
-                return None
-            w_offset = None if wp.offset is None or ff.fused_linear.known_zero_offset(wp.offset) else wp.offset
-            params.append(((xp.scale, xp.offset), (wp.scale, w_offset)))
-        out = ff.ops.mlp_gate_up_w8a8_estimating(pre_gate[0].raw_data, pre_up[0].raw_data, pre_gate[1].raw_data, pre_up[1].raw_data,
-                                                 params[0][0], params[1][0], params[0][1], params[1][1], want_extrema=self._want_product_extrema)
-        if out is None:
-            return None
-        if self._want_product_extrema:
-            self._product_extrema = (out[0], out[1])
-            return out[0]
-        return out
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, logits: bool = False) -> torch.Tensor:

@@ -521,9 +521,11 @@ def test_gptq_invalidates_cached_weight_codes(oracle_backend):
 
 
 @pytest.mark.gpu
-def test_producers_leaving_extrema_change_no_range(hip_backend, monkeypatch):
-    """During range estimation the gated int8 GEMM leaves [min, max] of the SiLU * up product it writes and down_proj's input
-    estimator starts from those two numbers; weights take the one-pass
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_forward", "module_graph"])
+def test_producers_leaving_extrema_change_no_range(hip_backend, monkeypatch, fused):
+    """During range estimation gate + up + SiLU * up run as one op (one launch where the two input estimators agree, decided on the
+    device; else the gated int8 GEMM epilogue) that leaves [min, max] of the product, and down_proj's input
+    estimator starts from those two numbers — in the fused forward and in the module graph (QuantizedLlamaMLP.forward); weights take the one-pass
     estimator-step-and-quantize kernel. With every one of those shortcuts switched off — estimators reduce over the tensors,
     the SiLU * up pass runs, weights take the two steps — the calibrated parameters are the same bits."""
     from fastforward_amd import distributed as ffd
@@ -541,8 +543,9 @@ def test_producers_leaving_extrema_change_no_range(hip_backend, monkeypatch):
             if not shortcuts:
                 patch.setattr(RECENT, "remember_extrema", lambda data, pair: None)
                 patch.setattr(ff.ops, "linear_w8a8_gated", lambda *a, **k: None)
+                patch.setattr(ff.ops, "mlp_gate_up_w8a8_estimating", lambda *a, **k: None)
                 patch.setattr(ff.nn.LinearQuantizer, "update_range_and_quantize", lambda self, *a, **k: None)
-            ffd.calibrate_sharded(model, batches, disable_quantization=False, fused=True)
+            ffd.calibrate_sharded(model, batches, disable_quantization=False, fused=fused)
         return ffd.ranges_fingerprint(model), RECENT.extrema_hits - hits
 
     want, hits_without = calibrated(False)
