@@ -131,13 +131,21 @@ def cfg3(total_sequences: int) -> dict:
     steps = total_sequences // 8
     gen = torch.Generator(device=DEV).manual_seed(77)
     batches = [torch.randint(0, config.vocab_size, (8, 2048), device=DEV, generator=gen) for _ in range(steps)]
+    def reset() -> None:  # a timed run starts from uninitialised ranges, like a first calibration
+        for _, quantizer in ff.nn.named_quantizers(model):
+            quantizer.reset_parameters()
+
+    # untimed pass over one batch through either forward: code objects load, the allocator grows (once per process; bench.py does the same)
+    ffd.calibrate_sharded(model, batches[:1], disable_quantization=False)
+    reset()
+    ffd.calibrate_sharded(model, batches[:1], disable_quantization=False, fused=True)
+    reset()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ffd.calibrate_sharded(model, batches[:8], disable_quantization=False)  # the reference-shaped module graph, 64 sequences
     torch.cuda.synchronize()
     s_mg = time.perf_counter() - t0
-    for _, quantizer in ff.nn.named_quantizers(model):  # the timed run starts from uninitialised ranges, like a first calibration
-        quantizer.reset_parameters()
+    reset()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     payload = ffd.calibrate_sharded(model, batches, disable_quantization=False, fused=True)

@@ -1,6 +1,6 @@
 """Calibration step time with each estimation shortcut switched off, in ONE process (boxes differ by several percent, runs of
 one box do not): Llama-3-8B shapes, LAYERS decoder layers, batch 8 x 2048, RunningMinMax through distributed.calibrate_sharded.
-usage: python tools/calib_ab.py [layers=8] [steps=6]"""
+usage: python tools/calib_ab.py [layers=8] [steps=6] [module]   ("module": the reference-shaped module graph instead of the fused forward)"""
 import contextlib, pathlib, sys, time, dataclasses
 import torch
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
@@ -10,6 +10,7 @@ from fastforward_amd.quantization.affine._memo import RECENT
 
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+FUSED = not (len(sys.argv) > 3 and sys.argv[3] == "module")
 cfg = dataclasses.replace(llama.LlamaConfig.llama3_8b(), num_layers=layers)
 model = llama.build_model(cfg, "cuda", torch.bfloat16, seed=1)
 llama.quantize_llama(model, 8, 8, torch.int8)
@@ -49,11 +50,11 @@ def reset():
 def run(*names):
     with patched(*names):
         reset()
-        ffd.calibrate_sharded(model, calib[:1], disable_quantization=False, fused=True)
+        ffd.calibrate_sharded(model, calib[:1], disable_quantization=False, fused=FUSED)
         reset()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ffd.calibrate_sharded(model, calib, disable_quantization=False, fused=True)
+        ffd.calibrate_sharded(model, calib, disable_quantization=False, fused=FUSED)
         torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
 
@@ -68,12 +69,12 @@ for a in arms:
 
 # host-bound or device-bound? kernel time of one calibration pass against its wall time
 reset()
-ffd.calibrate_sharded(model, calib[:1], disable_quantization=False, fused=True)
+ffd.calibrate_sharded(model, calib[:1], disable_quantization=False, fused=FUSED)
 reset()
 torch.cuda.synchronize()
 with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA, torch.profiler.ProfilerActivity.CPU]) as prof:
     t0 = time.perf_counter()
-    ffd.calibrate_sharded(model, calib, disable_quantization=False, fused=True)
+    ffd.calibrate_sharded(model, calib, disable_quantization=False, fused=FUSED)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
 dev = sum(e.device_time_total for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA) / 1e3
