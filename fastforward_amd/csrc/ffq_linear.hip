@@ -660,7 +660,7 @@ __device__ __forceinline__ void mlp_epilogue16_product(const LinearArgs& a, v4i3
       }
     }
     __syncthreads();
-#pragma unroll
+#pragma unroll 1  // (one 16-byte piece at a time: the other half's 64 accumulator registers are still live)
     for (int t = 0; t < 4; ++t) {  // 128 rows x 16 segments of 16 B over 512 threads
       const int idx = wave * 256 + t * 64 + lane;
       const int rowl = idx >> 4, seg = idx & 15;
