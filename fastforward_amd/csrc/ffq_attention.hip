@@ -39,7 +39,10 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 constexpr int kD = 128;             // head dim
 constexpr int kKeys = 64;           // keys per tile
-constexpr int kWaves = 8;
+#ifndef FFQ_ATTN_WAVES
+#define FFQ_ATTN_WAVES 8  // waves (of 32 query rows) per workgroup; A/B hook (tools/build_variant.sh)
+#endif
+constexpr int kWaves = FFQ_ATTN_WAVES;
 constexpr int kRowsPerWave = 32;
 constexpr int kQBlock = kWaves * kRowsPerWave;  // 256 query rows per workgroup
 constexpr int kKPitch = 256;        // bytes per K row in LDS (swizzled slots)
