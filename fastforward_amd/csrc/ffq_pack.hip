@@ -130,31 +130,25 @@ __global__ __launch_bounds__(kBlock) void quantize_pack_int4_kernel(const T* __r
     const uint32_t t_hi = a.rows ? fdiv(e_hi[u] / 16, a.chunks_per_run) : 0u;
     const float s_lo = scale[t_lo * a.scale_stride];
     const float o_lo = HAS_OFFSET ? rne(offset[t_lo * a.offset_stride]) : 0.0f;
-    float xl[ITEM], xh[ITEM], rl[ITEM], rh[ITEM];
+    float xl[ITEM], xh[ITEM];
 #pragma unroll
     for (int i = 0; i < ITEM; ++i) { xl[i] = cl[u].get(i); xh[i] = ch[u].get(i); }
-    const Divider<1> d_lo(s_lo);
-    quantize_chunk_with<1, ITEM>(d_lo, xl, o_lo, rl);
-    if (t_hi == t_lo) {  // both halves of the packing block inside one tile (group >= block): one reciprocal
-      quantize_chunk_with<1, ITEM>(d_lo, xh, o_lo, rh);
+    // A1 into int8 bytes clamped to [-8, 7] by ffq_affine.h's packed arithmetic (two elements per VALU op, its NaN self-check and
+    // the reference chain behind it: the codes of ffq_quantize_by_tile at 4 bits), then nibble = (byte & 0xF) ^ 8 = code + 8, four
+    // codes per op. (Round 5; before: one IEEE division chain, a convert and two clamps per element.)
+    Chunk<int8_t, ITEM> bl, bh;
+    quantize_chunk_to_bytes<ITEM>(xl, s_lo, o_lo, -8.0f, 7.0f, bl);
+    if (t_hi == t_lo) {  // both halves of the packing block inside one tile (group >= block): the same parameters
+      quantize_chunk_to_bytes<ITEM>(xh, s_lo, o_lo, -8.0f, 7.0f, bh);
     } else {
       const float s_hi = scale[t_hi * a.scale_stride];
       const float o_hi = HAS_OFFSET ? rne(offset[t_hi * a.offset_stride]) : 0.0f;
-      quantize_chunk<1, ITEM>(xh, s_hi, o_hi, rh);
+      quantize_chunk_to_bytes<ITEM>(xh, s_hi, o_hi, -8.0f, 7.0f, bh);
     }
     Chunk<uint8_t, ITEM> out;
 #pragma unroll
-    for (int w = 0; w < ITEM / 4; ++w) {
-      uint32_t word = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int l = (int)rl[4 * w + i], h = (int)rh[4 * w + i];  // v_cvt_i32_f32: NaN -> 0 (the int8 container's value)
-        l = (l < -8 ? -8 : (l > 7 ? 7 : l)) + 8;
-        h = (h < -8 ? -8 : (h > 7 ? 7 : h)) + 8;
-        word |= (uint32_t)(l | (h << 4)) << (8 * i);
-      }
-      out.w[w] = word;
-    }
+    for (int w = 0; w < ITEM / 4; ++w)
+      out.w[w] = ((bl.w[w] & 0x0F0F0F0Fu) ^ 0x08080808u) | (((bh.w[w] & 0x0F0F0F0Fu) ^ 0x08080808u) << 4);
     out.FFQ_SSTORE(packed + (size_t)b[u] * (a.block / 2) + j[u] * ITEM);
   }
 }
