@@ -108,6 +108,33 @@ __global__ __launch_bounds__(kWaves * 64) void attention_fwd_kernel(AttnArgs a) 
   const int32_t q_end = q0 + QBLOCK < a.S ? q0 + QBLOCK : a.S;
   const int32_t ntiles = (CAUSAL ? q_end : a.S) / kKeys;
 
+  // ---- K/V staging: thread -> (row = tid / 16 [+32], 16-byte slot = tid % 16)
+  const uint32_t srow = tid >> 4, sslot = tid & 15;
+  const size_t kv_stride = (size_t)a.HKV * kD;  // elements between consecutive keys
+  const uint16_t* kbase = a.k + ((size_t)b * a.S * a.HKV + kvh) * kD + sslot * 8;
+  const uint16_t* vbase = a.v + ((size_t)b * a.S * a.HKV + kvh) * kD + sslot * 8;
+  u32x4 sk[PASSES], sv[PASSES];
+  auto stage_load = [&](int32_t tile) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const size_t row = (size_t)tile * kKeys + srow + kWaves * 4 * p;
+      sk[p] = *reinterpret_cast<const u32x4*>(kbase + row * kv_stride);
+      sv[p] = *reinterpret_cast<const u32x4*>(vbase + row * kv_stride);
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const uint32_t row = srow + kWaves * 4 * p;
+      *reinterpret_cast<u32x4*>(smem + buf * kKBytes + row * kKPitch + ((sslot ^ (row & 15)) << 4)) = sk[p];
+      *reinterpret_cast<u32x4*>(smem + 2 * kKBytes + buf * kVBytes + row * kVPitch + (sslot << 4)) = sv[p];
+    }
+  };
+
+  // the first tile's K / V rows are requested BEFORE the query fragments are loaded and rotated: one round trip for all of them,
+  // and the rotation's arithmetic (a prologue of this one-workgroup-per-CU kernel that nothing else overlaps) runs under it
+  stage_load(0);
+
   // ---- Q fragments: lane (r32, h) holds columns [(2t+h)*8, +8) of row qw0 + r32, t = 0..7
   bf16x8 qf[8];
   {
@@ -155,29 +182,6 @@ __global__ __launch_bounds__(kWaves * 64) void attention_fwd_kernel(AttnArgs a) 
     }
   }
 
-  // ---- K/V staging: thread -> (row = tid / 16 [+32], 16-byte slot = tid % 16)
-  const uint32_t srow = tid >> 4, sslot = tid & 15;
-  const size_t kv_stride = (size_t)a.HKV * kD;  // elements between consecutive keys
-  const uint16_t* kbase = a.k + ((size_t)b * a.S * a.HKV + kvh) * kD + sslot * 8;
-  const uint16_t* vbase = a.v + ((size_t)b * a.S * a.HKV + kvh) * kD + sslot * 8;
-  u32x4 sk[PASSES], sv[PASSES];
-  auto stage_load = [&](int32_t tile) {
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-      const size_t row = (size_t)tile * kKeys + srow + kWaves * 4 * p;
-      sk[p] = *reinterpret_cast<const u32x4*>(kbase + row * kv_stride);
-      sv[p] = *reinterpret_cast<const u32x4*>(vbase + row * kv_stride);
-    }
-  };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-      const uint32_t row = srow + kWaves * 4 * p;
-      *reinterpret_cast<u32x4*>(smem + buf * kKBytes + row * kKPitch + ((sslot ^ (row & 15)) << 4)) = sk[p];
-      *reinterpret_cast<u32x4*>(smem + 2 * kKBytes + buf * kVBytes + row * kVPitch + (sslot << 4)) = sv[p];
-    }
-  };
-
   f32x16 o[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -190,7 +194,6 @@ __global__ __launch_bounds__(kWaves * 64) void attention_fwd_kernel(AttnArgs a) 
   const uint32_t i16 = lane & 15, g16 = lane >> 4;
   const uint32_t vt_lane_off = (4 * (g16 >> 1) + (i16 >> 2)) * kVPitch + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
 
-  stage_load(0);
   stage_store(0);
   __syncthreads();
 
