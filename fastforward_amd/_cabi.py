@@ -172,6 +172,9 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
         _i,
         [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _d, _i, _i64, _i64, _i64, _vp, _sz, _vp],
     ),
+    "ffq_quantize_by_tile_unless_same": (_i, [_vp, _i, _vp, _vp, _i64, _d, _vp, _vp, _vp, _vp]),
+    "ffq_linear_w8a8_takes_earlier": (_i, [_i64, _i64, _i64]),
+    "ffq_linear_w8a8_earlier": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i64, _i64, _vp, _sz, _vp]),
     "ffq_linear_w8a8_gated": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _vp, _vp]),
     "ffq_gptq_block": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _d, _vp]),
     "ffq_pack_gguf_blocks": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),

@@ -157,4 +157,28 @@ __device__ __forceinline__ void quantize_chunk_to_bytes(const float (&x)[E], flo
   finalize_chunk<int8_t, E>(r, lo, hi, y);
 }
 
+// ---- the same tensor, quantized again by a quantizer whose parameters may or may not be the earlier one's -----------------------
+// q_proj / k_proj / v_proj (gate_proj / up_proj) each quantize the same hidden state with their own input quantizer (reference
+// nn/linear.py:32-39). While range estimators rewrite the parameters on every step the host cannot know whether two of them are
+// equal without reading them back, so the question is put to the device: A1's codes are a function of the scale's bits and of the
+// ROUNDED offset (_quantizer_impl.py:140-141), hence two quantizers that agree in both produce the same bytes. The later one's A1
+// launch (ffq_quantize_by_tile_unless_same) returns before its first load when they agree, and whoever consumes its codes is given
+// the earlier quantizer's as well and asks the same question (`codes_in_force`). Whether or not the later launch has written, the
+// earlier codes ARE the later quantizer's codes whenever the answer is yes — a consumer may always take them then.
+struct EarlierCodes {
+  const int8_t* codes;  // nullptr: there is no earlier quantizer
+  const float* scale;   // one element each (per-tensor quantizers); offset nullable = 0
+  const float* offset;
+};
+
+__device__ __forceinline__ bool same_parameters(const float* scale, const float* offset, const float* scale2, const float* offset2) {
+  const float o = offset ? rne(offset[0]) : 0.0f, o2 = offset2 ? rne(offset2[0]) : 0.0f;
+  // (a NaN offset is "not the same": the later quantizer then runs as itself, whatever it makes of the NaN)
+  return __builtin_bit_cast(uint32_t, scale[0]) == __builtin_bit_cast(uint32_t, scale2[0]) && o == o2;
+}
+
+__device__ __forceinline__ const int8_t* codes_in_force(const int8_t* own, const float* scale, const float* offset, const EarlierCodes& e) {
+  return e.codes && same_parameters(scale, offset, e.scale, e.offset) ? e.codes : own;
+}
+
 }  // namespace ffq

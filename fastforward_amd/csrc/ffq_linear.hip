@@ -67,6 +67,9 @@ struct LinearArgs {
   ExtremaSink extrema;  // words == nullptr: not wanted. [min, max] of the gated product (ffq_extrema.h)
   // a launch of a device-side either / or (ffq_mlp_gate_up_w8a8_estimating): it runs iff *run_if == run_when (nullptr: always)
   const int32_t* run_if; int run_when;
+  // the activation codes of an EARLIER quantizer of the same tensor (ffq_affine.h): read instead of `xq` when this linear's input
+  // quantizer turns out to hold the same parameters (WOFF and GATED instantiations of the persistent kernel only: range estimation)
+  EarlierCodes earlier;
 };
 
 // The value the linear would have returned in dtype `y_dt` (one rounding), as fp32
@@ -711,6 +714,8 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   if constexpr (WOFF || GATED || PRODUCT) {  // (the instantiations a device-side either / or is built from; the forward's are not among them)
     if (a.run_if && *a.run_if != a.run_when) return;
   }
+  const int8_t* xq_in_force = a.xq;
+  if constexpr (WOFF || GATED) xq_in_force = codes_in_force(a.xq, a.x_scale, a.x_offset, a.earlier);
   if (my_tiles == 0) {
     if constexpr (GATED || PRODUCT) {
       if (a.extrema.words && tid == 0) extrema_publish(a.extrema, 0.0f, 0.0f, false, false, gridDim.x);
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
 
   const int d_row = lane >> 3;
   uint32_t a_voff[4], b_voff[4];   // lane offsets inside the tile's rows: < 256 K + 128
-  const int8_t* a_base = a.xq;     // wave-uniform: first row of the tile
+  const int8_t* a_base = xq_in_force;  // wave-uniform: first row of the tile
   const int8_t* b_base[4];         // per piece (MLP mode: gate or up matrix)
   int m0 = 0, n0 = 0;
   auto tile_origin = [&](int it, int& tm0, int& tn0) {
@@ -754,7 +759,7 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
     return base + (((uint64_t)hi << 32) | lo);
   };
   auto set_sources = [&](int tm0, int tn0) {
-    a_base = row_base(a.xq, tm0);
+    a_base = row_base(xq_in_force, tm0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int row = (wave * 4 + c) * 8 + d_row;
@@ -947,7 +952,8 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
 __global__ __launch_bounds__(256) void rowsum_i8_kernel(const int8_t* __restrict__ q, int rows, int K,
                                                         int32_t* __restrict__ sums, const int32_t* __restrict__ gate,
                                                         const float* __restrict__ offsets = nullptr, int n_offsets = 0,
-                                                        int32_t* __restrict__ flag = nullptr) {
+                                                        int32_t* __restrict__ flag = nullptr, EarlierCodes earlier = {nullptr, nullptr, nullptr},
+                                                        const float* __restrict__ q_scale = nullptr, const float* __restrict__ q_offset = nullptr) {
   if (offsets && blockIdx.x == 0) {
     int any = 0;
     for (int i = threadIdx.x; i < n_offsets; i += 256) any |= rne(offsets[i]) != 0.0f;
@@ -955,6 +961,7 @@ __global__ __launch_bounds__(256) void rowsum_i8_kernel(const int8_t* __restrict
     if (threadIdx.x == 0) flag[0] = any ? 1 : 0;
   }
   if (gate && *gate == 0) return;
+  if (earlier.codes) q = codes_in_force(q, q_scale, q_offset, earlier);  // (`q` are activation codes their quantizer may not have written)
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   int s = 0;
@@ -993,15 +1000,27 @@ extern "C" size_t ffq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t 
   return (size_t)(((M + N + 1) * 4 + 255) & ~(int64_t)255);
 }
 
+// the persistent kernel's shape class (the only one whose launches can read an earlier quantizer's codes)
+static bool linear_takes_earlier(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return false;
+  const int64_t tiles256 = ((M + BM2 - 1) / BM2) * ((N + 255) / 256);
+  return K % 128 == 0 && K >= 256 && M >= 128 && N >= 128 && tiles256 >= 64;
+}
+
+extern "C" int ffq_linear_w8a8_takes_earlier(int64_t M, int64_t N, int64_t K) { return linear_takes_earlier(M, N, K) ? 1 : 0; }
+
 static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
                             const float* x_offset, int x_per_row, const float* w_scale, const float* w_offset,
                             int w_per_row, const void* bias, int bias_dt, void* out, int out_dt,
                             const float* out_scale, const float* out_offset, double out_num_bits, int y_dt, int64_t M,
                             int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream, const void* gate,
-                            uint32_t* extrema_words = nullptr, void* extrema_pair = nullptr, const int32_t* run_if = nullptr, int run_when = 0) {
+                            uint32_t* extrema_words = nullptr, void* extrema_pair = nullptr, const int32_t* run_if = nullptr, int run_when = 0,
+                            EarlierCodes earlier = {nullptr, nullptr, nullptr}) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
+  if (earlier.codes && (!earlier.scale || x_per_row || !aligned16(earlier.codes) || !linear_takes_earlier(M, N, K)))
+    return fail(FFQ_ERR_DTYPE, "earlier codes: per-tensor activation parameters on the persistent kernel's shapes (ffq_linear_w8a8_takes_earlier)");
   if (!xq || !wq || !x_scale || !w_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
   if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return fail(FFQ_ERR_ARG, "extent exceeds 2^31");
   if (K % 16 != 0 || !aligned16(xq) || !aligned16(wq))
@@ -1018,7 +1037,7 @@ static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w
     return fail(FFQ_ERR_DTYPE, "real-valued output must be f32, bf16 or f16");
   }
   const size_t need = ffq_linear_w8a8_workspace_bytes(M, N, K);
-  if (((x_offset && !w_rowsum) || w_offset) && (need > workspace_bytes || !workspace))
+  if (((x_offset && !w_rowsum) || w_offset || earlier.codes) && (need > workspace_bytes || !workspace))
     return fail(FFQ_ERR_WORKSPACE, "w8a8 linear needs %zu workspace bytes, got %zu", need, workspace_bytes);
 
   LinearArgs a;
@@ -1040,6 +1059,7 @@ static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w
   a.group_cols = 0;
   a.gate = static_cast<const bf16_t*>(gate);
   a.run_if = run_if; a.run_when = run_when;
+  a.earlier = earlier;
   a.extrema.words = extrema_words; a.extrema.pair = extrema_pair; a.extrema.pair_dt = FFQ_BF16;
 
   int32_t* ws = static_cast<int32_t*>(workspace);
@@ -1064,7 +1084,7 @@ static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w
     if (persistent) {  // ... only where an offset is really non-zero: decided and consumed on the device
       int32_t* flag = ws + M + N;
       if (!flag_written) offsets_nonzero_kernel<<<1, 1024, 0, s>>>(w_offset, w_per_row ? (int)N : 1, flag);
-      rowsum_i8_kernel<<<(unsigned)((M + 3) / 4), 256, 0, s>>>(xq, (int)M, (int)K, ws, flag);
+      rowsum_i8_kernel<<<(unsigned)((M + 3) / 4), 256, 0, s>>>(xq, (int)M, (int)K, ws, flag, nullptr, 0, nullptr, earlier, x_scale, x_offset);
       a.woff_live = flag;
     } else {
       rowsum_i8_kernel<<<(unsigned)((M + 3) / 4), 256, 0, s>>>(xq, (int)M, (int)K, ws, nullptr);
@@ -1105,7 +1125,13 @@ static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w
     // a predicated launch without weight offsets takes the WOFF instantiation too (the forward's own instantiations carry no
     // predicate): its "some offset is live" word is run_if[1], which the either / or's deciding kernel keeps at zero
     if (run_if && !w_offset) a.woff_live = run_if + 1;
-#define FFQ_FQ(T, RQ) do { if (w_offset || run_if) FFQ_FQ_LAUNCH(T, RQ, true); else FFQ_FQ_LAUNCH(T, RQ, false); } while (0)
+    // ... and so does one that may read an earlier quantizer's codes: its word is the workspace's flag slot, zeroed here
+    if (earlier.codes && !w_offset && !run_if) {
+      hipError_t e = hipMemsetAsync(ws + M + N, 0, 4, s);
+      if (e != hipSuccess) return fail(FFQ_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+      a.woff_live = ws + M + N;
+    }
+#define FFQ_FQ(T, RQ) do { if (w_offset || run_if || earlier.codes) FFQ_FQ_LAUNCH(T, RQ, true); else FFQ_FQ_LAUNCH(T, RQ, false); } while (0)
     if (requant) {
       switch (out_dt) {
         case FFQ_I8: FFQ_FQ(int8_t, true); break;
@@ -1154,6 +1180,17 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t
                                int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
   return linear_w8a8_impl(xq, wq, w_rowsum, x_scale, x_offset, x_per_row, w_scale, w_offset, w_per_row, bias, bias_dt, out, out_dt, out_scale,
                           out_offset, out_num_bits, y_dt, M, N, K, workspace, workspace_bytes, stream, nullptr);
+}
+
+// ffq_linear_w8a8 whose activation codes may not have been written (ffq_quantize_by_tile_unless_same) — see include/ffq.h
+extern "C" int ffq_linear_w8a8_earlier(const int8_t* xq, const int8_t* earlier_xq, const float* earlier_scale, const float* earlier_offset,
+                                       const int8_t* wq, const int32_t* w_rowsum, const float* x_scale, const float* x_offset,
+                                       const float* w_scale, const float* w_offset, int w_per_row, void* out, int out_dt, int64_t M,
+                                       int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!earlier_xq || !earlier_scale) return fail(FFQ_ERR_ARG, "NULL earlier codes / scale");
+  return linear_w8a8_impl(xq, wq, w_rowsum, x_scale, x_offset, 0, w_scale, w_offset, w_per_row, nullptr, 0, out, out_dt, nullptr, nullptr, 8.0, 0,
+                          M, N, K, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr, nullptr, 0,
+                          EarlierCodes{earlier_xq, earlier_scale, earlier_offset});
 }
 
 // out = bf16(silu(gate)) * bf16(linear(x, w))  — see include/ffq.h
@@ -1402,5 +1439,6 @@ extern "C" int ffq_mlp_gate_up_w8a8_estimating(const int8_t* xq_gate, const int8
                         nullptr, nullptr, 8.0, 0, M, N, K, lin_ws, lin_bytes, stream, nullptr, nullptr, nullptr, flag, 0);
   if (rc) return rc;
   return linear_w8a8_impl(xq_up, up_wq, rs_up, x_scale_up, x_offset_up, 0, up_w_scale, up_w_offset, 1, nullptr, 0, product_out, FFQ_BF16, nullptr, nullptr,
-                          8.0, 0, M, N, K, lin_ws, lin_bytes, stream, gate_scratch, extrema_words, extrema_pair, flag, 0);
+                          8.0, 0, M, N, K, lin_ws, lin_bytes, stream, gate_scratch, extrema_words, extrema_pair, flag, 0,
+                          EarlierCodes{xq_gate, x_scale_gate, x_offset_gate});
 }

@@ -569,6 +569,29 @@ __global__ __launch_bounds__(kBlock) void quantize_rows_batch_kernel(BatchArgs a
   }
 }
 
+
+// A1 of a per-tensor quantizer into int8 UNLESS an earlier quantizer's parameters are the same (ffq_affine.h: EarlierCodes) — then the
+// launch returns before its first load and `out` keeps whatever it held. Otherwise quantize_stream_kernel's codes (its E = 16, one
+// chunk per lane form, the one the product launches for this shape class).
+template <typename TIn>
+__global__ __launch_bounds__(kBlock) void quantize_unless_same_kernel(const TIn* __restrict__ in, int8_t* __restrict__ out,
+                                                                      const float* __restrict__ scale, const float* __restrict__ offset,
+                                                                      const float* __restrict__ scale2, const float* __restrict__ offset2,
+                                                                      float lo, float hi, uint32_t nchunks) {
+  if (same_parameters(scale, offset, scale2, offset2)) return;
+  const uint32_t c = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  if (c >= nchunks) return;
+  Chunk<TIn, 16> x;
+  x.load(in + (size_t)c * 16);
+  const float s = scale[0], o = offset ? rne(offset[0]) : 0.0f;
+  float xf[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) xf[i] = x.get(i);
+  Chunk<int8_t, 16> y;
+  quantize_chunk_to_bytes<16>(xf, s, o, lo, hi, y);
+  y.store(out + (size_t)c * 16);
+}
+
 }  // namespace ffq
 
 extern "C" int ffq_quantize_by_tile(const void* data, int data_dt, const void* scale, int scale_dt,
@@ -577,6 +600,30 @@ extern "C" int ffq_quantize_by_tile(const void* data, int data_dt, const void* s
                                     void* out, int out_dt, void* stream) {
   return ffq::quantize_impl(data, data_dt, scale, scale_dt, scale_numel, offset, offset_dt, offset_numel,
                             tiling, num_bits, out, out_dt, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ffq_quantize_by_tile_unless_same(const void* data, int data_dt, const float* scale, const float* offset, int64_t numel,
+                                                double num_bits, const float* earlier_scale, const float* earlier_offset, int8_t* out,
+                                                void* stream) {
+  using namespace ffq;
+  if (numel < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (!ffq_can_support_bitwidth(FFQ_I8, num_bits))
+    return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.", FFQ_I8, num_bits);
+  if (numel == 0) return FFQ_OK;
+  if (!data || !scale || !earlier_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (num_bits != floor(num_bits) || num_bits < 1 || numel % 16 != 0 || numel / 16 >= ((int64_t)1 << 32) - 4096 || !aligned16(data) || !aligned16(out) ||
+      !(data_dt == FFQ_F32 || data_dt == FFQ_BF16 || data_dt == FFQ_F16))
+    return fail(FFQ_ERR_DTYPE, "quantize unless same: whole 16-element chunks of f32 / bf16 / f16 data, 16-byte aligned (else ffq_quantize_by_tile)");
+  const double lo = -pow(2.0, num_bits - 1.0), hi = -lo - 1.0;
+  const uint32_t nchunks = (uint32_t)(numel / 16);
+  const unsigned grid = grid_for(nchunks, kBlock);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (data_dt) {
+    case FFQ_F32: quantize_unless_same_kernel<float><<<grid, kBlock, 0, s>>>(static_cast<const float*>(data), out, scale, offset, earlier_scale, earlier_offset, (float)lo, (float)hi, nchunks); break;
+    case FFQ_BF16: quantize_unless_same_kernel<bf16_t><<<grid, kBlock, 0, s>>>(static_cast<const bf16_t*>(data), out, scale, offset, earlier_scale, earlier_offset, (float)lo, (float)hi, nchunks); break;
+    default: quantize_unless_same_kernel<f16_t><<<grid, kBlock, 0, s>>>(static_cast<const f16_t*>(data), out, scale, offset, earlier_scale, earlier_offset, (float)lo, (float)hi, nchunks); break;
+  }
+  return check_launch("quantize_unless_same_kernel");
 }
 
 extern "C" int ffq_quantize_rows_rowsum(const void* data, int data_dt, const float* scale, const float* offset, int64_t rows,

@@ -385,6 +385,11 @@ def _w8a8_gate_up_product(x: torch.Tensor, gate_proj: torch.nn.Module, up_proj: 
             return None, None, pre
         w_offset = None if wp.offset is None or fused_linear.known_zero_offset(wp.offset) else wp.offset
         params.append(((xp.scale, xp.offset), (wp.scale, w_offset)))
+    # up_proj's codes may be an undecided sibling's (``sibling_quantizers(undecided=True)``): the op reads gate_proj's codes wherever
+    # the two input quantizers agree, which is exactly where those were left unwritten — provided gate_proj's ARE the earlier ones
+    earlier = RECENT.earlier_of(pre[1][0])
+    if earlier is not None and not (earlier[0].data_ptr() == pre[0][0].raw_data.data_ptr() and earlier[1] is params[0][0][0] and earlier[2] is params[0][0][1]):
+        RECENT.settle(pre[1][0])
     out = ff.ops.mlp_gate_up_w8a8_estimating(pre[0][0].raw_data, pre[1][0].raw_data, pre[0][1].raw_data, pre[1][1].raw_data,
                                              params[0][0], params[1][0], params[0][1], params[1][1], want_extrema=want_extrema)
     if out is None:
@@ -1120,14 +1125,26 @@ class FusedProducersForward:
                 return F.linear(x, weight)
             return linear(x)
         xq, wq = pre if pre is not None else (linear.input_quantizer(x), linear.weight_quantizer(linear.weight))
+        # codes of a sibling quantizer that may not have been written (``sibling_quantizers(undecided=True)``): the GEMM takes the
+        # earlier sibling's codes along and reads whichever are in force; every other reader gets them settled first
+        earlier = RECENT.earlier_of(xq)
         if not (isinstance(xq, ff.QuantizedTensor) and isinstance(wq, ff.QuantizedTensor)) or xq.raw_data.dtype != torch.int8 or wq.raw_data.dtype != torch.int8:
+            if earlier is not None:
+                RECENT.settle(xq)
             return ff.nn.functional.linear(xq, wq, None, output_quantizer=linear.output_quantizer)  # e.g. disable_quantization=True
         xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
         if xp.scale.numel() != 1 or ff.fused_linear.KERNELS.row_mode(wq) is None:
+            if earlier is not None:
+                RECENT.settle(xq)
             return ff.nn.functional.linear(xq, wq, None, output_quantizer=linear.output_quantizer)
         # an all-zero offset buffer of a symmetric weight quantizer: known from an earlier call once its version is stable, else
         # recognised by the GEMM on the device (no host read while a range estimator rewrites the parameters on every step)
         w_offset = None if wp.offset is None or ff.fused_linear.known_zero_offset(wp.offset) else wp.offset
+        if earlier is not None:
+            out = ff.ops.linear_w8a8_earlier(xq.raw_data, earlier, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, out_dtype=torch.bfloat16)
+            if out is not None:
+                return out
+            RECENT.settle(xq)
         return ff.ops.linear_w8a8(xq.raw_data, wq.raw_data, xp.scale, xp.offset, wp.scale, w_offset, None, out_dtype=torch.bfloat16)
 
     def _gated(self, x: torch.Tensor, linear: torch.nn.Module, gate: torch.Tensor, pre: tuple | None = None) -> torch.Tensor | None:
@@ -1137,6 +1154,7 @@ class FusedProducersForward:
                 or gate.dtype != torch.bfloat16):
             return None
         xq, wq = pre if pre is not None else (linear.input_quantizer(x), linear.weight_quantizer(linear.weight))
+        RECENT.settle(xq)  # (a no-op unless the codes are an undecided sibling's: this route reads them as they are)
         usable = (isinstance(xq, ff.QuantizedTensor) and isinstance(wq, ff.QuantizedTensor) and xq.raw_data.dtype == torch.int8 and wq.raw_data.dtype == torch.int8)
         if usable:
             xp, wp = xq.quantization_context.quantization_params, wq.quantization_context.quantization_params
@@ -1170,7 +1188,7 @@ class FusedProducersForward:
                 outs = _weight_only_qkv(normed, projections, stored)
                 if outs is not None:
                     return outs[0], outs[1], outs[2]
-        with sibling_quantizers():
+        with sibling_quantizers(undecided=True):
             return self._linear(normed, attn.q_proj), self._linear(normed, attn.k_proj), self._linear(normed, attn.v_proj)
 
     def _gate_up(self, normed: torch.Tensor, mlp: torch.nn.Module) -> torch.Tensor:
@@ -1185,7 +1203,7 @@ class FusedProducersForward:
                 product = _weight_only_gate_up(normed, gate_proj, up_proj, stored)
                 if product is not None:
                     return product
-        with sibling_quantizers():
+        with sibling_quantizers(undecided=True):
             if all(l.bias is None and not l.weight_quantizer.is_stub() and l.output_quantizer.is_stub() and not l.input_quantizer.is_stub()
                    for l in (gate_proj, up_proj)):
                 # every quantizer first (each is its own estimator step during range estimation), then ONE op for what consumes their

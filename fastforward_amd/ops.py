@@ -843,6 +843,88 @@ def _linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, bias, o
     return out
 
 
+def quantize_by_tile_unless_same(
+    data: torch.Tensor, scale: torch.Tensor, offset: torch.Tensor | None, num_bits: float,
+    earlier_scale: torch.Tensor, earlier_offset: torch.Tensor | None,
+) -> torch.Tensor | None:
+    """A1 of a per-tensor quantizer into an int8 container that does NOTHING where an earlier quantizer of the same tensor holds the
+    same parameters — decided on the device from the scale's bits and the rounded offsets (C ABI
+    ``ffq_quantize_by_tile_unless_same``): the result is then UNWRITTEN memory, and whoever reads it must be told about the earlier
+    codes (:func:`linear_w8a8_earlier`, :func:`mlp_gate_up_w8a8_estimating`), which are this quantizer's codes in that case. Where
+    the parameters differ the codes are :func:`quantize_by_tile`'s. None (nothing launched) outside the launch's coverage: fp32
+    one-element parameters on the data's device, whole 16-element chunks of f32 / bf16 / f16 data."""
+    if _host_route(data) or data.dtype not in (torch.float32, torch.bfloat16, torch.float16) or data.numel() % 16 != 0 or data.numel() == 0:
+        return None
+    tensors = (scale, offset, earlier_scale, earlier_offset)
+    if any(t is not None and (t.dtype != torch.float32 or t.numel() != 1 or t.device != data.device) for t in tensors) or not (float(num_bits) == int(num_bits) and 1 <= num_bits <= 8):
+        return None
+    data_c = data.detach().contiguous()
+    lib, stream = _prepare(data_c, scale, offset, earlier_scale, earlier_offset)
+    out = torch.empty(data_c.shape, dtype=torch.int8, device=data_c.device)
+    status = lib.ffq_quantize_by_tile_unless_same(
+        _ptr(data_c), _tag(data_c.dtype), _ptr(scale.detach()), _ptr(None if offset is None else offset.detach()), data_c.numel(), float(num_bits),
+        _ptr(earlier_scale.detach()), _ptr(None if earlier_offset is None else earlier_offset.detach()), _ptr(out), stream,
+    )
+    if status == 6:  # FFQ_ERR_DTYPE: alignment
+        return None
+    lib.check(status)
+    return out
+
+
+def linear_w8a8_takes_earlier(M: int, N: int, K: int) -> bool:
+    """Whether :func:`linear_w8a8_earlier` covers an [M, K] x [N, K]^T linear (the persistent int8 GEMM's shape class)."""
+    return bool(_native.library().ffq_linear_w8a8_takes_earlier(int(M), int(N), int(K)))
+
+
+def linear_w8a8_earlier(
+    x_codes: torch.Tensor,
+    earlier: tuple[torch.Tensor, torch.Tensor, torch.Tensor | None],
+    w_codes: torch.Tensor,
+    x_scale: torch.Tensor,
+    x_offset: torch.Tensor | None,
+    w_scale: torch.Tensor,
+    w_offset: torch.Tensor | None,
+    out_dtype: torch.dtype = torch.bfloat16,
+    w_rowsum: torch.Tensor | None = None,
+) -> torch.Tensor | None:
+    """:func:`linear_w8a8` (per-tensor activation parameters, no bias, real-valued output) on activation codes that come from
+    :func:`quantize_by_tile_unless_same`: ``earlier = (codes, scale, offset)`` of the earlier quantizer of the same tensor; the
+    launch reads those codes where the two parameter pairs are the same (they are this linear's codes then) and `x_codes` where
+    they are not. None outside ``linear_w8a8_takes_earlier`` or for per-token parameters — then the caller has to settle which
+    codes are in force before anything reads `x_codes`."""
+    if x_codes.dtype != torch.int8 or w_codes.dtype != torch.int8 or earlier[0].dtype != torch.int8:
+        raise TypeError("linear_w8a8_earlier expects int8 codes")
+    xc, wc, ec = x_codes.detach().contiguous(), w_codes.detach().contiguous(), earlier[0].detach().contiguous()
+    K, N = xc.shape[-1], wc.shape[0]
+    M = xc.numel() // K if K else 0
+    if wc.dim() != 2 or wc.shape[1] != K:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({M}x{K} and {tuple(wc.shape)}^T)")
+    if ec.shape != xc.shape:
+        raise RuntimeError(f"earlier codes of shape {tuple(ec.shape)} for activation codes of shape {tuple(xc.shape)}")
+
+    def f32(t: torch.Tensor | None) -> torch.Tensor | None:
+        return None if t is None else t.detach().reshape(-1).to(torch.float32).contiguous()
+
+    xs, xo, ws_, wo, es, eo = f32(x_scale), f32(x_offset), f32(w_scale), f32(w_offset), f32(earlier[1]), f32(earlier[2])
+    if xs.numel() != 1 or es.numel() != 1 or ws_.numel() not in (1, N) or out_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        return None
+    if w_rowsum is not None and (w_rowsum.dtype != torch.int32 or w_rowsum.numel() != N or not w_rowsum.is_contiguous() or w_rowsum.device != wc.device):
+        raise RuntimeError(f"w_rowsum must be a contiguous int32 tensor with {N} entries on the codes' device")
+    lib, stream = _prepare(xc, ec, wc, xs, xo, ws_, wo, es, eo)
+    if not lib.ffq_linear_w8a8_takes_earlier(M, N, K):
+        return None
+    out = torch.empty((*xc.shape[:-1], N), dtype=out_dtype, device=xc.device)
+    nbytes = lib.ffq_linear_w8a8_workspace_bytes(M, N, K)
+    ws = _workspace(nbytes, xc.device)
+    lib.check(
+        lib.ffq_linear_w8a8_earlier(
+            _ptr(xc), _ptr(ec), _ptr(es), _ptr(eo), _ptr(wc), _ptr(w_rowsum), _ptr(xs), _ptr(xo), _ptr(ws_), _ptr(wo), int(ws_.numel() != 1),
+            _ptr(out), _tag(out_dtype), M, N, K, _ptr(ws), nbytes, stream,
+        )
+    )
+    return out
+
+
 def linear_w8a8_gated(
     x_codes: torch.Tensor,
     w_codes: torch.Tensor,

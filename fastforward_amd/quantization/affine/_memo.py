@@ -20,6 +20,16 @@ synchronisation:
     fall between a ``remember`` and its ``lookup``; everywhere else every quantizer call launches A1, as the reference does
     (nn/linear.py:32-39). Codes produced before a hipGraph capture began are never handed out during it (the graph would
     lack the A1 launch and replay stale codes) and the other way round; the slot is per thread.
+
+While range estimators rewrite the parameters on every step none of that applies — no pair of versions is ever seen twice — and
+the three (two) launches come back. ``sibling_quantizers(undecided=True)`` moves the question to the device for callers that
+consume the codes through entry points which can ask it again: a later per-tensor int8 quantizer of the same tensor launches
+``ops.quantize_by_tile_unless_same`` against the first sibling's parameters — nothing is read or written where they are the
+same — and the QuantizedTensor it returns is MARKED with the first sibling's codes and parameters (``earlier_of``; the mark
+lives on that object: a copy, view or re-wrap of it does not carry it). The opener of the block owns the consequences: every
+reader of such codes inside the block is either ``ops.linear_w8a8_earlier`` / ``ops.mlp_gate_up_w8a8_estimating`` (which read
+the codes in force) or is preceded by ``settle`` (which writes them, a ``torch.where`` on the device); marked tensors still
+alive when the outermost block ends are settled there.
 """
 
 from __future__ import annotations
@@ -44,15 +54,23 @@ class RecentActivationCodes(threading.local):
         self.hits = 0
         self._extrema: tuple[weakref.ref, tuple[Any, ...], torch.Tensor] | None = None  # (data, key, [min, max] of it)
         self.extrema_hits = 0
+        self._undecided = False
+        self._marked: list[weakref.ref] = []  # QuantizedTensors whose codes the device may have left unwritten
+        self.undecided_launches = 0
 
     @contextlib.contextmanager
-    def scope(self) -> Iterator[None]:
-        """Sibling quantizer calls on one activation: reuse is allowed inside, the slot is emptied on the way out."""
+    def scope(self, undecided: bool = False) -> Iterator[None]:
+        """Sibling quantizer calls on one activation: reuse is allowed inside, the slot is emptied on the way out. `undecided`:
+        the opener consumes the siblings' codes through entry points that take the earlier sibling's codes along (module
+        docstring) — quantizers whose parameters cannot be compared on the host leave the comparison to the device."""
         self._depth += 1
+        was = self._undecided
+        self._undecided = was or undecided
         try:
             yield
         finally:
             self._depth -= 1
+            self._undecided = was
             if self._depth == 0:
                 self.clear()
 
@@ -143,6 +161,56 @@ class RecentActivationCodes(threading.local):
         if self._depth > 0 and type(data) is torch.Tensor and data.is_cuda:
             self._extrema = (weakref.ref(data), self._data_key(data), pair)
 
+    # Parameters the host cannot compare (module docstring, last paragraph)
+    def earlier_for(self, data: torch.Tensor, params: Any, tile: Any, container: torch.dtype) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None] | None:
+        """(codes, scale, offset) of the first sibling that quantized `data` the same way — per tensor, as many bits, into int8 —
+        with parameters that have not moved since, for a quantizer whose own parameters `lookup` could not match."""
+        if not self._undecided or container != torch.int8 or not self._eligible(data, params) or torch.is_grad_enabled():
+            return None
+        if self._data is None or self._data() is not data or self._key != self._data_key(data):
+            return None
+
+        def one_f32(t: torch.Tensor | None) -> bool:
+            return t is None or (t.numel() == 1 and t.dtype == torch.float32 and t.device == data.device)
+
+        if params.scale.numel() != 1 or not one_f32(params.scale) or not one_f32(params.offset):
+            return None
+        for scale, scale_v, offset, offset_v, bits, etile, econtainer, raw in self._entries:
+            if bits != params.num_bits or econtainer != container or etile != tile or not one_f32(scale) or not one_f32(offset):
+                continue
+            if scale._version != scale_v or (offset is not None and offset._version != offset_v):
+                continue
+            return raw, scale, offset
+        return None
+
+    def mark_undecided(self, quantized: Any, earlier: tuple[torch.Tensor, torch.Tensor, torch.Tensor | None], scale: torch.Tensor, offset: torch.Tensor | None) -> None:
+        """`quantized.raw_data` came from ``quantize_by_tile_unless_same(…, scale, offset, earlier's parameters)``: unwritten where
+        they agree."""
+        quantized._ffq_earlier = (earlier, scale, offset)
+        self._marked.append(weakref.ref(quantized))
+        self.undecided_launches += 1
+
+    @staticmethod
+    def earlier_of(quantized: Any) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None] | None:
+        mark = getattr(quantized, "_ffq_earlier", None)
+        return None if mark is None else mark[0]
+
+    @staticmethod
+    def settle(quantized: Any) -> None:
+        """Make `quantized` hold its quantizer's codes whatever the device decided (for a reader that cannot take the earlier codes
+        along): the comparison of ``ffq_quantize_by_tile_unless_same`` once more, then a select — a pass over the codes, no host read."""
+        mark = getattr(quantized, "_ffq_earlier", None)
+        if mark is None:
+            return
+        del quantized._ffq_earlier
+        (codes, e_scale, e_offset), scale, offset = mark
+        raw = quantized.raw_data
+        zero = torch.zeros((), dtype=torch.float32, device=raw.device)
+        o = zero if offset is None else torch.round(offset.detach().reshape(()))
+        eo = zero if e_offset is None else torch.round(e_offset.detach().reshape(()))
+        same = (scale.detach().reshape(()).view(torch.int32) == e_scale.detach().reshape(()).view(torch.int32)) & (o == eo)
+        raw.copy_(torch.where(same, codes, raw))
+
     @property
     def inside_scope(self) -> bool:
         return self._depth > 0
@@ -150,6 +218,11 @@ class RecentActivationCodes(threading.local):
     def clear(self) -> None:
         self._data, self._key, self._entries = None, (), []
         self._extrema = None
+        marked, self._marked = self._marked, []
+        for ref in marked:  # codes that outlive the block are ordinary codes from here on
+            quantized = ref()
+            if quantized is not None:
+                self.settle(quantized)
 
 
 RECENT = RecentActivationCodes()

@@ -104,6 +104,19 @@ class AffineQuantizationFunction(QuantizationFunction[Any]):
         # the same activation quantized again by a quantizer with equal parameters (q / k / v, gate / up): the earlier codes
         raw = RECENT.lookup(data, params, tile, container)
         if raw is None:
+            # ... or parameters an estimator has just rewritten, which only the device can compare with an earlier sibling's
+            # (inside ``sibling_quantizers(undecided=True)``): A1 that runs unless they are the same, the result marked as such
+            earlier = RECENT.earlier_for(data, params, tile, container)
+            if earlier is not None:
+                from fastforward_amd import ops
+
+                raw = ops.quantize_by_tile_unless_same(data, params.scale, params.offset, params.num_bits, earlier[1], earlier[2])
+                if raw is not None:
+                    stamped = params.with_changes(dequantize_dtype=params.dequantize_dtype or data.dtype)
+                    quantized = QuantizedTensor(raw, QuantizationContext(cls, stamped))
+                    RECENT.mark_undecided(quantized, earlier, params.scale, params.offset)
+                    return quantized
+        if raw is None:
             raw = quantize_affine(data, params.scale, params.offset, tile, params.num_bits, container)
             RECENT.remember(data, params, tile, container, raw)
         # the dequantize dtype is stamped at quantize time                      (reference :137)

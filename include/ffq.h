@@ -490,6 +490,31 @@ int ffq_mlp_gate_up_w8a8_estimating(const int8_t* xq_gate, const int8_t* xq_up, 
                                     uint32_t* extrema_words, void* extrema_pair, void* stream);
 
 /*
+ * Sibling quantizers while their ranges are being estimated (ABI version 8). q_proj / k_proj / v_proj (gate_proj / up_proj) each
+ * quantize the SAME hidden state with their own input quantizer (nn/linear.py:32-39; after every estimator step the parameters
+ * are new, range_setting/common.py:218-238), and A1's codes are a function of the scale's bits and the ROUNDED offset
+ * (_quantizer_impl.py:140-141). Whether a later quantizer's pair equals an earlier one's is decided on the device:
+ *   ffq_quantize_by_tile_unless_same   A1 of a per-tensor quantizer (`scale`, nullable `offset`: one fp32 each) into an int8
+ *       container — unless (bits of scale == bits of earlier_scale) and (round_half_even(offset) == round_half_even(earlier_offset)):
+ *       then nothing is read and `out` keeps what it held. Written codes are ffq_quantize_by_tile's. Whole 16-element chunks of
+ *       f32 / bf16 / f16 data, 16-byte aligned; else FFQ_ERR_DTYPE before anything is touched.
+ *   ffq_linear_w8a8_earlier            ffq_linear_w8a8 (per-tensor activation parameters, no bias, real-valued output) whose
+ *       activation codes come from such a launch: it reads `earlier_xq` where the same comparison holds (they ARE this linear's
+ *       codes then, written or not) and `xq` where it does not — row sums of the activation codes included. Shapes of
+ *       ffq_linear_w8a8_takes_earlier(M, N, K) == 1 only (else FFQ_ERR_DTYPE); workspace of ffq_linear_w8a8_workspace_bytes always.
+ * ffq_mlp_gate_up_w8a8_estimating treats `xq_up` the same way with gate_proj's codes and parameters as the earlier ones.
+ * Same values as every quantizer quantizing and every linear reading its own codes; no host read.
+ */
+int ffq_quantize_by_tile_unless_same(const void* data, int data_dt, const float* scale, const float* offset, int64_t numel,
+                                     double num_bits, const float* earlier_scale, const float* earlier_offset, int8_t* out,
+                                     void* stream);
+int ffq_linear_w8a8_takes_earlier(int64_t M, int64_t N, int64_t K);
+int ffq_linear_w8a8_earlier(const int8_t* xq, const int8_t* earlier_xq, const float* earlier_scale, const float* earlier_offset,
+                            const int8_t* wq, const int32_t* w_rowsum, const float* x_scale, const float* x_offset,
+                            const float* w_scale, const float* w_offset, int w_per_row, void* out, int out_dt, int64_t M,
+                            int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * GGUF block-32 records — pack_q4_0_blocks / pack_q8_0_blocks, export/stages/gguf/_packing.py:23-72: `codes` is
  * [nblocks, 32] int8 in FastForward's signed convention, `scales` [nblocks] fp32 (positive). format 4 -> Q4_0:
  * 18 bytes per block = fp16(scale) then byte[j] = (code[j] + 8) | (code[j + 16] + 8) << 4 (nibbles clamped to

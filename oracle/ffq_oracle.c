@@ -1093,6 +1093,48 @@ int ffq_mlp_gate_up_w8a8(const int8_t* xq, const int8_t* gate_wq, const int8_t* 
   return rc;
 }
 
+/* Sibling quantizers while estimating (include/ffq.h): A1's codes depend on the scale's bits and the rounded offset
+ * (_quantizer_impl.py:140-141, :158-163), so a later quantizer with the same pair has the earlier one's codes. */
+static int same_parameters(const float* scale, const float* offset, const float* scale2, const float* offset2) {
+  const float o = offset ? nearbyintf(offset[0]) : 0.0f, o2 = offset2 ? nearbyintf(offset2[0]) : 0.0f;
+  return memcmp(scale, scale2, 4) == 0 && o == o2;
+}
+
+int ffq_quantize_by_tile_unless_same(const void* data, int data_dt, const float* scale, const float* offset, int64_t numel,
+                                     double num_bits, const float* earlier_scale, const float* earlier_offset, int8_t* out,
+                                     void* stream) {
+  if (numel < 0) return fail(FFQ_ERR_ARG, "negative extent");
+  if (!ffq_can_support_bitwidth(FFQ_I8, num_bits))
+    return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.", FFQ_I8, num_bits);
+  if (numel == 0) return FFQ_OK;
+  if (!data || !scale || !earlier_scale || !out) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (num_bits != floor(num_bits) || num_bits < 1 || numel % 16 != 0 || !(data_dt == FFQ_F32 || data_dt == FFQ_BF16 || data_dt == FFQ_F16))
+    return fail(FFQ_ERR_DTYPE, "quantize unless same: whole 16-element chunks of f32 / bf16 / f16 data (else ffq_quantize_by_tile)");
+  if (same_parameters(scale, offset, earlier_scale, earlier_offset)) return FFQ_OK;
+  ffq_tiling t;
+  memset(&t, 0, sizeof t);
+  t.ndim = 1; t.shape[0] = numel; t.tile[0] = numel;
+  return ffq_quantize_by_tile(data, data_dt, scale, FFQ_F32, 1, offset, FFQ_F32, offset ? 1 : 0, &t, num_bits, out, FFQ_I8, stream);
+}
+
+int ffq_linear_w8a8_takes_earlier(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return K % 128 == 0 && K >= 256 && M >= 128 && N >= 128 && ((M + 255) / 256) * ((N + 255) / 256) >= 64;
+}
+
+int ffq_linear_w8a8_earlier(const int8_t* xq, const int8_t* earlier_xq, const float* earlier_scale, const float* earlier_offset,
+                            const int8_t* wq, const int32_t* w_rowsum, const float* x_scale, const float* x_offset,
+                            const float* w_scale, const float* w_offset, int w_per_row, void* out, int out_dt, int64_t M,
+                            int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!earlier_xq || !earlier_scale) return fail(FFQ_ERR_ARG, "NULL earlier codes / scale");
+  if (M == 0 || N == 0) return FFQ_OK;
+  if (!x_scale) return fail(FFQ_ERR_ARG, "NULL buffer");
+  if (!ffq_linear_w8a8_takes_earlier(M, N, K)) return fail(FFQ_ERR_DTYPE, "earlier codes: the persistent kernel's shapes (ffq_linear_w8a8_takes_earlier)");
+  const int8_t* x = same_parameters(x_scale, x_offset, earlier_scale, earlier_offset) ? earlier_xq : xq;
+  return ffq_linear_w8a8(x, wq, w_rowsum, x_scale, x_offset, 0, w_scale, w_offset, w_per_row, NULL, 0, out, out_dt, NULL, NULL, 8.0, out_dt, M, N, K,
+                         workspace, workspace_bytes, stream);
+}
+
 /* mlp.py:30-40 up to the product, each linear on its own input quantizer's codes (nn/linear.py:33): two A6 linears (bf16), SiLU(gate) * up */
 size_t ffq_mlp_gate_up_w8a8_estimating_workspace_bytes(int64_t M, int64_t N, int64_t K) { return ffq_linear_w8a8_workspace_bytes(M, N, K); }
 
@@ -1109,6 +1151,8 @@ int ffq_mlp_gate_up_w8a8_estimating(const int8_t* xq_gate, const int8_t* xq_up, 
   int rc = ffq_linear_w8a8(xq_gate, gate_wq, NULL, x_scale_gate, x_offset_gate, 0, gate_w_scale, gate_w_offset, 1, NULL, 0, gate_scratch, FFQ_BF16, NULL,
                            NULL, 8.0, FFQ_BF16, M, N, K, workspace, workspace_bytes, stream);
   if (rc) return rc;
+  /* up_proj's codes may have been left unwritten where its quantizer holds gate_proj's parameters (ffq_quantize_by_tile_unless_same) */
+  if (x_scale_up && x_scale_gate && same_parameters(x_scale_up, x_offset_up, x_scale_gate, x_offset_gate)) xq_up = xq_gate;
   return ffq_linear_w8a8_gated(xq_up, up_wq, NULL, x_scale_up, x_offset_up, 0, up_w_scale, up_w_offset, 1, gate_scratch, product_out, M, N, K, workspace,
                                workspace_bytes, extrema_words, extrema_pair, stream);
 }

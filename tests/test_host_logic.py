@@ -644,3 +644,32 @@ def test_freeze_parameters_can_keep_the_quantizers_and_skips_disabled_ones():
         model(torch.randn(2, 16))
     assert all(torch.equal(layer.weight.detach(), b) for layer, b in zip(model, before))
     assert [layer.weight_quantizer for layer in model] == kept
+
+
+def test_sibling_codes_the_device_decides_restated_on_the_host(oracle_backend):
+    """ops.quantize_by_tile_unless_same / ops.linear_w8a8_earlier through the oracle's restatement (include/ffq.h: sibling quantizers
+    while estimating): A1 runs unless scale bits and rounded offsets are the earlier quantizer's, and the linear reads the earlier
+    codes exactly then. The GPU twins of these cases are tests/test_siblings_gpu.py."""
+    from fastforward_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    m, n, k = 2048, 2048, 256
+    x = (torch.randn(m, k, generator=g) * 2).to(torch.bfloat16)
+    wq = torch.randint(-128, 128, (n, k), dtype=torch.int8, generator=g)
+    sw = torch.rand(n, generator=g) * 1e-3 + 1e-4
+    e_scale, e_offset = torch.tensor([0.031]), torch.tensor([2.9])
+    first = ops.quantize_by_tile(x, e_scale, x.shape, 8, torch.int8, e_offset)
+    for scale, offset, same in ((0.031, 3.2, True), (0.031, 2.4, False), (0.04, 2.9, False)):
+        scale, offset = torch.tensor([scale]), torch.tensor([offset])
+        own = ops.quantize_by_tile(x, scale, x.shape, 8, torch.int8, offset)
+        maybe = ops.quantize_by_tile_unless_same(x, scale, offset, 8, e_scale, e_offset)
+        if same:
+            assert torch.equal(own, first)
+            maybe.fill_(77)  # (unwritten)
+        else:
+            assert torch.equal(maybe, own)
+        want = ops.linear_w8a8(own, wq, scale, offset, sw, None, None, out_dtype=torch.bfloat16)
+        got = ops.linear_w8a8_earlier(maybe, (first, e_scale, e_offset), wq, scale, offset, sw, None, out_dtype=torch.bfloat16)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert ops.linear_w8a8_earlier(maybe[:64], (first[:64], e_scale, e_offset), wq, scale, offset, sw, None) is None
+    assert ops.quantize_by_tile_unless_same(x.reshape(-1)[:40], scale, offset, 8, e_scale, e_offset) is None

@@ -521,35 +521,48 @@ def test_gptq_invalidates_cached_weight_codes(oracle_backend):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [True, False], ids=["fused_forward", "module_graph"])
-def test_producers_leaving_extrema_change_no_range(hip_backend, monkeypatch, fused):
+@pytest.mark.parametrize("fused,unequal", [(True, False), (False, False), (True, True)], ids=["fused_forward", "module_graph", "fused_forward_unequal_siblings"])
+def test_producers_leaving_extrema_change_no_range(hip_backend, monkeypatch, fused, unequal):
     """During range estimation gate + up + SiLU * up run as one op (one launch where the two input estimators agree, decided on the
     device; else the gated int8 GEMM epilogue) that leaves [min, max] of the product, and down_proj's input
     estimator starts from those two numbers — in the fused forward and in the module graph (QuantizedLlamaMLP.forward); weights take the one-pass
-    estimator-step-and-quantize kernel. With every one of those shortcuts switched off — estimators reduce over the tensors,
-    the SiLU * up pass runs, weights take the two steps — the calibrated parameters are the same bits."""
+    estimator-step-and-quantize kernel; in the fused forward the k / v / up input quantizers leave it to the device whether their A1
+    runs at all (it does not where their parameters are q's / gate's: ``sibling_quantizers(undecided=True)``). With every one of those
+    shortcuts switched off — estimators reduce over the tensors, the SiLU * up pass runs, weights take the two steps, every quantizer
+    quantizes — the calibrated parameters are the same bits. `unequal`: some siblings start from ranges of their own, so their
+    parameters never agree with the first sibling's and their own codes are the ones in force."""
     from fastforward_amd import distributed as ffd
     from fastforward_amd.quantization.affine._memo import RECENT
 
-    cfg = llama.LlamaConfig(hidden_size=2048, intermediate_size=4096, num_layers=2, num_heads=16, num_kv_heads=4, vocab_size=512)
+    # (as many k / v heads as q heads: the k and v projections are inside ops.linear_w8a8_takes_earlier at these 2048 token rows; the
+    # tiny fixture of test_fused_calibration_matches_module_graph_on_gpu is outside, its undecided codes get settled)
+    cfg = llama.LlamaConfig(hidden_size=2048, intermediate_size=4096, num_layers=2, num_heads=16, num_kv_heads=16, vocab_size=512)
+    assert ff.ops.linear_w8a8_takes_earlier(4 * 512, cfg.num_kv_heads * cfg.head_dim, cfg.hidden_size)
 
     def calibrated(shortcuts):
         torch.manual_seed(5)
         model = llama.build_model(cfg, "cuda", torch.bfloat16, seed=9)
         llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
+        if unequal:  # (an estimator starts from the range its quantizer already has)
+            model.layers[0].self_attn.k_proj.input_quantizer.quantization_range = (-40.0, 55.0)
+            model.layers[1].self_attn.q_proj.input_quantizer.quantization_range = (-3.0, 61.0)
+            model.layers[1].mlp.up_proj.input_quantizer.quantization_range = (-70.0, 9.0)
         batches = [torch.randint(0, cfg.vocab_size, (4, 512), device="cuda") for _ in range(3)]
-        hits = RECENT.extrema_hits
+        hits, launches = RECENT.extrema_hits, RECENT.undecided_launches
         with monkeypatch.context() as patch:
             if not shortcuts:
                 patch.setattr(RECENT, "remember_extrema", lambda data, pair: None)
+                patch.setattr(RECENT, "earlier_for", lambda *a, **k: None)
                 patch.setattr(ff.ops, "linear_w8a8_gated", lambda *a, **k: None)
                 patch.setattr(ff.ops, "mlp_gate_up_w8a8_estimating", lambda *a, **k: None)
                 patch.setattr(ff.nn.LinearQuantizer, "update_range_and_quantize", lambda self, *a, **k: None)
             ffd.calibrate_sharded(model, batches, disable_quantization=False, fused=fused)
-        return ffd.ranges_fingerprint(model), RECENT.extrema_hits - hits
+        return ffd.ranges_fingerprint(model), RECENT.extrema_hits - hits, RECENT.undecided_launches - launches
 
-    want, hits_without = calibrated(False)
-    got, hits_with = calibrated(True)
+    want, hits_without, launches_without = calibrated(False)
+    got, hits_with, launches_with = calibrated(True)
     # per layer and step: down_proj's estimator takes the product's pair (q/k/v and gate/up share one reduction either way)
     assert hits_with >= hits_without + 3 * cfg.num_layers
+    # ... and k, v and up put the question whether to quantize at all to the device (fused forward only)
+    assert launches_without == 0 and launches_with == (3 * cfg.num_layers * 3 if fused else 0)
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))

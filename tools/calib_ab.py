@@ -31,6 +31,8 @@ def patched(*names):
     if "no_gated" in names:
         swap(ff.ops, "mlp_gate_up_w8a8_estimating", lambda *a, **k: None)
         swap(ff.ops, "linear_w8a8_gated", lambda *a, **k: None)
+    if "no_undecided_siblings" in names:
+        swap(RECENT, "earlier_for", lambda *a, **k: None)  # k / v / up quantize unconditionally
     if "no_product_extrema" in names:
         swap(RECENT, "remember_extrema", lambda data, pair: None)  # (also un-shares the siblings' reduction)
     try:
@@ -59,7 +61,7 @@ def run(*names):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-arms = [(), ("no_either_or",), ("no_weight_one_pass",), ("no_gated",), ("no_product_extrema",), ("no_weight_one_pass", "no_gated")]
+arms = [(), ("no_undecided_siblings",), ("no_either_or",), ("no_weight_one_pass",), ("no_gated",), ("no_product_extrema",), ("no_weight_one_pass", "no_gated")]
 best = {a: 1e9 for a in arms}
 for rnd in range(3):
     for a in arms:
