@@ -4,6 +4,7 @@
   A3 with the symmetric one-sided fallback (guess / settle)                                              vs  the composed form
   estimator step + quantize in one pass                                                                  vs  the two calls
   gate/up while estimating (either / or) and the gated epilogue                                          vs  two linears + SiLU * up
+  sibling quantizers the device compares (A1 unless same, the linear on the codes in force, gate/up too)  vs  every quantizer for itself
 usage: python tools/fuzz_r05.py [seconds=120] [seed=0]"""
 import pathlib, random, sys, time
 import torch
@@ -149,7 +150,58 @@ def either_or():
             assert torch.equal(gated[1].view(torch.int16), torch.cat([lo, hi]).view(torch.int16)), ("gated extrema", m, n, k)
 
 
-cases = [skinny, skinny, a3_symmetric, running, either_or]
+def siblings():
+    m = 256 * rng.randint(2, 12) - rng.choice([0, 0, 56, 129])
+    n = 128 * rng.randint(4, 20)
+    k = 128 * rng.randint(2, 8)
+    g = torch.Generator(device=DEV).manual_seed(rng.randint(0, 1 << 30))
+    dtype = rng.choice([torch.bfloat16, torch.float16, torch.float32])
+    x = (torch.randn(m, k, device=DEV, generator=g) * 2).to(dtype)
+    t = lambda v: None if v is None else torch.tensor([v], device=DEV, dtype=torch.float32)  # noqa: E731
+    es, eo = rng.choice([0.03, 0.011]), rng.choice([None, 0.0, -2.6, 3.5, 0.3])
+    kind = rng.choice(["same", "same", "rounds_alike", "scale", "offset"])
+    s, o = es, eo
+    if kind == "rounds_alike":
+        o = (0.0 if eo is None else round(eo)) + rng.choice([-0.4, 0.2, 0.45])
+    if kind == "scale":
+        s = es * 1.25
+    if kind == "offset":
+        o = (0.0 if eo is None else eo) + rng.choice([1.0, -2.0, 7.0])
+    scale, offset, e_scale, e_offset = t(s), t(o), t(es), t(eo)
+    first = ops.quantize_by_tile(x, e_scale, x.shape, 8, torch.int8, e_offset)
+    own = ops.quantize_by_tile(x, scale, x.shape, 8, torch.int8, offset)
+    maybe = torch.full(x.shape, 77, dtype=torch.int8, device=DEV)
+    import ctypes
+    p = lambda u: ctypes.c_void_p(None if u is None else u.data_ptr())  # noqa: E731
+    lib.check(lib.ffq_quantize_by_tile_unless_same(p(x), ops._tag(x.dtype), p(scale), p(offset), x.numel(), 8.0, p(e_scale), p(e_offset), p(maybe),
+                                                   torch.cuda.current_stream().cuda_stream))
+    same_params = s == es and round(0.0 if o is None else o) == round(0.0 if eo is None else eo)  # (Python rounds half to even too)
+    assert bool((maybe == 77).all()) if same_params else torch.equal(maybe, own), ("unless same", kind, m, k, dtype, s, o, es, eo)
+    if same_params:
+        assert torch.equal(own, first), ("same parameters, other codes", kind, s, o, es, eo)
+    if dtype != torch.bfloat16:
+        return
+    wq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    sw = torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+    ow = rng.choice([None, torch.zeros(n, device=DEV), torch.round(torch.randn(n, device=DEV, generator=g))])
+    got = ops.linear_w8a8_earlier(maybe, (first, e_scale, e_offset), wq, scale, offset, sw, ow, out_dtype=torch.bfloat16)
+    if got is None:
+        assert not ops.linear_w8a8_takes_earlier(m, n, k)
+        return
+    want = ops.linear_w8a8(own, wq, scale, offset, sw, ow, None, out_dtype=torch.bfloat16)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), ("earlier", kind, m, n, k)
+    wg = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    swg = torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4
+    owg = None if ow is None else torch.zeros(n, device=DEV)
+    e_off = e_offset if e_offset is not None else torch.zeros(1, device=DEV)
+    gate = ops.linear_w8a8(first, wg, e_scale, e_off, swg, owg, None, out_dtype=torch.bfloat16)
+    product = ops.silu_mul_quantize(gate, want, (), want_product=True)[0]
+    out = ops.mlp_gate_up_w8a8_estimating(first, maybe, wg, wq, (e_scale, e_off), (scale, offset if offset is not None else torch.zeros(1, device=DEV)), (swg, owg), (sw, ow))
+    if out is not None:
+        assert torch.equal(out.view(torch.int16), product.view(torch.int16)), ("either/or on undecided codes", kind, m, n, k)
+
+
+cases = [skinny, skinny, a3_symmetric, running, either_or, siblings]
 t0 = time.time()
 while time.time() - t0 < budget:
     fn = rng.choice(cases)
