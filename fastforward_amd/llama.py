@@ -1188,7 +1188,8 @@ class FusedProducersForward:
                 outs = _weight_only_qkv(normed, projections, stored)
                 if outs is not None:
                     return outs[0], outs[1], outs[2]
-        with sibling_quantizers(undecided=True):
+        # (a forward hook on an input quantizer would be handed codes the device may have left unwritten: then every quantizer quantizes)
+        with sibling_quantizers(undecided=not _hooked(*(p.input_quantizer for p in projections))):
             return self._linear(normed, attn.q_proj), self._linear(normed, attn.k_proj), self._linear(normed, attn.v_proj)
 
     def _gate_up(self, normed: torch.Tensor, mlp: torch.nn.Module) -> torch.Tensor:
@@ -1203,7 +1204,7 @@ class FusedProducersForward:
                 product = _weight_only_gate_up(normed, gate_proj, up_proj, stored)
                 if product is not None:
                     return product
-        with sibling_quantizers(undecided=True):
+        with sibling_quantizers(undecided=not _hooked(gate_proj.input_quantizer, up_proj.input_quantizer)):
             if all(l.bias is None and not l.weight_quantizer.is_stub() and l.output_quantizer.is_stub() and not l.input_quantizer.is_stub()
                    for l in (gate_proj, up_proj)):
                 # every quantizer first (each is its own estimator step during range estimation), then ONE op for what consumes their

@@ -566,3 +566,33 @@ def test_producers_leaving_extrema_change_no_range(hip_backend, monkeypatch, fus
     # ... and k, v and up put the question whether to quantize at all to the device (fused forward only)
     assert launches_without == 0 and launches_with == (3 * cfg.num_layers * 3 if fused else 0)
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+@pytest.mark.gpu
+def test_a_hook_on_a_sibling_quantizer_sees_written_codes(hip_backend):
+    """``sibling_quantizers(undecided=True)`` hands later siblings' A1 launches to the device — their codes may stay unwritten and
+    only the GEMM entry points know. A forward hook on one of those quantizers is a reader this package does not own: with any
+    hook on a sibling's input quantizer every quantizer of the group quantizes as usual, and the hook sees the codes."""
+    from fastforward_amd import distributed as ffd
+    from fastforward_amd.quantization.affine._memo import RECENT
+
+    cfg = llama.LlamaConfig(hidden_size=2048, intermediate_size=4096, num_layers=1, num_heads=16, num_kv_heads=16, vocab_size=512)
+    model = llama.build_model(cfg, "cuda", torch.bfloat16, seed=4)
+    llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
+    k_quantizer = model.layers[0].self_attn.k_proj.input_quantizer
+    seen = []
+
+    def hook(module, args, output):
+        data = args[0]
+        want = ff.ops.quantize_by_tile(data, module.scale, data.shape, 8, torch.int8, module.offset)
+        seen.append(bool(torch.equal(output.raw_data, want)))
+
+    handle = k_quantizer.register_forward_hook(hook)
+    launches = RECENT.undecided_launches
+    batches = [torch.randint(0, cfg.vocab_size, (4, 512), device="cuda") for _ in range(2)]
+    ffd.calibrate_sharded(model, batches, disable_quantization=False, fused=True)
+    handle.remove()
+    assert seen == [True, True]
+    assert RECENT.undecided_launches - launches == 2 * 1  # up_proj's only: the q / k / v group ran as itself
+    ffd.calibrate_sharded(model, batches, disable_quantization=False, fused=True)
+    assert RECENT.undecided_launches - launches == 2 * 1 + 2 * 3
