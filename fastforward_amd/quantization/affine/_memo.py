@@ -186,24 +186,39 @@ class RecentActivationCodes(threading.local):
     def mark_undecided(self, quantized: Any, earlier: tuple[torch.Tensor, torch.Tensor, torch.Tensor | None], scale: torch.Tensor, offset: torch.Tensor | None) -> None:
         """`quantized.raw_data` came from ``quantize_by_tile_unless_same(…, scale, offset, earlier's parameters)``: unwritten where
         they agree."""
-        quantized._ffq_earlier = (earlier, scale, offset)
+        quantized._ffq_earlier = (earlier, scale, offset, self._versions(earlier[1], earlier[2], scale, offset))
         self._marked.append(weakref.ref(quantized))
         self.undecided_launches += 1
 
     @staticmethod
-    def earlier_of(quantized: Any) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None] | None:
-        mark = getattr(quantized, "_ffq_earlier", None)
-        return None if mark is None else mark[0]
+    def _versions(*tensors: torch.Tensor | None) -> tuple[int, ...]:
+        return tuple(-1 if t is None else t._version for t in tensors)
 
-    @staticmethod
-    def settle(quantized: Any) -> None:
+    @classmethod
+    def _checked(cls, mark: tuple[Any, ...]) -> None:
+        """The launch compared the four parameter tensors as they were; whoever repeats the comparison must find them unchanged."""
+        earlier, scale, offset, versions = mark
+        if cls._versions(earlier[1], earlier[2], scale, offset) != versions:
+            raise RuntimeError("quantization parameters were rewritten between a sibling quantizer's device-decided launch and the reader of its codes")
+
+    @classmethod
+    def earlier_of(cls, quantized: Any) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None] | None:
+        mark = getattr(quantized, "_ffq_earlier", None)
+        if mark is None:
+            return None
+        cls._checked(mark)
+        return mark[0]
+
+    @classmethod
+    def settle(cls, quantized: Any) -> None:
         """Make `quantized` hold its quantizer's codes whatever the device decided (for a reader that cannot take the earlier codes
         along): the comparison of ``ffq_quantize_by_tile_unless_same`` once more, then a select — a pass over the codes, no host read."""
         mark = getattr(quantized, "_ffq_earlier", None)
         if mark is None:
             return
         del quantized._ffq_earlier
-        (codes, e_scale, e_offset), scale, offset = mark
+        cls._checked(mark)
+        (codes, e_scale, e_offset), scale, offset, _ = mark
         raw = quantized.raw_data
         zero = torch.zeros((), dtype=torch.float32, device=raw.device)
         o = zero if offset is None else torch.round(offset.detach().reshape(()))

@@ -673,3 +673,34 @@ def test_sibling_codes_the_device_decides_restated_on_the_host(oracle_backend):
         assert torch.equal(got.view(torch.int16), want.view(torch.int16))
     assert ops.linear_w8a8_earlier(maybe[:64], (first[:64], e_scale, e_offset), wq, scale, offset, sw, None) is None
     assert ops.quantize_by_tile_unless_same(x.reshape(-1)[:40], scale, offset, 8, e_scale, e_offset) is None
+
+
+def test_marks_of_device_decided_siblings_are_settled_or_refused():
+    """_memo.RECENT's marks (``sibling_quantizers(undecided=True)``): ``settle`` selects the codes in force with the comparison the
+    launch made (scale bits, rounded offsets); a mark still alive when the outermost block ends is settled there; and a reader that
+    finds one of the four parameter tensors rewritten since the launch is refused — the comparison could no longer be repeated."""
+    from fastforward_amd.quantization.affine._memo import RECENT
+
+    class Holder:  # (what the memo needs of a QuantizedTensor)
+        def __init__(self, raw):
+            self.raw_data = raw
+
+    first = torch.ones(32, dtype=torch.int8)
+    e_scale, e_offset = torch.tensor([0.5]), torch.tensor([0.8])
+    for scale, offset, same in ((0.5, 1.2, True), (0.5, None, False), (0.25, 0.8, False), (0.5, 1.5, False)):
+        scale, offset = torch.tensor([scale]), None if offset is None else torch.tensor([offset])
+        own = Holder(torch.full((32,), 7, dtype=torch.int8))
+        with RECENT.scope(undecided=True):
+            RECENT.mark_undecided(own, (first, e_scale, e_offset), scale, offset)
+            assert RECENT.earlier_of(own)[0] is first
+        assert RECENT.earlier_of(own) is None  # settled on the way out
+        assert torch.equal(own.raw_data, first if same else torch.full((32,), 7, dtype=torch.int8))
+    own = Holder(torch.zeros(32, dtype=torch.int8))
+    scale = torch.tensor([0.5])
+    RECENT.mark_undecided(own, (first, e_scale, e_offset), scale, None)
+    scale.mul_(2.0)
+    with pytest.raises(RuntimeError, match="rewritten"):
+        RECENT.earlier_of(own)
+    with pytest.raises(RuntimeError, match="rewritten"):
+        RECENT.settle(own)
+    RECENT.clear()
