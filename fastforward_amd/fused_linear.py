@@ -302,6 +302,10 @@ class DispatcherKernels:
             bias = bias.dequantize()
         (xs, xo), (ws, wo) = self._scale_offset(input), self._scale_offset(weight)
         if self.row_mode(weight) is None:
+            if getattr(input, "_ffq_earlier", None) is not None:  # (see below: this branch reads the codes as they are)
+                from fastforward_amd.quantization.affine._memo import RECENT
+
+                RECENT.settle(input)
             # group-wise weight parameters cannot leave the contraction: A2 of the input (the reference's own first step,
             # fallback.py:94-100), then the GEMM that dequantizes the weight codes on their way into the matrix cores
             out = ops.linear_wq(input.dequantize(), self._int8_codes(weight), ws, wo, group=self.weight_group(weight), bias=bias, out_dtype=deq)
@@ -309,8 +313,21 @@ class DispatcherKernels:
                 out = torch.nn.functional.linear(input.dequantize(), weight.dequantize(), bias)
             return output_quantizer(out) if output_quantizer is not None else out
         fused = self._requant(output_quantizer, deq)
+        if getattr(input, "_ffq_earlier", None) is not None:
+            # the input quantizer left it to the device whether its A1 ran (``sibling_quantizers(undecided=True)``): the launch that
+            # takes the earlier sibling's codes along, else the codes in force written first
+            from fastforward_amd.quantization.affine._memo import RECENT
+
+            earlier = RECENT.earlier_of(input)
+            if fused is None and bias is None and earlier is not None:
+                out = ops.linear_w8a8_earlier(self._int8_codes(input), earlier, self._int8_codes(weight), xs, xo, ws, wo, out_dtype=deq)
+                if out is not None:
+                    return self._finish(out, None, input, output_quantizer, deq)
+            RECENT.settle(input)
         out = ops.linear_w8a8(self._int8_codes(input), self._int8_codes(weight), xs, xo, ws, wo, bias=bias, **(fused or dict(out_dtype=deq)))
         return self._finish(out, fused, input, output_quantizer, deq)
+
+    linear.reads_undecided_codes = True  # type: ignore[attr-defined]  # (nn/functional.py: nothing to settle before this kernel)
 
     def supported_weight_only(self, input: Any = None, weight: Any = None, bias: Any = None, **_: Any) -> bool:
         s = self.surface

@@ -229,6 +229,26 @@ def _hooked(*modules: torch.nn.Module | None) -> bool:
     return False
 
 
+def _codes_stay_with_the_linears(*linears: torch.nn.Module, module_calls: bool = False) -> bool:
+    """Whether what the input quantizers of `linears` return is read by nobody but the GEMM of their linear — the condition for
+    ``sibling_quantizers(undecided=True)``, under which a later sibling's codes may stay unwritten (quantization/affine/_memo.py):
+    no hook on those quantizers (a forward hook is handed the codes), no override on them from outside this package (an override
+    wraps the quantizer's forward and may look at what it returns; the range estimators of this package do not), and — where the
+    linears run as module calls (`module_calls`: the module graph) — linears that are exactly ``QuantizedLinear``, whose forward
+    hands the codes to ``ff.nn.functional.linear`` and to nothing else (that seam settles them for any kernel but this package's)."""
+    from fastforward_amd.nn import QuantizedLinear
+
+    for linear in linears:
+        quantizer = getattr(linear, "input_quantizer", None)
+        if quantizer is None or _hooked(quantizer):
+            return False
+        if any(not str(getattr(o, "__module__", "")).startswith("fastforward_amd.") for o in getattr(quantizer, "overrides", ())):
+            return False
+        if module_calls and (type(linear) is not QuantizedLinear or _hooked(linear)):
+            return False
+    return True
+
+
 def _one_pass(*tensors: torch.Tensor) -> bool:
     from fastforward_amd import _native
 
@@ -438,7 +458,9 @@ class QuantizedLlamaAttention(QuantizedModule, LlamaAttention):
             if fused_qkv is not None:
                 q, k, v = fused_qkv
             else:
-                with sibling_quantizers():  # equal input quantizers on the same hidden state share one A1 launch
+                # equal input quantizers on the same hidden state share one A1 launch; quantizers whose parameters only the device
+                # can compare (range estimation) leave it to the device whether the second and third launch run
+                with sibling_quantizers(undecided=_codes_stay_with_the_linears(self.q_proj, self.k_proj, self.v_proj, module_calls=True)):
                     q, k, v = self.q_proj(hidden_states), self.k_proj(hidden_states), self.v_proj(hidden_states)
             if _one_pass(q, k, v, cos, sin) and cos.dim() == 2 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous():
                 # rotary embedding in place on the projections, then softmax(q k^T) v as one flash-style launch
@@ -514,7 +536,7 @@ class QuantizedLlamaMLP(QuantizedModule, LlamaMLP):
             if parts is None and type(x) is torch.Tensor and _estimating(getattr(self.down_proj, "input_quantizer", None)):
                 # range estimation: the product from one op whatever the two input estimators hold (decided on the device), its
                 # [min, max] handed to down_proj's input estimator
-                with sibling_quantizers():
+                with sibling_quantizers(undecided=_codes_stay_with_the_linears(self.gate_proj, self.up_proj, module_calls=True)):
                     product, pair, pre = _w8a8_gate_up_product(x, self.gate_proj, self.up_proj, want_extrema=True)
                     if product is not None:
                         RECENT.remember_extrema(product, pair)
@@ -523,7 +545,7 @@ class QuantizedLlamaMLP(QuantizedModule, LlamaMLP):
                         parts = tuple(ff.nn.functional.linear(xq, wq, None, output_quantizer=lin.output_quantizer)
                                       for (xq, wq), lin in zip(pre, (self.gate_proj, self.up_proj)))
             if parts is None:
-                with sibling_quantizers():
+                with sibling_quantizers(undecided=_codes_stay_with_the_linears(self.gate_proj, self.up_proj, module_calls=True)):
                     parts = (self.gate_proj(x), self.up_proj(x))
             gate, up = parts
             if _one_pass(gate, up) and gate.shape == up.shape:
@@ -1189,7 +1211,7 @@ class FusedProducersForward:
                 if outs is not None:
                     return outs[0], outs[1], outs[2]
         # (a forward hook on an input quantizer would be handed codes the device may have left unwritten: then every quantizer quantizes)
-        with sibling_quantizers(undecided=not _hooked(*(p.input_quantizer for p in projections))):
+        with sibling_quantizers(undecided=_codes_stay_with_the_linears(*projections)):
             return self._linear(normed, attn.q_proj), self._linear(normed, attn.k_proj), self._linear(normed, attn.v_proj)
 
     def _gate_up(self, normed: torch.Tensor, mlp: torch.nn.Module) -> torch.Tensor:
@@ -1204,7 +1226,7 @@ class FusedProducersForward:
                 product = _weight_only_gate_up(normed, gate_proj, up_proj, stored)
                 if product is not None:
                     return product
-        with sibling_quantizers(undecided=not _hooked(gate_proj.input_quantizer, up_proj.input_quantizer)):
+        with sibling_quantizers(undecided=_codes_stay_with_the_linears(gate_proj, up_proj)):
             if all(l.bias is None and not l.weight_quantizer.is_stub() and l.output_quantizer.is_stub() and not l.input_quantizer.is_stub()
                    for l in (gate_proj, up_proj)):
                 # every quantizer first (each is its own estimator step during range estimation), then ONE op for what consumes their

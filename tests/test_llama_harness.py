@@ -526,7 +526,7 @@ def test_producers_leaving_extrema_change_no_range(hip_backend, monkeypatch, fus
     """During range estimation gate + up + SiLU * up run as one op (one launch where the two input estimators agree, decided on the
     device; else the gated int8 GEMM epilogue) that leaves [min, max] of the product, and down_proj's input
     estimator starts from those two numbers — in the fused forward and in the module graph (QuantizedLlamaMLP.forward); weights take the one-pass
-    estimator-step-and-quantize kernel; in the fused forward the k / v / up input quantizers leave it to the device whether their A1
+    estimator-step-and-quantize kernel; the k / v / up input quantizers leave it to the device whether their A1
     runs at all (it does not where their parameters are q's / gate's: ``sibling_quantizers(undecided=True)``). With every one of those
     shortcuts switched off — estimators reduce over the tensors, the SiLU * up pass runs, weights take the two steps, every quantizer
     quantizes — the calibrated parameters are the same bits. `unequal`: some siblings start from ranges of their own, so their
@@ -563,8 +563,9 @@ def test_producers_leaving_extrema_change_no_range(hip_backend, monkeypatch, fus
     got, hits_with, launches_with = calibrated(True)
     # per layer and step: down_proj's estimator takes the product's pair (q/k/v and gate/up share one reduction either way)
     assert hits_with >= hits_without + 3 * cfg.num_layers
-    # ... and k, v and up put the question whether to quantize at all to the device (fused forward only)
-    assert launches_without == 0 and launches_with == (3 * cfg.num_layers * 3 if fused else 0)
+    # ... and k, v and up put the question whether to quantize at all to the device (the module graph's linears through the
+    # ``ff.nn.functional.linear`` seam, its MLP through the same op as the fused forward)
+    assert launches_without == 0 and launches_with == 3 * cfg.num_layers * 3
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
 
 
@@ -596,3 +597,52 @@ def test_a_hook_on_a_sibling_quantizer_sees_written_codes(hip_backend):
     assert RECENT.undecided_launches - launches == 2 * 1  # up_proj's only: the q / k / v group ran as itself
     ffd.calibrate_sharded(model, batches, disable_quantization=False, fused=True)
     assert RECENT.undecided_launches - launches == 2 * 1 + 2 * 3
+
+
+@pytest.mark.gpu
+def test_the_linear_seam_settles_undecided_codes_for_foreign_kernels(hip_backend, monkeypatch):
+    """``ff.nn.functional.linear`` hands the codes of a device-decided sibling quantizer to this package's int8 linear as they are
+    (it takes the earlier sibling's codes along) and writes the codes in force first for any other kernel — a user-registered one,
+    or the dequantize-and-matmul fallback."""
+    from fastforward_amd.nn import functional
+    from fastforward_amd.quantization.affine._memo import RECENT
+
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x = (torch.randn(2048, 2048, device="cuda", generator=g) * 2).to(torch.bfloat16)
+    linear = ff.nn.QuantizedLinear(2048, 2048, bias=False, device="cuda", dtype=torch.bfloat16)
+    linear.weight_quantizer = ff.nn.LinearQuantizer(8, granularity=ff.PerChannel(0), quantized_dtype=torch.int8, device="cuda")
+    linear.weight_quantizer.quantization_range = (linear.weight.detach().float().min(dim=1).values, linear.weight.detach().float().max(dim=1).values)
+    first = ff.nn.LinearQuantizer(8, symmetric=False, granularity=ff.PerTensor(), quantized_dtype=torch.int8, device="cuda")
+    later = ff.nn.LinearQuantizer(8, symmetric=False, granularity=ff.PerTensor(), quantized_dtype=torch.int8, device="cuda")
+    first.quantization_range = (-6.0, 7.0)
+    later.quantization_range = (-6.0, 7.0)
+    wq = linear.weight_quantizer(linear.weight)
+    with ff.strict_quantization(False):
+        want = functional.linear(later(x), wq, None)
+
+    def marked():  # (inside a sibling block: marks that outlive it are settled on the way out)
+        later.quantization_range = (-6.0, 7.0)  # (rewritten parameters, as after an estimator step: nothing the host could compare)
+        first(x)
+        xq = later(x)
+        assert RECENT.earlier_of(xq) is not None
+        xq.raw_data.fill_(77)  # (what an unwritten buffer may hold)
+        return xq
+
+    seen = {}
+
+    def foreign(input, weight, bias=None, **_):  # a kernel that knows nothing of marks
+        seen["codes"] = input.raw_data.clone()
+        return torch.nn.functional.linear(input.dequantize(), weight.dequantize(), bias)
+
+    with torch.no_grad(), ff.strict_quantization(False):
+        with RECENT.scope(undecided=True):
+            xq = marked()
+            got = functional.linear(xq, wq, None)  # this package's kernel: reads the first sibling's codes
+            assert torch.equal(got, want) and bool((xq.raw_data == 77).all())
+        assert RECENT.earlier_of(xq) is None and torch.equal(xq.raw_data, later(x).raw_data)  # settled at the end of the block
+        with RECENT.scope(undecided=True):
+            xq = marked()
+            monkeypatch.setattr(functional, "dispatch", lambda name, **kwargs: foreign)
+            functional.linear(xq, wq, None)
+            assert RECENT.earlier_of(xq) is None
+        assert torch.equal(seen["codes"], later(x).raw_data)
