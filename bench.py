@@ -147,6 +147,47 @@ def pmc_traffic_mix(needle: "str | tuple[str, ...]", keep=None) -> tuple[float |
     return (total / launches if launches else None), variants, prof
 
 
+def same_box_probe(device: torch.device, target_ms: float = 50.0) -> dict | None:
+    """What THIS box's matrix pipes sustain on toggling operands, measured in this process AFTER the timed region (side measurement):
+    v_mfma_i32_16x16x64_i8 (and the bf16 twin) issued back to back on pseudo-random operands, 8 waves per CU, no LDS / global traffic
+    (tools/probes/ffq_probe.hip -> tools/probes/libffq_probe.so, built by __graft_entry__.build(); measurement code, not the product
+    library). The boards of the pool settle at different clocks under the same 1400 W limit: `frac_of_same_box_probe` is the figure
+    that can be compared across boxes, `frac` stays against the nominal 5 POP/s."""
+    import ctypes
+
+    so = ROOT / "tools" / "probes" / "libffq_probe.so"
+    if not so.exists():
+        return None
+    lib = ctypes.CDLL(str(so))
+    out = {}
+    sink = torch.zeros(4, dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream()
+    blocks = 2 * torch.cuda.get_device_properties(device).multi_processor_count  # 8 waves per CU
+    for name, fn, iters in (("int8_16x16x64", lib.ffq_probe_mfma_i8, 40000), ("bf16_16x16x32", lib.ffq_probe_mfma_bf16, 40000)):
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]
+        ops_per_launch = ctypes.c_double(0.0)
+        launch = lambda: fn(iters, blocks, sink.data_ptr(), ctypes.byref(ops_per_launch), stream.cuda_stream)  # noqa: E731
+        if launch() != 0:  # warm: clocks settle under load
+            return None
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        launch()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        one = e0.elapsed_time(e1)
+        reps = max(1, min(16, int(round(target_ms / max(one, 1e-3)))))
+        e0.record(stream)
+        for _ in range(reps):
+            launch()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        out[name] = {"T(FL)OP/s": round(ops_per_launch.value * reps / ms / 1e9, 1), "ms": round(ms, 2), "launches": reps}
+    return out
+
+
 def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, fused: "llama.FusedForward | None", batch: torch.Tensor) -> dict:
     """The dominant kernel of the step: the int8 MFMA GEMM. Algorithmic ops per launch = 2*T*N*K.
 
@@ -225,8 +266,16 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
     if probe.exists():
         rates = [float(line.split("toggling")[1].split("TOP/s")[0]) for line in probe.read_text().splitlines() if line.startswith("16x16x64 random bytes")]
         ceiling = round(statistics.mean(rates), 1) if rates else None
+    probe_now = same_box_probe(device)
+    probe_tops = None if not probe_now else probe_now["int8_16x16x64"]["T(FL)OP/s"]
     return {
         "bound": "mfma",
+        "same_box_probe_TOPs": probe_tops,
+        "frac_of_same_box_probe": None if not probe_tops else round(achieved / probe_tops, 4),
+        "same_box_probe": probe_now,
+        "same_box_probe_note": "v_mfma_i32_16x16x64_i8 (and its bf16 twin) back to back on toggling pseudo-random operands, 8 waves per CU, no LDS / global traffic, ~50 ms "
+                               "in this process after the timed region (tools/probes/ffq_probe.hip): what this board's matrix pipe sustains under its power limit; "
+                               "frac_of_same_box_probe = achieved / that, comparable across the pool's boxes",
         "kernel": "w8a8_gemm256fq_kernel (v_mfma_i32_16x16x64_i8, 256x256 tiles, persistent one-block-per-CU tile loop, ping-pong wave groups, full-line LDS-DMA staging; plain and gate+up/SiLU-epilogue modes) + rowsum_i8_kernel",
         "achieved": round(achieved, 1),
         "peak": INT8_PEAK_TOPS,
@@ -664,6 +713,16 @@ def main() -> None:
         result["host_us_per_op"] = host_us_per_op(device)
         if world == 1:
             result["cpu_baseline"] = cpu_baseline(config)
+        # the figures a reader needs first, repeated compactly at the END of the line: a log viewer that keeps only the last few kB
+        # of stdout still shows them (the calibration rate was cut off the record's tail)
+        roof = result["roofline"]
+        result["summary"] = {
+            "tokens_per_s": result["value"], "ms_per_step": result["ms_per_step"],
+            "calibration_sequences_per_s": result["calibration"]["sequences_per_s_all_gpus"],
+            "module_graph_drop_in_tokens_per_s": None if not module_graph else module_graph.get("value"),
+            "roofline_frac": roof["frac"], "same_box_probe_TOPs": roof["same_box_probe_TOPs"], "frac_of_same_box_probe": roof["frac_of_same_box_probe"],
+            "hbm_kernels_frac": {k["op"][:48]: k.get("frac") for k in result["hbm_kernels"] if isinstance(k, dict) and "op" in k},
+        }
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -13,6 +13,24 @@
 
 #include "../../include/ffq.h"
 
+// ---------------------------------------------------------------------------------------------
+// Cross-block hand-overs (split-K slabs of ffq_wlinear.hip / ffq_wskinny.hip, the one-launch min/max of ffq_minmax.hip, the extrema
+// words of ffq_extrema.h): a block publishes data, takes a ticket with an agent-scope read-modify-write, and the block whose ticket
+// says "everybody has published" reads its peers' data. The ticket RMW is ACQ_REL at agent scope (round 6) — release on the way in
+// (the block's earlier stores are visible to whoever observes the ticket), acquire on the way out (the last arriver's later loads
+// see what the others released): the hand-over is inside the HIP / HSA memory model instead of resting on how the hardware
+// happens to order sc1 write-through stores behind `s_waitcnt vmcnt(0)`. The data path itself keeps its sc1 stores / loads.
+// -DFFQ_TICKET_ORDER=__ATOMIC_RELAXED builds the round-5 form for the A/B (profiles/r06_ticket_order_ab.txt).
+// ---------------------------------------------------------------------------------------------
+#ifndef FFQ_TICKET_ORDER
+#define FFQ_TICKET_ORDER __ATOMIC_ACQ_REL
+#endif
+// acquire behind a relaxed polling loop (one fence when the loop leaves, none per poll)
+#define ffq_ticket_acquire()                                                      \
+  do {                                                                            \
+    if (FFQ_TICKET_ORDER != __ATOMIC_RELAXED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); \
+  } while (0)
+
 namespace ffq {
 
 // ---------------------------------------------------------------------------------------------

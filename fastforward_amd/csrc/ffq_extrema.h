@@ -61,7 +61,7 @@ __device__ __forceinline__ void extrema_publish(const ExtremaSink& s, float mn, 
       (void)__hip_atomic_fetch_or(s.words + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const uint32_t t = __hip_atomic_fetch_add(s.words + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t t = __hip_atomic_fetch_add(s.words + 3, 1u, FFQ_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
   if (t != arrivals - 1) return;
   asm volatile("" ::: "memory");
   extrema_finish(s);

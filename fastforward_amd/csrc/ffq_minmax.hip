@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void minmax_scalar_partial_kernel(const T* 
       __hip_atomic_store(cells + 2 * blockIdx.x, lohi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(cells + 2 * blockIdx.x + 1, (unsigned long long)(m.nan ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int t = __hip_atomic_fetch_add(fin.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int t = __hip_atomic_fetch_add(fin.ticket, 1, FFQ_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
       last_s = t == (int)gridDim.x - 1;
       if (last_s) __hip_atomic_store(fin.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
     }

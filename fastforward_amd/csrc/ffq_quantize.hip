@@ -647,6 +647,9 @@ extern "C" int ffq_quantize_rows_rowsum(const void* data, int data_dt, const flo
   if (cols % 1024 != 0) return fail(FFQ_ERR_DTYPE, "fused weight quantize + row sums needs cols %% 1024 == 0");
   if (!ffq_can_support_bitwidth(FFQ_I8, num_bits))
     return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.", FFQ_I8, num_bits);
+  // the kernel clamps BEFORE it rounds (quantize_chunk_to_bytes), which equals the reference's round-then-clamp only for integer clamp
+  // bounds: a fractional bit width goes back to ffq_quantize_by_tile
+  if (num_bits != floor(num_bits) || num_bits < 1) return fail(FFQ_ERR_DTYPE, "fused weight quantize + row sums needs an integral bit width (else ffq_quantize_by_tile)");
   if (rows == 0 || cols == 0) return FFQ_OK;
   if (!data || !scale || !codes || !rowsum) return fail(FFQ_ERR_ARG, "NULL buffer");
   if (!aligned16(data) || !aligned16(codes)) return fail(FFQ_ERR_ARG, "buffers must be 16-byte aligned");
@@ -673,6 +676,8 @@ extern "C" int ffq_quantize_rows_batch(const ffq_rows_batch* batch, int data_dt,
   if (data_dt != FFQ_BF16) return fail(FFQ_ERR_DTYPE, "batched weight quantization is built for bf16 weights");
   if (!ffq_can_support_bitwidth(FFQ_I8, batch->num_bits))
     return fail(FFQ_ERR_PRECISION, "Provided dtype (%d) is not enough to store %g bits quantized values.", FFQ_I8, batch->num_bits);
+  if (batch->num_bits != floor(batch->num_bits) || batch->num_bits < 1)  // clamp-before-round needs integer bounds (see ffq_quantize_rows_rowsum)
+    return fail(FFQ_ERR_DTYPE, "batched weight quantization needs an integral bit width (else ffq_quantize_by_tile per weight)");
   BatchArgs a;
   a.count = batch->count;
   const double lo = -pow(2.0, batch->num_bits - 1.0);

@@ -616,7 +616,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
       // the trailing pieces of the DMA stream): [0]: 1 = everybody is in, 3 = the wait ran out; [1]: abandoned slices seen by the last arriver
       int* const verdict = reinterpret_cast<int*>(lds + (slot ^ 1) * WL_SLOT + WL_SLOT - 16);
       if (tid == 0) {
-        const unsigned long long old = __hip_atomic_fetch_add(state, kArrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long old = __hip_atomic_fetch_add(state, kArrive, FFQ_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
         int v = 1;
         uint32_t seen = 0;
         if ((int)((old >> 32) & 0xFFu) + 1 == S) {
@@ -629,6 +629,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
             if (spins++ >= budget) { v = 3; break; }
             __builtin_amdgcn_s_sleep(8);
           }
+          ffq_ticket_acquire();  // the polls themselves stay relaxed: one acquire once everybody is in (or the wait ran out)
         }
         verdict[0] = v;
         verdict[1] = (int)seen;
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-          const unsigned long long old = __hip_atomic_fetch_or(state, 1ull << slice, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long old = __hip_atomic_fetch_or(state, 1ull << slice, FFQ_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
           verdict[0] = (int)((old >> 32) & 0xFFu) == S ? 1 : 2;  // everybody came in meanwhile: nobody will cover for this unit, carry on
         }
         __syncthreads();

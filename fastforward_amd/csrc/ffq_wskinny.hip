@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void wq_skinny_kernel(SkinnyArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left before the ticket is taken
     int t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(a.tickets + nb * SK_WAVES + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) t = __hip_atomic_fetch_add(a.tickets + nb * SK_WAVES + wave, 1, FFQ_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t != a.S - 1) return;  // somebody else finishes this strip
     if (lane == 0) __hip_atomic_store(a.tickets + nb * SK_WAVES + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void wq_skinny_rows_kernel(SkinnyArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(a.tickets + nb * TILES + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) t = __hip_atomic_fetch_add(a.tickets + nb * TILES + tile, 1, FFQ_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t != a.S - 1) return;
     if (lane == 0) __hip_atomic_store(a.tickets + nb * TILES + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1360,12 +1360,12 @@ def quantize_rows_rowsum(
     codes (the zero-point term of the W8A8 linear), one pass. Codes equal ``quantize_by_tile(weight, scale, (1, cols), ...)``.
     ``rowsum_out``: a ZEROED contiguous int32 ``[rows]`` tensor to receive the sums (the kernel adds into it; a forward hands
     out slices of one buffer it zeroes once). Returns None where the one-pass kernel does not apply (not bf16,
-    ``cols % 1024 != 0``): take ``quantize_by_tile``."""
+    ``cols % 1024 != 0``, a fractional bit width): take ``quantize_by_tile``."""
     if weight.dim() != 2:
         raise RuntimeError("quantize_rows_rowsum expects a [rows, cols] weight")
     rows, cols = weight.shape
-    if weight.dtype != torch.bfloat16 or cols % 1024 or not weight.is_contiguous():
-        return None
+    if weight.dtype != torch.bfloat16 or cols % 1024 or not weight.is_contiguous() or float(num_bits) != int(num_bits):
+        return None  # (a fractional bit width: the kernel clamps before it rounds, which needs integer bounds)
     sc = scale.detach().reshape(-1).to(torch.float32).contiguous()
     of = None if offset is None else offset.detach().reshape(-1).to(torch.float32).contiguous()
     if sc.numel() != rows or (of is not None and of.numel() != rows):
@@ -1393,7 +1393,7 @@ def quantize_rows_batch(
     below the streaming rate. `rowsums` (one ZEROED contiguous int32 [rows] tensor per weight, cols % 1024 == 0): the launch also
     adds each row's code sum into it — what :func:`linear_w8a8` takes as ``w_rowsum``. Returns None where the one-launch
     kernel does not apply (then quantize member by member)."""
-    if not weights or len(weights) > FFQ_MAX_BATCH or not (len(weights) == len(scales) == len(offsets)):
+    if not weights or len(weights) > FFQ_MAX_BATCH or not (len(weights) == len(scales) == len(offsets)) or float(num_bits) != int(num_bits):
         return None
     if rowsums is not None and (len(rowsums) != len(weights) or any(
             r.dtype != torch.int32 or r.numel() != w.shape[0] or not r.is_contiguous() or w.shape[1] % 1024 for r, w in zip(rowsums, weights))):

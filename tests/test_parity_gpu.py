@@ -1430,6 +1430,27 @@ def test_batched_weight_quantization_equals_member_by_member():
     assert ops.quantize_rows_batch([small[0].float()], [sc[0]], [None]) is None                # fp32 weights: member by member
 
 
+def test_fractional_bit_widths_do_not_take_the_clamp_first_row_kernels():
+    """ffq_quantize_rows_rowsum / ffq_quantize_rows_batch clamp before they round, which equals the reference's round, clamp,
+    truncating cast (_quantizer_impl.py:154-169) only for integer clamp bounds. With 3.5 bits both entries decline (ops return None, the C ABI
+    answers FFQ_ERR_DTYPE) and the general A1 kernel — whose codes are the oracle's (tests/test_oracle_golden.py) — is what a caller gets."""
+    torch.manual_seed(41)
+    w = (torch.randn(256, 1024, device=DEV) * 3).to(torch.bfloat16)
+    scale = torch.rand(256, device=DEV) * 0.5 + 0.25
+    assert ops.quantize_rows_rowsum(w, scale, None, 3.5) is None
+    assert ops.quantize_rows_batch([w, w], [scale, scale], [None, None], 3.5) is None
+    lib = ops._native.library()
+    codes = torch.empty(w.shape, dtype=torch.int8, device=DEV)
+    sums = torch.zeros(256, dtype=torch.int32, device=DEV)
+    rc = lib.ffq_quantize_rows_rowsum(ops._ptr(w), ops._tag(w.dtype), ops._ptr(scale), None, 256, 1024, 3.5, ops._ptr(codes), ops._ptr(sums), None)
+    assert rc == 6  # FFQ_ERR_DTYPE
+    got = ops.quantize_by_tile(w, scale, (1, 1024), 3.5, torch.int8)
+    with use_backend(load_oracle()):
+        want = ops.quantize_by_tile(w.cpu(), scale.cpu(), (1, 1024), 3.5, torch.int8)
+    assert torch.equal(got.cpu(), want)
+    assert int(got.min()) == -5 and int(got.max()) == 4  # trunc(-2^2.5) = -5, trunc(2^2.5 - 1) = 4: not the -6 a clamp-first kernel gives
+
+
 @pytest.mark.parametrize("causal", [True, False])
 def test_attention_rotates_q_on_the_way_in(causal):
     """ops.attention(q_rope=(cos, sin)) on an UN-rotated q == ops.rope_ on q followed by ops.attention: context and o_proj codes bit

@@ -1,6 +1,10 @@
 import sys, torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from fastforward_amd import ops
+from fastforward_amd import ops, _native
+import os
+if os.environ.get("FFQ_LIB"):
+    from fastforward_amd._cabi import FFQLibrary
+    _native._LIB = FFQLibrary(os.environ["FFQ_LIB"])
 from bench import event_time_ms
 dev = "cuda"
 ws = [(torch.randn(14336, 4096, device=dev) * 0.02).to(torch.bfloat16) for _ in range(6)]

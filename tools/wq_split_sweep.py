@@ -1,10 +1,14 @@
 """Split-K sweep of the weight-only GEMM on the Llama-3-8B shapes at T tokens: every forced split next to the library's plan,
 the vendor's bf16 GEMM on the dequantized weight and A2 + that GEMM (what the kernel replaces). Tunes wq_split()'s cost model.
-usage: python tools/wq_split_sweep.py [T ...]"""
+usage: [FFQ_LIB=...] python tools/wq_split_sweep.py [T ...]"""
 import pathlib, sys
 import torch
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 from fastforward_amd import ops, _native
+import os
+if os.environ.get("FFQ_LIB"):
+    from fastforward_amd._cabi import FFQLibrary
+    _native._LIB = FFQLibrary(os.environ["FFQ_LIB"])
 from bench import event_time_ms
 
 lib = _native.library()
