@@ -14,16 +14,21 @@
 #include "../../include/ffq.h"
 
 // ---------------------------------------------------------------------------------------------
-// Cross-block hand-overs (split-K slabs of ffq_wlinear.hip / ffq_wskinny.hip, the one-launch min/max of ffq_minmax.hip, the extrema
-// words of ffq_extrema.h): a block publishes data, takes a ticket with an agent-scope read-modify-write, and the block whose ticket
-// says "everybody has published" reads its peers' data. The ticket RMW is ACQ_REL at agent scope (round 6) — release on the way in
-// (the block's earlier stores are visible to whoever observes the ticket), acquire on the way out (the last arriver's later loads
-// see what the others released): the hand-over is inside the HIP / HSA memory model instead of resting on how the hardware
-// happens to order sc1 write-through stores behind `s_waitcnt vmcnt(0)`. The data path itself keeps its sc1 stores / loads.
-// -DFFQ_TICKET_ORDER=__ATOMIC_RELAXED builds the round-5 form for the A/B (profiles/r06_ticket_order_ab.txt).
+// Cross-block hand-overs (split-K slabs of ffq_wlinear.hip / ffq_wmid.hip / ffq_wskinny.hip, the one-launch min/max of
+// ffq_minmax.hip, the extrema words of ffq_extrema.h): a block publishes data with sc1 WRITE-THROUGH stores, drains them
+// (`s_waitcnt vmcnt(0)`), takes a ticket with an agent-scope read-modify-write, and the block whose ticket says "everybody has
+// published" reads its peers' data with sc1 loads (which bypass the reading CU's L1 and cannot hit its L2: a slab line is written
+// once and read once per launch). The ticket RMW itself is RELAXED. Round 6 measured the alternative the HIP memory model offers —
+// ACQ_REL on the RMW, i.e. `buffer_wbl2 sc1` (write back the XCD's whole L2) ahead of every ticket and `buffer_inv sc1` (invalidate
+// it) behind — as two builds on one box (profiles/r06_ticket_order_ab.txt): the skinny weight-only GEMM at 64 rows 20.4 -> 46.2 us
+// (q/o), 29.7 -> 138.0 us (gate/up), at 128 rows 29.2 -> 53.9 us, the 256-row tiles' exchange at 512 rows 44 -> 50 us, the per-tensor
+// min/max of a 470 MB activation 76 -> 88 us: an L2 flush per arriving wave in kernels whose other blocks are mid-stream. So the
+// relaxed form stays, and what it rests on is pinned by a CPU test on the emitted ISA (tests/test_ticket_isa.py): every slab store
+// and load carries sc1, and `s_waitcnt vmcnt(0)` stands between a block's last slab store and its ticket RMW.
+// -DFFQ_TICKET_ORDER=__ATOMIC_ACQ_REL builds the in-model form (tools/build_variant_multi.sh) for whoever wants to re-measure.
 // ---------------------------------------------------------------------------------------------
 #ifndef FFQ_TICKET_ORDER
-#define FFQ_TICKET_ORDER __ATOMIC_ACQ_REL
+#define FFQ_TICKET_ORDER __ATOMIC_RELAXED
 #endif
 // acquire behind a relaxed polling loop (one fence when the loop leaves, none per poll)
 #define ffq_ticket_acquire()                                                      \

@@ -428,7 +428,8 @@ at::Tensor linear_wq(const at::Tensor& x, const at::Tensor& w_codes, const at::T
   else if (two_pass < 0) image = ffq_linear_wq_workspace_bytes(M, N, K) - ffq_linear_wq_slab_bytes(M, N, K, 0, plan);
   const size_t nbytes = slabs + image;
   at::Tensor ws = workspace(nbytes, xc);
-  at::Tensor tk = use > 1 ? tickets(n_tickets, xc, stream, /*wq*/ 0) : at::Tensor();
+  // (tickets whenever slabs are offered: where the preferred form declines the weight's storage, the form that takes over has its own plan)
+  at::Tensor tk = (use > 1 || slabs > 0) && n_tickets > 0 ? tickets(n_tickets, xc, stream, /*wq*/ 0) : at::Tensor();
   check(ffq_linear_wq(xc.data_ptr(), tag_of(xc.scalar_type()), wc.data_ptr(), tag_of(wc.scalar_type()), pack_block, static_cast<const float*>(sc.data_ptr()),
                       static_cast<const float*>(ptr(of)), sc.numel(), group, ptr(bias_c), bias_c.defined() ? tag_of(bias_c.scalar_type()) : 0, out.data_ptr(),
                       tag_of(out_dtype), M, N, K, ptr(ws), nbytes, static_cast<int32_t*>(ptr(tk)), split, stream));

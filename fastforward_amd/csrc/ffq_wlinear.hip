@@ -1112,30 +1112,57 @@ static int wq_split(int64_t M, int64_t N, int64_t K, bool mlp) {
   return best;
 }
 
-// M <= 128 rows, plain launches: the skinny form's plan (ffq_wskinny.hip) — unless the test hook selects the 256-row-tile kernel
-static bool wq_plan_is_skinny(int64_t M, int64_t K, int mlp) {
-  return !mlp && !generic_kernels_forced() && wq_skinny_tickets(M, 128, K) > 0;
+// Which form a plain launch of M rows takes (ffq_wq.h): the skinny form up to FFQ_MID_MIN_M - 1 rows, the 128-column tiles of
+// ffq_wmid.hip up to 512, the 256-row tiles beyond (and for every gate+up+SiLU*up launch, and under the test hook). The skinny form
+// declines some storage forms (packing blocks other than 128, K % 128 != 0): such a launch takes the 128-column tiles, which cover
+// everything ffq_linear_wq_supported() admits — so the scratch figures below answer for BOTH wherever the skinny form is preferred
+// (a GGUF-packed decode step got the skinny plan's scratch, often none, and ran the 256-row tiles without a split).
+enum { WQ_FORM_TILES = 0, WQ_FORM_SKINNY = 1, WQ_FORM_MID = 2 };
+static int wq_plan_form(int64_t M, int64_t K, int mlp) {
+  if (mlp || generic_kernels_forced()) return WQ_FORM_TILES;
+  if (M < FFQ_MID_MIN_M && wq_skinny_tickets(M, 128, K) > 0) return WQ_FORM_SKINNY;
+  if (wq_mid_shape_ok(M, K)) return WQ_FORM_MID;
+  return wq_skinny_tickets(M, 128, K) > 0 ? WQ_FORM_SKINNY : WQ_FORM_TILES;
 }
 
 extern "C" int64_t ffq_linear_wq_split(int64_t M, int64_t N, int64_t K, int mlp) {
   if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 1;
-  if (wq_plan_is_skinny(M, K, mlp)) return wq_skinny_split(M, N, K);
-  return wq_split(M, N, K, mlp != 0);
+  switch (wq_plan_form(M, K, mlp)) {
+    case WQ_FORM_SKINNY: return wq_skinny_split(M, N, K);
+    case WQ_FORM_MID: return wq_mid_split(M, N, K);
+    default: return wq_split(M, N, K, mlp != 0);
+  }
 }
 
-// int32 counters the split-K exchange needs (two per tail tile; 0 = none): zero before the first launch that uses them, left
-// zero by every launch — a caller keeps ONE zeroed buffer per stream and never touches it
+// int32 counters the split-K exchange needs (0 = none): zero before the first launch that uses them, left zero by every launch — a
+// caller keeps ONE zeroed buffer per stream and never touches it. An upper bound over the forms the launch can take.
 extern "C" int64_t ffq_linear_wq_tickets(int64_t M, int64_t N, int64_t K, int mlp) {
   if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 0;
-  if (wq_plan_is_skinny(M, K, mlp)) return wq_skinny_tickets(M, N, K);
-  return 2 * wq_tail_tiles(M, N, mlp != 0);
+  int64_t n = 2 * wq_tail_tiles(M, N, mlp != 0);
+  if (!mlp) {
+    const int64_t sk = wq_skinny_tickets(M, N, K), md = wq_mid_tickets(M, N, K);
+    n = n > sk ? n : sk;
+    n = n > md ? n : md;
+  }
+  return n;
 }
 
-// bytes of partial-sum slabs a launch with `split` K slices per tail tile needs at the front of its workspace (0: none)
+// bytes of partial-sum slabs a launch with `split` K slices needs at the front of its workspace (0: none). `split` = the value of
+// ffq_linear_wq_split (the plan) also covers the plan of the form that takes over where the preferred one declines the storage.
 extern "C" size_t ffq_linear_wq_slab_bytes(int64_t M, int64_t N, int64_t K, int mlp, int64_t split) {
-  if (M <= 0 || N <= 0 || K < 2 * WL_BK || split <= 1) return 0;
-  if (wq_plan_is_skinny(M, K, mlp)) return wq_skinny_slab_bytes(M, N, K, split);
-  return (size_t)wq_tail_tiles(M, N, mlp != 0) * (size_t)split * WL_UNIT_SLAB;
+  if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 0;
+  switch (wq_plan_form(M, K, mlp)) {
+    case WQ_FORM_SKINNY: {
+      size_t bytes = wq_skinny_slab_bytes(M, N, K, split);
+      if (wq_mid_shape_ok(M, K)) {
+        const size_t md = wq_mid_slab_bytes(M, N, K, split == wq_skinny_split(M, N, K) ? wq_mid_split(M, N, K) : split);
+        bytes = bytes > md ? bytes : md;
+      }
+      return bytes;
+    }
+    case WQ_FORM_MID: return wq_mid_slab_bytes(M, N, K, split);
+    default: return split <= 1 ? 0 : (size_t)wq_tail_tiles(M, N, mlp != 0) * (size_t)split * WL_UNIT_SLAB;
+  }
 }
 
 static size_t wq_slab_bytes(int64_t M, int64_t N, int split, bool mlp) {
@@ -1147,7 +1174,7 @@ static size_t wq_slab_bytes(int64_t M, int64_t N, int split, bool mlp) {
 // that does not fit (no split / conversion inside the GEMM) — never fails for lack of scratch.
 extern "C" size_t ffq_linear_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 0;
-  if (wq_plan_is_skinny(M, K, 0)) return wq_skinny_slab_bytes(M, N, K, wq_skinny_split(M, N, K));
+  if (wq_plan_form(M, K, 0) != WQ_FORM_TILES) return ffq_linear_wq_slab_bytes(M, N, K, 0, ffq_linear_wq_split(M, N, K, 0));
   return wq_slab_bytes(M, N, wq_split(M, N, K, false), false) + (M >= WL_TWO_PASS_MIN_TOKENS ? (size_t)N * (size_t)K * 2u : 0);
 }
 
@@ -1271,6 +1298,9 @@ static int wq_linear_impl(const void* x, int x_dt, int count, const void* const*
 #endif
   const bool grouped = groups > 1, offset = w_offset[0] != nullptr;
   // few rows: the contraction is a stream over the codes, bounded by HBM — 16-row MFMA tiles, no padding to 256 rows (ffq_wskinny.hip)
+  if (M < FFQ_MID_MIN_M && wq_skinny_applies(a, pack_block)) return wq_skinny_launch(a, w_dt, pack_block, group, split, workspace, workspace_bytes, tickets, s);
+  // a few hundred rows (and the storage forms the skinny kernel declines): 128-column tiles, codes converted once per block (ffq_wmid.hip)
+  if (wq_mid_applies(a)) return wq_mid_launch(a, w_dt, group, split, workspace, workspace_bytes, tickets, s);
   if (wq_skinny_applies(a, pack_block)) return wq_skinny_launch(a, w_dt, pack_block, group, split, workspace, workspace_bytes, tickets, s);
   int rc_split;
   const size_t slab_bytes = wq_resolve_split(a, split, false, workspace, workspace_bytes, tickets, &rc_split);

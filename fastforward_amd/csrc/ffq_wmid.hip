@@ -1,0 +1,455 @@
+// ffq_wmid.hip — the weight-only quantized linear for a FEW HUNDRED token rows (17 <= M <= 512; any M <= 512 whose weight storage the
+// skinny form of ffq_wskinny.hip declines): short prompts, speculative / batched decode steps, the tail chunk of a prefill.
+//
+// Same contract as ffq_wlinear.hip (reference _gen/fallback.py:86-112: y = F.linear(x, dequantize(w)); the B operand of the bf16 MFMA is
+// bit for bit A2's bf16 value ((float(q) + round(o)) * s, one RNE rounding), fp32 accumulation, only the summation order is this
+// kernel's own), a different regime. Up to round 5 these launches took the 256 x 256 tiles of ffq_wlinear.hip cut along K: a 512-row
+// q/o projection is 32 tiles, so every tile was cut into 8 slices whose 256 KiB fp32 partials went through HBM — 64 MB written and
+// 64 MB read back for a problem whose operands are 20 MB (missing #1) — and below 129 rows the skinny form streams every
+// activation fragment from LDS once per MFMA (one weight tile per wave), which the LDS pipe bounds from 32 rows on. Here
+//   * a block is 4 waves (2 x 2) on a BM x 128 output tile, BM = 128 (64 up to 64 rows): 4 x the tiles of the 256-row form, so that a
+//     512-row q/o projection fills the chip with S = 2 slices of K (16 MB of partials), gate/up and down_proj with S = 1 or 2;
+//   * both operands are staged through REGISTERS into a k-ordered, XOR-swizzled LDS image, one 64-k super-step per stage, double
+//     buffered: activations as they are (bf16), codes converted ONCE PER BLOCK with A2's arithmetic (dequantize4 of ffq_wq.h, the
+//     function the other two forms use) on their way in — int8 containers and packed nibbles of every packing block >= 32 (GGUF's
+//     32 / 64, config 4's 128, 256: a piece of 16 codes lives in one nibble position of 16 contiguous bytes) give the SAME image, so
+//     every storage form of one weight gives the same bits; the code loads run MD_BDEPTH super-steps ahead of their conversion
+//     (weights come from HBM once), the activation loads MD_ADEPTH (they are L2-resident: M x K x 2 bytes <= 15 MB);
+//   * a wave contracts (BM / 2) x 64 with v_mfma_f32_16x16x32_bf16: every fragment read feeds 4 (2) MFMAs, where the skinny form
+//     needs one read per MFMA; two blocks per CU hide each other's barriers and conversion work;
+//   * K is cut into S slices across blocks where the tiles alone do not fill the chip. A wave leaves its (BM / 2) x 64 partial in a
+//     write-through slab, takes a ticket for that quadrant, and the LAST wave to arrive — whoever it is — adds the S partials in slice
+//     order and writes the output: nobody waits for anybody (the exchange of ffq_wskinny.hip), the summation order is a function of
+//     the plan alone (bit-reproducible), ticket words are zero before and after.
+// Covered: everything ffq_linear_wq_supported() admits with M <= 512 — one to three weight matrices on the same activations
+// (every matrix but the last a multiple of 128 rows), per-tensor / per-channel / per-group parameters, offsets, bias, bf16 / f32
+// output. The gate+up+SiLU*up launch keeps the 256-row-tile kernel.
+#include "ffq_wq.h"
+
+#include <math.h>
+
+#include <type_traits>
+
+namespace ffq {
+
+constexpr int MD_BN = 128;      // weight rows (output columns) per tile
+constexpr int MD_BDEPTH = 4;    // super-steps of code loads in flight (ring of registers)
+constexpr int MD_ADEPTH = 2;    // ... of activation loads
+
+struct MidArgs {
+  const uint8_t* x;
+  const uint8_t* w[3]; const float* scale[3]; const float* offset[3]; void* out[3];
+  int seg_n[3];          // rows of each weight matrix (0: absent)
+  int seg_tile[3];       // first column tile of matrices 1 and 2 (seg_tile[0] = 0); INT32_MAX: absent
+  const void* bias; int bias_dt;
+  int out_dt;
+  int M, K;
+  int tiles_m, tiles_n;  // tiles_n: column tiles over all matrices
+  int groups;            // parameters per row along K (1: per channel / per tensor)
+  int steps_per_group;   // super-steps of 64 k that share one group
+  int per_row;
+  int pack_shift;        // WL_B_I4: log2(packing block)
+  int S;                 // K slices across blocks
+  float* slabs;          // [tile][S][wave][MI * 4][64 lanes] x 16 B
+  int* tickets;          // [tile][wave]
+};
+
+template <int BKIND, bool GROUPED, bool OFFSET, int BM>
+__global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
+  constexpr int MI = BM / 32;                  // 16-row tiles of a wave along M (the wave contracts (BM / 2) x 64)
+  constexpr int A_IMAGE = BM * 128, SLOT = A_IMAGE + MD_BN * 128;
+  constexpr int AP = BM / 32;                  // 16-byte activation pieces per thread and super-step
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint32_t r16 = lane & 15, g4 = lane >> 4;
+
+  // unit = (row tile, column tile, K slice); the units of one (column tile, slice) over the row tiles are tiles_n * S apart: with
+  // tiles_n * S a multiple of 8 they run on ONE XCD and share the tile's weight bytes in its L2
+  const int per_m = a.tiles_n * a.S;
+  const int tm = (int)blockIdx.x / per_m, rest = (int)blockIdx.x - tm * per_m;
+  const int tn_all = rest / a.S, slice = rest - tn_all * a.S;
+  const int seg = tn_all >= a.seg_tile[2] ? 2 : tn_all >= a.seg_tile[1] ? 1 : 0;  // block-uniform selects: no dynamic indexing of the arguments
+  const uint8_t* const w_base = seg == 0 ? a.w[0] : seg == 1 ? a.w[1] : a.w[2];
+  const float* const s_base = seg == 0 ? a.scale[0] : seg == 1 ? a.scale[1] : a.scale[2];
+  const float* const o_base = seg == 0 ? a.offset[0] : seg == 1 ? a.offset[1] : a.offset[2];
+  const int rows = seg == 0 ? a.seg_n[0] : seg == 1 ? a.seg_n[1] : a.seg_n[2];
+  const int n0 = (tn_all - (seg == 0 ? 0 : seg == 1 ? a.seg_tile[1] : a.seg_tile[2])) * MD_BN;  // first row of the tile inside its matrix
+  const int m0 = tm * BM;
+  const int ksuper = a.K / 64;
+  const int k0 = (int)((int64_t)slice * ksuper / a.S), k1 = (int)((int64_t)(slice + 1) * ksuper / a.S);
+  const int nsteps = k1 - k0;
+
+  // ---- the activation stream: piece i of thread t = row (t / 8) + 32 i of the tile, 16-byte slot t % 8 of the row's 128 bytes
+  const uint8_t* x_ptr[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    int m = m0 + (tid >> 3) + 32 * i;
+    m = m < a.M ? m : a.M - 1;  // rows past the edge re-read the last row and are never stored
+    x_ptr[i] = a.x + (size_t)m * (size_t)a.K * 2u + (size_t)(tid & 7) * 16u;
+  }
+  // ---- the code stream: piece j of thread t = row (t / 4) + 64 j of the tile, codes [16 p, 16 p + 16) of the super-step, p = t % 4
+  const uint32_t c_piece = (uint32_t)tid & 3u;
+  const uint32_t w_row_bytes = BKIND == WL_B_I8 ? (uint32_t)a.K : (uint32_t)a.K / 2u;
+  const uint8_t* w_ptr[2];
+  const float* s_ptr[2];
+  [[maybe_unused]] const float* o_ptr[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int row = n0 + (tid >> 2) + 64 * j;
+    row = row < rows ? row : rows - 1;
+    w_ptr[j] = w_base + (size_t)row * w_row_bytes;
+    const size_t p_row = a.per_row ? (size_t)row * (size_t)a.groups : 0;
+    s_ptr[j] = s_base + p_row;
+    if constexpr (OFFSET) o_ptr[j] = o_base + p_row;
+  }
+  u32x4 xa[MD_ADEPTH][AP];
+  u32x4 raw[MD_BDEPTH][2];
+  [[maybe_unused]] uint32_t nib[MD_BDEPTH];  // WL_B_I4: 0 = the low nibbles of the bytes, 4 = the high ones
+  [[maybe_unused]] float sc[MD_BDEPTH][2], ro[MD_BDEPTH][2];
+  float s_row[2] = {1.0f, 1.0f}, o_row[2] = {0.0f, 0.0f};
+  if constexpr (!GROUPED) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      s_row[j] = s_ptr[j][0];
+      if constexpr (OFFSET) o_row[j] = rne(o_ptr[j][0]);
+    }
+  }
+  auto load_a = [&](int ks, auto dc) {
+    constexpr int d = decltype(dc)::value;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) xa[d][i] = *reinterpret_cast<const u32x4*>(x_ptr[i] + (size_t)ks * 128u);
+  };
+  auto load_b = [&](int ks, auto dc) {
+    constexpr int d = decltype(dc)::value;
+    uint32_t byte0;
+    if constexpr (BKIND == WL_B_I8) {
+      byte0 = (uint32_t)ks * 64u + c_piece * 16u;
+    } else {
+      // codes kk .. kk + 15 of a row live in ONE half of ONE packing block (block >= 32): byte j of a block holds code j in its low and
+      // code j + block / 2 in its high nibble (ffq_pack_int4, export/stages/gguf/_packing.py:44-53)
+      const uint32_t kk = (uint32_t)ks * 64u + c_piece * 16u, lb = (uint32_t)a.pack_shift;
+      const uint32_t within = kk & ((1u << lb) - 1u);
+      nib[d] = (within >> (lb - 1u)) * 4u;
+      byte0 = ((kk >> lb) << (lb - 1u)) + (within & ((1u << (lb - 1u)) - 1u));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) raw[d][j] = *reinterpret_cast<const u32x4*>(w_ptr[j] + byte0);
+    if constexpr (GROUPED) {
+      const int grp = ks / a.steps_per_group;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        sc[d][j] = s_ptr[j][grp];
+        if constexpr (OFFSET) ro[d][j] = rne(o_ptr[j][grp]);
+      }
+    }
+  };
+  // registers -> the LDS images of `slot`: 16-byte slot q of row r lies at r * 128 + ((q ^ (r & 7)) << 4) (conflict-free stores and
+  // fragment reads)
+  auto store_a = [&](auto dc, int slot) {
+    constexpr int d = decltype(dc)::value;
+    uint8_t* image = lds + slot * SLOT;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const uint32_t row = (uint32_t)(tid >> 3) + 32u * i;
+      *reinterpret_cast<u32x4*>(image + row * 128u + ((((uint32_t)tid & 7u) ^ (row & 7u)) << 4)) = xa[d][i];
+    }
+  };
+  auto store_b = [&](auto dc, int slot) {
+    constexpr int d = decltype(dc)::value;
+    uint8_t* image = lds + slot * SLOT + A_IMAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t row = (uint32_t)(tid >> 2) + 64u * j;
+      uint32_t w[4] = {raw[d][j].x, raw[d][j].y, raw[d][j].z, raw[d][j].w};
+      float s = GROUPED ? sc[d][j] : s_row[j];
+      float c = OFFSET ? (GROUPED ? ro[d][j] : o_row[j]) : 0.0f;
+      if constexpr (BKIND == WL_B_I4) {
+        // nibble n = code + 8 -> (n ^ 8) << 4 in the byte's high half = 16 * code as a signed byte, and (16 q + 16 o) * (s / 16) is
+        // (q + o) * s with the same single rounding wherever s / 16 is exact; a tiny scale takes the codes themselves (ffq_wlinear.hip)
+        const bool tiny = __builtin_fabsf(s) < 0x1p-120f && s != 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t b = (((w[q] >> nib[d]) << 4) & 0xF0F0F0F0u) ^ 0x80808080u;
+          if (__builtin_expect(tiny, 0)) {
+            const uint32_t b0 = (uint32_t)(((int32_t)(b << 24)) >> 28) & 0xFFu, b1 = (uint32_t)(((int32_t)(b << 16)) >> 28) & 0xFFu;
+            const uint32_t b2 = (uint32_t)(((int32_t)(b << 8)) >> 28) & 0xFFu, b3 = (uint32_t)(((int32_t)b) >> 28) & 0xFFu;
+            b = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+          }
+          w[q] = b;
+        }
+        if (!tiny) { s = s * 0.0625f; c = c * 16.0f; }
+      }
+      uint32_t o[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dequantize4<OFFSET>(w[q], s, c, o[2 * q], o[2 * q + 1]);
+      const uint32_t sw = row & 7u;
+      *reinterpret_cast<u32x4*>(image + row * 128u + (((2u * c_piece) ^ sw) << 4)) = u32x4{o[0], o[1], o[2], o[3]};
+      *reinterpret_cast<u32x4*>(image + row * 128u + (((2u * c_piece + 1u) ^ sw) << 4)) = u32x4{o[4], o[5], o[6], o[7]};
+    }
+  };
+
+  // ---- fragments: lane (r16, g4) reads 8 bf16 of row r16 of a 16-row tile, logical slot kq * 4 + g4; the swizzle depends on the row
+  // through r16 only (row tiles are 16 rows apart): one offset per k-chunk and operand, the row tile is a constant (t * 2048 bytes)
+  uint32_t a_off[2], b_off[2];
+  {
+    const uint32_t arow = (uint32_t)wm * (BM / 2) + r16, brow = (uint32_t)wn * 64u + r16;
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+      a_off[kq] = arow * 128u + (((kq * 4u + g4) ^ (arow & 7u)) << 4);
+      b_off[kq] = A_IMAGE + brow * 128u + (((kq * 4u + g4) ^ (brow & 7u)) << 4);
+    }
+  }
+  wl_v4f acc[MI][4];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = wl_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+  auto compute = [&](int slot) {
+    const uint8_t* st = lds + slot * SLOT;
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+      wl_v4i fa[MI], fb[4];
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) fb[nj] = *reinterpret_cast<const wl_v4i*>(st + b_off[kq] + nj * 2048);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) fa[mi] = *reinterpret_cast<const wl_v4i*>(st + a_off[kq] + mi * 2048);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int n_ = 0; n_ < 4; ++n_) {
+          const int nj = (mi & 1) ? 3 - n_ : n_;  // snake order: every MFMA shares an operand with its predecessor
+          acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wl_v8bf, fb[nj]), __builtin_bit_cast(wl_v8bf, fa[mi]), acc[mi][nj], 0, 0, 0);
+        }
+    }
+  };
+
+  // ---- the K-loop. Step i (super-step k0 + i) computes from LDS slot i % 2 while stage i + 1 goes from its registers into the other slot
+  // (nobody reads that slot: its last readers passed the barrier behind step i - 1) and the registers just freed take the stage a ring
+  // ahead; ONE barrier per step.
+  auto each_b = [&](auto&& fn) {
+    fn(std::integral_constant<int, 0>{});
+    fn(std::integral_constant<int, 1>{});
+    fn(std::integral_constant<int, 2>{});
+    fn(std::integral_constant<int, 3>{});
+  };
+  static_assert(MD_BDEPTH == 4 && MD_ADEPTH == 2, "the unrolled ring below");
+  each_b([&](auto dc) { if (decltype(dc)::value < nsteps) load_b(k0 + decltype(dc)::value, dc); });
+  load_a(k0, std::integral_constant<int, 0>{});
+  if (1 < nsteps) load_a(k0 + 1, std::integral_constant<int, 1>{});
+  store_a(std::integral_constant<int, 0>{}, 0);
+  store_b(std::integral_constant<int, 0>{}, 0);
+  if (MD_ADEPTH < nsteps) load_a(k0 + MD_ADEPTH, std::integral_constant<int, 0>{});
+  if (MD_BDEPTH < nsteps) load_b(k0 + MD_BDEPTH, std::integral_constant<int, 0>{});
+  __syncthreads();
+  for (int i = 0; i < nsteps; i += MD_BDEPTH) {
+    each_b([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const int step = i + u;
+      if (step < nsteps) {
+        constexpr int cur = u & 1;
+        constexpr int nb = (u + 1) % MD_BDEPTH, na = (u + 1) % MD_ADEPTH;
+        compute(cur);
+        if (step + 1 < nsteps) {
+          store_a(std::integral_constant<int, na>{}, cur ^ 1);
+          store_b(std::integral_constant<int, nb>{}, cur ^ 1);
+          if (step + 1 + MD_ADEPTH < nsteps) load_a(k0 + step + 1 + MD_ADEPTH, std::integral_constant<int, na>{});
+          if (step + 1 + MD_BDEPTH < nsteps) load_b(k0 + step + 1 + MD_BDEPTH, std::integral_constant<int, nb>{});
+        }
+        __syncthreads();
+      }
+    });
+  }
+
+  // ---- a wave's result: acc[mi][nj][t] = y[m0 + wm * BM / 2 + 16 mi + r16][n0 + wn * 64 + 16 nj + 4 g4 + t] (partial over this block's k slice)
+  const int tile = tm * a.tiles_n + tn_all;
+  if (a.S > 1) {
+    constexpr size_t unit_bytes = (size_t)MI * 4 * 1024;  // one wave's partial of one slice
+    uint8_t* const strip = reinterpret_cast<uint8_t*>(a.slabs) + ((size_t)tile * a.S * 4 + wave) * unit_bytes;  // slice 0 of this quadrant
+    const size_t slice_stride = (size_t)4 * unit_bytes;
+    {
+      const auto mine = __builtin_amdgcn_make_buffer_rsrc(strip + (size_t)slice * slice_stride, 0, (int)unit_bytes, 0x00020000);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wl_v4u, acc[mi][nj]), mine, ((mi * 4 + nj) * 64 + lane) * 16, 0, /*sc1*/ 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left before the ticket is taken
+    int t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(a.tickets + tile * 4 + wave, 1, FFQ_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t != a.S - 1) return;  // somebody else finishes this quadrant
+    if (lane == 0) __hip_atomic_store(a.tickets + tile * 4 + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
+    asm volatile("" ::: "memory");  // the partials are read after the ticket said everybody has written
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = wl_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int sl = 0; sl < a.S; ++sl) {  // slice order, whoever reduces: the sum is a function of the plan alone
+      const auto peer = __builtin_amdgcn_make_buffer_rsrc(strip + (size_t)sl * slice_stride, 0, (int)unit_bytes, 0x00020000);
+      wl_v4u got[MI][4];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) got[mi][nj] = __builtin_amdgcn_raw_buffer_load_b128(peer, ((mi * 4 + nj) * 64 + lane) * 16, 0, /*sc1*/ 16);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+          const wl_v4f g = __builtin_bit_cast(wl_v4f, got[mi][nj]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mi][nj][e] = acc[mi][nj][e] + g[e];
+        }
+    }
+  }
+  // ---- epilogue: bias, cast, 4 consecutive columns per lane and row
+  void* const out = seg == 0 ? a.out[0] : seg == 1 ? a.out[1] : a.out[2];
+  const bool rows_by_4 = (rows & 3) == 0;
+#pragma unroll
+  for (int nj = 0; nj < 4; ++nj) {
+    const int ncol = n0 + wn * 64 + 16 * nj + 4 * (int)g4;
+    if (ncol >= rows) continue;
+    float b4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b4[e] = ncol + e < rows ? (float)load_any(a.bias, a.bias_dt, ncol + e) : 0.0f;
+    }
+    const bool whole = ncol + 4 <= rows && rows_by_4;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * (BM / 2) + 16 * mi + (int)r16;
+      if (m >= a.M) continue;
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = a.bias ? acc[mi][nj][e] + b4[e] : acc[mi][nj][e];
+      const size_t at = (size_t)m * (size_t)rows + (size_t)ncol;
+      if (a.out_dt == FFQ_BF16) {
+        bf16_t* o = static_cast<bf16_t*>(out) + at;
+        if (whole) {
+          u32x2 pk;
+          pk.x = pack2<bf16_t>(y[0], y[1]);
+          pk.y = pack2<bf16_t>(y[2], y[3]);
+          *reinterpret_cast<u32x2*>(o) = pk;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ncol + e < rows) o[e] = from_f32<bf16_t>(y[e]);
+        }
+      } else {
+        float* o = static_cast<float*>(out) + at;
+        if (whole) {
+          *reinterpret_cast<wl_v4f*>(o) = wl_v4f{y[0], y[1], y[2], y[3]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ncol + e < rows) o[e] = y[e];
+        }
+      }
+    }
+  }
+}
+
+// ---- the plan ---------------------------------------------------------------------------------------------------------------------
+// Everything below is a function of (M, N, K) alone — not of the container, the packing block or the group size: every storage form
+// of one weight takes the same tiles, the same K slices and the same summation order.
+static int md_bm(int64_t M) { return M <= 64 ? 64 : 128; }
+static int64_t md_tiles_m(int64_t M) { return (M + md_bm(M) - 1) / md_bm(M); }
+static int64_t md_tiles_n(int64_t N) { return (N + MD_BN - 1) / MD_BN; }
+
+bool wq_mid_shape_ok(int64_t M, int64_t K) { return M >= 1 && M <= WQ_MID_MAX_M && K % 64 == 0 && K >= 128; }
+
+// K slices: enough units for two blocks on every CU where the K range allows (a slice keeps at least 8 super-steps: the code stream
+// runs 4 ahead), no more than 8 (the last arriver of a quadrant reads S partials)
+int wq_mid_split(int64_t M, int64_t N, int64_t K) {
+  if (!wq_mid_shape_ok(M, K)) return 1;
+  const int64_t tiles = md_tiles_m(M) * md_tiles_n(N), ksuper = K / 64;
+  const int64_t want = (int64_t)wq_cus() * WQ_MID_BLOCKS_PER_CU;
+  int64_t S = tiles >= want ? 1 : (want + tiles - 1) / tiles;
+  // half-filled is better than a deeper cut: 1.5 blocks per CU without an exchange beat 2 with one
+  if (S > 1 && tiles * (S - 1) >= (int64_t)wq_cus() * 3 / 2) --S;
+  if (S > 8) S = 8;
+  if (S > ksuper / 8) S = ksuper / 8;
+  return S < 1 ? 1 : (int)S;
+}
+
+// ticket words: one per (tile, wave), for the widest launch of this (M, N, K): three matrices, each rounded up to whole tiles
+int64_t wq_mid_tickets(int64_t M, int64_t N, int64_t K) {
+  if (!wq_mid_shape_ok(M, K)) return 0;
+  return md_tiles_m(M) * (md_tiles_n(N) + 2) * 4;
+}
+
+size_t wq_mid_slab_bytes(int64_t M, int64_t N, int64_t K, int64_t split) {
+  if (!wq_mid_shape_ok(M, K) || split <= 1) return 0;
+  return (size_t)(md_tiles_m(M) * (md_tiles_n(N) + 2)) * (size_t)split * (size_t)md_bm(M) * MD_BN * 4u;
+}
+
+bool wq_mid_applies(const WLinearArgs& a) {
+  if (generic_kernels_forced()) return false;  // tests: the 256-row-tile kernel on the same operands (ffq_force_generic_kernels)
+  if (!wq_mid_shape_ok(a.M, a.K)) return false;
+  for (int i = 0; i < 2; ++i)
+    if (a.seg_n[i + 1] > 0 && a.seg_n[i] % MD_BN != 0) return false;  // every matrix but the last: whole column tiles
+  return true;
+}
+
+template <int BKIND, bool GROUPED, bool OFFSET>
+static void md_launch(const MidArgs& m, int bm, unsigned grid, hipStream_t stream) {
+#define FFQ_MD(BM_)                                                                                                      \
+  do {                                                                                                                   \
+    static uint64_t attr_set = 0;                                                                                        \
+    const int lds_bytes = 2 * (BM_ * 128 + MD_BN * 128);                                                                 \
+    ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_mid_kernel<BKIND, GROUPED, OFFSET, BM_>), lds_bytes); \
+    wq_mid_kernel<BKIND, GROUPED, OFFSET, BM_><<<grid, 256, lds_bytes, stream>>>(m);                                      \
+  } while (0)
+  if (bm == 64) FFQ_MD(64); else FFQ_MD(128);
+#undef FFQ_MD
+}
+
+int wq_mid_launch(const WLinearArgs& a, int w_dt, int64_t group, int64_t split, void* workspace, size_t workspace_bytes, int32_t* tickets,
+                  hipStream_t stream) {
+  MidArgs m;
+  m.x = a.x;
+  m.w[0] = a.w; m.scale[0] = a.w_scale; m.offset[0] = a.w_offset; m.out[0] = a.out;
+  int64_t N = 0, tiles_n = 0;
+  for (int i = 0; i < 3; ++i) {
+    m.seg_n[i] = a.seg_n[i];
+    m.seg_tile[i] = i == 0 ? 0 : (a.seg_n[i] > 0 ? (int)tiles_n : INT32_MAX);
+    if (i > 0) { m.w[i] = a.seg_w[i - 1]; m.scale[i] = a.seg_scale[i - 1]; m.offset[i] = a.seg_offset[i - 1]; m.out[i] = a.seg_out[i - 1]; }
+    N += a.seg_n[i];
+    tiles_n += md_tiles_n(a.seg_n[i]);
+  }
+  m.bias = a.bias; m.bias_dt = a.bias_dt; m.out_dt = a.out_dt;
+  m.M = a.M; m.K = a.K;
+  m.tiles_m = (int)md_tiles_m(a.M); m.tiles_n = (int)tiles_n;
+  m.groups = a.groups; m.steps_per_group = (int)(group / 64); m.per_row = a.per_row; m.pack_shift = a.pack_shift;
+  const int64_t ksuper = a.K / 64;
+  int64_t S = split > 0 ? split : wq_mid_split(a.M, N, a.K);
+  if (S > ksuper) {
+    if (split > 0) return fail(FFQ_ERR_ARG, "weight-only linear (128-column tiles): split %lld exceeds the %lld super-steps of 64 along K", (long long)split, (long long)ksuper);
+    S = ksuper;
+  }
+  const int bm = md_bm(a.M);
+  const int64_t tiles = (int64_t)m.tiles_m * tiles_n;
+  const size_t slab = S > 1 ? (size_t)tiles * (size_t)S * (size_t)bm * MD_BN * 4u : 0;
+  if (S > 1 && (!tickets || !workspace || workspace_bytes < slab || !aligned16(workspace))) {
+    if (split > 1) return fail(FFQ_ERR_ARG, "weight-only linear (128-column tiles): split %lld needs %zu bytes of workspace and a ticket buffer", (long long)S, slab);
+    S = 1;  // the plan is a preference: without scratch every block walks the whole K range
+  }
+  m.S = (int)S;
+  m.slabs = S > 1 ? static_cast<float*>(workspace) : nullptr;
+  m.tickets = S > 1 ? tickets : nullptr;
+  const unsigned grid = (unsigned)(tiles * S);
+  const bool grouped = a.groups > 1, offset = a.w_offset != nullptr;
+#define FFQ_MD_T(BK)                                                                                                                     \
+  do {                                                                                                                                   \
+    if (grouped) { if (offset) md_launch<BK, true, true>(m, bm, grid, stream); else md_launch<BK, true, false>(m, bm, grid, stream); }     \
+    else { if (offset) md_launch<BK, false, true>(m, bm, grid, stream); else md_launch<BK, false, false>(m, bm, grid, stream); }           \
+  } while (0)
+  if (w_dt == FFQ_U8) FFQ_MD_T(WL_B_I4); else FFQ_MD_T(WL_B_I8);
+#undef FFQ_MD_T
+  return check_launch("wq_mid_kernel");
+}
+
+}  // namespace ffq

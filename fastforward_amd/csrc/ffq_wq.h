@@ -1,5 +1,5 @@
-// ffq_wq.h — what the two weight-only GEMM translation units share (ffq_wlinear.hip: 256 x 256 tiles; ffq_wskinny.hip: up to 128
-// token rows): vector types, the launch arguments, A2 of four codes, the plan queries.
+// ffq_wq.h — what the three weight-only GEMM translation units share (ffq_wlinear.hip: 256 x 256 tiles; ffq_wmid.hip: 128-column tiles
+// for up to 512 token rows; ffq_wskinny.hip: up to 128 token rows): vector types, the launch arguments, A2 of four codes, the plan queries.
 #pragma once
 #include "ffq_common.h"
 #include "ffq_vec.h"
@@ -75,5 +75,19 @@ size_t wq_skinny_slab_bytes(int64_t M, int64_t N, int64_t K, int64_t split);
 int wq_skinny_launch(const WLinearArgs& a, int w_dt, int64_t pack_block, int64_t group, int64_t split, void* workspace, size_t workspace_bytes,
                      int32_t* tickets, hipStream_t stream);
 int wq_cus();
+
+// ---- 128-column tiles (ffq_wmid.hip): M <= 512 rows, plain launches, every storage form -------------------------------------------
+#ifndef FFQ_MID_MIN_M
+#define FFQ_MID_MIN_M 17     // token rows from which the 128-column tiles are preferred to the skinny form (A/B hook: tools/build_variant.sh)
+#endif
+constexpr int64_t WQ_MID_MAX_M = 512;      // beyond: the 256-row tiles of ffq_wlinear.hip
+constexpr int WQ_MID_BLOCKS_PER_CU = 2;
+bool wq_mid_shape_ok(int64_t M, int64_t K);
+bool wq_mid_applies(const WLinearArgs& a);
+int wq_mid_split(int64_t M, int64_t N, int64_t K);
+int64_t wq_mid_tickets(int64_t M, int64_t N, int64_t K);
+size_t wq_mid_slab_bytes(int64_t M, int64_t N, int64_t K, int64_t split);
+int wq_mid_launch(const WLinearArgs& a, int w_dt, int64_t group, int64_t split, void* workspace, size_t workspace_bytes, int32_t* tickets,
+                  hipStream_t stream);
 
 }  // namespace ffq

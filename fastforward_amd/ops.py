@@ -1186,7 +1186,8 @@ def _wq_scratch(lib: Any, M: int, N: int, K: int, mlp: bool, two_pass: bool | No
     else:  # the library's rule: its figure minus the slabs of its own plan
         full = int(lib.ffq_mlp_gate_up_wq_workspace_bytes(M, N, K) if mlp else lib.ffq_linear_wq_workspace_bytes(M, N, K))
         image = full - int(lib.ffq_linear_wq_slab_bytes(M, N, K, int(mlp), plan))
-    return slabs + image, (_tickets(tickets, device, stream) if use > 1 else None)
+    # (tickets whenever slabs are offered: where the preferred form declines the weight's storage, the form that takes over has a plan of its own)
+    return slabs + image, (_tickets(tickets, device, stream) if (use > 1 or slabs > 0) and tickets > 0 else None)
 
 
 def mlp_gate_up_wq(

@@ -4,7 +4,7 @@ weight codes) against
     ops.dequantize_by_tile produces bit for bit — within one output rounding,
   * exact values where every partial sum is exact in fp32 (small integers x power-of-two scales): any summation order, any split,
   * the 256-row-tile kernel on the same operands (ffq_force_generic_kernels selects it),
-at T in {1, 7, 64, 128} (skinny) and {300, 512} (256-row tiles: the boundary), for int8 containers and packed nibbles, per-tensor /
+at T in {1, 7, 16} (skinny), {17 ... 512} (the 128-column tiles of csrc/ffq_wmid.hip since round 6; exactness also at 129, 300, 512 under every split), for int8 containers and packed nibbles, per-tensor /
 per-channel / group-128 parameters, offsets, bias, f32 output, ragged N, one to three weight matrices in one launch, every forced split,
 repeated launches (a race hunt over the ticketed split-K reduction) and a hipGraph replay.
 """
@@ -60,7 +60,7 @@ def test_weight_only_linear_at_few_rows_matches_float64_of_the_same_operands(tok
             assert torch.equal(from_codes, from_nibbles), "packed nibbles and int8 containers of the same codes disagree"
 
 
-@pytest.mark.parametrize("tokens", [1, 7, 64, 128])
+@pytest.mark.parametrize("tokens", [1, 7, 17, 64, 128, 129, 300, 512])
 def test_skinny_form_is_exact_where_the_sum_is_order_independent(tokens):
     """Small-integer activations x integer codes x power-of-two scales: every product and partial sum is exact in fp32, so the result
     must equal the float64 value bit for bit — whatever the split, for every storage form, bias and f32 output included — and the

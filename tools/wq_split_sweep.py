@@ -27,12 +27,21 @@ for T in [int(a) for a in sys.argv[1:] if a.isdigit()] or [2048]:
         plan = int(lib.ffq_linear_wq_split(T, n, k, 0))
         row = []
         for split in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
-            if split > (k // 64) // 4 or (T + 255) // 256 * ((n + 255) // 256) * split > torch.cuda.get_device_properties(0).multi_processor_count:
-                continue  # all units of a tile must be resident at once
-            ms = event_time_ms(lambda r: ops.linear_wq(x, codes8, s8, None, two_pass=False, split=split), iters=5, reps=4)
+            if split > (k // 64) // 4 or split > 16:
+                continue
+            try:  # (a form declines a split it cannot run: the 256-row tiles need all units of a tile resident at once)
+                ms = event_time_ms(lambda r: ops.linear_wq(x, codes8, s8, None, two_pass=False, split=split), iters=5, reps=4)
+            except Exception:  # noqa: BLE001
+                continue
             row.append(f"S={split}{'*' if split == plan else ''} {ms * 1e3:.1f}us {f / ms / 1e9:.0f}TF")
         ms = event_time_ms(lambda r: ops.linear_wq(x, codes8, s8, None), iters=5, reps=4)
         row.append(f"default {ms * 1e3:.1f}us {f / ms / 1e9:.0f}TF")
+        previous = lib.ffq_force_generic_kernels(1)  # the 256-row tiles with their own plan (what every launch above 128 rows took up to round 5)
+        try:
+            ms = event_time_ms(lambda r: ops.linear_wq(x, codes8, s8, None), iters=5, reps=4)
+        finally:
+            lib.ffq_force_generic_kernels(previous)
+        row.append(f"256-row tiles {ms * 1e3:.1f}us {f / ms / 1e9:.0f}TF")
         ms = event_time_ms(lambda r: torch.nn.functional.linear(x, w8), iters=5, reps=4)
         row.append(f"vendor {ms * 1e3:.1f}us {f / ms / 1e9:.0f}TF")
         ms = event_time_ms(lambda r: torch.nn.functional.linear(x, ops.dequantize_by_tile(codes8, s8, (1, k), None, torch.bfloat16)), iters=5, reps=4)
