@@ -24,11 +24,28 @@ from fastforward_amd.exceptions import QuantizationError
 from fastforward_amd.quantization.tiled_tensor import rows_to_tiles, tiles_to_rows
 
 
+# explicit mantissa bits by torch.finfo(...).dtype name; complex dtypes report their component's name
+_MANTISSA_BITS = {"bfloat16": 7, "float16": 10, "float32": 23, "float64": 52,
+                  "float8_e4m3fn": 3, "float8_e4m3fnuz": 3, "float8_e5m2": 2, "float8_e5m2fnuz": 2}
+
+
 def can_support_bitwidth(dtype: torch.dtype, num_bits: float) -> bool:
-    """reference _quantizer_impl.py:44-75: mantissa bits + 2 (floats) or the integer width must cover `num_bits`."""
-    if dtype.is_floating_point:
-        return torch.finfo(dtype).bits - 1 - {torch.bfloat16: 8, torch.float16: 5, torch.float32: 8, torch.float64: 11}[dtype] + 2 >= num_bits
-    return torch.iinfo(dtype).bits + 2 >= num_bits
+    """reference _quantizer_impl.py:44-75: the container's precision bits + 2 (the first unrepresentable integer lies beyond
+    2^(mantissa + 1), and the sign is a bit of its own) must cover `num_bits`; precision bits = explicit mantissa of a float
+    (fp8 variants included, complex dtypes by their component), the width of an integer type, and — a float type the table does
+    not know — `num_bits` itself, with a warning, as the reference decides."""
+    if dtype.is_complex or dtype.is_floating_point:
+        name = torch.finfo(dtype).dtype
+        if name in _MANTISSA_BITS:
+            precision = _MANTISSA_BITS[name]
+        else:
+            import logging
+
+            logging.getLogger(__name__).warning(f"Unknown mantissa size for {dtype}; precision loss possible.")
+            precision = num_bits
+    else:
+        precision = torch.iinfo(dtype).bits
+    return precision + 2 >= num_bits
 
 
 def _params(scale: torch.Tensor, offset: torch.Tensor | None, rows: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:

@@ -45,6 +45,7 @@ struct LinearArgs {
   const float* x_scale; const float* x_offset;
   const float* w_scale; const float* w_offset;
   const int32_t* rowsum_x; const int32_t* rowsum_w;
+  int rowsum_w_inside;  // tail kernel: no side reduction — every block sums the codes of its own 128 weight rows as they pass through its registers
   // persistent kernel with a weight offset: 0 = every rounded weight offset is zero (rowsum_x was not produced and is
   // not read); written by offsets_nonzero_kernel ahead of the launch — no host read of the offsets anywhere
   const int32_t* woff_live;
@@ -142,6 +143,20 @@ __global__ __launch_bounds__(256) void w8a8_gemm_kernel(LinearArgs a) {
 
   const int ksteps = (a.K + BK - 1) / BK;
   u32x4 ra0, ra1, rb0, rb1;
+  // rowsum_w_inside: sum_k wq[n, k] of the block's own weight rows (the zero-point term ox * sum_k wq) from the staging registers —
+  // 8 byte-sum instructions per 64-deep step beside 8 MFMAs, instead of a launch of its own ahead of this one (a small eager
+  // linear costs the host one launch less: bench.py host_us_per_op). Rows past N and bytes past K were loaded as zeros.
+  int rs0 = 0, rs1 = 0;
+  auto add_rowsums = [&]() {
+    if (a.rowsum_w_inside) {
+      const uint32_t w0[4] = {rb0.x, rb0.y, rb0.z, rb0.w}, w1[4] = {rb1.x, rb1.y, rb1.z, rb1.w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        rs0 = __builtin_amdgcn_sdot4((int)w0[d], 0x01010101, rs0, false);
+        rs1 = __builtin_amdgcn_sdot4((int)w1[d], 0x01010101, rs1, false);
+      }
+    }
+  };
   auto fetch = [&](int kt) {
     const int kb = kt * BK + s_slot * 16;
     ra0 = load_slot(a.xq, m0 + s_row0, a.M, kb, a.K);
@@ -157,6 +172,7 @@ __global__ __launch_bounds__(256) void w8a8_gemm_kernel(LinearArgs a) {
   };
 
   fetch(0);
+  add_rowsums();
   stash(0);
   __syncthreads();
 
@@ -183,7 +199,14 @@ __global__ __launch_bounds__(256) void w8a8_gemm_kernel(LinearArgs a) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < ksteps) stash(cur ^ 1);
+    if (kt + 1 < ksteps) { add_rowsums(); stash(cur ^ 1); }
+    __syncthreads();
+  }
+  __shared__ int rowsum_s[BN];
+  if (a.rowsum_w_inside) {  // the four lanes that staged a row's four 16-byte slots meet; block-uniform branch
+    rs0 += __shfl_xor(rs0, 1, 64); rs0 += __shfl_xor(rs0, 2, 64);
+    rs1 += __shfl_xor(rs1, 1, 64); rs1 += __shfl_xor(rs1, 2, 64);
+    if (s_slot == 0) { rowsum_s[s_row0] = rs0; rowsum_s[s_row1] = rs1; }
     __syncthreads();
   }
 
@@ -201,7 +224,7 @@ __global__ __launch_bounds__(256) void w8a8_gemm_kernel(LinearArgs a) {
     if (n >= a.N) continue;
     const float sw = a.w_scale[a.w_per_row ? n : 0];
     const float ow = a.w_offset ? rne(a.w_offset[a.w_per_row ? n : 0]) : 0.0f;
-    const float rsw = a.rowsum_w ? (float)a.rowsum_w[n] : 0.0f;
+    const float rsw = a.rowsum_w_inside ? (float)rowsum_s[wn * 64 + j * 32 + (lane & 31)] : a.rowsum_w ? (float)a.rowsum_w[n] : 0.0f;
     const float bias = a.bias ? (float)load_any(a.bias, a.bias_dt, n) : 0.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1044,7 +1067,7 @@ static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w
   a.xq = xq; a.wq = wq;
   a.x_scale = x_scale; a.x_offset = x_offset;
   a.w_scale = w_scale; a.w_offset = w_offset;
-  a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.woff_live = nullptr;
+  a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.woff_live = nullptr; a.rowsum_w_inside = 0;
   a.wq2 = nullptr; a.w_scale2 = nullptr; a.rowsum_w2 = nullptr;
   a.batch_x = a.batch_w = a.batch_out = 0;
   a.bias = bias; a.bias_dt = bias_dt;
@@ -1072,6 +1095,8 @@ static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w
   if (x_offset) {  // sum_k wq[n, k] for the zero-point term: one pass over the weight codes, unless the caller has them
     if (w_rowsum) {
       a.rowsum_w = w_rowsum;
+    } else if (!persistent) {
+      a.rowsum_w_inside = 1;  // the tail kernel sums its own weight rows (no launch ahead of it)
     } else {
       const bool with_flag = w_offset && persistent;  // the weight-offset decision rides in this launch
       rowsum_i8_kernel<<<(unsigned)((N + 3) / 4), 256, 0, s>>>(wq, (int)N, (int)K, ws + M, nullptr, with_flag ? w_offset : nullptr,
@@ -1240,7 +1265,7 @@ extern "C" int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_s
   a.xq = xq; a.wq = wq;
   a.x_scale = x_scale; a.x_offset = x_offset;
   a.w_scale = w_scale; a.w_offset = w_offset;
-  a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.woff_live = nullptr;
+  a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.woff_live = nullptr; a.rowsum_w_inside = 0;
   a.wq2 = nullptr; a.w_scale2 = nullptr; a.rowsum_w2 = nullptr;
   a.batch_x = M * K; a.batch_w = N * K; a.batch_out = M * N;
   a.gate = nullptr; a.extrema.words = nullptr; a.extrema.pair = nullptr; a.extrema.pair_dt = 0; a.run_if = nullptr; a.run_when = 0;
@@ -1255,10 +1280,7 @@ extern "C" int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_s
   a.group_m = GROUP_M2;
   a.group_cols = 0;
   int32_t* ws = static_cast<int32_t*>(workspace);
-  if (x_offset) {
-    rowsum_i8_kernel<<<(unsigned)((batch * N + 3) / 4), 256, 0, s>>>(wq, (int)(batch * N), (int)K, ws + batch * M, nullptr);
-    a.rowsum_w = ws + batch * M;
-  }
+  if (x_offset) a.rowsum_w_inside = 1;  // every block sums its own weight rows (w8a8_gemm_kernel)
   if (w_offset) {
     rowsum_i8_kernel<<<(unsigned)((batch * M + 3) / 4), 256, 0, s>>>(xq, (int)(batch * M), (int)K, ws, nullptr);
     a.rowsum_x = ws;
@@ -1315,7 +1337,7 @@ static int mlp_gate_up_w8a8_impl(const int8_t* xq, const int8_t* gate_wq, const 
   a.xq = xq; a.wq = gate_wq; a.wq2 = up_wq;
   a.x_scale = x_scale; a.x_offset = x_offset;
   a.w_scale = gate_w_scale; a.w_scale2 = up_w_scale; a.w_offset = nullptr;
-  a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.rowsum_w2 = nullptr; a.woff_live = nullptr;
+  a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.rowsum_w2 = nullptr; a.woff_live = nullptr; a.rowsum_w_inside = 0;
   a.batch_x = a.batch_w = a.batch_out = 0;
   a.gate = nullptr; a.extrema.words = extrema_words; a.extrema.pair = extrema_pair; a.extrema.pair_dt = FFQ_BF16;
   a.run_if = run_if; a.run_when = run_when;

@@ -890,7 +890,7 @@ __global__ __launch_bounds__(kBlock) void quantize_dynamic_rows_kernel(const TIn
                                                                        float* __restrict__ scale_out, float* __restrict__ offset_out,
                                                                        DynRowsArgs a, int32_t* __restrict__ ticket, uint32_t logical_blocks) {
   static_assert(P <= 64 || P == kBlock, "a group is part of a wave or the whole block");
-  static_assert(R == 1 || P == kBlock, "several tiles in flight: whole-block groups");
+  static_assert(R == 1 || P == kBlock || P == 64, "several tiles in flight: whole-block or whole-wave groups");
   constexpr int TILES_PER_BLOCK = kBlock / P;
   const uint32_t lane = threadIdx.x % P;
   [[maybe_unused]] int verdict = 0;     // DYN_SETTLE: one-sided?
@@ -1097,7 +1097,7 @@ static bool launch_dynamic_rows(const void* data, void* out, float* scale_out, f
   else if (chunks <= 64) FFQ_DYN(64, 1);
   else if (chunks <= 128) FFQ_DYN(64, 2);
 #if FFQ_DYN_WAVE_ROWS  // A/B: one wave per run up to 256 chunks (no block barrier, four loads in flight per lane)
-  else if (chunks <= 256) FFQ_DYN(64, 4);
+  else if (chunks <= 256) FFQ_DYN_R(64, 4, FFQ_DYN_ROWS_IN_FLIGHT);
 #else
   else if (chunks <= 256) FFQ_DYN_R(256, 1, FFQ_DYN_ROWS_IN_FLIGHT);
 #endif

@@ -29,12 +29,24 @@
 #include <math.h>
 
 #include <type_traits>
+#include <utility>
 
 namespace ffq {
 
 constexpr int MD_BN = 128;      // weight rows (output columns) per tile
-constexpr int MD_BDEPTH = 4;    // super-steps of code loads in flight (ring of registers)
-constexpr int MD_ADEPTH = 2;    // ... of activation loads
+#ifndef FFQ_MD_BDEPTH
+#define FFQ_MD_BDEPTH 4
+#endif
+#ifndef FFQ_MD_ADEPTH
+#define FFQ_MD_ADEPTH 2
+#endif
+constexpr int MD_BDEPTH = FFQ_MD_BDEPTH;  // super-steps of code loads in flight (ring of registers; A/B hook: tools/build_variant.sh)
+constexpr int MD_ADEPTH = FFQ_MD_ADEPTH;  // ... of activation loads
+constexpr int md_lcm(int a, int b) { int x = a; while (x % b) x += a; return x; }
+constexpr int MD_UNROLL = md_lcm(md_lcm(MD_BDEPTH, MD_ADEPTH), 2);  // steps after which (slot, code ring, activation ring) repeat
+
+template <typename F, int... I>
+__device__ __forceinline__ void md_each(F&& fn, std::integer_sequence<int, I...>) { (fn(std::integral_constant<int, I>{}), ...); }
 
 struct MidArgs {
   const uint8_t* x;
@@ -105,6 +117,10 @@ __global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
     s_ptr[j] = s_base + p_row;
     if constexpr (OFFSET) o_ptr[j] = o_base + p_row;
   }
+  // (scalars the stream lambdas use, copied out of the argument struct: with `a.pack_shift` named inside the unrolled ring hipcc kept
+  // the whole by-value struct in scratch memory for the nibble instantiations — 262 scratch instructions, found by tools/kernel_resources.py)
+  [[maybe_unused]] const uint32_t pack_shift = (uint32_t)a.pack_shift;
+  [[maybe_unused]] const int steps_per_group = a.steps_per_group;
   u32x4 xa[MD_ADEPTH][AP];
   u32x4 raw[MD_BDEPTH][2];
   [[maybe_unused]] uint32_t nib[MD_BDEPTH];  // WL_B_I4: 0 = the low nibbles of the bytes, 4 = the high ones
@@ -117,12 +133,12 @@ __global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
       if constexpr (OFFSET) o_row[j] = rne(o_ptr[j][0]);
     }
   }
-  auto load_a = [&](int ks, auto dc) {
+  auto load_a = [&](int ks, auto dc) __attribute__((always_inline)) {
     constexpr int d = decltype(dc)::value;
 #pragma unroll
     for (int i = 0; i < AP; ++i) xa[d][i] = *reinterpret_cast<const u32x4*>(x_ptr[i] + (size_t)ks * 128u);
   };
-  auto load_b = [&](int ks, auto dc) {
+  auto load_b = [&](int ks, auto dc) __attribute__((always_inline)) {
     constexpr int d = decltype(dc)::value;
     uint32_t byte0;
     if constexpr (BKIND == WL_B_I8) {
@@ -130,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
     } else {
       // codes kk .. kk + 15 of a row live in ONE half of ONE packing block (block >= 32): byte j of a block holds code j in its low and
       // code j + block / 2 in its high nibble (ffq_pack_int4, export/stages/gguf/_packing.py:44-53)
-      const uint32_t kk = (uint32_t)ks * 64u + c_piece * 16u, lb = (uint32_t)a.pack_shift;
+      const uint32_t kk = (uint32_t)ks * 64u + c_piece * 16u, lb = pack_shift;
       const uint32_t within = kk & ((1u << lb) - 1u);
       nib[d] = (within >> (lb - 1u)) * 4u;
       byte0 = ((kk >> lb) << (lb - 1u)) + (within & ((1u << (lb - 1u)) - 1u));
@@ -138,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) raw[d][j] = *reinterpret_cast<const u32x4*>(w_ptr[j] + byte0);
     if constexpr (GROUPED) {
-      const int grp = ks / a.steps_per_group;
+      const int grp = ks / steps_per_group;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         sc[d][j] = s_ptr[j][grp];
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
   };
   // registers -> the LDS images of `slot`: 16-byte slot q of row r lies at r * 128 + ((q ^ (r & 7)) << 4) (conflict-free stores and
   // fragment reads)
-  auto store_a = [&](auto dc, int slot) {
+  auto store_a = [&](auto dc, int slot) __attribute__((always_inline)) {
     constexpr int d = decltype(dc)::value;
     uint8_t* image = lds + slot * SLOT;
 #pragma unroll
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
       *reinterpret_cast<u32x4*>(image + row * 128u + ((((uint32_t)tid & 7u) ^ (row & 7u)) << 4)) = xa[d][i];
     }
   };
-  auto store_b = [&](auto dc, int slot) {
+  auto store_b = [&](auto dc, int slot) __attribute__((always_inline)) {
     constexpr int d = decltype(dc)::value;
     uint8_t* image = lds + slot * SLOT + A_IMAGE;
 #pragma unroll
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = wl_v4f{0.0f, 0.0f, 0.0f, 0.0f};
-  auto compute = [&](int slot) {
+  auto compute = [&](int slot) __attribute__((always_inline)) {
     const uint8_t* st = lds + slot * SLOT;
 #pragma unroll
     for (int kq = 0; kq < 2; ++kq) {
@@ -229,39 +245,40 @@ __global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
   // ---- the K-loop. Step i (super-step k0 + i) computes from LDS slot i % 2 while stage i + 1 goes from its registers into the other slot
   // (nobody reads that slot: its last readers passed the barrier behind step i - 1) and the registers just freed take the stage a ring
   // ahead; ONE barrier per step.
-  auto each_b = [&](auto&& fn) {
-    fn(std::integral_constant<int, 0>{});
-    fn(std::integral_constant<int, 1>{});
-    fn(std::integral_constant<int, 2>{});
-    fn(std::integral_constant<int, 3>{});
-  };
-  static_assert(MD_BDEPTH == 4 && MD_ADEPTH == 2, "the unrolled ring below");
-  each_b([&](auto dc) { if (decltype(dc)::value < nsteps) load_b(k0 + decltype(dc)::value, dc); });
-  load_a(k0, std::integral_constant<int, 0>{});
-  if (1 < nsteps) load_a(k0 + 1, std::integral_constant<int, 1>{});
+  auto each_b = [&](auto&& fn) { md_each(fn, std::make_integer_sequence<int, MD_BDEPTH>{}); };
+  auto each_u = [&](auto&& fn) { md_each(fn, std::make_integer_sequence<int, MD_UNROLL>{}); };
+  // Loads past the slice's last super-step are CLAMPED to it, never skipped: the loop body is straight-line code, so the compiler's
+  // wait insertion counts the loads in flight exactly (`s_waitcnt vmcnt(N)` with N = what was issued behind the stage being stored).
+  // A first version guarded every load with `if (step + depth < nsteps)`: the merged control flow made hipcc wait `vmcnt(0)` in every
+  // step — the newest code loads included, i.e. one HBM round trip per 64-k step (0.83 us per step, profiles/r06_wq_mid_sweep_v1.txt).
+  const int k_last = k1 - 1;
+  auto clamped = [&](int ks) __attribute__((always_inline)) { return ks < k_last ? ks : k_last; };
+  each_b([&](auto dc) { load_b(clamped(k0 + decltype(dc)::value), dc); });
+  md_each([&](auto dc) { load_a(clamped(k0 + decltype(dc)::value), dc); }, std::make_integer_sequence<int, MD_ADEPTH>{});
   store_a(std::integral_constant<int, 0>{}, 0);
   store_b(std::integral_constant<int, 0>{}, 0);
-  if (MD_ADEPTH < nsteps) load_a(k0 + MD_ADEPTH, std::integral_constant<int, 0>{});
-  if (MD_BDEPTH < nsteps) load_b(k0 + MD_BDEPTH, std::integral_constant<int, 0>{});
+  load_a(clamped(k0 + MD_ADEPTH), std::integral_constant<int, 0>{});
+  load_b(clamped(k0 + MD_BDEPTH), std::integral_constant<int, 0>{});
   __syncthreads();
-  for (int i = 0; i < nsteps; i += MD_BDEPTH) {
-    each_b([&](auto uc) {
-      constexpr int u = decltype(uc)::value;
-      const int step = i + u;
-      if (step < nsteps) {
-        constexpr int cur = u & 1;
-        constexpr int nb = (u + 1) % MD_BDEPTH, na = (u + 1) % MD_ADEPTH;
-        compute(cur);
-        if (step + 1 < nsteps) {
-          store_a(std::integral_constant<int, na>{}, cur ^ 1);
-          store_b(std::integral_constant<int, nb>{}, cur ^ 1);
-          if (step + 1 + MD_ADEPTH < nsteps) load_a(k0 + step + 1 + MD_ADEPTH, std::integral_constant<int, na>{});
-          if (step + 1 + MD_BDEPTH < nsteps) load_b(k0 + step + 1 + MD_BDEPTH, std::integral_constant<int, nb>{});
-        }
-        __syncthreads();
-      }
-    });
-  }
+  // step `step` = i + u: compute from slot u % 2; stage step + 1 goes from its registers into the other slot (when step + 1 is past the
+  // end: a copy of the last stage that nobody reads); the registers just freed take the stage a ring ahead
+  auto body = [&](int i, auto uc) __attribute__((always_inline)) {
+    constexpr int u = decltype(uc)::value;
+    constexpr int cur = u & 1;
+    constexpr int nb = (u + 1) % MD_BDEPTH, na = (u + 1) % MD_ADEPTH;
+    const int step = i + u;
+    compute(cur);
+    store_a(std::integral_constant<int, na>{}, cur ^ 1);
+    store_b(std::integral_constant<int, nb>{}, cur ^ 1);
+    load_a(clamped(k0 + step + 1 + MD_ADEPTH), std::integral_constant<int, na>{});
+    load_b(clamped(k0 + step + 1 + MD_BDEPTH), std::integral_constant<int, nb>{});
+    __syncthreads();
+  };
+  int i = 0;
+  for (; i + MD_UNROLL <= nsteps; i += MD_UNROLL) each_u([&](auto uc) { body(i, uc); });
+  each_u([&](auto uc) {  // the last nsteps % MD_UNROLL steps
+    if (i + decltype(uc)::value < nsteps) body(i, uc);
+  });
 
   // ---- a wave's result: acc[mi][nj][t] = y[m0 + wm * BM / 2 + 16 mi + r16][n0 + wn * 64 + 16 nj + 4 g4 + t] (partial over this block's k slice)
   const int tile = tm * a.tiles_n + tn_all;

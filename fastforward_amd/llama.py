@@ -407,6 +407,9 @@ def _w8a8_gate_up_product(x: torch.Tensor, gate_proj: torch.nn.Module, up_proj: 
         params.append(((xp.scale, xp.offset), (wp.scale, w_offset)))
     # up_proj's codes may be an undecided sibling's (``sibling_quantizers(undecided=True)``): the op reads gate_proj's codes wherever
     # the two input quantizers agree, which is exactly where those were left unwritten — provided gate_proj's ARE the earlier ones
+    # gate_proj's own codes may be an undecided sibling's too (an OUTER ``sibling_quantizers(undecided=True)`` scope that had quantized `x`
+    # before): they are handed to the op both as codes and as "the earlier codes", so they have to be written
+    RECENT.settle(pre[0][0])
     earlier = RECENT.earlier_of(pre[1][0])
     if earlier is not None and not (earlier[0].data_ptr() == pre[0][0].raw_data.data_ptr() and earlier[1] is params[0][0][0] and earlier[2] is params[0][0][1]):
         RECENT.settle(pre[1][0])

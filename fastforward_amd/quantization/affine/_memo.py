@@ -234,10 +234,20 @@ class RecentActivationCodes(threading.local):
         self._data, self._key, self._entries = None, (), []
         self._extrema = None
         marked, self._marked = self._marked, []
-        for ref in marked:  # codes that outlive the block are ordinary codes from here on
+        # codes that outlive the block are ordinary codes from here on. `clear` runs from the `finally` of `scope()`: one tensor whose
+        # parameters were rewritten (settle -> _checked raises) must neither leave the REST with unwritten codes nor mask the exception
+        # that is unwinding — every marked tensor is settled, the first failure is raised behind the loop
+        failure: RuntimeError | None = None
+        for ref in marked:
             quantized = ref()
-            if quantized is not None:
+            if quantized is None:
+                continue
+            try:
                 self.settle(quantized)
+            except RuntimeError as e:
+                failure = failure or e
+        if failure is not None:
+            raise failure
 
 
 RECENT = RecentActivationCodes()

@@ -71,7 +71,11 @@ class RunningMinMaxEstimator(_MinMaxState):
         estimator is the quantizer's only override, works sync-free and the quantizer offers ``update_range_and_quantize`` (per-channel /
         per-token / per-block tilings of a plain LinearQuantizer on the device): a weight is read once per calibration step
         instead of twice. Same running state, parameters, status flags and codes as the two steps."""
-        if self.sync_free and not self._disable_quantization and not kwargs and len(args) == 1 and isinstance(args[0], torch.Tensor):
+        # a subclass that overrides estimate_step / initialize_parameters (logging, clamping, an EMA on this class's state) must see
+        # every batch: the one-pass route is this class's own two steps fused, nothing else's (ADVICE r5)
+        own_steps = (type(self).estimate_step is RunningMinMaxEstimator.estimate_step
+                     and type(self).initialize_parameters is RunningMinMaxEstimator.initialize_parameters)
+        if own_steps and self.sync_free and not self._disable_quantization and not kwargs and len(args) == 1 and isinstance(args[0], torch.Tensor):
             fused = getattr(quantizer, "update_range_and_quantize", None)
             overrides = getattr(quantizer, "_quantizer_overrides", None)
             data = args[0]

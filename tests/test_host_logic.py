@@ -704,3 +704,26 @@ def test_marks_of_device_decided_siblings_are_settled_or_refused():
     with pytest.raises(RuntimeError, match="rewritten"):
         RECENT.settle(own)
     RECENT.clear()
+    # `clear` (the `finally` of `scope()`) settles EVERY marked tensor and raises the first failure behind the loop — one
+    # rewritten parameter must not leave the other marked tensors with unwritten codes
+    stale, fine = Holder(torch.zeros(32, dtype=torch.int8)), Holder(torch.full((32,), 7, dtype=torch.int8))
+    moved, kept = torch.tensor([0.5]), torch.tensor([0.5])
+    with pytest.raises(RuntimeError, match="rewritten"):
+        with RECENT.scope(undecided=True):
+            RECENT.mark_undecided(stale, (first, e_scale, e_offset), moved, None)
+            RECENT.mark_undecided(fine, (first, e_scale, e_offset), kept, torch.tensor([1.2]))
+            moved.mul_(2.0)
+    assert torch.equal(fine.raw_data, first) and getattr(fine, "_ffq_earlier", None) is None  # settled although its neighbour failed
+    RECENT.clear()
+
+
+def test_host_route_bit_width_rule_follows_the_reference_table():
+    """fastforward_amd/_host.py::can_support_bitwidth == reference _quantizer_impl.py:44-75 (mantissa + 2 for floats incl. the fp8
+    variants and complex dtypes by component, integer width + 2): the widest admitted and the first refused bit width per dtype."""
+    from fastforward_amd import _host
+
+    table = {torch.bfloat16: 9, torch.float16: 12, torch.float32: 25, torch.float64: 54, torch.float8_e4m3fn: 5, torch.float8_e4m3fnuz: 5,
+             torch.float8_e5m2: 4, torch.float8_e5m2fnuz: 4, torch.complex64: 25, torch.int8: 10, torch.int16: 18, torch.int32: 34, torch.uint8: 10}
+    for dtype, widest in table.items():
+        assert _host.can_support_bitwidth(dtype, widest) and _host.can_support_bitwidth(dtype, widest - 0.5), dtype
+        assert not _host.can_support_bitwidth(dtype, widest + 0.5), dtype

@@ -77,3 +77,14 @@ def test_the_one_wave_per_simd_k_loop_is_what_was_written():
     assert count("v_") - count("v_mfma") == 0  # buffer addressing: the piece and the super-step are in the scalar offset
     rows = [k for k in _kernels("wq_gemm4w_kernel")]
     assert len(rows) == 1 and rows[0]["agpr_count"] == 256
+
+
+def test_the_128_column_tile_kernels_keep_everything_in_registers_at_two_blocks_per_cu():
+    """wq_mid_kernel (csrc/ffq_wmid.hip): 16 instantiations, none with scratch memory (round 6 found hipcc keeping the by-value argument
+    struct and the register rings in scratch for the nibble forms until the stream lambdas were force-inlined), all within the 256
+    registers that two blocks per CU leave a wave."""
+    rows = _kernels("wq_mid_kernel")
+    assert len(rows) == 16
+    bad = {str(k["name"]): (k["vgpr_count"], k["vgpr_spill_count"], k["private_segment_fixed_size"]) for k in rows
+           if k["vgpr_spill_count"] or k["private_segment_fixed_size"] or k["vgpr_count"] + k["agpr_count"] > 256}
+    assert not bad, bad

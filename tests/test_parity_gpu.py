@@ -492,6 +492,38 @@ def test_estimator_step_and_quantize_in_one_pass(shape, gran, dtype, symmetric, 
         assert int(buf.abs().sum()) == 0
 
 
+def test_an_estimator_subclass_that_overrides_a_step_sees_every_batch():
+    """the one-pass route of RunningMinMaxEstimator.forward (estimator step + A5 + A1 in one launch) is this class's own
+    two steps fused — a subclass that overrides estimate_step must be called for every batch, also in sync_free mode, and the
+    quantizer's parameters and codes must still be those of the two-step form."""
+    from fastforward_amd.range_setting.minmax import RunningMinMaxEstimator
+
+    seen = []
+
+    class Logging(RunningMinMaxEstimator):
+        def estimate_step(self, quantizer, data):
+            seen.append(tuple(data.shape))
+            super().estimate_step(quantizer, data)
+
+    torch.manual_seed(0)
+    batches = [torch.randn(64, 1024, device=DEV).to(torch.bfloat16) * (i + 1) for i in range(3)]
+
+    def run(estimator_cls):
+        quantizer = ff.nn.LinearQuantizer(8, granularity=ff.PerChannel(0), quantized_dtype=torch.int8, device=DEV)
+        handle = quantizer.register_override(estimator_cls(quantizer, sync_free=True))
+        try:
+            codes = [quantizer(x).raw_data.clone() for x in batches]
+        finally:
+            handle.remove()
+        return codes, quantizer.scale.detach().clone()
+
+    plain_codes, plain_scale = run(RunningMinMaxEstimator)
+    assert not seen
+    logged_codes, logged_scale = run(Logging)
+    assert seen == [(64, 1024)] * 3
+    assert torch.equal(plain_scale, logged_scale) and all(torch.equal(a, b) for a, b in zip(plain_codes, logged_codes))
+
+
 @pytest.mark.parametrize("ntiles", [8193, 20000, 458752])
 @pytest.mark.parametrize("range_dtype", [torch.float32, torch.bfloat16])
 def test_parameters_for_range_grid_form_matches_oracle(ntiles, range_dtype):
@@ -1020,15 +1052,15 @@ def test_weight_only_linear_matches_float64_of_the_same_operands(m, n, k, group,
     w_hat = ops.dequantize_by_tile(codes, scale, (1, group), off, torch.bfloat16)
     ref = x.double() @ w_hat.double().t() + (0 if b is None else b.double())
     rtol = 2.0**-8 if out_dtype == torch.bfloat16 else 1e-5
-    # Up to 128 rows the int8 container and nibbles packed with block 128 take the skinny kernel (csrc/ffq_wskinny.hip), other packing
-    # blocks the 256-row-tile kernel: forms agree bit for bit within a kernel (same operands, same walk, same summation order); across
-    # the two kernels only the fp32 summation order differs (include/ffq.h)
+    # Up to 16 rows the int8 container and nibbles packed with block 128 take the skinny kernel (csrc/ffq_wskinny.hip) where K % 128 == 0,
+    # everything else up to 512 rows the 128-column tiles (csrc/ffq_wmid.hip), beyond that the 256-row tiles: forms agree bit for bit
+    # within a kernel (same operands, same walk, same summation order); across kernels only the fp32 summation order differs (include/ffq.h)
     first: dict[bool, torch.Tensor] = {}
     for label, kwargs, weight in _wq_forms(codes, group, bits, m):
         y = ops.linear_wq(x, weight, scale, off, group=group, bias=b, out_dtype=out_dtype, **kwargs)
         assert y is not None and y.dtype == out_dtype and y.shape == (m, n), label
         torch.testing.assert_close(y.double(), ref, rtol=rtol, atol=1e-5 * float(ref.abs().max()) + 1e-6 * k, msg=lambda msg: f"{label}: {msg}")
-        skinny = m <= 128 and k % (128 if m <= 16 or m > 64 else 256) == 0 and kwargs.get("pack_block", 0) in (0, 128)
+        skinny = m <= 16 and k % 128 == 0 and kwargs.get("pack_block", 0) in (0, 128)
         assert torch.equal(y, first.setdefault(skinny, y)), f"{label} differs from the first form of its kernel"
 
 
@@ -1044,9 +1076,16 @@ def test_weight_only_gate_up_launch_is_the_two_linears_and_silu_mul(m, n, k, gro
     x = (torch.randn(m, k, generator=gen) * 1.5).to(torch.bfloat16).to(DEV)
     x[0, :] *= 40.0  # gate values outside the table's window on one row: the patch path
     # both sides on the K slices the one-launch form plans for itself: the split fixes the fp32 summation order (include/ffq.h)
-    split = int(_native.library().ffq_linear_wq_split(m, n, k, 1))
-    gate = ops.linear_wq(x, gc, gs, go, group=group, two_pass=False, split=split)
-    up = ops.linear_wq(x, uc, us, uo, group=group, two_pass=False, split=split)
+    # ... and on the kernel family the one-launch form belongs to, the 256-row tiles (up to 512 rows a plain launch takes the skinny form or
+    # the 128-column tiles otherwise, whose summation orders are their own)
+    lib = _native.library()
+    split = int(lib.ffq_linear_wq_split(m, n, k, 1))
+    previous = lib.ffq_force_generic_kernels(1)
+    try:
+        gate = ops.linear_wq(x, gc, gs, go, group=group, two_pass=False, split=split)
+        up = ops.linear_wq(x, uc, us, uo, group=group, two_pass=False, split=split)
+    finally:
+        lib.ffq_force_generic_kernels(previous)
     want, _ = ops.silu_mul_quantize(gate, up, (), want_product=True)
     assert float(want.float().abs().max()) > 0
     for (label, kwargs, gw), (_, _, uw) in zip(_wq_forms(gc, group, bits, m), _wq_forms(uc, group, bits, m)):
@@ -1064,8 +1103,9 @@ def test_weight_only_gate_up_launch_is_the_two_linears_and_silu_mul(m, n, k, gro
 @pytest.mark.parametrize("m,n,k,group,bits", [(1, 256, 2048, 2048, 8), (40, 520, 1024, 128, 4), (300, 256, 1536, 1536, 8), (515, 770, 2048, 128, 4), (2048, 1024, 4096, 4096, 8),
                                               (4352, 4096, 1024, 1024, 8), (4200, 4224, 768, 128, 4)])
 def test_weight_only_linear_split_k_slices_sum_in_a_fixed_order(m, n, k, group, bits, generic_kernels):
-    """(Up to 128 rows the product takes the skinny kernel, whose own split-K is covered by tests/test_skinny_gpu.py: those cases run
-    the 256-row-tile kernel here through the library's test hook, so its exchange stays covered at every row count.)
+    """(Up to 512 rows the product takes the skinny kernel or the 128-column tiles, whose own split-K is covered by tests/test_skinny_gpu.py
+    and tests/test_mid_gpu.py: those cases run the 256-row-tile kernel here through the library's test hook, so its exchange stays covered
+    at every row count.)
     Split-K (the tiles of the last, partly filled round of the persistent walk — all tiles when there are fewer than CUs — have
     their K range cut into slices; the units of a tile exchange fp32 partial sums and each finishes a fixed share in a fixed
     order): every forced split — incl. uneven slices, ragged M / N, whole rounds ahead of the split tail (272 tiles: 16 of them
@@ -1078,7 +1118,7 @@ def test_weight_only_linear_split_k_slices_sum_in_a_fixed_order(m, n, k, group, 
     w_hat = ops.dequantize_by_tile(codes, scale, (1, group), off, torch.bfloat16)
     ref = x.double() @ w_hat.double().t()
     lib = _native.library()
-    generic_kernels(m <= 128)
+    generic_kernels(m <= 512)
     plan = int(lib.ffq_linear_wq_split(m, n, k, 0))
     # all units of a tile wait for each other: a split is admitted while tiles * split <= CUs (and slices keep >= 2 super-steps)
     tail = int(lib.ffq_linear_wq_tickets(m, n, k, 0)) // 2  # tiles of the last round
@@ -1100,7 +1140,7 @@ def test_weight_only_linear_split_k_slices_sum_in_a_fixed_order(m, n, k, group, 
         if split > 1:
             # units that give up their wait (a peer that cannot become resident; here: every odd slice, at once, through the library's
             # test hook) publish all their pieces and leave; the last arriver finishes them in the same order: the same bits
-            previous = lib.ffq_force_generic_kernels(2 | int(m <= 128))
+            previous = lib.ffq_force_generic_kernels(2 | int(m <= 512))
             try:
                 for _ in range(3):
                     assert torch.equal(ops.linear_wq(x, codes, scale, off, group=group, split=split), y), f"split {split}: abandoned units change the result"
@@ -1145,9 +1185,9 @@ def test_weight_only_linears_on_one_input_as_one_launch(m, rows, k, group, bits,
     for label, kwargs, weights in forms:
         got = ops.linear_wq_multi(x, weights, scales, offs, group=group, split=1, **kwargs)
         assert got is not None and len(got) == len(rows), label
-        # the separate launches of the SAME storage form (up to 128 rows a packing block other than 128 takes the 256-row-tile kernel,
-        # the int8 container the skinny one: another summation order, include/ffq.h)
-        same_kernel = want if m > 128 or "pack_block" not in kwargs else [ops.linear_wq(x, w_, s_, o, group=group, split=1, **kwargs) for w_, (_, s_, o) in zip(weights, cases)]
+        # the separate launches of the SAME storage form (up to 16 rows a packing block other than 128 takes the 128-column tiles,
+        # the int8 container the skinny kernel: another summation order, include/ffq.h)
+        same_kernel = want if m > 16 or "pack_block" not in kwargs else [ops.linear_wq(x, w_, s_, o, group=group, split=1, **kwargs) for w_, (_, s_, o) in zip(weights, cases)]
         for g, w_, n in zip(got, same_kernel, rows):
             assert g.shape == (m, n) and torch.equal(g, w_), f"{label}: " + mismatch_report(g.cpu(), w_.cpu())
         for g, w_ in zip(got, want):
