@@ -380,7 +380,7 @@ def hbm_kernels(device: torch.device) -> list[dict]:
     add("running min/max per-channel bf16", "minmax_rows_kernel<bf16>", ("minmax_rows_kernel<ffq::bf16_t",), 2, lambda r: ops.minmax_by_tile(ws[r % 6], tile))
     # A3, per-token dynamic quantization of an activation [8, 2048, 4096] (asymmetric: min, max, A5, A1 in ONE launch, 2 R + 1 W)
     acts = [torch.randn(8, 2048, 4096, device=device, dtype=torch.bfloat16) for _ in range(5)]  # 5 x 134 MB > Infinity Cache
-    add("dynamic quantize per-token bf16->int8 [8,2048,4096] (A4 + A5 + A1, one launch)", "quantize_dynamic_rows_kernel<bf16,i8,16,256,1>", ("quantize_dynamic_rows_kernel<ffq::bf16_t, signed char",), 3,
+    add("dynamic quantize per-token bf16->int8 [8,2048,4096] (A4 + A5 + A1, one launch)", "quantize_dynamic_rows_kernel<bf16,i8,16,64,4> (one wave per row)", ("quantize_dynamic_rows_kernel<ffq::bf16_t, signed char",), 3,
         lambda r: ops.quantize_dynamic_by_tile(acts[r % 5], (1, 1, 4096), 8, False, True, torch.int8), n=8 * 2048 * 4096)
     del acts
     # producer-fused A1 on the same number of elements ([14336, 4096] read as 14336 rows of 4096)

@@ -849,7 +849,10 @@ static int parameters_impl(const void* min_range, const void* max_range, int ran
 // still sitting in registers are quantized with A1's arithmetic (ffq_affine.h) and stored: 2 R + 1 W = 3 B/elem.
 // Codes, scales and offsets are bit-identical to the composed form (same min / max, same A5 expression, same division).
 #ifndef FFQ_DYN_WAVE_ROWS
-#define FFQ_DYN_WAVE_ROWS 0
+#define FFQ_DYN_WAVE_ROWS 1  // 129..256-chunk runs (4096-wide rows into int8): 1 = one WAVE per run, no block barrier (round 6: 39.2 -> 37.7 us on
+#endif                       // [8, 2048, 4096], [4096, 4096] per channel 15.0 -> 14.0; two runs per wave 42.7, the block form with four in flight 44.8: profiles/r06_a3_variants.txt)
+#ifndef FFQ_DYN_WAVE_ROWS_IN_FLIGHT
+#define FFQ_DYN_WAVE_ROWS_IN_FLIGHT 1  // runs a wave of the wave-per-run plan works on at once (A/B: 1, 2)
 #endif
 #ifndef FFQ_DYN_ROWS_IN_FLIGHT
 #define FFQ_DYN_ROWS_IN_FLIGHT 2  // tiles a block of the 129..256-chunk plan works on at once (A/B: 1, 2, 4)
@@ -1097,7 +1100,7 @@ static bool launch_dynamic_rows(const void* data, void* out, float* scale_out, f
   else if (chunks <= 64) FFQ_DYN(64, 1);
   else if (chunks <= 128) FFQ_DYN(64, 2);
 #if FFQ_DYN_WAVE_ROWS  // A/B: one wave per run up to 256 chunks (no block barrier, four loads in flight per lane)
-  else if (chunks <= 256) FFQ_DYN_R(64, 4, FFQ_DYN_ROWS_IN_FLIGHT);
+  else if (chunks <= 256) FFQ_DYN_R(64, 4, FFQ_DYN_WAVE_ROWS_IN_FLIGHT);
 #else
   else if (chunks <= 256) FFQ_DYN_R(256, 1, FFQ_DYN_ROWS_IN_FLIGHT);
 #endif

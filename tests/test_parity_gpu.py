@@ -1121,9 +1121,10 @@ def test_weight_only_linear_split_k_slices_sum_in_a_fixed_order(m, n, k, group, 
     generic_kernels(m <= 512)
     plan = int(lib.ffq_linear_wq_split(m, n, k, 0))
     # all units of a tile wait for each other: a split is admitted while tiles * split <= CUs (and slices keep >= 2 super-steps)
-    tail = int(lib.ffq_linear_wq_tickets(m, n, k, 0)) // 2  # tiles of the last round
-    assert tail > 0
-    most = min(torch.cuda.get_device_properties(0).multi_processor_count // tail, (k // 64) // 2, 32)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tail = (-(-m // 256) * -(-n // 256)) % cus  # tiles of the last, partly filled round of the persistent walk
+    assert tail > 0 and int(lib.ffq_linear_wq_tickets(m, n, k, 0)) >= 2 * tail  # (the ticket figure is an upper bound over the forms)
+    most = min(cus // tail, (k // 64) // 2, 32)
     assert 1 <= plan <= most
     packed = ops.pack_int4(codes, block=128) if bits == 4 else None
     for split in sorted({1, 2, 3, 5, 8, 16, plan}):
