@@ -46,6 +46,7 @@ int fail(int code, const char* fmt, ...);
 // ffq_force_generic_kernels (include/ffq.h): the one-element-per-lane kernels instead of the streaming ones, for tests that
 // compare the two families. The library reads NO environment variables (tuning knobs exist only under -DFFQ_EXPERIMENTS).
 bool generic_kernels_forced();
+bool mid_register_form_forced();  // test hook (bit 2): the register-staged 128-column-tile kernel instead of the LDS-DMA one (ffq_wmid.hip)
 bool splitk_abandon_forced();  // test hook (bit 1 of ffq_force_generic_kernels): odd K slices of a split tile abandon their wait at once
 int check_launch(const char* what);
 

@@ -202,10 +202,12 @@ namespace ffq {
 static int g_force_generic = 0;
 bool generic_kernels_forced() { return (__atomic_load_n(&g_force_generic, __ATOMIC_RELAXED) & 1) != 0; }
 bool splitk_abandon_forced() { return (__atomic_load_n(&g_force_generic, __ATOMIC_RELAXED) & 2) != 0; }
+bool mid_register_form_forced() { return (__atomic_load_n(&g_force_generic, __ATOMIC_RELAXED) & 4) != 0; }
 }  // namespace ffq
 
 // bit 0: the generic kernel families; bit 1: every odd K slice of a split-K tile gives up waiting for its peers at once (the
-// path a unit takes when its peers cannot become resident: include/ffq.h, ffq_linear_wq)
+// path a unit takes when its peers cannot become resident: include/ffq.h, ffq_linear_wq); bit 2: the 128-column tiles of the
+// weight-only linear take their register-staged kernel where the LDS-DMA kernel would run (bit-equal results: ffq_wmid.hip)
 extern "C" int ffq_force_generic_kernels(int on) {
-  return __atomic_exchange_n(&ffq::g_force_generic, on & 3, __ATOMIC_RELAXED);
+  return __atomic_exchange_n(&ffq::g_force_generic, on & 7, __ATOMIC_RELAXED);
 }

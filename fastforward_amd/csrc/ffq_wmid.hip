@@ -369,6 +369,358 @@ __global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
   }
 }
 
+// ---- the LDS-DMA form (round 6, second version) ------------------------------------------------------------------------------------------
+// The register-staged kernel above is bound by its LDS STORES: 32 KiB per 64-k step and block go VGPR -> LDS through `ds_write_b128`
+// (13 cycles per wave-instruction, MI355X_MICROARCH.md "LDS"), 0.74 us per step measured with one block per CU against 0.27 for the step's
+// 32 MFMAs (profiles/r06_wq_mid_sweep_v2.txt). Here NOTHING is stored to LDS by a wave:
+//   * both operands arrive by LDS-DMA (`global_load_lds`, 16 bytes per lane straight from L2 / HBM into LDS) in a ring of MDD_RING
+//     stages of one 64-k super-step each — activations as they are (bf16, 128 bytes per row, XOR swizzle on the SOURCE address as in
+//     ffq_wlinear.hip), the weight CODES as they are stored (64 bytes per row: int8 containers, or the 64 packed bytes that hold the
+//     super-step's nibbles for packing blocks >= 128) and, for grouped parameters, each wave's 32 scales / offsets of the step's group:
+//     5 stages (122 KiB) in flight per CU without a single register, i.e. 1.2 - 1.5 us of prefetch distance at the MFMA-bound step rate;
+//   * a wave owns 32 output columns for ALL BM rows (4 waves side by side along N): lane (r, g) reads the 8 code bytes it multiplies
+//     (`ds_read_b64`, conflict-free under slot ^= ((row / 4) % 4) * 2), converts them with A2's arithmetic (dequantize4) INTO the MFMA's
+//     operand registers — every weight code is converted exactly once per row tile, by the wave that consumes it (no redundancy across
+//     waves, no LDS round trip of the bf16 image) — and 8 VALU conversions ride under each group of 8 (BM = 128) MFMAs;
+//   * one `s_waitcnt vmcnt(NI * (RING - 2))` + one raw barrier per step: the stage about to be computed has landed for every wave,
+//     and the slot computed a step ago is free for the stage RING - 1 ahead. The waits are written by hand (hipcc does not order
+//     `ds_read` behind LDS-DMA), every issue is unconditional (stages past the slice's end re-read its last stage), so the count of
+//     requests in flight is the same in every step.
+// Same tiles, same K slices, same k order inside a tile (k ascending in steps of 32) as the register-staged kernel: both give the
+// SAME bits for the same plan — and so do all storage forms (tests/test_mid_gpu.py). Packing blocks 32 / 64 (GGUF) keep the
+// register-staged kernel (their 64 codes of a step are 32 bytes holding both nibbles).
+#ifndef FFQ_MDD_RING
+#define FFQ_MDD_RING 6
+#endif
+constexpr int MDD_RING = FFQ_MDD_RING;
+
+template <int BKIND, bool GROUPED, bool OFFSET, int BM>
+__global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
+  constexpr int MI = BM / 16, NJ = 2;          // a wave: all BM rows x 32 columns
+  constexpr int A_BYTES = BM * 128, B_BYTES = MD_BN * 64, P_BYTES = GROUPED ? 4 * 256 : 0;
+  constexpr int STAGE = A_BYTES + B_BYTES + P_BYTES;
+  constexpr int APW = BM / 32;                 // 1 KiB activation pieces (8 rows) per wave and stage
+  constexpr int NI = APW + 2 + (GROUPED ? 1 : 0);  // LDS-DMA instructions per wave and stage
+  static_assert(NI * (MDD_RING - 2) <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t r16 = lane & 15, g4 = lane >> 4;
+
+  const int per_m = a.tiles_n * a.S;
+  const int tm = (int)blockIdx.x / per_m, rest = (int)blockIdx.x - tm * per_m;
+  const int tn_all = rest / a.S, slice = rest - tn_all * a.S;
+  const int seg = tn_all >= a.seg_tile[2] ? 2 : tn_all >= a.seg_tile[1] ? 1 : 0;
+  const uint8_t* const w_base = seg == 0 ? a.w[0] : seg == 1 ? a.w[1] : a.w[2];
+  const float* const s_base = seg == 0 ? a.scale[0] : seg == 1 ? a.scale[1] : a.scale[2];
+  const float* const o_base = seg == 0 ? a.offset[0] : seg == 1 ? a.offset[1] : a.offset[2];
+  const int rows = seg == 0 ? a.seg_n[0] : seg == 1 ? a.seg_n[1] : a.seg_n[2];
+  const int n0 = (tn_all - (seg == 0 ? 0 : seg == 1 ? a.seg_tile[1] : a.seg_tile[2])) * MD_BN;
+  const int m0 = tm * BM;
+  const int ksuper = a.K / 64;
+  const int k0 = (int)((int64_t)slice * ksuper / a.S), k1 = (int)((int64_t)(slice + 1) * ksuper / a.S);
+  const int nsteps = k1 - k0, k_last = k1 - 1;
+  const uint32_t pack_shift = (uint32_t)a.pack_shift;
+  const int steps_per_group = a.steps_per_group;
+
+  // ---- LDS-DMA sources (per lane, fixed for the tile). A piece = 8 rows x 128 bytes: lane L -> row L / 8, 16-byte chunk L % 8 of the
+  // LDS image, which holds logical chunk (L % 8) ^ ((row / 2) % 8). B piece = 16 rows x 64 bytes: lane L -> row L / 4, chunk L % 4
+  // of the image = logical chunk (L % 4) ^ ((row / 4) % 4). Rows past an edge re-read the last row and are never stored.
+  const uint8_t* a_src[APW];
+#pragma unroll
+  for (int c = 0; c < APW; ++c) {
+    const int row = (wave * APW + c) * 8 + (lane >> 3);
+    int m = m0 + row;
+    m = m < a.M ? m : a.M - 1;
+    a_src[c] = a.x + (size_t)m * (size_t)a.K * 2u + (size_t)((((uint32_t)lane & 7u) ^ (((uint32_t)row >> 1) & 7u)) << 4);
+  }
+  const uint32_t w_row_bytes = BKIND == WL_B_I8 ? (uint32_t)a.K : (uint32_t)a.K / 2u;
+  const uint8_t* b_src[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 16 + (lane >> 2);
+    int n = n0 + row;
+    n = n < rows ? n : rows - 1;
+    b_src[j] = w_base + (size_t)n * w_row_bytes + (size_t)((((uint32_t)lane & 3u) ^ (((uint32_t)row >> 2) & 3u)) << 4);
+  }
+  [[maybe_unused]] const float* p_src = nullptr;  // GROUPED: lanes 0-31 the scales of the wave's 32 rows, lanes 32-63 their offsets
+  float s_row[NJ] = {1.0f, 1.0f}, o_row[NJ] = {0.0f, 0.0f};
+  {
+    int n = n0 + wave * 32 + (lane & 31);
+    n = n < rows ? n : rows - 1;
+    const size_t p_row = a.per_row ? (size_t)n * (size_t)a.groups : 0;
+    if constexpr (GROUPED) p_src = ((OFFSET && lane >= 32) ? o_base : s_base) + p_row;
+  }
+  if constexpr (!GROUPED) {
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+      int n = n0 + wave * 32 + nj * 16 + (int)r16;
+      n = n < rows ? n : rows - 1;
+      const size_t p_row = a.per_row ? (size_t)n : 0;
+      s_row[nj] = s_base[p_row];
+      if constexpr (OFFSET) o_row[nj] = rne(o_base[p_row]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(s_row[0]), "+v"(s_row[1]), "+v"(o_row[0]), "+v"(o_row[1]) : : "memory");  // nothing of these in the loop's count
+  }
+  // first byte of super-step ks inside a row of codes (and, nibbles: which nibble holds them — one packing-block half spans >= 64 codes)
+  auto code_byte0 = [&](int ks, uint32_t& nib) __attribute__((always_inline)) -> uint32_t {
+    if constexpr (BKIND == WL_B_I8) {
+      nib = 0;
+      return (uint32_t)ks * 64u;
+    } else {
+      const uint32_t kk = (uint32_t)ks * 64u, lb = pack_shift;
+      const uint32_t within = kk & ((1u << lb) - 1u);
+      nib = (within >> (lb - 1u)) * 4u;
+      return ((kk >> lb) << (lb - 1u)) + (within & ((1u << (lb - 1u)) - 1u));
+    }
+  };
+  auto issue = [&](int ks, int slot) __attribute__((always_inline)) {
+    ks = ks < k_last ? ks : k_last;
+    uint8_t* base = lds + slot * STAGE;
+#pragma unroll
+    for (int c = 0; c < APW; ++c)
+      __builtin_amdgcn_global_load_lds((wl_gbl_t*)(a_src[c] + (size_t)ks * 128u), (wl_lds_t*)(base + (wave * APW + c) * 1024), 16, 0, 0);
+    uint32_t nib;
+    const uint32_t byte0 = code_byte0(ks, nib);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((wl_gbl_t*)(b_src[j] + byte0), (wl_lds_t*)(base + A_BYTES + (wave * 2 + j) * 1024), 16, 0, 0);
+    if constexpr (GROUPED)
+      __builtin_amdgcn_global_load_lds((wl_gbl_t*)(p_src + ks / steps_per_group), (wl_lds_t*)(base + A_BYTES + B_BYTES + wave * 256), 4, 0, 0);
+  };
+
+  // ---- fragment addresses inside a stage
+  uint32_t a_off[2], b_off[2];
+#pragma unroll
+  for (int kq = 0; kq < 2; ++kq) {
+    a_off[kq] = r16 * 128u + (((kq * 4u + g4) ^ ((r16 >> 1) & 7u)) << 4);
+    b_off[kq] = A_BYTES + ((uint32_t)wave * 32u + r16) * 64u + (((kq * 4u + g4) ^ (((r16 >> 2) & 3u) << 1)) << 3);
+  }
+  [[maybe_unused]] const uint32_t p_off = A_BYTES + B_BYTES + (uint32_t)wave * 256u + r16 * 4u;
+
+  wl_v4f acc[MI][NJ];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) acc[mi][nj] = wl_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+
+  // Fragment reads are inline assembly with hand-written waits: with LDS-DMA requests in flight hipcc puts `s_waitcnt lgkmcnt(0)` in front
+  // of the first use of ANY compiler-visible ds_read result (seen in the ISA of a first version: chunk 1's reads could not fly under chunk
+  // 0's MFMAs). A wait names the registers it guards as operands, which keeps their uses behind it.
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+#define MDD_READ128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define MDD_READ64(DST, ADDR, OFF) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define MDD_READ32(DST, ADDR, OFF) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+  auto compute = [&](int ks, int slot) __attribute__((always_inline)) {
+    const uint32_t st = lds_base + (uint32_t)slot * STAGE;
+    uint32_t nib;
+    (void)code_byte0(ks, nib);
+    float s[NJ], c[NJ];
+    wl_v4i fa[2][MI];
+    u32x2 codes[2][NJ];
+    // (macros, not lambdas: clang does not capture a variable that a nested generic lambda names only as an asm operand)
+#define MDD_READ_CHUNK(KQ)                                                                                       \
+  do {                                                                                                           \
+    const uint32_t b_addr = st + b_off[KQ], a_addr = st + a_off[KQ];                                             \
+    MDD_READ64(codes[KQ][0], b_addr, 0);                                                                         \
+    MDD_READ64(codes[KQ][1], b_addr, 1024);                                                                      \
+    MDD_READ128(fa[KQ][0], a_addr, 0 * 2048);                                                                    \
+    MDD_READ128(fa[KQ][1], a_addr, 1 * 2048);                                                                    \
+    MDD_READ128(fa[KQ][2], a_addr, 2 * 2048);                                                                    \
+    MDD_READ128(fa[KQ][3], a_addr, 3 * 2048);                                                                    \
+    if constexpr (MI == 8) {                                                                                     \
+      MDD_READ128(fa[KQ][MI - 4], a_addr, 4 * 2048);                                                             \
+      MDD_READ128(fa[KQ][MI - 3], a_addr, 5 * 2048);                                                             \
+      MDD_READ128(fa[KQ][MI - 2], a_addr, 6 * 2048);                                                             \
+      MDD_READ128(fa[KQ][MI - 1], a_addr, 7 * 2048);                                                             \
+    }                                                                                                            \
+  } while (0)
+    // everything read so far is back; the listed registers are defined HERE as far as the compiler is concerned
+#define MDD_WAIT(KQ)                                                                                                                            \
+  do {                                                                                                                                         \
+    if constexpr (MI == 8) {                                                                                                                   \
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[KQ][0]), "+v"(fa[KQ][1]), "+v"(fa[KQ][2]), "+v"(fa[KQ][3]), "+v"(fa[KQ][MI - 4]),           \
+                   "+v"(fa[KQ][MI - 3]), "+v"(fa[KQ][MI - 2]), "+v"(fa[KQ][MI - 1]), "+v"(codes[KQ][0]), "+v"(codes[KQ][1]), "+v"(s[0]),        \
+                   "+v"(s[1]), "+v"(c[0]), "+v"(c[1]) : : "memory");                                                                         \
+    } else {                                                                                                                                   \
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[KQ][0]), "+v"(fa[KQ][1]), "+v"(fa[KQ][2]), "+v"(fa[KQ][3]), "+v"(codes[KQ][0]),             \
+                   "+v"(codes[KQ][1]), "+v"(s[0]), "+v"(s[1]), "+v"(c[0]), "+v"(c[1]) : : "memory");                                          \
+    }                                                                                                                                          \
+  } while (0)
+    auto mfma_chunk = [&](auto kc) __attribute__((always_inline)) {
+      constexpr int kq = decltype(kc)::value;
+      wl_v4i fb[NJ];
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) {
+        uint32_t w[2] = {codes[kq][nj].x, codes[kq][nj].y};
+        float sv = s[nj], cv = OFFSET ? c[nj] : 0.0f;
+        if constexpr (BKIND == WL_B_I4) {
+          // nibble n = code + 8 -> (n ^ 8) << 4 in the byte's high half = 16 * code as a signed byte; (16 q + 16 o) * (s / 16) is (q + o) * s
+          // with the same single rounding wherever s / 16 is exact; a tiny scale takes the codes themselves (ffq_wlinear.hip)
+          const bool tiny = __builtin_fabsf(sv) < 0x1p-120f && sv != 0.0f;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            uint32_t b = (((w[q] >> nib) << 4) & 0xF0F0F0F0u) ^ 0x80808080u;
+            if (__builtin_expect(tiny, 0)) {
+              const uint32_t b0 = (uint32_t)(((int32_t)(b << 24)) >> 28) & 0xFFu, b1 = (uint32_t)(((int32_t)(b << 16)) >> 28) & 0xFFu;
+              const uint32_t b2 = (uint32_t)(((int32_t)(b << 8)) >> 28) & 0xFFu, b3 = (uint32_t)(((int32_t)b) >> 28) & 0xFFu;
+              b = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            }
+            w[q] = b;
+          }
+          if (!tiny) { sv = sv * 0.0625f; cv = cv * 16.0f; }
+        }
+        uint32_t o[4];
+        dequantize4<OFFSET>(w[0], sv, cv, o[0], o[1]);
+        dequantize4<OFFSET>(w[1], sv, cv, o[2], o[3]);
+        fb[nj] = wl_v4i{(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int n_ = 0; n_ < NJ; ++n_) {
+          const int nj = (mi & 1) ? NJ - 1 - n_ : n_;
+          acc[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wl_v8bf, fb[nj]), __builtin_bit_cast(wl_v8bf, fa[kq][mi]), acc[mi][nj], 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) { s[nj] = s_row[nj]; c[nj] = o_row[nj]; }
+    if constexpr (GROUPED) {  // the step's group parameters of this lane's two weight rows, from the stage's parameter strip
+      const uint32_t p_addr = st + p_off;
+      MDD_READ32(s[0], p_addr, 0);
+      MDD_READ32(s[1], p_addr, 64);
+      if constexpr (OFFSET) {
+        MDD_READ32(c[0], p_addr, 128);
+        MDD_READ32(c[1], p_addr, 128 + 64);
+      }
+    }
+    // (lgkmcnt is a 4-bit counter: a chunk's 10 reads + 4 parameter reads stay below 16 in flight)
+    MDD_READ_CHUNK(0);
+    MDD_WAIT(0);  // the one exposed LDS round trip of a step
+    if constexpr (GROUPED && OFFSET) {
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) c[nj] = rne(c[nj]);
+    }
+    MDD_READ_CHUNK(1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(std::integral_constant<int, 0>{});  // chunk 1's reads fly under these MFMAs and conversions
+    __builtin_amdgcn_sched_barrier(0);
+    MDD_WAIT(1);
+    mfma_chunk(std::integral_constant<int, 1>{});
+  };
+
+  // ---- the K-loop
+#pragma unroll
+  for (int st = 0; st < MDD_RING - 1; ++st) issue(k0 + st, st);
+  int slot = 0, slot_free = MDD_RING - 1;
+  for (int step = 0; step < nsteps; ++step) {
+    // this wave's pieces of stage `step` have landed (the RING - 2 younger stages may still fly); behind the barrier everybody's have,
+    // and everybody is done reading the slot computed a step ago
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NI * (MDD_RING - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issue(k0 + step + MDD_RING - 1, slot_free);
+    compute(k0 + step, slot);
+    slot_free = slot;
+    slot = slot + 1 == MDD_RING ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing requests must not outlive the block's LDS
+#undef MDD_WAIT
+#undef MDD_READ_CHUNK
+#undef MDD_READ128
+#undef MDD_READ64
+#undef MDD_READ32
+
+  // ---- a wave's result: acc[mi][nj][t] = y[m0 + 16 mi + r16][n0 + 32 wave + 16 nj + 4 g4 + t] (partial over this block's k slice)
+  const int tile = tm * a.tiles_n + tn_all;
+  if (a.S > 1) {
+    constexpr size_t unit_bytes = (size_t)MI * NJ * 1024;
+    uint8_t* const strip = reinterpret_cast<uint8_t*>(a.slabs) + ((size_t)tile * a.S * 4 + wave) * unit_bytes;
+    const size_t slice_stride = (size_t)4 * unit_bytes;
+    {
+      const auto mine = __builtin_amdgcn_make_buffer_rsrc(strip + (size_t)slice * slice_stride, 0, (int)unit_bytes, 0x00020000);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wl_v4u, acc[mi][nj]), mine, ((mi * NJ + nj) * 64 + lane) * 16, 0, /*sc1*/ 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left before the ticket is taken
+    int t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(a.tickets + tile * 4 + wave, 1, FFQ_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t != a.S - 1) return;  // somebody else finishes this strip
+    if (lane == 0) __hip_atomic_store(a.tickets + tile * 4 + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) acc[mi][nj] = wl_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int sl = 0; sl < a.S; ++sl) {  // slice order, whoever reduces
+      const auto peer = __builtin_amdgcn_make_buffer_rsrc(strip + (size_t)sl * slice_stride, 0, (int)unit_bytes, 0x00020000);
+      wl_v4u got[MI][NJ];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) got[mi][nj] = __builtin_amdgcn_raw_buffer_load_b128(peer, ((mi * NJ + nj) * 64 + lane) * 16, 0, /*sc1*/ 16);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+          const wl_v4f g = __builtin_bit_cast(wl_v4f, got[mi][nj]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mi][nj][e] = acc[mi][nj][e] + g[e];
+        }
+    }
+  }
+  // ---- epilogue: bias, cast, 4 consecutive columns per lane and row
+  void* const out = seg == 0 ? a.out[0] : seg == 1 ? a.out[1] : a.out[2];
+  const bool rows_by_4 = (rows & 3) == 0;
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj) {
+    const int ncol = n0 + wave * 32 + 16 * nj + 4 * (int)g4;
+    if (ncol >= rows) continue;
+    float b4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b4[e] = ncol + e < rows ? (float)load_any(a.bias, a.bias_dt, ncol + e) : 0.0f;
+    }
+    const bool whole = ncol + 4 <= rows && rows_by_4;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + 16 * mi + (int)r16;
+      if (m >= a.M) continue;
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = a.bias ? acc[mi][nj][e] + b4[e] : acc[mi][nj][e];
+      const size_t at = (size_t)m * (size_t)rows + (size_t)ncol;
+      if (a.out_dt == FFQ_BF16) {
+        bf16_t* o = static_cast<bf16_t*>(out) + at;
+        if (whole) {
+          u32x2 pk;
+          pk.x = pack2<bf16_t>(y[0], y[1]);
+          pk.y = pack2<bf16_t>(y[2], y[3]);
+          *reinterpret_cast<u32x2*>(o) = pk;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ncol + e < rows) o[e] = from_f32<bf16_t>(y[e]);
+        }
+      } else {
+        float* o = static_cast<float*>(out) + at;
+        if (whole) {
+          *reinterpret_cast<wl_v4f*>(o) = wl_v4f{y[0], y[1], y[2], y[3]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ncol + e < rows) o[e] = y[e];
+        }
+      }
+    }
+  }
+}
+
 // ---- the plan ---------------------------------------------------------------------------------------------------------------------
 // Everything below is a function of (M, N, K) alone — not of the container, the packing block or the group size: every storage form
 // of one weight takes the same tiles, the same K slices and the same summation order.
@@ -409,6 +761,29 @@ bool wq_mid_applies(const WLinearArgs& a) {
   for (int i = 0; i < 2; ++i)
     if (a.seg_n[i + 1] > 0 && a.seg_n[i] % MD_BN != 0) return false;  // every matrix but the last: whole column tiles
   return true;
+}
+
+// the LDS-DMA form covers int8 containers and nibbles whose packing-block half holds a whole 64-code super-step
+static bool md_takes_dma(int w_dt, int pack_shift) {
+#ifdef FFQ_MID_NO_DMA  // A/B builds (tools/build_variant.sh)
+  return false;
+#else
+  if (mid_register_form_forced()) return false;  // tests: the register-staged kernel on the same operands (ffq_force_generic_kernels bit 2)
+  return w_dt != FFQ_U8 || pack_shift >= 7;
+#endif
+}
+
+template <int BKIND, bool GROUPED, bool OFFSET>
+static void md_launch_dma(const MidArgs& m, int bm, unsigned grid, hipStream_t stream) {
+#define FFQ_MDD(BM_)                                                                                                         \
+  do {                                                                                                                       \
+    static uint64_t attr_set = 0;                                                                                            \
+    const int lds_bytes = MDD_RING * (BM_ * 128 + MD_BN * 64 + (GROUPED ? 1024 : 0));                                        \
+    ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_mid_dma_kernel<BKIND, GROUPED, OFFSET, BM_>), lds_bytes); \
+    wq_mid_dma_kernel<BKIND, GROUPED, OFFSET, BM_><<<grid, 256, lds_bytes, stream>>>(m);                                      \
+  } while (0)
+  if (bm == 64) FFQ_MDD(64); else FFQ_MDD(128);
+#undef FFQ_MDD
 }
 
 template <int BKIND, bool GROUPED, bool OFFSET>
@@ -464,6 +839,16 @@ int wq_mid_launch(const WLinearArgs& a, int w_dt, int64_t group, int64_t split, 
     if (grouped) { if (offset) md_launch<BK, true, true>(m, bm, grid, stream); else md_launch<BK, true, false>(m, bm, grid, stream); }     \
     else { if (offset) md_launch<BK, false, true>(m, bm, grid, stream); else md_launch<BK, false, false>(m, bm, grid, stream); }           \
   } while (0)
+  if (md_takes_dma(w_dt, a.pack_shift)) {
+#define FFQ_MDD_T(BK)                                                                                                                            \
+  do {                                                                                                                                           \
+    if (grouped) { if (offset) md_launch_dma<BK, true, true>(m, bm, grid, stream); else md_launch_dma<BK, true, false>(m, bm, grid, stream); }     \
+    else { if (offset) md_launch_dma<BK, false, true>(m, bm, grid, stream); else md_launch_dma<BK, false, false>(m, bm, grid, stream); }           \
+  } while (0)
+    if (w_dt == FFQ_U8) FFQ_MDD_T(WL_B_I4); else FFQ_MDD_T(WL_B_I8);
+#undef FFQ_MDD_T
+    return check_launch("wq_mid_dma_kernel");
+  }
   if (w_dt == FFQ_U8) FFQ_MD_T(WL_B_I4); else FFQ_MD_T(WL_B_I8);
 #undef FFQ_MD_T
   return check_launch("wq_mid_kernel");

@@ -598,7 +598,9 @@ int ffq_attention(const void* q, const void* k, const void* v, int dt, int64_t b
  * Test hook. The streaming kernels (fp32 parameters, one 16-byte chunk per lane, Markstein division) and the generic kernels
  * (any dtype mix / tiling, one element per lane, the compiler's IEEE division, every eager rounding reproduced) must agree
  * wherever both apply; ffq_force_generic_kernels(1) routes A1 / A2 / A4 to the generic family until it is called with 0 — and the
- * bf16-image form of ffq_linear_wq / ffq_mlp_gate_up_wq to its 8-wave kernel instead of the one-wave-per-SIMD one (bit-equal results).
+ * bf16-image form of ffq_linear_wq / ffq_mlp_gate_up_wq to its 8-wave kernel instead of the one-wave-per-SIMD one (bit-equal results),
+ * and plain launches of up to 512 rows to the 256-row tiles. Bit 1 (2): odd K slices of a split tile abandon their wait at once.
+ * Bit 2 (4): the 128-column tiles (up to 512 rows) take their register-staged kernel instead of the LDS-DMA one (bit-equal results).
  * Returns the previous setting. Process-wide; the library reads no environment variables.
  */
 int ffq_force_generic_kernels(int on);

@@ -88,3 +88,29 @@ def test_the_128_column_tile_kernels_keep_everything_in_registers_at_two_blocks_
     bad = {str(k["name"]): (k["vgpr_count"], k["vgpr_spill_count"], k["private_segment_fixed_size"]) for k in rows
            if k["vgpr_spill_count"] or k["private_segment_fixed_size"] or k["vgpr_count"] + k["agpr_count"] > 256}
     assert not bad, bad
+
+
+def test_the_lds_dma_form_of_the_128_column_tiles_is_the_loop_that_was_written():
+    """wq_mid_dma_kernel (csrc/ffq_wmid.hip): no spills, no scratch; its K-loop holds ONE counted `s_waitcnt vmcnt(N)` with N = the LDS-DMA
+    instructions of the ring's RING - 2 younger stages (4 x 6 for int8 per-channel weights at BM = 128), one raw barrier, the step's
+    6 LDS-DMA requests, 2 x (2 + 8) fragment reads in inline assembly and 32 MFMAs — and no compiler-inserted `vmcnt(0)`."""
+    import re
+
+    rows = _kernels("wq_mid_dma_kernel")
+    assert len(rows) == 16
+    assert all(k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0 and k["vgpr_count"] <= 256 for k in rows), rows
+    if not pathlib.Path("/opt/rocm/bin/hipcc").exists():
+        pytest.skip("hipcc is missing")
+    text = asm_cluster_check.build_assembly(ROOT / "fastforward_amd" / "csrc/ffq_wmid.hip")
+    lines = text.split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN3ffq17wq_mid_dma_kernelILi1ELb0ELb0ELi128EEEvNS_7MidArgsE:", l))
+    end = next(i for i in range(start, len(lines)) if ".end_amdhsa_kernel" in lines[i])
+    header = next(i for i in range(start, end) if "Inner Loop Header" in lines[i])
+    label = next(lines[j].split(":")[0] for j in range(header, start, -1) if re.match(r"^\.LBB\d+_\d+:", lines[j]))
+    back = next(i for i in range(header, end) if re.search(r"s_cbranch_\w+ " + re.escape(label) + r"\b", lines[i]))
+    body = [x.strip() for x in lines[header:back] if x.strip() and not x.strip().startswith((";", ".", "//"))]
+    count = lambda prefix: sum(1 for o in body if o.startswith(prefix))  # noqa: E731
+    assert count("v_mfma_f32_16x16x32_bf16") == 32 and count("global_load_lds_dwordx4") == 6 and count("s_barrier") == 1
+    assert count("ds_read_b128") == 16 and count("ds_read_b64") == 4 and count("scratch_") == 0
+    waits = [o for o in body if o.startswith("s_waitcnt") and "vmcnt" in o]
+    assert waits == ["s_waitcnt vmcnt(24)"], waits

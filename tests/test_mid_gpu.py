@@ -137,3 +137,43 @@ def test_exact_sums_agree_with_the_256_row_tiles_and_the_c_plus_plus_route(token
     if ops.NATIVE_DISPATCH:  # dispatcher -> C++ -> C ABI (csrc/ffq_torch.cpp) sizes the scratch itself
         via_op = torch.ops.fastforward_amd.linear_wq(x, w, s, None, k, None, torch.bfloat16, 0, -1, 0)
         assert torch.equal(via_op, got)
+
+
+@pytest.mark.parametrize("tokens", [17, 64, 65, 128, 300, 512])
+@pytest.mark.parametrize("form", ["int8 per channel", "int8 per channel + offset", "int8 per tensor", "nibbles g128", "nibbles g128 + offset", "nibbles block 256 g256"])
+def test_the_lds_dma_kernel_and_the_register_staged_kernel_give_the_same_bits(tokens, form):
+    """wq_mid_dma_kernel (operands by LDS-DMA into a ring, codes converted on the way into the MFMA's registers) against wq_mid_kernel
+    (both operands staged through registers, codes converted into a bf16 LDS image; selected with bit 2 of ffq_force_generic_kernels): the
+    same tiles, K slices and k order — bit-equal outputs for every forced split, ragged M and N, one to three matrices, bias and f32."""
+    g = torch.Generator(device=DEV).manual_seed(tokens + len(form))
+    lib = _native.library()
+    for n, k in ((1024, 4096), (1000, 1024), (4096, 1152)):
+        x = torch.randn(tokens, k, device=DEV, generator=g).to(torch.bfloat16)
+        kwargs = {}
+        if form.startswith("int8"):
+            w = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+            s = (torch.rand(1 if "tensor" in form else n, device=DEV, generator=g) * 1e-2 + 1e-3)
+            o = torch.round(torch.randn(s.numel(), device=DEV, generator=g) * 5) if "offset" in form else None
+            group = k
+        else:
+            block, group = (256, 256) if "256" in form else (128, 128)
+            if k % group:
+                continue
+            w4 = torch.randint(-8, 8, (n, k), device=DEV, dtype=torch.int8, generator=g)
+            w = ops.pack_int4(w4, block=block)
+            s = torch.rand(n * (k // group), device=DEV, generator=g) * 0.1 + 0.01
+            o = torch.round(torch.randn(s.numel(), device=DEV, generator=g) * 2) if "offset" in form else None
+            kwargs = dict(pack_block=block)
+        bias = torch.randn(n, device=DEV, generator=g).to(torch.bfloat16)
+        for split in (0, 1, 2, 3):
+            for extra in (dict(), dict(bias=bias, out_dtype=torch.float32)):
+                dma = ops.linear_wq(x, w, s, o, group=group, split=split, **kwargs, **extra)
+                previous = lib.ffq_force_generic_kernels(4)
+                try:
+                    staged = ops.linear_wq(x, w, s, o, group=group, split=split, **kwargs, **extra)
+                finally:
+                    lib.ffq_force_generic_kernels(previous)
+                assert torch.equal(dma, staged), (form, n, k, split, list(extra))
+    torch.cuda.synchronize()
+    for buf in ops._TICKETS.values():
+        assert int(buf.abs().sum()) == 0

@@ -44,7 +44,7 @@ def _kernels(source: str, needle: str):
 
 
 @pytest.mark.parametrize("source,needle,instantiations", [("ffq_wskinny.hip", "wq_skinny_kernel", 12), ("ffq_wskinny.hip", "wq_skinny_rows_kernel", 20),
-                                                         ("ffq_wmid.hip", "wq_mid_kernel", 16)])
+                                                         ("ffq_wmid.hip", "wq_mid_kernel", 16), ("ffq_wmid.hip", "wq_mid_dma_kernel", 16)])
 def test_slabs_are_write_through_and_drained_before_the_ticket(source, needle, instantiations):
     seen = 0
     for name, code in _kernels(source, needle):

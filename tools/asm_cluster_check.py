@@ -21,10 +21,31 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 
 
 def build_assembly(source: pathlib.Path) -> str:
+    """gfx950 assembly of one kernel source. Cached under the system's temp directory, keyed by the contents of the source, of every
+    header beside it and of the flags: the CPU test suite asks for the same file from several test modules (a compile is 20-70 s)."""
+    import hashlib
+
+    source = pathlib.Path(source)
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in [source, *sorted(source.parent.glob("*.h")), source.parent.parent.parent / "include" / "ffq.h"]:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    cache = pathlib.Path(tempfile.gettempdir()) / "ffq_isa_cache"
+    cached = cache / f"{source.stem}-{h.hexdigest()[:24]}.s"
+    if cached.exists():
+        return cached.read_text()
     with tempfile.TemporaryDirectory() as tmp:
         out = pathlib.Path(tmp) / "kernel.s"
         subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, str(source), "-o", str(out)], check=True, capture_output=True)
-        return out.read_text()
+        text = out.read_text()
+    try:
+        cache.mkdir(exist_ok=True)
+        partial = cached.with_suffix(f".{__import__('os').getpid()}.tmp")
+        partial.write_text(text)
+        partial.replace(cached)
+    except OSError:
+        pass  # a read-only temp directory: no cache
+    return text
 
 
 def clusters_of(text: str, name_filter: str = ""):
