@@ -724,7 +724,10 @@ __global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
 // ---- the plan ---------------------------------------------------------------------------------------------------------------------
 // Everything below is a function of (M, N, K) alone — not of the container, the packing block or the group size: every storage form
 // of one weight takes the same tiles, the same K slices and the same summation order.
-static int md_bm(int64_t M) { return M <= 64 ? 64 : 128; }
+#ifndef FFQ_MD_BM64_ALWAYS
+#define FFQ_MD_BM64_ALWAYS 0  // A/B hook: 64-row tiles at every row count (more, smaller blocks per CU)
+#endif
+static int md_bm(int64_t M) { return (FFQ_MD_BM64_ALWAYS || M <= 64) ? 64 : 128; }
 static int64_t md_tiles_m(int64_t M) { return (M + md_bm(M) - 1) / md_bm(M); }
 static int64_t md_tiles_n(int64_t N) { return (N + MD_BN - 1) / MD_BN; }
 

@@ -1,6 +1,7 @@
 """TEST INFRASTRUCTURE — lets the host logic of fastforward_amd run on CPU tensors with the C oracle as the checker.
 
-The product has no CPU path: ``fastforward_amd.ops._prepare`` refuses host tensors and the dispatcher predicates of
+The product has no CPU path: ``fastforward_amd.ops._base._prepare`` (the device check every entry point of the ``ops`` package looks up at call
+time) refuses host tensors and the dispatcher predicates of
 ``fastforward_amd.fused_linear`` accept HIP tensors only. ``use_oracle`` replaces those two seams for the duration of a
 ``with`` block so that tests (tests/conftest.py), ``__graft_entry__.smoke()`` and nothing else can drive the same Python
 code with ``oracle/_build/libffq_oracle.so`` on host pointers. Nothing under ``fastforward_amd/`` imports this module.
@@ -25,10 +26,10 @@ def use_library(lib):
 
     global _PRODUCT
     if _PRODUCT is None:  # the product's own functions, captured before the first injection
-        _PRODUCT = (ops._prepare, fused_linear._on_backend)
-    previous = (_native._LIB, ops._prepare, fused_linear._on_backend)
+        _PRODUCT = (ops._base._prepare, fused_linear._on_backend)
+    previous = (_native._LIB, ops._base._prepare, fused_linear._on_backend)
     _native._LIB = lib
-    ops._prepare, fused_linear._on_backend = _PRODUCT  # a HIP library runs the product code as shipped (also when nested)
+    ops._base._prepare, fused_linear._on_backend = _PRODUCT  # a HIP library runs the product code as shipped (also when nested)
     if not lib.backend_name.startswith("hip"):
 
         def prepare_host(*tensors):
@@ -45,9 +46,9 @@ def use_library(lib):
                 raise BackendError("the injected oracle computes on host memory only")
             return lib, None
 
-        ops._prepare = prepare_host
+        ops._base._prepare = prepare_host
         fused_linear._on_backend = lambda *tensors: all(t.device.type == "cpu" for t in tensors)
     try:
         yield lib
     finally:
-        _native._LIB, ops._prepare, fused_linear._on_backend = previous
+        _native._LIB, ops._base._prepare, fused_linear._on_backend = previous
