@@ -1118,16 +1118,16 @@ static int wq_split(int64_t M, int64_t N, int64_t K, bool mlp) {
 // everything ffq_linear_wq_supported() admits — so the scratch figures below answer for BOTH wherever the skinny form is preferred
 // (a GGUF-packed decode step got the skinny plan's scratch, often none, and ran the 256-row tiles without a split).
 enum { WQ_FORM_TILES = 0, WQ_FORM_SKINNY = 1, WQ_FORM_MID = 2 };
-static int wq_plan_form(int64_t M, int64_t K, int mlp) {
+static int wq_plan_form(int64_t M, int64_t N, int64_t K, int mlp) {
   if (mlp || generic_kernels_forced()) return WQ_FORM_TILES;
   if (M < FFQ_MID_MIN_M && wq_skinny_tickets(M, 128, K) > 0) return WQ_FORM_SKINNY;
-  if (wq_mid_shape_ok(M, K)) return WQ_FORM_MID;
-  return wq_skinny_tickets(M, 128, K) > 0 ? WQ_FORM_SKINNY : WQ_FORM_TILES;
+  if (wq_mid_prefers(M, N, K)) return WQ_FORM_MID;
+  return M < FFQ_MID_MIN_M && wq_skinny_tickets(M, 128, K) > 0 ? WQ_FORM_SKINNY : WQ_FORM_TILES;
 }
 
 extern "C" int64_t ffq_linear_wq_split(int64_t M, int64_t N, int64_t K, int mlp) {
   if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 1;
-  switch (wq_plan_form(M, K, mlp)) {
+  switch (wq_plan_form(M, N, K, mlp)) {
     case WQ_FORM_SKINNY: return wq_skinny_split(M, N, K);
     case WQ_FORM_MID: return wq_mid_split(M, N, K);
     default: return wq_split(M, N, K, mlp != 0);
@@ -1151,10 +1151,10 @@ extern "C" int64_t ffq_linear_wq_tickets(int64_t M, int64_t N, int64_t K, int ml
 // ffq_linear_wq_split (the plan) also covers the plan of the form that takes over where the preferred one declines the storage.
 extern "C" size_t ffq_linear_wq_slab_bytes(int64_t M, int64_t N, int64_t K, int mlp, int64_t split) {
   if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 0;
-  switch (wq_plan_form(M, K, mlp)) {
+  switch (wq_plan_form(M, N, K, mlp)) {
     case WQ_FORM_SKINNY: {
       size_t bytes = wq_skinny_slab_bytes(M, N, K, split);
-      if (wq_mid_shape_ok(M, K)) {
+      if (wq_mid_prefers(M, N, K)) {
         const size_t md = wq_mid_slab_bytes(M, N, K, split == wq_skinny_split(M, N, K) ? wq_mid_split(M, N, K) : split);
         bytes = bytes > md ? bytes : md;
       }
@@ -1174,7 +1174,7 @@ static size_t wq_slab_bytes(int64_t M, int64_t N, int split, bool mlp) {
 // that does not fit (no split / conversion inside the GEMM) — never fails for lack of scratch.
 extern "C" size_t ffq_linear_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 0;
-  if (wq_plan_form(M, K, 0) != WQ_FORM_TILES) return ffq_linear_wq_slab_bytes(M, N, K, 0, ffq_linear_wq_split(M, N, K, 0));
+  if (wq_plan_form(M, N, K, 0) != WQ_FORM_TILES) return ffq_linear_wq_slab_bytes(M, N, K, 0, ffq_linear_wq_split(M, N, K, 0));
   return wq_slab_bytes(M, N, wq_split(M, N, K, false), false) + (M >= WL_TWO_PASS_MIN_TOKENS ? (size_t)N * (size_t)K * 2u : 0);
 }
 
@@ -1300,8 +1300,7 @@ static int wq_linear_impl(const void* x, int x_dt, int count, const void* const*
   // few rows: the contraction is a stream over the codes, bounded by HBM — 16-row MFMA tiles, no padding to 256 rows (ffq_wskinny.hip)
   if (M < FFQ_MID_MIN_M && wq_skinny_applies(a, pack_block)) return wq_skinny_launch(a, w_dt, pack_block, group, split, workspace, workspace_bytes, tickets, s);
   // a few hundred rows (and the storage forms the skinny kernel declines): 128-column tiles, codes converted once per block (ffq_wmid.hip)
-  if (wq_mid_applies(a)) return wq_mid_launch(a, w_dt, group, split, workspace, workspace_bytes, tickets, s);
-  if (wq_skinny_applies(a, pack_block)) return wq_skinny_launch(a, w_dt, pack_block, group, split, workspace, workspace_bytes, tickets, s);
+  if (wq_mid_prefers(M, N, K) && wq_mid_applies(a)) return wq_mid_launch(a, w_dt, group, split, workspace, workspace_bytes, tickets, s);
   int rc_split;
   const size_t slab_bytes = wq_resolve_split(a, split, false, workspace, workspace_bytes, tickets, &rc_split);
   if (rc_split != FFQ_OK) return rc_split;

@@ -373,11 +373,11 @@ __global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
 // The register-staged kernel above is bound by its LDS STORES: 32 KiB per 64-k step and block go VGPR -> LDS through `ds_write_b128`
 // (13 cycles per wave-instruction, MI355X_MICROARCH.md "LDS"), 0.74 us per step measured with one block per CU against 0.27 for the step's
 // 32 MFMAs (profiles/r06_wq_mid_sweep_v2.txt). Here NOTHING is stored to LDS by a wave:
-//   * both operands arrive by LDS-DMA (`global_load_lds`, 16 bytes per lane straight from L2 / HBM into LDS) in a ring of MDD_RING
+//   * both operands arrive by LDS-DMA (`global_load_lds`, 16 bytes per lane straight from L2 / HBM into LDS) in a ring of 3 - 4
 //     stages of one 64-k super-step each — activations as they are (bf16, 128 bytes per row, XOR swizzle on the SOURCE address as in
 //     ffq_wlinear.hip), the weight CODES as they are stored (64 bytes per row: int8 containers, or the 64 packed bytes that hold the
 //     super-step's nibbles for packing blocks >= 128) and, for grouped parameters, each wave's 32 scales / offsets of the step's group:
-//     5 stages (122 KiB) in flight per CU without a single register, i.e. 1.2 - 1.5 us of prefetch distance at the MFMA-bound step rate;
+//     two to three stages in flight per block, two blocks per CU, without a single register;
 //   * a wave owns 32 output columns for ALL BM rows (4 waves side by side along N): lane (r, g) reads the 8 code bytes it multiplies
 //     (`ds_read_b64`, conflict-free under slot ^= ((row / 4) % 4) * 2), converts them with A2's arithmetic (dequantize4) INTO the MFMA's
 //     operand registers — every weight code is converted exactly once per row tile, by the wave that consumes it (no redundancy across
@@ -389,13 +389,15 @@ __global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
 // Same tiles, same K slices, same k order inside a tile (k ascending in steps of 32) as the register-staged kernel: both give the
 // SAME bits for the same plan — and so do all storage forms (tests/test_mid_gpu.py). Packing blocks 32 / 64 (GGUF) keep the
 // register-staged kernel (their 64 codes of a step are 32 bytes holding both nibbles).
-#ifndef FFQ_MDD_RING
-#define FFQ_MDD_RING 6
-#endif
-constexpr int MDD_RING = FFQ_MDD_RING;
+// stages of the ring: 64-row tiles 4 x 16 KiB (two blocks per CU), 128-row tiles 3 x 24 KiB (two blocks per CU). Round-6 sweeps
+// (profiles/r06_wq_mid_sweep_v3.txt, _v4.txt): one block per CU with a six-stage ring was no faster at one tile per CU and 18 % slower
+// at two (gate/up at 512 rows 87 against 72 us) — from ~256 rows on these launches are bound by the L2 -> LDS traffic of the whole
+// chip (8.5 TB/s measured), not by the prefetch distance of a block.
+constexpr int mdd_ring(int bm) { return bm == 64 ? 4 : 3; }
 
 template <int BKIND, bool GROUPED, bool OFFSET, int BM>
 __global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
+  constexpr int MDD_RING = mdd_ring(BM);
   constexpr int MI = BM / 16, NJ = 2;          // a wave: all BM rows x 32 columns
   constexpr int A_BYTES = BM * 128, B_BYTES = MD_BN * 64, P_BYTES = GROUPED ? 4 * 256 : 0;
   constexpr int STAGE = A_BYTES + B_BYTES + P_BYTES;
@@ -724,25 +726,26 @@ __global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
 // ---- the plan ---------------------------------------------------------------------------------------------------------------------
 // Everything below is a function of (M, N, K) alone — not of the container, the packing block or the group size: every storage form
 // of one weight takes the same tiles, the same K slices and the same summation order.
-#ifndef FFQ_MD_BM64_ALWAYS
-#define FFQ_MD_BM64_ALWAYS 0  // A/B hook: 64-row tiles at every row count (more, smaller blocks per CU)
-#endif
-static int md_bm(int64_t M) { return (FFQ_MD_BM64_ALWAYS || M <= 64) ? 64 : 128; }
-static int64_t md_tiles_m(int64_t M) { return (M + md_bm(M) - 1) / md_bm(M); }
+// 64-row tiles up to 256 rows and for contractions up to 8192 deep, 128-row tiles for the long contractions of a few hundred rows
+// (down_proj at 512 rows: 78 us against 91; q/o at 512 rows the other way round: 31.6 against 35.0 — profiles/r06_wq_mid_sweep_v4.txt)
+static int md_bm(int64_t M, int64_t K) { return (M <= 256 || K <= 8192) ? 64 : 128; }
+static int64_t md_tiles_m(int64_t M, int64_t K) { return (M + md_bm(M, K) - 1) / md_bm(M, K); }
 static int64_t md_tiles_n(int64_t N) { return (N + MD_BN - 1) / MD_BN; }
 
 bool wq_mid_shape_ok(int64_t M, int64_t K) { return M >= 1 && M <= WQ_MID_MAX_M && K % 64 == 0 && K >= 128; }
 
-// K slices: enough units for two blocks on every CU where the K range allows (a slice keeps at least 8 super-steps: the code stream
-// runs 4 ahead), no more than 8 (the last arriver of a quadrant reads S partials)
+// where the 128-column tiles are the preferred form: everything they cover up to 256 rows; beyond that the narrow projections — with
+// >= 8192 output columns and > 256 rows the 256-row tiles move less through the L2 (gate/up at 512 rows: 71 against 74 us)
+bool wq_mid_prefers(int64_t M, int64_t N, int64_t K) { return wq_mid_shape_ok(M, K) && (M <= 256 || N < 8192); }
+
+// K slices: one unit per CU where the tiles alone do not fill the chip, at most 4 (the last arriver of a quadrant reads S partials: from
+// 8 slices on the exchange costs more than the idle CUs it fills — k/v at 128 rows 16.3 us with 4 slices, 18.0 with 8), each slice at
+// least 8 super-steps long
 int wq_mid_split(int64_t M, int64_t N, int64_t K) {
   if (!wq_mid_shape_ok(M, K)) return 1;
-  const int64_t tiles = md_tiles_m(M) * md_tiles_n(N), ksuper = K / 64;
-  const int64_t want = (int64_t)wq_cus() * WQ_MID_BLOCKS_PER_CU;
-  int64_t S = tiles >= want ? 1 : (want + tiles - 1) / tiles;
-  // half-filled is better than a deeper cut: 1.5 blocks per CU without an exchange beat 2 with one
-  if (S > 1 && tiles * (S - 1) >= (int64_t)wq_cus() * 3 / 2) --S;
-  if (S > 8) S = 8;
+  const int64_t tiles = md_tiles_m(M, K) * md_tiles_n(N), ksuper = K / 64;
+  int64_t S = (wq_cus() + tiles - 1) / tiles;
+  if (S > 4) S = 4;
   if (S > ksuper / 8) S = ksuper / 8;
   return S < 1 ? 1 : (int)S;
 }
@@ -750,12 +753,12 @@ int wq_mid_split(int64_t M, int64_t N, int64_t K) {
 // ticket words: one per (tile, wave), for the widest launch of this (M, N, K): three matrices, each rounded up to whole tiles
 int64_t wq_mid_tickets(int64_t M, int64_t N, int64_t K) {
   if (!wq_mid_shape_ok(M, K)) return 0;
-  return md_tiles_m(M) * (md_tiles_n(N) + 2) * 4;
+  return md_tiles_m(M, K) * (md_tiles_n(N) + 2) * 4;
 }
 
 size_t wq_mid_slab_bytes(int64_t M, int64_t N, int64_t K, int64_t split) {
   if (!wq_mid_shape_ok(M, K) || split <= 1) return 0;
-  return (size_t)(md_tiles_m(M) * (md_tiles_n(N) + 2)) * (size_t)split * (size_t)md_bm(M) * MD_BN * 4u;
+  return (size_t)(md_tiles_m(M, K) * (md_tiles_n(N) + 2)) * (size_t)split * (size_t)md_bm(M, K) * MD_BN * 4u;
 }
 
 bool wq_mid_applies(const WLinearArgs& a) {
@@ -781,7 +784,7 @@ static void md_launch_dma(const MidArgs& m, int bm, unsigned grid, hipStream_t s
 #define FFQ_MDD(BM_)                                                                                                         \
   do {                                                                                                                       \
     static uint64_t attr_set = 0;                                                                                            \
-    const int lds_bytes = MDD_RING * (BM_ * 128 + MD_BN * 64 + (GROUPED ? 1024 : 0));                                        \
+    const int lds_bytes = mdd_ring(BM_) * (BM_ * 128 + MD_BN * 64 + (GROUPED ? 1024 : 0));                                        \
     ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_mid_dma_kernel<BKIND, GROUPED, OFFSET, BM_>), lds_bytes); \
     wq_mid_dma_kernel<BKIND, GROUPED, OFFSET, BM_><<<grid, 256, lds_bytes, stream>>>(m);                                      \
   } while (0)
@@ -817,7 +820,7 @@ int wq_mid_launch(const WLinearArgs& a, int w_dt, int64_t group, int64_t split, 
   }
   m.bias = a.bias; m.bias_dt = a.bias_dt; m.out_dt = a.out_dt;
   m.M = a.M; m.K = a.K;
-  m.tiles_m = (int)md_tiles_m(a.M); m.tiles_n = (int)tiles_n;
+  m.tiles_m = (int)md_tiles_m(a.M, a.K); m.tiles_n = (int)tiles_n;
   m.groups = a.groups; m.steps_per_group = (int)(group / 64); m.per_row = a.per_row; m.pack_shift = a.pack_shift;
   const int64_t ksuper = a.K / 64;
   int64_t S = split > 0 ? split : wq_mid_split(a.M, N, a.K);
@@ -825,7 +828,7 @@ int wq_mid_launch(const WLinearArgs& a, int w_dt, int64_t group, int64_t split, 
     if (split > 0) return fail(FFQ_ERR_ARG, "weight-only linear (128-column tiles): split %lld exceeds the %lld super-steps of 64 along K", (long long)split, (long long)ksuper);
     S = ksuper;
   }
-  const int bm = md_bm(a.M);
+  const int bm = md_bm(a.M, a.K);
   const int64_t tiles = (int64_t)m.tiles_m * tiles_n;
   const size_t slab = S > 1 ? (size_t)tiles * (size_t)S * (size_t)bm * MD_BN * 4u : 0;
   if (S > 1 && (!tickets || !workspace || workspace_bytes < slab || !aligned16(workspace))) {

@@ -81,11 +81,9 @@ int wq_cus();
 #define FFQ_MID_MIN_M 17     // token rows from which the 128-column tiles are preferred to the skinny form (A/B hook: tools/build_variant.sh)
 #endif
 constexpr int64_t WQ_MID_MAX_M = 512;      // beyond: the 256-row tiles of ffq_wlinear.hip
-#ifndef FFQ_MID_BLOCKS_PER_CU
-#define FFQ_MID_BLOCKS_PER_CU 2
-#endif
-constexpr int WQ_MID_BLOCKS_PER_CU = FFQ_MID_BLOCKS_PER_CU;  // units per CU the K split aims for (A/B hook)
+
 bool wq_mid_shape_ok(int64_t M, int64_t K);
+bool wq_mid_prefers(int64_t M, int64_t N, int64_t K);  // ... and are the preferred form for (M, N = all output columns of the launch, K)
 bool wq_mid_applies(const WLinearArgs& a);
 int wq_mid_split(int64_t M, int64_t N, int64_t K);
 int64_t wq_mid_tickets(int64_t M, int64_t N, int64_t K);
