@@ -92,7 +92,7 @@ def test_the_128_column_tile_kernels_keep_everything_in_registers_at_two_blocks_
 
 def test_the_lds_dma_form_of_the_128_column_tiles_is_the_loop_that_was_written():
     """wq_mid_dma_kernel (csrc/ffq_wmid.hip): no spills, no scratch; its K-loop holds ONE counted `s_waitcnt vmcnt(N)` with N = the LDS-DMA
-    instructions of the ring's RING - 2 younger stages (4 x 6 for int8 per-channel weights at BM = 128), one raw barrier, the step's
+    instructions of the ring's RING - 2 younger stages (1 x 6 for int8 per-channel weights at BM = 128, a three-stage ring), one raw barrier, the step's
     6 LDS-DMA requests, 2 x (2 + 8) fragment reads in inline assembly and 32 MFMAs — and no compiler-inserted `vmcnt(0)`."""
     import re
 
@@ -113,4 +113,4 @@ def test_the_lds_dma_form_of_the_128_column_tiles_is_the_loop_that_was_written()
     assert count("v_mfma_f32_16x16x32_bf16") == 32 and count("global_load_lds_dwordx4") == 6 and count("s_barrier") == 1
     assert count("ds_read_b128") == 16 and count("ds_read_b64") == 4 and count("scratch_") == 0
     waits = [o for o in body if o.startswith("s_waitcnt") and "vmcnt" in o]
-    assert waits == ["s_waitcnt vmcnt(24)"], waits
+    assert waits == ["s_waitcnt vmcnt(6)"], waits
