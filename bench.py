@@ -192,7 +192,7 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
     """The dominant kernel of the step: the int8 MFMA GEMM. Algorithmic ops per launch = 2*T*N*K.
 
     `achieved` comes from the launches of a REAL forward (the code distributions the timed steps see): one eager
-    forward with a HIP event pair around each int8 GEMM launch (192 per forward: q, k, v, o, down and the fused
+    forward with a HIP event pair around each int8 GEMM launch (128 per forward since round 6: q+k+v as one launch, o, down and the fused
     gate+up launch, which contracts both weight matrices and carries the SiLU*up + quantize epilogue), on the stream
     they are launched on.
     The event pair also covers the one-pass side kernel with the weight row sums (1 B/elem of the weight).
@@ -234,7 +234,8 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
                 samples.setdefault((n, k), []).append(a.elapsed_time(b))
             fused.linear_events = None
         names = {(h, h): "q/o_proj", (kv, h): "k/v_proj", (i, h): "gate/up_proj", (h, i): "down_proj",
-                 (2 * i, h): "gate_proj + up_proj + SiLU*up + quantize (one launch, both weight matrices)"}
+                 (2 * i, h): "gate_proj + up_proj + SiLU*up + quantize (one launch, both weight matrices)",
+                 (h + 2 * kv, h): "q_proj + k_proj + v_proj (one launch, three weight matrices)"}
         for (n, k), times in samples.items():
             ms = statistics.mean(times)
             per_shape[names.get((n, k), f"{n}x{k}")] = {"N": n, "K": k, "ms": round(ms, 4), "TOP/s": round(2.0 * tokens * n * k / ms / 1e9, 1), "launches_per_forward": len(times) // 2}
@@ -258,6 +259,8 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
     # (bf16 for the plain launches; int8 codes for the gate+up launch, which reads two weight matrices)
     # (shape, launches per layer) as a LIST: with kv == h (an MHA config such as --model tiny) dict keys would collide
     plain_launches = [((h, h), 2), ((kv, h), 2), ((h, i), 1)]
+    if (h + 2 * kv, h) in {(v["N"], v["K"]) for v in per_shape.values()} and kv != h:  # q / k / v ran as one launch (llama.FusedForward.qkv_one_launch)
+        plain_launches = [((h + 2 * kv, h), 1), ((h, h), 1), ((h, i), 1)]
     alg_bytes = sum(c * (tokens * k + n * k + tokens * n * 2) for (n, k), c in plain_launches) + (tokens * h + 2 * i * h + tokens * i)
     alg_launches = sum(c for _, c in plain_launches) + 1
     # what back-to-back MFMAs alone sustain on toggling operands (no memory traffic): tools/probes/mfma_power.hip, committed run
@@ -294,7 +297,7 @@ def gemm_roofline(config: llama.LlamaConfig, tokens: int, device: torch.device, 
         "traffic_calibration_variant": {"bytes_per_launch": traffic_calibration, "variants": calibration_variants,
                                         "note": "WOFF=true instantiation (weight offsets decided on the device): calibration steps only, NOT part of `traffic`"},
         "algorithmic_bytes_per_launch": alg_bytes / alg_launches,
-        "algorithmic_bytes_note": "codes of x and W read once + output written once, mean over the same launch mix (5 plain launches + 1 gate+up launch per layer)",
+        "algorithmic_bytes_note": f"codes of x and W read once + output written once, mean over the same launch mix ({alg_launches - 1} plain launches + 1 gate+up launch per layer)",
         "avg_launch_ms": round(total_ms / launches, 4),
         "algorithmic_ops_per_launch": total_ops / launches,
         "measured_on": source,
@@ -519,6 +522,7 @@ def main() -> None:
                     "eager RMSNorm / rotary / SiLU) instead of llama.FusedForward (A1 fused into those producers)")
     ap.add_argument("--cache-weight-codes", action="store_true", help="keep int8 weight codes across steps (NOT the headline: the reference re-quantizes)")
     ap.add_argument("--no-side-measurements", action="store_true", help="skip roofline / cpu_baseline legs")
+    ap.add_argument("--qkv-three-launches", action="store_true", help="A/B arm: q_proj / k_proj / v_proj as three launches of the int8 GEMM (round 5) instead of one")
     ap.add_argument("--batch-rowsums", action="store_true", help="A/B: weight row sums from the batched weight-quantization launch instead of one rowsum_i8 launch per linear (measured slower: llama.FusedForward)")
     ap.add_argument("--layer-batched-weights", action="store_true", help="A/B: all seven weights of a layer re-quantized by one launch at the top of the layer (round 4's schedule) instead of group by group right before their GEMMs")
     ap.add_argument("--fuse-rowsums", action="store_true", help="A/B: every weight re-quantized right before its GEMM by the one-pass codes + row sums kernel (no batched launch, no rowsum_i8 launches)")
@@ -571,7 +575,7 @@ def main() -> None:
     ranges_identical, ranks_seen = ffd.ranges_agree_across_ranks(model)
     exchange = dict(ffd.last_exchange)
 
-    fused = None if args.module_graph else llama.FusedForward(model, cache_weight_codes=args.cache_weight_codes, batch_rowsums=args.batch_rowsums, fuse_rowsums=args.fuse_rowsums, just_in_time_weights=not args.layer_batched_weights)
+    fused = None if args.module_graph else llama.FusedForward(model, cache_weight_codes=args.cache_weight_codes, batch_rowsums=args.batch_rowsums, fuse_rowsums=args.fuse_rowsums, just_in_time_weights=not args.layer_batched_weights, qkv_one_launch=not args.qkv_three_launches)
 
     def forward():
         if fused is not None:

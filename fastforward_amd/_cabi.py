@@ -19,7 +19,7 @@ from fastforward_amd.exceptions import QuantizationError
 
 FFQ_MAX_DIMS = 8
 FFQ_MAX_FANOUT = 3
-FFQ_ABI_VERSION = 8
+FFQ_ABI_VERSION = 9
 
 
 class Status(enum.IntEnum):
@@ -172,6 +172,7 @@ SIGNATURES: dict[str, tuple[object, list[object]]] = {
         _i,
         [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _d, _i, _i64, _i64, _i64, _vp, _sz, _vp],
     ),
+    "ffq_linear_w8a8_multi": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _i64, _vp, _sz, _vp]),
     "ffq_quantize_by_tile_unless_same": (_i, [_vp, _i, _vp, _vp, _i64, _d, _vp, _vp, _vp, _vp]),
     "ffq_linear_w8a8_takes_earlier": (_i, [_i64, _i64, _i64]),
     "ffq_linear_w8a8_earlier": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i64, _i64, _vp, _sz, _vp]),

@@ -71,6 +71,12 @@ struct LinearArgs {
   // the activation codes of an EARLIER quantizer of the same tensor (ffq_affine.h): read instead of `xq` when this linear's input
   // quantizer turns out to hold the same parameters (WOFF and GATED instantiations of the persistent kernel only: range estimation)
   EarlierCodes earlier;
+  // several weight matrices side by side along N in ONE launch (ffq_linear_w8a8_multi: q / k / v of an attention block): the codes, scales
+  // and row sums are ONE [N, K] / [N] run (matrix after matrix), only the outputs are separate tensors. Columns [0, seg_start[0]) belong
+  // to `out`, [seg_start[0], seg_start[1]) to seg_out[0], the rest to seg_out[1]; INT32_MAX: absent. Every boundary is a multiple of 256
+  // (a tile belongs to one matrix). Plain bf16 / f16 / f32 output of the persistent kernel only.
+  int seg_start[2];
+  void* seg_out[2];
 };
 
 // The value the linear would have returned in dtype `y_dt` (one rounding), as fp32
@@ -307,6 +313,13 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
                                                          int wm, int wn, int m0, int n0, [[maybe_unused]] const uint16_t* silu_table = nullptr,
                                                          [[maybe_unused]] float* zext = nullptr /* GATED: this lane's running {min, max, NaN seen} of the product */) {
   TOut* out = static_cast<TOut*>(a.out);
+  // the tile's output matrix: its first element, its row pitch and its first column in the launch's column space (tile-uniform selects)
+  int out_n = a.N, col0 = 0;
+  if (a.seg_start[0] != INT32_MAX) {
+    if (n0 >= a.seg_start[1]) { out = static_cast<TOut*>(a.seg_out[1]); col0 = a.seg_start[1]; out_n = a.N - col0; }
+    else if (n0 >= a.seg_start[0]) { out = static_cast<TOut*>(a.seg_out[0]); col0 = a.seg_start[0]; out_n = (a.seg_start[1] == INT32_MAX ? a.N : a.seg_start[1]) - col0; }
+    else out_n = a.seg_start[0];
+  }
   float oscale = 1.0f, ooff = 0.0f;
   if constexpr (REQUANT) {
     oscale = a.out_scale[0];
@@ -324,7 +337,7 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
   const int wave_n0 = n0 + wn * 64;
   const int wave_m0 = m0 + wm * 128;
   // whole-line stores need 16-byte aligned rows: 2-byte containers through the slab, anything else element stores
-  const bool lds_path = sizeof(TOut) == 2 && (a.N & 7) == 0 && wave_n0 + 64 <= a.N;
+  const bool lds_path = sizeof(TOut) == 2 && (out_n & 7) == 0 && wave_n0 + 64 <= a.N;
   bool woff_live = false;
   if constexpr (WOFF) woff_live = *a.woff_live != 0;
   // GATED: the gate lines of slab round i + 1 are fetched while round i is computed (round 0's here, ahead of the parameter
@@ -425,7 +438,7 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
           }
         }
         if (m_ok) {
-          const size_t at = (size_t)m * a.N + wave_n0 + nb;
+          const size_t at = (size_t)m * out_n + (wave_n0 - col0) + nb;
 #pragma unroll
           for (int t = 0; t < 4; ++t)
             if (wave_n0 + nb + t < a.N) store_out<TOut>(out + at + t, y[t]);
@@ -476,7 +489,7 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
           }
         }
         if (mm < a.M)
-          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * a.N + wave_n0) * 2 + seg * 16));
+          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * out_n + (wave_n0 - col0)) * 2 + seg * 16));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slab is re-written by the next i
     }
@@ -1038,7 +1051,8 @@ static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w
                             const float* out_scale, const float* out_offset, double out_num_bits, int y_dt, int64_t M,
                             int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream, const void* gate,
                             uint32_t* extrema_words = nullptr, void* extrema_pair = nullptr, const int32_t* run_if = nullptr, int run_when = 0,
-                            EarlierCodes earlier = {nullptr, nullptr, nullptr}) {
+                            EarlierCodes earlier = {nullptr, nullptr, nullptr}, int seg_count = 1, const int64_t* seg_ns = nullptr,
+                            void* const* seg_outs = nullptr) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (M < 0 || N < 0 || K < 0) return fail(FFQ_ERR_ARG, "negative extent");
   if (M == 0 || N == 0) return FFQ_OK;
@@ -1068,6 +1082,7 @@ static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w
   a.x_scale = x_scale; a.x_offset = x_offset;
   a.w_scale = w_scale; a.w_offset = w_offset;
   a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.woff_live = nullptr; a.rowsum_w_inside = 0;
+  a.seg_start[0] = a.seg_start[1] = INT32_MAX; a.seg_out[0] = a.seg_out[1] = nullptr;
   a.wq2 = nullptr; a.w_scale2 = nullptr; a.rowsum_w2 = nullptr;
   a.batch_x = a.batch_w = a.batch_out = 0;
   a.bias = bias; a.bias_dt = bias_dt;
@@ -1091,6 +1106,16 @@ static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w
   // the gated epilogue lives in the persistent kernel's whole-line store path: everything else is the caller's two launches
   if (gate && !(persistent && N % 64 == 0 && out_dt == FFQ_BF16 && !requant && !bias && aligned16(gate) && aligned16(out)))
     return fail(FFQ_ERR_DTYPE, "gated w8a8 linear: outside the persistent kernel's whole-line path (bf16 out, N %% 64 == 0, >= 64 tiles of 256 x 256)");
+  if (seg_count > 1) {  // several weight matrices side by side (ffq_linear_w8a8_multi): whole tiles per matrix, the persistent kernel's plain epilogue
+    if (!persistent || requant || w_offset || gate || earlier.codes) return fail(FFQ_ERR_DTYPE, "w8a8 linears in one launch: the persistent kernel's plain form only (>= 64 tiles, no weight offsets, no output quantizer)");
+    int64_t at = 0;
+    for (int i = 0; i + 1 < seg_count; ++i) {
+      if (seg_ns[i] % 256 != 0) return fail(FFQ_ERR_DTYPE, "w8a8 linears in one launch: every weight matrix but the last needs a multiple of 256 rows");
+      at += seg_ns[i];
+      a.seg_start[i] = (int)at;
+      a.seg_out[i] = seg_outs[i + 1];
+    }
+  }
   bool flag_written = false;
   if (x_offset) {  // sum_k wq[n, k] for the zero-point term: one pass over the weight codes, unless the caller has them
     if (w_rowsum) {
@@ -1208,6 +1233,27 @@ extern "C" int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t
 }
 
 // ffq_linear_w8a8 whose activation codes may not have been written (ffq_quantize_by_tile_unless_same) — see include/ffq.h
+// q_proj / k_proj / v_proj of a W8A8 attention block (three QuantizedLinear modules on one quantized hidden state, reference nn/linear.py:32-39
+// three times over _gen/fallback.py:77-112) as ONE launch: `count` (2 or 3) weight matrices whose int8 codes, scales and (optional) row
+// sums lie matrix after matrix in ONE [N, K] / [N] run each (N = the sum of Ns), separate outputs outs[i] = [M, Ns[i]]. Exactly the values
+// of `count` ffq_linear_w8a8 calls (the same tiles, the same epilogue): a k/v projection (4 column tiles per row tile) no longer runs
+// alone on a corner of the chip. Every matrix but the last needs a multiple of 256 rows; per-tensor or per-row activation parameters,
+// one scale per weight row, no weight offsets, no bias, no output quantizer; shapes the persistent kernel does not take return
+// FFQ_ERR_DTYPE before touching a buffer (the caller launches the matrices one by one). Workspace: ffq_linear_w8a8_workspace_bytes(M, N, K).
+extern "C" int ffq_linear_w8a8_multi(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale, const float* x_offset,
+                                     int x_per_row, const float* w_scale, int count, void* const* outs, int out_dt, int64_t M, const int64_t* Ns,
+                                     int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  if (count < 2 || count > 3 || !outs || !Ns) return fail(FFQ_ERR_ARG, "2 or 3 weight matrices");
+  int64_t N = 0;
+  for (int i = 0; i < count; ++i) {
+    if (Ns[i] <= 0 || !outs[i]) return fail(FFQ_ERR_ARG, "empty weight matrix or NULL output");
+    if (!aligned16(outs[i])) return fail(FFQ_ERR_DTYPE, "w8a8 linears in one launch need 16-byte aligned outputs");
+    N += Ns[i];
+  }
+  return linear_w8a8_impl(xq, wq, w_rowsum, x_scale, x_offset, x_per_row, w_scale, nullptr, 1, nullptr, 0, outs[0], out_dt, nullptr, nullptr, 8.0, 0, M, N, K,
+                          workspace, workspace_bytes, stream, nullptr, nullptr, nullptr, nullptr, 0, EarlierCodes{nullptr, nullptr, nullptr}, count, Ns, outs);
+}
+
 extern "C" int ffq_linear_w8a8_earlier(const int8_t* xq, const int8_t* earlier_xq, const float* earlier_scale, const float* earlier_offset,
                                        const int8_t* wq, const int32_t* w_rowsum, const float* x_scale, const float* x_offset,
                                        const float* w_scale, const float* w_offset, int w_per_row, void* out, int out_dt, int64_t M,
@@ -1266,6 +1312,7 @@ extern "C" int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_s
   a.x_scale = x_scale; a.x_offset = x_offset;
   a.w_scale = w_scale; a.w_offset = w_offset;
   a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.woff_live = nullptr; a.rowsum_w_inside = 0;
+  a.seg_start[0] = a.seg_start[1] = INT32_MAX; a.seg_out[0] = a.seg_out[1] = nullptr;
   a.wq2 = nullptr; a.w_scale2 = nullptr; a.rowsum_w2 = nullptr;
   a.batch_x = M * K; a.batch_w = N * K; a.batch_out = M * N;
   a.gate = nullptr; a.extrema.words = nullptr; a.extrema.pair = nullptr; a.extrema.pair_dt = 0; a.run_if = nullptr; a.run_when = 0;
@@ -1338,6 +1385,7 @@ static int mlp_gate_up_w8a8_impl(const int8_t* xq, const int8_t* gate_wq, const 
   a.x_scale = x_scale; a.x_offset = x_offset;
   a.w_scale = gate_w_scale; a.w_scale2 = up_w_scale; a.w_offset = nullptr;
   a.rowsum_x = nullptr; a.rowsum_w = nullptr; a.rowsum_w2 = nullptr; a.woff_live = nullptr; a.rowsum_w_inside = 0;
+  a.seg_start[0] = a.seg_start[1] = INT32_MAX; a.seg_out[0] = a.seg_out[1] = nullptr;
   a.batch_x = a.batch_w = a.batch_out = 0;
   a.gate = nullptr; a.extrema.words = extrema_words; a.extrema.pair = extrema_pair; a.extrema.pair_dt = FFQ_BF16;
   a.run_if = run_if; a.run_when = run_when;

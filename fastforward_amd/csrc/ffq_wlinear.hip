@@ -1118,11 +1118,16 @@ static int wq_split(int64_t M, int64_t N, int64_t K, bool mlp) {
 // everything ffq_linear_wq_supported() admits — so the scratch figures below answer for BOTH wherever the skinny form is preferred
 // (a GGUF-packed decode step got the skinny plan's scratch, often none, and ran the 256-row tiles without a split).
 enum { WQ_FORM_TILES = 0, WQ_FORM_SKINNY = 1, WQ_FORM_MID = 2 };
+// the skinny form up to 16 rows, and up to 32 for the narrow projections (q/o at 32 rows 14.8 us against 16.6 on the 128-column tiles, k/v
+// 14.8 against 15.5, down_proj 27.1 against 32.5; gate/up the other way round: 32.9 against 28.4 — profiles/r06_wq_rows_sweep.txt)
+static bool wq_prefers_skinny(int64_t M, int64_t N, int64_t K) {
+  return (M < FFQ_MID_MIN_M || (M <= 32 && N < 8192)) && wq_skinny_tickets(M, 128, K) > 0;
+}
 static int wq_plan_form(int64_t M, int64_t N, int64_t K, int mlp) {
   if (mlp || generic_kernels_forced()) return WQ_FORM_TILES;
-  if (M < FFQ_MID_MIN_M && wq_skinny_tickets(M, 128, K) > 0) return WQ_FORM_SKINNY;
+  if (wq_prefers_skinny(M, N, K)) return WQ_FORM_SKINNY;
   if (wq_mid_prefers(M, N, K)) return WQ_FORM_MID;
-  return M < FFQ_MID_MIN_M && wq_skinny_tickets(M, 128, K) > 0 ? WQ_FORM_SKINNY : WQ_FORM_TILES;
+  return wq_skinny_tickets(M, 128, K) > 0 ? WQ_FORM_SKINNY : WQ_FORM_TILES;
 }
 
 extern "C" int64_t ffq_linear_wq_split(int64_t M, int64_t N, int64_t K, int mlp) {
@@ -1298,7 +1303,7 @@ static int wq_linear_impl(const void* x, int x_dt, int count, const void* const*
 #endif
   const bool grouped = groups > 1, offset = w_offset[0] != nullptr;
   // few rows: the contraction is a stream over the codes, bounded by HBM — 16-row MFMA tiles, no padding to 256 rows (ffq_wskinny.hip)
-  if (M < FFQ_MID_MIN_M && wq_skinny_applies(a, pack_block)) return wq_skinny_launch(a, w_dt, pack_block, group, split, workspace, workspace_bytes, tickets, s);
+  if (wq_prefers_skinny(M, N, K) && wq_skinny_applies(a, pack_block)) return wq_skinny_launch(a, w_dt, pack_block, group, split, workspace, workspace_bytes, tickets, s);
   // a few hundred rows (and the storage forms the skinny kernel declines): 128-column tiles, codes converted once per block (ffq_wmid.hip)
   if (wq_mid_prefers(M, N, K) && wq_mid_applies(a)) return wq_mid_launch(a, w_dt, group, split, workspace, workspace_bytes, tickets, s);
   int rc_split;

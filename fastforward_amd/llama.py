@@ -740,7 +740,7 @@ class FusedForward:
     """
 
     def __init__(self, model: LlamaModel, cache_weight_codes: bool = False, fuse_mlp: bool = True, fuse_attention: bool = True, fuse_rowsums: bool = False,
-                 batch_weight_quantization: bool = True, batch_rowsums: bool = False, just_in_time_weights: bool = True) -> None:
+                 batch_weight_quantization: bool = True, batch_rowsums: bool = False, just_in_time_weights: bool = True, qkv_one_launch: bool = True) -> None:
         problems = self.unsupported(model)
         if problems:
             raise ff.exceptions.QuantizationError("FusedForward cannot run this model: " + "; ".join(problems[:4]))
@@ -775,6 +775,12 @@ class FusedForward:
         # the 7 rowsum_i8 launches per layer gone) — while gate/up (117 MB of codes behind 235 MB of bf16 reads: more than the cache
         # keeps) stay one launch followed by their two rowsum_i8 launches, which double as the prefetch.
         self.just_in_time_weights = just_in_time_weights and batch_weight_quantization and not fuse_rowsums and not batch_rowsums
+        # q_proj / k_proj / v_proj as ONE launch of the int8 GEMM on the code tensor their input quantizers share (round 6; ops.linear_w8a8_multi):
+        # the just-in-time re-quantization of the three weights writes their codes and row sums side by side into one buffer; k / v (four
+        # column tiles per row tile) no longer run alone, and a forward issues 64 launches fewer
+        self.qkv_one_launch = qkv_one_launch and self.just_in_time_weights
+        self._qkv_side: dict[int, tuple[torch.Tensor, torch.Tensor | None]] = {}  # layer -> (codes [Nq + Nk + Nv, K], row sums) of THIS forward
+        self._qkv_scales: dict[int, tuple[tuple[int, ...], torch.Tensor]] = {}     # layer -> (scale versions, the three scale vectors as one)
         self._layer_rowsums: dict[int, torch.Tensor] = {}
         self._jit_single: set[int] = set()  # o_proj / down_proj of the layer in flight: one-pass codes + row sums right before their GEMM
         self._layer_codes: dict[int, torch.Tensor] = {}
@@ -940,15 +946,29 @@ class FusedForward:
         if len(todo) < 2:
             return
         offsets = [None if self._symmetric_weights(l) else l.weight_quantizer.offset for l in todo]  # an all-zero offset buffer: same codes
-        sums = None
+        # q / k / v re-quantized together: their codes (and row sums) side by side in ONE buffer, so that the three linears can run as one
+        # launch of the int8 GEMM (`_qkv_one_launch`); the per-linear entries are views of it
+        together = (group is not None and len(todo) == 3 and tuple(todo) == (attn.q_proj, attn.k_proj, attn.v_proj) and self.qkv_one_launch
+                    and len({l.weight.shape[1] for l in todo}) == 1 and all(l.weight.shape[0] % 256 == 0 for l in todo[:2]))
+        sums, pool_slice = None, None
         if want_rowsums and all(l.weight.shape[1] % 1024 == 0 for l in todo):
-            sums = [self._rowsum_slice(l.weight.shape[0], l.weight.device) for l in todo]
-            sums = sums if all(t is not None for t in sums) else None
+            if together:
+                pool_slice = self._rowsum_slice(sum(l.weight.shape[0] for l in todo), todo[0].weight.device)
+                sums = None if pool_slice is None else list(torch.split(pool_slice, [l.weight.shape[0] for l in todo]))
+            else:
+                sums = [self._rowsum_slice(l.weight.shape[0], l.weight.device) for l in todo]
+                sums = sums if all(t is not None for t in sums) else None
+        codes_out, cat = None, None
+        if together:
+            cat = torch.empty((sum(l.weight.shape[0] for l in todo), todo[0].weight.shape[1]), dtype=torch.int8, device=todo[0].weight.device)
+            codes_out = list(torch.split(cat, [l.weight.shape[0] for l in todo]))
         codes = ff.ops.quantize_rows_batch([l.weight for l in todo], [l.weight_quantizer.scale for l in todo], offsets, todo[0].weight_quantizer.num_bits,
-                                           rowsums=sums)
+                                           rowsums=sums, codes_out=codes_out)
         if codes is None and sums is not None:
             codes, sums = ff.ops.quantize_rows_batch([l.weight for l in todo], [l.weight_quantizer.scale for l in todo], offsets,
-                                                     todo[0].weight_quantizer.num_bits), None
+                                                     todo[0].weight_quantizer.num_bits, codes_out=codes_out), None
+        if codes is not None and together:
+            self._qkv_side[id(layer)] = (cat, pool_slice if sums is not None else None)
         if codes is not None:
             self._layer_codes.update({id(l): c for l, c in zip(todo, codes)})
             if sums is not None:
@@ -967,6 +987,42 @@ class FusedForward:
             return produced[0], produced[1], wq.scale, wq.offset
         codes, rowsum = self._quantize_weight(linear)
         return codes, rowsum, wq.scale, wq.offset
+
+    def _qkv_one_launch(self, layer: torch.nn.Module, codes: Sequence[torch.Tensor], index: Sequence[int]) -> list[torch.Tensor] | None:
+        """q_proj, k_proj and v_proj on the one code tensor their (equal) input quantizers share, as ONE launch of the int8 GEMM
+        (ops.linear_w8a8_multi; reference nn/linear.py:32-39 three times): possible when this forward has just re-quantized the three
+        weights into one buffer (`_quantize_layer` with the q / k / v group) and none of them carries a live offset. Bit for bit the three
+        separate launches; None: the caller runs them."""
+        side = self._qkv_side.pop(id(layer), None)
+        attn = layer.self_attn
+        linears = (attn.q_proj, attn.k_proj, attn.v_proj)
+        if side is None or not all(self._symmetric_weights(l) for l in linears):
+            return None
+        w_codes, w_rowsum = side
+        scales = [l.weight_quantizer.scale for l in linears]
+        key = tuple(t._version for t in scales)
+        hit = self._qkv_scales.get(id(layer))
+        if hit is None or hit[0] != key:
+            if w_codes.is_cuda and torch.cuda.is_current_stream_capturing():
+                return None  # (the concatenated scales are made outside a capture: run the shape once before capturing)
+            hit = (key, torch.cat([t.detach().reshape(-1).to(torch.float32) for t in scales]))
+            self._qkv_scales[id(layer)] = hit
+        x_scale, x_offset = self._params(attn.q_proj)
+        rows = [l.weight.shape[0] for l in linears]
+        if self.linear_events is not None:
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+        outs = ff.ops.linear_w8a8_multi(codes[index[0]], w_codes, x_scale, x_offset, hit[1], rows, out_dtype=torch.bfloat16, w_rowsum=w_rowsum)
+        if outs is None:
+            # (the separate launches find their codes where `_quantize_layer` left them: views of the same buffer)
+            return None
+        for l in linears:  # consumed: the per-linear entries of this forward are not needed any more
+            self._layer_codes.pop(id(l), None)
+            self._layer_rowsums.pop(id(l), None)
+        if self.linear_events is not None:
+            end.record()
+            self.linear_events.append((sum(rows), w_codes.shape[1], start, end))
+        return outs
 
     def _linear(self, x_codes: torch.Tensor, linear: torch.nn.Module) -> torch.Tensor:
         """The int8 GEMM of one quantized linear (the RMSNorm kernel that follows adds its output to the residual stream)."""
@@ -1010,9 +1066,13 @@ class FusedForward:
             if self.just_in_time_weights:
                 self._jit_single = {id(attn.o_proj), id(mlp.down_proj)}
                 self._quantize_layer(layer, (attn.q_proj, attn.k_proj, attn.v_proj), with_rowsums=True)
-            q = self._linear(codes[index[0]], attn.q_proj)
-            k = self._linear(codes[index[1]], attn.k_proj)
-            v = self._linear(codes[index[2]], attn.v_proj)
+            qkv = self._qkv_one_launch(layer, codes, index) if index[0] == index[1] == index[2] else None
+            if qkv is not None:
+                q, k, v = qkv
+            else:
+                q = self._linear(codes[index[0]], attn.q_proj)
+                k = self._linear(codes[index[1]], attn.k_proj)
+                v = self._linear(codes[index[2]], attn.v_proj)
             o_in = attn.o_proj.input_quantizer
             if self.fuse_attention and attention_kernel_covers(cfg, s, q.dtype):
                 # rotary embedding: k in place, q as the attention launch loads it (no pass over the q projection); softmax(q k^T) v

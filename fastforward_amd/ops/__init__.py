@@ -34,7 +34,7 @@ from fastforward_amd.ops.reductions import (  # noqa: F401
     _running_minmax_step, minmax_by_tile, parameters_for_range, running_minmax_quantize, running_minmax_step,
 )
 from fastforward_amd.ops.gemm import (  # noqa: F401
-    _bmm_w8a8, _linear_w8a8, bmm_w8a8, linear_w8a8, linear_w8a8_earlier, linear_w8a8_gated, linear_w8a8_takes_earlier, mlp_gate_up_w8a8, mlp_gate_up_w8a8_estimating,
+    _bmm_w8a8, _linear_w8a8, bmm_w8a8, linear_w8a8, linear_w8a8_earlier, linear_w8a8_gated, linear_w8a8_multi, linear_w8a8_takes_earlier, mlp_gate_up_w8a8, mlp_gate_up_w8a8_estimating,
 )
 from fastforward_amd.ops.wq import (  # noqa: F401
     _linear_wq, _wq_scratch, linear_wq, linear_wq_multi, mlp_gate_up_wq,
@@ -61,6 +61,7 @@ __all__ = [
     "gptq_block",
     "grid_sqerror_by_tile",
     "linear_w8a8",
+    "linear_w8a8_multi",
     "bmm_w8a8",
     "linear_wq",
     "linear_wq_multi",

@@ -3,6 +3,8 @@ forms range estimation needs (earlier codes, gated epilogue, the device-decided 
 
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from fastforward_amd import _native
@@ -81,6 +83,55 @@ def _linear_w8a8(x_codes, w_codes, x_scale, x_offset, w_scale, w_offset, bias, o
         )
     )
     return out
+
+
+def linear_w8a8_multi(
+    x_codes: torch.Tensor,
+    w_codes: torch.Tensor,
+    x_scale: torch.Tensor,
+    x_offset: torch.Tensor | None,
+    w_scale: torch.Tensor,
+    rows: Sequence[int],
+    out_dtype: torch.dtype = torch.bfloat16,
+    w_rowsum: torch.Tensor | None = None,
+) -> list[torch.Tensor] | None:
+    """Two or three W8A8 linears on the SAME activation codes in one launch (q_proj / k_proj / v_proj: three ``QuantizedLinear`` modules
+    on one quantized hidden state, reference nn/linear.py:32-39): ``w_codes`` holds the matrices' int8 codes one after the other
+    (``[sum(rows), K]``), ``w_scale`` (and ``w_rowsum``) their per-row scales (row sums) in the same order; returns one ``[..., rows[i]]``
+    tensor per matrix, each bit for bit what :func:`linear_w8a8` returns for that matrix alone. None where the one-launch form does not
+    apply (fewer than 64 tiles of 256 x 256, K % 128 != 0, a matrix but the last that is no multiple of 256 rows): the caller launches
+    the linears one by one."""
+    if x_codes.dtype != torch.int8 or w_codes.dtype != torch.int8:
+        raise TypeError("linear_w8a8_multi expects int8 codes")
+    count = len(rows)
+    if not 2 <= count <= 3 or out_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        return None
+    xc, wc = x_codes.detach().contiguous(), w_codes.detach().contiguous()
+    K, N = xc.shape[-1], int(sum(rows))
+    M = xc.numel() // K if K else 0
+    if wc.dim() != 2 or wc.shape != (N, K) or any(int(r) <= 0 for r in rows) or any(int(r) % 256 for r in rows[:-1]):
+        return None
+
+    def f32(t: torch.Tensor | None) -> torch.Tensor | None:
+        return None if t is None else t.detach().reshape(-1).to(torch.float32).contiguous()
+
+    xs, xo, ws_ = f32(x_scale), f32(x_offset), f32(w_scale)
+    if xs.numel() not in (1, M) or ws_.numel() != N:
+        return None
+    if w_rowsum is not None and (w_rowsum.dtype != torch.int32 or w_rowsum.numel() != N or not w_rowsum.is_contiguous() or w_rowsum.device != wc.device):
+        raise RuntimeError(f"w_rowsum must be a contiguous int32 tensor with {N} entries on the codes' device")
+    lib, stream = _base._prepare(xc, wc, xs, xo, ws_)
+    outs = [torch.empty((*xc.shape[:-1], int(r)), dtype=out_dtype, device=xc.device) for r in rows]
+    nbytes = lib.ffq_linear_w8a8_workspace_bytes(M, N, K)
+    ws = _workspace(nbytes, xc.device)
+    status = lib.ffq_linear_w8a8_multi(
+        _ptr(xc), _ptr(wc), _ptr(w_rowsum), _ptr(xs), _ptr(xo), int(xs.numel() != 1), _ptr(ws_), count, (ctypes.c_void_p * count)(*[_ptr(o) for o in outs]),
+        _tag(out_dtype), M, (ctypes.c_int64 * count)(*[int(r) for r in rows]), K, _ptr(ws), nbytes, stream,
+    )
+    if status == 6:  # FFQ_ERR_DTYPE: not the persistent kernel's shape class
+        return None
+    lib.check(status)
+    return outs
 
 
 def linear_w8a8_takes_earlier(M: int, N: int, K: int) -> bool:

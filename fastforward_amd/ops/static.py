@@ -262,14 +262,14 @@ def quantize_rows_rowsum(
 
 def quantize_rows_batch(
     weights: Sequence[torch.Tensor], scales: Sequence[torch.Tensor], offsets: Sequence[torch.Tensor | None], num_bits: float = 8.0,
-    rowsums: Sequence[torch.Tensor] | None = None,
+    rowsums: Sequence[torch.Tensor] | None = None, codes_out: Sequence[torch.Tensor] | None = None,
 ) -> list[torch.Tensor] | None:
     """A1 of up to 8 ``[rows, cols]`` bf16 weights with one (scale, offset) per row into int8 codes, ONE launch; each result
     equals ``quantize_by_tile(weight, scale, (1, cols), num_bits, torch.int8, offset)``. The seven linears of a decoder layer
     are re-quantized on every forward (reference nn/linear.py:34); as seven launches the short ones (k_proj / v_proj) run far
     below the streaming rate. `rowsums` (one ZEROED contiguous int32 [rows] tensor per weight, cols % 1024 == 0): the launch also
     adds each row's code sum into it — what :func:`linear_w8a8` takes as ``w_rowsum``. Returns None where the one-launch
-    kernel does not apply (then quantize member by member)."""
+    kernel does not apply (then quantize member by member). `codes_out`: int8 tensors to receive the codes instead of fresh ones."""
     if not weights or len(weights) > FFQ_MAX_BATCH or not (len(weights) == len(scales) == len(offsets)) or float(num_bits) != int(num_bits):
         return None
     if rowsums is not None and (len(rowsums) != len(weights) or any(
@@ -286,7 +286,13 @@ def quantize_rows_batch(
         sc.append(s32)
         of.append(o32)
     lib, stream = _base._prepare(*[w.detach() for w in weights], *sc, *[o for o in of if o is not None])
-    codes = [torch.empty(w.shape, dtype=torch.int8, device=w.device) for w in weights]
+    if codes_out is not None:  # the caller's own int8 tensors (e.g. slices of one buffer: q / k / v codes side by side for linear_w8a8_multi)
+        if len(codes_out) != len(weights) or any(c.dtype != torch.int8 or c.shape != w.shape or not c.is_contiguous() or c.device != w.device or c.data_ptr() % 16
+                                                 for c, w in zip(codes_out, weights)):
+            return None
+        codes = list(codes_out)
+    else:
+        codes = [torch.empty(w.shape, dtype=torch.int8, device=w.device) for w in weights]
     batch = RowsBatch()
     batch.count, batch.num_bits = len(weights), float(num_bits)
     for i, (w, s, o, c) in enumerate(zip(weights, sc, of, codes)):

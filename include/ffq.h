@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define FFQ_MAX_DIMS 8
-#define FFQ_ABI_VERSION 8
+#define FFQ_ABI_VERSION 9
 
 typedef enum ffq_status {
   FFQ_OK = 0,
@@ -242,6 +242,20 @@ int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum,
                     const void* bias, int bias_dt, void* out, int out_dt, const float* out_scale,
                     const float* out_offset, double out_num_bits, int y_dt, int64_t M, int64_t N, int64_t K,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Two or three W8A8 linears on the SAME activation codes in one launch (ABI 9) — q_proj / k_proj / v_proj of an attention block: three
+ * QuantizedLinear modules reading one quantized hidden state (reference nn/linear.py:32-39 three times over _gen/fallback.py:77-112).
+ * The weight codes of the `count` matrices lie matrix after matrix in ONE [N, K] run (N = the sum of Ns), their scales (one per weight
+ * row) and — optionally — their int32 row sums in ONE [N] run each; outs[i] is a separate [M, Ns[i]] tensor. outs[i] equals what
+ * ffq_linear_w8a8 returns for matrix i alone, bit for bit (the same tiles, accumulators and epilogue; only the tile walk covers all
+ * column tiles). Every matrix but the last needs a multiple of 256 rows; activation parameters per tensor or per row; no weight
+ * offsets, bias or output quantizer. Problems the persistent kernel does not take (fewer than 64 tiles of 256 x 256, K % 128 != 0)
+ * return FFQ_ERR_DTYPE before touching a buffer: launch the matrices one by one. Workspace: ffq_linear_w8a8_workspace_bytes(M, N, K).
+ */
+int ffq_linear_w8a8_multi(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale, const float* x_offset,
+                          int x_per_row, const float* w_scale, int count, void* const* outs, int out_dt, int64_t M, const int64_t* Ns,
+                          int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * The second linear of a gated MLP on int8 codes: out = bf16(silu(gate)) * bf16(y), y = ffq_linear_w8a8(...) in bf16 —

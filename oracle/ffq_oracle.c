@@ -1363,6 +1363,23 @@ int ffq_quantize_rows_rowsum(const void* data, int data_dt, const float* scale, 
 }
 
 /* test hook of the HIP library (kernel-family selection): the oracle has one implementation, nothing to select */
+/* ABI 9: q / k / v on the same activation codes in one call = the single-matrix entry once per matrix (fallback.py:77-112 three times) */
+int ffq_linear_w8a8_multi(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale, const float* x_offset,
+                          int x_per_row, const float* w_scale, int count, void* const* outs, int out_dt, int64_t M, const int64_t* Ns,
+                          int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  if (count < 2 || count > 3 || !outs || !Ns) return fail(FFQ_ERR_ARG, "2 or 3 weight matrices");
+  int64_t at = 0;
+  for (int i = 0; i < count; ++i) {
+    if (Ns[i] <= 0 || !outs[i]) return fail(FFQ_ERR_ARG, "empty weight matrix or NULL output");
+    if (i + 1 < count && Ns[i] % 256 != 0) return fail(FFQ_ERR_DTYPE, "every weight matrix but the last needs a multiple of 256 rows");
+    int rc = ffq_linear_w8a8(xq, wq + at * K, w_rowsum ? w_rowsum + at : NULL, x_scale, x_offset, x_per_row, w_scale + at, NULL, 1, NULL, 0, outs[i],
+                             out_dt, NULL, NULL, 8.0, 0, M, Ns[i], K, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    at += Ns[i];
+  }
+  return FFQ_OK;
+}
+
 int ffq_force_generic_kernels(int on) { (void)on; return 0; }
 
 /* A1 of several row-quantized weights: the composition the one-launch form replaces (_quantizer_impl.py:154-169 per member) */

@@ -549,3 +549,31 @@ def test_gate_up_while_estimating_takes_either_route_to_the_same_product(route):
     for words in ops._EXTREMA_WORDS.values():
         assert words.tolist() == [-1, 0, 0, 0]
     assert ops.mlp_gate_up_w8a8_estimating(xg[:100], xu[:100], wg, wu, (sg, og), (su, ou), (swg, None), (swu, None)) is None  # too few tiles
+
+
+@pytest.mark.parametrize("tokens,rows,k", [(16384, (4096, 1024, 1024), 4096), (4096, (8192, 1024, 1024), 8192), (2050, (512, 256, 300), 1024), (1024, (2048, 512), 512)])
+@pytest.mark.parametrize("per_token,with_sums", [(False, True), (True, False)])
+def test_q_k_v_as_one_int8_launch_equal_three_launches(tokens, rows, k, per_token, with_sums):
+    """ops.linear_w8a8_multi (ABI 9: q_proj / k_proj / v_proj on the code tensor their input quantizers share — reference nn/linear.py:32-39
+    three times over fallback.py:77-112 — as ONE launch of the persistent int8 GEMM, the three weight code matrices side by side in one
+    buffer) == three ops.linear_w8a8 launches BIT FOR BIT at the Llama-3-8B and 70B shapes, ragged M, a ragged last matrix, per-tensor and
+    per-token activation parameters, row sums handed in or reduced by the library; shapes outside the persistent kernel's class return None."""
+    g = torch.Generator(device=DEV).manual_seed(tokens + k)
+    x = torch.randint(-128, 128, (tokens, k), device=DEV, dtype=torch.int8, generator=g)
+    w = torch.randint(-128, 128, (sum(rows), k), device=DEV, dtype=torch.int8, generator=g)
+    sw = torch.rand(sum(rows), device=DEV, generator=g) * 1e-3 + 1e-4
+    n_x = tokens if per_token else 1
+    sx, ox = torch.rand(n_x, device=DEV, generator=g) * 0.05 + 0.01, torch.round(torch.randn(n_x, device=DEV, generator=g) * 20)
+    sums = w.to(torch.int32).sum(1, dtype=torch.int32) if with_sums else None
+    got = ops.linear_w8a8_multi(x, w, sx, ox, sw, rows, w_rowsum=sums)
+    assert got is not None and [tuple(t.shape) for t in got] == [(tokens, r) for r in rows]
+    at = 0
+    for out, r in zip(got, rows):
+        want = ops.linear_w8a8(x, w[at:at + r], sx, ox, sw[at:at + r], None, None, out_dtype=torch.bfloat16, w_rowsum=None if sums is None else sums[at:at + r].contiguous())
+        assert torch.equal(out, want), (r, at)
+        at += r
+    f32 = ops.linear_w8a8_multi(x, w, sx, ox, sw, rows, out_dtype=torch.float32, w_rowsum=sums)
+    assert f32 is not None and all(torch.equal(a.to(torch.bfloat16), b) for a, b in zip(f32, got))
+    # not this launch's: a middle matrix that is no multiple of 256 rows, too few tiles for the persistent kernel
+    assert ops.linear_w8a8_multi(x, w, sx, ox, sw, (rows[0] - 8, sum(rows[1:]) + 8)) is None
+    assert ops.linear_w8a8_multi(x[:64], w[:768], sx[:64] if per_token else sx, ox[:64] if per_token else ox, sw[:768], (256, 256, 256)) is None

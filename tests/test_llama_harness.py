@@ -131,6 +131,8 @@ def check_fused_against_module_graph(fixture, device):
         assert float((as_built - want).pow(2).mean().sqrt()) < 0.01 * spread and float((as_built - want).abs().max()) < 0.25 * spread
     # the MLP front half in one launch is the same arithmetic as gate GEMM, up GEMM and the SiLU*up producer
     assert torch.equal(llama.FusedForward(model, fuse_mlp=False)(ids).float().cpu(), got)
+    # ... and q / k / v as one launch of the int8 GEMM (round 6) the same as three
+    assert torch.equal(llama.FusedForward(model, qkv_one_launch=False)(ids).float().cpu(), got)
     cached = llama.FusedForward(model, cache_weight_codes=True)
     assert torch.equal(cached(ids).float().cpu(), got) and torch.equal(cached(ids).float().cpu(), got)
     with torch.no_grad():  # a changed weight invalidates its cached codes
@@ -227,6 +229,37 @@ def test_producers_forward_weight_only_on_gpu(hip_backend):
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu
+def test_fused_forward_runs_q_k_v_as_one_int8_launch(hip_backend, monkeypatch):
+    """llama.FusedForward at widths the persistent int8 GEMM takes (hidden 2048, 16 / 4 heads of 128: q 2048, k / v 512 rows; 4096 tokens):
+    every layer's q_proj / k_proj / v_proj run as ONE ops.linear_w8a8_multi launch on the code tensor their input quantizers share, from
+    weight codes that the just-in-time re-quantization wrote side by side into one buffer — and the logits are bit for bit those of the
+    three-launch forward (``qkv_one_launch=False``), also from a hipGraph replay."""
+    cfg = llama.LlamaConfig(hidden_size=2048, intermediate_size=1024, num_layers=2, num_heads=16, num_kv_heads=4, vocab_size=512)
+    model = llama.build_model(cfg, "cuda", torch.bfloat16, seed=7, std=0.03)
+    llama.quantize_llama(model, w_bits=8, a_bits=8, quantized_dtype=torch.int8)
+    ids = torch.randint(0, cfg.vocab_size, (2, 2048), device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    llama.calibrate(model, [ids[:, :256]])
+    calls = []
+    real = ff.ops.linear_w8a8_multi
+    monkeypatch.setattr(ff.ops, "linear_w8a8_multi", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    one = llama.FusedForward(model)
+    got = one(ids)
+    assert len(calls) == cfg.num_layers
+    three = llama.FusedForward(model, qkv_one_launch=False)(ids)
+    assert len(calls) == cfg.num_layers and torch.equal(got, three)
+    assert torch.equal(one(ids), got)  # a second forward: fresh codes, the cached scales
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.cuda.graph(graph, stream=side):
+        captured = one(ids)
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured, got)
+
+
 @pytest.mark.parametrize("w_bits,block", [(8, None), (4, 128)])
 def test_weight_only_storage_forms_agree_bit_for_bit(hip_backend, w_bits, block):
     """BASELINE configs 2 / 4 on a small Llama: the weight quantizer on every call ("requantize"), kept int8 codes, kept
