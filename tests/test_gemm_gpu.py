@@ -551,7 +551,7 @@ def test_gate_up_while_estimating_takes_either_route_to_the_same_product(route):
     assert ops.mlp_gate_up_w8a8_estimating(xg[:100], xu[:100], wg, wu, (sg, og), (su, ou), (swg, None), (swu, None)) is None  # too few tiles
 
 
-@pytest.mark.parametrize("tokens,rows,k", [(16384, (4096, 1024, 1024), 4096), (4096, (8192, 1024, 1024), 8192), (2050, (512, 256, 300), 1024), (1024, (2048, 512), 512)])
+@pytest.mark.parametrize("tokens,rows,k", [(16384, (4096, 1024, 1024), 4096), (4096, (8192, 1024, 1024), 8192), (4300, (512, 256, 300), 1024), (4096, (2048, 512), 512)])  # (>= 64 tiles of 256 x 256 each)
 @pytest.mark.parametrize("per_token,with_sums", [(False, True), (True, False)])
 def test_q_k_v_as_one_int8_launch_equal_three_launches(tokens, rows, k, per_token, with_sums):
     """ops.linear_w8a8_multi (ABI 9: q_proj / k_proj / v_proj on the code tensor their input quantizers share — reference nn/linear.py:32-39
