@@ -795,6 +795,9 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
 // and with an even number of super-steps (wq_dispatch); bf16 output.
 // (A gate+up+SiLU*up mode of this kernel was built and is bit-equal too, but measured 3-5 % SLOWER than the 8-wave kernel's —
 // 2.83 against 2.75 ms at 16 k tokens — and was removed; the plain form is +2 % on q/o and gate/up, +4 % on down_proj.)
+#ifndef FFQ_W4_SPREAD
+#define FFQ_W4_SPREAD 0
+#endif
 #ifndef FFQ_W4_AHEAD
 #define FFQ_W4_AHEAD 0  // A/B hook (tools/build_variant.sh): L2 warm-up distance in super-steps beyond the LDS-DMA's own
 #endif
@@ -873,11 +876,15 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
     a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row_base(a.x, tm0, row_bytes), 0, extent(a.M - tm0), 0x00020000);
     b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row_base(seg_codes(seg), tn0, row_bytes), 0, extent(seg_rows(seg) - tn0), 0x00020000);
   };
-  auto issue = [&](int ks, int slot, int c) {  // piece c of both images of super-step ks (of the tile the descriptors point at)
+  auto issue_one = [&](int ks, int slot, int c, int which) {  // piece c of the A (0) or B (1) image of super-step ks
     uint8_t* base = lds + slot * WL_SLOT;
     const uint32_t soff = (uint32_t)c * 8u * row_bytes + (uint32_t)ks * 128u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (wl_lds_t*)(base + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (wl_lds_t*)(base + WL_IMAGE + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);
+    if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (wl_lds_t*)(base + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (wl_lds_t*)(base + WL_IMAGE + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);
+  };
+  auto issue = [&](int ks, int slot, int c) {  // piece c of both images of super-step ks (of the tile the descriptors point at)
+    issue_one(ks, slot, c, 0);
+    issue_one(ks, slot, c, 1);
   };
 
   // ---- L2 warm-up (FFQ_W4_AHEAD super-steps ahead of the LDS-DMA): a super-step of an image is ONE 128-byte line per row, so one
@@ -947,7 +954,12 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
       FFQ_W4_MFMA(acc[mi][nj], fb[nj], fa[mi]);
       if (i % 3 == 1 && i / 3 < 16) read_one(i / 3, ao, bo, na, nb);
       if constexpr (decltype(with_dma)::value) {
+#if FFQ_W4_SPREAD  // A/B hook (tools/build_variant.sh): the A and the B piece four MFMAs apart instead of back to back
+        if ((i & 7) == 1) dma(i >> 3, 0);
+        if ((i & 7) == 5) dma(i >> 3, 1);
+#else
         if ((i & 7) == 3) dma(i >> 3);
+#endif
       }
     }
   };
@@ -986,7 +998,11 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
 #endif
       __builtin_amdgcn_s_barrier();
       // ---- second k-half: MFMAs on set 1 | LDS-DMA of super-step `kn` into `cur` | read the first k-half of `nxt` into set 0
+#if FFQ_W4_SPREAD
+      phase(fa1, fb1, fa0, fb0, a_off[nxt][0], b_off[nxt][0], [&](int c, int which) { issue_one(kn, cur, c, which); }, std::true_type{});
+#else
       phase(fa1, fb1, fa0, fb0, a_off[nxt][0], b_off[nxt][0], [&](int c) { issue(kn, cur, c); }, std::true_type{});
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 #pragma unroll 1
