@@ -796,7 +796,8 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
 // (A gate+up+SiLU*up mode of this kernel was built and is bit-equal too, but measured 3-5 % SLOWER than the 8-wave kernel's —
 // 2.83 against 2.75 ms at 16 k tokens — and was removed; the plain form is +2 % on q/o and gate/up, +4 % on down_proj.)
 #ifndef FFQ_W4_SPREAD
-#define FFQ_W4_SPREAD 0
+#define FFQ_W4_SPREAD 1  // round 6: the A and the B LDS-DMA piece of a pair four MFMAs apart (0: back to back, round 4). A/B, three interleaved rounds on one box
+                         // (profiles/r06_w4_spread_ab.txt): gate/up 1.316 -> 1.291 ms (+1.9 %), q/o and down_proj +-0, layer mix 1439 -> 1455 TFLOP/s
 #endif
 #ifndef FFQ_W4_AHEAD
 #define FFQ_W4_AHEAD 0  // A/B hook (tools/build_variant.sh): L2 warm-up distance in super-steps beyond the LDS-DMA's own
@@ -987,7 +988,11 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
       const int nxt = cur ^ 1;
       // ---- first k-half: MFMAs on set 0 | read the second k-half of `cur` into set 1
 #if FFQ_W4_AHEAD > 0
+#if FFQ_W4_SPREAD
+      phase(fa0, fb0, fa1, fb1, a_off[cur][1], b_off[cur][1], [&](int c, int which) { if (c == 0) warm_up(kn, which); }, std::true_type{});
+#else
       phase(fa0, fb0, fa1, fb1, a_off[cur][1], b_off[cur][1], [&](int c) { if (c < 2) warm_up(kn, c); }, std::true_type{});
+#endif
       // the images of the next super-step have landed (this wave's pieces; the barrier makes it everybody's), `cur` has been read in
       // full; the two warm-up dwords issued in this k-half are younger than the pieces and stay in flight
       asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
