@@ -378,7 +378,9 @@ __global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
 //     ffq_wlinear.hip), the weight CODES as they are stored (64 bytes per row: int8 containers, or the 64 packed bytes that hold the
 //     super-step's nibbles for packing blocks >= 128) and, for grouped parameters, each wave's 32 scales / offsets of the step's group:
 //     two to three stages in flight per block, two blocks per CU, without a single register;
-//   * a wave owns 32 output columns for ALL BM rows (4 waves side by side along N): lane (r, g) reads the 8 code bytes it multiplies
+//   * a wave owns 16 output columns for ALL BM rows (8 waves side by side along N, two per SIMD: while one issues its LDS-DMA requests
+//     — ~60-100 cycles each in its in-order stream — or waits for fragments, the other feeds the matrix pipe; the first version had 4
+//     waves of 32 columns, A/B in profiles/r06_wq_mid_waves_ab.txt): lane (r, g) reads the 8 code bytes it multiplies
 //     (`ds_read_b64`, conflict-free under slot ^= ((row / 4) % 4) * 2), converts them with A2's arithmetic (dequantize4) INTO the MFMA's
 //     operand registers — every weight code is converted exactly once per row tile, by the wave that consumes it (no redundancy across
 //     waves, no LDS round trip of the bf16 image) — and 8 VALU conversions ride under each group of 8 (BM = 128) MFMAs;
@@ -394,15 +396,22 @@ __global__ __launch_bounds__(256, 2) void wq_mid_kernel(MidArgs a) {
 // at two (gate/up at 512 rows 87 against 72 us) — from ~256 rows on these launches are bound by the L2 -> LDS traffic of the whole
 // chip (8.5 TB/s measured), not by the prefetch distance of a block.
 constexpr int mdd_ring(int bm) { return bm == 64 ? 4 : 3; }
+#ifndef FFQ_MDD_WAVES
+#define FFQ_MDD_WAVES 8  // waves of a block, side by side along N (A/B hook: 4 = 32 columns per wave, round 6's first LDS-DMA version)
+#endif
+constexpr int MDD_WAVES = FFQ_MDD_WAVES;
+static_assert(MDD_WAVES == 4 || MDD_WAVES == 8, "4 x 32 or 8 x 16 columns");
 
 template <int BKIND, bool GROUPED, bool OFFSET, int BM>
-__global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
+__global__ __launch_bounds__(64 * MDD_WAVES, 2) void wq_mid_dma_kernel(MidArgs a) {
   constexpr int MDD_RING = mdd_ring(BM);
-  constexpr int MI = BM / 16, NJ = 2;          // a wave: all BM rows x 32 columns
-  constexpr int A_BYTES = BM * 128, B_BYTES = MD_BN * 64, P_BYTES = GROUPED ? 4 * 256 : 0;
+  constexpr int W = MDD_WAVES;                 // waves side by side along N
+  constexpr int MI = BM / 16, NJ = 8 / W;      // a wave: all BM rows x 16 NJ columns
+  constexpr int A_BYTES = BM * 128, B_BYTES = MD_BN * 64, P_BYTES = GROUPED ? W * 256 : 0;
   constexpr int STAGE = A_BYTES + B_BYTES + P_BYTES;
-  constexpr int APW = BM / 32;                 // 1 KiB activation pieces (8 rows) per wave and stage
-  constexpr int NI = APW + 2 + (GROUPED ? 1 : 0);  // LDS-DMA instructions per wave and stage
+  constexpr int APW = BM / 8 / W;              // 1 KiB activation pieces (8 rows) per wave and stage
+  constexpr int BPW = 8 / W;                   // 1 KiB code pieces (16 rows) per wave and stage: the wave's own columns
+  constexpr int NI = APW + BPW + (GROUPED ? 1 : 0);  // LDS-DMA instructions per wave and stage
   static_assert(NI * (MDD_RING - 2) <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
@@ -438,32 +447,38 @@ __global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
     a_src[c] = a.x + (size_t)m * (size_t)a.K * 2u + (size_t)((((uint32_t)lane & 7u) ^ (((uint32_t)row >> 1) & 7u)) << 4);
   }
   const uint32_t w_row_bytes = BKIND == WL_B_I8 ? (uint32_t)a.K : (uint32_t)a.K / 2u;
-  const uint8_t* b_src[2];
+  const uint8_t* b_src[BPW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (wave * 2 + j) * 16 + (lane >> 2);
+  for (int j = 0; j < BPW; ++j) {
+    const int row = (wave * BPW + j) * 16 + (lane >> 2);
     int n = n0 + row;
     n = n < rows ? n : rows - 1;
     b_src[j] = w_base + (size_t)n * w_row_bytes + (size_t)((((uint32_t)lane & 3u) ^ (((uint32_t)row >> 2) & 3u)) << 4);
   }
-  [[maybe_unused]] const float* p_src = nullptr;  // GROUPED: lanes 0-31 the scales of the wave's 32 rows, lanes 32-63 their offsets
-  float s_row[NJ] = {1.0f, 1.0f}, o_row[NJ] = {0.0f, 0.0f};
+  // GROUPED: the wave's strip of the step's parameters — dword l of 64: scale of the wave's row l % (16 NJ) for (l / (16 NJ)) even, its
+  // offset for odd (NJ = 1: the upper 32 lanes repeat the lower)
+  [[maybe_unused]] const float* p_src = nullptr;
+  float s_row[NJ], o_row[NJ];
   {
-    int n = n0 + wave * 32 + (lane & 31);
+    int n = n0 + wave * 16 * NJ + (lane % (16 * NJ));
     n = n < rows ? n : rows - 1;
     const size_t p_row = a.per_row ? (size_t)n * (size_t)a.groups : 0;
-    if constexpr (GROUPED) p_src = ((OFFSET && lane >= 32) ? o_base : s_base) + p_row;
+    if constexpr (GROUPED) p_src = ((OFFSET && ((lane / (16 * NJ)) & 1)) ? o_base : s_base) + p_row;
   }
+#pragma unroll
+  for (int nj = 0; nj < NJ; ++nj) { s_row[nj] = 1.0f; o_row[nj] = 0.0f; }
   if constexpr (!GROUPED) {
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
-      int n = n0 + wave * 32 + nj * 16 + (int)r16;
+      int n = n0 + wave * 16 * NJ + nj * 16 + (int)r16;
       n = n < rows ? n : rows - 1;
       const size_t p_row = a.per_row ? (size_t)n : 0;
       s_row[nj] = s_base[p_row];
       if constexpr (OFFSET) o_row[nj] = rne(o_base[p_row]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(s_row[0]), "+v"(s_row[1]), "+v"(o_row[0]), "+v"(o_row[1]) : : "memory");  // nothing of these in the loop's count
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of these in the loop's count
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) asm volatile("" : "+v"(s_row[nj]), "+v"(o_row[nj]));
   }
   // first byte of super-step ks inside a row of codes (and, nibbles: which nibble holds them — one packing-block half spans >= 64 codes)
   auto code_byte0 = [&](int ks, uint32_t& nib) __attribute__((always_inline)) -> uint32_t {
@@ -486,8 +501,8 @@ __global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
     uint32_t nib;
     const uint32_t byte0 = code_byte0(ks, nib);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((wl_gbl_t*)(b_src[j] + byte0), (wl_lds_t*)(base + A_BYTES + (wave * 2 + j) * 1024), 16, 0, 0);
+    for (int j = 0; j < BPW; ++j)
+      __builtin_amdgcn_global_load_lds((wl_gbl_t*)(b_src[j] + byte0), (wl_lds_t*)(base + A_BYTES + (wave * BPW + j) * 1024), 16, 0, 0);
     if constexpr (GROUPED)
       __builtin_amdgcn_global_load_lds((wl_gbl_t*)(p_src + ks / steps_per_group), (wl_lds_t*)(base + A_BYTES + B_BYTES + wave * 256), 4, 0, 0);
   };
@@ -497,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
 #pragma unroll
   for (int kq = 0; kq < 2; ++kq) {
     a_off[kq] = r16 * 128u + (((kq * 4u + g4) ^ ((r16 >> 1) & 7u)) << 4);
-    b_off[kq] = A_BYTES + ((uint32_t)wave * 32u + r16) * 64u + (((kq * 4u + g4) ^ (((r16 >> 2) & 3u) << 1)) << 3);
+    b_off[kq] = A_BYTES + ((uint32_t)wave * 16u * NJ + r16) * 64u + (((kq * 4u + g4) ^ (((r16 >> 2) & 3u) << 1)) << 3);
   }
   [[maybe_unused]] const uint32_t p_off = A_BYTES + B_BYTES + (uint32_t)wave * 256u + r16 * 4u;
 
@@ -526,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
   do {                                                                                                           \
     const uint32_t b_addr = st + b_off[KQ], a_addr = st + a_off[KQ];                                             \
     MDD_READ64(codes[KQ][0], b_addr, 0);                                                                         \
-    MDD_READ64(codes[KQ][1], b_addr, 1024);                                                                      \
+    if constexpr (NJ == 2) MDD_READ64(codes[KQ][NJ - 1], b_addr, 1024);                                          \
     MDD_READ128(fa[KQ][0], a_addr, 0 * 2048);                                                                    \
     MDD_READ128(fa[KQ][1], a_addr, 1 * 2048);                                                                    \
     MDD_READ128(fa[KQ][2], a_addr, 2 * 2048);                                                                    \
@@ -538,17 +553,13 @@ __global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
       MDD_READ128(fa[KQ][MI - 1], a_addr, 7 * 2048);                                                             \
     }                                                                                                            \
   } while (0)
-    // everything read so far is back; the listed registers are defined HERE as far as the compiler is concerned
-#define MDD_WAIT(KQ)                                                                                                                            \
-  do {                                                                                                                                         \
-    if constexpr (MI == 8) {                                                                                                                   \
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[KQ][0]), "+v"(fa[KQ][1]), "+v"(fa[KQ][2]), "+v"(fa[KQ][3]), "+v"(fa[KQ][MI - 4]),           \
-                   "+v"(fa[KQ][MI - 3]), "+v"(fa[KQ][MI - 2]), "+v"(fa[KQ][MI - 1]), "+v"(codes[KQ][0]), "+v"(codes[KQ][1]), "+v"(s[0]),        \
-                   "+v"(s[1]), "+v"(c[0]), "+v"(c[1]) : : "memory");                                                                         \
-    } else {                                                                                                                                   \
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[KQ][0]), "+v"(fa[KQ][1]), "+v"(fa[KQ][2]), "+v"(fa[KQ][3]), "+v"(codes[KQ][0]),             \
-                   "+v"(codes[KQ][1]), "+v"(s[0]), "+v"(s[1]), "+v"(c[0]), "+v"(c[1]) : : "memory");                                          \
-    }                                                                                                                                          \
+    // everything read so far is back; every register of the chunk is re-defined behind the wait as far as the compiler is concerned (an
+    // empty asm with the register as a read-write operand: volatile statements keep their order, so its uses stay behind the wait)
+#define MDD_WAIT(KQ)                                                                       \
+  do {                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+    _Pragma("unroll") for (int mi_ = 0; mi_ < MI; ++mi_) asm volatile("" : "+v"(fa[KQ][mi_])); \
+    _Pragma("unroll") for (int nj_ = 0; nj_ < NJ; ++nj_) asm volatile("" : "+v"(codes[KQ][nj_]), "+v"(s[nj_]), "+v"(c[nj_])); \
   } while (0)
     auto mfma_chunk = [&](auto kc) __attribute__((always_inline)) {
       constexpr int kq = decltype(kc)::value;
@@ -591,10 +602,10 @@ __global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
     if constexpr (GROUPED) {  // the step's group parameters of this lane's two weight rows, from the stage's parameter strip
       const uint32_t p_addr = st + p_off;
       MDD_READ32(s[0], p_addr, 0);
-      MDD_READ32(s[1], p_addr, 64);
+      if constexpr (NJ == 2) MDD_READ32(s[NJ - 1], p_addr, 64);
       if constexpr (OFFSET) {
-        MDD_READ32(c[0], p_addr, 128);
-        MDD_READ32(c[1], p_addr, 128 + 64);
+        MDD_READ32(c[0], p_addr, 64 * NJ);
+        if constexpr (NJ == 2) MDD_READ32(c[NJ - 1], p_addr, 64 * NJ + 64);
       }
     }
     // (lgkmcnt is a 4-bit counter: a chunk's 10 reads + 4 parameter reads stay below 16 in flight)
@@ -634,12 +645,12 @@ __global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
 #undef MDD_READ64
 #undef MDD_READ32
 
-  // ---- a wave's result: acc[mi][nj][t] = y[m0 + 16 mi + r16][n0 + 32 wave + 16 nj + 4 g4 + t] (partial over this block's k slice)
+  // ---- a wave's result: acc[mi][nj][t] = y[m0 + 16 mi + r16][n0 + 16 NJ wave + 16 nj + 4 g4 + t] (partial over this block's k slice)
   const int tile = tm * a.tiles_n + tn_all;
   if (a.S > 1) {
     constexpr size_t unit_bytes = (size_t)MI * NJ * 1024;
-    uint8_t* const strip = reinterpret_cast<uint8_t*>(a.slabs) + ((size_t)tile * a.S * 4 + wave) * unit_bytes;
-    const size_t slice_stride = (size_t)4 * unit_bytes;
+    uint8_t* const strip = reinterpret_cast<uint8_t*>(a.slabs) + ((size_t)tile * a.S * W + wave) * unit_bytes;
+    const size_t slice_stride = (size_t)W * unit_bytes;
     {
       const auto mine = __builtin_amdgcn_make_buffer_rsrc(strip + (size_t)slice * slice_stride, 0, (int)unit_bytes, 0x00020000);
 #pragma unroll
@@ -650,30 +661,41 @@ __global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left before the ticket is taken
     int t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(a.tickets + tile * 4 + wave, 1, FFQ_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) t = __hip_atomic_fetch_add(a.tickets + tile * W + wave, 1, FFQ_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t != a.S - 1) return;  // somebody else finishes this strip
-    if (lane == 0) __hip_atomic_store(a.tickets + tile * 4 + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(a.tickets + tile * W + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int nj = 0; nj < NJ; ++nj) acc[mi][nj] = wl_v4f{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int sl = 0; sl < a.S; ++sl) {  // slice order, whoever reduces
-      const auto peer = __builtin_amdgcn_make_buffer_rsrc(strip + (size_t)sl * slice_stride, 0, (int)unit_bytes, 0x00020000);
-      wl_v4u got[MI][NJ];
+    // slice order, whoever reduces: acc = ((0 + p0) + p1) + ... The partials of up to GROUP slices are requested before the first is
+    // added (the loads of one slice are one L2 / Infinity-Cache round trip: four of them in series were ~3 us of a 18 us launch)
+    constexpr int GROUP = MI <= 4 ? 4 : 2;
+    for (int sl0 = 0; sl0 < a.S; sl0 += GROUP) {
+      wl_v4u got[GROUP][MI][NJ];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+      for (int g = 0; g < GROUP; ++g) {
+        const int sl = sl0 + g < a.S ? sl0 + g : a.S - 1;  // (past the last slice: a re-read that is not added)
+        const auto peer = __builtin_amdgcn_make_buffer_rsrc(strip + (size_t)sl * slice_stride, 0, (int)unit_bytes, 0x00020000);
 #pragma unroll
-        for (int nj = 0; nj < NJ; ++nj) got[mi][nj] = __builtin_amdgcn_raw_buffer_load_b128(peer, ((mi * NJ + nj) * 64 + lane) * 16, 0, /*sc1*/ 16);
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+          for (int nj = 0; nj < NJ; ++nj) got[g][mi][nj] = __builtin_amdgcn_raw_buffer_load_b128(peer, ((mi * NJ + nj) * 64 + lane) * 16, 0, /*sc1*/ 16);
+      }
 #pragma unroll
-        for (int nj = 0; nj < NJ; ++nj) {
-          const wl_v4f g = __builtin_bit_cast(wl_v4f, got[mi][nj]);
+      for (int g = 0; g < GROUP; ++g) {
+        if (sl0 + g >= a.S) break;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[mi][nj][e] = acc[mi][nj][e] + g[e];
-        }
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int nj = 0; nj < NJ; ++nj) {
+            const wl_v4f p = __builtin_bit_cast(wl_v4f, got[g][mi][nj]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mi][nj][e] = acc[mi][nj][e] + p[e];
+          }
+      }
     }
   }
   // ---- epilogue: bias, cast, 4 consecutive columns per lane and row
@@ -681,7 +703,7 @@ __global__ __launch_bounds__(256, 2) void wq_mid_dma_kernel(MidArgs a) {
   const bool rows_by_4 = (rows & 3) == 0;
 #pragma unroll
   for (int nj = 0; nj < NJ; ++nj) {
-    const int ncol = n0 + wave * 32 + 16 * nj + 4 * (int)g4;
+    const int ncol = n0 + wave * 16 * NJ + 16 * nj + 4 * (int)g4;
     if (ncol >= rows) continue;
     float b4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (a.bias) {
@@ -753,7 +775,7 @@ int wq_mid_split(int64_t M, int64_t N, int64_t K) {
 // ticket words: one per (tile, wave), for the widest launch of this (M, N, K): three matrices, each rounded up to whole tiles
 int64_t wq_mid_tickets(int64_t M, int64_t N, int64_t K) {
   if (!wq_mid_shape_ok(M, K)) return 0;
-  return md_tiles_m(M, K) * (md_tiles_n(N) + 2) * 4;
+  return md_tiles_m(M, K) * (md_tiles_n(N) + 2) * 8;  // (tile, wave): up to 8 waves per tile
 }
 
 size_t wq_mid_slab_bytes(int64_t M, int64_t N, int64_t K, int64_t split) {
@@ -784,9 +806,9 @@ static void md_launch_dma(const MidArgs& m, int bm, unsigned grid, hipStream_t s
 #define FFQ_MDD(BM_)                                                                                                         \
   do {                                                                                                                       \
     static uint64_t attr_set = 0;                                                                                            \
-    const int lds_bytes = mdd_ring(BM_) * (BM_ * 128 + MD_BN * 64 + (GROUPED ? 1024 : 0));                                        \
+    const int lds_bytes = mdd_ring(BM_) * (BM_ * 128 + MD_BN * 64 + (GROUPED ? MDD_WAVES * 256 : 0));                                        \
     ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_mid_dma_kernel<BKIND, GROUPED, OFFSET, BM_>), lds_bytes); \
-    wq_mid_dma_kernel<BKIND, GROUPED, OFFSET, BM_><<<grid, 256, lds_bytes, stream>>>(m);                                      \
+    wq_mid_dma_kernel<BKIND, GROUPED, OFFSET, BM_><<<grid, 64 * MDD_WAVES, lds_bytes, stream>>>(m);                                      \
   } while (0)
   if (bm == 64) FFQ_MDD(64); else FFQ_MDD(128);
 #undef FFQ_MDD

@@ -91,9 +91,10 @@ def test_the_128_column_tile_kernels_keep_everything_in_registers_at_two_blocks_
 
 
 def test_the_lds_dma_form_of_the_128_column_tiles_is_the_loop_that_was_written():
-    """wq_mid_dma_kernel (csrc/ffq_wmid.hip): no spills, no scratch; its K-loop holds ONE counted `s_waitcnt vmcnt(N)` with N = the LDS-DMA
-    instructions of the ring's RING - 2 younger stages (1 x 6 for int8 per-channel weights at BM = 128, a three-stage ring), one raw barrier, the step's
-    6 LDS-DMA requests, 2 x (2 + 8) fragment reads in inline assembly and 32 MFMAs — and no compiler-inserted `vmcnt(0)`."""
+    """wq_mid_dma_kernel (csrc/ffq_wmid.hip): no spills, no scratch; its K-loop (int8 per-channel weights, BM = 128, 8 waves of 16 columns) holds
+    ONE counted `s_waitcnt vmcnt(N)` with N = the wave's LDS-DMA requests of the ring's RING - 2 younger stages (1 x 3), one raw barrier, the
+    step's 3 LDS-DMA requests (2 activation pieces + the wave's own 16 code rows), 2 x (1 + 8) fragment reads in inline assembly and 16 MFMAs
+    — and no compiler-inserted `vmcnt(0)`."""
     import re
 
     rows = _kernels("wq_mid_dma_kernel")
@@ -110,7 +111,7 @@ def test_the_lds_dma_form_of_the_128_column_tiles_is_the_loop_that_was_written()
     back = next(i for i in range(header, end) if re.search(r"s_cbranch_\w+ " + re.escape(label) + r"\b", lines[i]))
     body = [x.strip() for x in lines[header:back] if x.strip() and not x.strip().startswith((";", ".", "//"))]
     count = lambda prefix: sum(1 for o in body if o.startswith(prefix))  # noqa: E731
-    assert count("v_mfma_f32_16x16x32_bf16") == 32 and count("global_load_lds_dwordx4") == 6 and count("s_barrier") == 1
-    assert count("ds_read_b128") == 16 and count("ds_read_b64") == 4 and count("scratch_") == 0
+    assert count("v_mfma_f32_16x16x32_bf16") == 16 and count("global_load_lds_dwordx4") == 3 and count("s_barrier") == 1
+    assert count("ds_read_b128") == 16 and count("ds_read_b64") == 2 and count("scratch_") == 0
     waits = [o for o in body if o.startswith("s_waitcnt") and "vmcnt" in o]
-    assert waits == ["s_waitcnt vmcnt(6)"], waits
+    assert waits == ["s_waitcnt vmcnt(3)"], waits
