@@ -230,7 +230,10 @@ extern "C" int ffq_quantize_by_tile_backward(const void* data, const void* outpu
   uint32_t nchunks, units, nparts;
   int per_block;
   const double lo_d = -pow(2.0, num_bits - 1.0);
-  if (!backward_plan(info, &nchunks, &per_block, &units, &nparts) || !aligned16(data) || !aligned16(output_grad) || !aligned16(dinput) ||
+  // small problems of a few tiles (an eager quantizer of a small model: the host pays per launch, bench.py host_us_per_op) take the by-tile
+  // kernel as well: ONE launch instead of the streaming pass + its finalize (round 6: 11.8 us per call on the host with two launches)
+  const bool small = info.numel <= ((int64_t)1 << 16) && info.ntiles >= 4 && info.numel / info.ntiles <= 4096;
+  if (small || !backward_plan(info, &nchunks, &per_block, &units, &nparts) || !aligned16(data) || !aligned16(output_grad) || !aligned16(dinput) ||
       (scale_numel == 1 && info.ntiles != 1)) {
     // strided channels, N-d tiles, odd sizes, broadcast parameters: the by-tile kernel
     const TileWalk w = make_tile_walk(tiling);

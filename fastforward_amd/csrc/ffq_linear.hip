@@ -725,6 +725,9 @@ __device__ __forceinline__ void mlp_epilogue16_product(const LinearArgs& a, v4i3
   }
 }
 
+#ifndef FFQ_I8_KROT
+#define FFQ_I8_KROT 0
+#endif
 template <typename TOut, bool REQUANT, bool MLP, bool WOFF = false, bool GATED = false>
 __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, int total_tiles) {
   constexpr int BN2 = 256, WAVES_N = 4;
@@ -767,6 +770,9 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   }
   if constexpr (MLP || GATED) silu_table_fill(silu_table, (uint32_t)tid, 512u);
 
+#if FFQ_I8_KROT
+  const uint32_t k_rot = FFQ_I8_KROT == 1 ? xcd * (uint32_t)(a.K / 128) / 8u : (blockIdx.x * 37u) % (uint32_t)(a.K / 128);
+#endif
   const int d_row = lane >> 3;
   uint32_t a_voff[4], b_voff[4];   // lane offsets inside the tile's rows: < 256 K + 128
   const int8_t* a_base = xq_in_force;  // wave-uniform: first row of the tile
@@ -818,6 +824,10 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   };
   auto issue_a = [&](int ks, int slot, int c0) {
     uint8_t* base = lds2 + slot * SLOT_BYTES;
+#if FFQ_I8_KROT  // A/B hook: every XCD walks the contraction from its own starting depth (integer sums: the result does not change)
+    ks += (int)k_rot;
+    ks = ks >= a.K / 128 ? ks - a.K / 128 : ks;
+#endif
 #pragma unroll
     for (int c = c0; c < c0 + 2; ++c) {
       asm volatile("" : "+v"(a_voff[c]));  // see the header: keeps the saddr form in every unrolled body
@@ -826,6 +836,10 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   };
   auto issue_b = [&](int ks, int slot, int c0) {
     uint8_t* base = lds2 + slot * SLOT_BYTES + B_IMAGE;
+#if FFQ_I8_KROT
+    ks += (int)k_rot;
+    ks = ks >= a.K / 128 ? ks - a.K / 128 : ks;
+#endif
 #pragma unroll
     for (int c = c0; c < c0 + 2; ++c) {
       asm volatile("" : "+v"(b_voff[c]));
