@@ -315,7 +315,7 @@ __device__ __forceinline__ void gemm256_epilogue_slabs16(const LinearArgs& a, v4
   TOut* out = static_cast<TOut*>(a.out);
   // the tile's output matrix: its first element, its row pitch and its first column in the launch's column space (tile-uniform selects)
   int out_n = a.N, col0 = 0;
-  if (a.seg_start[0] != INT32_MAX) {
+  if (!GATED && !WOFF && a.seg_start[0] != INT32_MAX) {  // (several outputs: the plain launch only; the either / or instantiations have no register to spare)
     if (n0 >= a.seg_start[1]) { out = static_cast<TOut*>(a.seg_out[1]); col0 = a.seg_start[1]; out_n = a.N - col0; }
     else if (n0 >= a.seg_start[0]) { out = static_cast<TOut*>(a.seg_out[0]); col0 = a.seg_start[0]; out_n = (a.seg_start[1] == INT32_MAX ? a.N : a.seg_start[1]) - col0; }
     else out_n = a.seg_start[0];
@@ -725,9 +725,6 @@ __device__ __forceinline__ void mlp_epilogue16_product(const LinearArgs& a, v4i3
   }
 }
 
-#ifndef FFQ_I8_KROT
-#define FFQ_I8_KROT 0
-#endif
 template <typename TOut, bool REQUANT, bool MLP, bool WOFF = false, bool GATED = false>
 __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, int total_tiles) {
   constexpr int BN2 = 256, WAVES_N = 4;
@@ -754,7 +751,13 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
     if (a.run_if && *a.run_if != a.run_when) return;
   }
   const int8_t* xq_in_force = a.xq;
-  if constexpr (WOFF || GATED) xq_in_force = codes_in_force(a.xq, a.x_scale, a.x_offset, a.earlier);
+  if constexpr (WOFF || GATED) {
+    // (read back through readfirstlane: a pointer that is the result of a select on loaded values is a VECTOR value to hipcc — the four
+    // A pieces then carry 64-bit per-lane addresses, the K-loop 64-bit vector adds, and the GATED form spills)
+    const uint64_t p = reinterpret_cast<uint64_t>(codes_in_force(a.xq, a.x_scale, a.x_offset, a.earlier));
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    xq_in_force = reinterpret_cast<const int8_t*>(((uint64_t)hi << 32) | lo);
+  }
   if (my_tiles == 0) {
     if constexpr (GATED || PRODUCT) {
       if (a.extrema.words && tid == 0) extrema_publish(a.extrema, 0.0f, 0.0f, false, false, gridDim.x);
@@ -770,9 +773,12 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   }
   if constexpr (MLP || GATED) silu_table_fill(silu_table, (uint32_t)tid, 512u);
 
-#if FFQ_I8_KROT
-  const uint32_t k_rot = FFQ_I8_KROT == 1 ? xcd * (uint32_t)(a.K / 128) / 8u : (blockIdx.x * 37u) % (uint32_t)(a.K / 128);
-#endif
+  // A contraction depth that is a large power of two puts the same depth of every row of every tile on the same few memory channels,
+  // and all 256 CUs walk the depth in step: XCD x starts x/8 of the way in and wraps. Integer sums: the result does not change.
+  // Round 6, A/B of two builds, two rounds (profiles/r06_krot_ab.txt): 70B gate/up (K = 8192) 1.461 -> 1.399 ms at 8192 tokens, the
+  // gate+up+SiLU launch 2.97 -> 2.81; K = 4096 / 14336 / 28672 +-0.3 % (off there).
+  // (not in the GATED instantiations, the device-side either / or of a calibration step: they have no register to spare)
+  const int k_rot = (!GATED && a.K >= 8192 && (a.K & (a.K - 1)) == 0) ? (int)(xcd * (uint32_t)(a.K / 128) / 8u) : 0;
   const int d_row = lane >> 3;
   uint32_t a_voff[4], b_voff[4];   // lane offsets inside the tile's rows: < 256 K + 128
   const int8_t* a_base = xq_in_force;  // wave-uniform: first row of the tile
@@ -808,7 +814,10 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
       const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
       int ra = row;
       ra = tm0 + ra < a.M ? ra : a.M - 1 - tm0;  // rows past the edge re-read the last row and are never stored
-      a_voff[c] = (uint32_t)ra * (uint32_t)a.K + d_slot * 16;
+      // (GATED: as a 24-bit multiply-add — hipcc forms row * K + slot with v_mad_u64_u32, a register PAIR per offset and per addend, and
+      // this instantiation has none to spare: it spilled four. ra < 256, K < 2^24. The other instantiations keep their allocation.)
+      if constexpr (GATED) a_voff[c] = __umul24((uint32_t)ra, (uint32_t)a.K) + (uint32_t)(d_slot * 16);
+      else a_voff[c] = (uint32_t)ra * (uint32_t)a.K + d_slot * 16;
       if constexpr (MLP) {
         // rows 32..63 of a wave's 64 come from the up matrix: row & 32 is the same for all lanes of a piece (8 rows per piece)
         const int rb = (row >> 6) * 32 + (row & 31);
@@ -818,16 +827,13 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
         int rb = row;
         rb = tn0 + rb < a.N ? rb : a.N - 1 - tn0;
         b_base[c] = row_base(a.wq, tn0);
-        b_voff[c] = (uint32_t)rb * (uint32_t)a.K + d_slot * 16;
+        if constexpr (GATED) b_voff[c] = __umul24((uint32_t)rb, (uint32_t)a.K) + (uint32_t)(d_slot * 16);
+        else b_voff[c] = (uint32_t)rb * (uint32_t)a.K + d_slot * 16;
       }
     }
   };
   auto issue_a = [&](int ks, int slot, int c0) {
     uint8_t* base = lds2 + slot * SLOT_BYTES;
-#if FFQ_I8_KROT  // A/B hook: every XCD walks the contraction from its own starting depth (integer sums: the result does not change)
-    ks += (int)k_rot;
-    ks = ks >= a.K / 128 ? ks - a.K / 128 : ks;
-#endif
 #pragma unroll
     for (int c = c0; c < c0 + 2; ++c) {
       asm volatile("" : "+v"(a_voff[c]));  // see the header: keeps the saddr form in every unrolled body
@@ -836,10 +842,6 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   };
   auto issue_b = [&](int ks, int slot, int c0) {
     uint8_t* base = lds2 + slot * SLOT_BYTES + B_IMAGE;
-#if FFQ_I8_KROT
-    ks += (int)k_rot;
-    ks = ks >= a.K / 128 ? ks - a.K / 128 : ks;
-#endif
 #pragma unroll
     for (int c = c0; c < c0 + 2; ++c) {
       asm volatile("" : "+v"(b_voff[c]));
@@ -896,7 +898,7 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
   int slot = 0;  // slot of the super-step about to be computed
   tile_origin(0, m0, n0);
   set_sources(m0, n0);
-  issue_a(0, 0, 0); issue_a(0, 0, 2); issue_b(0, 0, 0); issue_b(0, 0, 2);
+  issue_a(k_rot, 0, 0); issue_a(k_rot, 0, 2); issue_b(k_rot, 0, 0); issue_b(k_rot, 0, 2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -920,6 +922,8 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
         fetch = has_next ? 0 : ks;
         if (has_next) set_sources(nm0, nn0);
       }
+      fetch += k_rot;  // the depth this XCD is at (see k_rot)
+      fetch = fetch >= ksuper ? fetch - ksuper : fetch;
       // The eight LDS-DMA pieces of a wave are issued in the LOAD segments of phases 0 and 1 — by the group that is NOT
       // computing, behind its own fragment reads (lgkmcnt(0)) and ahead of the barrier. An LDS-DMA instruction blocks its wave's
       // instruction stream for 60+ cycles: inside a cluster (rounds 1-2) that let the matrix pipe run dry behind every piece

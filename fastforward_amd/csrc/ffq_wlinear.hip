@@ -795,9 +795,6 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
 // and with an even number of super-steps (wq_dispatch); bf16 output.
 // (A gate+up+SiLU*up mode of this kernel was built and is bit-equal too, but measured 3-5 % SLOWER than the 8-wave kernel's —
 // 2.83 against 2.75 ms at 16 k tokens — and was removed; the plain form is +2 % on q/o and gate/up, +4 % on down_proj.)
-#ifndef FFQ_W4_KROT
-#define FFQ_W4_KROT 0
-#endif
 #ifndef FFQ_W4_SPREAD
 #define FFQ_W4_SPREAD 1  // round 6: the A and the B LDS-DMA piece of a pair four MFMAs apart (0: back to back, round 4). A/B, three interleaved rounds on one box
                          // (profiles/r06_w4_spread_ab.txt): gate/up 1.316 -> 1.291 ms (+1.9 %), q/o and down_proj +-0, layer mix 1439 -> 1455 TFLOP/s
@@ -828,9 +825,11 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
   if (my_tiles == 0) return;
   const int ksuper = a.K / WL_BK;  // even (wq_dispatch)
   uint8_t* const stage = lds + 2 * WL_SLOT + wave * W4_WAVE_PLAIN;
-#if FFQ_W4_KROT
-  const uint32_t k_rot = FFQ_W4_KROT == 1 ? xcd * (uint32_t)ksuper / 8u : (blockIdx.x * 37u) % (uint32_t)ksuper;
-#endif
+  // A contraction depth that is a large power of two puts the same depth of every row of every tile on the same few memory channels,
+  // and all 256 CUs walk the depth in step: XCD x starts x/8 of the way in and wraps (round 6, A/B of two builds, two rounds,
+  // profiles/r06_krot_ab.txt: K = 8192 848 -> 743 us at 16 k tokens x 4096 columns, 16384 +2 %; other depths +-1.5 % or worse — off there).
+  // The fp32 sum of a tile is then taken in that rotated order: a function of the shape and the grid, like the rest of the plan.
+  const uint32_t k_rot = (a.K >= 8192 && (a.K & (a.K - 1)) == 0) ? xcd * (uint32_t)ksuper / 8u : 0u;
 
   auto tile_origin = [&](int it, int& tm0, int& tn0, int& seg) {
     it = it < my_tiles ? it : my_tiles - 1;  // the stream running past the block's last tile re-reads it (never used)
@@ -885,10 +884,8 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
   };
   auto issue_one = [&](int ks, int slot, int c, int which) {  // piece c of the A (0) or B (1) image of super-step ks
     uint8_t* base = lds + slot * WL_SLOT;
-#if FFQ_W4_KROT  // A/B hook: every XCD walks the contraction from its own starting depth (the sum's order changes: timing builds only)
-    ks += (int)k_rot;
+    ks += (int)k_rot;  // (scalar: two instructions per piece)
     ks = ks >= ksuper ? ks - ksuper : ks;
-#endif
     const uint32_t soff = (uint32_t)c * 8u * row_bytes + (uint32_t)ks * 128u;
     if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (wl_lds_t*)(base + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (wl_lds_t*)(base + WL_IMAGE + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);

@@ -229,7 +229,6 @@ def test_producers_forward_weight_only_on_gpu(hip_backend):
 
 
 @pytest.mark.gpu
-@pytest.mark.gpu
 def test_fused_forward_runs_q_k_v_as_one_int8_launch(hip_backend, monkeypatch):
     """llama.FusedForward at widths the persistent int8 GEMM takes (hidden 2048, 16 / 4 heads of 128: q 2048, k / v 512 rows; 4096 tokens):
     every layer's q_proj / k_proj / v_proj run as ONE ops.linear_w8a8_multi launch on the code tensor their input quantizers share, from
@@ -260,6 +259,7 @@ def test_fused_forward_runs_q_k_v_as_one_int8_launch(hip_backend, monkeypatch):
     assert torch.equal(captured, got)
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("w_bits,block", [(8, None), (4, 128)])
 def test_weight_only_storage_forms_agree_bit_for_bit(hip_backend, w_bits, block):
     """BASELINE configs 2 / 4 on a small Llama: the weight quantizer on every call ("requantize"), kept int8 codes, kept
