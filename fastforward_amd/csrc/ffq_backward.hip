@@ -202,9 +202,15 @@ static bool backward_plan(const TileInfo& info, uint32_t* nchunks, int* per_bloc
 
 using namespace ffq;
 
+// small problems of a few tiles take the by-tile kernel: ONE launch, no workspace (see ffq_quantize_by_tile_backward)
+static bool backward_small(const TileInfo& info) {
+  return info.numel <= ((int64_t)1 << 16) && info.ntiles >= 4 && info.numel / info.ntiles <= 4096;
+}
+
 extern "C" size_t ffq_quantize_backward_workspace_bytes(const ffq_tiling* tiling) {
   TileInfo info;
   if (analyse(tiling, &info)) return 0;
+  if (backward_small(info)) return 0;
   uint32_t nchunks, units, nparts;
   int per_block;
   if (!backward_plan(info, &nchunks, &per_block, &units, &nparts)) return 0;
@@ -232,7 +238,7 @@ extern "C" int ffq_quantize_by_tile_backward(const void* data, const void* outpu
   const double lo_d = -pow(2.0, num_bits - 1.0);
   // small problems of a few tiles (an eager quantizer of a small model: the host pays per launch, bench.py host_us_per_op) take the by-tile
   // kernel as well: ONE launch instead of the streaming pass + its finalize (round 6: 11.8 us per call on the host with two launches)
-  const bool small = info.numel <= ((int64_t)1 << 16) && info.ntiles >= 4 && info.numel / info.ntiles <= 4096;
+  const bool small = backward_small(info);
   if (small || !backward_plan(info, &nchunks, &per_block, &units, &nparts) || !aligned16(data) || !aligned16(output_grad) || !aligned16(dinput) ||
       (scale_numel == 1 && info.ntiles != 1)) {
     // strided channels, N-d tiles, odd sizes, broadcast parameters: the by-tile kernel

@@ -1092,7 +1092,10 @@ static int linear_w8a8_impl(const int8_t* xq, const int8_t* wq, const int32_t* w
     return fail(FFQ_ERR_DTYPE, "real-valued output must be f32, bf16 or f16");
   }
   const size_t need = ffq_linear_w8a8_workspace_bytes(M, N, K);
-  if (((x_offset && !w_rowsum) || w_offset || earlier.codes) && (need > workspace_bytes || !workspace))
+  // what the workspace holds: the weight row sums of a persistent launch (the tail kernel sums its own), the activation row sums and
+  // the flag of a launch with weight offsets / earlier codes. A launch with none of them runs with workspace == NULL (include/ffq.h)
+  const bool sums_in_workspace = x_offset && !w_rowsum && linear_takes_earlier(M, N, K);
+  if ((sums_in_workspace || w_offset || earlier.codes) && (need > workspace_bytes || !workspace))
     return fail(FFQ_ERR_WORKSPACE, "w8a8 linear needs %zu workspace bytes, got %zu", need, workspace_bytes);
 
   LinearArgs a;
@@ -1324,7 +1327,7 @@ extern "C" int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_s
     return fail(FFQ_ERR_DTYPE, "real-valued output must be f32, bf16 or f16");
   }
   const size_t need = ffq_bmm_w8a8_workspace_bytes(batch, M, N, K);
-  if ((x_offset || w_offset) && (need > workspace_bytes || !workspace)) return fail(FFQ_ERR_WORKSPACE, "batched w8a8 matmul needs %zu workspace bytes, got %zu", need, workspace_bytes);
+  if (w_offset && (need > workspace_bytes || !workspace)) return fail(FFQ_ERR_WORKSPACE, "batched w8a8 matmul needs %zu workspace bytes, got %zu", need, workspace_bytes);
   LinearArgs a;
   a.xq = xq; a.wq = wq;
   a.x_scale = x_scale; a.x_offset = x_offset;

@@ -360,7 +360,10 @@ at::Tensor linear_w8a8(const at::Tensor& x_codes, const at::Tensor& w_codes, con
   std::vector<int64_t> shape(xc.sizes().begin(), xc.sizes().end());
   if (!shape.empty()) shape.back() = N;
   at::Tensor out = at::empty(shape, xc.options().dtype(out_dtype));
-  const size_t nbytes = ffq_linear_w8a8_workspace_bytes(M, N, K);
+  // (include/ffq.h: no workspace without weight offsets when the weight row sums come with the call, are not needed, or the shape is
+  // below the persistent kernel's class — an eager linear of a small model is one allocation less)
+  const bool needs_ws = wo.defined() || (xo.defined() && !rowsum.defined() && ffq_linear_w8a8_takes_earlier(M, N, K));
+  const size_t nbytes = needs_ws ? ffq_linear_w8a8_workspace_bytes(M, N, K) : 0;
   at::Tensor ws = workspace(nbytes, xc);
   const int y_dt = os_.defined() ? tag_of(requant_from.value_or(at::kBFloat16)) : 0;
   check(ffq_linear_w8a8(static_cast<const int8_t*>(xc.data_ptr()), static_cast<const int8_t*>(wc.data_ptr()), static_cast<const int32_t*>(ptr(rowsum)),
@@ -388,7 +391,7 @@ at::Tensor bmm_w8a8(const at::Tensor& x_codes, const at::Tensor& w_codes, const 
   for (const at::Tensor* t : {&wc, &xs, &xo, &ws_, &wo, &os_, &oo})
     if (t->defined()) same_device(xc, *t);
   at::Tensor out = at::empty({B, M, N}, xc.options().dtype(out_dtype));
-  const size_t nbytes = ffq_bmm_w8a8_workspace_bytes(B, M, N, K);
+  const size_t nbytes = wo.defined() ? ffq_bmm_w8a8_workspace_bytes(B, M, N, K) : 0;  // (the activation row sums of a launch with weight offsets)
   at::Tensor ws = workspace(nbytes, xc);
   const int y_dt = os_.defined() ? tag_of(requant_from.value_or(at::kBFloat16)) : 0;
   check(ffq_bmm_w8a8(static_cast<const int8_t*>(xc.data_ptr()), static_cast<const int8_t*>(wc.data_ptr()), static_cast<const float*>(xs.data_ptr()),

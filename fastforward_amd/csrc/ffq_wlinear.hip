@@ -784,27 +784,34 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
 // The bf16-image form with ONE wavefront per SIMD (round 4; tools/probes/gemm4w_probe.hip is the experiment this came out of):
 // 4 waves x 128 x 128 accumulators — 256 registers per lane, pinned to AGPRs as "+a" operands of inline-assembly MFMAs (with the
 // builtin hipcc rotates them through VGPRs: ~590 v_accvgpr moves per two super-steps) — so a k-half of 64 MFMAs needs 16 fragment
-// reads (0.25 per MFMA against 0.375 with 128 x 64 per wave), hand-placed one per three MFMAs a k-half AHEAD of their use into a
-// second register set; both operand images by LDS-DMA into the two 64 KiB slots, the sixteen pieces of a wave spread over the
-// second k-half; ONE barrier per super-step (behind the first k-half: the next images have landed, this slot has been read in
-// full). The K-loop is `asm volatile` in source order: 256 MFMAs + 64 ds_read_b128 + 32 LDS-DMA pieces + scalar bookkeeping per
-// two super-steps and nothing else. It runs ACROSS tile boundaries: the last two super-steps of a tile fetch the first two of
-// the next, its last k-half reads the next tile's first fragments, and the epilogue in between goes through wave-private rows
-// of LDS behind the slots while those images land. Same MFMA instruction, same k order as wq_gemm256_kernel: bit-identical results.
+// reads (0.25 per MFMA against 0.375 with 128 x 64 per wave), hand-placed between the MFMAs ahead of their use; both operand images by
+// LDS-DMA into the two 64 KiB slots. The K-loop is `asm volatile` in source order: 256 MFMAs + 64 ds_read_b128 + 32 LDS-DMA pieces +
+// scalar bookkeeping per two super-steps and nothing else. It runs ACROSS tile boundaries: the last two super-steps of a tile fetch the
+// first two of the next and read its first fragments, and the epilogue in between goes through wave-private rows of LDS behind the
+// slots while those images land. Same MFMA instruction, same k order as wq_gemm256_kernel: bit-identical results.
+//
+// Round 6 — the A operand runs HALF A STEP AHEAD of the B operand (super_step below). Rounds 4-5 refilled a slot as a whole: all 16
+// pieces of a wave in the second k-half, none in the first. A piece occupies the CU's texture path for 16 cycles (1 KiB at 64 B/clk):
+// four waves x 16 pieces are 1024 cycles of it inside a k-half of 1024 MFMA cycles, and a wave that cannot issue its piece cannot
+// issue its next MFMA either — the "60+ cycles per LDS-DMA issue" of rounds 2-5 was this queue, not the instruction. With A's fetch,
+// fragment reads and refill shifted half a step against B's, each IMAGE of a slot is refilled as soon as its last reader is done and
+// every k-half issues 8 pieces; A(k+2) gets 1 - 1.5 super-steps to land (counted `vmcnt(8)` waits), B(k+2) 0.5 - 1 as before. Same
+// tiles, same k order, same bits (tests/test_gemm_gpu.py). A/B of two builds, two interleaved rounds (profiles/r06_w4_half_ab.txt,
+// 16 k tokens x 4096 columns): K = 4096 401 -> 375 us, 12288 1154 -> 1074, 14336 (down_proj) 1373 -> 1253, 16384 1690 -> 1435; the
+// distance to the vendor's GEMM on the dequantized weight 8 - 23 % -> 2.5 - 5.5 %. (Earlier placements of the 16 pieces INSIDE the second
+// k-half — back to back, four MFMAs apart (+1.9 %), an L2 warm-up 2 - 4 steps ahead (-3..-6 %: more texture work) — are in
+// profiles/r06_w4_spread_ab.txt / r06_w4_ahead_ab.txt and docs/experiments.md.)
 // Taken for plain launches of whole tiles (M and every weight matrix a multiple of 256 rows) without a split tail, without a bias
 // and with an even number of super-steps (wq_dispatch); bf16 output.
-// (A gate+up+SiLU*up mode of this kernel was built and is bit-equal too, but measured 3-5 % SLOWER than the 8-wave kernel's —
-// 2.83 against 2.75 ms at 16 k tokens — and was removed; the plain form is +2 % on q/o and gate/up, +4 % on down_proj.)
-#ifndef FFQ_W4_SPREAD
-#define FFQ_W4_SPREAD 1  // round 6: the A and the B LDS-DMA piece of a pair four MFMAs apart (0: back to back, round 4). A/B, three interleaved rounds on one box
-                         // (profiles/r06_w4_spread_ab.txt): gate/up 1.316 -> 1.291 ms (+1.9 %), q/o and down_proj +-0, layer mix 1439 -> 1455 TFLOP/s
-#endif
-#ifndef FFQ_W4_AHEAD
-#define FFQ_W4_AHEAD 0  // A/B hook (tools/build_variant.sh): L2 warm-up distance in super-steps beyond the LDS-DMA's own
-#endif
+// (A gate+up+SiLU*up mode of this kernel was built in round 4 and is bit-equal too, but measured 3-5 % SLOWER than the 8-wave kernel's
+// — 2.83 against 2.75 ms at 16 k tokens, with the slot-at-a-time schedule — and was removed.)
 constexpr int W4_PITCH_PLAIN = 128 * 2 + 16;  // a staged row of a wave: 128 bf16 + pad
 constexpr int W4_WAVE_PLAIN = 16 * W4_PITCH_PLAIN;
 
+// fn(integral_constant<int, 0>), fn(<1>), ...: a loop whose index is a constant expression in every body (hipcc gives up fully unrolling
+// a 64-trip loop around a 24-case switch; with constant indices no switch is needed)
+template <typename F, int... I>
+__device__ __forceinline__ void w4_each(F&& fn, std::integer_sequence<int, I...>) { (fn(std::integral_constant<int, I>{}), ...); }
 __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -890,24 +897,6 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
     if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (wl_lds_t*)(base + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (wl_lds_t*)(base + WL_IMAGE + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);
   };
-  auto issue = [&](int ks, int slot, int c) {  // piece c of both images of super-step ks (of the tile the descriptors point at)
-    issue_one(ks, slot, c, 0);
-    issue_one(ks, slot, c, 1);
-  };
-
-  // ---- L2 warm-up (FFQ_W4_AHEAD super-steps ahead of the LDS-DMA): a super-step of an image is ONE 128-byte line per row, so one
-  // dword per lane touches the 64 lines of this wave's rows of either operand. The dwords go to a scratch corner of LDS (no register
-  // is written: nothing to keep alive while the request flies) and stay outstanding across the mid-step wait (vmcnt counts in order:
-  // the DMA pieces are older), which gives a line from HBM two or three super-steps to arrive instead of one.
-#if FFQ_W4_AHEAD > 0
-  uint8_t* const warm = lds + 2 * WL_SLOT + 4 * W4_WAVE_PLAIN + wave * 512;
-  const uint32_t warm_voff = (uint32_t)(wave * 64 + lane) * row_bytes;
-  auto warm_up = [&](int kn, int which) {
-    int ks = kn + FFQ_W4_AHEAD;
-    ks = ks < ksuper ? ks : ksuper - 1;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(which ? b_rsrc : a_rsrc, (wl_lds_t*)(warm + which * 256), 4, warm_voff, (uint32_t)ks * 128u, 0, 0);
-  };
-#endif
 
   // ---- fragment addresses: lane (r16, g4) reads 8 bf16 of row r16 of a 16-row tile, logical slot kq * 4 + g4; one register per
   // (slot, k-half, operand), the row tile in the instruction's offset field (t * 2048)
@@ -923,7 +912,9 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
         b_off[sl][kq] = sl * WL_SLOT + WL_IMAGE + brow * 128 + (((kq * 4 + g4) ^ ((brow >> 1) & 7u)) << 4);
       }
   }
-  wl_v4i fa0[8], fb0[8], fa1[8], fb1[8];
+  wl_v4i fX[8];      // A fragments of the first k-half of the current super-step (re-loaded for the next one during the second k-half)
+  wl_v4i fY[2][8];   // A fragments of the second k-half, by super-step parity
+  wl_v4i fB[2][8];   // B fragments [k-half][column tile]
   wl_v4f acc[8][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -931,101 +922,103 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
     for (int j = 0; j < 8; ++j) acc[i][j] = wl_v4f{0.f, 0.f, 0.f, 0.f};
 #define FFQ_W4_MFMA(ACC, B, A) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(B), "v"(A))
 #define FFQ_W4_READ(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
-  // fragment read r (0..15) of a k-half in the order the next k-half's MFMAs need them: fb0, fa0, fb1..fb7, fa1..fa7
-  auto read_one = [&](int r, uint32_t ao, uint32_t bo, wl_v4i (&fa)[8], wl_v4i (&fb)[8]) {
-    switch (r) {
-      case 0: FFQ_W4_READ(fb[0], bo, 0 * 2048); break;
-      case 1: FFQ_W4_READ(fa[0], ao, 0 * 2048); break;
-      case 2: FFQ_W4_READ(fb[1], bo, 1 * 2048); break;
-      case 3: FFQ_W4_READ(fb[2], bo, 2 * 2048); break;
-      case 4: FFQ_W4_READ(fb[3], bo, 3 * 2048); break;
-      case 5: FFQ_W4_READ(fb[4], bo, 4 * 2048); break;
-      case 6: FFQ_W4_READ(fb[5], bo, 5 * 2048); break;
-      case 7: FFQ_W4_READ(fb[6], bo, 6 * 2048); break;
-      case 8: FFQ_W4_READ(fb[7], bo, 7 * 2048); break;
-      case 9: FFQ_W4_READ(fa[1], ao, 1 * 2048); break;
-      case 10: FFQ_W4_READ(fa[2], ao, 2 * 2048); break;
-      case 11: FFQ_W4_READ(fa[3], ao, 3 * 2048); break;
-      case 12: FFQ_W4_READ(fa[4], ao, 4 * 2048); break;
-      case 13: FFQ_W4_READ(fa[5], ao, 5 * 2048); break;
-      case 14: FFQ_W4_READ(fa[6], ao, 6 * 2048); break;
-      default: FFQ_W4_READ(fa[7], ao, 7 * 2048); break;
+  // one fragment: 16-row tile t of the image whose lane address is `off`
+  auto read_tile = [&](wl_v4i (&dst)[8], uint32_t off, int t) __attribute__((always_inline)) {
+    switch (t) {
+      case 0: FFQ_W4_READ(dst[0], off, 0 * 2048); break;
+      case 1: FFQ_W4_READ(dst[1], off, 1 * 2048); break;
+      case 2: FFQ_W4_READ(dst[2], off, 2 * 2048); break;
+      case 3: FFQ_W4_READ(dst[3], off, 3 * 2048); break;
+      case 4: FFQ_W4_READ(dst[4], off, 4 * 2048); break;
+      case 5: FFQ_W4_READ(dst[5], off, 5 * 2048); break;
+      case 6: FFQ_W4_READ(dst[6], off, 6 * 2048); break;
+      default: FFQ_W4_READ(dst[7], off, 7 * 2048); break;
     }
   };
-  // one k-half: 64 MFMAs on (fa, fb) in snake order (every MFMA shares an operand with its predecessor); fragment read r of the NEXT
-  // k-half behind MFMA 3 r + 1 (all sixteen issued by MFMA 46: the last has 17 MFMAs to return in); with DMA: piece c behind MFMA 8 c + 3
-  auto phase = [&](const wl_v4i (&fa)[8], const wl_v4i (&fb)[8], wl_v4i (&na)[8], wl_v4i (&nb)[8], uint32_t ao, uint32_t bo, auto dma, auto with_dma) {
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
-      const int mi = i >> 3, n_ = i & 7;
-      const int nj = (mi & 1) ? 7 - n_ : n_;
+  // one k-half: 64 MFMAs on (fa, fb) in snake order with `reads(<i>)` behind MFMA i and LDS-DMA piece c behind MFMA 8 c + 3
+  auto half = [&](const wl_v4i (&fa)[8], const wl_v4i (&fb)[8], auto reads, auto dma) __attribute__((always_inline)) {
+    w4_each([&acc, &fa, &fb, &reads, &dma](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value, mi = i >> 3, n_ = i & 7, nj = (mi & 1) ? 7 - n_ : n_;
       FFQ_W4_MFMA(acc[mi][nj], fb[nj], fa[mi]);
-      if (i % 3 == 1 && i / 3 < 16) read_one(i / 3, ao, bo, na, nb);
-      if constexpr (decltype(with_dma)::value) {
-#if FFQ_W4_SPREAD  // A/B hook (tools/build_variant.sh): the A and the B piece four MFMAs apart instead of back to back
-        if ((i & 7) == 1) dma(i >> 3, 0);
-        if ((i & 7) == 5) dma(i >> 3, 1);
-#else
-        if ((i & 7) == 3) dma(i >> 3);
-#endif
-      }
-    }
+      reads(ic);
+      if constexpr ((i & 7) == 3) dma(i >> 3);
+    }, std::make_integer_sequence<int, 64>{});
   };
-
   int m0 = 0, n0 = 0, seg = 0;
   tile_origin(0, m0, n0, seg);
   set_image_sources(m0, n0, seg);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) issue(0, 0, c);
+  for (int c = 0; c < 8; ++c) issue_one(0, 0, c, 0);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) issue(1, 1, c);
+  for (int c = 0; c < 8; ++c) issue_one(0, 0, c, 1);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) issue_one(1, 1, c, 0);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) issue_one(1, 1, c, 1);
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // super-step 0 has landed (this wave's pieces), super-step 1 may still fly
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 16; ++r) read_one(r, a_off[0][0], b_off[0][0], fa0, fb0);
+  for (int t = 0; t < 8; ++t) read_tile(fB[0], b_off[0][0], t);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) read_tile(fX, a_off[0][0], t);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
+#pragma unroll
+  for (int t = 0; t < 8; ++t) read_tile(fY[0], a_off[0][1], t);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();  // everybody has read A(0): super-step 0 refills that image
 #pragma unroll 1
   for (int it = 0; it < my_tiles; ++it) {
     int nm0, nn0, nseg;
     tile_origin(it + 1, nm0, nn0, nseg);
-    // super-step ks from slot `cur` (compile-time after inlining); its second k-half fetches super-step `kn` of the tile the image
-    // sources point at into `cur`
-    auto super_step = [&](int kn, int cur) {
-      const int nxt = cur ^ 1;
-      // ---- first k-half: MFMAs on set 0 | read the second k-half of `cur` into set 1
-#if FFQ_W4_AHEAD > 0
-#if FFQ_W4_SPREAD
-      phase(fa0, fb0, fa1, fb1, a_off[cur][1], b_off[cur][1], [&](int c, int which) { if (c == 0) warm_up(kn, which); }, std::true_type{});
-#else
-      phase(fa0, fb0, fa1, fb1, a_off[cur][1], b_off[cur][1], [&](int c) { if (c < 2) warm_up(kn, c); }, std::true_type{});
-#endif
-      // the images of the next super-step have landed (this wave's pieces; the barrier makes it everybody's), `cur` has been read in
-      // full; the two warm-up dwords issued in this k-half are younger than the pieces and stay in flight
-      asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-#else
-      phase(fa0, fb0, fa1, fb1, a_off[cur][1], b_off[cur][1], [](int) {}, std::false_type{});
-      // the images of the next super-step have landed (this wave's pieces; the barrier makes it everybody's), `cur` has been read in full
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
+    // Super-step ks from slot `cur` with the A operand HALF A STEP AHEAD of the B operand: at entry the registers hold A(ks) for both
+    // k-halves and B(ks, k-half 0). Each image of a slot is refilled as soon as its last reader is done, so the LDS-DMA stream is spread
+    // over the whole super-step — 8 pieces per wave and k-half — where the slot-at-a-time schedule issues all 16 in the second k-half:
+    // a piece occupies the CU's texture path for 16 cycles (1 KiB at 64 B/clk), four waves x 16 pieces are 1024 cycles of it inside a
+    // k-half of 1024 MFMA cycles, and a wave that cannot issue its piece cannot issue its next MFMA either.
+    //   first k-half   MFMAs A(ks,0) x B(ks,0) | read B(ks,1) from `cur` | DMA A(kn) -> the A image of `cur` (last readers: the second
+    //                  k-half of step ks-1, behind that step's closing barrier)
+    //   barrier        vmcnt(8): everything but the 8 A pieces just issued has landed — A(ks+1), B(ks+1)
+    //   second k-half  MFMAs A(ks,1) x B(ks,1) | read B(ks+1,0), A(ks+1,0), A(ks+1,1) from `nxt` | DMA B(kn) -> the B image of `cur`
+    //                  (last readers: the first k-half, behind the barrier above)
+    //   barrier        the A image of `nxt` has been read in full (no memory wait: nothing new is needed yet)
+    // A(kn) has 1 - 1.5 super-steps to land, B(kn) 0.5 - 1. Loads return in order, so "at most 8 outstanding" means the 8 newest
+    // whatever stores of an epilogue are still in flight.
+    auto super_step = [&](int kn, auto cur_c) __attribute__((always_inline)) {
+      constexpr int cur = decltype(cur_c)::value, nxt = cur ^ 1;
+      half(fX, fB[0],
+           [&fB, &b_off](auto ic) __attribute__((always_inline)) {  // 8 reads behind MFMAs 1, 4, .. 22
+             // (explicit captures: clang does not capture what a generic lambda names only as an asm operand; the casts keep -Wall quiet)
+             (void)fB; (void)b_off;
+             constexpr int i = decltype(ic)::value;
+             if constexpr (i % 3 == 1 && i / 3 < 8) FFQ_W4_READ(fB[1][i / 3], b_off[cur][1], (i / 3) * 2048);
+           },
+           [&](int c) __attribute__((always_inline)) { issue_one(kn, cur, c, 0); });
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      // ---- second k-half: MFMAs on set 1 | LDS-DMA of super-step `kn` into `cur` | read the first k-half of `nxt` into set 0
-#if FFQ_W4_SPREAD
-      phase(fa1, fb1, fa0, fb0, a_off[nxt][0], b_off[nxt][0], [&](int c, int which) { issue_one(kn, cur, c, which); }, std::true_type{});
-#else
-      phase(fa1, fb1, fa0, fb0, a_off[nxt][0], b_off[nxt][0], [&](int c) { issue(kn, cur, c); }, std::true_type{});
-#endif
+      half(fY[cur], fB[1],
+           [&fB, &fX, &fY, &a_off, &b_off](auto ic) __attribute__((always_inline)) {  // 24 reads behind MFMAs 1, 3, .. 47
+             (void)fB; (void)fX; (void)fY; (void)a_off; (void)b_off;
+             constexpr int i = decltype(ic)::value, r = i >> 1;
+             if constexpr ((i & 1) == 1 && r < 8) FFQ_W4_READ(fB[0][r], b_off[nxt][0], r * 2048);
+             else if constexpr ((i & 1) == 1 && r < 16) FFQ_W4_READ(fX[r - 8], a_off[nxt][0], (r - 8) * 2048);
+             else if constexpr ((i & 1) == 1 && r < 24) FFQ_W4_READ(fY[nxt][r - 16], a_off[nxt][1], (r - 16) * 2048);
+           },
+           [&](int c) __attribute__((always_inline)) { issue_one(kn, cur, c, 1); });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     };
+    // ONE loop body for every pair of super-steps (a separate copy for the tile's last pair got its own register allocation from
+    // hipcc, 256 VGPRs and a spilled fragment): the last pair fetches super-steps 0 and 1 of the NEXT tile and reads its first fragments
 #pragma unroll 1
-    for (int ks = 0; ks < ksuper - 2; ks += 2) {
-      super_step(ks + 2, 0);
-      super_step(ks + 3, 1);
+    for (int ks = 0; ks < ksuper; ks += 2) {
+      int k0 = ks + 2, k1 = ks + 3;
+      if (ks == ksuper - 2) {
+        set_image_sources(nm0, nn0, nseg);
+        k0 = 0; k1 = 1;
+      }
+      super_step(k0, std::integral_constant<int, 0>{});
+      super_step(k1, std::integral_constant<int, 1>{});
     }
-    // the tile's last two super-steps fetch super-steps 0 and 1 of the NEXT tile; the last k-half reads its first fragments
-    set_image_sources(nm0, nn0, nseg);
-    super_step(0, 0);
-    super_step(1, 1);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before the accumulators are read
 
     // ---- epilogue: 16 rows of the wave at a time through its own staging rows (no block barrier: the slots belong to the next
@@ -1036,6 +1029,11 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
       const int out_n = seg_rows(seg);
       constexpr int PITCH = W4_PITCH_PLAIN;
       const int wave_n0 = n0 + wn * 128, wave_m0 = m0 + wm * 128;
+      // (the lane's staging and store addresses are formed HERE, from an opaque copy of the lane id: hoisted above the tile loop they sit
+      // in ~20 registers across a K-loop that has 192 fragment registers live)
+      uint32_t lane = threadIdx.x & 63u;
+      asm volatile("" : "+v"(lane));
+      const uint32_t r16 = lane & 15, g4 = lane >> 4;
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
@@ -1251,7 +1249,7 @@ static void wq_launch4w(const WLinearArgs& a, hipStream_t s) {
   const int total = a.tiles_m * a.tiles_n;
   const int cus = wq_cus();
   const unsigned grid = (unsigned)(total < cus ? total : cus);
-  const size_t lds_bytes = (size_t)2 * WL_SLOT + (size_t)4 * W4_WAVE_PLAIN + (FFQ_W4_AHEAD > 0 ? 4 * 512 : 0);
+  const size_t lds_bytes = (size_t)2 * WL_SLOT + (size_t)4 * W4_WAVE_PLAIN;
   static uint64_t attr_set = 0;
   ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_gemm4w_kernel), (int)lds_bytes);
   wq_gemm4w_kernel<<<grid, 256, lds_bytes, s>>>(a, total);

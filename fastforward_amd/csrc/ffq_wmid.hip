@@ -7,18 +7,21 @@
 // q/o projection is 32 tiles, so every tile was cut into 8 slices whose 256 KiB fp32 partials went through HBM — 64 MB written and
 // 64 MB read back for a problem whose operands are 20 MB (missing #1) — and below 129 rows the skinny form streams every
 // activation fragment from LDS once per MFMA (one weight tile per wave), which the LDS pipe bounds from 32 rows on. Here
-//   * a block is 4 waves (2 x 2) on a BM x 128 output tile, BM = 128 (64 up to 64 rows): 4 x the tiles of the 256-row form, so that a
-//     512-row q/o projection fills the chip with S = 2 slices of K (16 MB of partials), gate/up and down_proj with S = 1 or 2;
-//   * both operands are staged through REGISTERS into a k-ordered, XOR-swizzled LDS image, one 64-k super-step per stage, double
-//     buffered: activations as they are (bf16), codes converted ONCE PER BLOCK with A2's arithmetic (dequantize4 of ffq_wq.h, the
-//     function the other two forms use) on their way in — int8 containers and packed nibbles of every packing block >= 32 (GGUF's
-//     32 / 64, config 4's 128, 256: a piece of 16 codes lives in one nibble position of 16 contiguous bytes) give the SAME image, so
-//     every storage form of one weight gives the same bits; the code loads run MD_BDEPTH super-steps ahead of their conversion
-//     (weights come from HBM once), the activation loads MD_ADEPTH (they are L2-resident: M x K x 2 bytes <= 15 MB);
-//   * a wave contracts (BM / 2) x 64 with v_mfma_f32_16x16x32_bf16: every fragment read feeds 4 (2) MFMAs, where the skinny form
-//     needs one read per MFMA; two blocks per CU hide each other's barriers and conversion work;
-//   * K is cut into S slices across blocks where the tiles alone do not fill the chip. A wave leaves its (BM / 2) x 64 partial in a
-//     write-through slab, takes a ticket for that quadrant, and the LAST wave to arrive — whoever it is — adds the S partials in slice
+//   * a block owns a BM x 128 output tile, BM = 64 (128 for contractions deeper than 8192 above 256 rows: md_bm): 4 - 8 x the tiles of
+//     the 256-row form, so that a 512-row q/o projection fills the chip without any K slice and k/v with 4 (wq_mid_split: at most 4);
+//   * TWO kernels of the same tiles, the same K slices and the same k order (hence the same bits, tests/test_mid_gpu.py):
+//       - wq_mid_dma_kernel (further down; what runs for int8 containers and packing blocks >= 128): 8 waves side by side along N, both
+//         operands by LDS-DMA into a ring of 3 - 4 stages, codes converted on their way from LDS into the MFMA's registers;
+//       - wq_mid_kernel (below; packing blocks 32 / 64, and the test hook's bit 2): 4 waves (2 x 2), both operands staged through
+//         REGISTERS into a k-ordered, XOR-swizzled LDS image, one 64-k super-step per stage, double buffered; codes converted ONCE PER
+//         BLOCK with A2's arithmetic (dequantize4 of ffq_wq.h, the function every form uses) on their way in; the code loads run
+//         MD_BDEPTH super-steps ahead of their conversion, the activation loads MD_ADEPTH (they are L2-resident: M x K x 2 <= 15 MB);
+//     int8 containers and packed nibbles of every packing block >= 32 (GGUF's 32 / 64, config 4's 128, 256: a piece of 16 codes
+//     lives in one nibble position of 16 contiguous bytes) give the SAME operand, so every storage form of one weight gives the same bits;
+//   * v_mfma_f32_16x16x32_bf16 on 16-row tiles: every fragment read feeds MI = BM / 16 (DMA form) or 4 / 2 (register form) MFMAs, where
+//     the skinny form needs one read per MFMA; two blocks per CU hide each other's barriers and conversion work;
+//   * K is cut into S slices across blocks where the tiles alone do not fill the chip. A wave leaves its partial in a write-through
+//     slab, takes a ticket for its part of the tile, and the LAST wave to arrive — whoever it is — adds the S partials in slice
 //     order and writes the output: nobody waits for anybody (the exchange of ffq_wskinny.hip), the summation order is a function of
 //     the plan alone (bit-reproducible), ticket words are zero before and after.
 // Covered: everything ffq_linear_wq_supported() admits with M <= 512 — one to three weight matrices on the same activations

@@ -235,6 +235,9 @@ int ffq_unpack_int4(const uint8_t* packed, int64_t numel, int64_t block, void* c
  * nn/linear_quantizer.py:164-170) is detected on the device and costs nothing but a 1-block check.
  * Tolerance vs the reference's bf16 eager path is stated in tests/parity_cases.py::check_linear (G6) and
  * tests/test_parity_gpu.py::test_w8a8_linear_*; exact-integer checks at full BASELINE sizes: tests/test_fullsize_gpu.py.
+ * Workspace: ffq_linear_w8a8_workspace_bytes(M, N, K) bytes cover every launch. It may be NULL / 0 when w_offset == NULL and either
+ * x_offset == NULL, or w_rowsum != NULL, or ffq_linear_w8a8_takes_earlier(M, N, K) == 0 (below the persistent kernel's shape class
+ * the tile kernel sums its own weight rows); a launch that needs it and gets less returns FFQ_ERR_WORKSPACE before touching a buffer.
  */
 size_t ffq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int ffq_linear_w8a8(const int8_t* xq, const int8_t* wq, const int32_t* w_rowsum, const float* x_scale,
@@ -279,7 +282,7 @@ int ffq_linear_w8a8_gated(const int8_t* xq, const int8_t* wq, const int32_t* w_r
  * bmm on int8 codes — the quantized-operand pattern of _gen/fallback.py:699-798 (dequantize both operands, the float op, the output
  * quantizer) for `batch` independent products out[b] = xq[b] [M, K] x wq[b]^T [N, K] with ONE parameter pair per operand (per-tensor
  * quantizers: the batch shares them), as ONE launch; arithmetic, epilogue and the optional fused output quantizer exactly as
- * ffq_linear_w8a8 (per matrix pair: bit-identical to `batch` calls of it). K % 16 == 0.
+ * ffq_linear_w8a8 (per matrix pair: bit-identical to `batch` calls of it). K % 16 == 0. Workspace: needed with w_offset != NULL only.
  */
 size_t ffq_bmm_w8a8_workspace_bytes(int64_t batch, int64_t M, int64_t N, int64_t K);
 int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, const float* x_offset, const float* w_scale,
@@ -429,7 +432,8 @@ int ffq_rope_inplace(void* q, int64_t q_heads, void* k, int64_t k_heads, int dt,
  * scale / offset are fp32 with one entry per tile. The elementwise part is exact; the per-tile sums are
  * fp32 sums in this implementation's own (fixed, deterministic) order. Tilings covered: one tile
  * (per-tensor) and contiguous-run tiles (per-channel on dim 0, per-block along the last dim,
- * per-token) with numel % 8 == 0; anything else returns FFQ_ERR_DTYPE.
+ * per-token) with numel % 8 == 0; anything else returns FFQ_ERR_DTYPE. ffq_quantize_backward_workspace_bytes is 0 for the problems
+ * that run as one launch (up to 65536 elements in >= 4 tiles of <= 4096 elements, and every tiling of the by-tile kernel).
  */
 size_t ffq_quantize_backward_workspace_bytes(const ffq_tiling* tiling);
 int ffq_quantize_by_tile_backward(const void* data, const void* output_grad, int dt, const float* scale,

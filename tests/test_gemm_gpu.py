@@ -577,3 +577,39 @@ def test_q_k_v_as_one_int8_launch_equal_three_launches(tokens, rows, k, per_toke
     # not this launch's: a middle matrix that is no multiple of 256 rows, too few tiles for the persistent kernel
     assert ops.linear_w8a8_multi(x, w, sx, ox, sw, (rows[0] - 8, sum(rows[1:]) + 8)) is None
     assert ops.linear_w8a8_multi(x[:64], w[:768], sx[:64] if per_token else sx, ox[:64] if per_token else ox, sw[:768], (256, 256, 256)) is None
+
+
+def test_no_workspace_where_nothing_lives_in_it():
+    """include/ffq.h: the workspace holds the weight row sums of a PERSISTENT launch and the activation row sums / flag of a launch with
+    weight offsets. Below the persistent kernel's shape class (the tile kernel sums its own weight rows), or with the row sums handed in,
+    a launch without weight offsets runs with workspace == NULL and gives the same bits; one that needs it says so before touching `out`."""
+    from fastforward_amd import _native
+    from fastforward_amd.ops._base import _ptr
+
+    lib = _native.library()
+    stream = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=DEV).manual_seed(5)
+
+    def call(m, n, k, workspace, rowsum=None):
+        xq = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+        wq = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+        sx, ox = torch.tensor([0.02], device=DEV), torch.tensor([3.0], device=DEV)
+        sw = torch.rand(n, device=DEV, generator=g) * 1e-2 + 1e-3
+        sums = wq.sum(1, dtype=torch.int32) if rowsum else None
+        out = torch.full((m, n), 7.0, device=DEV, dtype=torch.bfloat16)
+        ws = torch.empty(lib.ffq_linear_w8a8_workspace_bytes(m, n, k), device=DEV, dtype=torch.uint8) if workspace else None
+        rc = lib.ffq_linear_w8a8(_ptr(xq), _ptr(wq), _ptr(sums), _ptr(sx), _ptr(ox), 0, _ptr(sw), None, 1, None, 0, _ptr(out), ops._tag(torch.bfloat16),
+                                 None, None, 8.0, 0, m, n, k, _ptr(ws), ws.numel() if workspace else 0, stream)
+        torch.cuda.synchronize()
+        return rc, out, ops.linear_w8a8(xq, wq, sx, ox, sw, None, out_dtype=torch.bfloat16)
+
+    for m, n, k in ((16, 128, 256), (300, 520, 1040)):  # below the persistent class
+        assert lib.ffq_linear_w8a8_takes_earlier(m, n, k) == 0
+        rc, out, want = call(m, n, k, workspace=False)
+        assert rc == 0 and torch.equal(out, want)
+    m, n, k = 2048, 2048, 512  # 64 tiles of 256 x 256: the persistent kernel
+    assert lib.ffq_linear_w8a8_takes_earlier(m, n, k) == 1
+    rc, out, want = call(m, n, k, workspace=False, rowsum=True)
+    assert rc == 0 and torch.equal(out, want)
+    rc, out, _ = call(m, n, k, workspace=False)
+    assert rc == 8 and bool((out == 7.0).all())  # FFQ_ERR_WORKSPACE, nothing written

@@ -57,8 +57,11 @@ def test_no_scratch_access_inside_a_k_loop(source, needle):
 
 def test_the_one_wave_per_simd_k_loop_is_what_was_written():
     """wq_gemm4w_kernel's K-loop is inline assembly in source order; what hipcc may add is scalar bookkeeping and address moves.
-    Its inner loop (two super-steps) must hold exactly 256 MFMAs, 64 fragment reads and 32 LDS-DMA pieces (buffer_load ... lds), no other vector instruction, no scratch access, no
-    accumulator traffic between AGPRs and VGPRs, and the kernel must own all 256 AGPRs (the accumulators pinned there)."""
+    Its inner loop (two super-steps) must hold exactly 256 MFMAs, 64 fragment reads and 32 LDS-DMA pieces (buffer_load ... lds), four barriers
+    (round 6: the A operand half a step ahead of B, a barrier per k-half) behind two counted `vmcnt(8)` and two lgkm-only waits, no scratch
+    access, no accumulator traffic between AGPRs and VGPRs, no other vector instruction except the handful that switch the image
+    descriptors to the next tile (the tile's last pair of super-steps is the same loop body), and the kernel must own all 256 AGPRs
+    (the accumulators pinned there) without a spill."""
     import re
 
     if not pathlib.Path("/opt/rocm/bin/hipcc").exists():
@@ -67,16 +70,20 @@ def test_the_one_wave_per_simd_k_loop_is_what_was_written():
     lines = text.split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN3ffq16wq_gemm4w_kernel\w*:", l))
     end = next(i for i in range(start, len(lines)) if ".end_amdhsa_kernel" in lines[i])
-    header = next(i for i in range(start, end) if "Inner Loop Header" in lines[i])
-    label = next(lines[j].split(":")[0] for j in range(header, start, -1) if re.match(r"^\.LBB\d+_\d+:", lines[j]))
-    back = next(i for i in range(header, end) if re.search(r"s_cbranch_\w+ " + re.escape(label) + r"\b", lines[i]))
+    # the K-loop = the innermost loop around the MFMAs: its header is the last loop-header label ahead of the first MFMA, its end the
+    # first branch behind the last one
+    mfma = [i for i in range(start, end) if "v_mfma" in lines[i]]
+    header = next(j for j in range(mfma[0], start, -1) if re.match(r"^\.LBB\d+_\d+:", lines[j]) and "Loop Header" in " ".join(lines[j:j + 3]))
+    back = next(i for i in range(mfma[-1], end) if "s_cbranch" in lines[i])
     ops = [l.split()[0] for l in (x.strip() for x in lines[header:back]) if l and not l.startswith((";", ".", "//"))]
     count = lambda prefix: sum(1 for o in ops if o.startswith(prefix))  # noqa: E731
     assert count("v_mfma_f32_16x16x32_bf16") == 256 and count("ds_read_b128") == 64 and count("buffer_load_dwordx4") == 32
-    assert count("scratch_") == 0 and count("v_accvgpr") == 0 and count("s_barrier") == 2
-    assert count("v_") - count("v_mfma") == 0  # buffer addressing: the piece and the super-step are in the scalar offset
+    assert count("scratch_") == 0 and count("v_accvgpr") == 0 and count("s_barrier") == 4
+    body = "\n".join(lines[header:back])
+    assert len(re.findall(r"s_waitcnt vmcnt\(8\) lgkmcnt\(0\)", body)) == 2 and "vmcnt(0)" not in body
+    assert count("v_") - count("v_mfma") <= 4  # buffer addressing: the piece and the super-step are in the scalar offset
     rows = [k for k in _kernels("wq_gemm4w_kernel")]
-    assert len(rows) == 1 and rows[0]["agpr_count"] == 256
+    assert len(rows) == 1 and rows[0]["agpr_count"] == 256 and rows[0]["vgpr_spill_count"] == 0 and rows[0]["private_segment_fixed_size"] == 0
 
 
 def test_the_128_column_tile_kernels_keep_everything_in_registers_at_two_blocks_per_cu():
