@@ -803,15 +803,23 @@ __global__ __launch_bounds__(512, 2) void wq_gemm256_kernel(WLinearArgs a, int t
 // profiles/r06_w4_spread_ab.txt / r06_w4_ahead_ab.txt and docs/experiments.md.)
 // Taken for plain launches of whole tiles (M and every weight matrix a multiple of 256 rows) without a split tail, without a bias
 // and with an even number of super-steps (wq_dispatch); bf16 output.
-// (A gate+up+SiLU*up mode of this kernel was built in round 4 and is bit-equal too, but measured 3-5 % SLOWER than the 8-wave kernel's
-// — 2.83 against 2.75 ms at 16 k tokens, with the slot-at-a-time schedule — and was removed.)
+// The gate+up+SiLU*up launch runs here as well (template parameter MLP, whole tiles of 256 rows x 128 output columns): round 4 had built
+// that mode on the slot-at-a-time schedule, measured it 3-5 % SLOWER than the 8-wave kernel's (2.83 against 2.75 ms at 16 k tokens) and
+// removed it; on the half-step-ahead schedule it is 6-8 % FASTER (profiles/r06_w4_mlp_ab.txt: 2.74-2.79 -> 2.59 ms at 16 k tokens,
+// 0.75 -> 0.70 at 4 k; two launches of the vendor's GEMM + SiLU*up: 2.71 / 0.735), bit-equal to the 8-wave kernel and to the
+// composition of its parts.
 constexpr int W4_PITCH_PLAIN = 128 * 2 + 16;  // a staged row of a wave: 128 bf16 + pad
-constexpr int W4_WAVE_PLAIN = 16 * W4_PITCH_PLAIN;
 
 // fn(integral_constant<int, 0>), fn(<1>), ...: a loop whose index is a constant expression in every body (hipcc gives up fully unrolling
 // a 64-trip loop around a 24-case switch; with constant indices no switch is needed)
 template <typename F, int... I>
 __device__ __forceinline__ void w4_each(F&& fn, std::integer_sequence<int, I...>) { (fn(std::integral_constant<int, I>{}), ...); }
+// MLP (round 6): gate_proj + up_proj + SiLU * up in this kernel — the B image holds, per wave column (wn), 64 gate_proj rows and the same
+// 64 up_proj rows (a wave's column tiles nj = 0..3 are gate, nj + 4 up of the SAME 64 output columns), the output tile is 256 x 128
+// bf16(silu(bf16(gate))) * bf16(up) with the roundings of wq_gemm256_kernel's MLP mode (the reference's quantized_llama/mlp.py:30-40):
+// same MFMA instruction, same k order, same epilogue arithmetic — bit-equal to that kernel, which keeps ragged shapes and splits.
+constexpr int W4_PITCH_MLP = 64 * 2 + 16;  // a staged row of a wave in MLP mode: 64 bf16 + pad (the SiLU table needs 16 KiB of the LDS)
+template <bool MLP>
 __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -831,7 +839,10 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
   const int my_tiles = j_in_xcd < count ? (int)((count - j_in_xcd + blocks_in_xcd - 1) / blocks_in_xcd) : 0;
   if (my_tiles == 0) return;
   const int ksuper = a.K / WL_BK;  // even (wq_dispatch)
-  uint8_t* const stage = lds + 2 * WL_SLOT + wave * W4_WAVE_PLAIN;
+  constexpr int STAGE_PITCH = MLP ? W4_PITCH_MLP : W4_PITCH_PLAIN;
+  uint8_t* const stage = lds + 2 * WL_SLOT + wave * (16 * STAGE_PITCH);
+  [[maybe_unused]] uint16_t* const silu_table = reinterpret_cast<uint16_t*>(lds + 2 * WL_SLOT + 4 * (16 * STAGE_PITCH));
+  if constexpr (MLP) silu_table_fill(silu_table, (uint32_t)tid, 256u);  // published by the prologue's barriers
   // A contraction depth that is a large power of two puts the same depth of every row of every tile on the same few memory channels,
   // and all 256 CUs walk the depth in step: XCD x starts x/8 of the way in and wraps (round 6, A/B of two builds, two rounds,
   // profiles/r06_krot_ab.txt: K = 8192 848 -> 743 us at 16 k tokens x 4096 columns, 16384 +2 %; other depths +-1.5 % or worse — off there).
@@ -851,9 +862,13 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
     tm0 = (int)(a.group_cols ? outer : inner) * WL_BM;
     int tn = (int)(a.group_cols ? inner : outer);
     seg = 0;  // which weight matrix the column tile belongs to, and the tile's origin inside it
-    if (tn >= a.seg_tile[1]) { seg = 2; tn -= a.seg_tile[1]; }
-    else if (tn >= a.seg_tile[0]) { seg = 1; tn -= a.seg_tile[0]; }
-    tn0 = tn * WL_BN;
+    if constexpr (MLP) {
+      tn0 = tn * 128;  // 128 output columns per tile: 128 gate + 128 up rows in the B image
+    } else {
+      if (tn >= a.seg_tile[1]) { seg = 2; tn -= a.seg_tile[1]; }
+      else if (tn >= a.seg_tile[0]) { seg = 1; tn -= a.seg_tile[0]; }
+      tn0 = tn * WL_BN;
+    }
   };
   auto seg_codes = [&](int seg) { return seg == 0 ? a.w : seg == 1 ? a.seg_w[0] : a.seg_w[1]; };
   auto seg_rows = [&](int seg) { return seg == 0 ? a.seg_n[0] : seg == 1 ? a.seg_n[1] : a.seg_n[2]; };
@@ -879,6 +894,18 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
     const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
     d_voff[odd] = (uint32_t)(wave * 64 + d_row) * row_bytes + d_slot * 16;
   }
+  // MLP: image rows 64 w .. 64 w + 63 of the B image are rows 64 (w / 2) .. of gate_proj (even waves) or up_proj (odd waves) counted
+  // from the tile's first output column: a wave fetches from ONE matrix, its descriptor points at that matrix, and the lane offset
+  // names the matrix row (the swizzle term stays the image row's)
+  [[maybe_unused]] uint32_t b_voff[2] = {0u, 0u};
+  if constexpr (MLP) {
+#pragma unroll
+    for (int odd = 0; odd < 2; ++odd) {
+      const int row = (wave * 8 + odd) * 8 + d_row;
+      const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
+      b_voff[odd] = (uint32_t)((wave >> 1) * 64 + d_row) * row_bytes + d_slot * 16;
+    }
+  }
   __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0, 0x00020000);
   __amdgpu_buffer_rsrc_t b_rsrc = a_rsrc;
   auto extent = [&](int rows_left) {  // bytes from the tile's first row to the end of the matrix, as a descriptor extent
@@ -887,7 +914,8 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
   };
   auto set_image_sources = [&](int tm0, int tn0, int seg) {
     a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row_base(a.x, tm0, row_bytes), 0, extent(a.M - tm0), 0x00020000);
-    b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row_base(seg_codes(seg), tn0, row_bytes), 0, extent(seg_rows(seg) - tn0), 0x00020000);
+    if constexpr (MLP) b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row_base((wave & 1) ? a.w2 : a.w, tn0, row_bytes), 0, extent(a.N - tn0), 0x00020000);
+    else b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row_base(seg_codes(seg), tn0, row_bytes), 0, extent(seg_rows(seg) - tn0), 0x00020000);
   };
   auto issue_one = [&](int ks, int slot, int c, int which) {  // piece c of the A (0) or B (1) image of super-step ks
     uint8_t* base = lds + slot * WL_SLOT;
@@ -895,7 +923,7 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
     ks = ks >= ksuper ? ks - ksuper : ks;
     const uint32_t soff = (uint32_t)c * 8u * row_bytes + (uint32_t)ks * 128u;
     if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (wl_lds_t*)(base + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (wl_lds_t*)(base + WL_IMAGE + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (wl_lds_t*)(base + WL_IMAGE + (wave * 8 + c) * 1024), 16, MLP ? b_voff[c & 1] : d_voff[c & 1], soff, 0, 0);
   };
 
   // ---- fragment addresses: lane (r16, g4) reads 8 bf16 of row r16 of a 16-row tile, logical slot kq * 4 + g4; one register per
@@ -1021,40 +1049,94 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before the accumulators are read
 
-    // ---- epilogue: 16 rows of the wave at a time through its own staging rows (no block barrier: the slots belong to the next
-    // tile's images already). Lane l holds, for tile (mi, nj), register t: row m = 16 mi + l % 16, column n = 16 nj + 4 (l / 16) + t.
-    // Whole tiles (wq_takes_4w): every row and column exists, rows are 16-byte aligned.
-    {
-      bf16_t* out = static_cast<bf16_t*>(seg == 0 ? a.out : seg == 1 ? a.seg_out[0] : a.seg_out[1]);
-      const int out_n = seg_rows(seg);
-      constexpr int PITCH = W4_PITCH_PLAIN;
-      const int wave_n0 = n0 + wn * 128, wave_m0 = m0 + wm * 128;
-      // (the lane's staging and store addresses are formed HERE, from an opaque copy of the lane id: hoisted above the tile loop they sit
-      // in ~20 registers across a K-loop that has 192 fragment registers live)
-      uint32_t lane = threadIdx.x & 63u;
+    if constexpr (MLP) {
+      // ---- MLP epilogue: z = bf16(silu(bf16(gate))) * bf16(up) of the wave's 128 rows x 64 output columns, 16 rows at a time through its
+      // own staging rows (no block barrier). silu through the LDS table of ffq_silu.h: the 16 reads of a row tile issued back to back,
+      // one wave-uniform branch for values outside its window (wq_gemm256_kernel's MLP epilogue, operation for operation).
+      bf16_t* out = static_cast<bf16_t*>(a.out);
+      const int out_n = a.N;
+      constexpr int PITCH = W4_PITCH_MLP;
+      const int wave_n0 = n0 + wn * 64, wave_m0 = m0 + wm * 128;
+      uint32_t lane = threadIdx.x & 63u;  // (formed here, from an opaque copy: see the plain epilogue)
       asm volatile("" : "+v"(lane));
       const uint32_t r16 = lane & 15, g4 = lane >> 4;
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) {
+        uint32_t wg[4][2], ws[4][2], bad = 0;
 #pragma unroll
-        for (int nj = 0; nj < 8; ++nj) {
-          const int nb = nj * 16 + 4 * g4;
-          u32x2 pk;
-          pk.x = pack2<bf16_t>(acc[mi][nj][0], acc[mi][nj][1]);
-          pk.y = pack2<bf16_t>(acc[mi][nj][2], acc[mi][nj][3]);
-          *reinterpret_cast<u32x2*>(stage + r16 * PITCH + nb * 2) = pk;
-          acc[mi][nj] = wl_v4f{0.f, 0.f, 0.f, 0.f};
+        for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            wg[nj][h] = pack2<bf16_t>(acc[mi][nj][2 * h], acc[mi][nj][2 * h + 1]);
+            ws[nj][h] = silu_pair_lookup(wg[nj][h], silu_table, bad);
+          }
+        if (__builtin_expect(silu_any_outside(bad), 0)) {
+#pragma unroll
+          for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) ws[nj][h] = silu_pair_patch(wg[nj][h], ws[nj][h]);
         }
-        // (no wait between the writes and the reads below, nor before the next row tile's writes: a wave's LDS instructions
-        // execute in order, and the rows are this wave's own)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int nj = 0; nj < 4; ++nj) {
+          uint32_t z[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t wu = pack2<bf16_t>(acc[mi][nj + 4][2 * h], acc[mi][nj + 4][2 * h + 1]);
+            const float a0 = __builtin_bit_cast(float, ws[nj][h] << 16), a1 = __builtin_bit_cast(float, ws[nj][h] & 0xFFFF0000u);
+            const float u0 = __builtin_bit_cast(float, wu << 16), u1 = __builtin_bit_cast(float, wu & 0xFFFF0000u);
+            z[h] = pack2<bf16_t>(a0 * u0, a1 * u1);  // one rounding, as the eager multiply
+          }
+          u32x2 pk;
+          pk.x = z[0]; pk.y = z[1];
+          *reinterpret_cast<u32x2*>(stage + r16 * PITCH + (nj * 16 + 4 * g4) * 2) = pk;
+          acc[mi][nj] = wl_v4f{0.f, 0.f, 0.f, 0.f};
+          acc[mi][nj + 4] = wl_v4f{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
           const int c = lane + 64 * t;
-          const int row = c >> 4, sg = c & 15;  // 16 segments of 16 bytes per 128-column row
+          const int row = c >> 3, sg = c & 7;  // 8 segments of 16 bytes per 64-column row
           const int mm = wave_m0 + mi * 16 + row;
           const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * PITCH + sg * 16);
-          // non-temporal, as in ffq_linear.hip: the output must not push the operand panels out of L2
           __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * out_n + wave_n0) * 2 + sg * 16));
+        }
+      }
+    } else {
+    // ---- epilogue: 16 rows of the wave at a time through its own staging rows (no block barrier: the slots belong to the next
+      // tile's images already). Lane l holds, for tile (mi, nj), register t: row m = 16 mi + l % 16, column n = 16 nj + 4 (l / 16) + t.
+      // Whole tiles (wq_takes_4w): every row and column exists, rows are 16-byte aligned.
+      {
+        bf16_t* out = static_cast<bf16_t*>(seg == 0 ? a.out : seg == 1 ? a.seg_out[0] : a.seg_out[1]);
+        const int out_n = seg_rows(seg);
+        constexpr int PITCH = W4_PITCH_PLAIN;
+        const int wave_n0 = n0 + wn * 128, wave_m0 = m0 + wm * 128;
+        // (the lane's staging and store addresses are formed HERE, from an opaque copy of the lane id: hoisted above the tile loop they sit
+        // in ~20 registers across a K-loop that has 192 fragment registers live)
+        uint32_t lane = threadIdx.x & 63u;
+        asm volatile("" : "+v"(lane));
+        const uint32_t r16 = lane & 15, g4 = lane >> 4;
+  #pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+  #pragma unroll
+          for (int nj = 0; nj < 8; ++nj) {
+            const int nb = nj * 16 + 4 * g4;
+            u32x2 pk;
+            pk.x = pack2<bf16_t>(acc[mi][nj][0], acc[mi][nj][1]);
+            pk.y = pack2<bf16_t>(acc[mi][nj][2], acc[mi][nj][3]);
+            *reinterpret_cast<u32x2*>(stage + r16 * PITCH + nb * 2) = pk;
+            acc[mi][nj] = wl_v4f{0.f, 0.f, 0.f, 0.f};
+          }
+          // (no wait between the writes and the reads below, nor before the next row tile's writes: a wave's LDS instructions
+          // execute in order, and the rows are this wave's own)
+  #pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int c = lane + 64 * t;
+            const int row = c >> 4, sg = c & 15;  // 16 segments of 16 bytes per 128-column row
+            const int mm = wave_m0 + mi * 16 + row;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * PITCH + sg * 16);
+            // non-temporal, as in ffq_linear.hip: the output must not push the operand panels out of L2
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * out_n + wave_n0) * 2 + sg * 16));
+          }
         }
       }
     }
@@ -1245,27 +1327,35 @@ static void wq_launch(const WLinearArgs& a, hipStream_t s) {
 }
 
 // the one-wave-per-SIMD kernel: plain launches, whole tiles only (no split tail), an even number of super-steps, bf16 output
+template <bool MLP>
 static void wq_launch4w(const WLinearArgs& a, hipStream_t s) {
   const int total = a.tiles_m * a.tiles_n;
   const int cus = wq_cus();
   const unsigned grid = (unsigned)(total < cus ? total : cus);
-  const size_t lds_bytes = (size_t)2 * WL_SLOT + (size_t)4 * W4_WAVE_PLAIN;
+  const size_t lds_bytes = (size_t)2 * WL_SLOT + (size_t)4 * 16 * (MLP ? W4_PITCH_MLP : W4_PITCH_PLAIN) + (MLP ? kSiluBytes : 0);
   static uint64_t attr_set = 0;
-  ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_gemm4w_kernel), (int)lds_bytes);
-  wq_gemm4w_kernel<<<grid, 256, lds_bytes, s>>>(a, total);
+  ensure_dynamic_lds(&attr_set, reinterpret_cast<const void*>(&wq_gemm4w_kernel<MLP>), (int)lds_bytes);
+  wq_gemm4w_kernel<MLP><<<grid, 256, lds_bytes, s>>>(a, total);
 }
 
-static bool wq_takes_4w(const WLinearArgs& a) {
+static bool wq_takes_4w(const WLinearArgs& a, bool mlp = false) {
 #ifdef FFQ_WL_NO_4W  // A/B builds (tools/build_variant.sh)
   return false;
 #else
+#ifdef FFQ_WL_NO_4W_MLP  // A/B builds: the gate + up + SiLU*up launch on the 8-wave kernel
+  if (mlp) return false;
+#endif
   if (generic_kernels_forced()) return false;  // tests: the 8-wave kernel on the same operands (ffq_force_generic_kernels)
   // whole tiles only: the piece's row offset travels in the buffer instruction's SCALAR offset, which the hardware's range check
   // does not see (only the per-lane offset is compared with the descriptor's extent) — rows past a ragged edge would be read
   // from beyond the tensor. Ragged shapes take the 8-wave kernel, which clamps its source rows.
   if (a.M % WL_BM != 0) return false;
-  for (int i = 0; i < 3; ++i)
-    if (a.seg_n[i] % WL_BN != 0) return false;
+  if (mlp) {
+    if (a.N % 128 != 0) return false;  // tiles of 128 output columns (128 gate + 128 up rows)
+  } else {
+    for (int i = 0; i < 3; ++i)
+      if (a.seg_n[i] % WL_BN != 0) return false;
+  }
   return a.split == 1 && a.out_dt == FFQ_BF16 && a.bias == nullptr && (a.K / WL_BK) % 2 == 0 && a.K >= 4 * WL_BK;
 #endif
 }
@@ -1273,7 +1363,7 @@ static bool wq_takes_4w(const WLinearArgs& a) {
 template <int BKIND, bool MLP = false>
 static void wq_dispatch(const WLinearArgs& a, bool grouped, bool offset, hipStream_t s) {
   if constexpr (BKIND == WL_B_BF16) {
-    if (!MLP && wq_takes_4w(a)) wq_launch4w(a, s);
+    if (wq_takes_4w(a, MLP)) wq_launch4w<MLP>(a, s);
     else if (MLP || a.out_dt == FFQ_BF16) wq_launch<BKIND, false, false, bf16_t, MLP>(a, s);
     else if constexpr (!MLP) wq_launch<BKIND, false, false, float, false>(a, s);
   } else {

@@ -180,8 +180,9 @@ def test_one_wave_per_simd_form_equals_the_eight_wave_kernel():
     wave in AGPRs; taken by plain launches of whole 256 x 256 tiles without a split tail, with an even number of 64-deep super-steps,
     bf16 output) and the 8-wave wq_gemm256_kernel. Same MFMA instruction, same k order: bit-equal — one to many tiles per block
     (the K-loop running across tile boundaries), three weight matrices in one launch, down_proj at 16 k tokens (470 MB of
-    activations switch the walk to column groups); ragged shapes, an odd super-step count and the gate+up+SiLU*up mode keep both
-    arms on the 8-wave kernel (the dispatch must not send them to a kernel that assumes whole tiles)."""
+    activations switch the walk to column groups), and since round 6 the gate+up+SiLU*up mode on whole tiles (the same epilogue
+    arithmetic in both kernels, equal to the composition of its parts); ragged shapes and an odd super-step count keep both arms on
+    the 8-wave kernel (the dispatch must not send them to a kernel that assumes whole tiles)."""
     from fastforward_amd import _native
 
     lib = _native.library()
@@ -217,8 +218,11 @@ def test_one_wave_per_simd_form_equals_the_eight_wave_kernel():
         got, want = both(lambda: ops.linear_wq_multi(x, ws, ss, [None] * 3, two_pass=True, split=1))
         assert all(torch.equal(a, b) for a, b in zip(got, want))
         assert all(torch.equal(a, ops.linear_wq(x, wi, si, None, two_pass=True, split=1)) for a, wi, si in zip(got, ws, ss))
-    for m, n, k in ((700, 384, 512), (4096, 1024, 1024)):
+    # gate + up + SiLU*up: whole tiles of 256 rows x 128 output columns take the one-wave-per-SIMD kernel's MLP mode (round 6), ragged
+    # rows the 8-wave kernel's; one to many tiles per block, silu arguments inside and (x 30) outside the table's window
+    for m, n, k, scale in ((700, 384, 512, 1.0), (4096, 1024, 1024, 1.0), (1024, 512, 256, 30.0), (2048, 1024, 640, 30.0), (16384, 2048, 512, 1.0), (768, 384, 384, 1.0)):
         x, w, s = operands(m, n, k)
+        x = x * scale
         u = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
         got, want = both(lambda: ops.mlp_gate_up_wq(x, w, u, s, None, s, None, two_pass=True, split=1))
         assert torch.equal(got, want), (m, n, k)

@@ -68,7 +68,17 @@ def test_the_one_wave_per_simd_k_loop_is_what_was_written():
         pytest.skip("hipcc is missing")
     text = asm_cluster_check.build_assembly(ROOT / "fastforward_amd" / "csrc/ffq_wlinear.hip")
     lines = text.split("\n")
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN3ffq16wq_gemm4w_kernel\w*:", l))
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN3ffq16wq_gemm4w_kernel\w*:", l)]
+    assert len(starts) == 2  # plain, and gate + up + SiLU*up (round 6)
+    for start in starts:
+        _check_one_wave_per_simd_loop(lines, start)
+    rows = [k for k in _kernels("wq_gemm4w_kernel")]
+    assert len(rows) == 2 and all(k["agpr_count"] == 256 and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0 for k in rows), rows
+
+
+def _check_one_wave_per_simd_loop(lines, start):
+    import re
+
     end = next(i for i in range(start, len(lines)) if ".end_amdhsa_kernel" in lines[i])
     # the K-loop = the innermost loop around the MFMAs: its header is the last loop-header label ahead of the first MFMA, its end the
     # first branch behind the last one
@@ -82,8 +92,6 @@ def test_the_one_wave_per_simd_k_loop_is_what_was_written():
     body = "\n".join(lines[header:back])
     assert len(re.findall(r"s_waitcnt vmcnt\(8\) lgkmcnt\(0\)", body)) == 2 and "vmcnt(0)" not in body
     assert count("v_") - count("v_mfma") <= 4  # buffer addressing: the piece and the super-step are in the scalar offset
-    rows = [k for k in _kernels("wq_gemm4w_kernel")]
-    assert len(rows) == 1 and rows[0]["agpr_count"] == 256 and rows[0]["vgpr_spill_count"] == 0 and rows[0]["private_segment_fixed_size"] == 0
 
 
 def test_the_128_column_tile_kernels_keep_everything_in_registers_at_two_blocks_per_cu():
