@@ -272,6 +272,55 @@ def test_repeated_split_k_launches_are_bit_identical():
             assert torch.equal(captured, first), name
 
 
+def test_repeated_one_wave_per_simd_launches_are_bit_identical():
+    """Race hunt on `wq_gemm4w_kernel`'s round-6 schedule (every image of a slot refilled as soon as its last reader is done, counted
+    `vmcnt(8)` waits, a K-loop that runs across tile boundaries with an epilogue's stores in flight): the plain launch at a deep and a
+    shallow contraction, q / k / v in one launch and the gate + up + SiLU*up mode at 4096 tokens — several tiles per block — 40 repeats
+    back to back, 10 on a second stream while the first keeps the chip busy, and replayed from a hipGraph: all bit-equal to the first
+    result, which equals the 8-wave kernel's."""
+    from fastforward_amd import _native
+
+    lib = _native.library()
+    g = torch.Generator(device=DEV).manual_seed(9)
+    t = 4096
+    xs = {k: torch.randn(t, k, device=DEV, generator=g).to(torch.bfloat16) for k in (4096, 14336, 512)}
+    w = lambda n, k: torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)  # noqa: E731
+    sc = lambda n: torch.rand(n, device=DEV, generator=g) * 1e-3 + 1e-4  # noqa: E731
+    wd, sd = w(4096, 14336), sc(4096)
+    wo, so = w(4096, 512), sc(4096)
+    wq_, wk, wv, sq, sk, sv = w(4096, 4096), w(1024, 4096), w(1024, 4096), sc(4096), sc(1024), sc(1024)
+    wg, wu, sg, su = w(14336, 4096), w(14336, 4096), sc(14336), sc(14336)
+    forms = [
+        ("down", lambda: ops.linear_wq(xs[14336], wd, sd, None, two_pass=True, split=1)),
+        ("K=512", lambda: ops.linear_wq(xs[512], wo, so, None, two_pass=True, split=1)),
+        ("q/k/v", lambda: torch.cat(ops.linear_wq_multi(xs[4096], [wq_, wk, wv], [sq, sk, sv], [None] * 3, two_pass=True, split=1), dim=1)),
+        ("mlp", lambda: ops.mlp_gate_up_wq(xs[4096], wg, wu, sg, None, su, None, two_pass=True, split=1)),
+    ]
+    side = torch.cuda.Stream()
+    for name, fn in forms:
+        first = fn()
+        previous = lib.ffq_force_generic_kernels(1)
+        try:
+            assert torch.equal(fn(), first), name  # the 8-wave kernel on the same operands
+        finally:
+            lib.ffq_force_generic_kernels(previous)
+        assert all(torch.equal(fn(), first) for _ in range(40)), name
+        side.wait_stream(torch.cuda.current_stream())
+        busy = [fn() for _ in range(4)]  # keeps the first stream's CUs contended while the second one launches
+        with torch.cuda.stream(side):
+            assert all(torch.equal(fn(), first) for _ in range(10)), name
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                captured = fn()
+        torch.cuda.synchronize()
+        assert all(torch.equal(b, first) for b in busy), name
+        for _ in range(5):
+            captured.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(captured, first), name
+
+
 def test_all_zero_weight_offsets_cost_no_row_sums_and_change_nothing():
     """The offset BUFFER of a symmetric quantizer (reference nn/linear_quantizer.py:164-170) at a persistent-kernel shape:
     same bits as no offset at all; one non-zero entry switches the exact ow terms on (for every column)."""
