@@ -55,6 +55,39 @@ def skinny():
             assert torch.equal(outs[0], exact), ("skinny multi", m, n, k)
 
 
+def wide():
+    """Round 6: the weight-only linear above the skinny form's rows — 128-column tiles (17 .. 512 rows), 256-row tiles with split tails,
+    the one-wave-per-SIMD kernel (whole tiles, two-pass) and its gate + up + SiLU*up mode — on operands whose sums are exact in fp32
+    whatever the order (small integers, power-of-two scales): every form must give the SAME bits."""
+    m = rng.choice([17, 40, 129, 200, 256, 300, 512, 513, 768, 1000, 1024, 1280, 2048, 4096])
+    k = 128 * rng.randint(2, 40)
+    n = rng.choice([128, 256, 384, 512, 1024, 2048, 4096])
+    g = torch.Generator(device=DEV).manual_seed(rng.randint(0, 1 << 30))
+    x = torch.randint(-4, 5, (m, k), device=DEV, generator=g).to(torch.bfloat16)
+    w4 = torch.randint(-8, 8, (n, k), device=DEV, dtype=torch.int8, generator=g)
+    grouped = rng.random() < 0.4
+    groups = k // 128 if grouped else 1
+    s = torch.full((n * groups,), 0.25 if rng.random() < 0.5 else 0.5, device=DEV)
+    o = torch.round(torch.randn(n * groups, device=DEV, generator=g) * 2) if rng.random() < 0.3 else None
+    group = 128 if grouped else k
+    wd = (w4.double().view(n, groups, k // groups) + (0 if o is None else o.double().view(n, groups, 1))).view(n, k) * s.double().view(n, groups, 1).expand(n, groups, k // groups).reshape(n, k)
+    exact = (x.double() @ wd.t()).to(torch.bfloat16)
+    for two_pass in (None, False, True):
+        got = ops.linear_wq(x, w4, s, o, group=group, two_pass=two_pass)
+        assert got is not None and torch.equal(got, exact), ("wide int8", m, n, k, grouped, o is not None, two_pass)
+    if grouped:
+        got = ops.linear_wq(x, ops.pack_int4(w4, block=128), s, o, group=128, pack_block=128)
+        assert torch.equal(got, exact), ("wide packed", m, n, k)
+    if not grouped and rng.random() < 0.5:
+        u4 = torch.randint(-8, 8, (n, k), device=DEV, dtype=torch.int8, generator=g)
+        ud = (u4.double() + (0 if o is None else o.double().view(n, 1))) * s.double().view(n, 1)
+        up = (x.double() @ ud.t()).to(torch.bfloat16)
+        want = ops.silu_mul_quantize(exact, up, (), want_product=True)[0]
+        for two_pass in (None, True):
+            got = ops.mlp_gate_up_wq(x, w4, u4, s, o, s, o, two_pass=two_pass)
+            assert got is not None and torch.equal(got.view(torch.int16), want.view(torch.int16)), ("wide mlp", m, n, k, two_pass)
+
+
 def a3_symmetric():
     rows = rng.choice([1, 3, 33, 100, 257, 1000])
     cols = 16 * rng.randint(1, 600)
@@ -201,7 +234,7 @@ def siblings():
         assert torch.equal(out.view(torch.int16), product.view(torch.int16)), ("either/or on undecided codes", kind, m, n, k)
 
 
-cases = [skinny, skinny, a3_symmetric, running, either_or, siblings]
+cases = [skinny, skinny, wide, wide, a3_symmetric, running, either_or, siblings]
 t0 = time.time()
 while time.time() - t0 < budget:
     fn = rng.choice(cases)
