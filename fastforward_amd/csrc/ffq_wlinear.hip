@@ -1282,13 +1282,23 @@ static size_t wq_slab_bytes(int64_t M, int64_t N, int split, bool mlp) {
   return split > 1 ? (size_t)wq_tail_tiles(M, N, mlp) * (size_t)split * WL_UNIT_SLAB : 0;
 }
 
+// Where the two-pass form (A2 of the whole weight into a bf16 image, then the one-wave-per-SIMD GEMM) is the plan of a plain launch: from
+// 4096 tokens on, and from 1536 on where the 256 x 256 tiles make at least 144 — A2 costs N K 3 bytes whatever M is (26 % of the GEMM
+// at 1536 tokens), the one-pass loop is ~25 % slower than the image loop, and below ~half a round of tiles the one-pass form's K split
+// is what fills the chip. Round 6 (profiles/r06_wq_twopass_sweep.txt, 8B shapes): q/k/v as one launch (N = 6144) at 1536 / 2048 / 3072
+// tokens 0.85 / 0.89 / 0.97 of the one-pass time, o_proj / down_proj at 3072 0.81 / 0.79; at 2048 (128 tiles) down_proj is 1.09: one-pass.
+static bool wq_two_pass_planned(int64_t M, int64_t N) {
+  if (M >= WL_TWO_PASS_MIN_TOKENS) return true;
+  return M >= 1536 && ((M + WL_BM - 1) / WL_BM) * ((N + WL_BN - 1) / WL_BN) >= 144;
+}
+
 // workspace: [split-K slabs of the library's plan | bf16 image(s) of the two-pass form (A2 of the whole weight, then the GEMM on
-// that image): N * K * 2 bytes from 4096 tokens on]. The caller may pass less (or NULL): the launch then runs without the part
+// that image): N * K * 2 bytes where wq_two_pass_planned]. The caller may pass less (or NULL): the launch then runs without the part
 // that does not fit (no split / conversion inside the GEMM) — never fails for lack of scratch.
 extern "C" size_t ffq_linear_wq_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K < 2 * WL_BK) return 0;
   if (wq_plan_form(M, N, K, 0) != WQ_FORM_TILES) return ffq_linear_wq_slab_bytes(M, N, K, 0, ffq_linear_wq_split(M, N, K, 0));
-  return wq_slab_bytes(M, N, wq_split(M, N, K, false), false) + (M >= WL_TWO_PASS_MIN_TOKENS ? (size_t)N * (size_t)K * 2u : 0);
+  return wq_slab_bytes(M, N, wq_split(M, N, K, false), false) + (wq_two_pass_planned(M, N) ? (size_t)N * (size_t)K * 2u : 0);
 }
 
 // resolves (requested split, scratch on offer) into what the launch uses; returns the bytes the slabs take at the front of `workspace`

@@ -35,7 +35,8 @@ def linear_wq(
     byte, [N * K / 2] or [N, K / 2]). `w_scale` / `w_offset` fp32 with 1 entry (per-tensor), N entries (per output channel)
     or N * K / group entries ([N, K / group] row-major: groups of `group` input channels, PerBlock(1, group, 0)).
     The weight the matrix cores see is bit for bit A2's bf16 result. ``two_pass``: None = the library's rule (from 4096
-    tokens on A2 runs once per call into a scratch tensor and the GEMM streams that image), False = always convert inside
+    tokens on, and from 1536 where the launch has at least 144 tiles of 256 x 256, A2 runs once per call into a scratch tensor and the
+    GEMM streams that image), False = always convert inside
     the GEMM, True = offer the scratch tensor regardless of M (the library still decides). ``split``: 0 = the library's plan
     for cutting the K range of every output tile into slices when the launch has fewer tiles than the chip has CUs
     (``ffq_linear_wq_split``), >= 1 forces that many slices (tests, tuning).

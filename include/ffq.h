@@ -303,7 +303,8 @@ int ffq_bmm_w8a8(const int8_t* xq, const int8_t* wq, const float* x_scale, const
  * The codes are dequantized with A2's arithmetic, (float(q) + round_half_even(o)) * s in fp32 rounded once to bf16 — the B
  * operand of the bf16 MFMA is bit for bit the reference's dequantized weight, accumulation is fp32; only the summation order
  * differs from F.linear. One launch converts the codes once per 256-row tile on their way into LDS; with enough `workspace`
- * behind the slabs (below) and from 4096 tokens on the weight is dequantized once per CALL by A2 into it and the GEMM streams
+ * behind the slabs (below) and from 4096 tokens on (from 1536 where the launch has at least 144 tiles of 256 x 256: what
+ * ffq_linear_wq_workspace_bytes() sizes the scratch for) the weight is dequantized once per CALL by A2 into it and the GEMM streams
  * the bf16 image — same operands, same k order: bit-identical, faster at large M (whole-tile launches of that form with a bf16
  * output, no bias and K % 128 == 0 run a one-wave-per-SIMD kernel, 4 waves x 128 x 128 accumulators; also bit-identical).
  * Split-K (ABI 7): the kernel is one persistent block per CU on 256 x 256 output tiles; the tiles of the LAST, partly filled
