@@ -883,8 +883,10 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
   // (`buffer_load_dwordx4 ... offen lds`): one descriptor per operand and tile (base = the tile's first row, extent = what is
   // left of the matrix), ONE per-lane offset for the even and one for the odd pieces (the swizzle term (row / 2) % 8 contains
   // bit 0 of the piece number), the piece and the super-step in the scalar offset — no vector arithmetic in the K-loop, no
-  // per-piece registers (the vendor kernel's addressing). The scalar offset is outside the hardware's range check, so the
-  // launcher admits whole tiles only (wq_takes_4w): every row a piece names exists.
+  // per-piece registers (the vendor kernel's addressing). The scalar offset is outside the hardware's range check: that is fine for
+  // the WEIGHT image (whole tiles only, wq_takes_4w: every row a piece names exists). The ACTIVATION pieces carry their row in the
+  // per-lane offset instead (eight registers, round 6): rows past a ragged last row tile fail the range check and arrive as zeros,
+  // so any token count takes this kernel; the epilogue stores the rows that exist.
   const uint32_t row_bytes = (uint32_t)a.K * 2u;
   const int d_row = lane >> 3;
   uint32_t d_voff[2];
@@ -894,6 +896,9 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
     const int d_slot = (lane & 7) ^ ((row >> 1) & 7);
     d_voff[odd] = (uint32_t)(wave * 64 + d_row) * row_bytes + d_slot * 16;
   }
+  uint32_t a_voff[8];  // activation piece c: the lane's row INSIDE the descriptor's range check
+#pragma unroll
+  for (int c = 0; c < 8; ++c) a_voff[c] = d_voff[c & 1] + (uint32_t)c * 8u * row_bytes;
   // MLP: image rows 64 w .. 64 w + 63 of the B image are rows 64 (w / 2) .. of gate_proj (even waves) or up_proj (odd waves) counted
   // from the tile's first output column: a wave fetches from ONE matrix, its descriptor points at that matrix, and the lane offset
   // names the matrix row (the swizzle term stays the image row's)
@@ -922,7 +927,7 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
     ks += (int)k_rot;  // (scalar: two instructions per piece)
     ks = ks >= ksuper ? ks - ksuper : ks;
     const uint32_t soff = (uint32_t)c * 8u * row_bytes + (uint32_t)ks * 128u;
-    if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (wl_lds_t*)(base + (wave * 8 + c) * 1024), 16, d_voff[c & 1], soff, 0, 0);
+    if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (wl_lds_t*)(base + (wave * 8 + c) * 1024), 16, a_voff[c], (uint32_t)ks * 128u, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (wl_lds_t*)(base + WL_IMAGE + (wave * 8 + c) * 1024), 16, MLP ? b_voff[c & 1] : d_voff[c & 1], soff, 0, 0);
   };
 
@@ -1098,7 +1103,7 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
           const int row = c >> 3, sg = c & 7;  // 8 segments of 16 bytes per 64-column row
           const int mm = wave_m0 + mi * 16 + row;
           const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * PITCH + sg * 16);
-          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * out_n + wave_n0) * 2 + sg * 16));
+          if (mm < a.M) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * out_n + wave_n0) * 2 + sg * 16));
         }
       }
     } else {
@@ -1135,7 +1140,7 @@ __global__ __launch_bounds__(256, 1) void wq_gemm4w_kernel(WLinearArgs a, int to
             const int mm = wave_m0 + mi * 16 + row;
             const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * PITCH + sg * 16);
             // non-temporal, as in ffq_linear.hip: the output must not push the operand panels out of L2
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * out_n + wave_n0) * 2 + sg * 16));
+            if (mm < a.M) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)mm * out_n + wave_n0) * 2 + sg * 16));
           }
         }
       }
@@ -1356,10 +1361,10 @@ static bool wq_takes_4w(const WLinearArgs& a, bool mlp = false) {
   if (mlp) return false;
 #endif
   if (generic_kernels_forced()) return false;  // tests: the 8-wave kernel on the same operands (ffq_force_generic_kernels)
-  // whole tiles only: the piece's row offset travels in the buffer instruction's SCALAR offset, which the hardware's range check
-  // does not see (only the per-lane offset is compared with the descriptor's extent) — rows past a ragged edge would be read
-  // from beyond the tensor. Ragged shapes take the 8-wave kernel, which clamps its source rows.
-  if (a.M % WL_BM != 0) return false;
+  // whole tiles of the WEIGHT only: its pieces' row offsets travel in the buffer instruction's SCALAR offset, which the hardware's range
+  // check does not see (only the per-lane offset is compared with the descriptor's extent) — rows past a ragged edge would be read from
+  // beyond the tensor. The activation pieces carry their rows in the per-lane offset: any token count. Ragged weight matrices take the
+  // 8-wave kernel, which clamps its source rows.
   if (mlp) {
     if (a.N % 128 != 0) return false;  // tiles of 128 output columns (128 gate + 128 up rows)
   } else {
