@@ -27,6 +27,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python3 tools/pmc_summary.py $(ls $OUT/pmcm_$c/*counter_collection.csv | head -1) $c $OUT/${TAG}_pmc_hbm_${c}.json
   rm -rf $OUT/pmcm_$c $OUT/pmcm_$c.log
 done
+# the plain line looks its traffic figures up in profiles/: the passes above are the ones of THESE kernel sources
+cp $OUT/${TAG}_pmc_*.json profiles/ 2>/dev/null
 timeout 400 python3 bench.py > $OUT/${TAG}_bench_plain.log 2>&1
 grep '^{' $OUT/${TAG}_bench_plain.log > $OUT/${TAG}_bench_line.json
 rm -f $OUT/${TAG}_bench_plain.log
