@@ -968,10 +968,32 @@ __global__ __launch_bounds__(512, 2) void w8a8_gemm256fq_kernel(LinearArgs a, in
         rsw[0] = a.rowsum_w[n0 + wn * 32 + (lane & 31)];
         rsw[1] = a.rowsum_w2[n0 + wn * 32 + (lane & 31)];
       }
+#ifdef FFQ_ABLATE_EPILOGUE  // timing-only builds (tools/build_variant.sh): what the epilogues cost — one store per lane keeps the accumulators alive
+      {
+        int sum = rsw[0];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+          for (int nj = 0; nj < 4; ++nj) sum += (acc[mi][nj][0] ^ acc[mi][nj][1]) + (acc[mi][nj][2] ^ acc[mi][nj][3]);
+        if (sum == 0x7fffffff) static_cast<int8_t*>(a.out)[lane] = (int8_t)sum;
+      }
+#else
       if constexpr (REQUANT) mlp_epilogue16_body(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table);
       else mlp_epilogue16_product(a, acc, rsw, scratch, wave, lane, wm, wn, m0, n0, silu_table, zext);
+#endif
     } else {
+#ifdef FFQ_ABLATE_EPILOGUE
+      {
+        int sum = 0;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+          for (int nj = 0; nj < 4; ++nj) sum += (acc[mi][nj][0] ^ acc[mi][nj][1]) + (acc[mi][nj][2] ^ acc[mi][nj][3]);
+        if (sum == 0x7fffffff) static_cast<int8_t*>(a.out)[lane] = (int8_t)sum;
+      }
+#else
       gemm256_epilogue_slabs16<TOut, REQUANT, WOFF, GATED>(a, acc, scratch, wave, lane, wm, wn, m0, n0, silu_table, zext);
+#endif
     }
     __syncthreads();  // the scratch slot is the next tile's DMA target
     m0 = nm0; n0 = nn0;
