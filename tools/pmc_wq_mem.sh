@@ -17,7 +17,7 @@ i = sys.argv[1]
 cc = glob.glob(f"/tmp/pl_{i}/**/*counter_collection.csv", recursive=True)
 kt = glob.glob(f"/tmp/pl_{i}/**/*kernel_trace.csv", recursive=True)
 def key(name):
-    if "wq_gemm256_kernel" in name: return "ours"
+    if "wq_gemm256_kernel" in name or "wq_gemm4w_kernel" in name: return "ours"
     if "Cijk" in name: return "vendor"
     return None
 if kt:
